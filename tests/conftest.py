@@ -1,0 +1,30 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_point_ops():
+    return np.load(os.path.join(GOLDEN, "point_ops.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_model():
+    return np.load(os.path.join(GOLDEN, "model.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_loss():
+    return np.load(os.path.join(GOLDEN, "loss.npz"))
