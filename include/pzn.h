@@ -130,69 +130,6 @@ int pzn_emd_fused_f32(const float* xyz1, const float* xyz2, int B, int n, int m,
                       float* cost, float* g1, float* g2, void* workspace,
                       pzn_stream_t stream);
 
-/* ------------------------------------------------------------------------ */
-/* Loss tail: model5_b.py:1495-1505 chamfer_loss                            */
-/* ------------------------------------------------------------------------ */
-
-/* chamfer_loss(a[B,n,3], b[B,m,3]) -> (min over a for each b  [B,m],
- *                                      min over b for each a  [B,n])
- * using the reference's expansion P = |a|^2 + |b|^2 - 2 a.b, never
- * materialising P[B,n,m]. arg-min indices (int32) are written for backward. */
-int pzn_chamfer_fwd_f32(const float* a, const float* b, int B, int n, int m,
-                        float* min_over_a, int32_t* arg_over_a,
-                        float* min_over_b, int32_t* arg_over_b,
-                        pzn_stream_t stream);
-/* grad_a[B,n,3], grad_b[B,m,3] (zero-initialised by the caller) from the two
- * upstream gradients g_over_a[B,m], g_over_b[B,n]. */
-int pzn_chamfer_bwd_f32(const float* a, const float* b, int B, int n, int m,
-                        const float* g_over_a, const int32_t* arg_over_a,
-                        const float* g_over_b, const int32_t* arg_over_b,
-                        float* grad_a, float* grad_b, pzn_stream_t stream);
-
-/* ------------------------------------------------------------------------ */
-/* Dense path on MFMA (exact fp32 v_mfma_f32_32x32x2_f32): model5_b.py      */
-/* ------------------------------------------------------------------------ */
-
-/* nn.Linear as used throughout model5_b.py (e.g. :417-422, :559-599):
- * y[M,Nout] = act(x[M,Kin] @ W[Nout,Kin]^T + bias[Nout]),  act = ReLU if relu.
- * bias may be NULL. */
-int pzn_linear_fwd_f32(const float* x, const float* W, const float* bias, int M,
-                       int Kin, int Nout, int relu, float* y,
-                       pzn_stream_t stream);
-/* dx[M,Kin] = dy[M,Nout] @ W[Nout,Kin]  (dy already masked by the caller when
- * the forward had a ReLU, or pass y and relu=1 to mask on the fly). */
-int pzn_linear_dgrad_f32(const float* dy, const float* y, const float* W, int M,
-                         int Kin, int Nout, int relu, float* dx,
-                         pzn_stream_t stream);
-/* dW[Nout,Kin] = dy^T @ x,  db[Nout] = sum_rows dy  (same optional mask). */
-int pzn_linear_wgrad_f32(const float* dy, const float* y, const float* x, int M,
-                         int Kin, int Nout, int relu, float* dW, float* db,
-                         void* workspace, pzn_stream_t stream);
-size_t pzn_linear_wgrad_workspace_bytes(int M, int Kin, int Nout);
-
-/* Shared MLP + max over the K neighbours, model5_b.py:452-454 / :459-461:
- *   h = relu(x[R*K,C0] @ W1^T + b1);  y = relu(h @ W2^T + b2);
- *   out[R,C2] = max_k y[r*K+k, :],  argmax[R,C2] (int32, k of the max) .
- * h is not kept; backward recomputes it. */
-int pzn_sharedmlp_max_fwd_f32(const float* x, const float* W1, const float* b1,
-                              const float* W2, const float* b2, int R, int K,
-                              int C0, int C1, int C2, float* out,
-                              int32_t* argmax, pzn_stream_t stream);
-
-/* scaled_dot_production for layerAttention, model5_b.py:67-75:
- * attn[B,L,L] = softmax(q[B,L,dk] k[B,L,dk]^T / sqrt(dk)),
- * out[B,L,dv] = attn @ v[B,L,dv].  attn is returned because the reference
- * returns it (model5_b.py:97,101). */
-int pzn_attn_fwd_f32(const float* q, const float* k, const float* v, int B,
-                     int L, int dk, int dv, float* attn, float* out,
-                     pzn_stream_t stream);
-/* Backward: dq, dk, dv from d_out[B,L,dv] and d_attn[B,L,L] (may be NULL). */
-int pzn_attn_bwd_f32(const float* q, const float* k, const float* v,
-                     const float* attn, const float* d_out, const float* d_attn,
-                     int B, int L, int dk, int dv, float* dq, float* dk_out,
-                     float* dv_out, void* workspace, pzn_stream_t stream);
-size_t pzn_attn_bwd_workspace_bytes(int B, int L, int dk, int dv);
-
 #ifdef __cplusplus
 }
 #endif

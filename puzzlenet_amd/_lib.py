@@ -1,0 +1,70 @@
+"""ctypes binding of libpzn.so — the C ABI declared in include/pzn.h.
+
+The library is built ahead of time by ``python -m puzzlenet_amd.build`` (hipcc,
+gfx950) and lives next to this file.  There is NO fallback: if the shared
+object is missing, or a call returns a non-zero status, this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpzn.so")
+
+_c_f = ctypes.c_void_p      # device pointers travel as raw addresses
+_c_i = ctypes.c_int
+_c_sz = ctypes.c_size_t
+_c_fl = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/pzn.h one to one.
+SIGNATURES = {
+    "pzn_version": (_c_i, []),
+    "pzn_strerror": (ctypes.c_char_p, [_c_i]),
+    "pzn_device_check": (_c_i, []),
+    "pzn_square_distance_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
+    "pzn_fps_f32": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_knn_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),
+    "pzn_ball_query_f32": (_c_i, [_c_fl, _c_i, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
+    "pzn_gather_fwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),
+    "pzn_gather_bwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),
+    "pzn_group_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_group_bwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f]),
+    "pzn_emd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),
+    "pzn_emd_approxmatch_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_emd_matchcost_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
+    "pzn_emd_matchcost_grad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_emd_fused_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f]),
+}
+
+_lib = None
+
+
+class PznError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpzn.so (raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PznError(
+                f"{LIB_PATH} is missing: build it with `python -m puzzlenet_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU or eager fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().pzn_strerror(status).decode()
+        raise PznError(f"{what} failed: {msg} (status {status})")
+
+
+def call(name, *args):
+    """Invoke an int-status entry point and raise on error."""
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,364 @@
+// emd.hip — approximate Earth Mover's Distance (auction matching) for gfx950.
+//
+// Replaces PyTorchEMD/cuda/emd_kernel.cu: approxmatch (:25-158), matchcost
+// (:200-243), matchcostgrad1 (:333-355), matchcostgrad2 (:286-327).
+//
+// The reference runs <<<32,512>>>: one workgroup per cloud pair, <= 32 CUs busy,
+// and read-modify-writes the (B,m,n) `match` tensor ten times.  Here every one
+// of the 10 levels x 3 passes is its own launch over ALL (pair, row-tile)
+// workgroups, so a B=64, n=m=2048 call fills the chip, and the fused entry
+// point (pzn_emd_fused_f32) never writes `match`:
+//     cost  = sum_kl d_kl match_lk,   grad1_k = 2 sum_l match_lk (x1_k - x2_l),
+//     grad2_l = 2 sum_k match_lk (x2_l - x1_k)
+// are linear in match = sum_levels w, so they are accumulated level by level
+// inside the passes that compute w anyway.
+//
+// Data layout: points are repacked once per call to float4 {x, y, z, weight}
+// where `weight` is the per-point state the NEXT pass multiplies by
+// (remainR / ratioL / ratioR).  The inner loop of each pass walks the OTHER
+// cloud with a wave-uniform index, so those float4 come through the scalar
+// cache (s_load_dwordx4..x16) and feed the VALU as SGPR operands: no LDS, no
+// bank conflicts, ~10 VALU issues per (k,l) pair: 3 sub, 3 mul/fma, 1 mul,
+// v_exp_f32, 1-2 fma.
+//
+// Pass structure per level (emd_kernel.cu line numbers):
+//   A (:51-84)   ratioL_k  = remainL_k / (1e-9 + sum_l e_kl remainR_l)
+//   B (:86-119)  s_l = remainR_l sum_k e_kl ratioL_k;
+//                ratioR_l = min(remainR_l/(s_l+1e-9), 1) remainR_l;  remainR_l = max(0, remainR_l - s_l)
+//   C (:121-154) w_kl = e_kl ratioL_k ratioR_l;  match_lk += w_kl;  remainL_k = max(0, remainL_k - sum_l w_kl)
+// with e_kl = exp(level * d_kl), level = -4^j for j = 7..-1 and 0 for the last.
+#include "pzn_common.h"
+
+namespace {
+
+constexpr int EMD_T = 256;  // threads per workgroup = rows (k or l) per workgroup
+
+struct EmdWs {
+  float4* pk1;     // [B*n] {x1,y1,z1, ratioL}
+  float4* pk2a;    // [B*m] {x2,y2,z2, remainR}
+  float4* pk2b;    // [B*m] {x2,y2,z2, ratioR}
+  float* remainL;  // [B*n]
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+EmdWs carve(void* ws, int B, int n, int m) {
+  unsigned char* p = static_cast<unsigned char*>(ws);
+  EmdWs w;
+  w.pk1 = reinterpret_cast<float4*>(p);
+  p += align_up(sizeof(float4) * (size_t)B * n, 256);
+  w.pk2a = reinterpret_cast<float4*>(p);
+  p += align_up(sizeof(float4) * (size_t)B * m, 256);
+  w.pk2b = reinterpret_cast<float4*>(p);
+  p += align_up(sizeof(float4) * (size_t)B * m, 256);
+  w.remainL = reinterpret_cast<float*>(p);
+  return w;
+}
+
+__device__ __forceinline__ float fast_exp_scaled(float c_log2e, float d) {
+  // __expf(level*d) == exp2(level*d*log2e); level*log2e is folded on the host.
+  return __builtin_amdgcn_exp2f(c_log2e * d);
+}
+
+__device__ __forceinline__ float sq3(float dx, float dy, float dz) { return dx * dx + dy * dy + dz * dz; }
+
+__global__ __launch_bounds__(EMD_T) void emd_init_kernel(const float* __restrict__ xyz1,
+                                                         const float* __restrict__ xyz2, int n, int m,
+                                                         float multiL, float multiR, EmdWs w) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * EMD_T + threadIdx.x;
+  if (i < n) {
+    const float* p = xyz1 + ((size_t)b * n + i) * 3;
+    w.pk1[(size_t)b * n + i] = make_float4(p[0], p[1], p[2], 0.f);
+    w.remainL[(size_t)b * n + i] = multiL;  // :41-42
+  }
+  if (i < m) {
+    const float* p = xyz2 + ((size_t)b * m + i) * 3;
+    w.pk2a[(size_t)b * m + i] = make_float4(p[0], p[1], p[2], multiR);  // :43-44
+    w.pk2b[(size_t)b * m + i] = make_float4(p[0], p[1], p[2], 0.f);
+  }
+}
+
+// Pass A: one thread per k.
+__global__ __launch_bounds__(EMD_T) void emd_pass_a_kernel(int n, int m, float c, EmdWs w) {
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * EMD_T + threadIdx.x;
+  const float4* __restrict__ other = w.pk2a + (size_t)b * m;
+  float4 me = k < n ? w.pk1[(size_t)b * n + k] : make_float4(0, 0, 0, 0);
+  float suml = 1e-9f;  // :59
+#pragma unroll 4
+  for (int l = 0; l < m; ++l) {
+    float4 o = other[l];
+    float d = sq3(o.x - me.x, o.y - me.y, o.z - me.z);  // :76
+    suml += fast_exp_scaled(c, d) * o.w;                // :77-78
+  }
+  if (k < n) {
+    me.w = w.remainL[(size_t)b * n + k] / suml;  // :83
+    w.pk1[(size_t)b * n + k] = me;
+  }
+}
+
+// Pass B: one thread per l.  FUSED additionally accumulates
+// grad2_l += 2 ratioR_l sum_k e_kl ratioL_k (x2_l - x1_k).
+template <bool FUSED>
+__global__ __launch_bounds__(EMD_T) void emd_pass_b_kernel(int n, int m, float c, EmdWs w, float* __restrict__ g2) {
+  const int b = blockIdx.y;
+  const int l = blockIdx.x * EMD_T + threadIdx.x;
+  const float4* __restrict__ other = w.pk1 + (size_t)b * n;
+  float4 me = l < m ? w.pk2a[(size_t)b * m + l] : make_float4(0, 0, 0, 0);
+  float sumr = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll 4
+  for (int k = 0; k < n; ++k) {
+    float4 o = other[k];
+    float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
+    float e = fast_exp_scaled(c, sq3(dx, dy, dz)) * o.w;  // :108
+    sumr += e;                                            // :109
+    if (FUSED) {
+      sx += e * dx;
+      sy += e * dy;
+      sz += e * dz;
+    }
+  }
+  if (l < m) {
+    float remainR = me.w;
+    sumr *= remainR;                                              // :114
+    float consumption = fminf(remainR / (sumr + 1e-9f), 1.0f);    // :115
+    float ratioR = consumption * remainR;                         // :116
+    me.w = fmaxf(0.0f, remainR - sumr);                           // :117
+    w.pk2a[(size_t)b * m + l] = me;
+    w.pk2b[(size_t)b * m + l].w = ratioR;
+    if (FUSED) {
+      float* g = g2 + ((size_t)b * m + l) * 3;
+      float s = 2.f * ratioR;
+      g[0] += s * sx;
+      g[1] += s * sy;
+      g[2] += s * sz;
+    }
+  }
+}
+
+// Pass C: one thread per k.  MATCH writes match[b][l][k] += w (API-parity path);
+// FUSED accumulates cost_b += sum_l d_kl w_kl and grad1_k += 2 sum_l w_kl (x1_k - x2_l).
+template <bool MATCH, bool FUSED>
+__global__ __launch_bounds__(EMD_T) void emd_pass_c_kernel(int n, int m, float c, EmdWs w, float* __restrict__ match,
+                                                           float* __restrict__ cost, float* __restrict__ g1) {
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * EMD_T + threadIdx.x;
+  const float4* __restrict__ other = w.pk2b + (size_t)b * m;
+  float4 me = k < n ? w.pk1[(size_t)b * n + k] : make_float4(0, 0, 0, 0);
+  const float rl = me.w;  // :139
+  float suml = 0.f, sx = 0.f, sy = 0.f, sz = 0.f, sc = 0.f;
+  float* mt = MATCH ? match + (size_t)b * n * m + k : nullptr;
+#pragma unroll 4
+  for (int l = 0; l < m; ++l) {
+    float4 o = other[l];
+    float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
+    float d = sq3(dx, dy, dz);
+    float wv = fast_exp_scaled(c, d) * rl * o.w;  // :145
+    if (MATCH) {
+      if (k < n) mt[(size_t)l * n] += wv;  // :146
+    }
+    suml += wv;  // :147
+    if (FUSED) {
+      sx += wv * dx;
+      sy += wv * dy;
+      sz += wv * dz;
+      sc += wv * d;
+    }
+  }
+  if (k < n) {
+    float* r = w.remainL + (size_t)b * n + k;
+    *r = fmaxf(0.0f, *r - suml);  // :153
+    if (FUSED) {
+      float* g = g1 + ((size_t)b * n + k) * 3;
+      g[0] += 2.f * sx;
+      g[1] += 2.f * sy;
+      g[2] += 2.f * sz;
+    }
+  }
+  if (FUSED) {
+    __shared__ float red[EMD_T / PZN_WAVE];
+    sc = k < n ? sc : 0.f;
+    sc = pzn::wave_sum_f32(sc);
+    if ((threadIdx.x & (PZN_WAVE - 1)) == 0) red[threadIdx.x / PZN_WAVE] = sc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int i = 0; i < EMD_T / PZN_WAVE; ++i) t += red[i];
+      atomicAdd(cost + b, t);
+    }
+  }
+}
+
+// matchcost (:200-243): cost_b = sum_kl d_kl match[b][l][k].  Thread per k, a
+// workgroup takes a slab of l; partial sums meet in one atomic per workgroup.
+constexpr int MC_LSLAB = 64;
+__global__ __launch_bounds__(EMD_T) void emd_matchcost_kernel(const float* __restrict__ xyz1,
+                                                              const float* __restrict__ xyz2,
+                                                              const float* __restrict__ match, int n, int m,
+                                                              float* __restrict__ cost) {
+  const int b = blockIdx.z;
+  const int k = blockIdx.x * EMD_T + threadIdx.x;
+  const int l0 = blockIdx.y * MC_LSLAB;
+  const int l1 = min(m, l0 + MC_LSLAB);
+  float x1 = 0, y1 = 0, z1 = 0;
+  if (k < n) {
+    const float* p = xyz1 + ((size_t)b * n + k) * 3;
+    x1 = p[0], y1 = p[1], z1 = p[2];
+  }
+  const float* p2 = xyz2 + (size_t)b * m * 3;
+  const float* mt = match + (size_t)b * n * m + k;
+  float s = 0.f;
+  if (k < n)
+    for (int l = l0; l < l1; ++l) {
+      float dx = p2[l * 3] - x1, dy = p2[l * 3 + 1] - y1, dz = p2[l * 3 + 2] - z1;
+      s += sq3(dx, dy, dz) * mt[(size_t)l * n];  // :225-226
+    }
+  __shared__ float red[EMD_T / PZN_WAVE];
+  s = pzn::wave_sum_f32(s);
+  if ((threadIdx.x & (PZN_WAVE - 1)) == 0) red[threadIdx.x / PZN_WAVE] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < EMD_T / PZN_WAVE; ++i) t += red[i];
+    atomicAdd(cost + b, t);
+  }
+}
+
+// matchcostgrad1 (:333-355): thread per point of xyz1, serial over xyz2.
+__global__ __launch_bounds__(EMD_T) void emd_grad1_kernel(const float* __restrict__ grad_cost,
+                                                          const float* __restrict__ xyz1,
+                                                          const float* __restrict__ xyz2,
+                                                          const float* __restrict__ match, int n, int m,
+                                                          float* __restrict__ grad1) {
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * EMD_T + threadIdx.x;
+  if (k >= n) return;
+  const float* p = xyz1 + ((size_t)b * n + k) * 3;
+  const float x1 = p[0], y1 = p[1], z1 = p[2];
+  const float* p2 = xyz2 + (size_t)b * m * 3;
+  const float* mt = match + (size_t)b * n * m + k;
+  float dx = 0, dy = 0, dz = 0;
+  for (int l = 0; l < m; ++l) {
+    float d = mt[(size_t)l * n] * 2;  // :345
+    dx += (x1 - p2[l * 3]) * d;
+    dy += (y1 - p2[l * 3 + 1]) * d;
+    dz += (z1 - p2[l * 3 + 2]) * d;
+  }
+  const float gc = grad_cost[b];
+  float* g = grad1 + ((size_t)b * n + k) * 3;
+  g[0] = dx * gc;
+  g[1] = dy * gc;
+  g[2] = dz * gc;
+}
+
+// matchcostgrad2 (:286-327): one wavefront per point of xyz2, lanes stride over xyz1.
+__global__ __launch_bounds__(EMD_T) void emd_grad2_kernel(const float* __restrict__ grad_cost,
+                                                          const float* __restrict__ xyz1,
+                                                          const float* __restrict__ xyz2,
+                                                          const float* __restrict__ match, int n, int m,
+                                                          float* __restrict__ grad2) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & (PZN_WAVE - 1);
+  const int l = blockIdx.x * (EMD_T / PZN_WAVE) + threadIdx.x / PZN_WAVE;
+  if (l >= m) return;
+  const float* p = xyz2 + ((size_t)b * m + l) * 3;
+  const float x2 = p[0], y2 = p[1], z2 = p[2];
+  const float* p1 = xyz1 + (size_t)b * n * 3;
+  const float* mt = match + (size_t)b * n * m + (size_t)l * n;
+  float sx = 0, sy = 0, sz = 0;
+  for (int j = lane; j < n; j += PZN_WAVE) {
+    float d = mt[j] * 2;  // :301
+    sx += (x2 - p1[j * 3]) * d;
+    sy += (y2 - p1[j * 3 + 1]) * d;
+    sz += (z2 - p1[j * 3 + 2]) * d;
+  }
+  sx = pzn::wave_sum_f32(sx);
+  sy = pzn::wave_sum_f32(sy);
+  sz = pzn::wave_sum_f32(sz);
+  if (lane == 0) {
+    const float gc = grad_cost[b];
+    float* g = grad2 + ((size_t)b * m + l) * 3;
+    g[0] = sx * gc;
+    g[1] = sy * gc;
+    g[2] = sz * gc;
+  }
+}
+
+template <bool MATCH, bool FUSED>
+int run_levels(const float* xyz1, const float* xyz2, int B, int n, int m, float* match, float* cost, float* g1,
+               float* g2, void* workspace, hipStream_t st) {
+  EmdWs w = carve(workspace, B, n, m);
+  float multiL, multiR;  // :29-35 (integer division)
+  if (n >= m) {
+    multiL = 1.f;
+    multiR = (float)(n / m);
+  } else {
+    multiL = (float)(m / n);
+    multiR = 1.f;
+  }
+  const int mx = n > m ? n : m;
+  dim3 gi((mx + EMD_T - 1) / EMD_T, B), gk((n + EMD_T - 1) / EMD_T, B), gl((m + EMD_T - 1) / EMD_T, B);
+  hipLaunchKernelGGL(emd_init_kernel, gi, dim3(EMD_T), 0, st, xyz1, xyz2, n, m, multiL, multiR, w);
+  if (MATCH && hipMemsetAsync(match, 0, sizeof(float) * (size_t)B * n * m, st) != hipSuccess) return PZN_ELAUNCH;  // :39-40
+  if (FUSED) {
+    if (hipMemsetAsync(cost, 0, sizeof(float) * (size_t)B, st) != hipSuccess) return PZN_ELAUNCH;
+    if (hipMemsetAsync(g1, 0, sizeof(float) * (size_t)B * n * 3, st) != hipSuccess) return PZN_ELAUNCH;
+    if (hipMemsetAsync(g2, 0, sizeof(float) * (size_t)B * m * 3, st) != hipSuccess) return PZN_ELAUNCH;
+  }
+  for (int j = 7; j >= -2; --j) {                                // :46
+    float level = j == -2 ? 0.f : -powf(4.0f, (float)j);         // :47-50
+    float c = level * 1.44269504088896340736f;                   // * log2(e)
+    hipLaunchKernelGGL(emd_pass_a_kernel, gk, dim3(EMD_T), 0, st, n, m, c, w);
+    hipLaunchKernelGGL((emd_pass_b_kernel<FUSED>), gl, dim3(EMD_T), 0, st, n, m, c, w, g2);
+    hipLaunchKernelGGL((emd_pass_c_kernel<MATCH, FUSED>), gk, dim3(EMD_T), 0, st, n, m, c, w, match, cost, g1);
+  }
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+}  // namespace
+
+PZN_EXPORT size_t pzn_emd_workspace_bytes(int B, int n, int m) {
+  if (B <= 0 || n <= 0 || m <= 0) return 0;
+  return align_up(sizeof(float4) * (size_t)B * n, 256) + 2 * align_up(sizeof(float4) * (size_t)B * m, 256) +
+         align_up(sizeof(float) * (size_t)B * n, 256);
+}
+
+PZN_EXPORT int pzn_emd_approxmatch_f32(const float* xyz1, const float* xyz2, int B, int n, int m, float* match,
+                                       void* workspace, pzn_stream_t stream) {
+  PZN_CHECK_ARG(xyz1 && xyz2 && match && workspace && B > 0 && n > 0 && m > 0 && B <= 65535);
+  PZN_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 15) == 0);
+  return run_levels<true, false>(xyz1, xyz2, B, n, m, match, nullptr, nullptr, nullptr, workspace,
+                                 pzn_hip_stream(stream));
+}
+
+PZN_EXPORT int pzn_emd_fused_f32(const float* xyz1, const float* xyz2, int B, int n, int m, float* cost, float* g1,
+                                 float* g2, void* workspace, pzn_stream_t stream) {
+  PZN_CHECK_ARG(xyz1 && xyz2 && cost && g1 && g2 && workspace && B > 0 && n > 0 && m > 0 && B <= 65535);
+  PZN_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 15) == 0);
+  return run_levels<false, true>(xyz1, xyz2, B, n, m, nullptr, cost, g1, g2, workspace, pzn_hip_stream(stream));
+}
+
+PZN_EXPORT int pzn_emd_matchcost_f32(const float* xyz1, const float* xyz2, const float* match, int B, int n, int m,
+                                     float* cost, pzn_stream_t stream) {
+  PZN_CHECK_ARG(xyz1 && xyz2 && match && cost && B > 0 && n > 0 && m > 0 && B <= 65535);
+  hipStream_t st = pzn_hip_stream(stream);
+  if (hipMemsetAsync(cost, 0, sizeof(float) * (size_t)B, st) != hipSuccess) return PZN_ELAUNCH;
+  dim3 grid((n + EMD_T - 1) / EMD_T, (m + MC_LSLAB - 1) / MC_LSLAB, B);
+  PZN_CHECK_ARG(grid.y <= 65535);
+  hipLaunchKernelGGL(emd_matchcost_kernel, grid, dim3(EMD_T), 0, st, xyz1, xyz2, match, n, m, cost);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+PZN_EXPORT int pzn_emd_matchcost_grad_f32(const float* grad_cost, const float* xyz1, const float* xyz2,
+                                          const float* match, int B, int n, int m, float* grad1, float* grad2,
+                                          pzn_stream_t stream) {
+  PZN_CHECK_ARG(grad_cost && xyz1 && xyz2 && match && grad1 && grad2 && B > 0 && n > 0 && m > 0 && B <= 65535);
+  hipStream_t st = pzn_hip_stream(stream);
+  hipLaunchKernelGGL(emd_grad1_kernel, dim3((n + EMD_T - 1) / EMD_T, B), dim3(EMD_T), 0, st, grad_cost, xyz1, xyz2,
+                     match, n, m, grad1);
+  constexpr int LPB = EMD_T / PZN_WAVE;
+  hipLaunchKernelGGL(emd_grad2_kernel, dim3((m + LPB - 1) / LPB, B), dim3(EMD_T), 0, st, grad_cost, xyz1, xyz2, match,
+                     n, m, grad2);
+  PZN_RETURN_LAUNCH_STATUS();
+}

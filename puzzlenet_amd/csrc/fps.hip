@@ -1,0 +1,139 @@
+// fps.hip — farthest point sampling for gfx950.
+//
+// Replaces pointnet_util.farthest_point_sample (pointnet_util.py:53-73): a
+// Python loop of npoint iterations x 5 torch ops.  Here one workgroup owns one
+// cloud for the whole loop:
+//   * the cloud is read from HBM exactly once (coalesced flat copy of the
+//     (N,3) AoS rows), transposed into an SoA image in LDS (centroid fetch)
+//     and into registers (each thread keeps PPT points + their running
+//     min-distance for all iterations);
+//   * per iteration: distance update in registers, arg-max as ONE u64 max of
+//     key = (dist_bits << 32) | ~index  (dist >= 0 so its bit pattern is
+//     monotonic; ~index makes the LOWEST index win ties, as torch.max does on
+//     CPU), wavefront (64-lane) shuffle reduction, one LDS slot per wave, one
+//     barrier, every wave re-reduces the <=16 slots redundantly;
+//   * slots are double-buffered on the iteration parity, so one barrier per
+//     iteration is enough.
+// The loop is latency-bound by construction (npoint dependent rounds); the
+// launch is B workgroups, i.e. parallel over clouds only.
+#include "pzn_common.h"
+
+namespace {
+
+template <int T, int PPT>
+__global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int N, int npoint,
+                                                const int64_t* __restrict__ start,
+                                                int64_t* __restrict__ out, int use_lds) {
+  constexpr int W = T / PZN_WAVE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t* slots = reinterpret_cast<uint64_t*>(smem_raw);             // [2][W]
+  float* sx = reinterpret_cast<float*>(smem_raw + 2 * W * sizeof(uint64_t));
+  float* sy = sx + N;
+  float* sz = sy + N;
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (PZN_WAVE - 1);
+  const int wave = tid / PZN_WAVE;
+  const float* g = xyz + (size_t)b * N * 3;
+
+  float px[PPT], py[PPT], pz[PPT], dist[PPT];
+  if (use_lds) {
+    for (int i = tid; i < 3 * N; i += T) {
+      float v = g[i];
+      int p = i / 3, c = i - 3 * p;
+      (c == 0 ? sx : (c == 1 ? sy : sz))[p] = v;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    int j = tid + p * T;
+    bool ok = j < N;
+    if (use_lds) {
+      px[p] = ok ? sx[j] : 0.f;
+      py[p] = ok ? sy[j] : 0.f;
+      pz[p] = ok ? sz[j] : 0.f;
+    } else {
+      px[p] = ok ? g[(size_t)j * 3 + 0] : 0.f;
+      py[p] = ok ? g[(size_t)j * 3 + 1] : 0.f;
+      pz[p] = ok ? g[(size_t)j * 3 + 2] : 0.f;
+    }
+    dist[p] = 1e10f;  // pointnet_util.py:64
+  }
+
+  int far = (int)start[b];  // pointnet_util.py:65 (the caller's randint draw)
+  far = far < 0 ? 0 : (far >= N ? N - 1 : far);
+  int64_t* o = out + (size_t)b * npoint;
+
+  for (int i = 0; i < npoint; ++i) {
+    if (tid == 0) o[i] = far;  // :68
+    float cx, cy, cz;          // :69
+    if (use_lds) {
+      cx = sx[far];
+      cy = sy[far];
+      cz = sz[far];
+    } else {
+      cx = g[(size_t)far * 3 + 0];
+      cy = g[(size_t)far * 3 + 1];
+      cz = g[(size_t)far * 3 + 2];
+    }
+    uint64_t best = 0;  // below every real key: real keys have ~j >= 1
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      int j = tid + p * T;
+      float d = pzn::sqdist3(px[p], py[p], pz[p], cx, cy, cz);  // :70
+      float nd = d < dist[p] ? d : dist[p];                     // :71
+      dist[p] = nd;
+      uint64_t key = ((uint64_t)__float_as_uint(nd) << 32) | (uint32_t)(~(uint32_t)j);
+      key = j < N ? key : 0ull;
+      best = key > best ? key : best;
+    }
+    best = pzn::wave_max_u64(best);
+    uint64_t* sl = slots + (i & 1) * W;
+    if (lane == 0) sl[wave] = best;
+    __syncthreads();
+    uint64_t m = sl[0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) {
+      uint64_t v = sl[w];
+      m = v > m ? v : m;
+    }
+    far = (int)(~(uint32_t)m);  // :72 first (lowest-index) maximum
+  }
+}
+
+template <int T, int PPT>
+int launch(const float* xyz, int B, int N, int npoint, const int64_t* start, int64_t* out, hipStream_t st) {
+  constexpr int W = T / PZN_WAVE;
+  size_t lds_xyz = (size_t)3 * N * sizeof(float);
+  size_t lds = 2 * W * sizeof(uint64_t);
+  int use_lds = lds + lds_xyz <= 150 * 1024;
+  if (use_lds) lds += lds_xyz;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_kernel<T, PPT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return PZN_ELAUNCH;
+  }
+  hipLaunchKernelGGL((fps_kernel<T, PPT>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out, use_lds);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+}  // namespace
+
+PZN_EXPORT int pzn_fps_f32(const float* xyz, int B, int N, int npoint, const int64_t* start_idx,
+                           int64_t* out_idx, pzn_stream_t stream) {
+  PZN_CHECK_ARG(xyz && start_idx && out_idx && B > 0 && N > 0 && npoint > 0);
+  hipStream_t st = pzn_hip_stream(stream);
+  if (N <= 64) return launch<64, 1>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 128) return launch<128, 1>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 256) return launch<256, 1>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 512) return launch<256, 2>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 1024) return launch<256, 4>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 2048) return launch<512, 4>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 4096) return launch<512, 8>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 8192) return launch<1024, 8>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 16384) return launch<1024, 16>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 32768) return launch<1024, 32>(xyz, B, N, npoint, start_idx, out_idx, st);
+  return PZN_EUNSUPPORTED;
+}

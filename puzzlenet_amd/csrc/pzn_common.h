@@ -1,0 +1,68 @@
+// pzn_common.h — shared device/host helpers for libpzn.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pzn.h"
+
+#define PZN_EXPORT extern "C" __attribute__((visibility("default")))
+
+#define PZN_WAVE 64
+
+// Status of the launch that was just enqueued on this thread.
+#define PZN_RETURN_LAUNCH_STATUS()                          \
+  do {                                                      \
+    return hipGetLastError() == hipSuccess ? PZN_OK : PZN_ELAUNCH; \
+  } while (0)
+
+#define PZN_CHECK_ARG(cond) \
+  do {                      \
+    if (!(cond)) return PZN_EINVAL; \
+  } while (0)
+
+static inline hipStream_t pzn_hip_stream(pzn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+namespace pzn {
+
+// ((dx*dx + dy*dy) + dz*dz) with every operation individually rounded: the
+// *_rn intrinsics are never fused into an fma, whatever -ffp-contract says.
+// Bit-identical to pointnet_util.square_distance (pointnet_util.py:36) on CPU.
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+  float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  lo = __shfl_xor(lo, mask, PZN_WAVE);
+  hi = __shfl_xor(hi, mask, PZN_WAVE);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    uint64_t o = shfl_xor_u64(v, m);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    uint64_t o = shfl_xor_u64(v, m);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, PZN_WAVE);
+  return v;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (PZN_WAVE - 1); }
+
+}  // namespace pzn

@@ -1,0 +1,237 @@
+"""Host-side operators over the C ABI (include/pzn.h).
+
+torch is used for device memory, the current HIP stream and autograd plumbing
+only: every computation below is a call into libpzn.so with raw device
+pointers.  Inputs must live on a HIP device; there is no CPU path.
+"""
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.PznError(f"{name} must be a tensor on the GPU (got {type(t).__name__}"
+                            f"{'' if not isinstance(t, torch.Tensor) else ' on ' + str(t.device)}); "
+                            "puzzlenet_amd has no CPU fallback")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _f32(t, name):
+    return _req(t, torch.float32, name)
+
+
+def _i64(t, name):
+    return _req(t, torch.int64, name)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------- point ops
+
+def square_distance(src, dst):
+    src, dst = _f32(src, "src"), _f32(dst, "dst")
+    B, S, C = src.shape
+    if C != 3 or dst.shape[-1] != 3 or dst.shape[0] != B:
+        raise _lib.PznError("square_distance: expected src[B,S,3], dst[B,N,3]")
+    N = dst.shape[1]
+    out = torch.empty((B, S, N), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.call("pzn_square_distance_f32", _p(src), _p(dst), B, S, N, _p(out), _stream())
+    return out
+
+
+def farthest_point_sample(xyz, npoint, start_idx):
+    xyz = _f32(xyz, "xyz")
+    B, N, C = xyz.shape
+    if C != 3:
+        raise _lib.PznError("farthest_point_sample: expected xyz[B,N,3]")
+    start_idx = _i64(start_idx, "start_idx")
+    out = torch.empty((B, npoint), dtype=torch.int64, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.call("pzn_fps_f32", _p(xyz), B, N, int(npoint), _p(start_idx), _p(out), _stream())
+    return out
+
+
+def knn(xyz, new_xyz, K):
+    xyz, new_xyz = _f32(xyz, "xyz"), _f32(new_xyz, "new_xyz")
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    out = torch.empty((B, S, K), dtype=torch.int64, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.call("pzn_knn_f32", _p(xyz), _p(new_xyz), B, N, S, int(K), _p(out), _stream())
+    return out
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    xyz, new_xyz = _f32(xyz, "xyz"), _f32(new_xyz, "new_xyz")
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    out = torch.empty((B, S, nsample), dtype=torch.int64, device=xyz.device)
+    # `sqrdists > radius ** 2` is an fp32 comparison in the reference (pointnet_util.py:91)
+    r2 = float(torch.tensor(float(radius) ** 2, dtype=torch.float32))
+    with torch.cuda.device(xyz.device):
+        _lib.call("pzn_ball_query_f32", r2, int(nsample), _p(xyz), _p(new_xyz), B, N, S, _p(out), _stream())
+    return out
+
+
+class _Gather(torch.autograd.Function):
+    """index_points (pointnet_util.py:39-50): forward gather, backward scatter-add."""
+
+    @staticmethod
+    def forward(ctx, points, idx):
+        points = _f32(points, "points")
+        idx = _i64(idx, "idx")
+        B, N, C = points.shape
+        flat = idx.reshape(B, -1)
+        M = flat.shape[1]
+        out = torch.empty((B, M, C), dtype=torch.float32, device=points.device)
+        with torch.cuda.device(points.device):
+            _lib.call("pzn_gather_fwd_f32", _p(points), _p(flat), B, N, M, C, _p(out), _stream())
+        ctx.save_for_backward(flat)
+        ctx.dims = (B, N, M, C)
+        return out.reshape(*idx.shape, C)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (flat,) = ctx.saved_tensors
+        B, N, M, C = ctx.dims
+        grad_out = _f32(grad_out, "grad_out")
+        g = torch.zeros((B, N, C), dtype=torch.float32, device=grad_out.device)
+        with torch.cuda.device(grad_out.device):
+            _lib.call("pzn_gather_bwd_f32", _p(grad_out), _p(flat), B, N, M, C, _p(g), _stream())
+        return g, None
+
+
+def index_points(points, idx):
+    return _Gather.apply(points, idx)
+
+
+class _Group(torch.autograd.Function):
+    """pointnet_util.py:123-132: cat(xyz[idx] - new_xyz, feat[idx]) in one kernel."""
+
+    @staticmethod
+    def forward(ctx, xyz, feat, new_xyz, idx, want_grouped_xyz):
+        xyz, new_xyz, idx = _f32(xyz, "xyz"), _f32(new_xyz, "new_xyz"), _i64(idx, "idx")
+        B, N, _ = xyz.shape
+        _, S, K = idx.shape
+        D = 0 if feat is None else feat.shape[-1]
+        feat_c = None if feat is None else _f32(feat, "points")
+        out = torch.empty((B, S, K, 3 + D), dtype=torch.float32, device=xyz.device)
+        gx = torch.empty((B, S, K, 3), dtype=torch.float32, device=xyz.device) if want_grouped_xyz else None
+        with torch.cuda.device(xyz.device):
+            _lib.call("pzn_group_fwd_f32", _p(xyz), _p(feat_c), _p(new_xyz), _p(idx), B, N, S, K, D,
+                      _p(out), _p(gx), _stream())
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, S, K, D)
+        ctx.has_feat = feat is not None
+        if gx is not None:
+            ctx.mark_non_differentiable(gx)
+        return out, gx
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_gx):
+        (idx,) = ctx.saved_tensors
+        B, N, S, K, D = ctx.dims
+        need_xyz, need_feat, need_new = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        need_feat = need_feat and ctx.has_feat
+        if not (need_xyz or need_feat or need_new):
+            return None, None, None, None, None
+        grad_out = _f32(grad_out, "grad_out")
+        dev = grad_out.device
+        gxyz = torch.zeros((B, N, 3), dtype=torch.float32, device=dev) if need_xyz else None
+        gfeat = torch.zeros((B, N, D), dtype=torch.float32, device=dev) if need_feat else None
+        gnew = torch.empty((B, S, 3), dtype=torch.float32, device=dev) if need_new else None
+        with torch.cuda.device(dev):
+            _lib.call("pzn_group_bwd_f32", _p(grad_out), _p(idx), B, N, S, K, D, _p(gxyz), _p(gfeat), _p(gnew),
+                      _stream())
+        return gxyz, gfeat, gnew, None, None
+
+
+def group(xyz, feat, new_xyz, idx, want_grouped_xyz=False):
+    out, gx = _Group.apply(xyz, feat, new_xyz, idx, want_grouped_xyz)
+    return (out, gx) if want_grouped_xyz else out
+
+
+# --------------------------------------------------------------------------- EMD
+
+def _emd_ws(B, n, m, device):
+    nbytes = _lib.load().pzn_emd_workspace_bytes(B, n, m)
+    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+
+
+def _emd_shapes(xyz1, xyz2):
+    if xyz1.dim() != 3 or xyz2.dim() != 3 or xyz1.shape[2] != 3 or xyz2.shape[2] != 3 or xyz1.shape[0] != xyz2.shape[0]:
+        # emd_kernel.cu:178-180 CHECK_EQ
+        raise _lib.PznError(f"EMD expects xyz1[B,n,3], xyz2[B,m,3]; got {tuple(xyz1.shape)}, {tuple(xyz2.shape)}")
+    return xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
+
+
+def emd_approxmatch(xyz1, xyz2):
+    """emd_cuda.approxmatch_forward (emd.cpp:24, emd_kernel.cu:171-193) -> match[B,m,n]"""
+    xyz1, xyz2 = _f32(xyz1, "xyz1"), _f32(xyz2, "xyz2")
+    B, n, m = _emd_shapes(xyz1, xyz2)
+    match = torch.empty((B, m, n), dtype=torch.float32, device=xyz1.device)
+    ws = _emd_ws(B, n, m, xyz1.device)
+    with torch.cuda.device(xyz1.device):
+        _lib.call("pzn_emd_approxmatch_f32", _p(xyz1), _p(xyz2), B, n, m, _p(match), _p(ws), _stream())
+    return match
+
+
+def emd_matchcost(xyz1, xyz2, match):
+    """emd_cuda.matchcost_forward (emd.cpp:25, emd_kernel.cu:257-279) -> cost[B]"""
+    xyz1, xyz2, match = _f32(xyz1, "xyz1"), _f32(xyz2, "xyz2"), _f32(match, "match")
+    B, n, m = _emd_shapes(xyz1, xyz2)
+    cost = torch.empty((B,), dtype=torch.float32, device=xyz1.device)
+    with torch.cuda.device(xyz1.device):
+        _lib.call("pzn_emd_matchcost_f32", _p(xyz1), _p(xyz2), _p(match), B, n, m, _p(cost), _stream())
+    return cost
+
+
+def emd_matchcost_grad(grad_cost, xyz1, xyz2, match):
+    """emd_cuda.matchcost_backward (emd.cpp:26, emd_kernel.cu:373-398) -> [grad1, grad2]"""
+    grad_cost = _f32(grad_cost, "grad_cost")
+    xyz1, xyz2, match = _f32(xyz1, "xyz1"), _f32(xyz2, "xyz2"), _f32(match, "match")
+    B, n, m = _emd_shapes(xyz1, xyz2)
+    g1 = torch.empty((B, n, 3), dtype=torch.float32, device=xyz1.device)
+    g2 = torch.empty((B, m, 3), dtype=torch.float32, device=xyz1.device)
+    with torch.cuda.device(xyz1.device):
+        _lib.call("pzn_emd_matchcost_grad_f32", _p(grad_cost), _p(xyz1), _p(xyz2), _p(match), B, n, m,
+                  _p(g1), _p(g2), _stream())
+    return [g1, g2]
+
+
+class _EmdFused(torch.autograd.Function):
+    """EarthMoverDistanceFunction (PyTorchEMD/emd.py:5-21) without the match tensor."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        xyz1, xyz2 = _f32(xyz1, "xyz1"), _f32(xyz2, "xyz2")
+        B, n, m = _emd_shapes(xyz1, xyz2)
+        dev = xyz1.device
+        cost = torch.empty((B,), dtype=torch.float32, device=dev)
+        g1 = torch.empty((B, n, 3), dtype=torch.float32, device=dev)
+        g2 = torch.empty((B, m, 3), dtype=torch.float32, device=dev)
+        ws = _emd_ws(B, n, m, dev)
+        with torch.cuda.device(dev):
+            _lib.call("pzn_emd_fused_f32", _p(xyz1), _p(xyz2), B, n, m, _p(cost), _p(g1), _p(g2), _p(ws), _stream())
+        ctx.save_for_backward(g1, g2)
+        return cost
+
+    @staticmethod
+    def backward(ctx, grad_cost):
+        g1, g2 = ctx.saved_tensors
+        gc = grad_cost.contiguous().view(-1, 1, 1)
+        return g1 * gc, g2 * gc
+
+
+def emd_fused(xyz1, xyz2):
+    return _EmdFused.apply(xyz1, xyz2)

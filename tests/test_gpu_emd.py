@@ -1,0 +1,124 @@
+"""GPU parity for the EMD path (PyTorchEMD): HIP kernels vs the CPU restatement
+of emd_kernel.cu, the reference's only known-answer test (test_emd_loss.py:8-25),
+and structural invariants.  Tolerance: 1e-4 relative (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import point_ops as orc
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def test_known_answer_from_reference_test(dev):
+    """PyTorchEMD/test_emd_loss.py:8-25 (commented-out KAT): 2-point clouds, the
+    optimal assignment is the cross one, cost 0.30 + 0.41 = 0.71 per item;
+    loss = d0/2 + 2 d1 + d2/3 and its autograd gradients."""
+    from puzzlenet_amd.PyTorchEMD.emd import earth_mover_distance
+    p1 = np.array([[[1.7, -0.1, 0.1], [0.1, 1.2, 0.3]]], dtype=np.float32).repeat(3, 0)
+    p2 = np.array([[[0.3, 1.8, 0.2], [1.2, -0.2, 0.3]]], dtype=np.float32).repeat(3, 0)
+    for materialize in (False, True):
+        t1 = _t(p1, dev).requires_grad_(True)
+        t2 = _t(p2, dev).requires_grad_(True)
+        d = earth_mover_distance(t1, t2, transpose=False, materialize_match=materialize)
+        np.testing.assert_allclose(d.detach().cpu().numpy(), [0.71] * 3, rtol=1e-4)
+        loss = d[0] / 2 + d[1] * 2 + d[2] / 3
+        np.testing.assert_allclose(float(loss), 0.71 * (0.5 + 2 + 1 / 3), rtol=1e-4)
+        loss.backward()
+        w = np.array([0.5, 2.0, 1 / 3], np.float32)[:, None, None]
+        g1 = 2 * (p1 - p2[:, ::-1]) * w          # p1_0 <-> p2_1, p1_1 <-> p2_0
+        g2 = 2 * (p2 - p1[:, ::-1]) * w
+        np.testing.assert_allclose(t1.grad.cpu().numpy(), g1, rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(t2.grad.cpu().numpy(), g2, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,n,m", [(3, 128, 128), (2, 64, 64), (2, 256, 128), (2, 100, 300), (1, 513, 200), (2, 1024, 1024)])
+def test_three_call_path_vs_oracle(dev, B, n, m):
+    from puzzlenet_amd import emd_cuda
+    rng = np.random.default_rng(n * 3 + m)
+    x1 = rng.random((B, n, 3), dtype=np.float32)
+    x2 = rng.random((B, m, 3), dtype=np.float32)
+    match = emd_cuda.approxmatch_forward(_t(x1, dev), _t(x2, dev))
+    assert match.shape == (B, m, n)
+    omatch = orc.emd_approxmatch(x1, x2)
+    assert _rel(match.cpu().numpy(), omatch) < 2e-4
+    cost = emd_cuda.matchcost_forward(_t(x1, dev), _t(x2, dev), match)
+    assert _rel(cost.cpu().numpy(), orc.emd_matchcost(x1, x2, omatch)) < RTOL
+    gc = rng.standard_normal(B).astype(np.float32)
+    g1, g2 = emd_cuda.matchcost_backward(_t(gc, dev), _t(x1, dev), _t(x2, dev), _t(omatch, dev))
+    o1, o2 = orc.emd_matchcost_grad(gc, x1, x2, omatch)
+    assert _rel(g1.cpu().numpy(), o1) < RTOL and _rel(g2.cpu().numpy(), o2) < RTOL
+
+
+@pytest.mark.parametrize("B,n,m", [(3, 128, 128), (4, 64, 64), (2, 256, 128), (2, 100, 300), (2, 1024, 1024), (1, 2048, 2048)])
+def test_fused_path_vs_oracle(dev, B, n, m):
+    from puzzlenet_amd import ops
+    rng = np.random.default_rng(n * 5 + m)
+    x1 = rng.random((B, n, 3), dtype=np.float32)
+    x2 = (x1[:, rng.permutation(n)[:m] if m <= n else rng.integers(0, n, m)] +
+          0.02 * rng.standard_normal((B, m, 3))).astype(np.float32)
+    t1, t2 = _t(x1, dev).requires_grad_(True), _t(x2, dev).requires_grad_(True)
+    cost = ops.emd_fused(t1, t2)
+    ocost, omatch = orc.earth_mover_distance(x1, x2)
+    assert _rel(cost.detach().cpu().numpy(), ocost) < RTOL
+    gc = rng.standard_normal(B).astype(np.float32)
+    (cost * _t(gc, dev)).sum().backward()
+    o1, o2 = orc.emd_matchcost_grad(gc, x1, x2, omatch)
+    assert _rel(t1.grad.cpu().numpy(), o1) < RTOL
+    assert _rel(t2.grad.cpu().numpy(), o2) < RTOL
+
+
+def test_invariants_full_size(dev):
+    """B=64, N=2048 (BASELINE configs[1]): too big for the scalar oracle; check
+    what must hold for any correct auction."""
+    from puzzlenet_amd import emd_cuda, ops
+    g = torch.Generator().manual_seed(1)
+    B, n = 8, 2048
+    x1 = torch.rand(B, n, 3, generator=g).to(dev)
+    x2 = torch.rand(B, n, 3, generator=g).to(dev)
+    match = emd_cuda.approxmatch_forward(x1, x2)
+    assert bool((match >= 0).all())
+    assert float(match.sum(1).max()) <= 1 + 1e-4          # sum_l match[l,k] <= multiL = 1
+    assert float(match.sum(2).max()) <= 1 + 1e-4          # sum_k match[l,k] <= multiR = 1
+    assert float(match.sum((1, 2)).min()) > 0.99 * n      # (almost) all mass assigned after 10 levels
+    cost3 = emd_cuda.matchcost_forward(x1, x2, match)
+    costf = ops.emd_fused(x1, x2)
+    assert _rel(costf.cpu().numpy(), cost3.cpu().numpy()) < RTOL
+    # a cloud matched with a permutation of itself costs ~0
+    perm = torch.randperm(n, generator=g).to(dev)
+    assert float(ops.emd_fused(x1, x1[:, perm]).max()) < 1e-3 * float(costf.min())
+    # fused gradients == the reference's three-call gradients
+    ones = torch.ones(B, device=dev)
+    g1, g2 = emd_cuda.matchcost_backward(ones, x1, x2, match)
+    t1, t2 = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    ops.emd_fused(t1, t2).sum().backward()
+    assert _rel(t1.grad.cpu().numpy(), g1.cpu().numpy()) < RTOL
+    assert _rel(t2.grad.cpu().numpy(), g2.cpu().numpy()) < RTOL
+
+
+def test_dropin_signature(dev):
+    from puzzlenet_amd.PyTorchEMD.emd import earth_mover_distance
+    a = torch.rand(2, 3, 50, device=dev)
+    b = torch.rand(2, 3, 50, device=dev)
+    c_t = earth_mover_distance(a, b)                                   # transpose=True default: (b,3,n)
+    c_n = earth_mover_distance(a.transpose(1, 2), b.transpose(1, 2), transpose=False)
+    assert torch.allclose(c_t, c_n)
+    assert earth_mover_distance(a[0].t(), b[0].t(), transpose=False).shape == (1,)   # 2-D inputs are unsqueezed
+    with pytest.raises(AssertionError):
+        earth_mover_distance(a.cpu(), b.cpu())

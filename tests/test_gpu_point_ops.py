@@ -1,0 +1,223 @@
+"""GPU parity: the HIP kernels (through the C ABI, via puzzlenet_amd.ops /
+the pointnet_util drop-in) against (1) the committed golden outputs of the
+reference and (2) the CPU oracle on seeded inputs.  Indices bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import point_ops as orc
+
+pytestmark = pytest.mark.gpu
+
+SG_TAGS = ["a", "b", "c", "d", "e", "f"]
+TIE_TAGS = {"b", "c", "d"}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from puzzlenet_amd import _lib
+    assert _lib.load().pzn_device_check() == 0
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("tag", SG_TAGS)
+def test_fps_golden(golden_point_ops, dev, tag):
+    from puzzlenet_amd import ops
+    G = golden_point_ops
+    B, N, S, K, D = (int(v) for v in G[f"sg_{tag}_params"])
+    want = G[f"sg_{tag}_fps_idx"]
+    got = ops.farthest_point_sample(_t(G[f"sg_{tag}_xyz"], dev), S, _t(want[:, 0], dev))
+    assert got.dtype == torch.int64
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("tag", SG_TAGS)
+def test_knn_golden(golden_point_ops, dev, tag):
+    from puzzlenet_amd import ops
+    G = golden_point_ops
+    B, N, S, K, D = (int(v) for v in G[f"sg_{tag}_params"])
+    got = ops.knn(_t(G[f"sg_{tag}_xyz"], dev), _t(G[f"sg_{tag}_new_xyz"], dev), K).cpu().numpy()
+    # the stable (distance, index) order == the oracle, always
+    assert np.array_equal(got, orc.knn(G[f"sg_{tag}_xyz"], G[f"sg_{tag}_new_xyz"], K))
+    if tag not in TIE_TAGS:
+        assert np.array_equal(got, G[f"sg_{tag}_knn_idx"])          # == the reference itself
+
+
+@pytest.mark.parametrize("tag", SG_TAGS)
+def test_group_golden(golden_point_ops, dev, tag):
+    from puzzlenet_amd import ops
+    G = golden_point_ops
+    B, N, S, K, D = (int(v) for v in G[f"sg_{tag}_params"])
+    feat = _t(G[f"sg_{tag}_feat"], dev) if D else None
+    out, gx = ops.group(_t(G[f"sg_{tag}_xyz"], dev), feat, _t(G[f"sg_{tag}_new_xyz"], dev),
+                        _t(G[f"sg_{tag}_knn_idx"], dev), want_grouped_xyz=True)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), G[f"sg_{tag}_new_points"].view(np.uint32))
+    assert np.array_equal(gx.cpu().numpy(), G[f"sg_{tag}_grouped_xyz"])
+
+
+@pytest.mark.parametrize("tag", ["a", "e", "f"])
+def test_sample_and_group_dropin_golden(golden_point_ops, dev, tag):
+    """Full drop-in call, seeded exactly as the fixture generator seeded the reference."""
+    import puzzlenet_amd.pointnet_util as pu
+    G = golden_point_ops
+    B, N, S, K, D = (int(v) for v in G[f"sg_{tag}_params"])
+    feat = _t(G[f"sg_{tag}_feat"], dev) if D else None
+    torch.manual_seed(100 + ord(tag))
+    new_xyz, new_points, grouped_xyz, fps_idx = pu.sample_and_group(
+        S, 0, K, _t(G[f"sg_{tag}_xyz"], dev), feat, returnfps=True, knn=True)
+    assert np.array_equal(fps_idx.cpu().numpy(), G[f"sg_{tag}_fps_idx"])
+    assert np.array_equal(new_xyz.cpu().numpy(), G[f"sg_{tag}_new_xyz"])
+    assert np.array_equal(new_points.cpu().numpy().view(np.uint32), G[f"sg_{tag}_new_points"].view(np.uint32))
+    assert np.array_equal(grouped_xyz.cpu().numpy(), G[f"sg_{tag}_grouped_xyz"])
+    nx2, np2 = pu.sample_and_group(S, 0, K, _t(G[f"sg_{tag}_xyz"], dev), feat, knn=True)
+    assert nx2.shape == new_xyz.shape and np2.shape == new_points.shape
+
+
+@pytest.mark.parametrize("r", [0.1, 0.2, 0.37])
+@pytest.mark.parametrize("ns", [8, 32])
+def test_ball_query_golden(golden_point_ops, dev, r, ns):
+    import puzzlenet_amd.pointnet_util as pu
+    G = golden_point_ops
+    got = pu.query_ball_point(r, ns, _t(G["ball_xyz"], dev), _t(G["ball_new_xyz"], dev))
+    assert np.array_equal(got.cpu().numpy(), G[f"ball_r{r}_n{ns}"])
+
+
+def test_ball_query_edge_and_dropin(golden_point_ops, dev):
+    import puzzlenet_amd.pointnet_util as pu
+    G = golden_point_ops
+    r = float(G["ball_edge_radius"][0])
+    got = pu.query_ball_point(r, 3, _t(G["ball_edge_xyz"], dev), _t(G["ball_edge_query"], dev))
+    assert np.array_equal(got.cpu().numpy(), G["ball_edge_idx"])
+    torch.manual_seed(7)
+    o = pu.sample_and_group(32, 0.2, 16, _t(G["sgball_xyz"], dev), _t(G["sgball_feat"], dev), returnfps=True, knn=False)
+    assert np.array_equal(o[3].cpu().numpy(), G["sgball_fps_idx"])
+    assert np.array_equal(o[1].cpu().numpy().view(np.uint32), G["sgball_new_points"].view(np.uint32))
+    assert np.array_equal(o[2].cpu().numpy(), G["sgball_grouped_xyz"])
+
+
+def test_square_distance_golden(golden_point_ops, dev):
+    import puzzlenet_amd.pointnet_util as pu
+    G = golden_point_ops
+    got = pu.square_distance(_t(G["sg_d_new_xyz"], dev), _t(G["sg_d_xyz"], dev))
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), G["sg_d_sqdist"].view(np.uint32))
+
+
+def test_index_points_golden_and_grad(golden_point_ops, dev):
+    import puzzlenet_amd.pointnet_util as pu
+    G = golden_point_ops
+    pts = _t(G["ip_points"], dev).requires_grad_(True)
+    o2 = pu.index_points(pts, _t(G["ip_idx2"], dev))
+    o3 = pu.index_points(pts, _t(G["ip_idx3"], dev))
+    assert np.array_equal(o2.detach().cpu().numpy(), G["ip_out2"])
+    assert np.array_equal(o3.detach().cpu().numpy(), G["ip_out3"])
+    (o3 * _t(G["ip_w3"], dev)).sum().backward()
+    np.testing.assert_allclose(pts.grad.cpu().numpy(), G["ip_grad3"], rtol=1e-5, atol=1e-6)
+
+
+# ---- seeded inputs vs the oracle: sizes of every BASELINE config, edge cases ----
+
+@pytest.mark.parametrize("B,N,S", [(4, 1024, 512), (3, 2048, 512), (2, 4096, 512), (1, 8192, 512),
+                                   (5, 512, 256), (2, 100, 100), (1, 1, 1), (2, 65, 7), (1, 12000, 16),
+                                   (1, 20000, 8)])
+def test_fps_vs_oracle(dev, B, N, S):
+    from puzzlenet_amd import ops
+    rng = np.random.default_rng(N * 7 + S)
+    xyz = rng.random((B, N, 3), dtype=np.float32)
+    if N > 8:
+        xyz[:, N // 2] = xyz[:, 1]                      # an exact duplicate: tie in the arg-max
+    start = rng.integers(0, N, size=B)
+    got = ops.farthest_point_sample(_t(xyz, dev), S, _t(start, dev)).cpu().numpy()
+    assert np.array_equal(got, orc.farthest_point_sample(xyz, S, start))
+
+
+@pytest.mark.parametrize("B,N,S,K", [(2, 1024, 512, 32), (2, 2048, 512, 32), (2, 512, 256, 32), (1, 4096, 512, 32),
+                                     (1, 8192, 256, 32), (2, 100, 33, 7), (1, 64, 64, 64), (2, 33, 5, 33),
+                                     (1, 300, 9, 1), (1, 5000, 40, 48), (1, 13000, 12, 32)])
+def test_knn_vs_oracle(dev, B, N, S, K):
+    from puzzlenet_amd import ops
+    rng = np.random.default_rng(N + 13 * K)
+    xyz = rng.random((B, N, 3), dtype=np.float32)
+    if N >= 64:
+        xyz[:, 5:25] = xyz[:, 40:60]                    # 20 duplicate points -> distance ties
+    q = xyz[:, rng.permutation(N)[:S] if S <= N else rng.integers(0, N, S)].copy()
+    got = ops.knn(_t(xyz, dev), _t(q, dev), K).cpu().numpy()
+    assert np.array_equal(got, orc.knn(xyz, q, K))
+
+
+def test_knn_adversarial_layouts(dev):
+    """Inputs built to stress the candidate/merge path: all points identical,
+    points sorted by decreasing distance, and near points packed on few lanes."""
+    from puzzlenet_amd import ops
+    N, K = 2048, 32
+    rng = np.random.default_rng(5)
+    same = np.tile(np.float32([0.3, 0.4, 0.5]), (1, N, 1))
+    q = np.float32([[[0.3, 0.4, 0.5], [0.0, 0.0, 0.0]]])
+    desc = np.zeros((1, N, 3), np.float32)
+    desc[0, :, 0] = np.linspace(2.0, 0.01, N, dtype=np.float32)
+    lanes = rng.random((1, N, 3), dtype=np.float32) + 5.0
+    lanes[0, 3::64] = rng.random((N // 64, 3), dtype=np.float32) * 0.01     # lane 3 holds every near point
+    lanes[0, 7::64] = rng.random((N // 64, 3), dtype=np.float32) * 0.01
+    for xyz in (same, desc, lanes):
+        got = ops.knn(_t(xyz, dev), _t(q, dev), K).cpu().numpy()
+        assert np.array_equal(got, orc.knn(xyz, q, K))
+
+
+def test_group_backward_vs_oracle(dev):
+    from puzzlenet_amd import ops
+    rng = np.random.default_rng(11)
+    B, N, S, K, D = 2, 256, 64, 32, 64
+    xyz = rng.random((B, N, 3), dtype=np.float32)
+    feat = rng.standard_normal((B, N, D)).astype(np.float32)
+    new_xyz = xyz[:, :S].copy()
+    idx = orc.knn(xyz, new_xyz, K)
+    go = rng.standard_normal((B, S, K, 3 + D)).astype(np.float32)
+    txyz, tfeat, tnew = (_t(a, dev).requires_grad_(True) for a in (xyz, feat, new_xyz))
+    out = ops.group(txyz, tfeat, tnew, _t(idx, dev))
+    assert np.array_equal(out.detach().cpu().numpy().view(np.uint32), orc.group(xyz, feat, new_xyz, idx).view(np.uint32))
+    (out * _t(go, dev)).sum().backward()
+    gxyz, gfeat, gnew = orc.group_grad(go, idx, N)
+    np.testing.assert_allclose(tfeat.grad.cpu().numpy(), gfeat, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(txyz.grad.cpu().numpy(), gxyz, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(tnew.grad.cpu().numpy(), gnew, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("K,D", [(32, 64), (32, 128), (16, 6), (7, 5), (5, 0)])
+def test_group_shapes_vs_oracle(dev, K, D):
+    from puzzlenet_amd import ops
+    rng = np.random.default_rng(K * 100 + D)
+    B, N, S = 3, 300, 50
+    xyz = rng.random((B, N, 3), dtype=np.float32)
+    feat = rng.standard_normal((B, N, D)).astype(np.float32) if D else None
+    new_xyz = rng.random((B, S, 3), dtype=np.float32)
+    idx = rng.integers(0, N, size=(B, S, K))
+    out = ops.group(_t(xyz, dev), None if feat is None else _t(feat, dev), _t(new_xyz, dev), _t(idx, dev))
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), orc.group(xyz, feat, new_xyz, idx).view(np.uint32))
+
+
+def test_full_size_properties(dev):
+    """BASELINE configs[1] size (B=64, N=2048): properties that need no oracle run."""
+    import puzzlenet_amd.pointnet_util as pu
+    g = torch.Generator().manual_seed(3)
+    xyz = torch.rand(64, 2048, 3, generator=g).to(dev)
+    feat = torch.randn(64, 2048, 64, generator=g).to(dev)
+    new_xyz, new_points, grouped_xyz, fps_idx = pu.sample_and_group(512, 0, 32, xyz, feat, returnfps=True, knn=True)
+    # FPS: indices in range and distinct per cloud (random data has no duplicates)
+    assert int(fps_idx.min()) >= 0 and int(fps_idx.max()) < 2048
+    assert all(len(torch.unique(fps_idx[b])) == 512 for b in range(0, 64, 9))
+    # kNN: slot 0 is the centroid itself, distances ascend, neighbours distinct
+    d = ((grouped_xyz - new_xyz[:, :, None]) ** 2).sum(-1)
+    assert float(d[:, :, 0].abs().max()) == 0.0
+    assert bool((d[:, :, 1:] >= d[:, :, :-1]).all())
+    # kth distance is a true threshold: exactly 32 points within it
+    full = pu.square_distance(new_xyz[:2], xyz[:2])
+    assert bool(((full <= d[:2, :, -1:]).sum(-1) == 32).all())
+    # group: feature half equals a plain gather of the selected rows
+    knn_idx = torch.argsort(full, dim=-1, stable=True)[:, :, :32]
+    ref = torch.gather(feat[:2], 1, knn_idx.reshape(2, -1, 1).expand(-1, -1, 64)).reshape(2, 512, 32, 64)
+    assert torch.equal(new_points[:2, :, :, 3:], ref)
+    assert torch.equal(new_points[:, :, :, :3], grouped_xyz - new_xyz[:, :, None])
