@@ -1,0 +1,348 @@
+"""Drop-in for the live path of the reference's ``model5_b`` (the model used in the
+paper, model5_b.py): ``layerAttention``, ``PCTransformer_nonsort``,
+``TouchedRegraster`` with ``predict5`` / ``training_step`` / ``chamfer_loss`` /
+``comp`` / ``configure_optimizers`` — same class, attribute and parameter names,
+so a reference ``state_dict`` loads unchanged (8,059,220 parameters).
+
+What is different from the reference file
+  * every hard-wired 1024 (BatchNorm1d(num_points), repeat(1,1024,1),
+    zeros(B,1024)) follows ``num_points`` (``config.num_points``, default 1024);
+  * the point ops, EMD, chamfer, shared-MLP and attention run as hand-written
+    gfx950 kernels behind the C ABI (puzzlenet_amd.ops / .dense);
+  * TensorBoard meshes / matplotlib figures of the reference's training_step
+    (model5_b.py:975-982, 1130-1134) are host-side logging and are not produced;
+  * dead code of the reference (Encoder, decoders other than BiDecoderNoneCross,
+    predict2/3/4/6) is not restated; ``fpc_decoder`` / ``rpc_decoder`` exist because
+    their parameters are part of the reference's state_dict.
+Reference quirks that ARE reproduced: the model5_b.py:741 copy-paste (the fpc global
+feature is the max of the *mrpc* local feature) and the ``x2[:, idx[:, 0]]`` indexing
+at :940/:942 that yields a [B,B,3] tensor.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import dense, ops, se3
+from . import pointnet_util as pu
+from .PyTorchEMD.emd import earth_mover_distance
+
+try:  # the reference subclasses pl.LightningModule; keep that when Lightning is installed
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except ImportError:  # pragma: no cover - image without Lightning
+    class _Base(nn.Module):
+        current_epoch = 0
+        global_step = 0
+        logger = None
+
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log(self, *a, **k):
+            pass
+
+
+def scaled_dot_production(q, k, v, mask=None):
+    """model5_b.py:67-75 -> (values, attention)."""
+    if mask is not None:
+        raise NotImplementedError("mask is never passed on the live path (model5_b.py:96)")
+    return dense.attention(q, k, v)
+
+
+class layerAttention(nn.Module):
+    """model5_b.py:83-101: offset-attention block, r = x + relu(W_o (x - attn(x)))."""
+
+    def __init__(self, config, embed_dim):
+        super().__init__()
+        self.C = config
+        self.mlpq = nn.Linear(embed_dim, embed_dim // 4)
+        self.mlpk = nn.Linear(embed_dim, embed_dim // 4)
+        self.mlpv = nn.Linear(embed_dim, embed_dim)
+        self.out = nn.Linear(embed_dim, embed_dim)
+
+    def forward(self, xyz):
+        q = dense.linear(xyz, self.mlpq.weight, self.mlpq.bias)
+        k = dense.linear(xyz, self.mlpk.weight, self.mlpk.bias)
+        v = dense.linear(xyz, self.mlpv.weight, self.mlpv.bias)
+        r, attention = scaled_dot_production(q, k, v)
+        r = xyz - r
+        r = xyz + dense.linear(r, self.out.weight, self.out.bias, relu=True)
+        return r, attention
+
+
+class BiDecoderNoneCross(nn.Module):
+    """model5_b.py:325-352.  Instantiated by the reference (:537-538), never called by
+    predict5; kept for state_dict / parameter-count parity."""
+
+    def __init__(self, config, num_points=1024):
+        super().__init__()
+        self.C = config
+        self.mlp1 = nn.Linear(512, 512)
+        self.mlp2 = nn.Linear(512, 256)
+        self.mlp3 = nn.Linear(256, 2)
+
+    def forward(self, f_local, f_global):
+        f_global = f_global.unsqueeze(1) if len(f_global.shape) == 2 else f_global
+        f = f_global.repeat(1, 256, 1)
+        f = torch.cat([f_local, f], dim=1).permute(0, 2, 1)
+        f = dense.linear(f, self.mlp1.weight, self.mlp1.bias, relu=True)
+        f = dense.linear(f, self.mlp2.weight, self.mlp2.bias, relu=True)
+        f = dense.linear(f, self.mlp3.weight, self.mlp3.bias)
+        return f.permute(0, 2, 1)
+
+
+class PCTransformer_nonsort(nn.Module):
+    """model5_b.py:411-478: per-cloud encoder."""
+
+    def __init__(self, config, num_points=1024):
+        super().__init__()
+        self.C = config
+        feature_size = 64
+        gs2_feature_size = 128
+        self.mlp1 = nn.Linear(3, 64)
+        self.mlp2 = nn.Linear(64, feature_size)
+        self.mlp3 = nn.Linear(feature_size + 3, 128)
+        self.mlp4 = nn.Linear(128, gs2_feature_size)
+        self.mlp5 = nn.Linear(gs2_feature_size + 3, gs2_feature_size * 2)
+        self.mlp6 = nn.Linear(gs2_feature_size * 2, gs2_feature_size * 2)
+        self.bn1 = nn.BatchNorm1d(num_points)   # the channel axis of a [B,N,64] tensor is N (:424,:447)
+        self.bn2 = nn.BatchNorm1d(num_points)
+        self.sg1 = pu.sample_and_group
+        self.fps = pu.farthest_point_sample
+        self.sg2 = pu.sample_and_group
+        self.atten1 = layerAttention(self.C, gs2_feature_size * 2)
+        self.atten2 = layerAttention(self.C, gs2_feature_size * 2)
+        self.atten3 = layerAttention(self.C, gs2_feature_size * 2)
+        self.atten4 = layerAttention(self.C, gs2_feature_size * 2)
+        self.out = nn.Linear(gs2_feature_size * 2 * 5, 1024)
+
+    def forward(self, xyz):
+        x_feature = F.relu(self.bn1(dense.linear(xyz, self.mlp1.weight, self.mlp1.bias)))          # :447
+        x_feature = F.relu(self.bn2(dense.linear(x_feature, self.mlp2.weight, self.mlp2.bias)))   # :448
+        x, f1 = self.sg1(512, 0, 32, xyz, x_feature, False, True)                                 # :449
+        f1f = dense.shared_mlp_max(f1, self.mlp3.weight, self.mlp3.bias, self.mlp4.weight, self.mlp4.bias)  # :452-454
+        x2, f2 = self.sg2(256, 0, 32, x, f1f, False, True)                                        # :456
+        f2f = dense.shared_mlp_max(f2, self.mlp5.weight, self.mlp5.bias, self.mlp6.weight, self.mlp6.bias)  # :459-461
+        att1, attention1 = self.atten1(f2f)
+        att2, attention2 = self.atten2(att1)
+        att3, attention3 = self.atten3(att2)
+        att4, attention4 = self.atten4(att3)
+        att = torch.cat([att1, att2, att3, att4], dim=-1)
+        attention = attention1 + attention2 + attention3 + attention4
+        attention = attention / 4
+        att = torch.cat([att, f2f], dim=-1)
+        out = dense.linear(att, self.out.weight, self.out.bias)                                   # :474
+        f_global = torch.max(out, dim=1)[0]                                                       # :475
+        return f_global, x2, attention, out, x_feature
+
+
+def _seq(*dims):
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(nn.Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2:
+            layers.append(nn.ReLU())
+    return nn.Sequential(*layers)
+
+
+def _run_seq(seq, x):
+    """nn.Sequential(Linear, ReLU, Linear, ...) through the fused linear(+ReLU) kernel."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        lin = mods[i]
+        relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+        x = dense.linear(x, lin.weight, lin.bias, relu=relu)
+        i += 2 if relu else 1
+    return x
+
+
+class TouchedRegraster(_Base):
+    """model5_b.py:519-1519 (live path only)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.save_hyperparameters()
+        self.C = config
+        self.num_points = int(getattr(config, "num_points", 1024))
+        self.Encoder = PCTransformer_nonsort(config, self.num_points)
+        self.Encoder2 = PCTransformer_nonsort(config, self.num_points)
+        self.fpc_decoder = BiDecoderNoneCross(config)
+        self.rpc_decoder = BiDecoderNoneCross(config)
+        delta = 1.0e-2
+        self.dt = nn.Parameter(torch.full((1, 6), delta), requires_grad=True)      # :541-543
+        self.tfMLP = _seq(2048, 1024, 512, 512, 256, 6)                            # :559-569
+        self.MLPLocalPreRpc = _seq(64, 64, 64, 64)                                 # :571-577
+        self.MLPLocalPreFpc = _seq(64, 64, 64, 64)
+        self.MLPRpcb = _seq(128, 64, 32, 2)                                        # :586-592
+        self.MLPFpcb = _seq(128, 64, 32, 2)
+
+    # ------------------------------------------------------------------ forward
+    def predict5(self, batch, batch_indic, need=False, training=False):
+        """model5_b.py:672-759."""
+        for m in (self.Encoder, self.Encoder2, self.tfMLP, self.fpc_decoder, self.rpc_decoder):
+            m.train(training)                                                       # :677-690
+        fpc, mrpc = batch[0], batch[1]
+        if len(fpc.shape) == 2:
+            fpc = fpc.unsqueeze(0)
+            mrpc = mrpc.unsqueeze(0)
+        N = fpc.shape[1]
+
+        ffpcs = self.Encoder(fpc)                                                   # :710
+        ffpc, non_sg_ffpc = ffpcs[0], ffpcs[4]
+        fmrpcs = self.Encoder2(mrpc)                                                # :716
+        fmrpc, non_sg_fmrpc = fmrpcs[0], fmrpcs[4]
+
+        f = torch.cat([ffpc, fmrpc], dim=-1)                                        # :723
+        out = _run_seq(self.tfMLP, f)                                               # :725
+
+        non_sg_ffpc = _run_seq(self.MLPLocalPreFpc, non_sg_ffpc)                    # :738
+        non_sg_fmrpc = _run_seq(self.MLPLocalPreRpc, non_sg_fmrpc)                  # :739
+        # :741 — the reference takes the max of non_sg_fmrpc for BOTH globals (its bug, kept)
+        non_sg_ffpc_global = torch.max(non_sg_fmrpc, dim=1, keepdim=True)[0].repeat(1, N, 1)
+        non_sg_fmrpc_global = torch.max(non_sg_fmrpc, dim=1, keepdim=True)[0].repeat(1, N, 1)
+        ffpc_feature4seg = torch.cat([non_sg_fmrpc_global, non_sg_ffpc], dim=-1)    # :748
+        fmrpc_feature4seg = torch.cat([non_sg_ffpc_global, non_sg_fmrpc], dim=-1)   # :749
+        de_fpcb = _run_seq(self.MLPFpcb, ffpc_feature4seg).permute(0, 2, 1)         # :751-752
+        de_mrpcb = _run_seq(self.MLPRpcb, fmrpc_feature4seg).permute(0, 2, 1)       # :753-754
+        if not need:
+            return out, out, de_fpcb, de_mrpcb
+        return out, [0], ffpcs[1], ffpcs[2], fmrpcs[1], fmrpcs[2], de_fpcb, de_mrpcb
+
+    def forward(self, batch, bat=None):
+        return self.predict5(batch, bat)
+
+    # ------------------------------------------------------------------ losses
+    def chamfer_loss(self, a, b):
+        """model5_b.py:1495-1505 -> (min over a per b-point [B,m], min over b per a-point [B,n])."""
+        return dense.chamfer(a, b)
+
+    def comp(self, g, igt):
+        """model5_b.py:1512-1519: |g igt - I|^2 mean * 16."""
+        assert g.size(0) == igt.size(0)
+        assert g.size(1) == igt.size(1) and g.size(1) == 4
+        assert g.size(2) == igt.size(2) and g.size(2) == 4
+        A = g.matmul(igt)
+        I = torch.eye(4).to(A).view(1, 4, 4).repeat(A.size(0), 1, 1)
+        return F.mse_loss(A, I, reduction='mean') * 16
+
+    def training_step(self, batch, batch_indic):
+        """model5_b.py:912-1155 (non-pretrain branch), every loss term; logging calls kept as self.log."""
+        fpc, mrpc, igt, rpc, fpcb, rpcb = batch[0], batch[1], batch[2], batch[3], batch[4], batch[5]
+        batch_size = fpc.shape[0]
+        fpc_idx, rpc_idx = batch[6], batch[7]
+        N = fpc.shape[1]
+        C = self.C
+
+        out, t, x2, attention, mrpc_x2, mrpc_attention, de_fpcb, de_mrpcb = self.predict5(
+            batch, batch_size, training=True, need=True)                            # :933
+
+        att1 = attention.mean(dim=1)                                                # :937-942
+        att2 = mrpc_attention.mean(dim=1)
+        x2att1 = x2[:, torch.topk(att1, 32)[1][:, 0]]
+        x2att2 = mrpc_x2[:, torch.topk(att2, 32)[1][:, 0]]
+
+        mat = se3.exp(out).to(mrpc)                                                 # :947-952
+        de_mrpc = se3.transform(mat, mrpc.permute(0, 2, 1)).permute(0, 2, 1)
+        R = mat[:, :3, :3]
+        t = mat[:, :3, 3]
+
+        dg_mrpc_dist1, dg_mrpc_dist2 = self.chamfer_loss(rpc, de_mrpc)              # :956-960
+        if C.loss_sum:
+            loss_recoversy = torch.sum(dg_mrpc_dist1) + torch.sum(dg_mrpc_dist2)
+        else:
+            loss_recoversy = torch.mean(dg_mrpc_dist1) + torch.mean(dg_mrpc_dist2)
+
+        g = torch.eye(4).unsqueeze(0).repeat(R.shape[0], 1, 1).to(R)                # :963-967
+        g[:, :3, :3] = R
+        g[:, :3, 3] = t
+        loss_g = self.comp(g, igt)
+        self.log('train/loss_re', loss_recoversy)
+        self.log('train/loss_g', loss_g)
+
+        dg_att1_dist1, dg_att1_dist2 = self.chamfer_loss(x2att1, x2att2)            # :1001
+        emd = earth_mover_distance(de_mrpc, rpc, transpose=False)                   # :1002
+        if C.loss_sum:
+            loss_emd = torch.sum(emd)
+            loss_cd2 = torch.sum(dg_att1_dist1) + torch.sum(dg_att1_dist2)
+        else:
+            loss_emd = torch.mean(emd)
+            loss_cd2 = torch.mean(dg_att1_dist1) + torch.mean(dg_att1_dist2)
+        self.log('train/cd2', loss_cd2)
+        emd2 = earth_mover_distance(x2att1, x2att2, transpose=False)                # :1012
+        self.log('train/loss_emd', loss_emd)
+
+        mode = C.loss_mode                                                          # :1016-1029
+        if mode == 0:
+            loss = loss_recoversy + loss_g
+        elif mode == 1:
+            loss = loss_recoversy + loss_g + loss_emd
+        elif mode == 2:
+            loss = loss_emd
+        elif mode == 3:
+            loss = loss_emd + loss_g
+        elif mode == 4:
+            loss = loss_emd + loss_recoversy
+        elif mode == 5:
+            loss = loss_g
+        elif mode == 6:
+            loss = loss_recoversy
+        else:
+            raise ValueError(f"loss_mode {mode}")
+        emd2 = torch.sum(emd2)                                                      # :1033-1036
+        self.log('train_emd2', emd2)
+        if C.use_emd2:
+            loss = loss + emd2
+        if C.use_cd2:
+            loss = loss + loss_cd2
+
+        loss_fpcb_cel = F.cross_entropy(de_fpcb, fpc_idx.squeeze().long())          # :1063-1064
+        loss_rpcb_cel = F.cross_entropy(de_mrpcb, rpc_idx.squeeze().long())
+        loss = loss + loss_fpcb_cel + loss_rpcb_cel
+        self.log('train/loss_fpcb_cel', loss_fpcb_cel)
+        self.log('train/loss_rpcb_cel', loss_rpcb_cel)
+
+        de_fpcb_idx_sig = torch.softmax(de_fpcb, dim=1)[:, 1, :]                    # :1085-1091
+        de_fpcb_idx = torch.topk(de_fpcb_idx_sig, 128, 1)[1]
+        de_mrpcb_idx_sig = torch.softmax(de_mrpcb, dim=1)[:, 1, :]
+        de_mrpcb_idx = torch.topk(de_mrpcb_idx_sig, 128, 1)[1]
+
+        with torch.no_grad():                                                       # :1094-1105 (IoU, logged only)
+            pred_1_fpc = torch.zeros(fpc_idx.shape[0], N).to(fpc_idx).scatter(1, de_fpcb_idx, 1)
+            pred_1_mrpc = torch.zeros(fpc_idx.shape[0], N).to(fpc_idx).scatter(1, de_mrpcb_idx, 1)
+            fpc_iou = torch.sum(torch.logical_and(pred_1_fpc, fpc_idx)).float() / \
+                torch.sum(torch.logical_or(pred_1_fpc, fpc_idx)).float()
+            mrpcb_iou = torch.sum(torch.logical_and(pred_1_mrpc, rpc_idx)).float() / \
+                torch.sum(torch.logical_or(pred_1_mrpc, rpc_idx)).float()
+        self.log('train/fpc_iou', fpc_iou)
+        self.log('train/mrpcb_iou', mrpcb_iou)
+
+        de_fpcb_pts = ops.index_points(fpc, de_fpcb_idx)                            # :1109-1110
+        de_mrpcb_pts = ops.index_points(mrpc, de_mrpcb_idx)
+
+        cd_fpcb1, cd_fpcb2 = self.chamfer_loss(de_fpcb_pts, fpcb)                   # :1112-1113
+        loss_fpcb = torch.mean(cd_fpcb1) + torch.mean(cd_fpcb2)
+        self.log('train/loss_fpcb', loss_fpcb)
+        inverse_de_mrpcb = se3.transform(se3.exp(out).to(mrpc), de_mrpcb_pts.permute(0, 2, 1)).permute(0, 2, 1)  # :1116
+        cd_mrpcb1, cd_mrpcb2 = self.chamfer_loss(inverse_de_mrpcb, rpcb)            # :1119-1120
+        loss_mrpcb = torch.mean(cd_mrpcb1) + torch.mean(cd_mrpcb2)
+        self.log('train/loss_rpcb', loss_mrpcb)
+
+        emd_fpcb = torch.mean(earth_mover_distance(de_fpcb_pts, fpcb, transpose=False))         # :1123-1126
+        emd_mrpcb = torch.mean(earth_mover_distance(inverse_de_mrpcb, rpcb, transpose=False))
+        self.log('train/loss_emd_fpcb', emd_fpcb)
+        self.log('train/loss_emc_mrpcb', emd_mrpcb)
+
+        loss = loss + loss_mrpcb + loss_fpcb                                        # :1146-1151
+        if C.use_emd3:
+            loss = loss + emd_fpcb + emd_mrpcb
+        self.log('train_loss', loss)
+        return {'loss': loss}
+
+    def configure_optimizers(self):
+        """model5_b.py:1453-1457: Adam + StepLR(50, 0.999) stepped per batch."""
+        optimizer = torch.optim.Adam(self.parameters(), lr=self.C.lr)
+        self.scheduler = torch.optim.lr_scheduler.StepLR(optimizer, 50, 0.999)
+        return [optimizer], [{'scheduler': self.scheduler, 'interval': 'step'}]

@@ -1,0 +1,67 @@
+"""SE(3) exponential and point transform as used by the training step
+(reference: se_math/se3.py:57-80 `exp`, :110-120 `transform`; se_math/so3.py `mat`;
+se_math/sinc.py:6-18, 96-108, 126-138 `sinc1/2/3` with their |t| < 0.01 Taylor branches).
+
+Row (f1) of the scope table: B x 4 x 4 math, a few hundred flops per pair, kept
+as torch tensor ops (autograd included) — it is not a GPU hot spot.
+"""
+import torch
+
+
+def _sinc1(t):
+    """sin(t)/t  (sinc.py:6-18)"""
+    t2 = t * t
+    small = 1 - t2 / 6 * (1 - t2 / 20 * (1 - t2 / 42))
+    safe = torch.where(t.abs() < 0.01, torch.ones_like(t), t)
+    return torch.where(t.abs() < 0.01, small, torch.sin(safe) / safe)
+
+
+def _sinc2(t):
+    """(1 - cos t)/t^2  (sinc.py:96-108)"""
+    t2 = t * t
+    small = 1 / 2 * (1 - t2 / 12 * (1 - t2 / 30 * (1 - t2 / 56)))
+    safe = torch.where(t.abs() < 0.01, torch.ones_like(t), t)
+    return torch.where(t.abs() < 0.01, small, (1 - torch.cos(safe)) / (safe * safe))
+
+
+def _sinc3(t):
+    """(t - sin t)/t^3  (sinc.py:126-138)"""
+    t2 = t * t
+    small = 1 / 6 * (1 - t2 / 20 * (1 - t2 / 42 * (1 - t2 / 72)))
+    safe = torch.where(t.abs() < 0.01, torch.ones_like(t), t)
+    return torch.where(t.abs() < 0.01, small, (safe - torch.sin(safe)) / (safe ** 3))
+
+
+def _so3_mat(w):
+    """[*,3] -> skew matrices [*,3,3]  (so3.py `mat`)"""
+    w1, w2, w3 = w[:, 0], w[:, 1], w[:, 2]
+    O = torch.zeros_like(w1)
+    return torch.stack((torch.stack((O, -w3, w2), dim=1),
+                        torch.stack((w3, O, -w1), dim=1),
+                        torch.stack((-w2, w1, O), dim=1)), dim=1)
+
+
+def exp(x):
+    """twist [*,6] = (w, v) -> SE(3) [*,4,4]  (se3.py:57-80)"""
+    x_ = x.reshape(-1, 6)
+    w, v = x_[:, 0:3], x_[:, 3:6]
+    t = w.norm(p=2, dim=1).view(-1, 1, 1)
+    W = _so3_mat(w)
+    S = W.bmm(W)
+    I = torch.eye(3, dtype=x.dtype, device=x.device)
+    R = I + _sinc1(t) * W + _sinc2(t) * S          # Rodrigues
+    V = I + _sinc2(t) * W + _sinc3(t) * S
+    p = V.bmm(v.contiguous().view(-1, 3, 1))
+    z = torch.tensor([0, 0, 0, 1], dtype=x.dtype, device=x.device).view(1, 1, 4).repeat(x_.size(0), 1, 1)
+    g = torch.cat((torch.cat((R, p), dim=2), z), dim=1)
+    return g.view(*(x.size()[0:-1]), 4, 4)
+
+
+def transform(g, a):
+    """g [*,4,4], a [*,3,N] (or [*,3]) -> R a + p  (se3.py:110-120)"""
+    g_ = g.view(-1, 4, 4)
+    R = g_[:, 0:3, 0:3].contiguous().view(*(g.size()[0:-2]), 3, 3)
+    p = g_[:, 0:3, 3].contiguous().view(*(g.size()[0:-2]), 3)
+    if len(g.size()) == len(a.size()):
+        return R.matmul(a) + p.unsqueeze(-1)
+    return R.matmul(a.unsqueeze(-1)).squeeze(-1) + p

@@ -1,0 +1,145 @@
+"""GPU parity of the model path (puzzlenet_amd.model5_b drop-in) against the reference's
+own outputs (tests/golden/model.npz, loss.npz).  Tolerance: fp32 pose / logits / loss within
+1e-4 relative (BASELINE.json north_star); FPS-selected points bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref as mr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _close(got, want, rtol=1e-4, atol=1e-5, msg=""):
+    np.testing.assert_allclose(got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got, want,
+                               rtol=rtol, atol=atol, err_msg=msg)
+
+
+def test_state_dict_names_match_reference(golden_loss, golden_model):
+    from puzzlenet_amd import model5_b as mb
+    m = mb.TouchedRegraster(mr.Cfg())
+    assert sorted(n for n, _ in m.named_parameters()) == list(golden_loss["ts0_grad_names"])
+    assert sum(p.numel() for p in m.parameters()) == int(golden_model["n_params"][0])
+    # a state_dict of the (reference-named) oracle model loads strictly
+    m.load_state_dict(mr.RefModel(mr.Cfg()).state_dict(), strict=True)
+
+
+def test_layer_attention(golden_model, dev):
+    from puzzlenet_amd import model5_b as mb
+    G = golden_model
+    att = mb.layerAttention(mr.Cfg(), 256)
+    mr.fill_params(att)
+    att.to(dev)
+    x = _t(G["att_x"], dev).requires_grad_(True)
+    r, a = att(x)
+    _close(r, G["att_r"])
+    _close(a, G["att_a"], atol=1e-6)
+    ((r * _t(G["att_wr"], dev)).sum() + (a * _t(G["att_wa"], dev)).sum()).backward()
+    _close(x.grad, G["att_gx"], rtol=1e-4, atol=2e-5)
+    for n, p in att.named_parameters():
+        _close(p.grad, G["att_g_" + n], rtol=1e-4, atol=2e-4, msg=n)
+
+
+@pytest.mark.parametrize("N", [1024, 2048])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_encoder(golden_model, dev, N, mode):
+    from puzzlenet_amd import model5_b as mb
+    G = golden_model
+    enc = mb.PCTransformer_nonsort(mr.Cfg(), num_points=N)
+    mr.fill_params(enc)
+    enc.to(dev).train(mode == "train")
+    torch.manual_seed(1000 + N)
+    with torch.no_grad():
+        f_global, x2, attention, out, xf = enc(_t(G[f"enc{N}_xyz"], dev))
+    tag = f"enc{N}_{mode}_"
+    assert np.array_equal(x2.cpu().numpy(), G[tag + "x2"])          # same 256 points as the reference, bit for bit
+    _close(xf[:, ::8], G[tag + "x_feature_s8"])
+    _close(attention[:, ::8], G[tag + "attention_s8"], atol=1e-6)
+    _close(f_global, G[tag + "f_global"], atol=1e-4)
+    _close(out[:, ::16, ::8], G[tag + "out_sample"], atol=1e-4)
+    if mode == "train":
+        _close(enc.bn1.running_mean, G[tag + "bn1_running_mean"])
+        _close(enc.bn1.running_var, G[tag + "bn1_running_var"])
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_predict5(golden_model, dev, mode):
+    from puzzlenet_amd import model5_b as mb
+    G = golden_model
+    m = mb.TouchedRegraster(mr.Cfg())
+    mr.fill_params(m)
+    m.to(dev)
+    batch = [_t(G[f"p5_batch{i}"], dev) for i in range(8)]
+    torch.manual_seed(2024)
+    with torch.no_grad():
+        out = m.predict5(batch, 4, need=True, training=(mode == "train"))
+    _close(out[0], G[f"p5_{mode}_out"])                                   # pose twist [4,6]
+    g_ref = mr.se3_exp(torch.from_numpy(G[f"p5_{mode}_out"]))
+    from puzzlenet_amd import se3
+    _close(se3.exp(out[0]), g_ref.numpy())                                 # SE(3) [4,4,4]
+    assert np.array_equal(out[2].cpu().numpy(), G[f"p5_{mode}_x2"])
+    assert np.array_equal(out[4].cpu().numpy(), G[f"p5_{mode}_mrpc_x2"])
+    _close(out[3][:, ::8], G[f"p5_{mode}_attention_s8"], atol=1e-6)
+    _close(out[6], G[f"p5_{mode}_de_fpcb"], atol=1e-4)                     # boundary logits [4,2,1024]
+    _close(out[7], G[f"p5_{mode}_de_mrpcb"], atol=1e-4)
+    o4 = m.predict5(batch, 4, need=False, training=False)
+    assert len(o4) == 4 and o4[0].shape == (4, 6) and o4[2].shape == (4, 2, 1024)
+
+
+def test_se3_chamfer_comp(golden_loss, dev):
+    from puzzlenet_amd import model5_b as mb, se3
+    G = golden_loss
+    tw = _t(G["se3_twist"], dev).requires_grad_(True)
+    g = se3.exp(tw)
+    _close(g, G["se3_exp"], rtol=1e-5, atol=1e-6)
+    _close(se3.transform(g.detach(), _t(G["se3_pts"], dev)), G["se3_transform"], rtol=1e-5, atol=1e-6)
+    (g * _t(G["se3_w"], dev)).sum().backward()
+    _close(tw.grad, G["se3_exp_grad"], rtol=1e-4, atol=1e-5)
+    m = mb.TouchedRegraster(mr.Cfg())
+    a, b = _t(G["cd_a"], dev).requires_grad_(True), _t(G["cd_b"], dev).requires_grad_(True)
+    d1, d2 = m.chamfer_loss(a, b)
+    _close(d1, G["cd_d1"], rtol=1e-4, atol=2e-6)
+    _close(d2, G["cd_d2"], rtol=1e-4, atol=2e-6)
+    (d1.mean() + 2 * d2.mean()).backward()
+    _close(a.grad, G["cd_ga"], rtol=1e-3, atol=1e-6)
+    _close(b.grad, G["cd_gb"], rtol=1e-3, atol=1e-6)
+    _close(m.comp(_t(G["comp_g"], dev), _t(G["comp_igt"], dev)), G["comp_out"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("loss_mode", [0, 1])
+def test_training_step_vs_reference(golden_loss, dev, loss_mode):
+    """Loss value and per-parameter gradients of one whole training_step against the reference's
+    own training_step run on CPU.  loss_mode 0 has no EMD term in the loss (tight); loss_mode 1
+    adds all four EMD terms, whose gradients carry the auction's conditioning (see test_gpu_emd)."""
+    from puzzlenet_amd import model5_b as mb
+    G = golden_loss
+    flags = {} if loss_mode == 0 else dict(use_emd2=True, use_cd2=True, use_emd3=True)
+    m = mb.TouchedRegraster(mr.Cfg(loss_mode=loss_mode, **flags))
+    mr.fill_params(m)
+    m.to(dev)
+    batch = [_t(G[f"ts_batch{i}"], dev) for i in range(8)]
+    torch.manual_seed(99)
+    loss = m.training_step(batch, 0)["loss"]
+    tag = f"ts{loss_mode}_"
+    np.testing.assert_allclose(loss.item(), G[tag + "loss"][0], rtol=1e-4)
+    loss.backward()
+    params = dict(m.named_parameters())
+    rt_norm, rt_s = (1e-3, 5e-3) if loss_mode == 0 else (5e-3, 2e-2)
+    for name, norm, samp in zip(G[tag + "grad_names"], G[tag + "grad_norms"], G[tag + "grad_samples"]):
+        p = params[str(name)]
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        np.testing.assert_allclose(g.norm().item(), norm, rtol=rt_norm, atol=1e-6, err_msg=str(name))
+        flat = g.flatten()
+        idx = torch.linspace(0, flat.numel() - 1, 8).long().to(dev)
+        np.testing.assert_allclose(flat[idx].cpu().numpy(), samp, rtol=rt_s,
+                                   atol=1e-5 + 2e-3 * float(norm) / max(1.0, flat.numel() ** 0.5), err_msg=str(name))
