@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — point-cloud pairs / second, forward + backward + optimizer step.
+
+A "step" = one pass of the hot path over one batch of synthetic pairs:
+predict5(training=True) -> every loss term of training_step (loss_mode 1: recovery
+chamfer + comp + EMD(NxN) + CE x2 + boundary chamfer x2, EMD x4 computed as the
+reference does) -> backward -> gradient all-reduce (N>1) -> Adam + StepLR.
+Workload = BASELINE.json configs[1]: N=2048 points, 64 pairs per GPU, fp32.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline`
+(kNN + group stage, HBM-bound; algorithmic bytes from SURVEY §8(d)) and `cpu_baseline`
+(the torch-CPU + C restatement in oracle/, kind "port", timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+class Cfg:
+    dataset = "synthetic"
+    loss_mode = 1
+    loss_sum = False
+    use_emd2 = False
+    use_cd2 = False
+    use_emd3 = False
+    pretrain_epochs = 0
+    lr = 0.9e-3
+    m = "bench"
+    output_path = "TRG"
+    num_points = 2048
+
+
+def knn_group_bytes(N, S, K, D):
+    """bytes(N,S,K,D) = 12N + 4ND + 12S + 8SK + 4SK(D+3) per cloud per call."""
+    return 12 * N + 4 * N * D + 12 * S + 8 * S * K + 4 * S * K * (D + 3)
+
+
+def cpu_baseline(N, pairs, iters):
+    """The reference's algorithm on the host cores: oracle/model_ref.py (torch CPU ops in the
+    reference's own sequence) + the C EMD restatement.  Bounded sample of the same workload."""
+    from oracle import model_ref as mr
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = mr.Cfg(num_points=N, loss_mode=1)
+    model = mr.RefModel(cfg)
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.lr)
+    g = torch.Generator().manual_seed(1234)
+    fpc, rpc = torch.rand(pairs, N, 3, generator=g), torch.rand(pairs, N, 3, generator=g)
+    x = torch.randn(pairs, 6, generator=g)
+    igt = mr.se3_exp(0.8 * x / x.norm(dim=1, keepdim=True))
+    mrpc = mr.se3_transform(igt, rpc.permute(0, 2, 1)).permute(0, 2, 1).contiguous()
+    cd1, cd2 = mr.chamfer_loss(fpc, rpc)
+    r_top, f_top = torch.topk(-cd1, 128, dim=1)[1], torch.topk(-cd2, 128, dim=1)[1]
+    rpcb = torch.gather(rpc, 1, r_top.unsqueeze(-1).repeat(1, 1, 3))
+    fpcb = torch.gather(fpc, 1, f_top.unsqueeze(-1).repeat(1, 1, 3))
+    fi = torch.zeros(pairs, N).scatter_(1, f_top, 1.0)
+    ri = torch.zeros(pairs, N).scatter_(1, r_top, 1.0)
+    batch = [fpc, mrpc, igt, rpc, fpcb, rpcb, fi, ri]
+
+    def step():
+        opt.zero_grad()
+        loss = model.training_step(batch)
+        loss.backward()
+        opt.step()
+
+    step()                                   # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = time.perf_counter() - t0
+    return {
+        "value": pairs * iters / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{pairs} pairs, N={N}, 1 warm-up + {iters} timed fwd+bwd+Adam steps of oracle/model_ref.py "
+                  f"(torch CPU ops on {torch.get_num_threads()} threads; EMD = single-thread C restatement)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="pairs per GPU")
+    ap.add_argument("--points", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=4)
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    args = ap.parse_args()
+
+    from puzzlenet_amd import distributed as pdist
+    rank, world, local = pdist.init_from_env()
+    if world != args.gpus and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from puzzlenet_amd import _lib, model5_b, ops, synthetic
+    _lib.check(_lib.load().pzn_device_check(), "pzn_device_check")      # fail loudly off-gfx950
+
+    cfg = Cfg()
+    cfg.num_points = args.points
+    torch.manual_seed(0)
+    model = model5_b.TouchedRegraster(cfg).to(dev)
+    pdist.broadcast_parameters(model)
+    grads = pdist.FlatGradAllReduce(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.lr)
+    sched = torch.optim.lr_scheduler.StepLR(opt, 50, 0.999)              # model5_b.py:1453-1457
+    B, N = args.batch, args.points
+    batch = synthetic.make_batch(B, N, dev, seed=1234 + rank)           # inputs resident in HBM before timing
+    torch.manual_seed(1000 + rank)                                        # FPS start indices (pointnet_util.py:65)
+
+    def step():
+        grads.zero_()
+        loss = model.training_step(batch, 0)["loss"]
+        loss.backward()
+        grads.all_reduce_mean()
+        opt.step()
+        sched.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ops.KernelTimer.start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    kern = ops.KernelTimer.stop()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        # roofline of the kNN + group stage: 2 clouds x (sg1 + sg2) per pair per step
+        per_pair = 2 * (knn_group_bytes(N, 512, 32, 64) + knn_group_bytes(512, 256, 32, 128))
+        n_knn, ms_knn = kern.get("pzn_knn_f32", (0, 0.0))
+        n_grp, ms_grp = kern.get("pzn_group_fwd_f32", (0, 0.0))
+        stage_ms_per_step = (ms_knn + ms_grp) / max(1, args.steps)
+        achieved = per_pair * B / (stage_ms_per_step * 1e-3) / 1e9 if stage_ms_per_step > 0 else 0.0
+        roofline = {
+            "bound": "hbm", "kernel": "pzn_knn_f32 + pzn_group_fwd_f32 (4 launches each per step)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_step": per_pair * B,
+            "avg_launch_ms": {"pzn_knn_f32": ms_knn / max(1, n_knn), "pzn_group_fwd_f32": ms_grp / max(1, n_grp)},
+        }
+        stages = {k: {"launches_per_step": n / args.steps, "ms_per_step": ms / args.steps} for k, (n, ms) in sorted(kern.items())}
+        out = {
+            "metric": "point-cloud pairs/sec (fwd+bwd) at N=2048, B=64; FPS/kNN idx bit-exact",
+            "value": world * B * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1] shape: N={N} points, {B} pairs/GPU, fp32 train step "
+                                   f"(predict5 + loss_mode 1 losses incl. 4x EMD + backward + Adam)",
+                       "global_batch": world * B, "points": N, "parallelism": f"dp{world}"},
+            "roofline": roofline,
+            "stages": stages,
+            "loss": loss_val,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(N, args.cpu_pairs, args.cpu_iters)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

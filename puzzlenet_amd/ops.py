@@ -13,6 +13,39 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional per-entry-point device timing with HIP events recorded on the stream the
+    kernels are launched on (torch's current stream).  Off by default; bench.py turns it on
+    for the timed region to price individual kernels (roofline.achieved)."""
+    enabled = False
+    records = {}
+
+    @classmethod
+    def start(cls):
+        cls.records = {}
+        cls.enabled = True
+
+    @classmethod
+    def stop(cls):
+        """-> {entry point: (launches, total milliseconds)}; synchronises the device."""
+        cls.enabled = False
+        torch.cuda.synchronize()
+        out = {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in cls.records.items()}
+        cls.records = {}
+        return out
+
+
+def _call(name, *args):
+    if KernelTimer.enabled:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _lib.call(name, *args)
+        b.record()
+        KernelTimer.records.setdefault(name, []).append((a, b))
+    else:
+        _lib.call(name, *args)
+
+
 def _req(t, dtype, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _lib.PznError(f"{name} must be a tensor on the GPU (got {type(t).__name__}"
@@ -45,7 +78,7 @@ def square_distance(src, dst):
     N = dst.shape[1]
     out = torch.empty((B, S, N), dtype=torch.float32, device=src.device)
     with torch.cuda.device(src.device):
-        _lib.call("pzn_square_distance_f32", _p(src), _p(dst), B, S, N, _p(out), _stream())
+        _call("pzn_square_distance_f32", _p(src), _p(dst), B, S, N, _p(out), _stream())
     return out
 
 
@@ -57,7 +90,7 @@ def farthest_point_sample(xyz, npoint, start_idx):
     start_idx = _i64(start_idx, "start_idx")
     out = torch.empty((B, npoint), dtype=torch.int64, device=xyz.device)
     with torch.cuda.device(xyz.device):
-        _lib.call("pzn_fps_f32", _p(xyz), B, N, int(npoint), _p(start_idx), _p(out), _stream())
+        _call("pzn_fps_f32", _p(xyz), B, N, int(npoint), _p(start_idx), _p(out), _stream())
     return out
 
 
@@ -67,7 +100,7 @@ def knn(xyz, new_xyz, K):
     S = new_xyz.shape[1]
     out = torch.empty((B, S, K), dtype=torch.int64, device=xyz.device)
     with torch.cuda.device(xyz.device):
-        _lib.call("pzn_knn_f32", _p(xyz), _p(new_xyz), B, N, S, int(K), _p(out), _stream())
+        _call("pzn_knn_f32", _p(xyz), _p(new_xyz), B, N, S, int(K), _p(out), _stream())
     return out
 
 
@@ -79,7 +112,7 @@ def ball_query(radius, nsample, xyz, new_xyz):
     # `sqrdists > radius ** 2` is an fp32 comparison in the reference (pointnet_util.py:91)
     r2 = float(torch.tensor(float(radius) ** 2, dtype=torch.float32))
     with torch.cuda.device(xyz.device):
-        _lib.call("pzn_ball_query_f32", r2, int(nsample), _p(xyz), _p(new_xyz), B, N, S, _p(out), _stream())
+        _call("pzn_ball_query_f32", r2, int(nsample), _p(xyz), _p(new_xyz), B, N, S, _p(out), _stream())
     return out
 
 
@@ -95,7 +128,7 @@ class _Gather(torch.autograd.Function):
         M = flat.shape[1]
         out = torch.empty((B, M, C), dtype=torch.float32, device=points.device)
         with torch.cuda.device(points.device):
-            _lib.call("pzn_gather_fwd_f32", _p(points), _p(flat), B, N, M, C, _p(out), _stream())
+            _call("pzn_gather_fwd_f32", _p(points), _p(flat), B, N, M, C, _p(out), _stream())
         ctx.save_for_backward(flat)
         ctx.dims = (B, N, M, C)
         return out.reshape(*idx.shape, C)
@@ -107,7 +140,7 @@ class _Gather(torch.autograd.Function):
         grad_out = _f32(grad_out, "grad_out")
         g = torch.zeros((B, N, C), dtype=torch.float32, device=grad_out.device)
         with torch.cuda.device(grad_out.device):
-            _lib.call("pzn_gather_bwd_f32", _p(grad_out), _p(flat), B, N, M, C, _p(g), _stream())
+            _call("pzn_gather_bwd_f32", _p(grad_out), _p(flat), B, N, M, C, _p(g), _stream())
         return g, None
 
 
@@ -128,7 +161,7 @@ class _Group(torch.autograd.Function):
         out = torch.empty((B, S, K, 3 + D), dtype=torch.float32, device=xyz.device)
         gx = torch.empty((B, S, K, 3), dtype=torch.float32, device=xyz.device) if want_grouped_xyz else None
         with torch.cuda.device(xyz.device):
-            _lib.call("pzn_group_fwd_f32", _p(xyz), _p(feat_c), _p(new_xyz), _p(idx), B, N, S, K, D,
+            _call("pzn_group_fwd_f32", _p(xyz), _p(feat_c), _p(new_xyz), _p(idx), B, N, S, K, D,
                       _p(out), _p(gx), _stream())
         ctx.save_for_backward(idx)
         ctx.dims = (B, N, S, K, D)
@@ -151,7 +184,7 @@ class _Group(torch.autograd.Function):
         gfeat = torch.zeros((B, N, D), dtype=torch.float32, device=dev) if need_feat else None
         gnew = torch.empty((B, S, 3), dtype=torch.float32, device=dev) if need_new else None
         with torch.cuda.device(dev):
-            _lib.call("pzn_group_bwd_f32", _p(grad_out), _p(idx), B, N, S, K, D, _p(gxyz), _p(gfeat), _p(gnew),
+            _call("pzn_group_bwd_f32", _p(grad_out), _p(idx), B, N, S, K, D, _p(gxyz), _p(gfeat), _p(gnew),
                       _stream())
         return gxyz, gfeat, gnew, None, None
 
@@ -182,7 +215,7 @@ def emd_approxmatch(xyz1, xyz2):
     match = torch.empty((B, m, n), dtype=torch.float32, device=xyz1.device)
     ws = _emd_ws(B, n, m, xyz1.device)
     with torch.cuda.device(xyz1.device):
-        _lib.call("pzn_emd_approxmatch_f32", _p(xyz1), _p(xyz2), B, n, m, _p(match), _p(ws), _stream())
+        _call("pzn_emd_approxmatch_f32", _p(xyz1), _p(xyz2), B, n, m, _p(match), _p(ws), _stream())
     return match
 
 
@@ -192,7 +225,7 @@ def emd_matchcost(xyz1, xyz2, match):
     B, n, m = _emd_shapes(xyz1, xyz2)
     cost = torch.empty((B,), dtype=torch.float32, device=xyz1.device)
     with torch.cuda.device(xyz1.device):
-        _lib.call("pzn_emd_matchcost_f32", _p(xyz1), _p(xyz2), _p(match), B, n, m, _p(cost), _stream())
+        _call("pzn_emd_matchcost_f32", _p(xyz1), _p(xyz2), _p(match), B, n, m, _p(cost), _stream())
     return cost
 
 
@@ -204,7 +237,7 @@ def emd_matchcost_grad(grad_cost, xyz1, xyz2, match):
     g1 = torch.empty((B, n, 3), dtype=torch.float32, device=xyz1.device)
     g2 = torch.empty((B, m, 3), dtype=torch.float32, device=xyz1.device)
     with torch.cuda.device(xyz1.device):
-        _lib.call("pzn_emd_matchcost_grad_f32", _p(grad_cost), _p(xyz1), _p(xyz2), _p(match), B, n, m,
+        _call("pzn_emd_matchcost_grad_f32", _p(grad_cost), _p(xyz1), _p(xyz2), _p(match), B, n, m,
                   _p(g1), _p(g2), _stream())
     return [g1, g2]
 
@@ -222,7 +255,7 @@ class _EmdFused(torch.autograd.Function):
         g2 = torch.empty((B, m, 3), dtype=torch.float32, device=dev)
         ws = _emd_ws(B, n, m, dev)
         with torch.cuda.device(dev):
-            _lib.call("pzn_emd_fused_f32", _p(xyz1), _p(xyz2), B, n, m, _p(cost), _p(g1), _p(g2), _p(ws), _stream())
+            _call("pzn_emd_fused_f32", _p(xyz1), _p(xyz2), B, n, m, _p(cost), _p(g1), _p(g2), _p(ws), _stream())
         ctx.save_for_backward(g1, g2)
         return cost
 

