@@ -54,7 +54,9 @@ def cpu_baseline(N, pairs, iters):
     """The reference's algorithm on the host cores: oracle/model_ref.py (torch CPU ops in the
     reference's own sequence) + the C EMD restatement.  Bounded sample of the same workload."""
     from oracle import model_ref as mr
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives one job a 16-core share: more threads than that only spin
+    ncpu = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    torch.set_num_threads(max(1, ncpu))
     cfg = mr.Cfg(num_points=N, loss_mode=1)
     model = mr.RefModel(cfg)
     opt = torch.optim.Adam(model.parameters(), lr=cfg.lr)
@@ -77,7 +79,9 @@ def cpu_baseline(N, pairs, iters):
         loss.backward()
         opt.step()
 
+    t0 = time.perf_counter()
     step()                                   # warm-up
+    print(f"[bench] cpu_baseline warm-up step {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     for _ in range(iters):
         step()
@@ -138,8 +142,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        if rank == 0 and i == 0:
+            torch.cuda.synchronize()
+            print("[bench] first warm-up step done", file=sys.stderr, flush=True)
     fence()
     ops.KernelTimer.start()
     t0 = time.perf_counter()
@@ -153,6 +160,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss_val = float(loss.item())
+    if rank == 0:
+        print(f"[bench] gpu: {dt / args.steps * 1e3:.2f} ms/step, {world * args.batch * args.steps / dt:.1f} pairs/s",
+              file=sys.stderr, flush=True)
 
     if rank == 0:
         # roofline of the kNN + group stage: 2 clouds x (sg1 + sg2) per pair per step

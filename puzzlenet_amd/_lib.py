@@ -50,6 +50,10 @@ def load():
             raise PznError(
                 f"{LIB_PATH} is missing: build it with `python -m puzzlenet_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU or eager fallback.")
+        # torch ships its own libamdhip64.so.7; device pointers and streams handed to the
+        # C ABI belong to THAT runtime instance, so it must be the one libpzn.so binds to.
+        # Same SONAME => whichever copy is loaded first wins; load torch's first.
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
