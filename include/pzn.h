@@ -130,6 +130,99 @@ int pzn_emd_fused_f32(const float* xyz1, const float* xyz2, int B, int n, int m,
                       float* cost, float* g1, float* g2, void* workspace,
                       pzn_stream_t stream);
 
+/* ------------------------------------------------------------------------ */
+/* Loss tail: model5_b.py:1495-1505 chamfer_loss                            */
+/* ------------------------------------------------------------------------ */
+
+size_t pzn_chamfer_workspace_bytes(int B, int n, int m);
+/* chamfer_loss(a[B,n,3], b[B,m,3]) -> (torch.min(P,1): min over a for each b
+ * point [B,m],  torch.min(P,2): min over b for each a point [B,n]) with the
+ * reference's expansion P = |a|^2 + |b|^2 - 2 a.b, never materialising
+ * P[B,n,m].  arg-min indices (int32) are written for the backward. */
+int pzn_chamfer_fwd_f32(const float* a, const float* b, int B, int n, int m,
+                        float* min_over_a, int32_t* arg_over_a,
+                        float* min_over_b, int32_t* arg_over_b, void* workspace,
+                        pzn_stream_t stream);
+/* grad_a[B,n,3], grad_b[B,m,3] (zero-initialised by the caller) from the
+ * upstream gradients g_over_a[B,m], g_over_b[B,n] (either may be NULL). */
+int pzn_chamfer_bwd_f32(const float* a, const float* b, int B, int n, int m,
+                        const float* g_over_a, const int32_t* arg_over_a,
+                        const float* g_over_b, const int32_t* arg_over_b,
+                        float* grad_a, float* grad_b, pzn_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* Dense path on the matrix cores (exact fp32: v_mfma_f32_32x32x2_f32)      */
+/* ------------------------------------------------------------------------ */
+
+/* nn.Linear as used throughout model5_b.py (e.g. :417-422, :559-599):
+ * y[M,Nout] = act(x[M,Kin] W[Nout,Kin]^T + bias[Nout]); act = ReLU if relu.
+ * bias may be NULL. */
+int pzn_linear_fwd_f32(const float* x, const float* W, const float* bias, int M,
+                       int Kin, int Nout, int relu, float* y,
+                       pzn_stream_t stream);
+/* Same product with the epilogue of model5_b.py:453-454 / :460-461: ReLU then
+ * max over each group of 32 consecutive rows (the K=32 neighbours of one
+ * centroid): out[R,Nout], argmax[R,Nout] (row 0..31 of the maximum). */
+int pzn_linear_maxpool_fwd_f32(const float* x, const float* W, const float* bias,
+                               int R, int Kin, int Nout, float* out,
+                               int32_t* argmax, pzn_stream_t stream);
+/* dx[M,Kin] = (dy * [y_relu > 0]) W, then * [x_relu > 0].  y_relu / x_relu are
+ * the forward outputs of this / the previous layer when they ended in a ReLU,
+ * NULL otherwise. */
+int pzn_linear_dgrad_f32(const float* dy, const float* y_relu, const float* W,
+                         int M, int Kin, int Nout, const float* x_relu,
+                         float* dx, pzn_stream_t stream);
+/* dW[Nout,Kin] = (dy * [y_relu > 0])^T x,  db[Nout] = its column sums (db may
+ * be NULL).  Split over the row range, accumulated with fp32 atomics: both
+ * outputs are overwritten; results are reproducible to rounding, not bitwise. */
+int pzn_linear_wgrad_f32(const float* dy, const float* y_relu, const float* x,
+                         int M, int Kin, int Nout, float* dW, float* db,
+                         pzn_stream_t stream);
+/* Backward through the max-pool epilogue: the [R*32,Nout] gradient
+ * dy[g*32+k, c] = (argmax[g,c]==k && out[g,c]>0) ? dout[g,c] : 0 is generated
+ * inside the operand loader, never materialised. */
+int pzn_linear_maxpool_dgrad_f32(const float* dout, const int32_t* argmax,
+                                 const float* out, const float* W, int R, int Kin,
+                                 int Nout, const float* x_relu, float* dx,
+                                 pzn_stream_t stream);
+int pzn_linear_maxpool_wgrad_f32(const float* dout, const int32_t* argmax,
+                                 const float* out, const float* x, int R, int Kin,
+                                 int Nout, float* dW, float* db,
+                                 pzn_stream_t stream);
+/* Batched C[b] = alpha op(A[b]) op(B[b]), dense row-major.
+ * mode 0 "NT": A[M,K] B[N,K];  1 "NN": A[M,K] B[K,N];  2 "TN": A[K,M] B[K,N]. */
+int pzn_bgemm_f32(int mode, const float* A, const float* B, float* C, int batch,
+                  int M, int N, int K, float alpha, pzn_stream_t stream);
+
+/* Shared MLP + max over the K=32 neighbours, model5_b.py:452-454 / :459-461:
+ *   h = relu(x[R*32,C0] W1^T + b1)  (kept: the backward reads it);
+ *   out[R,C2] = max_k relu(h W2^T + b2),  argmax[R,C2]. */
+int pzn_sharedmlp_max_fwd_f32(const float* x, const float* W1, const float* b1,
+                              const float* W2, const float* b2, int R, int C0,
+                              int C1, int C2, float* h, float* out,
+                              int32_t* argmax, pzn_stream_t stream);
+/* dh_ws: [R*32,C1] scratch.  dx[R*32,C0] may be NULL.  dW1,db1,dW2,db2 are
+ * overwritten. */
+int pzn_sharedmlp_max_bwd_f32(const float* x, const float* W1, const float* W2,
+                              const float* h, const float* out,
+                              const int32_t* argmax, const float* dout, int R,
+                              int C0, int C1, int C2, float* dh_ws, float* dx,
+                              float* dW1, float* db1, float* dW2, float* db2,
+                              pzn_stream_t stream);
+
+/* scaled_dot_production of layerAttention, model5_b.py:67-75:
+ * attn[B,L,L] = softmax(q[B,L,dk] k[B,L,dk]^T / sqrt(dk)), out[B,L,dv] = attn v.
+ * attn is an output because the reference returns it (model5_b.py:97,101). */
+int pzn_attn_fwd_f32(const float* q, const float* k, const float* v, int B,
+                     int L, int dk, int dv, float* attn, float* out,
+                     pzn_stream_t stream);
+size_t pzn_attn_bwd_workspace_bytes(int B, int L, int dk, int dv);
+/* dq, dk_out, dv_out from d_out[B,L,dv] and d_attn[B,L,L] (may be NULL). */
+int pzn_attn_bwd_f32(const float* q, const float* k, const float* v,
+                     const float* attn, const float* d_out, const float* d_attn,
+                     int B, int L, int dk, int dv, float* dq, float* dk_out,
+                     float* dv_out, void* workspace, pzn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

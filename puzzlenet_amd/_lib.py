@@ -33,6 +33,21 @@ SIGNATURES = {
     "pzn_emd_matchcost_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_emd_matchcost_grad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_emd_fused_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f]),
+    "pzn_chamfer_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),
+    "pzn_chamfer_fwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f]),
+    "pzn_linear_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),
+    "pzn_linear_maxpool_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_linear_dgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_linear_wgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_linear_maxpool_dgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_linear_maxpool_wgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_bgemm_f32": (_c_i, [_c_i, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_fl, _c_f]),
+    "pzn_sharedmlp_max_fwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 4 + [_c_f] * 4),
+    "pzn_sharedmlp_max_bwd_f32": (_c_i, [_c_f] * 7 + [_c_i] * 4 + [_c_f] * 7),
+    "pzn_attn_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_attn_bwd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i]),
+    "pzn_attn_bwd_f32": (_c_i, [_c_f] * 6 + [_c_i] * 4 + [_c_f] * 5),
+    "pzn_chamfer_bwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f]),
 }
 
 _lib = None

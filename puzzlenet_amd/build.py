@@ -23,6 +23,8 @@ SOURCES = [
     ("knn.hip", ["-ffp-contract=off"]),
     ("group.hip", ["-ffp-contract=off"]),
     ("emd.hip", []),
+    ("chamfer.hip", []),
+    ("gemm.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]

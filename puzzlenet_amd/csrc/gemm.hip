@@ -1,0 +1,547 @@
+// gemm.hip — exact-fp32 dense engine on the matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Everything dense in model5_b.py funnels through ONE tile engine:
+//   * nn.Linear (+bias, +ReLU) forward              (model5_b.py:417-422, 559-599)   "NT"
+//   * shared MLP second layer with max-over-K=32    (model5_b.py:452-454, 459-461)   "NT" + max-pool epilogue
+//   * input gradients  dX = dY W                    "NN"
+//   * weight gradients dW = dY^T X, db = sum dY     "TN", split over the row range, fp32 atomics
+//   * attention products q k^T, attn v, and their backward (model5_b.py:67-75), batched.
+//
+// gfx950 has an f32-input MFMA whose result is bit-for-bit an fp32 fma chain (no TF32-like
+// truncation), at 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak.  That keeps the 1e-4 parity bar
+// reachable with plain fp32 semantics.
+//
+// Tile engine (256 threads = 4 wavefronts):
+//   block tile BM x BN (128x128 or 128x64), K-step 16, double-buffered LDS.
+//   LDS images are K-MAJOR for both operands (As[k][m], Bs[k][n]) so a fragment read for
+//   v_mfma_f32_32x32x2 (lane l: A[m = l&31][k = l>>5], B[k = l>>5][n = l&31]) is 32
+//   consecutive dwords per half-wave: conflict-free ds_read_b32.  Operands that are
+//   k-contiguous in HBM are transposed on the way in (float4 global load, 4 ds_write_b32);
+//   operands that are m/n-contiguous go in with ds_write_b128.
+//   Each wave owns a (BM/WM) x (BN/WN) sub-tile = TM x TN MFMA tiles of 32x32, accumulators
+//   in registers.  The 32 rows of one MFMA tile are exactly one (centroid, K=32 neighbours)
+//   group, so max-over-K is a register epilogue: 15 v_max per lane + one cross-half exchange.
+//   One barrier per K-step: next tile's global loads are issued before the MFMAs of the
+//   current one and written to the other LDS buffer after them.
+//
+// "Generators" synthesise the A operand on the fly so that sparse / masked gradients are
+// never materialised:  dY * (Y > 0)  (ReLU backward)  and the max-pool scatter
+// dy[g*32 + k, c] = (argmax[g,c] == k && out[g,c] > 0) ? dOut[g,c] : 0.
+#include "pzn_common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+constexpr int GT = 256;  // threads per block
+constexpr int PAD = 4;
+
+enum { GEN_NONE = 0, GEN_RELU = 1, GEN_MAXPOOL = 2 };
+enum { EPI_STORE = 0, EPI_MAXPOOL = 1, EPI_ATOMIC = 2 };
+
+struct GemmArgs {
+  // logical problem: C[M,N] = sum_k A(m,k) B(k,n)
+  int M, N, K;
+  const float* A;  // A_KC: A[m*lda + k]   else: A[k*lda + m]
+  int lda;
+  const float* B;  // B_KC: B[n*ldb + k]   else: B[k*ldb + n]
+  int ldb;
+  float* C;
+  int ldc;
+  long sA, sB, sC;  // batch strides (elements); batch index = blockIdx.z when splits == 1
+  int splits;       // > 1: blockIdx.z splits the K range, epilogue accumulates atomically
+  int k_chunk;      // K elements per split (multiple of BK)
+  // A generator (the "dY" matrix has rows r, columns c;  A_KC: (r,c) = (m,k)   else (r,c) = (k,m))
+  int gen;
+  const float* genY;        // GEN_RELU: same layout as A
+  const int32_t* genArg;    // GEN_MAXPOOL: argmax[r/32][c], ld = lda
+  const float* genOut;      // GEN_MAXPOOL: out[r/32][c]; A points at dOut[r/32][c]
+  // B extras
+  int b_ones_col;           // !B_KC only: column n == N-1 of B is all ones (bias gradient)
+  // epilogue
+  const float* bias;        // per column n (or NULL)
+  int relu;
+  float alpha;
+  const float* maskH;       // multiply C by (maskH[m*ldc + n] > 0)
+  int32_t* argmax;          // EPI_MAXPOOL: C is out[M/32][N], argmax[M/32][N]
+  float* bias_grad;         // EPI_ATOMIC with b_ones_col: column N-1 goes here instead of C
+};
+
+// ---- operand loaders ---------------------------------------------------------------------
+// Each fetch() pulls this thread's share of a BR x BK tile (BR = BM or BN) into registers,
+// store() puts it into the k-major LDS image.
+
+template <int BR, bool KC>
+struct Loader {
+  static constexpr int NV = BR * BK / 4 / GT;  // float4 per thread
+  float4 v[NV];
+
+  // (row index in the R dimension, k index) -> value, fully guarded scalar path
+  __device__ __forceinline__ static float fetch1(const GemmArgs& p, bool isA, const float* base, int ld, int R,
+                                                 int rr, int Kend, int kk) {
+    if (rr >= R || kk >= Kend) return 0.f;
+    if (isA && p.gen == GEN_MAXPOOL) {
+      // dY rows r, cols c:  A_KC: r = rr (m), c = kk   else r = kk, c = rr
+      long r = KC ? rr : kk;
+      int c = KC ? kk : rr;
+      long g = r >> 5;
+      long off = g * ld + c;
+      float o = p.genOut[off];
+      return (p.genArg[off] == (int)(r & 31) && o > 0.f) ? base[off] : 0.f;
+    }
+    if (!isA && p.b_ones_col && rr == R - 1) return 1.f;
+    long off = KC ? (long)rr * ld + kk : (long)kk * ld + rr;
+    float x = base[off];
+    if (isA && p.gen == GEN_RELU) x = p.genY[off] > 0.f ? x : 0.f;
+    return x;
+  }
+
+  __device__ __forceinline__ void fetch(const GemmArgs& p, bool isA, const float* base, int ld, int R, int r0,
+                                        int k0, int Kend, bool vec_ok, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int f = tid + i * GT;
+      int rr, kk;
+      if (KC) {  // float4 along k
+        rr = r0 + f / (BK / 4);
+        kk = k0 + (f % (BK / 4)) * 4;
+      } else {  // float4 along the row dimension
+        kk = k0 + f / (BR / 4);
+        rr = r0 + (f % (BR / 4)) * 4;
+      }
+      bool full = KC ? (rr < R && kk + 3 < Kend) : (kk < Kend && rr + 3 < R - ((!isA && p.b_ones_col) ? 1 : 0));
+      if (vec_ok && full) {
+        if (isA && p.gen == GEN_MAXPOOL) {
+          long r = KC ? rr : kk;
+          int c = KC ? kk : rr;
+          long off = (r >> 5) * ld + c;
+          float4 d = *reinterpret_cast<const float4*>(base + off);
+          float4 o = *reinterpret_cast<const float4*>(p.genOut + off);
+          int4 a = *reinterpret_cast<const int4*>(p.genArg + off);
+          int rl = (int)(r & 31);
+          if (KC) {  // the 4 elements share the row r
+            v[i] = make_float4((a.x == rl && o.x > 0.f) ? d.x : 0.f, (a.y == rl && o.y > 0.f) ? d.y : 0.f,
+                               (a.z == rl && o.z > 0.f) ? d.z : 0.f, (a.w == rl && o.w > 0.f) ? d.w : 0.f);
+          } else {  // also the same row r (k index), 4 consecutive columns
+            v[i] = make_float4((a.x == rl && o.x > 0.f) ? d.x : 0.f, (a.y == rl && o.y > 0.f) ? d.y : 0.f,
+                               (a.z == rl && o.z > 0.f) ? d.z : 0.f, (a.w == rl && o.w > 0.f) ? d.w : 0.f);
+          }
+        } else {
+          long off = KC ? (long)rr * ld + kk : (long)kk * ld + rr;
+          float4 d = *reinterpret_cast<const float4*>(base + off);
+          if (isA && p.gen == GEN_RELU) {
+            float4 y = *reinterpret_cast<const float4*>(p.genY + off);
+            d.x = y.x > 0.f ? d.x : 0.f;
+            d.y = y.y > 0.f ? d.y : 0.f;
+            d.z = y.z > 0.f ? d.z : 0.f;
+            d.w = y.w > 0.f ? d.w : 0.f;
+          }
+          v[i] = d;
+        }
+      } else {
+        float t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          t[c] = KC ? fetch1(p, isA, base, ld, R, rr, Kend, kk + c) : fetch1(p, isA, base, ld, R, rr + c, Kend, kk);
+        v[i] = make_float4(t[0], t[1], t[2], t[3]);
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(float (*S)[BR + PAD], int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int f = tid + i * GT;
+      if (KC) {
+        int r = f / (BK / 4), k = (f % (BK / 4)) * 4;
+        S[k + 0][r] = v[i].x;
+        S[k + 1][r] = v[i].y;
+        S[k + 2][r] = v[i].z;
+        S[k + 3][r] = v[i].w;
+      } else {
+        int k = f / (BR / 4), r = (f % (BR / 4)) * 4;
+        *reinterpret_cast<float4*>(&S[k][r]) = v[i];
+      }
+    }
+  }
+};
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(WM * WN == GT / PZN_WAVE, "4 waves");
+  __shared__ __attribute__((aligned(16))) float As[2][BK][BM + PAD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PAD];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  const float* A = p.A;
+  const float* B = p.B;
+  float* C = p.C;
+  int kbeg = 0, kend = p.K;
+  if (p.splits > 1) {
+    kbeg = blockIdx.z * p.k_chunk;
+    kend = min(p.K, kbeg + p.k_chunk);
+    if (kbeg >= kend) return;
+  } else {
+    A += (long)blockIdx.z * p.sA;
+    B += (long)blockIdx.z * p.sB;
+    C += (long)blockIdx.z * p.sC;
+  }
+  const bool a_vec = (p.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+                     (p.gen != GEN_RELU || (reinterpret_cast<uintptr_t>(p.genY) & 15) == 0) &&
+                     (p.gen != GEN_MAXPOOL || ((reinterpret_cast<uintptr_t>(p.genOut) & 15) == 0 &&
+                                               (reinterpret_cast<uintptr_t>(p.genArg) & 15) == 0));
+  const bool b_vec = (p.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Loader<BM, A_KC> la;
+  Loader<BN, B_KC> lb;
+  la.fetch(p, true, A, p.lda, p.M, m0, kbeg, kend, a_vec, tid);
+  lb.fetch(p, false, B, p.ldb, p.N, n0, kbeg, kend, b_vec, tid);
+  la.store(As[0], tid);
+  lb.store(Bs[0], tid);
+  __syncthreads();
+
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+  const int half = lane >> 5, l31 = lane & 31;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) {
+      la.fetch(p, true, A, p.lda, p.M, m0, kbeg + (kt + 1) * BK, kend, a_vec, tid);
+      lb.fetch(p, false, B, p.ldb, p.N, n0, kbeg + (kt + 1) * BK, kend, b_vec, tid);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[cur][kk + half][wm * (BM / WM) + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[cur][kk + half][wn * (BN / WN) + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) {
+      la.store(As[cur ^ 1], tid);
+      lb.store(Bs[cur ^ 1], tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----  C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (BN / WN) + j * 32 + l31;
+      const int rbase = m0 + wm * (BM / WM) + i * 32;
+      const bool col_ok = col < p.N;
+      const float bv = (p.bias && col_ok) ? p.bias[col] : 0.f;
+      if (EPI == EPI_MAXPOOL) {
+        float best = -INFINITY;
+        int bi = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = acc[i][j][r] * p.alpha + bv;
+          v = v > 0.f ? v : 0.f;  // ReLU before the max (model5_b.py:453-454)
+          bool gt = v > best;
+          best = gt ? v : best;
+          bi = gt ? rl : bi;
+        }
+        float ob = __shfl_xor(best, 32, PZN_WAVE);
+        int oi = __shfl_xor(bi, 32, PZN_WAVE);
+        bool take = ob > best || (ob == best && oi < bi);
+        best = take ? ob : best;
+        bi = take ? oi : bi;
+        if (half == 0 && col_ok && rbase < p.M) {
+          long g = rbase >> 5;
+          C[g * p.ldc + col] = best;
+          p.argmax[g * p.ldc + col] = bi;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = rbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row < p.M && col_ok) {
+            float v = acc[i][j][r] * p.alpha;
+            if (EPI == EPI_ATOMIC) {
+              if (p.bias_grad && col == p.N - 1)
+                atomicAdd(p.bias_grad + row, v);
+              else
+                atomicAdd(C + (long)row * p.ldc + col, v);
+            } else {
+              v += bv;
+              if (p.relu) v = v > 0.f ? v : 0.f;
+              if (p.maskH) v = p.maskH[(long)row * p.ldc + col] > 0.f ? v : 0.f;
+              C[(long)row * p.ldc + col] = v;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI>
+void launch_cfg(const GemmArgs& p, int batch, hipStream_t st) {
+  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splits > 1 ? p.splits : batch);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI>), grid, dim3(GT), 0, st, p);
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+void launch(const GemmArgs& p, int batch, hipStream_t st) {
+  if (p.N > 64)
+    launch_cfg<128, 128, 2, 2, A_KC, B_KC, EPI>(p, batch, st);
+  else
+    launch_cfg<128, 64, 4, 1, A_KC, B_KC, EPI>(p, batch, st);
+}
+
+GemmArgs base_args(int M, int N, int K) {
+  GemmArgs p = {};
+  p.M = M;
+  p.N = N;
+  p.K = K;
+  p.splits = 1;
+  p.alpha = 1.f;
+  return p;
+}
+
+// split the reduction range of a weight-gradient GEMM so that the grid fills the chip
+void choose_splits(GemmArgs& p) {
+  long tiles = (long)((p.N + 127) / 128) * ((p.M + 127) / 128);
+  long want = 1024 / (tiles > 0 ? tiles : 1);
+  long ksteps = (p.K + BK - 1) / BK;
+  long splits = want < 1 ? 1 : want;
+  if (splits > ksteps / 4) splits = ksteps / 4;  // at least 4 K-steps per split
+  if (splits < 1) splits = 1;
+  if (splits > 65535) splits = 65535;
+  long per = (ksteps + splits - 1) / splits;
+  p.k_chunk = (int)(per * BK);
+  p.splits = (int)((p.K + p.k_chunk - 1) / p.k_chunk);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------- C ABI ----
+
+PZN_EXPORT int pzn_linear_fwd_f32(const float* x, const float* W, const float* bias, int M, int Kin, int Nout, int relu,
+                                  float* y, pzn_stream_t stream) {
+  PZN_CHECK_ARG(x && W && y && M > 0 && Kin > 0 && Nout > 0);
+  GemmArgs p = base_args(M, Nout, Kin);
+  p.A = x, p.lda = Kin, p.B = W, p.ldb = Kin, p.C = y, p.ldc = Nout, p.bias = bias, p.relu = relu;
+  launch<true, true, EPI_STORE>(p, 1, pzn_hip_stream(stream));
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+PZN_EXPORT int pzn_linear_maxpool_fwd_f32(const float* x, const float* W, const float* bias, int R, int Kin, int Nout,
+                                          float* out, int32_t* argmax, pzn_stream_t stream) {
+  PZN_CHECK_ARG(x && W && out && argmax && R > 0 && Kin > 0 && Nout > 0);
+  GemmArgs p = base_args(R * 32, Nout, Kin);
+  p.A = x, p.lda = Kin, p.B = W, p.ldb = Kin, p.C = out, p.ldc = Nout, p.bias = bias, p.relu = 1, p.argmax = argmax;
+  launch<true, true, EPI_MAXPOOL>(p, 1, pzn_hip_stream(stream));
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+PZN_EXPORT int pzn_linear_dgrad_f32(const float* dy, const float* y_relu, const float* W, int M, int Kin, int Nout,
+                                    const float* x_relu, float* dx, pzn_stream_t stream) {
+  PZN_CHECK_ARG(dy && W && dx && M > 0 && Kin > 0 && Nout > 0);
+  GemmArgs p = base_args(M, Kin, Nout);
+  p.A = dy, p.lda = Nout, p.B = W, p.ldb = Kin, p.C = dx, p.ldc = Kin;
+  if (y_relu) p.gen = GEN_RELU, p.genY = y_relu;
+  p.maskH = x_relu;
+  launch<true, false, EPI_STORE>(p, 1, pzn_hip_stream(stream));
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+PZN_EXPORT int pzn_linear_maxpool_dgrad_f32(const float* dout, const int32_t* argmax, const float* out, const float* W,
+                                            int R, int Kin, int Nout, const float* x_relu, float* dx,
+                                            pzn_stream_t stream) {
+  PZN_CHECK_ARG(dout && argmax && out && W && dx && R > 0 && Kin > 0 && Nout > 0);
+  GemmArgs p = base_args(R * 32, Kin, Nout);
+  p.A = dout, p.lda = Nout, p.B = W, p.ldb = Kin, p.C = dx, p.ldc = Kin;
+  p.gen = GEN_MAXPOOL, p.genArg = argmax, p.genOut = out;
+  p.maskH = x_relu;
+  launch<true, false, EPI_STORE>(p, 1, pzn_hip_stream(stream));
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+// dW[Nout,Kin] = dY^T X, db[Nout] = column sums of dY (ones-column trick): both overwritten.
+static int wgrad_common(GemmArgs p, int Kin, int Nout, const float* x, float* dW, float* db, hipStream_t st) {
+  // logical C[Nout, Kin(+1)] = sum_r dY[r][n] * X[r][k]
+  p.B = x, p.ldb = Kin, p.C = dW, p.ldc = Kin;
+  if (db) {
+    p.N = Kin + 1;
+    p.b_ones_col = 1;
+    p.bias_grad = db;
+    if (hipMemsetAsync(db, 0, sizeof(float) * (size_t)Nout, st) != hipSuccess) return PZN_ELAUNCH;
+  }
+  if (hipMemsetAsync(dW, 0, sizeof(float) * (size_t)Nout * Kin, st) != hipSuccess) return PZN_ELAUNCH;
+  choose_splits(p);
+  if (p.splits == 1) p.splits = 2, p.k_chunk = ((p.K + 2 * BK - 1) / (2 * BK)) * BK;  // keep the atomic epilogue path
+  launch<false, false, EPI_ATOMIC>(p, 1, st);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+PZN_EXPORT int pzn_linear_wgrad_f32(const float* dy, const float* y_relu, const float* x, int M, int Kin, int Nout,
+                                    float* dW, float* db, pzn_stream_t stream) {
+  PZN_CHECK_ARG(dy && x && dW && M > 0 && Kin > 0 && Nout > 0);
+  GemmArgs p = base_args(Nout, Kin, M);
+  p.A = dy, p.lda = Nout;
+  if (y_relu) p.gen = GEN_RELU, p.genY = y_relu;
+  return wgrad_common(p, Kin, Nout, x, dW, db, pzn_hip_stream(stream));
+}
+
+PZN_EXPORT int pzn_linear_maxpool_wgrad_f32(const float* dout, const int32_t* argmax, const float* out, const float* x,
+                                            int R, int Kin, int Nout, float* dW, float* db, pzn_stream_t stream) {
+  PZN_CHECK_ARG(dout && argmax && out && x && dW && R > 0 && Kin > 0 && Nout > 0);
+  GemmArgs p = base_args(Nout, Kin, R * 32);
+  p.A = dout, p.lda = Nout, p.gen = GEN_MAXPOOL, p.genArg = argmax, p.genOut = out;
+  return wgrad_common(p, Kin, Nout, x, dW, db, pzn_hip_stream(stream));
+}
+
+// Batched C[b] = alpha * op(A[b]) op(B[b]);  mode 0 = "NT": A[M,K] B[N,K];  1 = "NN": A[M,K] B[K,N];
+// 2 = "TN": A[K,M] B[K,N].  Row-major, dense (leading dimension = row length).
+PZN_EXPORT int pzn_bgemm_f32(int mode, const float* A, const float* B, float* C, int batch, int M, int N, int K,
+                             float alpha, pzn_stream_t stream) {
+  PZN_CHECK_ARG(A && B && C && batch > 0 && batch <= 65535 && M > 0 && N > 0 && K > 0 && mode >= 0 && mode <= 2);
+  GemmArgs p = base_args(M, N, K);
+  p.A = A, p.B = B, p.C = C, p.ldc = N, p.alpha = alpha;
+  p.sA = (long)M * K, p.sB = (long)N * K, p.sC = (long)M * N;
+  hipStream_t st = pzn_hip_stream(stream);
+  if (mode == 0) {
+    p.lda = K, p.ldb = K;
+    launch<true, true, EPI_STORE>(p, batch, st);
+  } else if (mode == 1) {
+    p.lda = K, p.ldb = N;
+    launch<true, false, EPI_STORE>(p, batch, st);
+  } else {
+    p.lda = M, p.ldb = N;
+    launch<false, false, EPI_STORE>(p, batch, st);
+  }
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+// ------------------------------------------------------------------ softmax rows (attention) --
+namespace {
+
+// One wavefront per row.  fwd: io[r,:] = softmax(io[r,:] / div)   (model5_b.py:70,73)
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ io, long rows, int cols, float div) {
+  const int lane = threadIdx.x & 63;
+  long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float* x = io + r * cols;
+  float m = -INFINITY;
+  for (int c = lane; c < cols; c += 64) m = fmaxf(m, x[c] / div);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) {
+    float e = expf(x[c] / div - m);
+    x[c] = e;
+    s += e;
+  }
+  s = pzn::wave_sum_f32(s);
+  for (int c = lane; c < cols; c += 64) x[c] = x[c] / s;
+}
+
+// bwd: io[r,:] (= dAttn, optionally + extra) -> dLogits = attn * (dAttn - sum(dAttn * attn)) / div
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ attn, float* __restrict__ io,
+                                                          const float* __restrict__ extra, long rows, int cols,
+                                                          float div) {
+  const int lane = threadIdx.x & 63;
+  long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* a = attn + r * cols;
+  float* d = io + r * cols;
+  const float* e = extra ? extra + r * cols : nullptr;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) {
+    float g = d[c] + (e ? e[c] : 0.f);
+    d[c] = g;
+    s += g * a[c];
+  }
+  s = pzn::wave_sum_f32(s);
+  for (int c = lane; c < cols; c += 64) d[c] = a[c] * (d[c] - s) / div;
+}
+
+}  // namespace
+
+// scaled_dot_production (model5_b.py:67-75): attn[B,L,L] = softmax(q k^T / sqrt(dk)), out[B,L,dv] = attn v
+PZN_EXPORT int pzn_attn_fwd_f32(const float* q, const float* k, const float* v, int B, int L, int dk, int dv,
+                                float* attn, float* out, pzn_stream_t stream) {
+  PZN_CHECK_ARG(q && k && v && attn && out && B > 0 && L > 0 && dk > 0 && dv > 0);
+  int rc = pzn_bgemm_f32(0, q, k, attn, B, L, L, dk, 1.f, stream);
+  if (rc != PZN_OK) return rc;
+  long rows = (long)B * L;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, pzn_hip_stream(stream), attn,
+                     rows, L, sqrtf((float)dk));
+  if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
+  return pzn_bgemm_f32(1, attn, v, out, B, L, dv, L, 1.f, stream);
+}
+
+PZN_EXPORT size_t pzn_attn_bwd_workspace_bytes(int B, int L, int dk, int dv) {
+  (void)dk;
+  (void)dv;
+  return B > 0 && L > 0 ? sizeof(float) * (size_t)B * L * L : 0;
+}
+
+// dq, dk_out, dv_out from d_out[B,L,dv] and (optional) d_attn[B,L,L]
+PZN_EXPORT int pzn_attn_bwd_f32(const float* q, const float* k, const float* v, const float* attn, const float* d_out,
+                                const float* d_attn, int B, int L, int dk, int dv, float* dq, float* dk_out,
+                                float* dv_out, void* workspace, pzn_stream_t stream) {
+  PZN_CHECK_ARG(q && k && v && attn && d_out && dq && dk_out && dv_out && workspace && B > 0 && L > 0 && dk > 0 &&
+                dv > 0);
+  float* ds = static_cast<float*>(workspace);
+  int rc = pzn_bgemm_f32(2, attn, d_out, dv_out, B, L, dv, L, 1.f, stream);  // dV = attn^T dO
+  if (rc != PZN_OK) return rc;
+  rc = pzn_bgemm_f32(0, d_out, v, ds, B, L, L, dv, 1.f, stream);  // dAttn = dO V^T
+  if (rc != PZN_OK) return rc;
+  long rows = (long)B * L;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, pzn_hip_stream(stream), attn,
+                     ds, d_attn, rows, L, sqrtf((float)dk));
+  if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
+  rc = pzn_bgemm_f32(1, ds, k, dq, B, L, dk, L, 1.f, stream);  // dQ = dS K
+  if (rc != PZN_OK) return rc;
+  return pzn_bgemm_f32(2, ds, q, dk_out, B, L, dk, L, 1.f, stream);  // dK = dS^T Q
+}
+
+// Shared MLP + max over the K = 32 neighbours (model5_b.py:452-454 / 459-461):
+//   h = relu(x W1^T + b1) [R*32, C1] (kept for the backward);  out[R,C2] = max_k relu(h W2^T + b2), argmax
+PZN_EXPORT int pzn_sharedmlp_max_fwd_f32(const float* x, const float* W1, const float* b1, const float* W2,
+                                         const float* b2, int R, int C0, int C1, int C2, float* h, float* out,
+                                         int32_t* argmax, pzn_stream_t stream) {
+  PZN_CHECK_ARG(h);
+  int rc = pzn_linear_fwd_f32(x, W1, b1, R * 32, C0, C1, 1, h, stream);
+  if (rc != PZN_OK) return rc;
+  return pzn_linear_maxpool_fwd_f32(h, W2, b2, R, C1, C2, out, argmax, stream);
+}
+
+// Backward: dh_ws is [R*32, C1] scratch; dx may be NULL.  dW*, db* are overwritten.
+PZN_EXPORT int pzn_sharedmlp_max_bwd_f32(const float* x, const float* W1, const float* W2, const float* h,
+                                         const float* out, const int32_t* argmax, const float* dout, int R, int C0,
+                                         int C1, int C2, float* dh_ws, float* dx, float* dW1, float* db1, float* dW2,
+                                         float* db2, pzn_stream_t stream) {
+  PZN_CHECK_ARG(x && W1 && W2 && h && out && argmax && dout && dh_ws && dW1 && db1 && dW2 && db2);
+  int rc = pzn_linear_maxpool_dgrad_f32(dout, argmax, out, W2, R, C1, C2, h, dh_ws, stream);  // dh, ReLU-masked by h
+  if (rc != PZN_OK) return rc;
+  rc = pzn_linear_maxpool_wgrad_f32(dout, argmax, out, h, R, C1, C2, dW2, db2, stream);
+  if (rc != PZN_OK) return rc;
+  rc = pzn_linear_wgrad_f32(dh_ws, nullptr, x, R * 32, C0, C1, dW1, db1, stream);
+  if (rc != PZN_OK) return rc;
+  if (dx) rc = pzn_linear_dgrad_f32(dh_ws, nullptr, W1, R * 32, C0, C1, nullptr, dx, stream);
+  return rc;
+}

@@ -1,47 +1,30 @@
-"""Dense pieces of the encoder / heads / loss tail.
+"""Dense pieces of the encoder / heads / loss tail: the functional forms the model calls.
 
-linear / shared_mlp_max / attention / chamfer are the functional forms the
-model calls.  STATUS (round 1, first end-to-end slice): these four are still
-composed from torch GPU ops (rocBLAS GEMMs, elementwise kernels); the
-hand-written MFMA kernels replace them one by one behind the same signatures.
+All four run as hand-written gfx950 kernels behind the C ABI (include/pzn.h):
+  linear          nn.Linear (+bias +ReLU) fwd / dgrad / wgrad       exact-fp32 MFMA tile engine (csrc/gemm.hip)
+  shared_mlp_max  two shared-MLP layers + max over the K=32 axis    same engine, max-pool as a register epilogue
+  attention       softmax(q k^T / sqrt(dk)) v, returns the map too  batched engine + wave-per-row softmax
+  chamfer         min-both-ways of |a|^2+|b|^2-2ab without P[B,n,m] csrc/chamfer.hip
 """
-import math
-
-import torch
-import torch.nn.functional as F
+from . import ops
 
 
 def linear(x, weight, bias=None, relu=False):
     """nn.Linear (+ optional ReLU): y = act(x W^T + b)."""
-    y = F.linear(x, weight, bias)
-    return F.relu(y) if relu else y
+    return ops.linear(x, weight, bias, relu)
 
 
 def shared_mlp_max(x, w1, b1, w2, b2):
     """model5_b.py:452-454 / :459-461: relu(mlp_a) -> relu(mlp_b) -> max over the K axis.
-    x [B,S,K,C0] -> [B,S,C2]."""
-    h = F.relu(F.linear(x, w1, b1))
-    y = F.relu(F.linear(h, w2, b2))
-    return torch.max(y, dim=-2)[0]
+    x [B,S,K=32,C0] -> [B,S,C2]."""
+    return ops.shared_mlp_max(x, w1, b1, w2, b2)
 
 
 def attention(q, k, v):
     """model5_b.py:67-75 scaled_dot_production -> (values, attention)."""
-    dk = q.size()[-1]
-    logits = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(dk)
-    attn = F.softmax(logits, dim=-1)
-    return torch.matmul(attn, v), attn
+    return ops.attention(q, k, v)
 
 
 def chamfer(a, b):
-    """model5_b.py:1495-1505 chamfer_loss (expansion form, P materialised)."""
-    x, y = a, b
-    bs, numpoints, pc_dim = x.size()
-    xx = torch.bmm(x, x.transpose(2, 1))
-    yy = torch.bmm(y, y.transpose(2, 1))
-    zz = torch.bmm(x, y.transpose(2, 1))
-    diag_ind = torch.arange(0, numpoints, device=x.device)
-    rx = xx[:, diag_ind, diag_ind].unsqueeze(1).expand_as(xx)
-    ry = yy[:, diag_ind, diag_ind].unsqueeze(1).expand_as(yy)
-    P = (rx.transpose(2, 1) + ry - 2 * zz)
-    return torch.min(P, 1)[0], torch.min(P, 2)[0]
+    """model5_b.py:1495-1505 chamfer_loss: fused kernel, P[B,n,m] never materialised."""
+    return ops.chamfer(a, b)

@@ -268,3 +268,175 @@ class _EmdFused(torch.autograd.Function):
 
 def emd_fused(xyz1, xyz2):
     return _EmdFused.apply(xyz1, xyz2)
+
+
+# --------------------------------------------------------------------------- chamfer
+
+class _Chamfer(torch.autograd.Function):
+    """TouchedRegraster.chamfer_loss (model5_b.py:1495-1505) without P[B,n,m]."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f32(a, "a"), _f32(b, "b")
+        if a.dim() != 3 or b.dim() != 3 or a.shape[2] != 3 or b.shape[2] != 3 or a.shape[0] != b.shape[0]:
+            raise _lib.PznError(f"chamfer expects a[B,n,3], b[B,m,3]; got {tuple(a.shape)}, {tuple(b.shape)}")
+        B, n, m = a.shape[0], a.shape[1], b.shape[1]
+        dev = a.device
+        moa = torch.empty((B, m), dtype=torch.float32, device=dev)
+        mob = torch.empty((B, n), dtype=torch.float32, device=dev)
+        aoa = torch.empty((B, m), dtype=torch.int32, device=dev)
+        aob = torch.empty((B, n), dtype=torch.int32, device=dev)
+        ws = torch.empty((_lib.load().pzn_chamfer_workspace_bytes(B, n, m) + 3) // 4, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _call("pzn_chamfer_fwd_f32", _p(a), _p(b), B, n, m, _p(moa), _p(aoa), _p(mob), _p(aob), _p(ws), _stream())
+        ctx.save_for_backward(a, b, aoa, aob)
+        ctx.mark_non_differentiable(aoa, aob)
+        return moa, mob, aoa, aob
+
+    @staticmethod
+    def backward(ctx, g_moa, g_mob, _ga, _gb):
+        a, b, aoa, aob = ctx.saved_tensors
+        B, n, m = a.shape[0], a.shape[1], b.shape[1]
+        g_moa = None if g_moa is None else _f32(g_moa, "g_over_a")
+        g_mob = None if g_mob is None else _f32(g_mob, "g_over_b")
+        ga = torch.zeros_like(a)
+        gb = torch.zeros_like(b)
+        with torch.cuda.device(a.device):
+            _call("pzn_chamfer_bwd_f32", _p(a), _p(b), B, n, m, _p(g_moa), _p(aoa), _p(g_mob), _p(aob),
+                  _p(ga), _p(gb), _stream())
+        return ga, gb
+
+
+def chamfer(a, b):
+    """-> (min over a per b-point [B,m], min over b per a-point [B,n])  == torch.min(P,1)[0], torch.min(P,2)[0]."""
+    moa, mob, _, _ = _Chamfer.apply(a, b)
+    return moa, mob
+
+
+# --------------------------------------------------------------------------- dense (MFMA fp32)
+
+class _Linear(torch.autograd.Function):
+    """nn.Linear (+ReLU) on the fp32 matrix-core engine: y = act(x W^T + b)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x = _f32(x, "x")
+        weight = _f32(weight, "weight")
+        bias_c = None if bias is None else _f32(bias, "bias")
+        Kin = x.shape[-1]
+        Nout = weight.shape[0]
+        if weight.shape[1] != Kin:
+            raise _lib.PznError(f"linear: x[..., {Kin}] vs weight{tuple(weight.shape)}")
+        x2 = x.reshape(-1, Kin)
+        M = x2.shape[0]
+        y = torch.empty((M, Nout), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _call("pzn_linear_fwd_f32", _p(x2), _p(weight), _p(bias_c), M, Kin, Nout, int(bool(relu)), _p(y), _stream())
+        ctx.save_for_backward(x2, weight, y if relu else None)
+        ctx.has_bias = bias is not None
+        ctx.in_shape = x.shape
+        return y.reshape(*x.shape[:-1], Nout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, y = ctx.saved_tensors
+        M, Kin = x2.shape
+        Nout = weight.shape[0]
+        dy = _f32(dy, "dy").reshape(M, Nout)
+        dev = dy.device
+        dx = dW = db = None
+        with torch.cuda.device(dev):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty((M, Kin), dtype=torch.float32, device=dev)
+                _call("pzn_linear_dgrad_f32", _p(dy), _p(y), _p(weight), M, Kin, Nout, None, _p(dx), _stream())
+                dx = dx.reshape(ctx.in_shape)
+            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+                dW = torch.empty((Nout, Kin), dtype=torch.float32, device=dev)
+                db = torch.empty((Nout,), dtype=torch.float32, device=dev) if ctx.has_bias else None
+                _call("pzn_linear_wgrad_f32", _p(dy), _p(y), _p(x2), M, Kin, Nout, _p(dW), _p(db), _stream())
+        return dx, dW, db, None
+
+
+def linear(x, weight, bias=None, relu=False):
+    return _Linear.apply(x, weight, bias, relu)
+
+
+class _SharedMlpMax(torch.autograd.Function):
+    """relu(x W1^T + b1) -> relu(. W2^T + b2) -> max over the K=32 axis (model5_b.py:452-454, 459-461)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x = _f32(x, "x")
+        w1, b1, w2, b2 = _f32(w1, "w1"), _f32(b1, "b1"), _f32(w2, "w2"), _f32(b2, "b2")
+        Bq, S, K, C0 = x.shape
+        if K != 32:
+            raise _lib.PznError(f"shared_mlp_max: the fused epilogue pools over K=32 neighbours, got K={K}")
+        C1, C2 = w1.shape[0], w2.shape[0]
+        R = Bq * S
+        dev = x.device
+        h = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
+        out = torch.empty((R, C2), dtype=torch.float32, device=dev)
+        arg = torch.empty((R, C2), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _call("pzn_sharedmlp_max_fwd_f32", _p(x), _p(w1), _p(b1), _p(w2), _p(b2), R, C0, C1, C2,
+                  _p(h), _p(out), _p(arg), _stream())
+        ctx.save_for_backward(x, w1, w2, h, out, arg)
+        ctx.dims = (Bq, S, R, C0, C1, C2)
+        return out.reshape(Bq, S, C2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w1, w2, h, out, arg = ctx.saved_tensors
+        Bq, S, R, C0, C1, C2 = ctx.dims
+        dout = _f32(dout, "dout").reshape(R, C2)
+        dev = dout.device
+        dh = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
+        dx = torch.empty((R * 32, C0), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dW1 = torch.empty_like(w1)
+        db1 = torch.empty((C1,), dtype=torch.float32, device=dev)
+        dW2 = torch.empty_like(w2)
+        db2 = torch.empty((C2,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _call("pzn_sharedmlp_max_bwd_f32", _p(x), _p(w1), _p(w2), _p(h), _p(out), _p(arg), _p(dout),
+                  R, C0, C1, C2, _p(dh), _p(dx), _p(dW1), _p(db1), _p(dW2), _p(db2), _stream())
+        return (None if dx is None else dx.reshape(Bq, S, 32, C0)), dW1, db1, dW2, db2
+
+
+def shared_mlp_max(x, w1, b1, w2, b2):
+    return _SharedMlpMax.apply(x, w1, b1, w2, b2)
+
+
+class _Attention(torch.autograd.Function):
+    """scaled_dot_production (model5_b.py:67-75) -> (values, attention)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        q, k, v = _f32(q, "q"), _f32(k, "k"), _f32(v, "v")
+        B, L, dk = q.shape
+        dv = v.shape[-1]
+        dev = q.device
+        attn = torch.empty((B, L, L), dtype=torch.float32, device=dev)
+        out = torch.empty((B, L, dv), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _call("pzn_attn_fwd_f32", _p(q), _p(k), _p(v), B, L, dk, dv, _p(attn), _p(out), _stream())
+        ctx.save_for_backward(q, k, v, attn)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, d_out, d_attn):
+        q, k, v, attn = ctx.saved_tensors
+        B, L, dk = q.shape
+        dv = v.shape[-1]
+        dev = q.device
+        d_out = torch.zeros((B, L, dv), dtype=torch.float32, device=dev) if d_out is None else _f32(d_out, "d_out")
+        d_attn = None if d_attn is None else _f32(d_attn, "d_attn")
+        dq, dk_, dv_ = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ws = torch.empty((B, L, L), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _call("pzn_attn_bwd_f32", _p(q), _p(k), _p(v), _p(attn), _p(d_out), _p(d_attn), B, L, dk, dv,
+                  _p(dq), _p(dk_), _p(dv_), _p(ws), _stream())
+        return dq, dk_, dv_
+
+
+def attention(q, k, v):
+    return _Attention.apply(q, k, v)

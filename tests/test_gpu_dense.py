@@ -1,0 +1,150 @@
+"""GPU parity of the dense engine (csrc/gemm.hip, chamfer.hip) against plain fp32/fp64 torch
+restatements of the same ops evaluated on CPU.  Tolerance 1e-4 relative unless noted
+(the f32-input MFMA is an exact fp32 fma chain; differences are summation order only)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("M,K,N,relu,bias", [
+    (4096, 64, 128, True, True), (1000, 67, 128, True, True), (777, 131, 256, False, True),
+    (64, 2048, 1024, True, True), (64, 256, 6, False, True), (5000, 3, 64, False, True),
+    (300, 32, 2, False, True), (256, 1280, 1024, False, False), (129, 128, 64, True, True), (1, 64, 64, False, True)])
+def test_linear_fwd_bwd(dev, M, K, N, relu, bias):
+    from puzzlenet_amd import ops
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) if bias else None
+    go = torch.randn(M, N, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if bias else None
+    yr = F.linear(xr, wr, br)
+    yr = F.relu(yr) if relu else yr
+    (yr * go.double()).sum().backward()
+    xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True) if bias else None
+    y = ops.linear(xd, wd, bd, relu)
+    assert _rel(y, yr) < 1e-5
+    (y * go.to(dev)).sum().backward()
+    assert _rel(xd.grad, xr.grad) < 1e-5
+    assert _rel(wd.grad, wr.grad) < 1e-4
+    if bias:
+        assert _rel(bd.grad, br.grad) < 1e-4
+
+
+def test_linear_nd_input_and_no_grad_paths(dev):
+    from puzzlenet_amd import ops
+    x = torch.randn(3, 5, 7, 16, device=dev)
+    w = torch.randn(8, 16, device=dev, requires_grad=True)
+    y = ops.linear(x, w, None, False)
+    assert y.shape == (3, 5, 7, 8)
+    assert _rel(y, F.linear(x.cpu(), w.detach().cpu())) < 1e-5
+    y.sum().backward()
+    assert w.grad.shape == (8, 16)
+
+
+@pytest.mark.parametrize("B,S,C0,C1,C2", [(2, 64, 67, 128, 128), (2, 40, 131, 256, 256), (1, 5, 20, 32, 48)])
+def test_shared_mlp_max(dev, B, S, C0, C1, C2):
+    from puzzlenet_amd import ops
+    g = torch.Generator().manual_seed(C0)
+    x = torch.randn(B, S, 32, C0, generator=g)
+    w1, b1 = torch.randn(C1, C0, generator=g) / math.sqrt(C0), 0.1 * torch.randn(C1, generator=g)
+    w2, b2 = torch.randn(C2, C1, generator=g) / math.sqrt(C1), 0.1 * torch.randn(C2, generator=g)
+    go = torch.randn(B, S, C2, generator=g)
+    ref = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    yr = torch.max(F.relu(F.linear(F.relu(F.linear(ref[0], ref[1], ref[2])), ref[3], ref[4])), dim=-2)[0]
+    (yr * go.double()).sum().backward()
+    d = [t.to(dev).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    y = ops.shared_mlp_max(*d)
+    assert y.shape == (B, S, C2)
+    assert _rel(y, yr) < 1e-5
+    (y * go.to(dev)).sum().backward()
+    for a, r, name in zip(d, ref, ("x", "w1", "b1", "w2", "b2")):
+        assert _rel(a.grad, r.grad) < 1e-4, name
+
+
+@pytest.mark.parametrize("B,L,dk,dv", [(3, 256, 64, 256), (2, 100, 16, 40), (1, 33, 8, 8)])
+def test_attention(dev, B, L, dk, dv):
+    from puzzlenet_amd import ops
+    g = torch.Generator().manual_seed(L)
+    q, k, v = torch.randn(B, L, dk, generator=g), torch.randn(B, L, dk, generator=g), torch.randn(B, L, dv, generator=g)
+    go, ga = torch.randn(B, L, dv, generator=g), torch.randn(B, L, L, generator=g)
+    ref = [t.double().requires_grad_(True) for t in (q, k, v)]
+    attn_r = F.softmax(ref[0] @ ref[1].transpose(-2, -1) / math.sqrt(dk), dim=-1)
+    out_r = attn_r @ ref[2]
+    ((out_r * go.double()).sum() + (attn_r * ga.double()).sum()).backward()
+    d = [t.to(dev).requires_grad_(True) for t in (q, k, v)]
+    out, attn = ops.attention(*d)
+    assert _rel(out, out_r) < 1e-5 and _rel(attn, attn_r) < 1e-5
+    ((out * go.to(dev)).sum() + (attn * ga.to(dev)).sum()).backward()
+    for a, r, name in zip(d, ref, "qkv"):
+        assert _rel(a.grad, r.grad) < 1e-4, name
+    # values only (the model's case: the attention map feeds no differentiable op)
+    d2 = [t.to(dev).requires_grad_(True) for t in (q, k, v)]
+    (ops.attention(*d2)[0] * go.to(dev)).sum().backward()
+    assert d2[0].grad is not None
+
+
+@pytest.mark.parametrize("B,n,m", [(3, 200, 200), (2, 128, 128), (2, 300, 77), (4, 2048, 2048), (1, 64, 64)])
+def test_chamfer_vs_oracle(dev, B, n, m):
+    from oracle import point_ops as orc
+    from puzzlenet_amd import ops
+    rng = np.random.default_rng(n + m)
+    a = rng.random((B, n, 3), dtype=np.float32)
+    b = rng.random((B, m, 3), dtype=np.float32)
+    moa, aoa, mob, aob = orc.chamfer(a, b)
+    ta, tb = torch.from_numpy(a).to(dev).requires_grad_(True), torch.from_numpy(b).to(dev).requires_grad_(True)
+    d1, d2 = ops.chamfer(ta, tb)
+    # expansion form: absolute error ~ eps * |p|^2, compare absolutely
+    np.testing.assert_allclose(d1.detach().cpu().numpy(), moa, rtol=1e-4, atol=3e-6)
+    np.testing.assert_allclose(d2.detach().cpu().numpy(), mob, rtol=1e-4, atol=3e-6)
+    w1 = torch.from_numpy(rng.standard_normal((B, m)).astype(np.float32)).to(dev)
+    w2 = torch.from_numpy(rng.standard_normal((B, n)).astype(np.float32)).to(dev)
+    ((d1 * w1).sum() + (d2 * w2).sum()).backward()
+    # analytic gradient at the oracle's arg-mins
+    ga = np.zeros_like(a, dtype=np.float64)
+    gb = np.zeros_like(b, dtype=np.float64)
+    w1n, w2n = w1.cpu().numpy().astype(np.float64), w2.cpu().numpy().astype(np.float64)
+    for bb in range(B):
+        for j in range(m):
+            i = aoa[bb, j]
+            dlt = 2 * w1n[bb, j] * (a[bb, i].astype(np.float64) - b[bb, j])
+            ga[bb, i] += dlt
+            gb[bb, j] -= dlt
+        for i in range(n):
+            j = aob[bb, i]
+            dlt = 2 * w2n[bb, i] * (a[bb, i].astype(np.float64) - b[bb, j])
+            ga[bb, i] += dlt
+            gb[bb, j] -= dlt
+    # a near-tie may pick another partner: compare in L2
+    assert np.linalg.norm(ta.grad.cpu().numpy() - ga) / np.linalg.norm(ga) < 2e-3
+    assert np.linalg.norm(tb.grad.cpu().numpy() - gb) / np.linalg.norm(gb) < 2e-3
+
+
+def test_chamfer_identity_and_symmetry(dev):
+    from puzzlenet_amd import ops
+    a = torch.rand(2, 512, 3, device=dev)
+    b = torch.rand(2, 512, 3, device=dev)
+    d1, d2 = ops.chamfer(a, a)
+    assert float(d1.abs().max()) < 1e-5 and float(d2.abs().max()) < 1e-5
+    x1, x2 = ops.chamfer(a, b)
+    y1, y2 = ops.chamfer(b, a)
+    assert torch.equal(x1, y2) and torch.equal(x2, y1)         # both passes see bit-identical P
