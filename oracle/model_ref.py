@@ -217,7 +217,7 @@ class RefModel(nn.Module):
         de_mrpcb = self.MLPRpcb(torch.cat([gf, lm], dim=-1)).permute(0, 2, 1)
         return out, [0], ff[1], ff[2], fm[1], fm[2], de_fpcb, de_mrpcb
 
-    def training_step(self, batch):
+    def training_step(self, batch, return_terms=False):
         fpc, mrpc, igt, rpc, fpcb, rpcb, fpc_idx, rpc_idx = batch
         C = self.C
         N = fpc.shape[1]
@@ -253,23 +253,32 @@ class RefModel(nn.Module):
         loss = loss + (b1.mean() + b2.mean()) + (a1.mean() + a2.mean())
         if C.use_emd3:
             loss = loss + e1 + e2
+        if return_terms:
+            return loss, {"train/loss_re": loss_re, "train/loss_g": loss_g, "train/loss_emd": loss_emd,
+                          "train/cd2": loss_cd2, "train_emd2": emd2, "train/loss_fpcb": a1.mean() + a2.mean(),
+                          "train/loss_rpcb": b1.mean() + b2.mean(), "train/loss_emd_fpcb": e1,
+                          "train/loss_emc_mrpcb": e2, "fi": fi, "mi": mi, "out": out,
+                          "de_fpcb": de_fpcb, "de_mrpcb": de_mrpcb}
         return loss
 
 
 def fill_params(module):
-    """The closed-form fill the golden generator used (tests/golden/make_golden_model.py)."""
+    """Closed-form pseudo-random parameter fill (no RNG state, no state-dict file): parameters in
+    sorted-name order; element i of the k-th tensor is u = frac(sin(12.9898 i + 78.233 (k+1)) * 43758.5453)
+    in (-1, 1), evaluated in float64 (a 1-ulp libm difference moves u by ~4e-12).  Weights are scaled to
+    uniform(-sqrt(3/fan_in), sqrt(3/fan_in)); BatchNorm weights 1 + 0.1u; biases 0.1u."""
     with torch.no_grad():
         for k, (name, p) in enumerate(sorted(module.named_parameters())):
             if name.endswith("dt"):
                 continue
-            i = torch.arange(p.numel(), dtype=torch.float64)
-            base = torch.cos(0.37 * i + 1.3 * k)
+            i = np.arange(p.numel(), dtype=np.float64)
+            u = torch.from_numpy(np.modf(np.sin(i * 12.9898 + (k + 1) * 78.233) * 43758.5453)[0])
             if p.dim() == 2:
-                v = base / math.sqrt(p.shape[1])
+                v = u * math.sqrt(3.0 / p.shape[1])
             elif "bn" in name and name.endswith("weight"):
-                v = 1.0 + 0.1 * base
+                v = 1.0 + 0.1 * u
             else:
-                v = 0.1 * base
+                v = 0.1 * u
             p.copy_(v.reshape(p.shape).to(p.dtype))
 
 

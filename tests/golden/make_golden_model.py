@@ -73,22 +73,22 @@ def import_reference_model():
 
 
 def fill_params(module):
-    """Closed-form, architecture-independent parameter fill (no RNG, no state-dict file):
-    parameters in sorted-name order, k-th tensor gets a*cos(0.37*i + 1.3*k)."""
+    """Closed-form pseudo-random parameter fill (no RNG state, no state-dict file): parameters in
+    sorted-name order; element i of the k-th tensor is u = frac(sin(12.9898 i + 78.233 (k+1)) * 43758.5453)
+    in (-1, 1), evaluated in float64 (a 1-ulp libm difference moves u by ~4e-12).  Weights are scaled to
+    uniform(-sqrt(3/fan_in), sqrt(3/fan_in)); BatchNorm weights 1 + 0.1u; biases 0.1u."""
     with torch.no_grad():
         for k, (name, p) in enumerate(sorted(module.named_parameters())):
-            n = p.numel()
-            i = torch.arange(n, dtype=torch.float64)
-            base = torch.cos(0.37 * i + 1.3 * k)
             if name.endswith("dt"):
                 continue
+            i = np.arange(p.numel(), dtype=np.float64)
+            u = torch.from_numpy(np.modf(np.sin(i * 12.9898 + (k + 1) * 78.233) * 43758.5453)[0])
             if p.dim() == 2:
-                a = 1.0 / math.sqrt(p.shape[1])
-                v = a * base
+                v = u * math.sqrt(3.0 / p.shape[1])
             elif "bn" in name and name.endswith("weight"):
-                v = 1.0 + 0.1 * base
+                v = 1.0 + 0.1 * u
             else:
-                v = 0.1 * base
+                v = 0.1 * u
             p.copy_(v.reshape(p.shape).to(p.dtype))
 
 
@@ -249,6 +249,27 @@ def make_loss():
         return _OracleEMD.apply(x1, x2)
 
     mb.earth_mover_distance = oracle_emd
+
+    # The boundary branch picks the 128 most probable points with torch.topk (model5_b.py:1089-1091);
+    # a pair of near-equal probabilities at rank 128/129 would make the fixture depend on rounding
+    # noise.  Take the first batch seed whose rank-128 gap is comfortably above fp32 noise.
+    def _gap(seed):
+        cfg = Cfg()
+        model = mb.TouchedRegraster(cfg)
+        fill_params(model)
+        b_ = synth_batch(np.random.default_rng(seed), 4, 1024)
+        torch.manual_seed(99)
+        with torch.no_grad():
+            o = model.predict5(b_, 4, need=True, training=True)
+        g_ = []
+        for lg in (o[6], o[7]):
+            s_ = torch.sort(torch.softmax(lg, dim=1)[:, 1, :], dim=1, descending=True)[0]
+            g_.append((s_[:, 127] - s_[:, 128]).min().item())
+        return min(g_)
+
+    ts_seed = next(sd for sd in range(4242, 4342) if _gap(sd) > 1e-5)
+    G["ts_seed"] = np.array([ts_seed], np.int64)
+    print("training-step batch seed", ts_seed)
     from make_golden_model import synth_batch as _sb  # same function (module name when run via make_golden.py)
     for loss_mode, flags in ((0, {}), (1, dict(use_emd2=True, use_cd2=True, use_emd3=True))):
         cfg = Cfg()
@@ -260,8 +281,7 @@ def make_loss():
         model.configure_optimizers()                       # creates self.scheduler (read at model5_b.py:978)
         model.vis = lambda *a_, **k_: None                 # TensorBoard meshes (host-side logging only)
         model.vis_attention = lambda *a_, **k_: None
-        brng = np.random.default_rng(4242)
-        batch = _sb(brng, 4, 1024)
+        batch = _sb(np.random.default_rng(ts_seed), 4, 1024)
         torch.manual_seed(99)
         model.zero_grad()
         loss = model.training_step(batch, 0)["loss"]
