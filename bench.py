@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU")
     ap.add_argument("--points", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="EXPERIMENTAL: replay the step as one HIP graph (see DESIGN.md: small memset nodes misreplay on this ROCm)")
     ap.add_argument("--cpu-pairs", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=2)
     args = ap.parse_args()
@@ -112,7 +114,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from puzzlenet_amd import _lib, model5_b, ops, synthetic
+    from puzzlenet_amd import _lib, engine, model5_b, ops, synthetic
     _lib.check(_lib.load().pzn_device_check(), "pzn_device_check")      # fail loudly off-gfx950
 
     cfg = Cfg()
@@ -120,21 +122,14 @@ def main():
     torch.manual_seed(0)
     model = model5_b.TouchedRegraster(cfg).to(dev)
     pdist.broadcast_parameters(model)
-    grads = pdist.FlatGradAllReduce(model.parameters())
-    opt = torch.optim.Adam(model.parameters(), lr=cfg.lr)
-    sched = torch.optim.lr_scheduler.StepLR(opt, 50, 0.999)              # model5_b.py:1453-1457
     B, N = args.batch, args.points
     batch = synthetic.make_batch(B, N, dev, seed=1234 + rank)           # inputs resident in HBM before timing
     torch.manual_seed(1000 + rank)                                        # FPS start indices (pointnet_util.py:65)
 
-    def step():
-        grads.zero_()
-        loss = model.training_step(batch, 0)["loss"]
-        loss.backward()
-        grads.all_reduce_mean()
-        opt.step()
-        sched.step()
-        return loss
+    use_graph = bool(args.graph)
+    runner = engine.TrainStep(model, batch, cfg.lr, world=world, use_graph=use_graph, warmup=max(1, args.warmup))
+    if rank == 0:
+        print(f"[bench] runner ready (hip graph: {use_graph})", file=sys.stderr, flush=True)
 
     def fence():
         torch.cuda.synchronize()
@@ -143,33 +138,41 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        step()
-        if rank == 0 and i == 0:
-            torch.cuda.synchronize()
-            print("[bench] first warm-up step done", file=sys.stderr, flush=True)
+        runner.step()
     fence()
-    ops.KernelTimer.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = runner.step()
     fence()
     dt = time.perf_counter() - t0
-    kern = ops.KernelTimer.stop()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss_val = float(loss.item())
+    runner.close()
     if rank == 0:
         print(f"[bench] gpu: {dt / args.steps * 1e3:.2f} ms/step, {world * args.batch * args.steps / dt:.1f} pairs/s",
               file=sys.stderr, flush=True)
+    # Per-kernel pricing (roofline.achieved, stages): the same step, same shapes, same stream, with a HIP
+    # event pair around every C-ABI launch.  Creating ~500 event pairs per step costs host time, so this
+    # instrumented pass runs right after the timed region instead of inside it (3 steps).
+    kern, prof_steps = {}, 3
+    if rank == 0:
+        eager = engine.TrainStep(model, batch, cfg.lr, world=1, use_graph=False)
+        eager.step()
+        torch.cuda.synchronize()
+        ops.KernelTimer.start()
+        for _ in range(prof_steps):
+            eager.step()
+        kern = ops.KernelTimer.stop()
 
     if rank == 0:
         # roofline of the kNN + group stage: 2 clouds x (sg1 + sg2) per pair per step
         per_pair = 2 * (knn_group_bytes(N, 512, 32, 64) + knn_group_bytes(512, 256, 32, 128))
         n_knn, ms_knn = kern.get("pzn_knn_f32", (0, 0.0))
         n_grp, ms_grp = kern.get("pzn_group_fwd_f32", (0, 0.0))
-        stage_ms_per_step = (ms_knn + ms_grp) / max(1, args.steps)
+        stage_ms_per_step = (ms_knn + ms_grp) / max(1, prof_steps)
         achieved = per_pair * B / (stage_ms_per_step * 1e-3) / 1e9 if stage_ms_per_step > 0 else 0.0
         roofline = {
             "bound": "hbm", "kernel": "pzn_knn_f32 + pzn_group_fwd_f32 (4 launches each per step)",
@@ -178,7 +181,7 @@ def main():
             "algorithmic_bytes_per_step": per_pair * B,
             "avg_launch_ms": {"pzn_knn_f32": ms_knn / max(1, n_knn), "pzn_group_fwd_f32": ms_grp / max(1, n_grp)},
         }
-        stages = {k: {"launches_per_step": n / args.steps, "ms_per_step": ms / args.steps} for k, (n, ms) in sorted(kern.items())}
+        stages = {k: {"launches_per_step": n / prof_steps, "ms_per_step": ms / prof_steps} for k, (n, ms) in sorted(kern.items())}
         out = {
             "metric": "point-cloud pairs/sec (fwd+bwd) at N=2048, B=64; FPS/kNN idx bit-exact",
             "value": world * B * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
@@ -186,7 +189,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1] shape: N={N} points, {B} pairs/GPU, fp32 train step "
                                    f"(predict5 + loss_mode 1 losses incl. 4x EMD + backward + Adam)",
-                       "global_batch": world * B, "points": N, "parallelism": f"dp{world}"},
+                       "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "hip_graph": use_graph},
             "roofline": roofline,
             "stages": stages,
             "loss": loss_val,

@@ -300,11 +300,11 @@ int run_levels(const float* xyz1, const float* xyz2, int B, int n, int m, float*
   const int mx = n > m ? n : m;
   dim3 gi((mx + EMD_T - 1) / EMD_T, B), gk((n + EMD_T - 1) / EMD_T, B), gl((m + EMD_T - 1) / EMD_T, B);
   hipLaunchKernelGGL(emd_init_kernel, gi, dim3(EMD_T), 0, st, xyz1, xyz2, n, m, multiL, multiR, w);
-  if (MATCH && hipMemsetAsync(match, 0, sizeof(float) * (size_t)B * n * m, st) != hipSuccess) return PZN_ELAUNCH;  // :39-40
+  if (MATCH && pzn_zero_async(match, (size_t)B * n * m, st) != PZN_OK) return PZN_ELAUNCH;  // :39-40
   if (FUSED) {
-    if (hipMemsetAsync(cost, 0, sizeof(float) * (size_t)B, st) != hipSuccess) return PZN_ELAUNCH;
-    if (hipMemsetAsync(g1, 0, sizeof(float) * (size_t)B * n * 3, st) != hipSuccess) return PZN_ELAUNCH;
-    if (hipMemsetAsync(g2, 0, sizeof(float) * (size_t)B * m * 3, st) != hipSuccess) return PZN_ELAUNCH;
+    if (pzn_zero_async(cost, (size_t)B, st) != PZN_OK) return PZN_ELAUNCH;
+    if (pzn_zero_async(g1, (size_t)B * n * 3, st) != PZN_OK) return PZN_ELAUNCH;
+    if (pzn_zero_async(g2, (size_t)B * m * 3, st) != PZN_OK) return PZN_ELAUNCH;
   }
   for (int j = 7; j >= -2; --j) {                                // :46
     float level = j == -2 ? 0.f : -powf(4.0f, (float)j);         // :47-50
@@ -343,7 +343,7 @@ PZN_EXPORT int pzn_emd_matchcost_f32(const float* xyz1, const float* xyz2, const
                                      float* cost, pzn_stream_t stream) {
   PZN_CHECK_ARG(xyz1 && xyz2 && match && cost && B > 0 && n > 0 && m > 0 && B <= 65535);
   hipStream_t st = pzn_hip_stream(stream);
-  if (hipMemsetAsync(cost, 0, sizeof(float) * (size_t)B, st) != hipSuccess) return PZN_ELAUNCH;
+  if (pzn_zero_async(cost, (size_t)B, st) != PZN_OK) return PZN_ELAUNCH;
   dim3 grid((n + EMD_T - 1) / EMD_T, (m + MC_LSLAB - 1) / MC_LSLAB, B);
   PZN_CHECK_ARG(grid.y <= 65535);
   hipLaunchKernelGGL(emd_matchcost_kernel, grid, dim3(EMD_T), 0, st, xyz1, xyz2, match, n, m, cost);

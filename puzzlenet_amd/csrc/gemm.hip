@@ -57,15 +57,14 @@ struct GemmArgs {
   const float* genY;        // GEN_RELU: same layout as A
   const int32_t* genArg;    // GEN_MAXPOOL: argmax[r/32][c], ld = lda
   const float* genOut;      // GEN_MAXPOOL: out[r/32][c]; A points at dOut[r/32][c]
-  // B extras
-  int b_ones_col;           // !B_KC only: column n == N-1 of B is all ones (bias gradient)
   // epilogue
   const float* bias;        // per column n (or NULL)
   int relu;
   float alpha;
   const float* maskH;       // multiply C by (maskH[m*ldc + n] > 0)
   int32_t* argmax;          // EPI_MAXPOOL: C is out[M/32][N], argmax[M/32][N]
-  float* bias_grad;         // EPI_ATOMIC with b_ones_col: column N-1 goes here instead of C
+  float* bias_grad;         // "TN" (A k-major) only: bias_grad[m] += sum_k A(m,k), taken from the A tiles as
+                            // they stream through the loader of the blockIdx.x == 0 column of workgroups
 };
 
 // ---- operand loaders ---------------------------------------------------------------------
@@ -90,7 +89,6 @@ struct Loader {
       float o = p.genOut[off];
       return (p.genArg[off] == (int)(r & 31) && o > 0.f) ? base[off] : 0.f;
     }
-    if (!isA && p.b_ones_col && rr == R - 1) return 1.f;
     long off = KC ? (long)rr * ld + kk : (long)kk * ld + rr;
     float x = base[off];
     if (isA && p.gen == GEN_RELU) x = p.genY[off] > 0.f ? x : 0.f;
@@ -110,7 +108,7 @@ struct Loader {
         kk = k0 + f / (BR / 4);
         rr = r0 + (f % (BR / 4)) * 4;
       }
-      bool full = KC ? (rr < R && kk + 3 < Kend) : (kk < Kend && rr + 3 < R - ((!isA && p.b_ones_col) ? 1 : 0));
+      bool full = KC ? (rr < R && kk + 3 < Kend) : (kk < Kend && rr + 3 < R);
       if (vec_ok && full) {
         if (isA && p.gen == GEN_MAXPOOL) {
           long r = KC ? rr : kk;
@@ -146,6 +144,17 @@ struct Loader {
           t[c] = KC ? fetch1(p, isA, base, ld, R, rr, Kend, kk + c) : fetch1(p, isA, base, ld, R, rr + c, Kend, kk);
         v[i] = make_float4(t[0], t[1], t[2], t[3]);
       }
+    }
+  }
+
+  // sum of this thread's float4s (k-major loaders only: every float4 of a thread covers the same 4 rows)
+  __device__ __forceinline__ void accumulate(float4& acc) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      acc.x += v[i].x;
+      acc.y += v[i].y;
+      acc.z += v[i].z;
+      acc.w += v[i].w;
     }
   }
 
@@ -208,8 +217,12 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
 
   Loader<BM, A_KC> la;
   Loader<BN, B_KC> lb;
+  // bias gradient: this thread's A float4s always cover the same 4 output rows (m-quad tid % (BM/4))
+  const bool do_bias = !A_KC && p.bias_grad != nullptr && blockIdx.x == 0;
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   la.fetch(p, true, A, p.lda, p.M, m0, kbeg, kend, a_vec, tid);
   lb.fetch(p, false, B, p.ldb, p.N, n0, kbeg, kend, b_vec, tid);
+  if (do_bias) la.accumulate(bsum);
   la.store(As[0], tid);
   lb.store(Bs[0], tid);
   __syncthreads();
@@ -235,10 +248,30 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nkt) {
+      if (do_bias) la.accumulate(bsum);
       la.store(As[cur ^ 1], tid);
       lb.store(Bs[cur ^ 1], tid);
     }
     __syncthreads();
+  }
+  if (p.bias_grad != nullptr && !A_KC && blockIdx.x == 0) {  // (uniform over the workgroup)
+    // 8 threads (lane, lane+32 in each of the 4 waves) hold partial sums of the same 4 rows:
+    // fold them on chip so that the contended atomics are 128 per workgroup, not 1024.
+    bsum.x += __shfl_xor(bsum.x, 32, PZN_WAVE);
+    bsum.y += __shfl_xor(bsum.y, 32, PZN_WAVE);
+    bsum.z += __shfl_xor(bsum.z, 32, PZN_WAVE);
+    bsum.w += __shfl_xor(bsum.w, 32, PZN_WAVE);
+    float4* red = reinterpret_cast<float4*>(&As[0][0][0]);  // the K loop is over: LDS is free (last barrier passed)
+    if (half == 0) red[wave * 32 + l31] = bsum;
+    __syncthreads();
+    if (wave == 0 && half == 0) {
+      float4 a = red[l31], b = red[32 + l31], c = red[64 + l31], d = red[96 + l31];
+      int r = m0 + l31 * 4;
+      if (r + 0 < p.M) atomicAdd(p.bias_grad + r + 0, (a.x + b.x) + (c.x + d.x));
+      if (r + 1 < p.M) atomicAdd(p.bias_grad + r + 1, (a.y + b.y) + (c.y + d.y));
+      if (r + 2 < p.M) atomicAdd(p.bias_grad + r + 2, (a.z + b.z) + (c.z + d.z));
+      if (r + 3 < p.M) atomicAdd(p.bias_grad + r + 3, (a.w + b.w) + (c.w + d.w));
+    }
   }
 
   // ---- epilogue ----  C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -279,10 +312,7 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
           if (row < p.M && col_ok) {
             float v = acc[i][j][r] * p.alpha;
             if (EPI == EPI_ATOMIC) {
-              if (p.bias_grad && col == p.N - 1)
-                atomicAdd(p.bias_grad + row, v);
-              else
-                atomicAdd(C + (long)row * p.ldc + col, v);
+              atomicAdd(C + (long)row * p.ldc + col, v);
             } else {
               v += bv;
               if (p.relu) v = v > 0.f ? v : 0.f;
@@ -379,17 +409,15 @@ PZN_EXPORT int pzn_linear_maxpool_dgrad_f32(const float* dout, const int32_t* ar
   PZN_RETURN_LAUNCH_STATUS();
 }
 
-// dW[Nout,Kin] = dY^T X, db[Nout] = column sums of dY (ones-column trick): both overwritten.
+// dW[Nout,Kin] = dY^T X, db[Nout] = column sums of dY (row sums of the streamed A tiles): both overwritten.
 static int wgrad_common(GemmArgs p, int Kin, int Nout, const float* x, float* dW, float* db, hipStream_t st) {
-  // logical C[Nout, Kin(+1)] = sum_r dY[r][n] * X[r][k]
+  // logical C[Nout, Kin] = sum_r dY[r][n] * X[r][k];  db[n] = sum_r dY[r][n] from the A tiles
   p.B = x, p.ldb = Kin, p.C = dW, p.ldc = Kin;
   if (db) {
-    p.N = Kin + 1;
-    p.b_ones_col = 1;
     p.bias_grad = db;
-    if (hipMemsetAsync(db, 0, sizeof(float) * (size_t)Nout, st) != hipSuccess) return PZN_ELAUNCH;
+    if (pzn_zero_async(db, (size_t)Nout, st) != PZN_OK) return PZN_ELAUNCH;
   }
-  if (hipMemsetAsync(dW, 0, sizeof(float) * (size_t)Nout * Kin, st) != hipSuccess) return PZN_ELAUNCH;
+  if (pzn_zero_async(dW, (size_t)Nout * Kin, st) != PZN_OK) return PZN_ELAUNCH;
   choose_splits(p);
   if (p.splits == 1) p.splits = 2, p.k_chunk = ((p.K + 2 * BK - 1) / (2 * BK)) * BK;  // keep the atomic epilogue path
   launch<false, false, EPI_ATOMIC>(p, 1, st);

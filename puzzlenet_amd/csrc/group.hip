@@ -183,8 +183,12 @@ PZN_EXPORT int pzn_group_fwd_f32(const float* xyz, const float* feat, const floa
   const int W = 3 + D;
   const long total_q = (long)B * S;
   size_t lds = (size_t)GRP_WAVES * K * W * sizeof(float);
-  if (D > 0 && (D & 3) == 0 && ((K * W) & 3) == 0 && lds <= 64 * 1024 &&
+  if (D > 0 && (D & 3) == 0 && ((K * W) & 3) == 0 && lds <= 150 * 1024 &&
       (reinterpret_cast<uintptr_t>(feat) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&group_fwd_vec_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return PZN_ELAUNCH;
     long blocks = (total_q + GRP_WAVES - 1) / GRP_WAVES;
     long cap = 256L * 8;
     int grid = (int)(blocks < cap ? blocks : cap);

@@ -22,6 +22,22 @@
 
 static inline hipStream_t pzn_hip_stream(pzn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Zero-fill as a KERNEL, not hipMemsetAsync: inside a captured HIP graph (ROCm 7.0 runtime shipped
+// with torch) memset nodes were observed to run out of stream order relative to kernels that reuse the
+// same allocation, so accumulators were zeroed too early.  A kernel node keeps the stream order.
+static __global__ void pzn_zero_kernel(float* __restrict__ p, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = 0.f;
+}
+static inline int pzn_zero_async(float* p, size_t n, hipStream_t st) {
+  if (n == 0) return PZN_OK;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pzn_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n);
+  return hipGetLastError() == hipSuccess ? PZN_OK : PZN_ELAUNCH;
+}
+
 namespace pzn {
 
 // ((dx*dx + dy*dy) + dz*dz) with every operation individually rounded: the

@@ -1,0 +1,87 @@
+"""Training-step runner: the whole step (predict5 + losses + backward [+ Adam]) as ONE HIP graph.
+
+The reference leaves scheduling to PyTorch eager mode: ~1,000 kernel launches per step, each paid
+for on the host.  On MI355X the step's kernels are short (tens of microseconds), so the host, not
+the GPU, sets the pace.  Here the step is captured once into a HIP graph and replayed: launch cost
+collapses to one graph launch, and the GPU runs the kernels back to back.
+
+What makes the step capturable:
+  * every op is enqueued on the current stream (the C ABI takes the stream explicitly);
+  * no host<->device copies inside: FPS start indices come from StartIndexFeed buffers that are
+    refilled from the CPU generator before each replay (same draws as the eager path);
+  * gradients live in one flat buffer that is zeroed in place (FlatGradAllReduce);
+  * Adam runs with capturable=True and a device-resident learning rate.
+With more than one rank the gradient all-reduce (RCCL) and the optimizer run after the graph.
+"""
+import torch
+
+from . import distributed as pdist
+from . import pointnet_util as pu
+
+
+class TrainStep:
+    def __init__(self, model, batch, lr, world=1, use_graph=True, warmup=3):
+        self.model = model
+        self.batch = batch
+        self.world = world
+        self.grads = pdist.FlatGradAllReduce(model.parameters())
+        dev = self.grads.flat.device
+        self.graph = None
+        self.opt_in_graph = use_graph and world == 1
+        lr_arg = torch.tensor(float(lr), device=dev) if use_graph else lr
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr_arg, capturable=bool(use_graph))
+        self.sched = torch.optim.lr_scheduler.StepLR(self.opt, 50, 0.999)       # model5_b.py:1453-1457
+        self.loss = None
+        self.feed = None
+        if use_graph:
+            self._capture(warmup)
+
+    # -- one eager step (also the body that gets captured)
+    def _fwd_bwd(self):
+        self.grads.zero_()
+        loss = self.model.training_step(self.batch, 0)["loss"]
+        loss.backward()
+        return loss
+
+    def _capture(self, warmup):
+        self.feed = pu.StartIndexFeed()
+        pu.set_start_index_feed(self.feed)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                      # warm-up off the default stream
+            for i in range(max(2, warmup)):
+                if i == 0:
+                    pass                                # first pass RECORDS the FPS call sequence (allocates the slots)
+                else:
+                    self.feed.refill()
+                self._fwd_bwd()
+                if i == 0:
+                    self.feed.freeze()
+                self.grads.all_reduce_mean()
+                self.opt.step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.feed.refill()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._fwd_bwd()
+            if self.opt_in_graph:
+                self.opt.step()
+
+    def step(self):
+        if self.graph is None:
+            self.loss = self._fwd_bwd()
+            self.grads.all_reduce_mean()
+            self.opt.step()
+        else:
+            self.feed.refill()
+            self.graph.replay()
+            if not self.opt_in_graph:
+                self.grads.all_reduce_mean()
+                self.opt.step()
+        self.sched.step()
+        return self.loss
+
+    def close(self):
+        if self.feed is not None:
+            pu.set_start_index_feed(None)

@@ -225,7 +225,7 @@ class TouchedRegraster(_Base):
         assert g.size(1) == igt.size(1) and g.size(1) == 4
         assert g.size(2) == igt.size(2) and g.size(2) == 4
         A = g.matmul(igt)
-        I = torch.eye(4).to(A).view(1, 4, 4).repeat(A.size(0), 1, 1)
+        I = torch.eye(4, dtype=A.dtype, device=A.device).view(1, 4, 4).repeat(A.size(0), 1, 1)
         return F.mse_loss(A, I, reduction='mean') * 16
 
     def training_step(self, batch, batch_indic):
@@ -255,7 +255,7 @@ class TouchedRegraster(_Base):
         else:
             loss_recoversy = torch.mean(dg_mrpc_dist1) + torch.mean(dg_mrpc_dist2)
 
-        g = torch.eye(4).unsqueeze(0).repeat(R.shape[0], 1, 1).to(R)                # :963-967
+        g = torch.eye(4, dtype=R.dtype, device=R.device).unsqueeze(0).repeat(R.shape[0], 1, 1)   # :963-967
         g[:, :3, :3] = R
         g[:, :3, 3] = t
         loss_g = self.comp(g, igt)
@@ -310,8 +310,8 @@ class TouchedRegraster(_Base):
         de_mrpcb_idx = torch.topk(de_mrpcb_idx_sig, 128, 1)[1]
 
         with torch.no_grad():                                                       # :1094-1105 (IoU, logged only)
-            pred_1_fpc = torch.zeros(fpc_idx.shape[0], N).to(fpc_idx).scatter(1, de_fpcb_idx, 1)
-            pred_1_mrpc = torch.zeros(fpc_idx.shape[0], N).to(fpc_idx).scatter(1, de_mrpcb_idx, 1)
+            pred_1_fpc = torch.zeros_like(fpc_idx).scatter(1, de_fpcb_idx, 1)
+            pred_1_mrpc = torch.zeros_like(fpc_idx).scatter(1, de_mrpcb_idx, 1)
             fpc_iou = torch.sum(torch.logical_and(pred_1_fpc, fpc_idx)).float() / \
                 torch.sum(torch.logical_or(pred_1_fpc, fpc_idx)).float()
             mrpcb_iou = torch.sum(torch.logical_and(pred_1_mrpc, rpc_idx)).float() / \

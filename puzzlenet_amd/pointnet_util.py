@@ -15,7 +15,53 @@ import torch
 
 from . import ops
 
-__all__ = ["square_distance", "index_points", "farthest_point_sample", "query_ball_point", "sample_and_group"]
+__all__ = ["square_distance", "index_points", "farthest_point_sample", "query_ball_point", "sample_and_group",
+           "StartIndexFeed", "set_start_index_feed"]
+
+
+class StartIndexFeed:
+    """Stages the FPS start indices through static device buffers.
+
+    The reference draws the first centroid with ``torch.randint(0, N, (B,))`` on the CPU generator
+    at every call (pointnet_util.py:65).  A host draw + host-to-device copy cannot live inside a
+    HIP graph, so when a whole training step is captured the draws are made by ``refill()`` *before*
+    each replay — same generator, same order, same values as the eager path — into buffers the
+    captured FPS kernels read.
+    """
+
+    def __init__(self):
+        self.slots = []          # (device tensor, N) in call order
+        self.cursor = 0
+        self.recording = True    # first pass (capture): create slots; afterwards: slots are fixed
+
+    def next(self, B, N, device):
+        if self.recording:
+            t = torch.randint(0, N, (B,), dtype=torch.long).to(device)
+            self.slots.append((t, N))
+            return t
+        t, n = self.slots[self.cursor]
+        assert n == N and t.shape[0] == B, "FPS call sequence changed since capture"
+        self.cursor += 1
+        return t
+
+    def freeze(self):
+        self.recording = False
+        self.cursor = 0
+
+    def refill(self):
+        """Draw fresh start indices for every recorded FPS call (call before each graph replay)."""
+        self.cursor = 0
+        for t, n in self.slots:
+            t.copy_(torch.randint(0, n, (t.shape[0],), dtype=torch.long), non_blocking=False)
+
+
+_FEED = None
+
+
+def set_start_index_feed(feed):
+    """Install (or clear with None) a StartIndexFeed used by farthest_point_sample."""
+    global _FEED
+    _FEED = feed
 
 
 def square_distance(src, dst):
@@ -37,6 +83,8 @@ def farthest_point_sample(xyz, npoint, start_idx=None):
     """
     B, N, _ = xyz.shape
     if start_idx is None:
+        if _FEED is not None:
+            return ops.farthest_point_sample(xyz, npoint, _FEED.next(B, N, xyz.device))
         start_idx = torch.randint(0, N, (B,), dtype=torch.long)
     return ops.farthest_point_sample(xyz, npoint, start_idx.to(xyz.device))
 

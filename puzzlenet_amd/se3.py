@@ -52,7 +52,8 @@ def exp(x):
     R = I + _sinc1(t) * W + _sinc2(t) * S          # Rodrigues
     V = I + _sinc2(t) * W + _sinc3(t) * S
     p = V.bmm(v.contiguous().view(-1, 3, 1))
-    z = torch.tensor([0, 0, 0, 1], dtype=x.dtype, device=x.device).view(1, 1, 4).repeat(x_.size(0), 1, 1)
+    z = torch.zeros(x_.size(0), 1, 4, dtype=x.dtype, device=x.device)     # built on the device: no host copy,
+    z[:, :, 3] = 1                                                         # so the step stays HIP-graph capturable
     g = torch.cat((torch.cat((R, p), dim=2), z), dim=1)
     return g.view(*(x.size()[0:-1]), 4, 4)
 
