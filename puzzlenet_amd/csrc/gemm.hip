@@ -180,8 +180,13 @@ template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(WM * WN == GT / PZN_WAVE, "4 waves");
-  __shared__ __attribute__((aligned(16))) float As[2][BK][BM + PAD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PAD];
+  // ONE LDS array: operand images during the K loop, per-wave 32 x 64 staging tiles in the epilogue.
+  constexpr int A_ELEMS = 2 * BK * (BM + PAD), B_ELEMS = 2 * BK * (BN + PAD);
+  constexpr int STG_LD = 64 + PAD, STG_ELEMS = (GT / PZN_WAVE) * 32 * STG_LD;
+  constexpr int SMEM_ELEMS = A_ELEMS + B_ELEMS > STG_ELEMS ? A_ELEMS + B_ELEMS : STG_ELEMS;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_ELEMS];
+  float (*As)[BK][BM + PAD] = reinterpret_cast<float (*)[BK][BM + PAD]>(smem);
+  float (*Bs)[BK][BN + PAD] = reinterpret_cast<float (*)[BK][BN + PAD]>(smem + A_ELEMS);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
     bsum.y += __shfl_xor(bsum.y, 32, PZN_WAVE);
     bsum.z += __shfl_xor(bsum.z, 32, PZN_WAVE);
     bsum.w += __shfl_xor(bsum.w, 32, PZN_WAVE);
-    float4* red = reinterpret_cast<float4*>(&As[0][0][0]);  // the K loop is over: LDS is free (last barrier passed)
+    float4* red = reinterpret_cast<float4*>(smem);  // the K loop is over: LDS is free (last barrier passed)
     if (half == 0) red[wave * 32 + l31] = bsum;
     __syncthreads();
     if (wave == 0 && half == 0) {
@@ -275,6 +280,62 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
   }
 
   // ---- epilogue ----  C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  if (EPI == EPI_STORE) {
+    // Stage each 32 x 64 strip of the wave's sub-tile through LDS and write it as whole 256-B row
+    // segments with 16-B stores (a register-direct store is one dword per lane: 4x the store
+    // instructions, 128-B segments, and a dword-gather for the ReLU mask).
+    static_assert(TN == 2, "a wave's sub-tile is 64 columns wide");
+    float* stg = smem + wave * 32 * STG_LD;
+    const int cbase = n0 + wn * (BN / WN);
+    const bool c_vec = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+                       (!p.maskH || (reinterpret_cast<uintptr_t>(p.maskH) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rbase = m0 + wm * (BM / WM) + i * 32;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = cbase + j * 32 + l31;
+        const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = acc[i][j][r] * p.alpha + bv;
+          if (p.relu) v = v > 0.f ? v : 0.f;
+          stg[rl * STG_LD + j * 32 + l31] = v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int rl = ps * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+        const int row = rbase + rl, col = cbase + c4;
+        if (row >= p.M || col >= p.N) continue;
+        float4 v = *reinterpret_cast<const float4*>(stg + rl * STG_LD + c4);
+        const long off = (long)row * p.ldc + col;
+        if (c_vec && col + 3 < p.N) {
+          if (p.maskH) {
+            float4 h = *reinterpret_cast<const float4*>(p.maskH + off);
+            v.x = h.x > 0.f ? v.x : 0.f;
+            v.y = h.y > 0.f ? v.y : 0.f;
+            v.z = h.z > 0.f ? v.z : 0.f;
+            v.w = h.w > 0.f ? v.w : 0.f;
+          }
+          *reinterpret_cast<float4*>(C + off) = v;
+        } else {
+          float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (col + c < p.N) {
+              float x = t[c];
+              if (p.maskH) x = p.maskH[off + c] > 0.f ? x : 0.f;
+              C[off + c] = x;
+            }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -305,21 +366,11 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
           C[g * p.ldc + col] = best;
           p.argmax[g * p.ldc + col] = bi;
         }
-      } else {
+      } else {  // EPI_ATOMIC
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           int row = rbase + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (row < p.M && col_ok) {
-            float v = acc[i][j][r] * p.alpha;
-            if (EPI == EPI_ATOMIC) {
-              atomicAdd(C + (long)row * p.ldc + col, v);
-            } else {
-              v += bv;
-              if (p.relu) v = v > 0.f ? v : 0.f;
-              if (p.maskH) v = p.maskH[(long)row * p.ldc + col] > 0.f ? v : 0.f;
-              C[(long)row * p.ldc + col] = v;
-            }
-          }
+          if (row < p.M && col_ok) atomicAdd(C + (long)row * p.ldc + col, acc[i][j][r] * p.alpha);
         }
       }
     }
@@ -353,11 +404,11 @@ GemmArgs base_args(int M, int N, int K) {
 // split the reduction range of a weight-gradient GEMM so that the grid fills the chip
 void choose_splits(GemmArgs& p) {
   long tiles = (long)((p.N + 127) / 128) * ((p.M + 127) / 128);
-  long want = 1024 / (tiles > 0 ? tiles : 1);
+  long want = 768 / (tiles > 0 ? tiles : 1);  // ~3 workgroups per CU
   long ksteps = (p.K + BK - 1) / BK;
   long splits = want < 1 ? 1 : want;
-  if (splits > ksteps / 4) splits = ksteps / 4;  // at least 4 K-steps per split
-  if (splits < 1) splits = 1;
+  if (splits > ksteps / 16) splits = ksteps / 16;  // >= 16 K-steps (256 rows) per split: the atomic epilogue
+  if (splits < 1) splits = 1;                      // and the zero-fill must stay small next to the MFMA work
   if (splits > 65535) splits = 65535;
   long per = (ksteps + splits - 1) / splits;
   p.k_chunk = (int)(per * BK);
