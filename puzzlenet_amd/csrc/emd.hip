@@ -31,7 +31,7 @@
 
 namespace {
 
-constexpr int EMD_T = 256;  // threads per workgroup = rows (k or l) per workgroup
+constexpr int EMD_T = 256;  // threads per workgroup (4 wavefronts)
 
 struct EmdWs {
   float4* pk1;     // [B*n] {x1,y1,z1, ratioL}
@@ -57,10 +57,70 @@ EmdWs carve(void* ws, int B, int n, int m) {
 
 __device__ __forceinline__ float fast_exp_scaled(float c_log2e, float d) {
   // __expf(level*d) == exp2(level*d*log2e); level*log2e is folded on the host.
+#ifdef PZN_EMD_EXACT_EXP
+  return expf((c_log2e * 0.69314718055994530942f) * d);
+#else
   return __builtin_amdgcn_exp2f(c_log2e * d);
+#endif
 }
 
 __device__ __forceinline__ float sq3(float dx, float dy, float dz) { return dx * dx + dy * dy + dz * dz; }
+
+// Walk `cnt` packed points of the other cloud.  A workgroup = 4 wavefronts that own the SAME 64 rows
+// (k or l = blockIdx.x*64 + lane); each wavefront walks one quarter of every tile and the four partial
+// sums meet through LDS at the end.  That quadruples the wavefronts of a pass (8 per SIMD at B=64,
+// n=2048, where one thread per row gives only 2) — the pass is a long dependent VALU/exp chain per
+// lane, and resident waves are the only latency cover.  The walked points are staged through LDS in
+// 512-point tiles (double-buffered, one barrier per tile) and read back with a wave-uniform index: a
+// broadcast ds_read_b128 per point.  (A first version fed them through the scalar cache with
+// s_load_dwordx16: every wave of a pair streams the same 32 KB through a small scalar cache shared
+// between CUs, which thrashes — ~10 cycles per VALU instruction measured.)
+constexpr int EMD_TL = 512;
+constexpr int EMD_ROWS = 64;  // rows per workgroup
+#define EMD_WALK(PTR, CNT, EVAL)                                              \
+  do {                                                                        \
+    __shared__ float4 emd_tile_[2][EMD_TL];                                   \
+    const int cnt_ = (CNT);                                                   \
+    const int wq_ = threadIdx.x >> 6;                                         \
+    const int ntile_ = (cnt_ + EMD_TL - 1) / EMD_TL;                          \
+    for (int i_ = threadIdx.x; i_ < EMD_TL && i_ < cnt_; i_ += EMD_T) emd_tile_[0][i_] = (PTR)[i_]; \
+    __syncthreads();                                                          \
+    for (int t_ = 0; t_ < ntile_; ++t_) {                                     \
+      const int base_ = t_ * EMD_TL;                                          \
+      const int len_ = min(EMD_TL, cnt_ - base_);                             \
+      if (t_ + 1 < ntile_) {                                                  \
+        const int nb_ = base_ + EMD_TL;                                       \
+        for (int i_ = threadIdx.x; i_ < EMD_TL && nb_ + i_ < cnt_; i_ += EMD_T) \
+          emd_tile_[(t_ + 1) & 1][i_] = (PTR)[nb_ + i_];                      \
+      }                                                                       \
+      const float4* tp_ = emd_tile_[t_ & 1];                                  \
+      const int per_ = (((len_ + 3) >> 2) + 3) & ~3;                          \
+      int i_ = min(len_, wq_ * per_);                                         \
+      const int end_ = min(len_, i_ + per_);                                  \
+      for (; i_ + 3 < end_; i_ += 4) {                                        \
+        float4 c0_ = tp_[i_], c1_ = tp_[i_ + 1], c2_ = tp_[i_ + 2], c3_ = tp_[i_ + 3]; \
+        EVAL(c0_, base_ + i_);                                                \
+        EVAL(c1_, base_ + i_ + 1);                                            \
+        EVAL(c2_, base_ + i_ + 2);                                            \
+        EVAL(c3_, base_ + i_ + 3);                                            \
+      }                                                                       \
+      for (; i_ < end_; ++i_) {                                               \
+        float4 c0_ = tp_[i_];                                                 \
+        EVAL(c0_, base_ + i_);                                                \
+      }                                                                       \
+      __syncthreads();                                                        \
+    }                                                                         \
+  } while (0)
+
+// sum over the 4 wavefronts of a workgroup, lane by lane (all threads get the total)
+__device__ __forceinline__ float cross_wave_sum(float v, float* red) {
+  red[threadIdx.x] = v;
+  __syncthreads();
+  const int l = threadIdx.x & 63;
+  float t = (red[l] + red[64 + l]) + (red[128 + l] + red[192 + l]);
+  __syncthreads();
+  return t;
+}
 
 __global__ __launch_bounds__(EMD_T) void emd_init_kernel(const float* __restrict__ xyz1,
                                                          const float* __restrict__ xyz2, int n, int m,
@@ -79,37 +139,37 @@ __global__ __launch_bounds__(EMD_T) void emd_init_kernel(const float* __restrict
   }
 }
 
-// Pass A: one thread per k.
+// Pass A: rows = points k of xyz1.
 __global__ __launch_bounds__(EMD_T) void emd_pass_a_kernel(int n, int m, float c, EmdWs w) {
+  __shared__ float red[EMD_T];
   const int b = blockIdx.y;
-  const int k = blockIdx.x * EMD_T + threadIdx.x;
+  const int k = blockIdx.x * EMD_ROWS + (threadIdx.x & 63);
   const float4* __restrict__ other = w.pk2a + (size_t)b * m;
   float4 me = k < n ? w.pk1[(size_t)b * n + k] : make_float4(0, 0, 0, 0);
-  float suml = 1e-9f;  // :59
-#pragma unroll 4
-  for (int l = 0; l < m; ++l) {
-    float4 o = other[l];
+  float suml = 0.f;
+  auto eval = [&](const float4& o, int) {
     float d = sq3(o.x - me.x, o.y - me.y, o.z - me.z);  // :76
     suml += fast_exp_scaled(c, d) * o.w;                // :77-78
-  }
-  if (k < n) {
+  };
+  EMD_WALK(other, m, eval);
+  suml = 1e-9f + cross_wave_sum(suml, red);  // :59
+  if (k < n && threadIdx.x < 64) {
     me.w = w.remainL[(size_t)b * n + k] / suml;  // :83
     w.pk1[(size_t)b * n + k] = me;
   }
 }
 
-// Pass B: one thread per l.  FUSED additionally accumulates
+// Pass B: rows = points l of xyz2.  FUSED additionally accumulates
 // grad2_l += 2 ratioR_l sum_k e_kl ratioL_k (x2_l - x1_k).
 template <bool FUSED>
 __global__ __launch_bounds__(EMD_T) void emd_pass_b_kernel(int n, int m, float c, EmdWs w, float* __restrict__ g2) {
+  __shared__ float red[EMD_T];
   const int b = blockIdx.y;
-  const int l = blockIdx.x * EMD_T + threadIdx.x;
+  const int l = blockIdx.x * EMD_ROWS + (threadIdx.x & 63);
   const float4* __restrict__ other = w.pk1 + (size_t)b * n;
   float4 me = l < m ? w.pk2a[(size_t)b * m + l] : make_float4(0, 0, 0, 0);
   float sumr = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
-#pragma unroll 4
-  for (int k = 0; k < n; ++k) {
-    float4 o = other[k];
+  auto eval = [&](const float4& o, int) {
     float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
     float e = fast_exp_scaled(c, sq3(dx, dy, dz)) * o.w;  // :108
     sumr += e;                                            // :109
@@ -118,8 +178,15 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_b_kernel(int n, int m, float c
       sy += e * dy;
       sz += e * dz;
     }
+  };
+  EMD_WALK(other, n, eval);
+  sumr = cross_wave_sum(sumr, red);
+  if (FUSED) {
+    sx = cross_wave_sum(sx, red);
+    sy = cross_wave_sum(sy, red);
+    sz = cross_wave_sum(sz, red);
   }
-  if (l < m) {
+  if (l < m && threadIdx.x < 64) {
     float remainR = me.w;
     sumr *= remainR;                                              // :114
     float consumption = fminf(remainR / (sumr + 1e-9f), 1.0f);    // :115
@@ -137,21 +204,20 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_b_kernel(int n, int m, float c
   }
 }
 
-// Pass C: one thread per k.  MATCH writes match[b][l][k] += w (API-parity path);
+// Pass C: rows = points k of xyz1.  MATCH writes match[b][l][k] += w (API-parity path);
 // FUSED accumulates cost_b += sum_l d_kl w_kl and grad1_k += 2 sum_l w_kl (x1_k - x2_l).
 template <bool MATCH, bool FUSED>
 __global__ __launch_bounds__(EMD_T) void emd_pass_c_kernel(int n, int m, float c, EmdWs w, float* __restrict__ match,
                                                            float* __restrict__ cost, float* __restrict__ g1) {
+  __shared__ float red[EMD_T];
   const int b = blockIdx.y;
-  const int k = blockIdx.x * EMD_T + threadIdx.x;
+  const int k = blockIdx.x * EMD_ROWS + (threadIdx.x & 63);
   const float4* __restrict__ other = w.pk2b + (size_t)b * m;
   float4 me = k < n ? w.pk1[(size_t)b * n + k] : make_float4(0, 0, 0, 0);
   const float rl = me.w;  // :139
   float suml = 0.f, sx = 0.f, sy = 0.f, sz = 0.f, sc = 0.f;
   float* mt = MATCH ? match + (size_t)b * n * m + k : nullptr;
-#pragma unroll 4
-  for (int l = 0; l < m; ++l) {
-    float4 o = other[l];
+  auto eval = [&](const float4& o, int l) {
     float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
     float d = sq3(dx, dy, dz);
     float wv = fast_exp_scaled(c, d) * rl * o.w;  // :145
@@ -165,8 +231,16 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_c_kernel(int n, int m, float c
       sz += wv * dz;
       sc += wv * d;
     }
+  };
+  EMD_WALK(other, m, eval);
+  suml = cross_wave_sum(suml, red);
+  if (FUSED) {
+    sx = cross_wave_sum(sx, red);
+    sy = cross_wave_sum(sy, red);
+    sz = cross_wave_sum(sz, red);
+    sc = cross_wave_sum(sc, red);
   }
-  if (k < n) {
+  if (k < n && threadIdx.x < 64) {
     float* r = w.remainL + (size_t)b * n + k;
     *r = fmaxf(0.0f, *r - suml);  // :153
     if (FUSED) {
@@ -176,17 +250,10 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_c_kernel(int n, int m, float c
       g[2] += 2.f * sz;
     }
   }
-  if (FUSED) {
-    __shared__ float red[EMD_T / PZN_WAVE];
+  if (FUSED && threadIdx.x < 64) {  // one wavefront holds the 64 row totals
     sc = k < n ? sc : 0.f;
     sc = pzn::wave_sum_f32(sc);
-    if ((threadIdx.x & (PZN_WAVE - 1)) == 0) red[threadIdx.x / PZN_WAVE] = sc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float t = 0.f;
-      for (int i = 0; i < EMD_T / PZN_WAVE; ++i) t += red[i];
-      atomicAdd(cost + b, t);
-    }
+    if (threadIdx.x == 0) atomicAdd(cost + b, sc);
   }
 }
 
@@ -298,7 +365,7 @@ int run_levels(const float* xyz1, const float* xyz2, int B, int n, int m, float*
     multiR = 1.f;
   }
   const int mx = n > m ? n : m;
-  dim3 gi((mx + EMD_T - 1) / EMD_T, B), gk((n + EMD_T - 1) / EMD_T, B), gl((m + EMD_T - 1) / EMD_T, B);
+  dim3 gi((mx + EMD_T - 1) / EMD_T, B), gk((n + EMD_ROWS - 1) / EMD_ROWS, B), gl((m + EMD_ROWS - 1) / EMD_ROWS, B);
   hipLaunchKernelGGL(emd_init_kernel, gi, dim3(EMD_T), 0, st, xyz1, xyz2, n, m, multiL, multiR, w);
   if (MATCH && pzn_zero_async(match, (size_t)B * n * m, st) != PZN_OK) return PZN_ELAUNCH;  // :39-40
   if (FUSED) {
