@@ -171,15 +171,15 @@ def main():
         # roofline of the kNN + group stage: 2 clouds x (sg1 + sg2) per pair per step
         per_pair = 2 * (knn_group_bytes(N, 512, 32, 64) + knn_group_bytes(512, 256, 32, 128))
         n_knn, ms_knn = kern.get("pzn_knn_f32", (0, 0.0))
-        n_grp, ms_grp = kern.get("pzn_group_fwd_f32", (0, 0.0))
+        n_grp, ms_grp = kern.get("pzn_group_pad_fwd_f32", kern.get("pzn_group_fwd_f32", (0, 0.0)))
         stage_ms_per_step = (ms_knn + ms_grp) / max(1, prof_steps)
         achieved = per_pair * B / (stage_ms_per_step * 1e-3) / 1e9 if stage_ms_per_step > 0 else 0.0
         roofline = {
-            "bound": "hbm", "kernel": "pzn_knn_f32 + pzn_group_fwd_f32 (4 launches each per step)",
+            "bound": "hbm", "kernel": "pzn_knn_f32 + pzn_group_pad_fwd_f32 (knn32_kernel + group_fwd_vec_kernel, 4 launches each per step)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
             "algorithmic_bytes_per_step": per_pair * B,
-            "avg_launch_ms": {"pzn_knn_f32": ms_knn / max(1, n_knn), "pzn_group_fwd_f32": ms_grp / max(1, n_grp)},
+            "avg_launch_ms": {"knn32_kernel": ms_knn / max(1, n_knn), "group_fwd_vec_kernel": ms_grp / max(1, n_grp)},
         }
         stages = {k: {"launches_per_step": n / prof_steps, "ms_per_step": ms / prof_steps} for k, (n, ms) in sorted(kern.items())}
         out = {

@@ -210,6 +210,26 @@ int pzn_sharedmlp_max_bwd_f32(const float* x, const float* W1, const float* W2,
                               float* dW1, float* db1, float* dW2, float* db2,
                               pzn_stream_t stream);
 
+/* Model-internal set-abstraction path (the drop-in sample_and_group keeps the reference's
+ * [B,S,K,3+D] layout; this one is what model5_b's encoder runs):
+ * rows {dx,dy,dz,0,f_0..f_{D-1}} (16-byte aligned, feature block on a 16-byte boundary). */
+int pzn_group_pad_fwd_f32(const float* xyz, const float* feat, const float* new_xyz,
+                          const int64_t* idx, int B, int N, int S, int K, int D,
+                          float* out, pzn_stream_t stream);
+/* grad_feat[b, idx[b,s,k], :] += rows[b,s,k,:], rows D wide; grad_feat zero-initialised
+ * by the caller. */
+int pzn_group_feat_bwd_f32(const float* rows, const int64_t* idx, int B, int N, int S,
+                           int K, int D, float* grad_feat, pzn_stream_t stream);
+/* Backward of pzn_sharedmlp_max_fwd_f32 run on padded rows xg[R*32,4+D] with
+ * W1p[C1,4+D] = {W1[:,0:3], 0, W1[:,3:]} (model5_b.py:452-454 / :459-461 with the grouping of
+ * pointnet_util.py:123-132 folded in): dW1p, db1, dW2, db2 overwritten; dfeat_rows[R*32,D]
+ * (gradient of the gathered feature block only; may be NULL); dh_ws[R*32,C1] scratch. */
+int pzn_sa_mlp_max_bwd_f32(const float* xg, const float* W1p, const float* W2,
+                           const float* h, const float* out, const int32_t* argmax,
+                           const float* dout, int R, int D, int C1, int C2, float* dh_ws,
+                           float* dfeat_rows, float* dW1p, float* db1, float* dW2,
+                           float* db2, pzn_stream_t stream);
+
 /* scaled_dot_production of layerAttention, model5_b.py:67-75:
  * attn[B,L,L] = softmax(q[B,L,dk] k[B,L,dk]^T / sqrt(dk)), out[B,L,dv] = attn v.
  * attn is an output because the reference returns it (model5_b.py:97,101). */

@@ -65,6 +65,10 @@ struct GemmArgs {
   int32_t* argmax;          // EPI_MAXPOOL: C is out[M/32][N], argmax[M/32][N]
   float* bias_grad;         // "TN" (A k-major) only: bias_grad[m] += sum_k A(m,k), taken from the A tiles as
                             // they stream through the loader of the blockIdx.x == 0 column of workgroups
+  const float* side;        // same mechanism with weights: side_out[m*ld_side_out + c] += sum_k A(m,k) side[k*ld_side + c],
+  int ld_side;              // c = 0..2  (the three xyz columns of a grouped row: a 3-wide GEMM for free)
+  float* side_out;
+  int ld_side_out;
 };
 
 // ---- operand loaders ---------------------------------------------------------------------
@@ -147,6 +151,26 @@ struct Loader {
     }
   }
 
+  // weighted sums for the three side columns (k-major loaders only)
+  __device__ __forceinline__ void accumulate_side(float4* acc3, const float* side, int ld, int k0, int Kend,
+                                                  int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int kk = k0 + (tid + i * GT) / (BR / 4);
+      if (kk < Kend) {
+        const float* sp = side + (long)kk * ld;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float w = sp[c];
+          acc3[c].x += v[i].x * w;
+          acc3[c].y += v[i].y * w;
+          acc3[c].z += v[i].z * w;
+          acc3[c].w += v[i].w * w;
+        }
+      }
+    }
+  }
+
   // sum of this thread's float4s (k-major loaders only: every float4 of a thread covers the same 4 rows)
   __device__ __forceinline__ void accumulate(float4& acc) const {
 #pragma unroll
@@ -224,10 +248,13 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
   Loader<BN, B_KC> lb;
   // bias gradient: this thread's A float4s always cover the same 4 output rows (m-quad tid % (BM/4))
   const bool do_bias = !A_KC && p.bias_grad != nullptr && blockIdx.x == 0;
+  const bool do_side = !A_KC && p.side != nullptr && blockIdx.x == 0;
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 ssum[3] = {bsum, bsum, bsum};
   la.fetch(p, true, A, p.lda, p.M, m0, kbeg, kend, a_vec, tid);
   lb.fetch(p, false, B, p.ldb, p.N, n0, kbeg, kend, b_vec, tid);
   if (do_bias) la.accumulate(bsum);
+  if (do_side) la.accumulate_side(ssum, p.side, p.ld_side, kbeg, kend, tid);
   la.store(As[0], tid);
   lb.store(Bs[0], tid);
   __syncthreads();
@@ -254,28 +281,38 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
     }
     if (kt + 1 < nkt) {
       if (do_bias) la.accumulate(bsum);
+      if (do_side) la.accumulate_side(ssum, p.side, p.ld_side, kbeg + (kt + 1) * BK, kend, tid);
       la.store(As[cur ^ 1], tid);
       lb.store(Bs[cur ^ 1], tid);
     }
     __syncthreads();
   }
-  if (p.bias_grad != nullptr && !A_KC && blockIdx.x == 0) {  // (uniform over the workgroup)
+  if (!A_KC && blockIdx.x == 0 && (p.bias_grad != nullptr || p.side != nullptr)) {  // (uniform over the workgroup)
     // 8 threads (lane, lane+32 in each of the 4 waves) hold partial sums of the same 4 rows:
     // fold them on chip so that the contended atomics are 128 per workgroup, not 1024.
-    bsum.x += __shfl_xor(bsum.x, 32, PZN_WAVE);
-    bsum.y += __shfl_xor(bsum.y, 32, PZN_WAVE);
-    bsum.z += __shfl_xor(bsum.z, 32, PZN_WAVE);
-    bsum.w += __shfl_xor(bsum.w, 32, PZN_WAVE);
     float4* red = reinterpret_cast<float4*>(smem);  // the K loop is over: LDS is free (last barrier passed)
-    if (half == 0) red[wave * 32 + l31] = bsum;
-    __syncthreads();
-    if (wave == 0 && half == 0) {
-      float4 a = red[l31], b = red[32 + l31], c = red[64 + l31], d = red[96 + l31];
-      int r = m0 + l31 * 4;
-      if (r + 0 < p.M) atomicAdd(p.bias_grad + r + 0, (a.x + b.x) + (c.x + d.x));
-      if (r + 1 < p.M) atomicAdd(p.bias_grad + r + 1, (a.y + b.y) + (c.y + d.y));
-      if (r + 2 < p.M) atomicAdd(p.bias_grad + r + 2, (a.z + b.z) + (c.z + d.z));
-      if (r + 3 < p.M) atomicAdd(p.bias_grad + r + 3, (a.w + b.w) + (c.w + d.w));
+    auto fold = [&](float4 v, float* out, int ld, int col) {
+      v.x += __shfl_xor(v.x, 32, PZN_WAVE);
+      v.y += __shfl_xor(v.y, 32, PZN_WAVE);
+      v.z += __shfl_xor(v.z, 32, PZN_WAVE);
+      v.w += __shfl_xor(v.w, 32, PZN_WAVE);
+      if (half == 0) red[wave * 32 + l31] = v;
+      __syncthreads();
+      if (wave == 0 && half == 0) {
+        float4 a = red[l31], b = red[32 + l31], c = red[64 + l31], d = red[96 + l31];
+        int r = m0 + l31 * 4;
+        if (r + 0 < p.M) atomicAdd(out + (long)(r + 0) * ld + col, (a.x + b.x) + (c.x + d.x));
+        if (r + 1 < p.M) atomicAdd(out + (long)(r + 1) * ld + col, (a.y + b.y) + (c.y + d.y));
+        if (r + 2 < p.M) atomicAdd(out + (long)(r + 2) * ld + col, (a.z + b.z) + (c.z + d.z));
+        if (r + 3 < p.M) atomicAdd(out + (long)(r + 3) * ld + col, (a.w + b.w) + (c.w + d.w));
+      }
+      __syncthreads();
+    };
+    if (p.bias_grad != nullptr) fold(bsum, p.bias_grad, 1, 0);
+    if (p.side != nullptr) {
+      fold(ssum[0], p.side_out, p.ld_side_out, 0);
+      fold(ssum[1], p.side_out, p.ld_side_out, 1);
+      fold(ssum[2], p.side_out, p.ld_side_out, 2);
     }
   }
 
@@ -623,4 +660,42 @@ PZN_EXPORT int pzn_sharedmlp_max_bwd_f32(const float* x, const float* W1, const 
   if (rc != PZN_OK) return rc;
   if (dx) rc = pzn_linear_dgrad_f32(dh_ws, nullptr, W1, R * 32, C0, C1, nullptr, dx, stream);
   return rc;
+}
+
+// Set-abstraction MLP on the model-internal padded rows xg[R*32, 4+D] = {dx,dy,dz,0,f...} (group.hip):
+// forward = pzn_sharedmlp_max_fwd_f32 with C0 = 4+D and W1p[C1,4+D] = {W1[:,0:3], 0, W1[:,3:]}.
+// Backward: feature part of the first layer as clean D-wide GEMMs (no 67/131-wide tiles), the three xyz
+// columns and the bias from the A stream, input gradient only for the D feature columns (xyz needs none).
+//   dh_ws[R*32,C1] scratch; dfeat_rows[R*32,D] may be NULL; dW1p[C1,4+D], db1, dW2, db2 overwritten.
+PZN_EXPORT int pzn_sa_mlp_max_bwd_f32(const float* xg, const float* W1p, const float* W2, const float* h,
+                                      const float* out, const int32_t* argmax, const float* dout, int R, int D, int C1,
+                                      int C2, float* dh_ws, float* dfeat_rows, float* dW1p, float* db1, float* dW2,
+                                      float* db2, pzn_stream_t stream) {
+  PZN_CHECK_ARG(xg && W1p && W2 && h && out && argmax && dout && dh_ws && dW1p && db1 && dW2 && db2);
+  PZN_CHECK_ARG(R > 0 && D > 0 && (D & 3) == 0 && C1 > 0 && C2 > 0);
+  hipStream_t st = pzn_hip_stream(stream);
+  const int ldx = 4 + D, M = R * 32;
+  int rc = pzn_linear_maxpool_dgrad_f32(dout, argmax, out, W2, R, C1, C2, h, dh_ws, stream);  // dh (ReLU-masked by h)
+  if (rc != PZN_OK) return rc;
+  rc = pzn_linear_maxpool_wgrad_f32(dout, argmax, out, h, R, C1, C2, dW2, db2, stream);
+  if (rc != PZN_OK) return rc;
+  {  // dW1p[:, 4:] = dh^T xg[:, 4:],  dW1p[:, 0:3] and db1 from the streamed dh tiles, dW1p[:, 3] = 0
+    if (pzn_zero_async(dW1p, (size_t)C1 * ldx, st) != PZN_OK) return PZN_ELAUNCH;
+    if (pzn_zero_async(db1, (size_t)C1, st) != PZN_OK) return PZN_ELAUNCH;
+    GemmArgs p = base_args(C1, D, M);
+    p.A = dh_ws, p.lda = C1, p.B = xg + 4, p.ldb = ldx, p.C = dW1p + 4, p.ldc = ldx;
+    p.bias_grad = db1;
+    p.side = xg, p.ld_side = ldx, p.side_out = dW1p, p.ld_side_out = ldx;
+    choose_splits(p);
+    if (p.splits == 1) p.splits = 2, p.k_chunk = ((p.K + 2 * BK - 1) / (2 * BK)) * BK;
+    launch<false, false, EPI_ATOMIC>(p, 1, st);
+    if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
+  }
+  if (dfeat_rows) {  // dfeat_rows[M, D] = dh W1p[:, 4:]
+    GemmArgs p = base_args(M, D, C1);
+    p.A = dh_ws, p.lda = C1, p.B = W1p + 4, p.ldb = ldx, p.C = dfeat_rows, p.ldc = D;
+    launch<true, false, EPI_STORE>(p, 1, st);
+    if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
+  }
+  return PZN_OK;
 }

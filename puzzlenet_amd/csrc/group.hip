@@ -28,13 +28,16 @@ __device__ __forceinline__ int clamp_idx(int64_t j, int N) {
   return j < 0 ? 0 : (j >= N ? N - 1 : (int)j);
 }
 
-// Fast path: D % 4 == 0 and K*(3+D) % 4 == 0.
+// Fast path: D % 4 == 0 and K*(3+PAD+D) % 4 == 0.  PAD = 1 is the model-internal layout
+// {dx, dy, dz, 0, f_0 .. f_{D-1}}: rows are 16-byte aligned, so the dense engine reads them with
+// 16-byte loads and the feature block starts on a 16-byte boundary.
+template <int PAD>
 __global__ __launch_bounds__(GRP_WAVES* PZN_WAVE) void group_fwd_vec_kernel(
     const float* __restrict__ xyz, const float* __restrict__ feat, const float* __restrict__ new_xyz,
     const int64_t* __restrict__ idx, int N, int S, int K, int D, long total_q, float* __restrict__ out,
     float* __restrict__ grouped_xyz) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int W = 3 + D;
+  const int W = 3 + PAD + D;
   const int lane = threadIdx.x & (PZN_WAVE - 1);
   const int wave = threadIdx.x / PZN_WAVE;
   float* chunk = reinterpret_cast<float*>(smem_raw) + (size_t)wave * K * W;
@@ -51,12 +54,18 @@ __global__ __launch_bounds__(GRP_WAVES* PZN_WAVE) void group_fwd_vec_kernel(
       int k = t / V, v = t - k * V;
       int j = clamp_idx(qidx[k], N);
       float4 f = *reinterpret_cast<const float4*>(cf + (size_t)j * D + 4 * v);
-      float* dst = chunk + k * W + 3 + 4 * v;
-      dst[0] = f.x;
-      dst[1] = f.y;
-      dst[2] = f.z;
-      dst[3] = f.w;
+      float* dst = chunk + k * W + 3 + PAD + 4 * v;
+      if (PAD) {
+        *reinterpret_cast<float4*>(dst) = f;
+      } else {
+        dst[0] = f.x;
+        dst[1] = f.y;
+        dst[2] = f.z;
+        dst[3] = f.w;
+      }
     }
+    if (PAD)
+      for (int k = lane; k < K; k += PZN_WAVE) chunk[k * W + 3] = 0.f;
     // coordinates: K rows x 3
     for (int t = lane; t < K * 3; t += PZN_WAVE) {
       int k = t / 3, c = t - 3 * k;
@@ -186,13 +195,13 @@ PZN_EXPORT int pzn_group_fwd_f32(const float* xyz, const float* feat, const floa
   if (D > 0 && (D & 3) == 0 && ((K * W) & 3) == 0 && lds <= 150 * 1024 &&
       (reinterpret_cast<uintptr_t>(feat) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&group_fwd_vec_kernel),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&group_fwd_vec_kernel<0>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return PZN_ELAUNCH;
     long blocks = (total_q + GRP_WAVES - 1) / GRP_WAVES;
     long cap = 256L * 8;
     int grid = (int)(blocks < cap ? blocks : cap);
-    hipLaunchKernelGGL(group_fwd_vec_kernel, dim3(grid), dim3(GRP_WAVES * PZN_WAVE), lds, st, xyz, feat, new_xyz, idx,
+    hipLaunchKernelGGL(group_fwd_vec_kernel<0>, dim3(grid), dim3(GRP_WAVES * PZN_WAVE), lds, st, xyz, feat, new_xyz, idx,
                        N, S, K, D, total_q, out, grouped_xyz);
   } else {
     long total = total_q * K * W;
@@ -241,5 +250,63 @@ PZN_EXPORT int pzn_square_distance_f32(const float* src, const float* dst, int B
   long total = (long)B * S * N;
   hipLaunchKernelGGL(sqdist_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, pzn_hip_stream(stream), src, dst, S, N,
                      total, out);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+// Model-internal variants (the drop-in sample_and_group keeps the reference layout above).
+PZN_EXPORT int pzn_group_pad_fwd_f32(const float* xyz, const float* feat, const float* new_xyz, const int64_t* idx,
+                                     int B, int N, int S, int K, int D, float* out, pzn_stream_t stream) {
+  PZN_CHECK_ARG(xyz && feat && new_xyz && idx && out && B > 0 && N > 0 && S > 0 && K > 0 && D > 0);
+  PZN_CHECK_ARG((D & 3) == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  hipStream_t st = pzn_hip_stream(stream);
+  const int W = 4 + D;
+  const long total_q = (long)B * S;
+  size_t lds = (size_t)GRP_WAVES * K * W * sizeof(float);
+  PZN_CHECK_ARG(lds <= 150 * 1024);
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&group_fwd_vec_kernel<1>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PZN_ELAUNCH;
+  long blocks = (total_q + GRP_WAVES - 1) / GRP_WAVES;
+  long cap = 256L * 8;
+  int grid = (int)(blocks < cap ? blocks : cap);
+  hipLaunchKernelGGL(group_fwd_vec_kernel<1>, dim3(grid), dim3(GRP_WAVES * PZN_WAVE), lds, st, xyz, feat, new_xyz, idx,
+                     N, S, K, D, total_q, out, (float*)nullptr);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+namespace {
+// grad_feat[b, idx[b,s,k], :] += rows[b,s,k,:]   (rows are D wide: the feature block only)
+__global__ __launch_bounds__(GRP_WAVES* PZN_WAVE) void group_feat_bwd_kernel(const float* __restrict__ rows,
+                                                                             const int64_t* __restrict__ idx, int N,
+                                                                             int S, int K, int D, long total_q,
+                                                                             float* __restrict__ grad_feat) {
+  const int lane = threadIdx.x & (PZN_WAVE - 1);
+  const int wave = threadIdx.x / PZN_WAVE;
+  const long q_stride = (long)gridDim.x * GRP_WAVES;
+  for (long qi = (long)blockIdx.x * GRP_WAVES + wave; qi < total_q; qi += q_stride) {
+    const long b = qi / S;
+    const int64_t* qidx = idx + qi * K;
+    const float* go = rows + qi * K * D;
+    for (int k = 0; k < K; ++k) {
+      int j = clamp_idx(qidx[k], N);
+      float* dst = grad_feat + ((size_t)b * N + j) * D;
+      const float* g = go + (size_t)k * D;
+      for (int c = lane; c < D; c += PZN_WAVE) atomicAdd(dst + c, g[c]);
+    }
+  }
+}
+}  // namespace
+
+PZN_EXPORT int pzn_group_feat_bwd_f32(const float* rows, const int64_t* idx, int B, int N, int S, int K, int D,
+                                      float* grad_feat, pzn_stream_t stream) {
+  PZN_CHECK_ARG(rows && idx && grad_feat && B > 0 && N > 0 && S > 0 && K > 0 && D > 0);
+  const long total_q = (long)B * S;
+  long blocks = (total_q + GRP_WAVES - 1) / GRP_WAVES;
+  long cap = 256L * 8;
+  int grid = (int)(blocks < cap ? blocks : cap);
+  hipLaunchKernelGGL(group_feat_bwd_kernel, dim3(grid), dim3(GRP_WAVES * PZN_WAVE), 0, pzn_hip_stream(stream), rows, idx,
+                     N, S, K, D, total_q, grad_feat);
   PZN_RETURN_LAUNCH_STATUS();
 }

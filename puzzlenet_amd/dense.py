@@ -28,3 +28,9 @@ def attention(q, k, v):
 def chamfer(a, b):
     """model5_b.py:1495-1505 chamfer_loss: fused kernel, P[B,n,m] never materialised."""
     return ops.chamfer(a, b)
+
+
+def sa_mlp_max(xyz, feat, new_xyz, idx, w1, b1, w2, b2):
+    """group (pointnet_util.py:123-132) + shared MLP + max over K (model5_b.py:452-454 / :459-461) on the
+    model-internal padded layout; the [B,S,K,3+D] tensor of the drop-in sample_and_group is not built."""
+    return ops.sa_mlp_max(xyz, feat, new_xyz, idx, w1, b1, w2, b2)

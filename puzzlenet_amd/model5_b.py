@@ -118,13 +118,27 @@ class PCTransformer_nonsort(nn.Module):
         self.atten4 = layerAttention(self.C, gs2_feature_size * 2)
         self.out = nn.Linear(gs2_feature_size * 2 * 5, 1024)
 
+    fused_sa = True     # False: literally sample_and_group -> [B,S,K,3+D] -> shared MLP, as the reference composes it
+
+    def _set_abstraction(self, npoint, nsample, xyz, feat, lin_a, lin_b):
+        """sample_and_group(npoint, 0, nsample, xyz, feat, knn=True) + relu(lin_a) + relu(lin_b) + max over K."""
+        fps_idx = self.fps(xyz, npoint)                                   # pointnet_util.py:113
+        new_xyz = ops.index_points(xyz, fps_idx)                          # :115
+        idx = ops.knn(xyz, new_xyz, nsample)                              # :118-119
+        return new_xyz, dense.sa_mlp_max(xyz, feat, new_xyz, idx, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias)
+
     def forward(self, xyz):
         x_feature = F.relu(self.bn1(dense.linear(xyz, self.mlp1.weight, self.mlp1.bias)))          # :447
         x_feature = F.relu(self.bn2(dense.linear(x_feature, self.mlp2.weight, self.mlp2.bias)))   # :448
-        x, f1 = self.sg1(512, 0, 32, xyz, x_feature, False, True)                                 # :449
-        f1f = dense.shared_mlp_max(f1, self.mlp3.weight, self.mlp3.bias, self.mlp4.weight, self.mlp4.bias)  # :452-454
-        x2, f2 = self.sg2(256, 0, 32, x, f1f, False, True)                                        # :456
-        f2f = dense.shared_mlp_max(f2, self.mlp5.weight, self.mlp5.bias, self.mlp6.weight, self.mlp6.bias)  # :459-461
+        if self.fused_sa and not xyz.requires_grad:
+            # :449-461 with the grouping folded into the shared MLP (same FPS draw order as sample_and_group)
+            x, f1f = self._set_abstraction(512, 32, xyz, x_feature, self.mlp3, self.mlp4)
+            x2, f2f = self._set_abstraction(256, 32, x, f1f, self.mlp5, self.mlp6)
+        else:
+            x, f1 = self.sg1(512, 0, 32, xyz, x_feature, False, True)                             # :449
+            f1f = dense.shared_mlp_max(f1, self.mlp3.weight, self.mlp3.bias, self.mlp4.weight, self.mlp4.bias)  # :452-454
+            x2, f2 = self.sg2(256, 0, 32, x, f1f, False, True)                                    # :456
+            f2f = dense.shared_mlp_max(f2, self.mlp5.weight, self.mlp5.bias, self.mlp6.weight, self.mlp6.bias)  # :459-461
         att1, attention1 = self.atten1(f2f)
         att2, attention2 = self.atten2(att1)
         att3, attention3 = self.atten3(att2)

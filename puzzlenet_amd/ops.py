@@ -440,3 +440,65 @@ class _Attention(torch.autograd.Function):
 
 def attention(q, k, v):
     return _Attention.apply(q, k, v)
+
+
+class _SaMlpMax(torch.autograd.Function):
+    """Set abstraction as the encoder runs it (model5_b.py:449-454 / :456-461): group the K=32 neighbours
+    (pointnet_util.py:123-132), two shared-MLP layers, max over K — on padded rows {dx,dy,dz,0,f...}, with
+    the first layer's feature block as clean D-wide GEMMs.  Gradients: features and weights (the point
+    coordinates carry none on this path)."""
+
+    @staticmethod
+    def forward(ctx, xyz, feat, new_xyz, idx, w1, b1, w2, b2):
+        xyz, feat, new_xyz, idx = _f32(xyz, "xyz"), _f32(feat, "points"), _f32(new_xyz, "new_xyz"), _i64(idx, "idx")
+        w1, b1, w2, b2 = _f32(w1, "w1"), _f32(b1, "b1"), _f32(w2, "w2"), _f32(b2, "b2")
+        B, N, _ = xyz.shape
+        _, S, K = idx.shape
+        D = feat.shape[-1]
+        C1, C2 = w1.shape[0], w2.shape[0]
+        if K != 32 or D % 4 != 0 or w1.shape[1] != 3 + D:
+            raise _lib.PznError(f"sa_mlp_max: needs K=32, D%4==0, w1[C1,3+D]; got K={K}, D={D}, w1{tuple(w1.shape)}")
+        dev = xyz.device
+        R = B * S
+        xg = torch.empty((R * 32, 4 + D), dtype=torch.float32, device=dev)
+        w1p = torch.cat([w1[:, :3], torch.zeros((C1, 1), dtype=torch.float32, device=dev), w1[:, 3:]], dim=1).contiguous()
+        h = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
+        out = torch.empty((R, C2), dtype=torch.float32, device=dev)
+        arg = torch.empty((R, C2), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _call("pzn_group_pad_fwd_f32", _p(xyz), _p(feat), _p(new_xyz), _p(idx), B, N, S, K, D, _p(xg), _stream())
+            _call("pzn_sharedmlp_max_fwd_f32", _p(xg), _p(w1p), _p(b1), _p(w2), _p(b2), R, 4 + D, C1, C2,
+                  _p(h), _p(out), _p(arg), _stream())
+        ctx.save_for_backward(xg, w1p, w2, h, out, arg, idx)
+        ctx.dims = (B, N, S, K, D, R, C1, C2)
+        return out.reshape(B, S, C2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xg, w1p, w2, h, out, arg, idx = ctx.saved_tensors
+        B, N, S, K, D, R, C1, C2 = ctx.dims
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            raise _lib.PznError("sa_mlp_max: gradients w.r.t. point coordinates are not provided on the fused "
+                                "encoder path; use pointnet_util.sample_and_group + dense.shared_mlp_max")
+        dout = _f32(dout, "dout").reshape(R, C2)
+        dev = dout.device
+        need_feat = ctx.needs_input_grad[1]
+        dh = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
+        drows = torch.empty((R * 32, D), dtype=torch.float32, device=dev) if need_feat else None
+        dW1p = torch.empty((C1, 4 + D), dtype=torch.float32, device=dev)
+        db1 = torch.empty((C1,), dtype=torch.float32, device=dev)
+        dW2 = torch.empty_like(w2)
+        db2 = torch.empty((C2,), dtype=torch.float32, device=dev)
+        dfeat = None
+        with torch.cuda.device(dev):
+            _call("pzn_sa_mlp_max_bwd_f32", _p(xg), _p(w1p), _p(w2), _p(h), _p(out), _p(arg), _p(dout), R, D, C1, C2,
+                  _p(dh), _p(drows), _p(dW1p), _p(db1), _p(dW2), _p(db2), _stream())
+            if need_feat:
+                dfeat = torch.zeros((B, N, D), dtype=torch.float32, device=dev)
+                _call("pzn_group_feat_bwd_f32", _p(drows), _p(idx), B, N, S, K, D, _p(dfeat), _stream())
+        dW1 = torch.cat([dW1p[:, :3], dW1p[:, 4:]], dim=1)
+        return None, dfeat, None, None, dW1, db1, dW2, db2
+
+
+def sa_mlp_max(xyz, feat, new_xyz, idx, w1, b1, w2, b2):
+    return _SaMlpMax.apply(xyz, feat, new_xyz, idx, w1, b1, w2, b2)

@@ -148,3 +148,35 @@ def test_chamfer_identity_and_symmetry(dev):
     x1, x2 = ops.chamfer(a, b)
     y1, y2 = ops.chamfer(b, a)
     assert torch.equal(x1, y2) and torch.equal(x2, y1)         # both passes see bit-identical P
+
+
+@pytest.mark.parametrize("B,N,S,D,C1,C2", [(2, 300, 40, 64, 128, 128), (2, 128, 24, 128, 256, 256), (1, 64, 5, 8, 16, 24)])
+def test_sa_mlp_max_fused_vs_composed(dev, B, N, S, D, C1, C2):
+    """Fused set-abstraction path == group -> shared MLP -> max composed from fp64 torch ops."""
+    from oracle import point_ops as orc
+    from puzzlenet_amd import ops
+    rng = np.random.default_rng(D + S)
+    xyz = rng.random((B, N, 3), dtype=np.float32)
+    feat = rng.standard_normal((B, N, D)).astype(np.float32)
+    new_xyz = xyz[:, :S].copy()
+    idx = orc.knn(xyz, new_xyz, 32)
+    g = torch.Generator().manual_seed(1)
+    w1, b1 = torch.randn(C1, 3 + D, generator=g) / math.sqrt(3 + D), 0.1 * torch.randn(C1, generator=g)
+    w2, b2 = torch.randn(C2, C1, generator=g) / math.sqrt(C1), 0.1 * torch.randn(C2, generator=g)
+    go = torch.randn(B, S, C2, generator=g)
+    grouped = torch.from_numpy(orc.group(xyz, feat, new_xyz, idx)).double()
+    featr = torch.from_numpy(feat).double().requires_grad_(True)
+    tidx = torch.from_numpy(idx)
+    gfe = torch.gather(featr, 1, tidx.reshape(B, -1, 1).expand(-1, -1, D)).reshape(B, S, 32, D)
+    xin = torch.cat([grouped[..., :3], gfe], dim=-1)
+    ref = [t.double().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    yr = torch.max(F.relu(F.linear(F.relu(F.linear(xin, ref[0], ref[1])), ref[2], ref[3])), dim=-2)[0]
+    (yr * go.double()).sum().backward()
+    d = [t.to(dev).requires_grad_(True) for t in (w1, b1, w2, b2)]
+    fd = torch.from_numpy(feat).to(dev).requires_grad_(True)
+    y = ops.sa_mlp_max(torch.from_numpy(xyz).to(dev), fd, torch.from_numpy(new_xyz).to(dev), torch.from_numpy(idx).to(dev), *d)
+    assert _rel(y, yr) < 1e-5
+    (y * go.to(dev)).sum().backward()
+    assert _rel(fd.grad, featr.grad) < 1e-4
+    for a, r, name in zip(d, ref, ("w1", "b1", "w2", "b2")):
+        assert _rel(a.grad, r.grad) < 1e-4, name
