@@ -254,25 +254,51 @@ PZN_EXPORT int pzn_square_distance_f32(const float* src, const float* dst, int B
 }
 
 // Model-internal variants (the drop-in sample_and_group keeps the reference layout above).
+namespace {
+// Padded rows {dx,dy,dz,0,f...}: every row and its feature block start on a 16-byte boundary, so a
+// wavefront moves a neighbourhood with 16-byte loads and 16-byte stores straight through registers —
+// no LDS image (the 3+D layout needs one to turn 268-byte rows into aligned stores), hence no LDS
+// occupancy limit: 8 waves per SIMD keep ~8 x 1 KiB gathers in flight per wave.
+__global__ __launch_bounds__(256) void group_pad_direct_kernel(const float* __restrict__ xyz,
+                                                               const float* __restrict__ feat,
+                                                               const float* __restrict__ new_xyz,
+                                                               const int64_t* __restrict__ idx, int N, int S, int K,
+                                                               int D, long total_q, float* __restrict__ out) {
+  const int lane = threadIdx.x & (PZN_WAVE - 1);
+  const int wave = threadIdx.x / PZN_WAVE;
+  const int V = D >> 2, W4 = 1 + V;  // float4 per row
+  const long q_stride = (long)gridDim.x * 4;
+  for (long qi = (long)blockIdx.x * 4 + wave; qi < total_q; qi += q_stride) {
+    const long b = qi / S;
+    const float4* cf = reinterpret_cast<const float4*>(feat + (size_t)b * N * D);
+    float4* o4 = reinterpret_cast<float4*>(out) + qi * K * W4;
+    // K <= 64: lane k owns neighbour k's index; everyone else fetches it with a lane broadcast
+    int myj = lane < K ? clamp_idx(idx[qi * K + lane], N) : 0;
+    for (int t = lane; t < K * V; t += PZN_WAVE) {
+      int k = t / V, v = t - k * V;
+      int j = __shfl(myj, k, PZN_WAVE);
+      o4[k * W4 + 1 + v] = cf[(size_t)j * V + v];
+    }
+    if (lane < K) {
+      const float* p = xyz + ((size_t)b * N + myj) * 3;
+      const float* c = new_xyz + qi * 3;
+      o4[lane * W4] = make_float4(__fsub_rn(p[0], c[0]), __fsub_rn(p[1], c[1]), __fsub_rn(p[2], c[2]), 0.f);
+    }
+  }
+}
+}  // namespace
+
 PZN_EXPORT int pzn_group_pad_fwd_f32(const float* xyz, const float* feat, const float* new_xyz, const int64_t* idx,
                                      int B, int N, int S, int K, int D, float* out, pzn_stream_t stream) {
-  PZN_CHECK_ARG(xyz && feat && new_xyz && idx && out && B > 0 && N > 0 && S > 0 && K > 0 && D > 0);
+  PZN_CHECK_ARG(xyz && feat && new_xyz && idx && out && B > 0 && N > 0 && S > 0 && K > 0 && K <= 64 && D > 0);
   PZN_CHECK_ARG((D & 3) == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0 &&
                 (reinterpret_cast<uintptr_t>(out) & 15) == 0);
-  hipStream_t st = pzn_hip_stream(stream);
-  const int W = 4 + D;
   const long total_q = (long)B * S;
-  size_t lds = (size_t)GRP_WAVES * K * W * sizeof(float);
-  PZN_CHECK_ARG(lds <= 150 * 1024);
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&group_fwd_vec_kernel<1>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return PZN_ELAUNCH;
-  long blocks = (total_q + GRP_WAVES - 1) / GRP_WAVES;
-  long cap = 256L * 8;
+  long blocks = (total_q + 3) / 4;
+  long cap = 256L * 16;
   int grid = (int)(blocks < cap ? blocks : cap);
-  hipLaunchKernelGGL(group_fwd_vec_kernel<1>, dim3(grid), dim3(GRP_WAVES * PZN_WAVE), lds, st, xyz, feat, new_xyz, idx,
-                     N, S, K, D, total_q, out, (float*)nullptr);
+  hipLaunchKernelGGL(group_pad_direct_kernel, dim3(grid), dim3(256), 0, pzn_hip_stream(stream), xyz, feat, new_xyz, idx,
+                     N, S, K, D, total_q, out);
   PZN_RETURN_LAUNCH_STATUS();
 }
 

@@ -28,19 +28,54 @@ namespace {
 constexpr int KNN_WAVES = 4;
 constexpr int KNN_CAND_CAP = 96;  // >= 32 + 63 rounded up
 
-__device__ __forceinline__ uint64_t bitonic_sort64(uint64_t v, int lane) {
-#pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      uint64_t o = pzn::shfl_xor_u64(v, j);
-      bool up = (lane & k) == 0;
-      bool lower = (lane & j) == 0;
-      bool keepmin = (lower == up);
-      uint64_t mn = o < v ? o : v, mx = o < v ? v : o;
-      v = keepmin ? mn : mx;
-    }
+// lane i <- lane i^J for one dword.  J = 1, 2, 4, 8 are DPP modifiers on a v_mov (no LDS round trip):
+// quad_perm for 1 and 2, row_half_mirror (i^7) followed by quad_perm [3,2,1,0] (i^3) for 4,
+// row_ror:8 for 8; J = 16 is a ds_swizzle (bit mode, no address VGPR); only J = 32 pays a ds_bpermute.
+template <int J>
+__device__ __forceinline__ uint32_t xor_lane(uint32_t v) {
+  if (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+  if (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+  if (J == 4) {
+    int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, t, 0x1B, 0xF, 0xF, true);
   }
+  if (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);
+  if (J == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (16 << 10) | 0x1F);
+  return (uint32_t)__shfl_xor((int)v, 32, PZN_WAVE);
+}
+
+template <int K, int J>
+__device__ __forceinline__ uint64_t bitonic_step(uint64_t v, int lane) {
+  uint32_t lo = xor_lane<J>((uint32_t)v), hi = xor_lane<J>((uint32_t)(v >> 32));
+  uint64_t o = ((uint64_t)hi << 32) | lo;
+  bool keepmin = ((lane & J) == 0) == ((lane & K) == 0);
+  bool olt = o < v;
+  return (olt == keepmin) ? o : v;
+}
+
+// ascending bitonic sort of 64 keys, one per lane
+__device__ __forceinline__ uint64_t bitonic_sort64(uint64_t v, int lane) {
+  v = bitonic_step<2, 1>(v, lane);
+  v = bitonic_step<4, 2>(v, lane);
+  v = bitonic_step<4, 1>(v, lane);
+  v = bitonic_step<8, 4>(v, lane);
+  v = bitonic_step<8, 2>(v, lane);
+  v = bitonic_step<8, 1>(v, lane);
+  v = bitonic_step<16, 8>(v, lane);
+  v = bitonic_step<16, 4>(v, lane);
+  v = bitonic_step<16, 2>(v, lane);
+  v = bitonic_step<16, 1>(v, lane);
+  v = bitonic_step<32, 16>(v, lane);
+  v = bitonic_step<32, 8>(v, lane);
+  v = bitonic_step<32, 4>(v, lane);
+  v = bitonic_step<32, 2>(v, lane);
+  v = bitonic_step<32, 1>(v, lane);
+  v = bitonic_step<64, 32>(v, lane);
+  v = bitonic_step<64, 16>(v, lane);
+  v = bitonic_step<64, 8>(v, lane);
+  v = bitonic_step<64, 4>(v, lane);
+  v = bitonic_step<64, 2>(v, lane);
+  v = bitonic_step<64, 1>(v, lane);
   return v;
 }
 
@@ -135,6 +170,85 @@ __global__ __launch_bounds__(KNN_WAVES* PZN_WAVE) void knn32_kernel(
         best = bitonic_sort64(c, lane);
         tau = bcast_u64(best, 31);
         // shift the (< 64) leftovers down by 32
+        uint64_t mv = (lane + 32 < cnt) ? cand[lane + 32] : 0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane + 32 < cnt) cand[lane] = mv;
+        cnt -= 32;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (cnt > 0) {
+      __builtin_amdgcn_wave_barrier();
+      uint64_t c = lane >= 32 ? ((lane - 32 < cnt) ? cand[lane - 32] : ~0ull) : best;
+      best = bitonic_sort64(c, lane);
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < K) idx[((size_t)b * S + s) * K + lane] = (int64_t)(uint32_t)best;
+  }
+}
+
+// ------------------------------------------ K <= 32, distances kept in registers --
+// Same algorithm as knn32_kernel, for 64 <= N <= 64*R: the R distances a lane owns stay in VGPRs
+// between the two passes, so pass 2 is one v_cmp + ballot per row (a float pre-filter d <= tau_d,
+// exact key test only on the rare rows that pass) instead of recomputing every distance.
+template <int R>
+__global__ __launch_bounds__(KNN_WAVES* PZN_WAVE) void knn32_reg_kernel(
+    const float* __restrict__ xyz, const float* __restrict__ new_xyz, int N, int S, int K, int q_per_block,
+    int64_t* __restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t* cand_all = reinterpret_cast<uint64_t*>(smem_raw);
+  float* sx = reinterpret_cast<float*>(smem_raw + KNN_WAVES * KNN_CAND_CAP * sizeof(uint64_t));
+  const float* sy = sx + N;
+  const float* sz = sy + N;
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int lane = tid & (PZN_WAVE - 1);
+  const int wave = tid / PZN_WAVE;
+  stage_cloud(xyz + (size_t)b * N * 3, N, sx, KNN_WAVES * PZN_WAVE, tid);
+  __syncthreads();
+  uint64_t* cand = cand_all + wave * KNN_CAND_CAP;
+  const int s_begin = blockIdx.x * q_per_block;
+  const int s_end = min(S, s_begin + q_per_block);
+
+  for (int s = s_begin + wave; s < s_end; s += KNN_WAVES) {
+    const float* q = new_xyz + ((size_t)b * S + s) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    float d[R];
+    float md = INFINITY;
+    int mi = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int j = r * PZN_WAVE + lane;
+      float v = INFINITY;
+      if (j < N) v = pzn::sqdist3(qx, qy, qz, sx[j], sy[j], sz[j]);
+      d[r] = v;
+      bool lt = v < md;  // strict: the lowest index of equal distances stays (rows ascend with the index)
+      md = lt ? v : md;
+      mi = lt ? j : mi;
+    }
+    const uint64_t lmin = md < INFINITY ? (((uint64_t)__float_as_uint(md) << 32) | (uint32_t)mi) : ~0ull;
+    uint64_t best = bitonic_sort64(lmin, lane);
+    uint64_t tau = bcast_u64(best, 31);
+    float tau_d = __uint_as_float((uint32_t)(tau >> 32));
+
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (__ballot(d[r] <= tau_d) == 0) continue;  // the common case: nobody in this row can matter
+      int j = r * PZN_WAVE + lane;
+      uint64_t key = ((uint64_t)__float_as_uint(d[r]) << 32) | (uint32_t)j;
+      bool pred = d[r] < INFINITY && key < tau && key != lmin;
+      unsigned long long mask = __ballot(pred);
+      if (mask == 0) continue;
+      int pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+      if (pred) cand[pos] = key;
+      cnt += __popcll(mask);
+      while (cnt >= 32) {
+        __builtin_amdgcn_wave_barrier();
+        uint64_t c = lane >= 32 ? cand[lane - 32] : best;
+        best = bitonic_sort64(c, lane);
+        tau = bcast_u64(best, 31);
+        tau_d = __uint_as_float((uint32_t)(tau >> 32));
         uint64_t mv = (lane + 32 < cnt) ? cand[lane + 32] : 0;
         __builtin_amdgcn_wave_barrier();
         if (lane + 32 < cnt) cand[lane] = mv;
@@ -285,9 +399,27 @@ PZN_EXPORT int pzn_knn_f32(const float* xyz, const float* new_xyz, int B, int N,
   hipStream_t st = pzn_hip_stream(stream);
   if (K <= 32) {
     Geometry g = geometry(B, N, S, KNN_WAVES * KNN_CAND_CAP * sizeof(uint64_t));
-    if (set_lds(&knn32_kernel, g.lds) != PZN_OK) return PZN_ELAUNCH;
-    hipLaunchKernelGGL(knn32_kernel, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
-                       g.q_per_block, idx, g.use_lds);
+    const int rows = (N + PZN_WAVE - 1) / PZN_WAVE;
+#define PZN_KNN_REG(RR)                                                                                          \
+  do {                                                                                                           \
+    if (set_lds(&knn32_reg_kernel<RR>, g.lds) != PZN_OK) return PZN_ELAUNCH;                                     \
+    hipLaunchKernelGGL((knn32_reg_kernel<RR>), g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K, \
+                       g.q_per_block, idx);                                                                      \
+  } while (0)
+    if (g.use_lds && N >= 64 && rows <= 8)
+      PZN_KNN_REG(8);
+    else if (g.use_lds && N >= 64 && rows <= 16)
+      PZN_KNN_REG(16);
+    else if (g.use_lds && N >= 64 && rows <= 32)
+      PZN_KNN_REG(32);
+    else if (g.use_lds && N >= 64 && rows <= 64)
+      PZN_KNN_REG(64);
+    else {
+      if (set_lds(&knn32_kernel, g.lds) != PZN_OK) return PZN_ELAUNCH;
+      hipLaunchKernelGGL(knn32_kernel, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
+                         g.q_per_block, idx, g.use_lds);
+    }
+#undef PZN_KNN_REG
   } else {
     Geometry g = geometry(B, N, S, 0);
     if (set_lds(&knn_any_kernel, g.lds) != PZN_OK) return PZN_ELAUNCH;
