@@ -27,11 +27,35 @@
 // "Generators" synthesise the A operand on the fly so that sparse / masked gradients are
 // never materialised:  dY * (Y > 0)  (ReLU backward)  and the max-pool scatter
 // dy[g*32 + k, c] = (argmax[g,c] == k && out[g,c] > 0) ? dOut[g,c] : 0.
+#include <stdlib.h>
+
 #include "pzn_common.h"
 
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// ---- split precision ("bf16x3") -------------------------------------------------------------
+// x = x1 + x2 + x3 exactly, each xi a bf16 (8 significant bits, fp32's exponent range): x1 = bf16(x),
+// x2 = bf16(x - x1), x3 = bf16(x - x1 - x2).  a*b is then summed from the six products whose magnitude is
+// >= 2^-16 of the leading one: (1,1) (1,2) (2,1) (1,3) (2,2) (3,1); the three dropped ones are <= 2^-24
+// relative, i.e. below fp32 rounding.  Each product of two bf16 is exact in fp32 and the MFMA accumulates
+// in fp32, so the result has fp32-GEMM accuracy — at 6 v_mfma_f32_32x32x16_bf16 (32 cycles for 16 k) against
+// 8 v_mfma_f32_32x32x2_f32 (64 cycles for 2 k): 2.67x the matrix-pipe throughput.
+__device__ __forceinline__ uint32_t f2bf(float x) {
+  __bf16 b = (__bf16)x;  // v_cvt_pk_bf16_f32, round to nearest even
+  return (uint32_t)__builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ void split3(float x, uint32_t& a, uint32_t& b, uint32_t& c) {
+  a = f2bf(x);
+  float r = x - bf2f(a);
+  b = f2bf(r);
+  float r2 = r - bf2f(b);
+  c = f2bf(r2);
+}
 
 constexpr int BK = 16;
 constexpr int GT = 256;  // threads per block
@@ -101,6 +125,39 @@ struct Loader {
 
   __device__ __forceinline__ void fetch(const GemmArgs& p, bool isA, const float* base, int ld, int R, int r0,
                                         int k0, int Kend, bool vec_ok, int tid) {
+    // Interior tiles (all but the last row/K tile of a problem): one workgroup-uniform branch, then
+    // straight-line 16-byte loads — no per-element bounds tests, no exec-mask divergence.
+    if (vec_ok && r0 + BR <= R && k0 + BK <= Kend) {
+      const int gen = isA ? p.gen : GEN_NONE;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int f = tid + i * GT;
+        const int rr = KC ? r0 + f / (BK / 4) : r0 + (f % (BR / 4)) * 4;
+        const int kk = KC ? k0 + (f % (BK / 4)) * 4 : k0 + f / (BR / 4);
+        if (gen == GEN_MAXPOOL) {
+          const long r = KC ? rr : kk;
+          const long off = (r >> 5) * ld + (KC ? kk : rr);
+          const float4 d = *reinterpret_cast<const float4*>(base + off);
+          const float4 o = *reinterpret_cast<const float4*>(p.genOut + off);
+          const int4 a = *reinterpret_cast<const int4*>(p.genArg + off);
+          const int rl = (int)(r & 31);
+          v[i] = make_float4((a.x == rl && o.x > 0.f) ? d.x : 0.f, (a.y == rl && o.y > 0.f) ? d.y : 0.f,
+                             (a.z == rl && o.z > 0.f) ? d.z : 0.f, (a.w == rl && o.w > 0.f) ? d.w : 0.f);
+        } else {
+          const long off = KC ? (long)rr * ld + kk : (long)kk * ld + rr;
+          float4 d = *reinterpret_cast<const float4*>(base + off);
+          if (gen == GEN_RELU) {
+            const float4 y = *reinterpret_cast<const float4*>(p.genY + off);
+            d.x = y.x > 0.f ? d.x : 0.f;
+            d.y = y.y > 0.f ? d.y : 0.f;
+            d.z = y.z > 0.f ? d.z : 0.f;
+            d.w = y.w > 0.f ? d.w : 0.f;
+          }
+          v[i] = d;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int f = tid + i * GT;
@@ -182,6 +239,50 @@ struct Loader {
     }
   }
 
+  // bf16x3 image: three planes of BR x 16 bf16, each in MFMA-fragment order: the 16-byte chunk of
+  // (row r, k-half h) sits at chunk index (r/32 * 2 + h) * 32 + r % 32, so a wave's fragment read for one
+  // 32-row tile is 64 consecutive chunks (lane = h*32 + r%32): conflict-free ds_read_b128, no padding.
+  __device__ __forceinline__ void store_x3(unsigned char* img, int tid) const {
+    constexpr int PLANE = KC ? BR * 32 : 16 * (BR + 32) * 2;  // bytes
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int f = tid + i * GT;
+      float t[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+      uint32_t a[4], b[4], c[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split3(t[e], a[e], b[e], c[e]);
+      if (KC) {  // 4 consecutive k of one row: one 8-byte store per plane
+        int r = f / (BK / 4), kq = (f % (BK / 4)) * 4;
+        int off = (((r >> 5) * 2 + (kq >> 3)) * 32 + (r & 31)) * 16 + (kq & 7) * 2;
+        *reinterpret_cast<uint2*>(img + off) = make_uint2(a[0] | (a[1] << 16), a[2] | (a[3] << 16));
+        *reinterpret_cast<uint2*>(img + PLANE + off) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
+        *reinterpret_cast<uint2*>(img + 2 * PLANE + off) = make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16));
+      } else {  // 4 consecutive rows at one k: k-major plane [16][BR+32] bf16, one 8-byte store per plane;
+                // the fragment is produced at read time by ds_read_b64_tr_b16 (hardware transpose)
+        int k = f / (BR / 4), r0 = (f % (BR / 4)) * 4;
+        int off = (k * (BR + 32) + r0) * 2;
+        *reinterpret_cast<uint2*>(img + off) = make_uint2(a[0] | (a[1] << 16), a[2] | (a[3] << 16));
+        *reinterpret_cast<uint2*>(img + PLANE + off) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
+        *reinterpret_cast<uint2*>(img + 2 * PLANE + off) = make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16));
+      }
+    }
+  }
+
+  // One bf16 MFMA fragment (8 consecutive k of row tile_row + lane%32, k-half lane/32) from plane `pl`.
+  __device__ __forceinline__ static bf16x8 read_frag(const unsigned char* pl, int tile_row, int lane) {
+    if (KC) return *reinterpret_cast<const bf16x8*>(pl + ((tile_row >> 5) * 64 + lane) * 16);
+    // k-major image: each 16-lane group transposes a 4(k) x 16(rows) block per read; lane 4q+p of the group
+    // supplies the address of k-row q, rows 4p..4p+3 and receives the 4 k-values of row `i`.
+    const int g = lane >> 4, i = lane & 15;
+    const int krow = 8 * (g >> 1) + (i >> 2);
+    const int col = tile_row + 16 * (g & 1) + 4 * (i & 3);
+    const unsigned char* a0 = pl + (krow * (BR + 32) + col) * 2;
+    typedef bf16x4 __attribute__((address_space(3))) * lds4_t;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(a0));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(a0 + 4 * (BR + 32) * 2));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+
   __device__ __forceinline__ void store(float (*S)[BR + PAD], int tid) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -200,12 +301,15 @@ struct Loader {
   }
 };
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, bool X3>
 __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(WM * WN == GT / PZN_WAVE, "4 waves");
   // ONE LDS array: operand images during the K loop, per-wave 32 x 64 staging tiles in the epilogue.
-  constexpr int A_ELEMS = 2 * BK * (BM + PAD), B_ELEMS = 2 * BK * (BN + PAD);
+  // fp32 images: k-major [2][BK][rows+PAD] floats; bf16x3 images: [2][3 planes][rows*16] bf16 = rows*24 floats/buffer.
+  constexpr int A_PLANE = A_KC ? BM * 32 : 16 * (BM + 32) * 2, B_PLANE = B_KC ? BN * 32 : 16 * (BN + 32) * 2;  // bytes
+  constexpr int A_ELEMS = X3 ? 2 * 3 * A_PLANE / 4 : 2 * BK * (BM + PAD);
+  constexpr int B_ELEMS = X3 ? 2 * 3 * B_PLANE / 4 : 2 * BK * (BN + PAD);
   constexpr int STG_LD = 64 + PAD, STG_ELEMS = (GT / PZN_WAVE) * 32 * STG_LD;
   constexpr int SMEM_ELEMS = A_ELEMS + B_ELEMS > STG_ELEMS ? A_ELEMS + B_ELEMS : STG_ELEMS;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_ELEMS];
@@ -255,37 +359,118 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
   lb.fetch(p, false, B, p.ldb, p.N, n0, kbeg, kend, b_vec, tid);
   if (do_bias) la.accumulate(bsum);
   if (do_side) la.accumulate_side(ssum, p.side, p.ld_side, kbeg, kend, tid);
-  la.store(As[0], tid);
-  lb.store(Bs[0], tid);
+  unsigned char* imgA = reinterpret_cast<unsigned char*>(smem);               // bf16x3: [2][3][A_PLANE]
+  unsigned char* imgB = reinterpret_cast<unsigned char*>(smem + A_ELEMS);     //         [2][3][B_PLANE]
+  if (X3) {
+    la.store_x3(imgA, tid);
+    lb.store_x3(imgB, tid);
+  } else {
+    la.store(As[0], tid);
+    lb.store(Bs[0], tid);
+  }
   __syncthreads();
 
   const int nkt = (kend - kbeg + BK - 1) / BK;
   const int half = lane >> 5, l31 = lane & 31;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) {
-      la.fetch(p, true, A, p.lda, p.M, m0, kbeg + (kt + 1) * BK, kend, a_vec, tid);
-      lb.fetch(p, false, B, p.ldb, p.N, n0, kbeg + (kt + 1) * BK, kend, b_vec, tid);
+  if (X3) {
+    // Software pipeline, two tiles deep:  LDS[cur] = tile kt (converted), registers = tile kt+1 (raw fp32,
+    // loads issued one iteration ago), and tile kt+2's loads are issued at the end of the iteration.
+    // The fp32 -> 3 x bf16 split of tile kt+1 (~110 VALU + 6 ds_write per thread) is interleaved with
+    // the 24 MFMAs of tile kt (sched_group_barrier): it runs in the shadow of the matrix pipe.
+    // register sets: (la, lb) and (la2, lb2) alternate between "landed tile kt+1, being converted" and
+    // "tile kt+2, loads in flight": the loads get a whole K-step of MFMA time to land.
+    Loader<BM, A_KC> la2;
+    Loader<BN, B_KC> lb2;
+    if (nkt > 1) {
+      la.fetch(p, true, A, p.lda, p.M, m0, kbeg + BK, kend, a_vec, tid);
+      lb.fetch(p, false, B, p.ldb, p.N, n0, kbeg + BK, kend, b_vec, tid);
     }
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[cur][kk + half][wm * (BM / WM) + i * 32 + l31];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[cur][kk + half][wn * (BN / WN) + j * 32 + l31];
+    auto mma_tile = [&](int cur, bool convert_next, Loader<BM, A_KC>& ca_regs, Loader<BN, B_KC>& cb_regs) {
+      const unsigned char* ca = imgA + cur * (3 * A_PLANE);
+      const unsigned char* cb = imgB + cur * (3 * B_PLANE);
+      bf16x8 af[TM][3], bf[TN][3];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int q = 0; q < 3; ++q) af[i][q] = Loader<BM, A_KC>::read_frag(ca + q * A_PLANE, wm * (BM / WM) + i * 32, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bf[j][q] = Loader<BN, B_KC>::read_frag(cb + q * B_PLANE, wn * (BN / WN) + j * 32, lane);
+      if (convert_next) {  // compile-time constant at every call site: no branch inside the scheduled region
+        ca_regs.store_x3(imgA + (cur ^ 1) * (3 * A_PLANE), tid);
+        cb_regs.store_x3(imgB + (cur ^ 1) * (3 * B_PLANE), tid);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          floatx16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);  // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+      if (convert_next) {
+#pragma unroll
+        for (int g = 0; g < TM * TN * 6; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // five VALU
+          if ((g & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // one DS write
+        }
+      }
+    };
+    auto step = [&](int kt, Loader<BM, A_KC>& xa, Loader<BN, B_KC>& xb, Loader<BM, A_KC>& ya, Loader<BN, B_KC>& yb) {
+      if (kt + 2 < nkt) {  // tile kt+2 -> the free register set, a full K-step ahead of its use
+        ya.fetch(p, true, A, p.lda, p.M, m0, kbeg + (kt + 2) * BK, kend, a_vec, tid);
+        yb.fetch(p, false, B, p.ldb, p.N, n0, kbeg + (kt + 2) * BK, kend, b_vec, tid);
+      }
+      if (do_bias) xa.accumulate(bsum);
+      if (do_side) xa.accumulate_side(ssum, p.side, p.ld_side, kbeg + (kt + 1) * BK, kend, tid);
+      mma_tile(kt & 1, true, xa, xb);
+      __syncthreads();
+    };
+    int kt = 0;
+    for (; kt + 2 < nkt; kt += 2) {
+      step(kt, la, lb, la2, lb2);
+      step(kt + 1, la2, lb2, la, lb);
     }
     if (kt + 1 < nkt) {
-      if (do_bias) la.accumulate(bsum);
-      if (do_side) la.accumulate_side(ssum, p.side, p.ld_side, kbeg + (kt + 1) * BK, kend, tid);
-      la.store(As[cur ^ 1], tid);
-      lb.store(Bs[cur ^ 1], tid);
+      step(kt, la, lb, la2, lb2);
+      ++kt;
     }
+    mma_tile((nkt - 1) & 1, false, la, lb);
     __syncthreads();
+  } else {
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nkt) {
+        la.fetch(p, true, A, p.lda, p.M, m0, kbeg + (kt + 1) * BK, kend, a_vec, tid);
+        lb.fetch(p, false, B, p.ldb, p.N, n0, kbeg + (kt + 1) * BK, kend, b_vec, tid);
+      }
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = As[cur][kk + half][wm * (BM / WM) + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Bs[cur][kk + half][wn * (BN / WN) + j * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (kt + 1 < nkt) {
+        if (do_bias) la.accumulate(bsum);
+        if (do_side) la.accumulate_side(ssum, p.side, p.ld_side, kbeg + (kt + 1) * BK, kend, tid);
+        la.store(As[cur ^ 1], tid);
+        lb.store(Bs[cur ^ 1], tid);
+      }
+      __syncthreads();
+    }
   }
   if (!A_KC && blockIdx.x == 0 && (p.bias_grad != nullptr || p.side != nullptr)) {  // (uniform over the workgroup)
     // 8 threads (lane, lane+32 in each of the 4 waves) hold partial sums of the same 4 rows:
@@ -414,10 +599,28 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
   }
 }
 
+// Which matrix-core path a launch takes.  Default "auto": bf16x3 split precision where it is faster
+// (operands whose reduction index is contiguous in memory stage with 8-byte LDS stores: forward NT and
+// input-gradient NN products), exact-fp32 MFMA for the weight-gradient TN products (both operands need the
+// transposing path, which today costs more than the matrix pipe saves).  PZN_GEMM_PRECISION=f32 | x3 | auto.
+int g_precision = -1;  // -1: not decided yet (environment, else auto)
+int gemm_precision() {
+  if (g_precision < 0) {
+    const char* e = getenv("PZN_GEMM_PRECISION");
+    g_precision = (e && (e[0] == 'f' || e[0] == 'F')) ? 0 : (e && (e[0] == 'x' || e[0] == 'X')) ? 1 : 2;
+  }
+  return g_precision;
+}
+
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI>
 void launch_cfg(const GemmArgs& p, int batch, hipStream_t st) {
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splits > 1 ? p.splits : batch);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI>), grid, dim3(GT), 0, st, p);
+  const int mode = gemm_precision();
+  const bool x3 = mode == 1 || (mode == 2 && A_KC);
+  if (x3)
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI, true>), grid, dim3(GT), 0, st, p);
+  else
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI, false>), grid, dim3(GT), 0, st, p);
 }
 
 template <bool A_KC, bool B_KC, int EPI>
@@ -699,3 +902,12 @@ PZN_EXPORT int pzn_sa_mlp_max_bwd_f32(const float* xg, const float* W1p, const f
   }
   return PZN_OK;
 }
+
+// 0 = exact-fp32 MFMA everywhere, 1 = bf16x3 split precision everywhere, 2 = auto (default; see gemm.hip).
+// Process-wide setting read at launch time; also settable with PZN_GEMM_PRECISION=f32|x3|auto.
+PZN_EXPORT int pzn_gemm_set_precision(int mode) {
+  PZN_CHECK_ARG(mode >= 0 && mode <= 2);
+  g_precision = mode;
+  return PZN_OK;
+}
+PZN_EXPORT int pzn_gemm_get_precision(void) { return gemm_precision(); }

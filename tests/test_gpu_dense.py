@@ -17,6 +17,17 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=["auto", "f32", "x3"])
+def precision(request):
+    """Run the dense tests on every matrix-core path (exact fp32 MFMA, bf16x3 split precision, auto)."""
+    from puzzlenet_amd import _lib
+    lib = _lib.load()
+    old = lib.pzn_gemm_get_precision()
+    _lib.check(lib.pzn_gemm_set_precision({"f32": 0, "x3": 1, "auto": 2}[request.param]), "set_precision")
+    yield request.param
+    lib.pzn_gemm_set_precision(old)
+
+
 def _rel(a, b):
     a = a.detach().cpu().double()
     b = b.detach().cpu().double()
@@ -27,7 +38,7 @@ def _rel(a, b):
     (4096, 64, 128, True, True), (1000, 67, 128, True, True), (777, 131, 256, False, True),
     (64, 2048, 1024, True, True), (64, 256, 6, False, True), (5000, 3, 64, False, True),
     (300, 32, 2, False, True), (256, 1280, 1024, False, False), (129, 128, 64, True, True), (1, 64, 64, False, True)])
-def test_linear_fwd_bwd(dev, M, K, N, relu, bias):
+def test_linear_fwd_bwd(dev, precision, M, K, N, relu, bias):
     from puzzlenet_amd import ops
     g = torch.Generator().manual_seed(M + K + N)
     x = torch.randn(M, K, generator=g)
@@ -62,7 +73,7 @@ def test_linear_nd_input_and_no_grad_paths(dev):
 
 
 @pytest.mark.parametrize("B,S,C0,C1,C2", [(2, 64, 67, 128, 128), (2, 40, 131, 256, 256), (1, 5, 20, 32, 48)])
-def test_shared_mlp_max(dev, B, S, C0, C1, C2):
+def test_shared_mlp_max(dev, precision, B, S, C0, C1, C2):
     from puzzlenet_amd import ops
     g = torch.Generator().manual_seed(C0)
     x = torch.randn(B, S, 32, C0, generator=g)
@@ -82,7 +93,7 @@ def test_shared_mlp_max(dev, B, S, C0, C1, C2):
 
 
 @pytest.mark.parametrize("B,L,dk,dv", [(3, 256, 64, 256), (2, 100, 16, 40), (1, 33, 8, 8)])
-def test_attention(dev, B, L, dk, dv):
+def test_attention(dev, precision, B, L, dk, dv):
     from puzzlenet_amd import ops
     g = torch.Generator().manual_seed(L)
     q, k, v = torch.randn(B, L, dk, generator=g), torch.randn(B, L, dk, generator=g), torch.randn(B, L, dv, generator=g)
@@ -151,7 +162,7 @@ def test_chamfer_identity_and_symmetry(dev):
 
 
 @pytest.mark.parametrize("B,N,S,D,C1,C2", [(2, 300, 40, 64, 128, 128), (2, 128, 24, 128, 256, 256), (1, 64, 5, 8, 16, 24)])
-def test_sa_mlp_max_fused_vs_composed(dev, B, N, S, D, C1, C2):
+def test_sa_mlp_max_fused_vs_composed(dev, precision, B, N, S, D, C1, C2):
     """Fused set-abstraction path == group -> shared MLP -> max composed from fp64 torch ops."""
     from oracle import point_ops as orc
     from puzzlenet_amd import ops
