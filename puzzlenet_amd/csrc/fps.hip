@@ -16,6 +16,8 @@
 //     iteration is enough.
 // The loop is latency-bound by construction (npoint dependent rounds); the
 // launch is B workgroups, i.e. parallel over clouds only.
+#include <stdlib.h>
+
 #include "pzn_common.h"
 
 namespace {
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
       key = j < N ? key : 0ull;
       best = key > best ? key : best;
     }
-    best = pzn::wave_max_u64(best);
+    best = pzn::wave_max_u64_dpp(best);
     uint64_t* sl = slots + (i & 1) * W;
     if (lane == 0) sl[wave] = best;
     __syncthreads();
@@ -130,7 +132,12 @@ PZN_EXPORT int pzn_fps_f32(const float* xyz, int B, int N, int npoint, const int
   if (N <= 256) return launch<256, 1>(xyz, B, N, npoint, start_idx, out_idx, st);
   if (N <= 512) return launch<256, 2>(xyz, B, N, npoint, start_idx, out_idx, st);
   if (N <= 1024) return launch<256, 4>(xyz, B, N, npoint, start_idx, out_idx, st);
-  if (N <= 2048) return launch<512, 4>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 2048) {
+    static const int tsel = [] { const char* e = getenv("PZN_FPS_T"); return e ? atoi(e) : 0; }();  // tuning aid
+    if (tsel == 256) return launch<256, 8>(xyz, B, N, npoint, start_idx, out_idx, st);
+    if (tsel == 1024) return launch<1024, 2>(xyz, B, N, npoint, start_idx, out_idx, st);
+    return launch<512, 4>(xyz, B, N, npoint, start_idx, out_idx, st);
+  }
   if (N <= 4096) return launch<512, 8>(xyz, B, N, npoint, start_idx, out_idx, st);
   if (N <= 8192) return launch<1024, 8>(xyz, B, N, npoint, start_idx, out_idx, st);
   if (N <= 16384) return launch<1024, 16>(xyz, B, N, npoint, start_idx, out_idx, st);

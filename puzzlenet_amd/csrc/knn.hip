@@ -28,25 +28,9 @@ namespace {
 constexpr int KNN_WAVES = 4;
 constexpr int KNN_CAND_CAP = 96;  // >= 32 + 63 rounded up
 
-// lane i <- lane i^J for one dword.  J = 1, 2, 4, 8 are DPP modifiers on a v_mov (no LDS round trip):
-// quad_perm for 1 and 2, row_half_mirror (i^7) followed by quad_perm [3,2,1,0] (i^3) for 4,
-// row_ror:8 for 8; J = 16 is a ds_swizzle (bit mode, no address VGPR); only J = 32 pays a ds_bpermute.
-template <int J>
-__device__ __forceinline__ uint32_t xor_lane(uint32_t v) {
-  if (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
-  if (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
-  if (J == 4) {
-    int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, t, 0x1B, 0xF, 0xF, true);
-  }
-  if (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);
-  if (J == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (16 << 10) | 0x1F);
-  return (uint32_t)__shfl_xor((int)v, 32, PZN_WAVE);
-}
-
 template <int K, int J>
 __device__ __forceinline__ uint64_t bitonic_step(uint64_t v, int lane) {
-  uint32_t lo = xor_lane<J>((uint32_t)v), hi = xor_lane<J>((uint32_t)(v >> 32));
+  uint32_t lo = pzn::xor_lane<J>((uint32_t)v), hi = pzn::xor_lane<J>((uint32_t)(v >> 32));
   uint64_t o = ((uint64_t)hi << 32) | lo;
   bool keepmin = ((lane & J) == 0) == ((lane & K) == 0);
   bool olt = o < v;

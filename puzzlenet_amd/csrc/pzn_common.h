@@ -48,6 +48,39 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
   return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
+// lane i <- lane i^J for one dword.  J = 1, 2, 4, 8 are DPP modifiers on a v_mov (no LDS round trip):
+// quad_perm for 1 and 2, row_half_mirror (i^7) followed by quad_perm [3,2,1,0] (i^3) for 4,
+// row_ror:8 for 8; J = 16 is a ds_swizzle (bit mode, no address VGPR); only J = 32 pays a ds_bpermute.
+template <int J>
+__device__ __forceinline__ uint32_t xor_lane(uint32_t v) {
+  if (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+  if (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+  if (J == 4) {
+    int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, t, 0x1B, 0xF, 0xF, true);
+  }
+  if (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);
+  if (J == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (16 << 10) | 0x1F);
+  return (uint32_t)__shfl_xor((int)v, 32, PZN_WAVE);
+}
+
+template <int J>
+__device__ __forceinline__ uint64_t xor_lane_u64(uint64_t v) {
+  return ((uint64_t)xor_lane<J>((uint32_t)(v >> 32)) << 32) | xor_lane<J>((uint32_t)v);
+}
+
+// 64-lane max of a u64 key: five DPP / swizzle steps and one bpermute instead of six bpermute pairs
+__device__ __forceinline__ uint64_t wave_max_u64_dpp(uint64_t v) {
+  uint64_t o;
+  o = xor_lane_u64<1>(v), v = o > v ? o : v;
+  o = xor_lane_u64<2>(v), v = o > v ? o : v;
+  o = xor_lane_u64<4>(v), v = o > v ? o : v;
+  o = xor_lane_u64<8>(v), v = o > v ? o : v;
+  o = xor_lane_u64<16>(v), v = o > v ? o : v;
+  o = xor_lane_u64<32>(v), v = o > v ? o : v;
+  return v;
+}
+
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
   uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
   lo = __shfl_xor(lo, mask, PZN_WAVE);

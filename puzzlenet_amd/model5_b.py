@@ -120,20 +120,25 @@ class PCTransformer_nonsort(nn.Module):
 
     fused_sa = True     # False: literally sample_and_group -> [B,S,K,3+D] -> shared MLP, as the reference composes it
 
-    def _set_abstraction(self, npoint, nsample, xyz, feat, lin_a, lin_b):
-        """sample_and_group(npoint, 0, nsample, xyz, feat, knn=True) + relu(lin_a) + relu(lin_b) + max over K."""
-        fps_idx = self.fps(xyz, npoint)                                   # pointnet_util.py:113
-        new_xyz = ops.index_points(xyz, fps_idx)                          # :115
-        idx = ops.knn(xyz, new_xyz, nsample)                              # :118-119
+    def _set_abstraction(self, npoint, nsample, xyz, feat, lin_a, lin_b, plan=None):
+        """sample_and_group(npoint, 0, nsample, xyz, feat, knn=True) + relu(lin_a) + relu(lin_b) + max over K.
+        `plan` = (new_xyz, idx) when the sampling / neighbour search was already done (sa_plan)."""
+        if plan is None:
+            fps_idx = self.fps(xyz, npoint)                               # pointnet_util.py:113
+            new_xyz = ops.index_points(xyz, fps_idx)                      # :115
+            idx = ops.knn(xyz, new_xyz, nsample)                          # :118-119
+        else:
+            new_xyz, idx = plan
         return new_xyz, dense.sa_mlp_max(xyz, feat, new_xyz, idx, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias)
 
-    def forward(self, xyz):
+    def forward(self, xyz, sa_plan=None):
         x_feature = F.relu(self.bn1(dense.linear(xyz, self.mlp1.weight, self.mlp1.bias)))          # :447
         x_feature = F.relu(self.bn2(dense.linear(x_feature, self.mlp2.weight, self.mlp2.bias)))   # :448
         if self.fused_sa and not xyz.requires_grad:
             # :449-461 with the grouping folded into the shared MLP (same FPS draw order as sample_and_group)
-            x, f1f = self._set_abstraction(512, 32, xyz, x_feature, self.mlp3, self.mlp4)
-            x2, f2f = self._set_abstraction(256, 32, x, f1f, self.mlp5, self.mlp6)
+            p1, p2 = sa_plan if sa_plan is not None else (None, None)
+            x, f1f = self._set_abstraction(512, 32, xyz, x_feature, self.mlp3, self.mlp4, p1)
+            x2, f2f = self._set_abstraction(256, 32, x, f1f, self.mlp5, self.mlp6, p2)
         else:
             x, f1 = self.sg1(512, 0, 32, xyz, x_feature, False, True)                             # :449
             f1f = dense.shared_mlp_max(f1, self.mlp3.weight, self.mlp3.bias, self.mlp4.weight, self.mlp4.bias)  # :452-454
@@ -204,9 +209,10 @@ class TouchedRegraster(_Base):
             mrpc = mrpc.unsqueeze(0)
         N = fpc.shape[1]
 
-        ffpcs = self.Encoder(fpc)                                                   # :710
+        plan_f, plan_m = self._sa_plans(fpc, mrpc)
+        ffpcs = self.Encoder(fpc, plan_f)                                           # :710
         ffpc, non_sg_ffpc = ffpcs[0], ffpcs[4]
-        fmrpcs = self.Encoder2(mrpc)                                                # :716
+        fmrpcs = self.Encoder2(mrpc, plan_m)                                        # :716
         fmrpc, non_sg_fmrpc = fmrpcs[0], fmrpcs[4]
 
         f = torch.cat([ffpc, fmrpc], dim=-1)                                        # :723
@@ -227,6 +233,34 @@ class TouchedRegraster(_Base):
 
     def forward(self, batch, bat=None):
         return self.predict5(batch, bat)
+
+    def _sa_plans(self, fpc, mrpc):
+        """FPS -> gather -> kNN of BOTH set-abstraction levels for BOTH clouds, hoisted in front of the
+        encoders: the sampling chain depends on coordinates only, so the two encoders' 64-workgroup,
+        latency-bound FPS launches become one 128-workgroup launch per level (same wall time each), and
+        kNN runs twice instead of four times.  The four start-index draws are made first, in the
+        reference's order (Encoder sg1, sg2, Encoder2 sg1, sg2; pointnet_util.py:65), so a seeded run
+        picks exactly the points the reference picks."""
+        if not (self.Encoder.fused_sa and self.Encoder2.fused_sa) or fpc.requires_grad or mrpc.requires_grad \
+                or fpc.shape != mrpc.shape:
+            return None, None
+        B, N, _ = fpc.shape
+        dev = fpc.device
+        if pu._FEED is not None:
+            d1, d2 = pu._FEED.next(B, N, dev), pu._FEED.next(B, 512, dev)
+            d3, d4 = pu._FEED.next(B, N, dev), pu._FEED.next(B, 512, dev)
+        else:
+            d1, d2 = torch.randint(0, N, (B,), dtype=torch.long), torch.randint(0, 512, (B,), dtype=torch.long)
+            d3, d4 = torch.randint(0, N, (B,), dtype=torch.long), torch.randint(0, 512, (B,), dtype=torch.long)
+            d1, d2, d3, d4 = (t.to(dev) for t in (d1, d2, d3, d4))
+        xyz = torch.cat([fpc, mrpc], dim=0)
+        f1 = ops.farthest_point_sample(xyz, 512, torch.cat([d1, d3]))
+        x1 = ops.index_points(xyz, f1)
+        i1 = ops.knn(xyz, x1, 32)
+        f2 = ops.farthest_point_sample(x1, 256, torch.cat([d2, d4]))
+        x2 = ops.index_points(x1, f2)
+        i2 = ops.knn(x1, x2, 32)
+        return ((x1[:B], i1[:B]), (x2[:B], i2[:B])), ((x1[B:], i1[B:]), (x2[B:], i2[B:]))
 
     # ------------------------------------------------------------------ losses
     def chamfer_loss(self, a, b):
