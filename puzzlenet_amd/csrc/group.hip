@@ -268,7 +268,12 @@ __global__ __launch_bounds__(256) void group_pad_direct_kernel(const float* __re
   const int wave = threadIdx.x / PZN_WAVE;
   const int V = D >> 2, W4 = 1 + V;  // float4 per row
   const long q_stride = (long)gridDim.x * 4;
-  for (long qi = (long)blockIdx.x * 4 + wave; qi < total_q; qi += q_stride) {
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Give each
+  // XCD a contiguous run of queries, i.e. whole clouds: a cloud's feature table (N*D*4 B <= 1 MB) is read
+  // S*K/N = 8 times by its own queries, and that reuse should hit ONE 4 MB L2 instead of eight.
+  const int nb = gridDim.x;
+  const int vb = (nb & 7) == 0 ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  for (long qi = (long)vb * 4 + wave; qi < total_q; qi += q_stride) {
     const long b = qi / S;
     const float4* cf = reinterpret_cast<const float4*>(feat + (size_t)b * N * D);
     float4* o4 = reinterpret_cast<float4*>(out) + qi * K * W4;
@@ -297,6 +302,7 @@ PZN_EXPORT int pzn_group_pad_fwd_f32(const float* xyz, const float* feat, const 
   long blocks = (total_q + 3) / 4;
   long cap = 256L * 16;
   int grid = (int)(blocks < cap ? blocks : cap);
+  if (grid >= 64) grid &= ~7;  // multiple of 8 for the XCD remap (the grid-stride loop covers the remainder)
   hipLaunchKernelGGL(group_pad_direct_kernel, dim3(grid), dim3(256), 0, pzn_hip_stream(stream), xyz, feat, new_xyz, idx,
                      N, S, K, D, total_q, out);
   PZN_RETURN_LAUNCH_STATUS();

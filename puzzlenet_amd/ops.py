@@ -19,6 +19,7 @@ class KernelTimer:
     for the timed region to price individual kernels (roofline.achieved)."""
     enabled = False
     records = {}
+    flops = {}
 
     @classmethod
     def start(cls):
@@ -30,18 +31,20 @@ class KernelTimer:
         """-> {entry point: (launches, total milliseconds)}; synchronises the device."""
         cls.enabled = False
         torch.cuda.synchronize()
-        out = {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in cls.records.items()}
+        out = {k: (len(v), sum(a.elapsed_time(b) for a, b, _ in v)) for k, v in cls.records.items()}
+        cls.flops = {k: sum(f for _, _, f in v) for k, v in cls.records.items()}
         cls.records = {}
         return out
 
 
-def _call(name, *args):
+def _call(name, *args, flops=0):
+    """Invoke a C-ABI entry point; `flops` = algorithmic 2*M*N*K of the dense entry points (bench accounting)."""
     if KernelTimer.enabled:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         _lib.call(name, *args)
         b.record()
-        KernelTimer.records.setdefault(name, []).append((a, b))
+        KernelTimer.records.setdefault(name, []).append((a, b, flops))
     else:
         _lib.call(name, *args)
 
@@ -331,7 +334,8 @@ class _Linear(torch.autograd.Function):
         M = x2.shape[0]
         y = torch.empty((M, Nout), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            _call("pzn_linear_fwd_f32", _p(x2), _p(weight), _p(bias_c), M, Kin, Nout, int(bool(relu)), _p(y), _stream())
+            _call("pzn_linear_fwd_f32", _p(x2), _p(weight), _p(bias_c), M, Kin, Nout, int(bool(relu)), _p(y), _stream(),
+                  flops=2 * M * Kin * Nout)
         ctx.save_for_backward(x2, weight, y if relu else None)
         ctx.has_bias = bias is not None
         ctx.in_shape = x.shape
@@ -348,12 +352,14 @@ class _Linear(torch.autograd.Function):
         with torch.cuda.device(dev):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty((M, Kin), dtype=torch.float32, device=dev)
-                _call("pzn_linear_dgrad_f32", _p(dy), _p(y), _p(weight), M, Kin, Nout, None, _p(dx), _stream())
+                _call("pzn_linear_dgrad_f32", _p(dy), _p(y), _p(weight), M, Kin, Nout, None, _p(dx), _stream(),
+                      flops=2 * M * Kin * Nout)
                 dx = dx.reshape(ctx.in_shape)
             if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
                 dW = torch.empty((Nout, Kin), dtype=torch.float32, device=dev)
                 db = torch.empty((Nout,), dtype=torch.float32, device=dev) if ctx.has_bias else None
-                _call("pzn_linear_wgrad_f32", _p(dy), _p(y), _p(x2), M, Kin, Nout, _p(dW), _p(db), _stream())
+                _call("pzn_linear_wgrad_f32", _p(dy), _p(y), _p(x2), M, Kin, Nout, _p(dW), _p(db), _stream(),
+                      flops=2 * M * Kin * Nout)
         return dx, dW, db, None
 
 
@@ -418,7 +424,8 @@ class _Attention(torch.autograd.Function):
         attn = torch.empty((B, L, L), dtype=torch.float32, device=dev)
         out = torch.empty((B, L, dv), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _call("pzn_attn_fwd_f32", _p(q), _p(k), _p(v), B, L, dk, dv, _p(attn), _p(out), _stream())
+            _call("pzn_attn_fwd_f32", _p(q), _p(k), _p(v), B, L, dk, dv, _p(attn), _p(out), _stream(),
+                  flops=2 * B * L * L * (dk + dv))
         ctx.save_for_backward(q, k, v, attn)
         return out, attn
 
@@ -434,7 +441,7 @@ class _Attention(torch.autograd.Function):
         ws = torch.empty((B, L, L), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _call("pzn_attn_bwd_f32", _p(q), _p(k), _p(v), _p(attn), _p(d_out), _p(d_attn), B, L, dk, dv,
-                  _p(dq), _p(dk_), _p(dv_), _p(ws), _stream())
+                  _p(dq), _p(dk_), _p(dv_), _p(ws), _stream(), flops=2 * B * L * L * (2 * dk + 2 * dv))
         return dq, dk_, dv_
 
 
@@ -468,7 +475,7 @@ class _SaMlpMax(torch.autograd.Function):
         with torch.cuda.device(dev):
             _call("pzn_group_pad_fwd_f32", _p(xyz), _p(feat), _p(new_xyz), _p(idx), B, N, S, K, D, _p(xg), _stream())
             _call("pzn_sharedmlp_max_fwd_f32", _p(xg), _p(w1p), _p(b1), _p(w2), _p(b2), R, 4 + D, C1, C2,
-                  _p(h), _p(out), _p(arg), _stream())
+                  _p(h), _p(out), _p(arg), _stream(), flops=2 * R * 32 * ((3 + D) * C1 + C1 * C2))
         ctx.save_for_backward(xg, w1p, w2, h, out, arg, idx)
         ctx.dims = (B, N, S, K, D, R, C1, C2)
         return out.reshape(B, S, C2)
@@ -492,7 +499,8 @@ class _SaMlpMax(torch.autograd.Function):
         dfeat = None
         with torch.cuda.device(dev):
             _call("pzn_sa_mlp_max_bwd_f32", _p(xg), _p(w1p), _p(w2), _p(h), _p(out), _p(arg), _p(dout), R, D, C1, C2,
-                  _p(dh), _p(drows), _p(dW1p), _p(db1), _p(dW2), _p(db2), _stream())
+                  _p(dh), _p(drows), _p(dW1p), _p(db1), _p(dW2), _p(db2), _stream(),
+                  flops=2 * R * 32 * (2 * C1 * C2 + (3 + D) * C1 + (D * C1 if need_feat else 0)))
             if need_feat:
                 dfeat = torch.zeros((B, N, D), dtype=torch.float32, device=dev)
                 _call("pzn_group_feat_bwd_f32", _p(drows), _p(idx), B, N, S, K, D, _p(dfeat), _stream())

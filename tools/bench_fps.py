@@ -1,5 +1,5 @@
 import torch, sys, os
-sys.path.insert(0,'.')
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from puzzlenet_amd import ops
 dev=torch.device('cuda:0')
 g=torch.Generator().manual_seed(0)

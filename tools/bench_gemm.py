@@ -1,5 +1,5 @@
 import torch, sys, time
-sys.path.insert(0,'.')
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from puzzlenet_amd import _lib
 lib=_lib.load()
 dev=torch.device('cuda:0')
