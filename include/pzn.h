@@ -191,8 +191,8 @@ int pzn_linear_maxpool_wgrad_f32(const float* dout, const int32_t* argmax,
                                  pzn_stream_t stream);
 /* Matrix-core path of every dense entry point below: 0 = exact fp32 (v_mfma_f32_32x32x2_f32),
  * 1 = bf16x3 split precision (x = x1+x2+x3 in bf16, six v_mfma_f32_32x32x16_bf16 products,
- * fp32 accumulate: fp32-GEMM accuracy at up to 2.67x the matrix-pipe rate), 2 = auto (default:
- * bf16x3 for forward / input-gradient products, fp32 for weight-gradient products).
+ * fp32 accumulate: fp32-GEMM accuracy at up to 2.67x the matrix-pipe rate), 2 = auto (default;
+ * currently bf16x3 for every product).
  * Process-wide; also PZN_GEMM_PRECISION=f32|x3|auto in the environment. */
 int pzn_gemm_set_precision(int mode);
 int pzn_gemm_get_precision(void);

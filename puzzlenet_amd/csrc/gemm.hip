@@ -599,10 +599,8 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
   }
 }
 
-// Which matrix-core path a launch takes.  Default "auto": bf16x3 split precision where it is faster
-// (operands whose reduction index is contiguous in memory stage with 8-byte LDS stores: forward NT and
-// input-gradient NN products), exact-fp32 MFMA for the weight-gradient TN products (both operands need the
-// transposing path, which today costs more than the matrix pipe saves).  PZN_GEMM_PRECISION=f32 | x3 | auto.
+// Which matrix-core path a launch takes: bf16x3 split precision (default, "auto" == "x3" today) or the
+// exact-fp32 MFMA (PZN_GEMM_PRECISION=f32, pzn_gemm_set_precision(0)) — same results to fp32 rounding.
 int g_precision = -1;  // -1: not decided yet (environment, else auto)
 int gemm_precision() {
   if (g_precision < 0) {
@@ -616,7 +614,7 @@ template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI>
 void launch_cfg(const GemmArgs& p, int batch, hipStream_t st) {
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splits > 1 ? p.splits : batch);
   const int mode = gemm_precision();
-  const bool x3 = mode == 1 || (mode == 2 && A_KC);
+  const bool x3 = mode != 0;  // auto == bf16x3 on every product (the split-K grid is sized for it, choose_splits)
   if (x3)
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI, true>), grid, dim3(GT), 0, st, p);
   else
@@ -644,7 +642,11 @@ GemmArgs base_args(int M, int N, int K) {
 // split the reduction range of a weight-gradient GEMM so that the grid fills the chip
 void choose_splits(GemmArgs& p) {
   long tiles = (long)((p.N + 127) / 128) * ((p.M + 127) / 128);
-  long want = 768 / (tiles > 0 ? tiles : 1);  // ~3 workgroups per CU
+  // one full wave of resident workgroups: the bf16x3 TN kernel holds 61 KB of LDS (2 per CU), the fp32 one 3 per CU;
+  // a grid of 1.5 waves costs as much as 2 (measured: 0.86 -> 0.69 ms on a 256x256x524288 weight gradient)
+  static const long forced = [] { const char* e = getenv("PZN_SPLIT_TARGET"); return e ? atol(e) : 0L; }();  // tuning aid
+  const long target = forced ? forced : (gemm_precision() == 0 ? 768L : 512L);
+  long want = target / (tiles > 0 ? tiles : 1);
   long ksteps = (p.K + BK - 1) / BK;
   long splits = want < 1 ? 1 : want;
   if (splits > ksteps / 16) splits = ksteps / 16;  // >= 16 K-steps (256 rows) per split: the atomic epilogue
