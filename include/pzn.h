@@ -173,11 +173,13 @@ int pzn_linear_dgrad_f32(const float* dy, const float* y_relu, const float* W,
                          int M, int Kin, int Nout, const float* x_relu,
                          float* dx, pzn_stream_t stream);
 /* dW[Nout,Kin] = (dy * [y_relu > 0])^T x,  db[Nout] = its column sums (db may
- * be NULL).  Split over the row range, accumulated with fp32 atomics: both
- * outputs are overwritten; results are reproducible to rounding, not bitwise. */
+ * be NULL).  Split over the row range, accumulated with fp32 atomics: results are
+ * reproducible to rounding, not bitwise.  accumulate == 0: both outputs are overwritten;
+ * accumulate != 0: added to (e.g. directly into a zeroed flat gradient bucket, which
+ * saves the zero-fill launches and autograd's separate "grad += dW" pass). */
 int pzn_linear_wgrad_f32(const float* dy, const float* y_relu, const float* x,
                          int M, int Kin, int Nout, float* dW, float* db,
-                         pzn_stream_t stream);
+                         int accumulate, pzn_stream_t stream);
 /* Backward through the max-pool epilogue: the [R*32,Nout] gradient
  * dy[g*32+k, c] = (argmax[g,c]==k && out[g,c]>0) ? dout[g,c] : 0 is generated
  * inside the operand loader, never materialised. */
@@ -187,7 +189,7 @@ int pzn_linear_maxpool_dgrad_f32(const float* dout, const int32_t* argmax,
                                  pzn_stream_t stream);
 int pzn_linear_maxpool_wgrad_f32(const float* dout, const int32_t* argmax,
                                  const float* out, const float* x, int R, int Kin,
-                                 int Nout, float* dW, float* db,
+                                 int Nout, float* dW, float* db, int accumulate,
                                  pzn_stream_t stream);
 /* Matrix-core path of every dense entry point below: 0 = exact fp32 (v_mfma_f32_32x32x2_f32),
  * 1 = bf16x3 split precision (x = x1+x2+x3 in bf16, six v_mfma_f32_32x32x16_bf16 products,
@@ -215,7 +217,7 @@ int pzn_sharedmlp_max_bwd_f32(const float* x, const float* W1, const float* W2,
                               const int32_t* argmax, const float* dout, int R,
                               int C0, int C1, int C2, float* dh_ws, float* dx,
                               float* dW1, float* db1, float* dW2, float* db2,
-                              pzn_stream_t stream);
+                              int accumulate, pzn_stream_t stream);
 
 /* Model-internal set-abstraction path (the drop-in sample_and_group keeps the reference's
  * [B,S,K,3+D] layout; this one is what model5_b's encoder runs):
@@ -229,13 +231,14 @@ int pzn_group_feat_bwd_f32(const float* rows, const int64_t* idx, int B, int N, 
                            int K, int D, float* grad_feat, pzn_stream_t stream);
 /* Backward of pzn_sharedmlp_max_fwd_f32 run on padded rows xg[R*32,4+D] with
  * W1p[C1,4+D] = {W1[:,0:3], 0, W1[:,3:]} (model5_b.py:452-454 / :459-461 with the grouping of
- * pointnet_util.py:123-132 folded in): dW1p, db1, dW2, db2 overwritten; dfeat_rows[R*32,D]
- * (gradient of the gathered feature block only; may be NULL); dh_ws[R*32,C1] scratch. */
+ * pointnet_util.py:123-132 folded in): dW1 in the PARAMETER layout [C1,3+D]; dW1, db1, dW2,
+ * db2 overwritten (accumulate == 0) or added to; dfeat_rows[R*32,D] (gradient of the gathered
+ * feature block only; may be NULL); dh_ws[R*32,C1] scratch. */
 int pzn_sa_mlp_max_bwd_f32(const float* xg, const float* W1p, const float* W2,
                            const float* h, const float* out, const int32_t* argmax,
                            const float* dout, int R, int D, int C1, int C2, float* dh_ws,
-                           float* dfeat_rows, float* dW1p, float* db1, float* dW2,
-                           float* db2, pzn_stream_t stream);
+                           float* dfeat_rows, float* dW1, float* db1, float* dW2,
+                           float* db2, int accumulate, pzn_stream_t stream);
 
 /* scaled_dot_production of layerAttention, model5_b.py:67-75:
  * attn[B,L,L] = softmax(q[B,L,dk] k[B,L,dk]^T / sqrt(dk)), out[B,L,dv] = attn v.

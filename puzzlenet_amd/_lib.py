@@ -38,17 +38,17 @@ SIGNATURES = {
     "pzn_linear_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_linear_maxpool_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_linear_dgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
-    "pzn_linear_wgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_linear_wgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_i, _c_f]),
     "pzn_linear_maxpool_dgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
-    "pzn_linear_maxpool_wgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_linear_maxpool_wgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_i, _c_f]),
     "pzn_gemm_set_precision": (_c_i, [_c_i]),
     "pzn_gemm_get_precision": (_c_i, []),
     "pzn_bgemm_f32": (_c_i, [_c_i, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_fl, _c_f]),
     "pzn_sharedmlp_max_fwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 4 + [_c_f] * 4),
-    "pzn_sharedmlp_max_bwd_f32": (_c_i, [_c_f] * 7 + [_c_i] * 4 + [_c_f] * 7),
+    "pzn_sharedmlp_max_bwd_f32": (_c_i, [_c_f] * 7 + [_c_i] * 4 + [_c_f] * 6 + [_c_i, _c_f]),
     "pzn_group_pad_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_group_feat_bwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),
-    "pzn_sa_mlp_max_bwd_f32": (_c_i, [_c_f] * 7 + [_c_i] * 4 + [_c_f] * 7),
+    "pzn_sa_mlp_max_bwd_f32": (_c_i, [_c_f] * 7 + [_c_i] * 4 + [_c_f] * 6 + [_c_i, _c_f]),
     "pzn_attn_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_attn_bwd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i]),
     "pzn_attn_bwd_f32": (_c_i, [_c_f] * 6 + [_c_i] * 4 + [_c_f] * 5),

@@ -703,14 +703,17 @@ PZN_EXPORT int pzn_linear_maxpool_dgrad_f32(const float* dout, const int32_t* ar
 }
 
 // dW[Nout,Kin] = dY^T X, db[Nout] = column sums of dY (row sums of the streamed A tiles): both overwritten.
-static int wgrad_common(GemmArgs p, int Kin, int Nout, const float* x, float* dW, float* db, hipStream_t st) {
-  // logical C[Nout, Kin] = sum_r dY[r][n] * X[r][k];  db[n] = sum_r dY[r][n] from the A tiles
+static int wgrad_common(GemmArgs p, int Kin, int Nout, const float* x, float* dW, float* db, int accumulate,
+                        hipStream_t st) {
+  // logical C[Nout, Kin] = sum_r dY[r][n] * X[r][k];  db[n] = sum_r dY[r][n] from the A tiles.
+  // accumulate != 0: add into dW / db as they are (e.g. straight into the flat gradient bucket, which the
+  // step zeroes once) — no zero-fill launches here and no separate "grad += dW" pass afterwards.
   p.B = x, p.ldb = Kin, p.C = dW, p.ldc = Kin;
   if (db) {
     p.bias_grad = db;
-    if (pzn_zero_async(db, (size_t)Nout, st) != PZN_OK) return PZN_ELAUNCH;
+    if (!accumulate && pzn_zero_async(db, (size_t)Nout, st) != PZN_OK) return PZN_ELAUNCH;
   }
-  if (pzn_zero_async(dW, (size_t)Nout * Kin, st) != PZN_OK) return PZN_ELAUNCH;
+  if (!accumulate && pzn_zero_async(dW, (size_t)Nout * Kin, st) != PZN_OK) return PZN_ELAUNCH;
   choose_splits(p);
   if (p.splits == 1) p.splits = 2, p.k_chunk = ((p.K + 2 * BK - 1) / (2 * BK)) * BK;  // keep the atomic epilogue path
   launch<false, false, EPI_ATOMIC>(p, 1, st);
@@ -718,20 +721,21 @@ static int wgrad_common(GemmArgs p, int Kin, int Nout, const float* x, float* dW
 }
 
 PZN_EXPORT int pzn_linear_wgrad_f32(const float* dy, const float* y_relu, const float* x, int M, int Kin, int Nout,
-                                    float* dW, float* db, pzn_stream_t stream) {
+                                    float* dW, float* db, int accumulate, pzn_stream_t stream) {
   PZN_CHECK_ARG(dy && x && dW && M > 0 && Kin > 0 && Nout > 0);
   GemmArgs p = base_args(Nout, Kin, M);
   p.A = dy, p.lda = Nout;
   if (y_relu) p.gen = GEN_RELU, p.genY = y_relu;
-  return wgrad_common(p, Kin, Nout, x, dW, db, pzn_hip_stream(stream));
+  return wgrad_common(p, Kin, Nout, x, dW, db, accumulate, pzn_hip_stream(stream));
 }
 
 PZN_EXPORT int pzn_linear_maxpool_wgrad_f32(const float* dout, const int32_t* argmax, const float* out, const float* x,
-                                            int R, int Kin, int Nout, float* dW, float* db, pzn_stream_t stream) {
+                                            int R, int Kin, int Nout, float* dW, float* db, int accumulate,
+                                            pzn_stream_t stream) {
   PZN_CHECK_ARG(dout && argmax && out && x && dW && R > 0 && Kin > 0 && Nout > 0);
   GemmArgs p = base_args(Nout, Kin, R * 32);
   p.A = dout, p.lda = Nout, p.gen = GEN_MAXPOOL, p.genArg = argmax, p.genOut = out;
-  return wgrad_common(p, Kin, Nout, x, dW, db, pzn_hip_stream(stream));
+  return wgrad_common(p, Kin, Nout, x, dW, db, accumulate, pzn_hip_stream(stream));
 }
 
 // Batched C[b] = alpha * op(A[b]) op(B[b]);  mode 0 = "NT": A[M,K] B[N,K];  1 = "NN": A[M,K] B[K,N];
@@ -855,13 +859,13 @@ PZN_EXPORT int pzn_sharedmlp_max_fwd_f32(const float* x, const float* W1, const 
 PZN_EXPORT int pzn_sharedmlp_max_bwd_f32(const float* x, const float* W1, const float* W2, const float* h,
                                          const float* out, const int32_t* argmax, const float* dout, int R, int C0,
                                          int C1, int C2, float* dh_ws, float* dx, float* dW1, float* db1, float* dW2,
-                                         float* db2, pzn_stream_t stream) {
+                                         float* db2, int accumulate, pzn_stream_t stream) {
   PZN_CHECK_ARG(x && W1 && W2 && h && out && argmax && dout && dh_ws && dW1 && db1 && dW2 && db2);
   int rc = pzn_linear_maxpool_dgrad_f32(dout, argmax, out, W2, R, C1, C2, h, dh_ws, stream);  // dh, ReLU-masked by h
   if (rc != PZN_OK) return rc;
-  rc = pzn_linear_maxpool_wgrad_f32(dout, argmax, out, h, R, C1, C2, dW2, db2, stream);
+  rc = pzn_linear_maxpool_wgrad_f32(dout, argmax, out, h, R, C1, C2, dW2, db2, accumulate, stream);
   if (rc != PZN_OK) return rc;
-  rc = pzn_linear_wgrad_f32(dh_ws, nullptr, x, R * 32, C0, C1, dW1, db1, stream);
+  rc = pzn_linear_wgrad_f32(dh_ws, nullptr, x, R * 32, C0, C1, dW1, db1, accumulate, stream);
   if (rc != PZN_OK) return rc;
   if (dx) rc = pzn_linear_dgrad_f32(dh_ws, nullptr, W1, R * 32, C0, C1, nullptr, dx, stream);
   return rc;
@@ -871,26 +875,29 @@ PZN_EXPORT int pzn_sharedmlp_max_bwd_f32(const float* x, const float* W1, const 
 // forward = pzn_sharedmlp_max_fwd_f32 with C0 = 4+D and W1p[C1,4+D] = {W1[:,0:3], 0, W1[:,3:]}.
 // Backward: feature part of the first layer as clean D-wide GEMMs (no 67/131-wide tiles), the three xyz
 // columns and the bias from the A stream, input gradient only for the D feature columns (xyz needs none).
-//   dh_ws[R*32,C1] scratch; dfeat_rows[R*32,D] may be NULL; dW1p[C1,4+D], db1, dW2, db2 overwritten.
+//   dh_ws[R*32,C1] scratch; dfeat_rows[R*32,D] may be NULL; dW1 is in the PARAMETER layout [C1,3+D];
+//   dW1, db1, dW2, db2 are overwritten, or added to when accumulate != 0.
 PZN_EXPORT int pzn_sa_mlp_max_bwd_f32(const float* xg, const float* W1p, const float* W2, const float* h,
                                       const float* out, const int32_t* argmax, const float* dout, int R, int D, int C1,
-                                      int C2, float* dh_ws, float* dfeat_rows, float* dW1p, float* db1, float* dW2,
-                                      float* db2, pzn_stream_t stream) {
-  PZN_CHECK_ARG(xg && W1p && W2 && h && out && argmax && dout && dh_ws && dW1p && db1 && dW2 && db2);
+                                      int C2, float* dh_ws, float* dfeat_rows, float* dW1, float* db1, float* dW2,
+                                      float* db2, int accumulate, pzn_stream_t stream) {
+  PZN_CHECK_ARG(xg && W1p && W2 && h && out && argmax && dout && dh_ws && dW1 && db1 && dW2 && db2);
   PZN_CHECK_ARG(R > 0 && D > 0 && (D & 3) == 0 && C1 > 0 && C2 > 0);
   hipStream_t st = pzn_hip_stream(stream);
-  const int ldx = 4 + D, M = R * 32;
+  const int ldx = 4 + D, ldw = 3 + D, M = R * 32;
   int rc = pzn_linear_maxpool_dgrad_f32(dout, argmax, out, W2, R, C1, C2, h, dh_ws, stream);  // dh (ReLU-masked by h)
   if (rc != PZN_OK) return rc;
-  rc = pzn_linear_maxpool_wgrad_f32(dout, argmax, out, h, R, C1, C2, dW2, db2, stream);
+  rc = pzn_linear_maxpool_wgrad_f32(dout, argmax, out, h, R, C1, C2, dW2, db2, accumulate, stream);
   if (rc != PZN_OK) return rc;
-  {  // dW1p[:, 4:] = dh^T xg[:, 4:],  dW1p[:, 0:3] and db1 from the streamed dh tiles, dW1p[:, 3] = 0
-    if (pzn_zero_async(dW1p, (size_t)C1 * ldx, st) != PZN_OK) return PZN_ELAUNCH;
-    if (pzn_zero_async(db1, (size_t)C1, st) != PZN_OK) return PZN_ELAUNCH;
+  {  // dW1[:, 3:] = dh^T xg[:, 4:];  dW1[:, 0:3] and db1 from the streamed dh tiles
+    if (!accumulate) {
+      if (pzn_zero_async(dW1, (size_t)C1 * ldw, st) != PZN_OK) return PZN_ELAUNCH;
+      if (pzn_zero_async(db1, (size_t)C1, st) != PZN_OK) return PZN_ELAUNCH;
+    }
     GemmArgs p = base_args(C1, D, M);
-    p.A = dh_ws, p.lda = C1, p.B = xg + 4, p.ldb = ldx, p.C = dW1p + 4, p.ldc = ldx;
+    p.A = dh_ws, p.lda = C1, p.B = xg + 4, p.ldb = ldx, p.C = dW1 + 3, p.ldc = ldw;
     p.bias_grad = db1;
-    p.side = xg, p.ld_side = ldx, p.side_out = dW1p, p.ld_side_out = ldx;
+    p.side = xg, p.ld_side = ldx, p.side_out = dW1, p.ld_side_out = ldw;
     choose_splits(p);
     if (p.splits == 1) p.splits = 2, p.k_chunk = ((p.K + 2 * BK - 1) / (2 * BK)) * BK;
     launch<false, false, EPI_ATOMIC>(p, 1, st);

@@ -43,6 +43,11 @@ class FlatGradAllReduce:
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
+        if self.flat.is_cuda:
+            # let the weight-gradient kernels add straight into the bucket (ops._GRAD_SINKS)
+            from . import ops
+            ops.clear_grad_sinks()
+            ops.register_grad_sinks(self.params)
 
     def zero_(self):
         self.flat.zero_()

@@ -318,6 +318,27 @@ def chamfer(a, b):
 
 # --------------------------------------------------------------------------- dense (MFMA fp32)
 
+# Gradient sinks: parameter storage address -> its (pre-zeroed) gradient tensor.  When a parameter has a
+# sink, the weight-gradient kernels ADD straight into it and the autograd Function returns None for that
+# input: no zero-fill launch, no temporary dW, no separate AccumulateGrad "grad += dW" kernel
+# (~280 small launches per training step).  distributed.FlatGradAllReduce registers the views of its flat
+# bucket; without sinks the Functions return ordinary gradient tensors.
+_GRAD_SINKS = {}
+
+
+def register_grad_sinks(params):
+    for p_ in params:
+        if p_.grad is not None:
+            _GRAD_SINKS[p_.data_ptr()] = p_.grad
+
+
+def clear_grad_sinks():
+    _GRAD_SINKS.clear()
+
+
+def _sink(t, needed):
+    return _GRAD_SINKS.get(t.data_ptr()) if (needed and t is not None) else None
+
 class _Linear(torch.autograd.Function):
     """nn.Linear (+ReLU) on the fp32 matrix-core engine: y = act(x W^T + b)."""
 
@@ -338,6 +359,7 @@ class _Linear(torch.autograd.Function):
                   flops=2 * M * Kin * Nout)
         ctx.save_for_backward(x2, weight, y if relu else None)
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias_c
         ctx.in_shape = x.shape
         return y.reshape(*x.shape[:-1], Nout)
 
@@ -356,10 +378,16 @@ class _Linear(torch.autograd.Function):
                       flops=2 * M * Kin * Nout)
                 dx = dx.reshape(ctx.in_shape)
             if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-                dW = torch.empty((Nout, Kin), dtype=torch.float32, device=dev)
-                db = torch.empty((Nout,), dtype=torch.float32, device=dev) if ctx.has_bias else None
-                _call("pzn_linear_wgrad_f32", _p(dy), _p(y), _p(x2), M, Kin, Nout, _p(dW), _p(db), _stream(),
-                      flops=2 * M * Kin * Nout)
+                sw = _sink(weight, ctx.needs_input_grad[1])
+                sb = _sink(ctx.bias_ref, ctx.has_bias and ctx.needs_input_grad[2])
+                if sw is not None and (sb is not None or not ctx.has_bias):
+                    _call("pzn_linear_wgrad_f32", _p(dy), _p(y), _p(x2), M, Kin, Nout, _p(sw), _p(sb), 1, _stream(),
+                          flops=2 * M * Kin * Nout)
+                else:
+                    dW = torch.empty((Nout, Kin), dtype=torch.float32, device=dev)
+                    db = torch.empty((Nout,), dtype=torch.float32, device=dev) if ctx.has_bias else None
+                    _call("pzn_linear_wgrad_f32", _p(dy), _p(y), _p(x2), M, Kin, Nout, _p(dW), _p(db), 0, _stream(),
+                          flops=2 * M * Kin * Nout)
         return dx, dW, db, None
 
 
@@ -404,7 +432,7 @@ class _SharedMlpMax(torch.autograd.Function):
         db2 = torch.empty((C2,), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _call("pzn_sharedmlp_max_bwd_f32", _p(x), _p(w1), _p(w2), _p(h), _p(out), _p(arg), _p(dout),
-                  R, C0, C1, C2, _p(dh), _p(dx), _p(dW1), _p(db1), _p(dW2), _p(db2), _stream())
+                  R, C0, C1, C2, _p(dh), _p(dx), _p(dW1), _p(db1), _p(dW2), _p(db2), 0, _stream())
         return (None if dx is None else dx.reshape(Bq, S, 32, C0)), dW1, db1, dW2, db2
 
 
@@ -478,6 +506,7 @@ class _SaMlpMax(torch.autograd.Function):
                   _p(h), _p(out), _p(arg), _stream(), flops=2 * R * 32 * ((3 + D) * C1 + C1 * C2))
         ctx.save_for_backward(xg, w1p, w2, h, out, arg, idx)
         ctx.dims = (B, N, S, K, D, R, C1, C2)
+        ctx.param_refs = (w1, b1, w2, b2)
         return out.reshape(B, S, C2)
 
     @staticmethod
@@ -492,19 +521,25 @@ class _SaMlpMax(torch.autograd.Function):
         need_feat = ctx.needs_input_grad[1]
         dh = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
         drows = torch.empty((R * 32, D), dtype=torch.float32, device=dev) if need_feat else None
-        dW1p = torch.empty((C1, 4 + D), dtype=torch.float32, device=dev)
-        db1 = torch.empty((C1,), dtype=torch.float32, device=dev)
-        dW2 = torch.empty_like(w2)
-        db2 = torch.empty((C2,), dtype=torch.float32, device=dev)
+        sinks = [_sink(t, ctx.needs_input_grad[4 + i]) for i, t in enumerate(ctx.param_refs)]
+        direct = all(s_ is not None for s_ in sinks)
+        if direct:
+            dW1, db1, dW2, db2 = sinks
+        else:
+            dW1 = torch.empty((C1, 3 + D), dtype=torch.float32, device=dev)
+            db1 = torch.empty((C1,), dtype=torch.float32, device=dev)
+            dW2 = torch.empty_like(w2)
+            db2 = torch.empty((C2,), dtype=torch.float32, device=dev)
         dfeat = None
         with torch.cuda.device(dev):
             _call("pzn_sa_mlp_max_bwd_f32", _p(xg), _p(w1p), _p(w2), _p(h), _p(out), _p(arg), _p(dout), R, D, C1, C2,
-                  _p(dh), _p(drows), _p(dW1p), _p(db1), _p(dW2), _p(db2), _stream(),
+                  _p(dh), _p(drows), _p(dW1), _p(db1), _p(dW2), _p(db2), int(direct), _stream(),
                   flops=2 * R * 32 * (2 * C1 * C2 + (3 + D) * C1 + (D * C1 if need_feat else 0)))
             if need_feat:
                 dfeat = torch.zeros((B, N, D), dtype=torch.float32, device=dev)
                 _call("pzn_group_feat_bwd_f32", _p(drows), _p(idx), B, N, S, K, D, _p(dfeat), _stream())
-        dW1 = torch.cat([dW1p[:, :3], dW1p[:, 4:]], dim=1)
+        if direct:
+            return None, dfeat, None, None, None, None, None, None
         return None, dfeat, None, None, dW1, db1, dW2, db2
 
 

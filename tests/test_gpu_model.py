@@ -149,3 +149,36 @@ def test_training_step_vs_reference(golden_loss, dev, loss_mode):
         rms = float(norm) / max(1.0, flat.numel() ** 0.5)
         np.testing.assert_allclose(flat[idx].cpu().numpy(), samp, rtol=rt_s, atol=1e-6 * total + 0.05 * rms,
                                    err_msg=str(name))
+
+
+def test_gradient_sinks_match_autograd_accumulation(golden_loss, dev):
+    """With the flat gradient bucket registered as sinks (what bench.py / engine.TrainStep use), the
+    weight-gradient kernels add straight into the bucket; the result must equal ordinary autograd
+    accumulation, also over two backward passes without zeroing in between."""
+    from puzzlenet_amd import distributed as pdist
+    from puzzlenet_amd import model5_b as mb
+    from puzzlenet_amd import ops
+    G = golden_loss
+    batch = [_t(G[f"ts_batch{i}"], dev) for i in range(8)]
+
+    def run(use_sinks):
+        m = mb.TouchedRegraster(mr.Cfg(loss_mode=1))
+        mr.fill_params(m)
+        m.to(dev)
+        ops.clear_grad_sinks()
+        bucket = pdist.FlatGradAllReduce(m.parameters()) if use_sinks else None
+        if not use_sinks:
+            ops.clear_grad_sinks()
+        for _ in range(2):
+            torch.manual_seed(99)
+            m.training_step(batch, 0)["loss"].backward()
+        grads = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in m.parameters()])
+        if use_sinks:
+            assert len(ops._GRAD_SINKS) == sum(1 for _ in m.parameters())
+            assert torch.equal(grads, bucket.flat)
+        ops.clear_grad_sinks()
+        return grads
+
+    a, b = run(True), run(False)
+    assert float((a - b).norm() / b.norm()) < 2e-3        # (EMD terms in the loss: see test_gpu_emd)
+    assert float(a.abs().max()) > 0

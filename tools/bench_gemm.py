@@ -22,11 +22,11 @@ for (M,K,N,tag) in [(1048576,128,128,'mlp4'),(524288,256,256,'mlp6'),(1048576,67
     dy=rnd(M,N); dx=torch.empty(M,K,device=dev)
     timeit(lambda: lib.pzn_linear_dgrad_f32(P(dy),P(y),P(w),M,K,N,None,P(dx),st()), 2*M*K*N, f'dgrad NN {tag} (relu gen)')
     dW=torch.empty(N,K,device=dev); db=torch.empty(N,device=dev)
-    timeit(lambda: lib.pzn_linear_wgrad_f32(P(dy),P(y),P(x),M,K,N,P(dW),P(db),st()), 2*M*K*N, f'wgrad TN {tag} (relu gen)')
+    timeit(lambda: lib.pzn_linear_wgrad_f32(P(dy),P(y),P(x),M,K,N,P(dW),P(db),0,st()), 2*M*K*N, f'wgrad TN {tag} (relu gen)')
     if M%32==0 and tag in('mlp4','mlp6'):
         R=M//32; out=torch.empty(R,N,device=dev); arg=torch.empty(R,N,dtype=torch.int32,device=dev)
         timeit(lambda: lib.pzn_linear_maxpool_fwd_f32(P(x),P(w),P(b),R,K,N,P(out),P(arg),st()), 2*M*K*N, f'fwd maxpool {tag}')
         dout=rnd(R,N)
         timeit(lambda: lib.pzn_linear_maxpool_dgrad_f32(P(dout),P(arg),P(out),P(w),R,K,N,P(x),P(dx),st()), 2*M*K*N, f'dgrad maxpool-gen+mask {tag}')
-        timeit(lambda: lib.pzn_linear_maxpool_wgrad_f32(P(dout),P(arg),P(out),P(x),R,K,N,P(dW),P(db),st()), 2*M*K*N, f'wgrad maxpool-gen {tag}')
+        timeit(lambda: lib.pzn_linear_maxpool_wgrad_f32(P(dout),P(arg),P(out),P(x),R,K,N,P(dW),P(db),0,st()), 2*M*K*N, f'wgrad maxpool-gen {tag}')
     del x,y,dy,dx
