@@ -77,40 +77,52 @@ __device__ __forceinline__ float sq3(float dx, float dy, float dz) { return dx *
 // between CUs, which thrashes — ~10 cycles per VALU instruction measured.)
 constexpr int EMD_TL = 512;
 constexpr int EMD_ROWS = 64;  // rows per workgroup
-#define EMD_WALK(PTR, CNT, EVAL)                                              \
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// The tile holds point PAIRS in SoA form — {x0,x1,y0,y1} {z0,z1,w0,w1} — so that one lane evaluates two
+// walked points per instruction with the packed fp32 ALU ops (v_pk_add/mul/fma_f32): ~8 issues per
+// (row, point) instead of ~21 for the float4-per-point form (whose pairs the compiler had to assemble
+// with v_mov).  An odd tail point is paired with a zero-weight copy of itself.
+#define EMD_WALK(PTR, CNT, EVAL2)                                             \
   do {                                                                        \
     __shared__ float4 emd_tile_[2][EMD_TL];                                   \
     const int cnt_ = (CNT);                                                   \
     const int wq_ = threadIdx.x >> 6;                                         \
     const int ntile_ = (cnt_ + EMD_TL - 1) / EMD_TL;                          \
-    for (int i_ = threadIdx.x; i_ < EMD_TL && i_ < cnt_; i_ += EMD_T) emd_tile_[0][i_] = (PTR)[i_]; \
+    auto stage_ = [&](int buf, int base) {                                    \
+      const int q = threadIdx.x; /* pair index inside the tile: EMD_T == EMD_TL / 2 */ \
+      const int i0 = base + 2 * q;                                            \
+      if (i0 < cnt_) {                                                        \
+        float4 a = (PTR)[i0];                                                 \
+        float4 b = i0 + 1 < cnt_ ? (PTR)[i0 + 1] : make_float4(a.x, a.y, a.z, 0.f); \
+        emd_tile_[buf][2 * q] = make_float4(a.x, b.x, a.y, b.y);              \
+        emd_tile_[buf][2 * q + 1] = make_float4(a.z, b.z, a.w, b.w);          \
+      }                                                                       \
+    };                                                                        \
+    stage_(0, 0);                                                             \
     __syncthreads();                                                          \
     for (int t_ = 0; t_ < ntile_; ++t_) {                                     \
       const int base_ = t_ * EMD_TL;                                          \
-      const int len_ = min(EMD_TL, cnt_ - base_);                             \
-      if (t_ + 1 < ntile_) {                                                  \
-        const int nb_ = base_ + EMD_TL;                                       \
-        for (int i_ = threadIdx.x; i_ < EMD_TL && nb_ + i_ < cnt_; i_ += EMD_T) \
-          emd_tile_[(t_ + 1) & 1][i_] = (PTR)[nb_ + i_];                      \
-      }                                                                       \
+      const int npair_ = (min(EMD_TL, cnt_ - base_) + 1) >> 1;                \
+      if (t_ + 1 < ntile_) stage_((t_ + 1) & 1, base_ + EMD_TL);              \
       const float4* tp_ = emd_tile_[t_ & 1];                                  \
-      const int per_ = (((len_ + 3) >> 2) + 3) & ~3;                          \
-      int i_ = min(len_, wq_ * per_);                                         \
-      const int end_ = min(len_, i_ + per_);                                  \
-      for (; i_ + 3 < end_; i_ += 4) {                                        \
-        float4 c0_ = tp_[i_], c1_ = tp_[i_ + 1], c2_ = tp_[i_ + 2], c3_ = tp_[i_ + 3]; \
-        EVAL(c0_, base_ + i_);                                                \
-        EVAL(c1_, base_ + i_ + 1);                                            \
-        EVAL(c2_, base_ + i_ + 2);                                            \
-        EVAL(c3_, base_ + i_ + 3);                                            \
+      const int per_ = (npair_ + 3) >> 2;                                     \
+      int q_ = min(npair_, wq_ * per_);                                       \
+      const int end_ = min(npair_, q_ + per_);                                \
+      for (; q_ + 1 < end_; q_ += 2) {                                        \
+        float4 a0_ = tp_[2 * q_], b0_ = tp_[2 * q_ + 1], a1_ = tp_[2 * q_ + 2], b1_ = tp_[2 * q_ + 3]; \
+        EVAL2((v2f){a0_.x, a0_.y}, (v2f){a0_.z, a0_.w}, (v2f){b0_.x, b0_.y}, (v2f){b0_.z, b0_.w}, base_ + 2 * q_); \
+        EVAL2((v2f){a1_.x, a1_.y}, (v2f){a1_.z, a1_.w}, (v2f){b1_.x, b1_.y}, (v2f){b1_.z, b1_.w}, base_ + 2 * q_ + 2); \
       }                                                                       \
-      for (; i_ < end_; ++i_) {                                               \
-        float4 c0_ = tp_[i_];                                                 \
-        EVAL(c0_, base_ + i_);                                                \
+      for (; q_ < end_; ++q_) {                                               \
+        float4 a0_ = tp_[2 * q_], b0_ = tp_[2 * q_ + 1];                      \
+        EVAL2((v2f){a0_.x, a0_.y}, (v2f){a0_.z, a0_.w}, (v2f){b0_.x, b0_.y}, (v2f){b0_.z, b0_.w}, base_ + 2 * q_); \
       }                                                                       \
       __syncthreads();                                                        \
     }                                                                         \
   } while (0)
+
+__device__ __forceinline__ v2f exp2_pair(v2f t) { return (v2f){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)}; }
 
 // sum over the 4 wavefronts of a workgroup, lane by lane (all threads get the total)
 __device__ __forceinline__ float cross_wave_sum(float v, float* red) {
@@ -146,13 +158,14 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_a_kernel(int n, int m, float c
   const int k = blockIdx.x * EMD_ROWS + (threadIdx.x & 63);
   const float4* __restrict__ other = w.pk2a + (size_t)b * m;
   float4 me = k < n ? w.pk1[(size_t)b * n + k] : make_float4(0, 0, 0, 0);
-  float suml = 0.f;
-  auto eval = [&](const float4& o, int) {
-    float d = sq3(o.x - me.x, o.y - me.y, o.z - me.z);  // :76
-    suml += fast_exp_scaled(c, d) * o.w;                // :77-78
+  v2f acc = {0.f, 0.f};
+  auto eval = [&](v2f X, v2f Y, v2f Z, v2f Wt, int) {
+    v2f dx = X - me.x, dy = Y - me.y, dz = Z - me.z;
+    v2f d = dx * dx + dy * dy + dz * dz;       // :76
+    acc += exp2_pair(d * c) * Wt;              // :77-78
   };
   EMD_WALK(other, m, eval);
-  suml = 1e-9f + cross_wave_sum(suml, red);  // :59
+  float suml = 1e-9f + cross_wave_sum(acc.x + acc.y, red);  // :59
   if (k < n && threadIdx.x < 64) {
     me.w = w.remainL[(size_t)b * n + k] / suml;  // :83
     w.pk1[(size_t)b * n + k] = me;
@@ -168,23 +181,23 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_b_kernel(int n, int m, float c
   const int l = blockIdx.x * EMD_ROWS + (threadIdx.x & 63);
   const float4* __restrict__ other = w.pk1 + (size_t)b * n;
   float4 me = l < m ? w.pk2a[(size_t)b * m + l] : make_float4(0, 0, 0, 0);
-  float sumr = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
-  auto eval = [&](const float4& o, int) {
-    float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
-    float e = fast_exp_scaled(c, sq3(dx, dy, dz)) * o.w;  // :108
-    sumr += e;                                            // :109
+  v2f ar = {0.f, 0.f}, ax = ar, ay = ar, az = ar;
+  auto eval = [&](v2f X, v2f Y, v2f Z, v2f Wt, int) {
+    v2f dx = me.x - X, dy = me.y - Y, dz = me.z - Z;
+    v2f e = exp2_pair((dx * dx + dy * dy + dz * dz) * c) * Wt;  // :108
+    ar += e;                                                    // :109
     if (FUSED) {
-      sx += e * dx;
-      sy += e * dy;
-      sz += e * dz;
+      ax += e * dx;
+      ay += e * dy;
+      az += e * dz;
     }
   };
   EMD_WALK(other, n, eval);
-  sumr = cross_wave_sum(sumr, red);
+  float sumr = cross_wave_sum(ar.x + ar.y, red), sx = 0.f, sy = 0.f, sz = 0.f;
   if (FUSED) {
-    sx = cross_wave_sum(sx, red);
-    sy = cross_wave_sum(sy, red);
-    sz = cross_wave_sum(sz, red);
+    sx = cross_wave_sum(ax.x + ax.y, red);
+    sy = cross_wave_sum(ay.x + ay.y, red);
+    sz = cross_wave_sum(az.x + az.y, red);
   }
   if (l < m && threadIdx.x < 64) {
     float remainR = me.w;
@@ -215,30 +228,33 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_c_kernel(int n, int m, float c
   const float4* __restrict__ other = w.pk2b + (size_t)b * m;
   float4 me = k < n ? w.pk1[(size_t)b * n + k] : make_float4(0, 0, 0, 0);
   const float rl = me.w;  // :139
-  float suml = 0.f, sx = 0.f, sy = 0.f, sz = 0.f, sc = 0.f;
+  v2f al = {0.f, 0.f}, ax = al, ay = al, az = al, ac = al;
   float* mt = MATCH ? match + (size_t)b * n * m + k : nullptr;
-  auto eval = [&](const float4& o, int l) {
-    float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
-    float d = sq3(dx, dy, dz);
-    float wv = fast_exp_scaled(c, d) * rl * o.w;  // :145
+  auto eval = [&](v2f X, v2f Y, v2f Z, v2f Wt, int l) {
+    v2f dx = me.x - X, dy = me.y - Y, dz = me.z - Z;
+    v2f d = dx * dx + dy * dy + dz * dz;
+    v2f wv = exp2_pair(d * c) * rl * Wt;  // :145
     if (MATCH) {
-      if (k < n) mt[(size_t)l * n] += wv;  // :146
+      if (k < n) {
+        mt[(size_t)l * n] += wv.x;  // :146
+        if (l + 1 < m) mt[(size_t)(l + 1) * n] += wv.y;
+      }
     }
-    suml += wv;  // :147
+    al += wv;  // :147
     if (FUSED) {
-      sx += wv * dx;
-      sy += wv * dy;
-      sz += wv * dz;
-      sc += wv * d;
+      ax += wv * dx;
+      ay += wv * dy;
+      az += wv * dz;
+      ac += wv * d;
     }
   };
   EMD_WALK(other, m, eval);
-  suml = cross_wave_sum(suml, red);
+  float suml = cross_wave_sum(al.x + al.y, red), sx = 0.f, sy = 0.f, sz = 0.f, sc = 0.f;
   if (FUSED) {
-    sx = cross_wave_sum(sx, red);
-    sy = cross_wave_sum(sy, red);
-    sz = cross_wave_sum(sz, red);
-    sc = cross_wave_sum(sc, red);
+    sx = cross_wave_sum(ax.x + ax.y, red);
+    sy = cross_wave_sum(ay.x + ay.y, red);
+    sz = cross_wave_sum(az.x + az.y, red);
+    sc = cross_wave_sum(ac.x + ac.y, red);
   }
   if (k < n && threadIdx.x < 64) {
     float* r = w.remainL + (size_t)b * n + k;
