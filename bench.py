@@ -189,21 +189,28 @@ def main():
         }
         # (2) the stage the north star names: kNN + group (HBM-bound), SURVEY 8(d) bytes.
         per_pair = 2 * (knn_group_bytes(N, 512, 32, 64) + knn_group_bytes(512, 256, 32, 128))
-        n_knn, ms_knn = kern.get("pzn_knn_f32", (0, 0.0))
-        n_grp, ms_grp = kern.get("pzn_group_pad_fwd_f32", kern.get("pzn_group_fwd_f32", (0, 0.0)))
-        stage_ms_per_step = (ms_knn + ms_grp) / max(1, prof_steps)
+        if "pzn_knn_group_pad_f32" in kern:       # kNN + group fused into one launch (the model path)
+            n_st, ms_st = kern["pzn_knn_group_pad_f32"]
+            stage_names = "knn_group_pad_kernel (pzn_knn_group_pad_f32: neighbour search + group write in one launch, 4 launches/step)"
+            avg_launch = {"knn_group_pad_kernel": ms_st / max(1, n_st)}
+        else:
+            n_knn, ms_knn = kern.get("pzn_knn_f32", (0, 0.0))
+            n_grp, ms_grp = kern.get("pzn_group_pad_fwd_f32", kern.get("pzn_group_fwd_f32", (0, 0.0)))
+            ms_st = ms_knn + ms_grp
+            stage_names = "knn32_reg_kernel (pzn_knn_f32) + group_pad_direct_kernel (pzn_group_pad_fwd_f32)"
+            avg_launch = {"knn32_reg_kernel": ms_knn / max(1, n_knn), "group_pad_direct_kernel": ms_grp / max(1, n_grp)}
+        stage_ms_per_step = ms_st / max(1, prof_steps)
         achieved = per_pair * B / (stage_ms_per_step * 1e-3) / 1e9 if stage_ms_per_step > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
         if os.path.exists(tpath) and (B, N) == (64, 2048):
             traffic = json.load(open(tpath)).get("knn_group_stage_bytes_per_step")
         roofline_knn_group = {
-            "bound": "hbm", "kernel": "knn32_reg_kernel (pzn_knn_f32, 2 launches/step) + group_pad_direct_kernel "
-                                      "(pzn_group_pad_fwd_f32, 4 launches/step)",
+            "bound": "hbm", "kernel": stage_names,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "algorithmic_bytes_per_step": per_pair * B,
-            "avg_launch_ms": {"knn32_reg_kernel": ms_knn / max(1, n_knn), "group_pad_direct_kernel": ms_grp / max(1, n_grp)},
+            "avg_launch_ms": avg_launch,
         }
         stages = {k: {"launches_per_step": n / prof_steps, "ms_per_step": ms / prof_steps} for k, (n, ms) in sorted(kern.items())}
         out = {

@@ -225,6 +225,12 @@ int pzn_sharedmlp_max_bwd_f32(const float* x, const float* W1, const float* W2,
 int pzn_group_pad_fwd_f32(const float* xyz, const float* feat, const float* new_xyz,
                           const int64_t* idx, int B, int N, int S, int K, int D,
                           float* out, pzn_stream_t stream);
+/* pzn_knn_f32 (K = 32) and pzn_group_pad_fwd_f32 in ONE launch (pointnet_util.py:117-132 on the
+ * encoder path): selection is VALU work, the group write is HBM work, and inside one kernel they
+ * overlap.  64 <= N <= 4096, D % 4 == 0.  idx[B,S,32] is kept for the backward. */
+int pzn_knn_group_pad_f32(const float* xyz, const float* feat, const float* new_xyz,
+                          int B, int N, int S, int D, int64_t* idx, float* out,
+                          pzn_stream_t stream);
 /* grad_feat[b, idx[b,s,k], :] += rows[b,s,k,:], rows D wide; grad_feat zero-initialised
  * by the caller. */
 int pzn_group_feat_bwd_f32(const float* rows, const int64_t* idx, int B, int N, int S,

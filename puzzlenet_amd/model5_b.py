@@ -126,7 +126,7 @@ class PCTransformer_nonsort(nn.Module):
         if plan is None:
             fps_idx = self.fps(xyz, npoint)                               # pointnet_util.py:113
             new_xyz = ops.index_points(xyz, fps_idx)                      # :115
-            idx = ops.knn(xyz, new_xyz, nsample)                          # :118-119
+            idx = None                                                    # :118-119 fused into the group launch
         else:
             new_xyz, idx = plan
         return new_xyz, dense.sa_mlp_max(xyz, feat, new_xyz, idx, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias)
@@ -235,10 +235,9 @@ class TouchedRegraster(_Base):
         return self.predict5(batch, bat)
 
     def _sa_plans(self, fpc, mrpc):
-        """FPS -> gather -> kNN of BOTH set-abstraction levels for BOTH clouds, hoisted in front of the
+        """FPS -> gather of BOTH set-abstraction levels for BOTH clouds, hoisted in front of the
         encoders: the sampling chain depends on coordinates only, so the two encoders' 64-workgroup,
-        latency-bound FPS launches become one 128-workgroup launch per level (same wall time each), and
-        kNN runs twice instead of four times.  The four start-index draws are made first, in the
+        latency-bound FPS launches become one 128-workgroup launch per level (same wall time each).  The four start-index draws are made first, in the
         reference's order (Encoder sg1, sg2, Encoder2 sg1, sg2; pointnet_util.py:65), so a seeded run
         picks exactly the points the reference picks."""
         if not (self.Encoder.fused_sa and self.Encoder2.fused_sa) or fpc.requires_grad or mrpc.requires_grad \
@@ -256,11 +255,10 @@ class TouchedRegraster(_Base):
         xyz = torch.cat([fpc, mrpc], dim=0)
         f1 = ops.farthest_point_sample(xyz, 512, torch.cat([d1, d3]))
         x1 = ops.index_points(xyz, f1)
-        i1 = ops.knn(xyz, x1, 32)
         f2 = ops.farthest_point_sample(x1, 256, torch.cat([d2, d4]))
         x2 = ops.index_points(x1, f2)
-        i2 = ops.knn(x1, x2, 32)
-        return ((x1[:B], i1[:B]), (x2[:B], i2[:B])), ((x1[B:], i1[B:]), (x2[B:], i2[B:]))
+        # the neighbour search itself runs inside each encoder, fused with the group write (idx = None)
+        return ((x1[:B], None), (x2[:B], None)), ((x1[B:], None), (x2[B:], None))
 
     # ------------------------------------------------------------------ losses
     def chamfer_loss(self, a, b):

@@ -480,15 +480,18 @@ def attention(q, k, v):
 class _SaMlpMax(torch.autograd.Function):
     """Set abstraction as the encoder runs it (model5_b.py:449-454 / :456-461): group the K=32 neighbours
     (pointnet_util.py:123-132), two shared-MLP layers, max over K — on padded rows {dx,dy,dz,0,f...}, with
-    the first layer's feature block as clean D-wide GEMMs.  Gradients: features and weights (the point
-    coordinates carry none on this path)."""
+    the first layer's feature block as clean D-wide GEMMs.  idx=None: the kNN search (pointnet_util.py:118-119)
+    runs fused with the grouping in one launch.  Gradients: features and weights (the point coordinates
+    carry none on this path)."""
 
     @staticmethod
     def forward(ctx, xyz, feat, new_xyz, idx, w1, b1, w2, b2):
-        xyz, feat, new_xyz, idx = _f32(xyz, "xyz"), _f32(feat, "points"), _f32(new_xyz, "new_xyz"), _i64(idx, "idx")
+        xyz, feat, new_xyz = _f32(xyz, "xyz"), _f32(feat, "points"), _f32(new_xyz, "new_xyz")
+        idx = None if idx is None else _i64(idx, "idx")
         w1, b1, w2, b2 = _f32(w1, "w1"), _f32(b1, "b1"), _f32(w2, "w2"), _f32(b2, "b2")
         B, N, _ = xyz.shape
-        _, S, K = idx.shape
+        S = new_xyz.shape[1]
+        K = 32 if idx is None else idx.shape[2]
         D = feat.shape[-1]
         C1, C2 = w1.shape[0], w2.shape[0]
         if K != 32 or D % 4 != 0 or w1.shape[1] != 3 + D:
@@ -496,12 +499,18 @@ class _SaMlpMax(torch.autograd.Function):
         dev = xyz.device
         R = B * S
         xg = torch.empty((R * 32, 4 + D), dtype=torch.float32, device=dev)
+        fuse_knn = idx is None
+        if fuse_knn:
+            idx = torch.empty((B, S, 32), dtype=torch.int64, device=dev)
         w1p = torch.cat([w1[:, :3], torch.zeros((C1, 1), dtype=torch.float32, device=dev), w1[:, 3:]], dim=1).contiguous()
         h = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
         out = torch.empty((R, C2), dtype=torch.float32, device=dev)
         arg = torch.empty((R, C2), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
-            _call("pzn_group_pad_fwd_f32", _p(xyz), _p(feat), _p(new_xyz), _p(idx), B, N, S, K, D, _p(xg), _stream())
+            if fuse_knn:     # neighbour search + group in one launch (idx is an output)
+                _call("pzn_knn_group_pad_f32", _p(xyz), _p(feat), _p(new_xyz), B, N, S, D, _p(idx), _p(xg), _stream())
+            else:
+                _call("pzn_group_pad_fwd_f32", _p(xyz), _p(feat), _p(new_xyz), _p(idx), B, N, S, K, D, _p(xg), _stream())
             _call("pzn_sharedmlp_max_fwd_f32", _p(xg), _p(w1p), _p(b1), _p(w2), _p(b2), R, 4 + D, C1, C2,
                   _p(h), _p(out), _p(arg), _stream(), flops=2 * R * 32 * ((3 + D) * C1 + C1 * C2))
         ctx.save_for_backward(xg, w1p, w2, h, out, arg, idx)

@@ -191,3 +191,11 @@ def test_sa_mlp_max_fused_vs_composed(dev, precision, B, N, S, D, C1, C2):
     assert _rel(fd.grad, featr.grad) < 1e-4
     for a, r, name in zip(d, ref, ("w1", "b1", "w2", "b2")):
         assert _rel(a.grad, r.grad) < 1e-4, name
+    if N >= 64:
+        # idx=None: neighbour search fused with the group write (pzn_knn_group_pad_f32) — same values
+        d2 = [t.to(dev).requires_grad_(True) for t in (w1, b1, w2, b2)]
+        f2 = torch.from_numpy(feat).to(dev).requires_grad_(True)
+        y2 = ops.sa_mlp_max(torch.from_numpy(xyz).to(dev), f2, torch.from_numpy(new_xyz).to(dev), None, *d2)
+        assert torch.equal(y2, y)
+        (y2 * go.to(dev)).sum().backward()
+        assert _rel(f2.grad, featr.grad) < 1e-4
