@@ -21,8 +21,8 @@ def load(d):
     rows = list(csv.DictReader(open(glob.glob(d + "/*/*counter_collection.csv")[0])))
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in rows:
-        name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("(anonymous namespace)::", "")
-        name = re.sub(r"<.*", "", name)
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        name = re.sub(r"[<(].*", "", name)
         agg[name][0] += 1
         agg[name][1] += float(r["Counter_Value"])
     return agg
@@ -38,8 +38,14 @@ def main():
         fk, wk = f[k][1] / f[k][0], w[k][1] / w[k][0]
         per[k] = {"launches": f[k][0], "FETCH_SIZE_KB_per_launch": round(fk, 1), "WRITE_SIZE_KB_per_launch": round(wk, 1),
                   "hbm_bytes_per_launch": round((2 * fk + wk) * 1024)}
+    # kNN + group stage of one step: the fused launch runs 4x per step (2 clouds x 2 levels) with
+    # different sizes, so take total bytes / steps; older traces had kNN (2 batched launches) and the
+    # padded group (4 launches) as separate kernels.
     stage = None
-    if "knn32_reg_kernel" in per and "group_pad_direct_kernel" in per:
+    if "knn_group_pad_kernel" in per:
+        k = per["knn_group_pad_kernel"]
+        stage = round(k["hbm_bytes_per_launch"] * 4)
+    elif "knn32_reg_kernel" in per and "group_pad_direct_kernel" in per:
         stage = 2 * per["knn32_reg_kernel"]["hbm_bytes_per_launch"] + 4 * per["group_pad_direct_kernel"]["hbm_bytes_per_launch"]
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, python bench.py --steps 2 --warmup 1 "
                      "--no-cpu-baseline (B=64, N=2048)",
