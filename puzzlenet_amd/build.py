@@ -25,6 +25,7 @@ SOURCES = [
     ("emd.hip", []),
     ("chamfer.hip", []),
     ("gemm.hip", []),
+    ("poolbwd.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 #include "pzn_common.h"
+#include "pzn_internal.h"
 
 namespace {
 
@@ -694,6 +695,8 @@ PZN_EXPORT int pzn_linear_maxpool_dgrad_f32(const float* dout, const int32_t* ar
                                             int R, int Kin, int Nout, const float* x_relu, float* dx,
                                             pzn_stream_t stream) {
   PZN_CHECK_ARG(dout && argmax && out && W && dx && R > 0 && Kin > 0 && Nout > 0);
+  if (pzn_pool_bwd_supported(Kin, Nout, W, x_relu, dx))  // one non-zero per (group, channel): sparse pass
+    return pzn_pool_bwd_sparse(dout, argmax, out, W, x_relu, dx, nullptr, nullptr, R, Kin, Nout, pzn_hip_stream(stream));
   GemmArgs p = base_args(R * 32, Kin, Nout);
   p.A = dout, p.lda = Nout, p.B = W, p.ldb = Kin, p.C = dx, p.ldc = Kin;
   p.gen = GEN_MAXPOOL, p.genArg = argmax, p.genOut = out;
@@ -733,6 +736,14 @@ PZN_EXPORT int pzn_linear_maxpool_wgrad_f32(const float* dout, const int32_t* ar
                                             int R, int Kin, int Nout, float* dW, float* db, int accumulate,
                                             pzn_stream_t stream) {
   PZN_CHECK_ARG(dout && argmax && out && x && dW && R > 0 && Kin > 0 && Nout > 0);
+  if (pzn_pool_bwd_supported(Kin, Nout, x, x, nullptr)) {
+    hipStream_t st = pzn_hip_stream(stream);
+    if (!accumulate) {
+      if (pzn_zero_async(dW, (size_t)Nout * Kin, st) != PZN_OK) return PZN_ELAUNCH;
+      if (db && pzn_zero_async(db, (size_t)Nout, st) != PZN_OK) return PZN_ELAUNCH;
+    }
+    return pzn_pool_bwd_sparse(dout, argmax, out, nullptr, x, nullptr, dW, db, R, Kin, Nout, st);
+  }
   GemmArgs p = base_args(Nout, Kin, R * 32);
   p.A = dout, p.lda = Nout, p.gen = GEN_MAXPOOL, p.genArg = argmax, p.genOut = out;
   return wgrad_common(p, Kin, Nout, x, dW, db, accumulate, pzn_hip_stream(stream));
@@ -855,15 +866,31 @@ PZN_EXPORT int pzn_sharedmlp_max_fwd_f32(const float* x, const float* W1, const 
   return pzn_linear_maxpool_fwd_f32(h, W2, b2, R, C1, C2, out, argmax, stream);
 }
 
+// Second-layer backward of the pooled shared MLP: dh (ReLU-masked by h), dW2, db2 — one sparse pass when the
+// shape allows (poolbwd.hip), else the two generated-operand GEMMs.
+static int pool_layer_bwd(const float* dout, const int32_t* argmax, const float* out, const float* W2, const float* h,
+                          int R, int C1, int C2, float* dh_ws, float* dW2, float* db2, int accumulate,
+                          pzn_stream_t stream) {
+  if (pzn_pool_bwd_supported(C1, C2, W2, h, dh_ws)) {
+    hipStream_t st = pzn_hip_stream(stream);
+    if (!accumulate) {
+      if (pzn_zero_async(dW2, (size_t)C2 * C1, st) != PZN_OK) return PZN_ELAUNCH;
+      if (pzn_zero_async(db2, (size_t)C2, st) != PZN_OK) return PZN_ELAUNCH;
+    }
+    return pzn_pool_bwd_sparse(dout, argmax, out, W2, h, dh_ws, dW2, db2, R, C1, C2, st);
+  }
+  int rc = pzn_linear_maxpool_dgrad_f32(dout, argmax, out, W2, R, C1, C2, h, dh_ws, stream);
+  if (rc != PZN_OK) return rc;
+  return pzn_linear_maxpool_wgrad_f32(dout, argmax, out, h, R, C1, C2, dW2, db2, accumulate, stream);
+}
+
 // Backward: dh_ws is [R*32, C1] scratch; dx may be NULL.  dW*, db* are overwritten.
 PZN_EXPORT int pzn_sharedmlp_max_bwd_f32(const float* x, const float* W1, const float* W2, const float* h,
                                          const float* out, const int32_t* argmax, const float* dout, int R, int C0,
                                          int C1, int C2, float* dh_ws, float* dx, float* dW1, float* db1, float* dW2,
                                          float* db2, int accumulate, pzn_stream_t stream) {
   PZN_CHECK_ARG(x && W1 && W2 && h && out && argmax && dout && dh_ws && dW1 && db1 && dW2 && db2);
-  int rc = pzn_linear_maxpool_dgrad_f32(dout, argmax, out, W2, R, C1, C2, h, dh_ws, stream);  // dh, ReLU-masked by h
-  if (rc != PZN_OK) return rc;
-  rc = pzn_linear_maxpool_wgrad_f32(dout, argmax, out, h, R, C1, C2, dW2, db2, accumulate, stream);
+  int rc = pool_layer_bwd(dout, argmax, out, W2, h, R, C1, C2, dh_ws, dW2, db2, accumulate, stream);
   if (rc != PZN_OK) return rc;
   rc = pzn_linear_wgrad_f32(dh_ws, nullptr, x, R * 32, C0, C1, dW1, db1, accumulate, stream);
   if (rc != PZN_OK) return rc;
@@ -885,9 +912,7 @@ PZN_EXPORT int pzn_sa_mlp_max_bwd_f32(const float* xg, const float* W1p, const f
   PZN_CHECK_ARG(R > 0 && D > 0 && (D & 3) == 0 && C1 > 0 && C2 > 0);
   hipStream_t st = pzn_hip_stream(stream);
   const int ldx = 4 + D, ldw = 3 + D, M = R * 32;
-  int rc = pzn_linear_maxpool_dgrad_f32(dout, argmax, out, W2, R, C1, C2, h, dh_ws, stream);  // dh (ReLU-masked by h)
-  if (rc != PZN_OK) return rc;
-  rc = pzn_linear_maxpool_wgrad_f32(dout, argmax, out, h, R, C1, C2, dW2, db2, accumulate, stream);
+  int rc = pool_layer_bwd(dout, argmax, out, W2, h, R, C1, C2, dh_ws, dW2, db2, accumulate, stream);
   if (rc != PZN_OK) return rc;
   {  // dW1[:, 3:] = dh^T xg[:, 4:];  dW1[:, 0:3] and db1 from the streamed dh tiles
     if (!accumulate) {

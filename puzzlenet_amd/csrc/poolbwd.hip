@@ -1,0 +1,232 @@
+// poolbwd.hip — backward of "linear + ReLU + max over the K = 32 neighbours" (model5_b.py:452-454 /
+// 459-461) as the sparse problem it is.
+//
+// The gradient that reaches the pre-pool activations has ONE non-zero per (centroid g, channel c):
+//     dy[g*32 + k, c] = (argmax[g,c] == k && out[g,c] > 0) ? dOut[g,c] : 0.
+// Written as dense GEMMs (dh = dy W, dW = dy^T h) 31 of every 32 multiply-adds are by zero.  Here
+//     dh[g*32 + a(g,c), :] += dOut[g,c] * W[c, :]          (C2 row-axpys per group instead of 32*C2)
+//     dW[c, :]             += dOut[g,c] * h[g*32 + a(g,c), :]
+//     db[c]                += dOut[g,c]
+// which is 32x fewer flops, so the pass is bound by streaming h in (and dh out) once.
+//
+// Two kernels, both walking groups g = blockIdx.x, += gridDim.x over a 128-column slice (blockIdx.y) of the
+// C1 hidden columns, lane l holding columns 2l, 2l+1:
+//  * pool_wgrad_kernel: 8 wavefronts, wave w owns CPW = C2/8 channels whose dW accumulators stay in registers
+//    for the whole walk.  Per group the 32 x 128 tile of h is staged in LDS (double-buffered, next tile
+//    prefetched into registers), the wave's CPW (argmax, gradient) pairs are read as one vector and
+//    broadcast with v_readlane, then per channel: one ds_read_b64 of the arg-max row + one packed fma.
+//  * pool_dgrad_kernel: 16 wavefronts, each walking whole groups on its own (no barrier in the walk, no LDS
+//    float atomics — those measured ~200 cycles per wave-instruction here).  The W slice [C2][128] sits in
+//    LDS; each lane holds the (argmax, gradient) pairs of channels lane, lane+64, ...; for a row k the
+//    channels that selected it come out of a v_cmp ballot and are visited two bits at a time: v_readlane of
+//    the gradient, ds_read_b64 of the W row, packed fma.  The finished row is ReLU-masked with h and stored
+//    straight from registers.  Work per group is exactly C2 hits however skewed the arg-max rows are (in the
+//    model the nearest neighbours win most channels; a rows-per-wave split was 3x slower there).
+#include "pzn_common.h"
+#include "pzn_internal.h"
+
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int PB_T = 512;     // threads per workgroup
+constexpr int PB_W = 8;       // wavefronts
+constexpr int PB_COLS = 128;  // hidden columns per workgroup
+
+struct PoolBwdArgs {
+  const float* dout;      // [G, C2]
+  const int32_t* argmax;  // [G, C2], values 0..31
+  const float* out;       // [G, C2] pooled output (gradient flows only where it is > 0)
+  const float* W;         // [C2, C1]           (DGRAD)
+  const float* h;         // [G*32, C1]         (WGRAD operand; DGRAD ReLU mask, may be NULL there)
+  float* dh;              // [G*32, C1]         (DGRAD)
+  float* dW;              // [C2, C1] += ...    (WGRAD)
+  float* db;              // [C2] += ...        (WGRAD, may be NULL)
+  int G, C1, C2;
+};
+
+template <int CPW>
+__global__ __launch_bounds__(PB_T) void pool_wgrad_kernel(PoolBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float hbuf[2][32][PB_COLS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col0 = blockIdx.y * PB_COLS;
+  const int ch = wave * CPW + (lane < CPW ? lane : 0);  // this lane's channel in the per-group vector loads
+
+  v2f acc[CPW];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) acc[c] = v2f{0.f, 0.f};
+  float dbacc = 0.f;
+
+  // staging map for the 32 x 128 tile: rows srow and srow + 16, 16-byte column scol
+  const int srow = tid >> 5, scol = (tid & 31) * 4;
+  float4 pre0 = make_float4(0.f, 0.f, 0.f, 0.f), pre1 = pre0;
+  int av_n = 0;
+  float gv_n = 0.f;
+#define PB_PREFETCH(gg)                                                             \
+  do {                                                                              \
+    const float* hp = p.h + ((size_t)(gg) * 32 + srow) * p.C1 + col0 + scol;       \
+    pre0 = *reinterpret_cast<const float4*>(hp);                                    \
+    pre1 = *reinterpret_cast<const float4*>(hp + (size_t)16 * p.C1);                \
+    size_t o = (size_t)(gg) * p.C2 + ch;                                            \
+    int a = p.argmax[o];                                                            \
+    float go = p.out[o], gd = p.dout[o];                                            \
+    av_n = a & 31;                                                                  \
+    gv_n = (lane < CPW && go > 0.f) ? gd : 0.f;                                     \
+  } while (0)
+  if ((int)blockIdx.x < p.G) PB_PREFETCH(blockIdx.x);
+
+  int it = 0;
+  for (int g = blockIdx.x; g < p.G; g += gridDim.x, ++it) {
+    const int cur = it & 1;
+    *reinterpret_cast<float4*>(&hbuf[cur][srow][scol]) = pre0;
+    *reinterpret_cast<float4*>(&hbuf[cur][srow + 16][scol]) = pre1;
+    const int av = av_n;
+    const float gv = gv_n;
+    __syncthreads();  // one barrier per group: the tile two groups back is free again by construction
+    if (g + (int)gridDim.x < p.G) PB_PREFETCH(g + gridDim.x);
+    dbacc += gv;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      const int a = __builtin_amdgcn_readlane(av, c);
+      const float gs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gv), c));
+      v2f hr = *reinterpret_cast<const v2f*>(&hbuf[cur][a][2 * lane]);
+      acc[c] += gs * hr;
+    }
+  }
+#undef PB_PREFETCH
+
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    float* o = p.dW + (size_t)(wave * CPW + c) * p.C1 + col0 + 2 * lane;
+    atomicAdd(o, acc[c].x);
+    atomicAdd(o + 1, acc[c].y);
+  }
+  if (p.db && blockIdx.y == 0 && lane < CPW) atomicAdd(p.db + wave * CPW + lane, dbacc);
+}
+
+constexpr int PD_T = 1024;  // dgrad: 16 wavefronts, each walking whole groups
+
+template <int NQ>  // C2 = 64 * NQ
+__global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];  // [C2][PB_COLS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col0 = blockIdx.y * PB_COLS;
+  const int C2 = NQ * 64;
+  for (int f = tid; f < C2 * (PB_COLS / 4); f += PD_T) {
+    const int c = f / (PB_COLS / 4), q4 = (f % (PB_COLS / 4)) * 4;
+    *reinterpret_cast<float4*>(&wlds[c * PB_COLS + q4]) =
+        *reinterpret_cast<const float4*>(p.W + (size_t)c * p.C1 + col0 + q4);
+  }
+  __syncthreads();  // the only barrier: from here on every wavefront walks its own groups
+
+  const int gw = blockIdx.x * (PD_T / 64) + wave, nw = gridDim.x * (PD_T / 64);
+  int av_n[NQ];
+  float gv_n[NQ];
+#define PD_PREFETCH(gg)                                             \
+  do {                                                              \
+    _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                \
+      size_t o = (size_t)(gg) * C2 + q * 64 + lane;                 \
+      av_n[q] = p.argmax[o];                                        \
+      float go = p.out[o], gd = p.dout[o];                          \
+      gv_n[q] = go > 0.f ? gd : 0.f;                                \
+    }                                                               \
+  } while (0)
+  if (gw < p.G) PD_PREFETCH(gw);
+
+  for (int g = gw; g < p.G; g += nw) {
+    int av[NQ];
+    float gv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) av[q] = av_n[q], gv[q] = gv_n[q];
+    if (g + nw < p.G) PD_PREFETCH(g + nw);
+    const size_t row0 = ((size_t)g * 32) * p.C1 + col0 + 2 * lane;
+    v2f hm = p.h ? *reinterpret_cast<const v2f*>(p.h + row0) : v2f{1.f, 1.f};
+    for (int k = 0; k < 32; ++k) {  // rows of the group in turn: exactly C2 hits per group, whatever the arg-max skew
+      v2f hm_next = v2f{1.f, 1.f};
+      if (p.h && k + 1 < 32) hm_next = *reinterpret_cast<const v2f*>(p.h + row0 + (size_t)(k + 1) * p.C1);
+      v2f acc0 = v2f{0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        uint64_t m = __ballot(av[q] == k);
+        while (m) {  // two hits per trip so that two LDS reads are in flight
+          const int b0 = __builtin_ctzll(m);
+          m &= m - 1;
+          const bool two = m != 0;
+          const int b1 = two ? __builtin_ctzll(m) : b0;
+          m &= m - 1;
+          const int gi = __builtin_bit_cast(int, gv[q]);
+          const float g0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gi, b0));
+          float g1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gi, b1));
+          g1 = two ? g1 : 0.f;
+          v2f w0 = *reinterpret_cast<const v2f*>(&wlds[(q * 64 + b0) * PB_COLS + 2 * lane]);
+          v2f w1 = *reinterpret_cast<const v2f*>(&wlds[(q * 64 + b1) * PB_COLS + 2 * lane]);
+          acc0 += g0 * w0;
+          acc1 += g1 * w1;
+        }
+      }
+      v2f acc = acc0 + acc1;
+      acc.x = hm.x > 0.f ? acc.x : 0.f;
+      acc.y = hm.y > 0.f ? acc.y : 0.f;
+      *reinterpret_cast<v2f*>(p.dh + row0 + (size_t)k * p.C1) = acc;
+      hm = hm_next;
+    }
+  }
+#undef PD_PREFETCH
+}
+
+int launch_wgrad(const PoolBwdArgs& p, hipStream_t st) {
+  const int ny = p.C1 / PB_COLS;
+  int gx = 768 / ny;  // ~3 workgroups per CU (32 KB of LDS each)
+  if (gx > p.G) gx = p.G;
+  dim3 grid((unsigned)gx, (unsigned)ny), block(PB_T);
+  const int cpw = p.C2 / PB_W;
+  if (cpw == 8)
+    hipLaunchKernelGGL((pool_wgrad_kernel<8>), grid, block, 0, st, p);
+  else if (cpw == 16)
+    hipLaunchKernelGGL((pool_wgrad_kernel<16>), grid, block, 0, st, p);
+  else
+    hipLaunchKernelGGL((pool_wgrad_kernel<32>), grid, block, 0, st, p);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+template <int NQ>
+int launch_dgrad_nq(const PoolBwdArgs& p, hipStream_t st) {
+  const int ny = p.C1 / PB_COLS;
+  const size_t lds = (size_t)p.C2 * PB_COLS * sizeof(float);
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_dgrad_kernel<NQ>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PZN_ELAUNCH;
+  const int per_cu = lds <= 64 * 1024 ? 2 : 1;  // 16 waves per workgroup, 32 per CU
+  int gx = 256 * per_cu / ny;
+  if (gx < 1) gx = 1;
+  if (gx > p.G) gx = p.G;
+  hipLaunchKernelGGL((pool_dgrad_kernel<NQ>), dim3((unsigned)gx, (unsigned)ny), dim3(PD_T), lds, st, p);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+int launch_dgrad(const PoolBwdArgs& p, hipStream_t st) {
+  if (p.C2 == 64) return launch_dgrad_nq<1>(p, st);
+  if (p.C2 == 128) return launch_dgrad_nq<2>(p, st);
+  return launch_dgrad_nq<4>(p, st);
+}
+
+bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+bool pzn_pool_bwd_supported(int C1, int C2, const float* W, const float* h, const float* dh) {
+  return C1 > 0 && C1 % PB_COLS == 0 && (C2 == 64 || C2 == 128 || C2 == 256) && aligned16(W) && aligned16(h) &&
+         aligned16(dh);
+}
+
+int pzn_pool_bwd_sparse(const float* dout, const int32_t* argmax, const float* out, const float* W, const float* h,
+                        float* dh, float* dW, float* db, int G, int C1, int C2, hipStream_t st) {
+  PoolBwdArgs p{dout, argmax, out, W, h, dh, dW, db, G, C1, C2};
+  if (!dh && !dW) return PZN_EINVAL;
+  if (dW) {
+    int rc = launch_wgrad(p, st);
+    if (rc != PZN_OK) return rc;
+  }
+  return dh ? launch_dgrad(p, st) : PZN_OK;
+}

@@ -543,7 +543,9 @@ class _SaMlpMax(torch.autograd.Function):
         with torch.cuda.device(dev):
             _call("pzn_sa_mlp_max_bwd_f32", _p(xg), _p(w1p), _p(w2), _p(h), _p(out), _p(arg), _p(dout), R, D, C1, C2,
                   _p(dh), _p(drows), _p(dW1), _p(db1), _p(dW2), _p(db2), int(direct), _stream(),
-                  flops=2 * R * 32 * (2 * C1 * C2 + (3 + D) * C1 + (D * C1 if need_feat else 0)))
+                  # layer 2 is the sparse pass (one non-zero per group and channel: R*C2 row-axpys each way),
+                  # layer 1 the dense matrix-core products
+                  flops=2 * R * (2 * C1 * C2) + 2 * R * 32 * ((3 + D) * C1 + (D * C1 if need_feat else 0)))
             if need_feat:
                 dfeat = torch.zeros((B, N, D), dtype=torch.float32, device=dev)
                 _call("pzn_group_feat_bwd_f32", _p(drows), _p(idx), B, N, S, K, D, _p(dfeat), _stream())
