@@ -26,6 +26,7 @@ SOURCES = [
     ("chamfer.hip", []),
     ("gemm.hip", []),
     ("poolbwd.hip", []),
+    ("wsgemm.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]

@@ -665,6 +665,9 @@ void choose_splits(GemmArgs& p) {
 PZN_EXPORT int pzn_linear_fwd_f32(const float* x, const float* W, const float* bias, int M, int Kin, int Nout, int relu,
                                   float* y, pzn_stream_t stream) {
   PZN_CHECK_ARG(x && W && y && M > 0 && Kin > 0 && Nout > 0);
+  if (gemm_precision() != 0 && pzn_ws_gemm_supported(M, Nout, Kin, x, Kin, nullptr, false))  // skinny layer: wsgemm.hip
+    return pzn_ws_gemm(x, Kin, W, Kin, 0, y, Nout, M, Nout, Kin, bias, relu, nullptr, nullptr, nullptr,
+                       pzn_hip_stream(stream));
   GemmArgs p = base_args(M, Nout, Kin);
   p.A = x, p.lda = Kin, p.B = W, p.ldb = Kin, p.C = y, p.ldc = Nout, p.bias = bias, p.relu = relu;
   launch<true, true, EPI_STORE>(p, 1, pzn_hip_stream(stream));
@@ -674,6 +677,9 @@ PZN_EXPORT int pzn_linear_fwd_f32(const float* x, const float* W, const float* b
 PZN_EXPORT int pzn_linear_maxpool_fwd_f32(const float* x, const float* W, const float* bias, int R, int Kin, int Nout,
                                           float* out, int32_t* argmax, pzn_stream_t stream) {
   PZN_CHECK_ARG(x && W && out && argmax && R > 0 && Kin > 0 && Nout > 0);
+  if (gemm_precision() != 0 && pzn_ws_gemm_supported(R * 32, Nout, Kin, x, Kin, nullptr, true))
+    return pzn_ws_gemm(x, Kin, W, Kin, 0, out, Nout, R * 32, Nout, Kin, bias, 1, nullptr, nullptr, argmax,
+                       pzn_hip_stream(stream));
   GemmArgs p = base_args(R * 32, Nout, Kin);
   p.A = x, p.lda = Kin, p.B = W, p.ldb = Kin, p.C = out, p.ldc = Nout, p.bias = bias, p.relu = 1, p.argmax = argmax;
   launch<true, true, EPI_MAXPOOL>(p, 1, pzn_hip_stream(stream));
@@ -683,6 +689,9 @@ PZN_EXPORT int pzn_linear_maxpool_fwd_f32(const float* x, const float* W, const 
 PZN_EXPORT int pzn_linear_dgrad_f32(const float* dy, const float* y_relu, const float* W, int M, int Kin, int Nout,
                                     const float* x_relu, float* dx, pzn_stream_t stream) {
   PZN_CHECK_ARG(dy && W && dx && M > 0 && Kin > 0 && Nout > 0);
+  if (gemm_precision() != 0 && pzn_ws_gemm_supported(M, Kin, Nout, dy, Nout, y_relu, false))
+    return pzn_ws_gemm(dy, Nout, W, Kin, 1, dx, Kin, M, Kin, Nout, nullptr, 0, y_relu, x_relu, nullptr,
+                       pzn_hip_stream(stream));
   GemmArgs p = base_args(M, Kin, Nout);
   p.A = dy, p.lda = Nout, p.B = W, p.ldb = Kin, p.C = dx, p.ldc = Kin;
   if (y_relu) p.gen = GEN_RELU, p.genY = y_relu;
@@ -928,7 +937,10 @@ PZN_EXPORT int pzn_sa_mlp_max_bwd_f32(const float* xg, const float* W1p, const f
     launch<false, false, EPI_ATOMIC>(p, 1, st);
     if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
   }
-  if (dfeat_rows) {  // dfeat_rows[M, D] = dh W1p[:, 4:]
+  if (dfeat_rows && gemm_precision() != 0 && pzn_ws_gemm_supported(M, D, C1, dh_ws, C1, nullptr, false)) {
+    rc = pzn_ws_gemm(dh_ws, C1, W1p + 4, ldx, 1, dfeat_rows, D, M, D, C1, nullptr, 0, nullptr, nullptr, nullptr, st);
+    if (rc != PZN_OK) return rc;
+  } else if (dfeat_rows) {  // dfeat_rows[M, D] = dh W1p[:, 4:]
     GemmArgs p = base_args(M, D, C1);
     p.A = dh_ws, p.lda = C1, p.B = W1p + 4, p.ldb = ldx, p.C = dfeat_rows, p.ldc = D;
     launch<true, false, EPI_STORE>(p, 1, st);

@@ -22,6 +22,8 @@
 //    the gradient, ds_read_b64 of the W row, packed fma.  The finished row is ReLU-masked with h and stored
 //    straight from registers.  Work per group is exactly C2 hits however skewed the arg-max rows are (in the
 //    model the nearest neighbours win most channels; a rows-per-wave split was 3x slower there).
+#include <stdlib.h>
+
 #include "pzn_common.h"
 #include "pzn_internal.h"
 
@@ -59,41 +61,50 @@ __global__ __launch_bounds__(PB_T) void pool_wgrad_kernel(PoolBwdArgs p) {
 
   // staging map for the 32 x 128 tile: rows srow and srow + 16, 16-byte column scol
   const int srow = tid >> 5, scol = (tid & 31) * 4;
-  float4 pre0 = make_float4(0.f, 0.f, 0.f, 0.f), pre1 = pre0;
-  int av_n = 0;
-  float gv_n = 0.f;
-#define PB_PREFETCH(gg)                                                             \
+  // Two register sets = two groups in flight.  The loads are unconditional (group index clamped) and the
+  // loop is unrolled by the two sets so that the compiler's vmcnt bookkeeping stays exact (a branch around
+  // a load makes it fall back to vmcnt(0), i.e. to a prefetch distance of nothing).
+  float4 pa0, pa1, pb0, pb1;
+  int ava, avb;
+  float gva, gvb;
+#define PB_ISSUE(gg, x0, x1, av_, gv_)                                              \
   do {                                                                              \
-    const float* hp = p.h + ((size_t)(gg) * 32 + srow) * p.C1 + col0 + scol;       \
-    pre0 = *reinterpret_cast<const float4*>(hp);                                    \
-    pre1 = *reinterpret_cast<const float4*>(hp + (size_t)16 * p.C1);                \
-    size_t o = (size_t)(gg) * p.C2 + ch;                                            \
-    int a = p.argmax[o];                                                            \
-    float go = p.out[o], gd = p.dout[o];                                            \
-    av_n = a & 31;                                                                  \
-    gv_n = (lane < CPW && go > 0.f) ? gd : 0.f;                                     \
+    const int g_ = (gg) < p.G ? (gg) : p.G - 1;                                     \
+    const float* hp = p.h + ((size_t)g_ * 32 + srow) * p.C1 + col0 + scol;          \
+    x0 = *reinterpret_cast<const float4*>(hp);                                      \
+    x1 = *reinterpret_cast<const float4*>(hp + (size_t)16 * p.C1);                  \
+    const size_t o = (size_t)g_ * p.C2 + ch;                                        \
+    const int a = p.argmax[o];                                                      \
+    const float go = p.out[o], gd = p.dout[o];                                      \
+    av_ = a & 31;                                                                   \
+    gv_ = (lane < CPW && go > 0.f) ? gd : 0.f;                                      \
   } while (0)
-  if ((int)blockIdx.x < p.G) PB_PREFETCH(blockIdx.x);
-
-  int it = 0;
-  for (int g = blockIdx.x; g < p.G; g += gridDim.x, ++it) {
-    const int cur = it & 1;
-    *reinterpret_cast<float4*>(&hbuf[cur][srow][scol]) = pre0;
-    *reinterpret_cast<float4*>(&hbuf[cur][srow + 16][scol]) = pre1;
-    const int av = av_n;
-    const float gv = gv_n;
-    __syncthreads();  // one barrier per group: the tile two groups back is free again by construction
-    if (g + (int)gridDim.x < p.G) PB_PREFETCH(g + gridDim.x);
-    dbacc += gv;
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-      const int a = __builtin_amdgcn_readlane(av, c);
-      const float gs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gv), c));
-      v2f hr = *reinterpret_cast<const v2f*>(&hbuf[cur][a][2 * lane]);
-      acc[c] += gs * hr;
-    }
+#define PB_GROUP(buf, x0, x1, av_, gv_, gnext)                                      \
+  do {                                                                              \
+    *reinterpret_cast<float4*>(&hbuf[buf][srow][scol]) = x0;                        \
+    *reinterpret_cast<float4*>(&hbuf[buf][srow + 16][scol]) = x1;                   \
+    const int av = av_;                                                             \
+    const float gv = gv_;                                                           \
+    __syncthreads(); /* one barrier per group: the tile two groups back is free again by construction */ \
+    PB_ISSUE(gnext, x0, x1, av_, gv_);                                              \
+    dbacc += gv;                                                                    \
+    _Pragma("unroll") for (int c = 0; c < CPW; ++c) {                               \
+      const int a = __builtin_amdgcn_readlane(av, c);                               \
+      const float gs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gv), c)); \
+      v2f hr = *reinterpret_cast<const v2f*>(&hbuf[buf][a][2 * lane]);             \
+      acc[c] += gs * hr;                                                            \
+    }                                                                               \
+  } while (0)
+  const int gs_ = gridDim.x;
+  PB_ISSUE((int)blockIdx.x, pa0, pa1, ava, gva);
+  PB_ISSUE((int)blockIdx.x + gs_, pb0, pb1, avb, gvb);
+  for (int g = blockIdx.x; g < p.G; g += 2 * gs_) {
+    PB_GROUP(0, pa0, pa1, ava, gva, g + 2 * gs_);
+    if (g + gs_ >= p.G) break;
+    PB_GROUP(1, pb0, pb1, avb, gvb, g + 3 * gs_);
   }
-#undef PB_PREFETCH
+#undef PB_GROUP
+#undef PB_ISSUE
 
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {
@@ -176,7 +187,8 @@ __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
 
 int launch_wgrad(const PoolBwdArgs& p, hipStream_t st) {
   const int ny = p.C1 / PB_COLS;
-  int gx = 768 / ny;  // ~3 workgroups per CU (32 KB of LDS each)
+  static const int total = [] { const char* e = getenv("PZN_POOL_WGRAD_GRID"); return e ? atoi(e) : 256; }();  // tuning aid (one workgroup per CU measured best)
+  int gx = total / ny;  // workgroups in flight; each ends with C2*128 atomic adds into dW
   if (gx > p.G) gx = p.G;
   dim3 grid((unsigned)gx, (unsigned)ny), block(PB_T);
   const int cpw = p.C2 / PB_W;

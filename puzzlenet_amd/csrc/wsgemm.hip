@@ -1,0 +1,329 @@
+// wsgemm.hip — weight-stationary bf16x3 GEMM for the skinny layers (K, N <= a few hundred, M huge).
+//
+//   C[M, N] = epilogue( A[M, K] * W^T )       A row-major (k contiguous), W = nn.Linear weight [N, K] ("NT",
+//   forward) or [K, N] ("NN", input gradient dX = dY W with K = Nout).
+//
+// Most of the step's dense time is in products whose weight matrix is tiny (<= 256 x 256) while the
+// activation matrix has 10^5..10^6 rows (shared MLPs of the set-abstraction levels, attention
+// projections, point-wise MLPs).  The general tile engine (gemm.hip) stages BOTH operands through LDS every
+// 16 k and synchronises its four waves at every step; on these shapes its waves sit in s_waitcnt /
+// s_barrier 50-70 % of the time (SQ_WAIT_ANY, profiles/).  Here instead
+//   * the weight slice (NT*32 columns x K) is split ONCE per workgroup into its three bf16 planes, stored
+//     in LDS in MFMA-fragment order, and stays there: workgroups are persistent and walk row tiles;
+//   * the activation rows never touch LDS: for v_mfma_f32_32x32x16_bf16 lane l holds A[row l&31][8
+//     consecutive k], which is exactly what a lane can load from global memory itself (16 consecutive
+//     floats per two MFMA steps; the reduction index is permuted identically on the weight side so that
+//     a lane's 64 bytes are contiguous) and split in registers;
+//   * so a wavefront owns a 32-row tile end to end: no barrier after the prologue, every wave runs its
+//     own software pipeline (next loads in flight while the current 16 floats are split and multiplied),
+//     and the 32 rows of a tile are one (centroid, K = 32 neighbours) group for the max-pool epilogue.
+// Split precision as in gemm.hip: x = x1 + x2 + x3 (bf16 each, exact), six products per tile and 16 k.
+#include <stdlib.h>
+
+#include "pzn_common.h"
+#include "pzn_internal.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WS_NW = 12;        // wavefronts per workgroup, each on its own row tiles
+constexpr int WS_STAGE_LD = 36;  // floats per row of a wave's 32 x 32 output patch in LDS (16-B aligned, conflict-free)
+constexpr int WS_LDS_MAX = 150 * 1024;
+
+struct WsArgs {
+  const float* A;
+  int lda;
+  const float* W;
+  int ldw;
+  int w_kmajor;  // 0: W[n*ldw + k]   1: W[k*ldw + n]
+  float* C;
+  int ldc;
+  int M, N, K;
+  int nd;               // double steps of 32 k: ceil(K / 32)
+  const float* bias;    // per column or NULL
+  int relu;
+  const float* genY;    // A(m,k) *= genY(m,k) > 0   (same layout as A) or NULL
+  const float* maskH;   // C(m,n) *= maskH(m,n) > 0  (same layout as C) or NULL
+  int32_t* argmax;      // max-pool epilogue: C is [M/32, N]
+};
+
+// two floats -> their three bf16 planes, packed (lo = first element)
+__device__ __forceinline__ void split_pair(v2f x, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+  bf16x2 a = __builtin_convertvector(x, bf16x2);
+  p1 = __builtin_bit_cast(uint32_t, a);
+  v2f fa = v2f{__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+  v2f r = x - fa;
+  bf16x2 b = __builtin_convertvector(r, bf16x2);
+  p2 = __builtin_bit_cast(uint32_t, b);
+  v2f fb = v2f{__uint_as_float(p2 << 16), __uint_as_float(p2 & 0xffff0000u)};
+  v2f r2 = r - fb;
+  bf16x2 c = __builtin_convertvector(r2, bf16x2);
+  p3 = __builtin_bit_cast(uint32_t, c);
+}
+
+__device__ __forceinline__ void split8(float4 lo, float4 hi, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+  uint32_t a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
+  split_pair(v2f{lo.x, lo.y}, a0, b0, c0);
+  split_pair(v2f{lo.z, lo.w}, a1, b1, c1);
+  split_pair(v2f{hi.x, hi.y}, a2, b2, c2);
+  split_pair(v2f{hi.z, hi.w}, a3, b3, c3);
+  const u32x4 a = {a0, a1, a2, a3}, b = {b0, b1, b2, b3}, c = {c0, c1, c2, c3};
+  p1 = __builtin_bit_cast(bf16x8, a);
+  p2 = __builtin_bit_cast(bf16x8, b);
+  p3 = __builtin_bit_cast(bf16x8, c);
+}
+
+__device__ __forceinline__ float4 relu_mask(float4 x, float4 y) {
+  return make_float4(y.x > 0.f ? x.x : 0.f, y.y > 0.f ? x.y : 0.f, y.z > 0.f ? x.z : 0.f, y.w > 0.f ? x.w : 0.f);
+}
+
+// NT = 32-column tiles per wavefront (weight slice = NT*32 columns), MAXPOOL = max over the tile's 32 rows,
+// GENY = ReLU-mask the activation stream with genY.
+template <int NT, bool MAXPOOL, bool GENY, int NW>
+__global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
+  constexpr int WS_T = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];  // [nd*2][NT][3][64 lanes][16 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int n0 = blockIdx.y * (NT * 32);
+
+  // ---- prologue: this slice of W -> three bf16 planes in fragment order (k permuted: lane half h of
+  //      double step d holds k = 32d + 16h + 8s + 0..7 in MFMA step s)
+  const int nfrag = p.nd * 2 * NT * 64;
+  for (int f = tid; f < nfrag; f += WS_T) {
+    const int l = f & 63, j = (f >> 6) % NT, ks = (f >> 6) / NT;
+    const int n = n0 + j * 32 + (l & 31);
+    const int k = (ks >> 1) * 32 + (l >> 5) * 16 + (ks & 1) * 8;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool ok = n < p.N && k + i < p.K;
+      const size_t off = p.w_kmajor ? (size_t)(k + i) * p.ldw + n : (size_t)n * p.ldw + k + i;
+      v[i] = ok ? p.W[off] : 0.f;
+    }
+    bf16x8 w1, w2, w3;
+    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), w1, w2, w3);
+    unsigned char* dst = wlds + ((size_t)(ks * NT + j) * 3) * 1024 + l * 16;
+    *reinterpret_cast<bf16x8*>(dst) = w1;
+    *reinterpret_cast<bf16x8*>(dst + 1024) = w2;
+    *reinterpret_cast<bf16x8*>(dst + 2048) = w3;
+  }
+  __syncthreads();  // the only barrier
+
+  const int ntiles = (p.M + 31) >> 5;
+  const int tstride = gridDim.x * NW;
+  int t = blockIdx.x * NW + wave;
+  if (t >= ntiles) return;
+
+  // This lane's stream: row (tile*32 + l31), 16 consecutive floats at k = 32d + 16*half per double step.
+  // One register set: the next 64 bytes are requested right after the current ones have arrived and stay in
+  // flight for a whole double step of MFMAs (this wave's and those of the other waves on the SIMD).
+  float4 pa0, pa1, pa2, pa3;                           // A
+  float4 ya0, ya1, ya2, ya3;                           // genY
+  int it = t, id = 0;                                  // issue cursor (tile, double step)
+  // Loads are issued UNCONDITIONALLY (rows past M and k past K are clamped to valid addresses and zeroed at
+  // consumption): a branch around them would make the compiler's vmcnt bookkeeping fall back to vmcnt(0) and
+  // collapse the prefetch distance.
+  const int kmax = p.K - 4;
+#define WS_ISSUE(x0, x1, x2, x3, y0, y1, y2, y3)                                                          \
+  do {                                                                                                    \
+    int row_ = it * 32 + l31;                                                                             \
+    row_ = row_ < p.M ? row_ : p.M - 1;                                                                   \
+    const int kb_ = id * 32 + half * 16;                                                                  \
+    const float* a_ = p.A + (size_t)row_ * p.lda;                                                         \
+    x0 = *reinterpret_cast<const float4*>(a_ + min(kb_, kmax));                                           \
+    x1 = *reinterpret_cast<const float4*>(a_ + min(kb_ + 4, kmax));                                       \
+    x2 = *reinterpret_cast<const float4*>(a_ + min(kb_ + 8, kmax));                                       \
+    x3 = *reinterpret_cast<const float4*>(a_ + min(kb_ + 12, kmax));                                      \
+    if (GENY) {                                                                                           \
+      const float* y_ = p.genY + (size_t)row_ * p.lda;                                                    \
+      y0 = *reinterpret_cast<const float4*>(y_ + min(kb_, kmax));                                         \
+      y1 = *reinterpret_cast<const float4*>(y_ + min(kb_ + 4, kmax));                                     \
+      y2 = *reinterpret_cast<const float4*>(y_ + min(kb_ + 8, kmax));                                     \
+      y3 = *reinterpret_cast<const float4*>(y_ + min(kb_ + 12, kmax));                                    \
+    }                                                                                                     \
+    if (++id == p.nd) id = 0, it += tstride;                                                              \
+  } while (0)
+  WS_ISSUE(pa0, pa1, pa2, pa3, ya0, ya1, ya2, ya3);
+
+  floatx16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float* stage = reinterpret_cast<float*>(wlds + (size_t)p.nd * 2 * NT * 3 * 1024) + wave * (32 * WS_STAGE_LD);
+
+  auto take = [&](float4 x, float4 y, bool in_k) {
+    if (GENY) x = relu_mask(x, y);
+    return in_k ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  int d = 0;
+  // one double step: consume a register set, refill it two double steps ahead, 2 x NT x 6 MFMAs
+  auto step = [&](float4 c0, float4 c1, float4 c2, float4 c3) {
+    const unsigned char* wb = wlds + (size_t)(d * 2) * (NT * 3 * 1024) + lane * 16;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a1, a2, a3;
+      split8(s ? c2 : c0, s ? c3 : c1, a1, a2, a3);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const unsigned char* wj = wb + (s * NT + j) * (3 * 1024);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wj);
+        const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(wj + 1024);
+        const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(wj + 2048);
+        floatx16 c = acc[j];
+        if (MAXPOOL) {  // C[row][col]: the 32 rows of the group sit in one lane's registers (+ the other half)
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, c, 0, 0, 0);  // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+        } else {  // transposed product C^T[col][row]: a lane ends up with 4 consecutive columns of one row
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a3, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a2, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3, a1, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a2, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a1, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, c, 0, 0, 0);
+        }
+        acc[j] = c;
+      }
+    }
+  };
+
+  auto epilogue = [&]() {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (MAXPOOL) {  // element r of lane l = row (r&3) + 8*(r>>2) + 4*half, column l31
+        const int col = n0 + j * 32 + l31;
+        const bool col_ok = col < p.N;
+        const float bv = (p.bias && col_ok) ? p.bias[col] : 0.f;
+        float best = -INFINITY;
+        int bi = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = acc[j][r] + bv;
+          v = v > 0.f ? v : 0.f;  // ReLU before the max (model5_b.py:453-454)
+          const bool gt = v > best;
+          best = gt ? v : best;
+          bi = gt ? rl : bi;
+        }
+        const float ob = __shfl_xor(best, 32, PZN_WAVE);
+        const int oi = __shfl_xor(bi, 32, PZN_WAVE);
+        const bool take = ob > best || (ob == best && oi < bi);
+        best = take ? ob : best;
+        bi = take ? oi : bi;
+        if (half == 0 && col_ok) {
+          p.C[(size_t)t * p.ldc + col] = best;
+          p.argmax[(size_t)t * p.ldc + col] = bi;
+        }
+      } else {  // element 4q+e of lane l = column 8q + 4*half + e, row l31: through the wave's LDS patch -> 16-B row stores
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cl = 8 * q + 4 * half, col = n0 + j * 32 + cl;
+          float4 v = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+          if (p.bias && col + 3 < p.N) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
+            v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+          }
+          if (p.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+          *reinterpret_cast<float4*>(stage + l31 * WS_STAGE_LD + cl) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rl = (lane >> 3) + 8 * i, c4 = (lane & 7) * 4;
+          float4 v = *reinterpret_cast<const float4*>(stage + rl * WS_STAGE_LD + c4);
+          const int row = t * 32 + rl, col = n0 + j * 32 + c4;
+          if (row < p.M && col + 3 < p.N) {
+            const size_t o = (size_t)row * p.ldc + col;
+            if (p.maskH) v = relu_mask(v, *reinterpret_cast<const float4*>(p.maskH + o));
+            *reinterpret_cast<float4*>(p.C + o) = v;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    }
+  };
+
+  for (; t < ntiles; t += tstride) {
+    for (d = 0; d < p.nd; ++d) {
+      const int kb = d * 32 + half * 16;
+      const float4 c0 = take(pa0, ya0, kb <= kmax), c1 = take(pa1, ya1, kb + 4 <= kmax);
+      const float4 c2 = take(pa2, ya2, kb + 8 <= kmax), c3 = take(pa3, ya3, kb + 12 <= kmax);
+      WS_ISSUE(pa0, pa1, pa2, pa3, ya0, ya1, ya2, ya3);
+      step(c0, c1, c2, c3);
+    }
+    epilogue();
+  }
+#undef WS_ISSUE
+}
+
+size_t stage_bytes(bool maxpool) { return maxpool ? 0 : (size_t)WS_NW * 32 * WS_STAGE_LD * sizeof(float); }
+
+template <int NT, bool MAXPOOL, bool GENY>
+int launch_nt(const WsArgs& p, hipStream_t st) {
+  auto kern = ws_gemm_kernel<NT, MAXPOOL, GENY, WS_NW>;
+  const size_t lds = (size_t)p.nd * 2 * NT * 3 * 1024 + stage_bytes(MAXPOOL);
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PZN_ELAUNCH;
+  const int nslices = (p.N + NT * 32 - 1) / (NT * 32);
+  const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+  int gx = (256 * per_cu) / nslices;
+  gx = gx < 8 ? 8 : (gx / 8) * 8;  // multiple of 8: the slices of one row range land on one XCD (shared L2)
+  const int ntiles = (p.M + 31) / 32, need = (ntiles + WS_NW - 1) / WS_NW;
+  if (gx > need) gx = need;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nslices), dim3(WS_NW * 64), lds, st, p);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+template <bool MAXPOOL, bool GENY>
+int launch_mg(const WsArgs& p, int nt, hipStream_t st) {
+  if (nt == 4) return launch_nt<4, MAXPOOL, GENY>(p, st);
+  if (nt == 2) return launch_nt<2, MAXPOOL, GENY>(p, st);
+  return launch_nt<1, MAXPOOL, GENY>(p, st);
+}
+
+// columns per workgroup (in 32-column tiles) such that the weight slice fits in LDS; 0 = does not fit
+int pick_nt(int N, int nd, bool maxpool) {
+  const size_t per_tile = (size_t)nd * 2 * 3 * 1024, room = (size_t)WS_LDS_MAX - stage_bytes(maxpool);
+  int nt = N > 64 ? 4 : (N > 32 ? 2 : 1);
+  while (nt > 1 && per_tile * nt > room) nt >>= 1;
+  return per_tile * nt <= room ? nt : 0;
+}
+
+bool ws_enabled() {
+  static const bool on = [] { const char* e = getenv("PZN_WS_GEMM"); return !(e && e[0] == '0'); }();  // tuning aid
+  return on;
+}
+
+}  // namespace
+
+bool pzn_ws_gemm_supported(int M, int N, int K, const float* A, int lda, const float* genY, bool maxpool) {
+  if (!ws_enabled()) return false;
+  if (M < 4096 || N < 32 || (N & 3) || K < 16 || (K & 3) || (lda & 3)) return false;  // small / unaligned: general engine
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(genY) & 15)) return false;
+  return pick_nt(N, (K + 31) / 32, maxpool) != 0;
+}
+
+int pzn_ws_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor, float* C, int ldc, int M, int N, int K,
+                const float* bias, int relu, const float* genY, const float* maskH, int32_t* argmax, hipStream_t st) {
+  WsArgs p{A, lda, W, ldw, w_kmajor, C, ldc, M, N, K, (K + 31) / 32, bias, relu, genY, maskH, argmax};
+  const int nt = pick_nt(N, p.nd, argmax != nullptr);
+  if (!nt) return PZN_EUNSUPPORTED;
+  if (argmax) return genY ? PZN_EUNSUPPORTED : launch_mg<true, false>(p, nt, st);
+  if ((ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15) || (reinterpret_cast<uintptr_t>(maskH) & 15) ||
+      (reinterpret_cast<uintptr_t>(bias) & 15))
+    return PZN_EUNSUPPORTED;
+  return genY ? launch_mg<false, true>(p, nt, st) : launch_mg<false, false>(p, nt, st);
+}

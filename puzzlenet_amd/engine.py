@@ -29,7 +29,8 @@ class TrainStep:
         self.graph = None
         self.opt_in_graph = use_graph and world == 1
         lr_arg = torch.tensor(float(lr), device=dev) if use_graph else lr
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr_arg, capturable=bool(use_graph))
+        # fused=True: one multi-tensor Adam kernel chain instead of ~10 foreach passes over 104 tensors (same update rule)
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr_arg, capturable=bool(use_graph), fused=not use_graph)
         self.sched = torch.optim.lr_scheduler.StepLR(self.opt, 50, 0.999)       # model5_b.py:1453-1457
         self.loss = None
         self.feed = None

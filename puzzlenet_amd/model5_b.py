@@ -389,6 +389,7 @@ class TouchedRegraster(_Base):
 
     def configure_optimizers(self):
         """model5_b.py:1453-1457: Adam + StepLR(50, 0.999) stepped per batch."""
-        optimizer = torch.optim.Adam(self.parameters(), lr=self.C.lr)
+        on_gpu = next(self.parameters()).is_cuda
+        optimizer = torch.optim.Adam(self.parameters(), lr=self.C.lr, fused=on_gpu)   # fused: same rule, one kernel chain
         self.scheduler = torch.optim.lr_scheduler.StepLR(optimizer, 50, 0.999)
         return [optimizer], [{'scheduler': self.scheduler, 'interval': 'step'}]

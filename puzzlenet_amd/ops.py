@@ -20,6 +20,7 @@ class KernelTimer:
     enabled = False
     records = {}
     flops = {}
+    shapes = None   # set to {} before start() to also collect {(entry point, int args): [ms, ...]} (tools/)
 
     @classmethod
     def start(cls):
@@ -32,6 +33,13 @@ class KernelTimer:
         cls.enabled = False
         torch.cuda.synchronize()
         out = {k: (len(v), sum(a.elapsed_time(b) for a, b, _ in v)) for k, v in cls.records.items()}
+        if cls.shapes is not None:
+            for k, v in cls.records.items():
+                for a, b, f in v:
+                    if isinstance(f, tuple):
+                        cls.shapes.setdefault((k,) + f[1], []).append(a.elapsed_time(b))
+            for v in cls.records.values():
+                v[:] = [(a, b, f[0] if isinstance(f, tuple) else f) for a, b, f in v]
         cls.flops = {k: sum(f for _, _, f in v) for k, v in cls.records.items()}
         cls.records = {}
         return out
@@ -44,6 +52,8 @@ def _call(name, *args, flops=0):
         a.record()
         _lib.call(name, *args)
         b.record()
+        if KernelTimer.shapes is not None:
+            flops = (flops, tuple(x for x in args if isinstance(x, int) and 0 <= x < (1 << 31)))
         KernelTimer.records.setdefault(name, []).append((a, b, flops))
     else:
         _lib.call(name, *args)
