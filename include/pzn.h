@@ -245,6 +245,18 @@ int pzn_sa_mlp_max_bwd_f32(const float* xg, const float* W1p, const float* W2,
                            const float* dout, int R, int D, int C1, int C2, float* dh_ws,
                            float* dfeat_rows, float* dW1, float* db1, float* dW2,
                            float* db2, int accumulate, pzn_stream_t stream);
+/* Same backward with the feature gradient scattered straight into grad_feat[B,N,D]
+ * (index_points backward, pointnet_util.py:39-50 under :123-126):
+ * grad_feat[b, idx[b,s,k], :] += (dh W1p[:,4:])[b,s,k,:]; grad_feat zero-initialised (or
+ * already holding other contributions) by the caller; R = B*S groups of K = 32 rows.
+ * rows_ws[B*S*32, D] is scratch for shapes the fused epilogue does not cover (may be NULL:
+ * PZN_EUNSUPPORTED is returned for those). */
+int pzn_sa_mlp_max_bwd_scatter_f32(const float* xg, const float* W1p, const float* W2,
+                                   const float* h, const float* out, const int32_t* argmax,
+                                   const float* dout, const int64_t* idx, int B, int N, int S,
+                                   int D, int C1, int C2, float* dh_ws, float* rows_ws,
+                                   float* grad_feat, float* dW1, float* db1, float* dW2,
+                                   float* db2, int accumulate, pzn_stream_t stream);
 
 /* scaled_dot_production of layerAttention, model5_b.py:67-75:
  * attn[B,L,L] = softmax(q[B,L,dk] k[B,L,dk]^T / sqrt(dk)), out[B,L,dv] = attn v.

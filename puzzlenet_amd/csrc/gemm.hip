@@ -666,7 +666,7 @@ PZN_EXPORT int pzn_linear_fwd_f32(const float* x, const float* W, const float* b
                                   float* y, pzn_stream_t stream) {
   PZN_CHECK_ARG(x && W && y && M > 0 && Kin > 0 && Nout > 0);
   if (gemm_precision() != 0 && pzn_ws_gemm_supported(M, Nout, Kin, x, Kin, nullptr, false))  // skinny layer: wsgemm.hip
-    return pzn_ws_gemm(x, Kin, W, Kin, 0, y, Nout, M, Nout, Kin, bias, relu, nullptr, nullptr, nullptr,
+    return pzn_ws_gemm(x, Kin, W, Kin, 0, y, Nout, M, Nout, Kin, bias, relu, nullptr, nullptr, nullptr, nullptr, 0, 0,
                        pzn_hip_stream(stream));
   GemmArgs p = base_args(M, Nout, Kin);
   p.A = x, p.lda = Kin, p.B = W, p.ldb = Kin, p.C = y, p.ldc = Nout, p.bias = bias, p.relu = relu;
@@ -678,7 +678,7 @@ PZN_EXPORT int pzn_linear_maxpool_fwd_f32(const float* x, const float* W, const 
                                           float* out, int32_t* argmax, pzn_stream_t stream) {
   PZN_CHECK_ARG(x && W && out && argmax && R > 0 && Kin > 0 && Nout > 0);
   if (gemm_precision() != 0 && pzn_ws_gemm_supported(R * 32, Nout, Kin, x, Kin, nullptr, true))
-    return pzn_ws_gemm(x, Kin, W, Kin, 0, out, Nout, R * 32, Nout, Kin, bias, 1, nullptr, nullptr, argmax,
+    return pzn_ws_gemm(x, Kin, W, Kin, 0, out, Nout, R * 32, Nout, Kin, bias, 1, nullptr, nullptr, argmax, nullptr, 0, 0,
                        pzn_hip_stream(stream));
   GemmArgs p = base_args(R * 32, Nout, Kin);
   p.A = x, p.lda = Kin, p.B = W, p.ldb = Kin, p.C = out, p.ldc = Nout, p.bias = bias, p.relu = 1, p.argmax = argmax;
@@ -690,7 +690,7 @@ PZN_EXPORT int pzn_linear_dgrad_f32(const float* dy, const float* y_relu, const 
                                     const float* x_relu, float* dx, pzn_stream_t stream) {
   PZN_CHECK_ARG(dy && W && dx && M > 0 && Kin > 0 && Nout > 0);
   if (gemm_precision() != 0 && pzn_ws_gemm_supported(M, Kin, Nout, dy, Nout, y_relu, false))
-    return pzn_ws_gemm(dy, Nout, W, Kin, 1, dx, Kin, M, Kin, Nout, nullptr, 0, y_relu, x_relu, nullptr,
+    return pzn_ws_gemm(dy, Nout, W, Kin, 1, dx, Kin, M, Kin, Nout, nullptr, 0, y_relu, x_relu, nullptr, nullptr, 0, 0,
                        pzn_hip_stream(stream));
   GemmArgs p = base_args(M, Kin, Nout);
   p.A = dy, p.lda = Nout, p.B = W, p.ldb = Kin, p.C = dx, p.ldc = Kin;
@@ -913,12 +913,10 @@ PZN_EXPORT int pzn_sharedmlp_max_bwd_f32(const float* x, const float* W1, const 
 // columns and the bias from the A stream, input gradient only for the D feature columns (xyz needs none).
 //   dh_ws[R*32,C1] scratch; dfeat_rows[R*32,D] may be NULL; dW1 is in the PARAMETER layout [C1,3+D];
 //   dW1, db1, dW2, db2 are overwritten, or added to when accumulate != 0.
-PZN_EXPORT int pzn_sa_mlp_max_bwd_f32(const float* xg, const float* W1p, const float* W2, const float* h,
-                                      const float* out, const int32_t* argmax, const float* dout, int R, int D, int C1,
-                                      int C2, float* dh_ws, float* dfeat_rows, float* dW1, float* db1, float* dW2,
-                                      float* db2, int accumulate, pzn_stream_t stream) {
-  PZN_CHECK_ARG(xg && W1p && W2 && h && out && argmax && dout && dh_ws && dW1 && db1 && dW2 && db2);
-  PZN_CHECK_ARG(R > 0 && D > 0 && (D & 3) == 0 && C1 > 0 && C2 > 0);
+static int sa_mlp_max_bwd(const float* xg, const float* W1p, const float* W2, const float* h, const float* out,
+                          const int32_t* argmax, const float* dout, int R, int D, int C1, int C2, float* dh_ws,
+                          float* dfeat_rows, const int64_t* idx, int rows_in, int rows_out, float* dfeat, float* dW1,
+                          float* db1, float* dW2, float* db2, int accumulate, pzn_stream_t stream) {
   hipStream_t st = pzn_hip_stream(stream);
   const int ldx = 4 + D, ldw = 3 + D, M = R * 32;
   int rc = pool_layer_bwd(dout, argmax, out, W2, h, R, C1, C2, dh_ws, dW2, db2, accumulate, stream);
@@ -937,16 +935,49 @@ PZN_EXPORT int pzn_sa_mlp_max_bwd_f32(const float* xg, const float* W1p, const f
     launch<false, false, EPI_ATOMIC>(p, 1, st);
     if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
   }
-  if (dfeat_rows && gemm_precision() != 0 && pzn_ws_gemm_supported(M, D, C1, dh_ws, C1, nullptr, false)) {
-    rc = pzn_ws_gemm(dh_ws, C1, W1p + 4, ldx, 1, dfeat_rows, D, M, D, C1, nullptr, 0, nullptr, nullptr, nullptr, st);
+  if (!dfeat_rows && !dfeat) return PZN_OK;
+  const bool ws = gemm_precision() != 0 && pzn_ws_gemm_supported(M, D, C1, dh_ws, C1, nullptr, false);
+  if (dfeat && ws)  // dh W1p[:, 4:] scatter-added row by row into grad_feat: the [M, D] rows are never written
+    return pzn_ws_gemm(dh_ws, C1, W1p + 4, ldx, 1, dfeat, D, M, D, C1, nullptr, 0, nullptr, nullptr, nullptr, idx, rows_in,
+                       rows_out, st);
+  if (!dfeat_rows) return PZN_EUNSUPPORTED;
+  if (ws) {
+    rc = pzn_ws_gemm(dh_ws, C1, W1p + 4, ldx, 1, dfeat_rows, D, M, D, C1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0,
+                     0, st);
     if (rc != PZN_OK) return rc;
-  } else if (dfeat_rows) {  // dfeat_rows[M, D] = dh W1p[:, 4:]
+  } else {  // dfeat_rows[M, D] = dh W1p[:, 4:]
     GemmArgs p = base_args(M, D, C1);
     p.A = dh_ws, p.lda = C1, p.B = W1p + 4, p.ldb = ldx, p.C = dfeat_rows, p.ldc = D;
     launch<true, false, EPI_STORE>(p, 1, st);
     if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
   }
+  if (dfeat)
+    return pzn_group_feat_bwd_f32(dfeat_rows, idx, rows_out ? M / rows_in : 1, rows_out, rows_in / 32, 32, D, dfeat, stream);
   return PZN_OK;
+}
+
+PZN_EXPORT int pzn_sa_mlp_max_bwd_f32(const float* xg, const float* W1p, const float* W2, const float* h,
+                                      const float* out, const int32_t* argmax, const float* dout, int R, int D, int C1,
+                                      int C2, float* dh_ws, float* dfeat_rows, float* dW1, float* db1, float* dW2,
+                                      float* db2, int accumulate, pzn_stream_t stream) {
+  PZN_CHECK_ARG(xg && W1p && W2 && h && out && argmax && dout && dh_ws && dW1 && db1 && dW2 && db2);
+  PZN_CHECK_ARG(R > 0 && D > 0 && (D & 3) == 0 && C1 > 0 && C2 > 0);
+  return sa_mlp_max_bwd(xg, W1p, W2, h, out, argmax, dout, R, D, C1, C2, dh_ws, dfeat_rows, nullptr, 0, 0, nullptr, dW1,
+                        db1, dW2, db2, accumulate, stream);
+}
+
+// Same, with the feature gradient scattered straight into grad_feat[B, N, D] (+=; zero-initialised by the
+// caller): grad_feat[b, idx[b,s,k], :] += (dh W1p[:, 4:])[b,s,k,:].  rows_ws[B*S*32, D] is scratch for the
+// shapes the fused epilogue does not cover (may be NULL: PZN_EUNSUPPORTED is returned for those).
+PZN_EXPORT int pzn_sa_mlp_max_bwd_scatter_f32(const float* xg, const float* W1p, const float* W2, const float* h,
+                                              const float* out, const int32_t* argmax, const float* dout,
+                                              const int64_t* idx, int B, int N, int S, int D, int C1, int C2,
+                                              float* dh_ws, float* rows_ws, float* grad_feat, float* dW1, float* db1,
+                                              float* dW2, float* db2, int accumulate, pzn_stream_t stream) {
+  PZN_CHECK_ARG(xg && W1p && W2 && h && out && argmax && dout && idx && dh_ws && grad_feat && dW1 && db1 && dW2 && db2);
+  PZN_CHECK_ARG(B > 0 && N > 0 && S > 0 && D > 0 && (D & 3) == 0 && C1 > 0 && C2 > 0);
+  return sa_mlp_max_bwd(xg, W1p, W2, h, out, argmax, dout, B * S, D, C1, C2, dh_ws, rows_ws, idx, S * 32, N, grad_feat, dW1,
+                        db1, dW2, db2, accumulate, stream);
 }
 
 // 0 = exact-fp32 MFMA everywhere, 1 = bf16x3 split precision everywhere, 2 = auto (default; see gemm.hip).

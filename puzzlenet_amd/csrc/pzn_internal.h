@@ -12,7 +12,9 @@ int pzn_pool_bwd_sparse(const float* dout, const int32_t* argmax, const float* o
 
 // wsgemm.hip: weight-stationary bf16x3 GEMM for skinny layers.  C[M,N] = epi(A[M,K] W^T), W[n*ldw+k]
 // (w_kmajor = 0) or W[k*ldw+n] (w_kmajor = 1); genY masks A by genY > 0, maskH masks C, argmax != NULL
-// selects the max-over-32-rows epilogue (C is then [M/32, N]).
+// selects the max-over-32-rows epilogue (C is then [M/32, N]); scat != NULL adds row m atomically into C row
+// (m / scat_in) * scat_out + scat[m] instead of storing it.
 bool pzn_ws_gemm_supported(int M, int N, int K, const float* A, int lda, const float* genY, bool maxpool);
 int pzn_ws_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor, float* C, int ldc, int M, int N, int K,
-                const float* bias, int relu, const float* genY, const float* maskH, int32_t* argmax, hipStream_t st);
+                const float* bias, int relu, const float* genY, const float* maskH, int32_t* argmax,
+                const int64_t* scat, int scat_in, int scat_out, hipStream_t st);

@@ -50,6 +50,8 @@ struct WsArgs {
   const float* genY;    // A(m,k) *= genY(m,k) > 0   (same layout as A) or NULL
   const float* maskH;   // C(m,n) *= maskH(m,n) > 0  (same layout as C) or NULL
   int32_t* argmax;      // max-pool epilogue: C is [M/32, N]
+  const int64_t* scat;  // scatter-add epilogue: row m goes to C row (m / scat_in) * scat_out + scat[m], atomically
+  int scat_in, scat_out;
 };
 
 // two floats -> their three bf16 planes, packed (lo = first element)
@@ -237,15 +239,27 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
           *reinterpret_cast<float4*>(stage + l31 * WS_STAGE_LD + cl) = v;
         }
         __builtin_amdgcn_wave_barrier();
+        if (p.scat) {  // grad_feat[b, idx[b,s,k], :] += row (index_points backward): 128-B contiguous atomic runs
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int rl = (lane >> 3) + 8 * i, c4 = (lane & 7) * 4;
-          float4 v = *reinterpret_cast<const float4*>(stage + rl * WS_STAGE_LD + c4);
-          const int row = t * 32 + rl, col = n0 + j * 32 + c4;
-          if (row < p.M && col + 3 < p.N) {
-            const size_t o = (size_t)row * p.ldc + col;
-            if (p.maskH) v = relu_mask(v, *reinterpret_cast<const float4*>(p.maskH + o));
-            *reinterpret_cast<float4*>(p.C + o) = v;
+          for (int i = 0; i < 16; ++i) {
+            const int rl = 2 * i + half, row = t * 32 + rl, col = n0 + j * 32 + l31;
+            const float v = stage[rl * WS_STAGE_LD + l31];
+            if (row < p.M && col < p.N) {
+              const long dst = (long)(row / p.scat_in) * p.scat_out + p.scat[row];
+              atomicAdd(p.C + (size_t)dst * p.ldc + col, v);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int rl = (lane >> 3) + 8 * i, c4 = (lane & 7) * 4;
+            float4 v = *reinterpret_cast<const float4*>(stage + rl * WS_STAGE_LD + c4);
+            const int row = t * 32 + rl, col = n0 + j * 32 + c4;
+            if (row < p.M && col + 3 < p.N) {
+              const size_t o = (size_t)row * p.ldc + col;
+              if (p.maskH) v = relu_mask(v, *reinterpret_cast<const float4*>(p.maskH + o));
+              *reinterpret_cast<float4*>(p.C + o) = v;
+            }
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -317,11 +331,12 @@ bool pzn_ws_gemm_supported(int M, int N, int K, const float* A, int lda, const f
 }
 
 int pzn_ws_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor, float* C, int ldc, int M, int N, int K,
-                const float* bias, int relu, const float* genY, const float* maskH, int32_t* argmax, hipStream_t st) {
-  WsArgs p{A, lda, W, ldw, w_kmajor, C, ldc, M, N, K, (K + 31) / 32, bias, relu, genY, maskH, argmax};
+                const float* bias, int relu, const float* genY, const float* maskH, int32_t* argmax,
+                const int64_t* scat, int scat_in, int scat_out, hipStream_t st) {
+  WsArgs p{A, lda, W, ldw, w_kmajor, C, ldc, M, N, K, (K + 31) / 32, bias, relu, genY, maskH, argmax, scat, scat_in, scat_out};
   const int nt = pick_nt(N, p.nd, argmax != nullptr);
   if (!nt) return PZN_EUNSUPPORTED;
-  if (argmax) return genY ? PZN_EUNSUPPORTED : launch_mg<true, false>(p, nt, st);
+  if (argmax) return (genY || scat) ? PZN_EUNSUPPORTED : launch_mg<true, false>(p, nt, st);
   if ((ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15) || (reinterpret_cast<uintptr_t>(maskH) & 15) ||
       (reinterpret_cast<uintptr_t>(bias) & 15))
     return PZN_EUNSUPPORTED;

@@ -539,7 +539,6 @@ class _SaMlpMax(torch.autograd.Function):
         dev = dout.device
         need_feat = ctx.needs_input_grad[1]
         dh = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
-        drows = torch.empty((R * 32, D), dtype=torch.float32, device=dev) if need_feat else None
         sinks = [_sink(t, ctx.needs_input_grad[4 + i]) for i, t in enumerate(ctx.param_refs)]
         direct = all(s_ is not None for s_ in sinks)
         if direct:
@@ -550,15 +549,19 @@ class _SaMlpMax(torch.autograd.Function):
             dW2 = torch.empty_like(w2)
             db2 = torch.empty((C2,), dtype=torch.float32, device=dev)
         dfeat = None
+        # layer 2 is the sparse pass (one non-zero per group and channel: R*C2 row-axpys each way), layer 1 the
+        # dense matrix-core products
+        fl = 2 * R * (2 * C1 * C2) + 2 * R * 32 * ((3 + D) * C1 + (D * C1 if need_feat else 0))
         with torch.cuda.device(dev):
-            _call("pzn_sa_mlp_max_bwd_f32", _p(xg), _p(w1p), _p(w2), _p(h), _p(out), _p(arg), _p(dout), R, D, C1, C2,
-                  _p(dh), _p(drows), _p(dW1), _p(db1), _p(dW2), _p(db2), int(direct), _stream(),
-                  # layer 2 is the sparse pass (one non-zero per group and channel: R*C2 row-axpys each way),
-                  # layer 1 the dense matrix-core products
-                  flops=2 * R * (2 * C1 * C2) + 2 * R * 32 * ((3 + D) * C1 + (D * C1 if need_feat else 0)))
-            if need_feat:
+            if need_feat:   # feature gradient scatter-added from the GEMM epilogue: the [R*32, D] rows are never written
                 dfeat = torch.zeros((B, N, D), dtype=torch.float32, device=dev)
-                _call("pzn_group_feat_bwd_f32", _p(drows), _p(idx), B, N, S, K, D, _p(dfeat), _stream())
+                rows_ws = torch.empty((R * 32, D), dtype=torch.float32, device=dev)   # fallback scratch (allocator only)
+                _call("pzn_sa_mlp_max_bwd_scatter_f32", _p(xg), _p(w1p), _p(w2), _p(h), _p(out), _p(arg), _p(dout),
+                      _p(idx), B, N, S, D, C1, C2, _p(dh), _p(rows_ws), _p(dfeat), _p(dW1), _p(db1), _p(dW2), _p(db2),
+                      int(direct), _stream(), flops=fl)
+            else:
+                _call("pzn_sa_mlp_max_bwd_f32", _p(xg), _p(w1p), _p(w2), _p(h), _p(out), _p(arg), _p(dout), R, D, C1, C2,
+                      _p(dh), None, _p(dW1), _p(db1), _p(dW2), _p(db2), int(direct), _stream(), flops=fl)
         if direct:
             return None, dfeat, None, None, None, None, None, None
         return None, dfeat, None, None, dW1, db1, dW2, db2
