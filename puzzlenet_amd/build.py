@@ -27,6 +27,7 @@ SOURCES = [
     ("gemm.hip", []),
     ("poolbwd.hip", []),
     ("wsgemm.hip", []),
+    ("dfgemm.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]

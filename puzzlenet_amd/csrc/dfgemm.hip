@@ -1,0 +1,263 @@
+// dfgemm.hip — weight gradients dW[N, K] += dY^T X for small weight matrices, fragments straight from
+// global memory ("direct fragment"), bf16x3 split precision.
+//
+//   dW[n, k] += sum_m dY[m, n] * X[m, k]        dY[M, N], X[M, K] row-major, M = 10^4..10^6 rows,
+//   db[n]    += sum_m dY[m, n]                   N, K <= a few hundred.
+//
+// The reduction runs over ROWS, which are the slow index of both operands.  The general tile engine
+// (gemm.hip, "TN") stages both tiles in LDS and reads them back transposed, one workgroup barrier per 16
+// rows; its waves are parked in s_waitcnt / s_barrier 70 % of the time (profiles/).  But the operand layout
+// v_mfma_f32_32x32x16_bf16 wants here — lane l holds, for column l&31 of its 32-column tile, the 8
+// consecutive reduction indices (l>>5)*8 .. +7 — is something a lane can fetch itself: 8 dword loads, each of
+// which is, across the wavefront, two fully coalesced 128-byte row segments.  So:
+//   * no LDS, no barrier: a wavefront owns TI x TJ output tiles of 32 x 32 (accumulators in registers) and
+//     streams its share of the rows in steps of 16: (TI + TJ) * 8 dword loads, split into bf16 planes in
+//     registers, TI * TJ * 6 MFMAs; the loads of the next step are issued as soon as the current values
+//     have been split;
+//   * a workgroup = every (TI x TJ) tile block of the output ("wave types") x a few replicas that take
+//     interleaved row steps, so the types re-read the same rows out of L1/L2 at about the same time;
+//   * partial sums meet in the fp32 atomics of the epilogue (dW is small), as the general engine's split-K
+//     path does; the grid is sized so that those atomics stay well below the streaming time (summing the
+//     replicas of a workgroup in LDS first was measured slower: one barrier round per replica);
+// No alignment requirements (K = 67, 131 are fine), ReLU mask on dY (genY) and the skipped pad column of the
+// set-abstraction rows are handled at the loads / stores.
+#include <stdlib.h>
+
+#include "pzn_common.h"
+#include "pzn_internal.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct DfArgs {
+  const float* dy;    // [M, N]
+  int ldy;
+  const float* genY;  // dY(m,n) *= genY(m,n) > 0 (same layout) or NULL
+  const float* x;     // [M, K]
+  int ldx;
+  float* dW;          // [N, K'] += ...   K' = K - (skip_col >= 0)
+  int ldw;
+  float* db;          // [N] += ... or NULL
+  int M, N, K;
+  int skip_col;       // column of X that has no weight (the zero pad of the padded group rows) or -1
+  int types_k;        // wave types along K
+  int types_per_wg;   // wave types handled by one workgroup (blockIdx.y selects the group)
+  int reps;           // replicas per type in a workgroup
+  int steps_per_wg;   // 16-row steps per workgroup
+};
+
+__device__ __forceinline__ void split_pair(v2f x, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+  bf16x2 a = __builtin_convertvector(x, bf16x2);
+  p1 = __builtin_bit_cast(uint32_t, a);
+  v2f fa = v2f{__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+  v2f r = x - fa;
+  bf16x2 b = __builtin_convertvector(r, bf16x2);
+  p2 = __builtin_bit_cast(uint32_t, b);
+  v2f fb = v2f{__uint_as_float(p2 << 16), __uint_as_float(p2 & 0xffff0000u)};
+  v2f r2 = r - fb;
+  bf16x2 c = __builtin_convertvector(r2, bf16x2);
+  p3 = __builtin_bit_cast(uint32_t, c);
+}
+
+struct Planes {
+  bf16x8 p1, p2, p3;
+};
+
+__device__ __forceinline__ Planes split8(const float (&v)[8]) {
+  uint32_t a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
+  split_pair(v2f{v[0], v[1]}, a0, b0, c0);
+  split_pair(v2f{v[2], v[3]}, a1, b1, c1);
+  split_pair(v2f{v[4], v[5]}, a2, b2, c2);
+  split_pair(v2f{v[6], v[7]}, a3, b3, c3);
+  const u32x4 a = {a0, a1, a2, a3}, b = {b0, b1, b2, b3}, c = {c0, c1, c2, c3};
+  return Planes{__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, c)};
+}
+
+template <int TI, int TJ, bool GENY, bool WITH_DB>
+__global__ __launch_bounds__(768) void df_wgrad_kernel(DfArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: row offsets must be provably uniform
+  const int l31 = lane & 31, half = lane >> 5;
+  const int tl = wave / p.reps, rep = wave - tl * p.reps;
+  const int type = blockIdx.y * p.types_per_wg + tl;
+  const int ti = type / p.types_k, tj = type - ti * p.types_k;
+  const int n0 = ti * (TI * 32), k0 = tj * (TJ * 32);
+  const bool active = n0 < p.N;  // false: padding type of the last group
+
+  // This lane's columns.  Columns past N / K are clamped for the loads and NOT zeroed: they only feed output
+  // rows / columns that the epilogue never stores.  Per-lane offsets are fixed for the whole walk; the row
+  // advance is wave-uniform, so every load is "scalar base + 32-bit lane offset" with no address VALU.
+  unsigned offn[TI], offk[TJ];
+  bool nok[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int c = n0 + i * 32 + l31;
+    nok[i] = c < p.N;
+    offn[i] = (unsigned)(half * 8 * p.ldy + (nok[i] ? c : p.N - 1));
+  }
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int c = k0 + j * 32 + l31;
+    offk[j] = (unsigned)(half * 8 * p.ldx + (c < p.K ? c : p.K - 1));
+  }
+
+  const int nsteps = p.M >> 4;  // M % 16 == 0 (checked on the host)
+  const int s_begin = blockIdx.x * p.steps_per_wg;
+  int s_end = s_begin + p.steps_per_wg;
+  s_end = s_end < nsteps ? s_end : nsteps;
+  if (!active) s_end = s_begin;
+
+  floatx16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float dbacc[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) dbacc[i] = 0.f;
+
+  // buffer loads: descriptor (scalar) + wave-uniform row offset (scalar) + fixed lane offset (vector): no address VALU
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rgy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GENY ? p.genY : p.dy), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, -1, 0x00020000);
+  float ra[TI][8], ry[TI][8], rb[TJ][8];
+  auto issue = [&](int s) {  // unconditional loads: the vmcnt bookkeeping stays exact
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int m = s * 16 + e;  // wave-uniform row; byte offsets stay below 2^32 (checked on the host)
+      const int sy = m * p.ldy * 4, sx = m * p.ldx * 4;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        ra[i][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdy, (int)(offn[i] * 4), sy, 0));
+        if (GENY) ry[i][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rgy, (int)(offn[i] * 4), sy, 0));
+      }
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+        rb[j][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)(offk[j] * 4), sx, 0));
+    }
+  };
+
+  int s = s_begin + rep;
+  if (s < s_end) issue(s);
+  for (; s < s_end; s += p.reps) {
+    Planes pa[TI], pb[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = (GENY && !(ry[i][e] > 0.f)) ? 0.f : ra[i][e];
+        if (WITH_DB) dbacc[i] += v[e];
+      }
+      pa[i] = split8(v);
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) pb[j] = split8(rb[j]);
+    {
+      const int sn = s + p.reps;
+      issue(sn < s_end ? sn : s);  // the last one re-reads its own rows: harmless, keeps the loop branch-free
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        floatx16 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i].p3, pb[j].p1, c, 0, 0, 0);  // small terms first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i].p2, pb[j].p2, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i].p1, pb[j].p3, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i].p2, pb[j].p1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i].p1, pb[j].p2, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i].p1, pb[j].p1, c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+  }
+
+  if (!active) return;
+
+  // epilogue: C element r of lane l = row n = (r&3) + 8*(r>>2) + 4*half of tile i, column k = l31 of tile j
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int k = k0 + j * 32 + l31;
+      if (k >= p.K || k == p.skip_col) continue;
+      const int kk = (p.skip_col >= 0 && k > p.skip_col) ? k - 1 : k;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (n < p.N) atomicAdd(p.dW + (size_t)n * p.ldw + kk, acc[i][j][r]);
+      }
+    }
+    if (WITH_DB && tj == 0) {
+      float t = dbacc[i] + __shfl_xor(dbacc[i], 32, PZN_WAVE);
+      if (half == 0 && nok[i]) atomicAdd(p.db + n0 + i * 32 + l31, t);
+    }
+  }
+}
+
+template <int TI, int TJ>
+int launch_ij(DfArgs p, hipStream_t st) {
+  const int types_n = (p.N + TI * 32 - 1) / (TI * 32);
+  p.types_k = (p.K + TJ * 32 - 1) / (TJ * 32);
+  const int types = types_n * p.types_k;
+  constexpr int MAXW = 12;  // wavefronts per workgroup (<= 168 registers each)
+  const int nsteps = p.M / 16;
+  static const int forced = [] { const char* e = getenv("PZN_DF_WGS"); return e ? atoi(e) : 0; }();  // tuning aid
+  // all types of a row range in one workgroup (they re-read the same rows out of L1 / L2); >= 8 steps per wave.
+  // (One type per workgroup with 12 replicas meeting in LDS was tried for the short row counts: slower.)
+  static const int tpw_cap = [] { const char* e = getenv("PZN_DF_TPW"); return e ? atoi(e) : 12; }();  // tuning aid (12 = all types together measured best)
+  const int cap = tpw_cap < MAXW ? tpw_cap : MAXW;
+  const int groups = (types + cap - 1) / cap;
+  p.types_per_wg = (types + groups - 1) / groups;
+  p.reps = MAXW / p.types_per_wg;
+  int wgs = 256;
+  const int max_by_steps = nsteps / (8 * p.reps);
+  if (wgs > max_by_steps) wgs = max_by_steps;
+  if (forced) wgs = forced;
+  if (wgs < 1) wgs = 1;
+  const int waves = p.types_per_wg * p.reps;
+  p.steps_per_wg = (nsteps + wgs - 1) / wgs;
+  wgs = (nsteps + p.steps_per_wg - 1) / p.steps_per_wg;
+  const size_t lds = 0;  // replicas meet in the epilogue atomics (an LDS round per replica was slower)
+  const dim3 grid((unsigned)wgs, (unsigned)groups), block(waves * 64);
+  if (p.genY && p.db)
+    hipLaunchKernelGGL((df_wgrad_kernel<TI, TJ, true, true>), grid, block, lds, st, p);
+  else if (p.genY)
+    hipLaunchKernelGGL((df_wgrad_kernel<TI, TJ, true, false>), grid, block, lds, st, p);
+  else if (p.db)
+    hipLaunchKernelGGL((df_wgrad_kernel<TI, TJ, false, true>), grid, block, lds, st, p);
+  else
+    hipLaunchKernelGGL((df_wgrad_kernel<TI, TJ, false, false>), grid, block, lds, st, p);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+bool df_enabled() {
+  static const bool on = [] { const char* e = getenv("PZN_DF_GEMM"); return !(e && e[0] == '0'); }();  // tuning aid
+  return on;
+}
+
+}  // namespace
+
+bool pzn_df_wgrad_supported(int M, int N, int K) {
+  if (!df_enabled() || M < 2048 || (M & 15) || N < 16 || K < 16) return false;
+  if ((double)M * (N > K ? N : K) * 4.0 >= 4294967296.0) return false;  // 32-bit buffer offsets
+  const int tn = (N + 63) / 64, tk = (K + 63) / 64;
+  return tn * tk <= 64;
+}
+
+int pzn_df_wgrad(const float* dy, int ldy, const float* genY, const float* x, int ldx, int M, int N, int K, float* dW,
+                 int ldw, float* db, int skip_col, hipStream_t st) {
+  DfArgs p{dy, ldy, genY, x, ldx, dW, ldw, db, M, N, K, skip_col, 0, 0, 0, 0};
+  const int tn = (N + 31) / 32, tk = (K + 31) / 32;
+  if (tn >= 2 && tk >= 2) return launch_ij<2, 2>(p, st);
+  if (tn >= 2) return launch_ij<2, 1>(p, st);
+  if (tk >= 2) return launch_ij<1, 2>(p, st);
+  return launch_ij<1, 1>(p, st);
+}

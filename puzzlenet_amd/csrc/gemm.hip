@@ -735,6 +735,14 @@ static int wgrad_common(GemmArgs p, int Kin, int Nout, const float* x, float* dW
 PZN_EXPORT int pzn_linear_wgrad_f32(const float* dy, const float* y_relu, const float* x, int M, int Kin, int Nout,
                                     float* dW, float* db, int accumulate, pzn_stream_t stream) {
   PZN_CHECK_ARG(dy && x && dW && M > 0 && Kin > 0 && Nout > 0);
+  if (gemm_precision() != 0 && pzn_df_wgrad_supported(M, Nout, Kin)) {  // small weight matrix: dfgemm.hip
+    hipStream_t st = pzn_hip_stream(stream);
+    if (!accumulate) {
+      if (pzn_zero_async(dW, (size_t)Nout * Kin, st) != PZN_OK) return PZN_ELAUNCH;
+      if (db && pzn_zero_async(db, (size_t)Nout, st) != PZN_OK) return PZN_ELAUNCH;
+    }
+    return pzn_df_wgrad(dy, Nout, y_relu, x, Kin, M, Nout, Kin, dW, Kin, db, -1, st);
+  }
   GemmArgs p = base_args(Nout, Kin, M);
   p.A = dy, p.lda = Nout;
   if (y_relu) p.gen = GEN_RELU, p.genY = y_relu;
@@ -921,11 +929,15 @@ static int sa_mlp_max_bwd(const float* xg, const float* W1p, const float* W2, co
   const int ldx = 4 + D, ldw = 3 + D, M = R * 32;
   int rc = pool_layer_bwd(dout, argmax, out, W2, h, R, C1, C2, dh_ws, dW2, db2, accumulate, stream);
   if (rc != PZN_OK) return rc;
-  {  // dW1[:, 3:] = dh^T xg[:, 4:];  dW1[:, 0:3] and db1 from the streamed dh tiles
-    if (!accumulate) {
-      if (pzn_zero_async(dW1, (size_t)C1 * ldw, st) != PZN_OK) return PZN_ELAUNCH;
-      if (pzn_zero_async(db1, (size_t)C1, st) != PZN_OK) return PZN_ELAUNCH;
-    }
+  if (!accumulate) {
+    if (pzn_zero_async(dW1, (size_t)C1 * ldw, st) != PZN_OK) return PZN_ELAUNCH;
+    if (pzn_zero_async(db1, (size_t)C1, st) != PZN_OK) return PZN_ELAUNCH;
+  }
+  if (gemm_precision() != 0 && pzn_df_wgrad_supported(M, C1, ldx)) {
+    // dW1 = dh^T xg over all 4+D columns of the padded rows, the pad column dropped at the store
+    rc = pzn_df_wgrad(dh_ws, C1, nullptr, xg, ldx, M, C1, ldx, dW1, ldw, db1, 3, st);
+    if (rc != PZN_OK) return rc;
+  } else {  // dW1[:, 3:] = dh^T xg[:, 4:];  dW1[:, 0:3] and db1 from the streamed dh tiles
     GemmArgs p = base_args(C1, D, M);
     p.A = dh_ws, p.lda = C1, p.B = xg + 4, p.ldb = ldx, p.C = dW1 + 3, p.ldc = ldw;
     p.bias_grad = db1;

@@ -18,3 +18,10 @@ bool pzn_ws_gemm_supported(int M, int N, int K, const float* A, int lda, const f
 int pzn_ws_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor, float* C, int ldc, int M, int N, int K,
                 const float* bias, int relu, const float* genY, const float* maskH, int32_t* argmax,
                 const int64_t* scat, int scat_in, int scat_out, hipStream_t st);
+
+// dfgemm.hip: weight gradient dW[N,K'] += dY^T X (+ db += column sums of dY) with MFMA fragments loaded
+// straight from global memory; genY masks dY by genY > 0; skip_col >= 0 drops that column of X from the
+// output (K' = K - 1: the zero pad of the padded group rows).  Accumulates: zero dW / db first if needed.
+bool pzn_df_wgrad_supported(int M, int N, int K);
+int pzn_df_wgrad(const float* dy, int ldy, const float* genY, const float* x, int ldx, int M, int N, int K, float* dW,
+                 int ldw, float* db, int skip_col, hipStream_t st);
