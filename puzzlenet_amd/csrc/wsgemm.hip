@@ -86,11 +86,14 @@ __device__ __forceinline__ float4 relu_mask(float4 x, float4 y) {
 
 // NT = 32-column tiles per wavefront (weight slice = NT*32 columns), MAXPOOL = max over the tile's 32 rows,
 // GENY = ReLU-mask the activation stream with genY.
-template <int NT, bool MAXPOOL, bool GENY, int NW>
+// DEEP: two register sets = two double steps in flight (needs nd even and full tiles: every load and store of the
+// walk is then unconditional, which keeps the compiler's vmcnt bookkeeping exact across the unrolled loop).
+template <int NT, bool MAXPOOL, bool GENY, int NW, bool DEEP>
 __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
   constexpr int WS_T = NW * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];  // [nd*2][NT][3][64 lanes][16 B]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: tile offsets must be provably uniform
   const int l31 = lane & 31, half = lane >> 5;
   const int n0 = blockIdx.y * (NT * 32);
 
@@ -125,15 +128,31 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
   // This lane's stream: row (tile*32 + l31), 16 consecutive floats at k = 32d + 16*half per double step.
   // One register set: the next 64 bytes are requested right after the current ones have arrived and stay in
   // flight for a whole double step of MFMAs (this wave's and those of the other waves on the SIMD).
-  float4 pa0, pa1, pa2, pa3;                           // A
-  float4 ya0, ya1, ya2, ya3;                           // genY
+  float4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;      // A
+  float4 ya0, ya1, ya2, ya3, yb0, yb1, yb2, yb3;      // genY
   int it = t, id = 0;                                  // issue cursor (tile, double step)
   // Loads are issued UNCONDITIONALLY (rows past M and k past K are clamped to valid addresses and zeroed at
   // consumption): a branch around them would make the compiler's vmcnt bookkeeping fall back to vmcnt(0) and
   // collapse the prefetch distance.
   const int kmax = p.K - 4;
+  // DEEP walks have no clamps at all, so their loads are buffer loads: descriptor + wave-uniform tile / k offset
+  // (scalar) + a lane offset that never changes: no address arithmetic on the vector ALU.
+  typedef unsigned int u32x4v __attribute__((__vector_size__(16)));
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GENY ? p.genY : p.A), 0, -1, 0x00020000);
+  const int voff = (l31 * p.lda + half * 16) * 4;
+#define WS_BLOAD(rs, o) __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (o), soff_, 0))
 #define WS_ISSUE(x0, x1, x2, x3, y0, y1, y2, y3)                                                          \
   do {                                                                                                    \
+    if (DEEP) {                                                                                           \
+      const int itc_ = it < ntiles ? it : ntiles - 1;                                                     \
+      const int soff_ = (itc_ * 32 * p.lda + id * 32) * 4;                                                \
+      x0 = WS_BLOAD(rsA, 0), x1 = WS_BLOAD(rsA, 16), x2 = WS_BLOAD(rsA, 32), x3 = WS_BLOAD(rsA, 48);        \
+      if (GENY) y0 = WS_BLOAD(rsY, 0), y1 = WS_BLOAD(rsY, 16), y2 = WS_BLOAD(rsY, 32), y3 = WS_BLOAD(rsY, 48); \
+      if (++id == p.nd) id = 0, it += tstride;                                                            \
+      break;                                                                                              \
+    }                                                                                                     \
     int row_ = it * 32 + l31;                                                                             \
     row_ = row_ < p.M ? row_ : p.M - 1;                                                                   \
     const int kb_ = id * 32 + half * 16;                                                                  \
@@ -152,6 +171,7 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
     if (++id == p.nd) id = 0, it += tstride;                                                              \
   } while (0)
   WS_ISSUE(pa0, pa1, pa2, pa3, ya0, ya1, ya2, ya3);
+  if (DEEP) WS_ISSUE(pb0, pb1, pb2, pb3, yb0, yb1, yb2, yb3);
 
   floatx16 acc[NT];
 #pragma unroll
@@ -197,6 +217,21 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
         acc[j] = c;
       }
     }
+    // Issue order for the whole double step (one scheduling region): the refill loads first, the split of the
+    // first 8 floats, then the MFMAs of step 0 with the split of the second 8 floats and the next tile's B
+    // fragments slotted into their gaps (left alone, the scheduler sinks the loads to the end of the block and
+    // runs all the VALU work in front of the first MFMA).
+    __builtin_amdgcn_sched_group_barrier(0x020, GENY ? 8 : 4, 0);  // VMEM reads
+    __builtin_amdgcn_sched_group_barrier(0x002, 52, 0);            // VALU: masks + first split
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);             // DS reads: B fragments of (0, 0)
+#pragma unroll
+    for (int b = 0; b < 2 * NT; ++b)
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (b < NT) __builtin_amdgcn_sched_group_barrier(0x002, NT == 1 ? 8 : (NT == 2 ? 4 : 2), 0);
+        if (m < 3 && b + 1 < 2 * NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
   };
 
   auto epilogue = [&]() {
@@ -222,7 +257,10 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
         const bool take = ob > best || (ob == best && oi < bi);
         best = take ? ob : best;
         bi = take ? oi : bi;
-        if (half == 0 && col_ok) {
+        if (DEEP) {  // one unconditional store per lane: lower half the value, upper half the index
+          float* dst = half ? reinterpret_cast<float*>(p.argmax) : p.C;
+          dst[(size_t)t * p.ldc + col] = half ? __int_as_float(bi) : best;
+        } else if (half == 0 && col_ok) {
           p.C[(size_t)t * p.ldc + col] = best;
           p.argmax[(size_t)t * p.ldc + col] = bi;
         }
@@ -244,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
           for (int i = 0; i < 16; ++i) {
             const int rl = 2 * i + half, row = t * 32 + rl, col = n0 + j * 32 + l31;
             const float v = stage[rl * WS_STAGE_LD + l31];
-            if (row < p.M && col < p.N) {
+            if (DEEP || (row < p.M && col < p.N)) {
               const long dst = (long)(row / p.scat_in) * p.scat_out + p.scat[row];
               atomicAdd(p.C + (size_t)dst * p.ldc + col, v);
             }
@@ -255,7 +293,7 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
             const int rl = (lane >> 3) + 8 * i, c4 = (lane & 7) * 4;
             float4 v = *reinterpret_cast<const float4*>(stage + rl * WS_STAGE_LD + c4);
             const int row = t * 32 + rl, col = n0 + j * 32 + c4;
-            if (row < p.M && col + 3 < p.N) {
+            if (DEEP || (row < p.M && col + 3 < p.N)) {
               const size_t o = (size_t)row * p.ldc + col;
               if (p.maskH) v = relu_mask(v, *reinterpret_cast<const float4*>(p.maskH + o));
               *reinterpret_cast<float4*>(p.C + o) = v;
@@ -270,23 +308,42 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
   };
 
   for (; t < ntiles; t += tstride) {
-    for (d = 0; d < p.nd; ++d) {
-      const int kb = d * 32 + half * 16;
-      const float4 c0 = take(pa0, ya0, kb <= kmax), c1 = take(pa1, ya1, kb + 4 <= kmax);
-      const float4 c2 = take(pa2, ya2, kb + 8 <= kmax), c3 = take(pa3, ya3, kb + 12 <= kmax);
-      WS_ISSUE(pa0, pa1, pa2, pa3, ya0, ya1, ya2, ya3);
-      step(c0, c1, c2, c3);
+    if (DEEP) {
+      for (d = 0; d < p.nd; ++d) {
+        {
+          const float4 c0 = take(pa0, ya0, true), c1 = take(pa1, ya1, true);
+          const float4 c2 = take(pa2, ya2, true), c3 = take(pa3, ya3, true);
+          WS_ISSUE(pa0, pa1, pa2, pa3, ya0, ya1, ya2, ya3);
+          step(c0, c1, c2, c3);
+        }
+        ++d;
+        {
+          const float4 c0 = take(pb0, yb0, true), c1 = take(pb1, yb1, true);
+          const float4 c2 = take(pb2, yb2, true), c3 = take(pb3, yb3, true);
+          WS_ISSUE(pb0, pb1, pb2, pb3, yb0, yb1, yb2, yb3);
+          step(c0, c1, c2, c3);
+        }
+      }
+    } else {
+      for (d = 0; d < p.nd; ++d) {
+        const int kb = d * 32 + half * 16;
+        const float4 c0 = take(pa0, ya0, kb <= kmax), c1 = take(pa1, ya1, kb + 4 <= kmax);
+        const float4 c2 = take(pa2, ya2, kb + 8 <= kmax), c3 = take(pa3, ya3, kb + 12 <= kmax);
+        WS_ISSUE(pa0, pa1, pa2, pa3, ya0, ya1, ya2, ya3);
+        step(c0, c1, c2, c3);
+      }
     }
     epilogue();
   }
 #undef WS_ISSUE
+#undef WS_BLOAD
 }
 
 size_t stage_bytes(bool maxpool) { return maxpool ? 0 : (size_t)WS_NW * 32 * WS_STAGE_LD * sizeof(float); }
 
-template <int NT, bool MAXPOOL, bool GENY>
-int launch_nt(const WsArgs& p, hipStream_t st) {
-  auto kern = ws_gemm_kernel<NT, MAXPOOL, GENY, WS_NW>;
+template <int NT, bool MAXPOOL, bool GENY, bool DEEP>
+int launch_nt_d(const WsArgs& p, hipStream_t st) {
+  auto kern = ws_gemm_kernel<NT, MAXPOOL, GENY, WS_NW, DEEP>;
   const size_t lds = (size_t)p.nd * 2 * NT * 3 * 1024 + stage_bytes(MAXPOOL);
   if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -299,6 +356,19 @@ int launch_nt(const WsArgs& p, hipStream_t st) {
   if (gx > need) gx = need;
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nslices), dim3(WS_NW * 64), lds, st, p);
   PZN_RETURN_LAUNCH_STATUS();
+}
+
+template <int NT, bool MAXPOOL, bool GENY>
+int launch_nt(const WsArgs& p, hipStream_t st) {
+  static const bool deep_on = [] { const char* e = getenv("PZN_WS_DEEP"); return !(e && e[0] == '0'); }();  // tuning aid
+  // two double steps in flight when every access of the walk can be unconditional and the registers allow it
+  const bool deep = deep_on && !GENY && (p.nd & 1) == 0 && (p.K & 31) == 0 && (p.M & 31) == 0 &&
+                    p.N % (NT * 32) == 0 && (double)p.M * p.lda * 4.0 < 4294967296.0;
+  if constexpr (GENY) {  // the mask stream doubles the prefetch registers: single set
+    return launch_nt_d<NT, MAXPOOL, GENY, false>(p, st);
+  } else {
+    return deep ? launch_nt_d<NT, MAXPOOL, GENY, true>(p, st) : launch_nt_d<NT, MAXPOOL, GENY, false>(p, st);
+  }
 }
 
 template <bool MAXPOOL, bool GENY>
