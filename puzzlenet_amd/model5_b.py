@@ -197,6 +197,8 @@ class TouchedRegraster(_Base):
         self.MLPLocalPreFpc = _seq(64, 64, 64, 64)
         self.MLPRpcb = _seq(128, 64, 32, 2)                                        # :586-592
         self.MLPFpcb = _seq(128, 64, 32, 2)
+        self.two_streams = True        # Encoder2 on a side stream (GPU only); False = everything on the current stream
+        self._side_stream = None
 
     # ------------------------------------------------------------------ forward
     def predict5(self, batch, batch_indic, need=False, training=False):
@@ -210,9 +212,26 @@ class TouchedRegraster(_Base):
         N = fpc.shape[1]
 
         plan_f, plan_m = self._sa_plans(fpc, mrpc)
-        ffpcs = self.Encoder(fpc, plan_f)                                           # :710
+        if self.two_streams and fpc.is_cuda and not torch.cuda.is_current_stream_capturing():
+            # The two encoders are independent (separate weights, separate clouds) and most of their launches
+            # are too small to fill 256 CUs: run Encoder2 on a side HIP stream next to Encoder.  Autograd
+            # replays each backward node on its forward stream, so the backward passes overlap as well.
+            cur = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream()
+            side = self._side_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                fmrpcs = self.Encoder2(mrpc, plan_m)                                # :716
+            ffpcs = self.Encoder(fpc, plan_f)                                       # :710
+            cur.wait_stream(side)
+            for t in fmrpcs:
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(cur)
+        else:
+            ffpcs = self.Encoder(fpc, plan_f)                                       # :710
+            fmrpcs = self.Encoder2(mrpc, plan_m)                                    # :716
         ffpc, non_sg_ffpc = ffpcs[0], ffpcs[4]
-        fmrpcs = self.Encoder2(mrpc, plan_m)                                        # :716
         fmrpc, non_sg_fmrpc = fmrpcs[0], fmrpcs[4]
 
         f = torch.cat([ffpc, fmrpc], dim=-1)                                        # :723

@@ -17,6 +17,7 @@ dev = torch.device("cuda:0")
 cfg = Cfg(); cfg.num_points = a.points
 torch.manual_seed(0)
 model = model5_b.TouchedRegraster(cfg).to(dev)
+model.two_streams = False
 batch = synthetic.make_batch(a.batch, a.points, dev, seed=1234)
 runner = engine.TrainStep(model, batch, cfg.lr, world=1, use_graph=False, warmup=2)
 for _ in range(2):
