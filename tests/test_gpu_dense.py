@@ -37,7 +37,13 @@ def _rel(a, b):
 @pytest.mark.parametrize("M,K,N,relu,bias", [
     (4096, 64, 128, True, True), (1000, 67, 128, True, True), (777, 131, 256, False, True),
     (64, 2048, 1024, True, True), (64, 256, 6, False, True), (5000, 3, 64, False, True),
-    (300, 32, 2, False, True), (256, 1280, 1024, False, False), (129, 128, 64, True, True), (1, 64, 64, False, True)])
+    (300, 32, 2, False, True), (256, 1280, 1024, False, False), (129, 128, 64, True, True), (1, 64, 64, False, True),
+    # shapes that take the weight-stationary forward / input-gradient kernel (wsgemm.hip) and the direct-fragment
+    # weight-gradient kernel (dfgemm.hip): ragged row tiles, K tails (68, 132 -> odd double-step counts), column
+    # tails, one / two / four 32-column tiles per wave, the two-sets-in-flight walk (16384 x 256 x 256)
+    (4100, 68, 96, True, True), (6000, 132, 256, True, True), (4096, 128, 32, False, True),
+    (8192, 256, 64, True, False), (16384, 256, 256, True, True), (4128, 96, 160, False, True),
+    (4112, 67, 128, True, True), (8192, 131, 256, False, True), (4096, 64, 64, True, True)])
 def test_linear_fwd_bwd(dev, precision, M, K, N, relu, bias):
     from puzzlenet_amd import ops
     g = torch.Generator().manual_seed(M + K + N)
@@ -47,12 +53,17 @@ def test_linear_fwd_bwd(dev, precision, M, K, N, relu, bias):
     go = torch.randn(M, N, generator=g)
     xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
     br = b.double().requires_grad_(True) if bias else None
-    yr = F.linear(xr, wr, br)
-    yr = F.relu(yr) if relu else yr
-    (yr * go.double()).sum().backward()
     xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
     bd = b.to(dev).requires_grad_(True) if bias else None
     y = ops.linear(xd, wd, bd, relu)
+    yr = F.linear(xr, wr, br)
+    if relu:
+        # the ReLU gate of the reference backward is taken from the device output: with millions of outputs a
+        # pre-activation within fp32 rounding of zero turns up, and its gate is then a coin flip, not an error
+        gate = (y.detach().cpu() > 0)
+        assert int((gate != (yr.detach() > 0)).sum()) <= max(2, y.numel() // 500000)
+        yr = torch.where(gate, yr, torch.zeros_like(yr))
+    (yr * go.double()).sum().backward()
     assert _rel(y, yr) < 1e-5
     (y * go.to(dev)).sum().backward()
     assert _rel(xd.grad, xr.grad) < 1e-5
@@ -72,7 +83,8 @@ def test_linear_nd_input_and_no_grad_paths(dev):
     assert w.grad.shape == (8, 16)
 
 
-@pytest.mark.parametrize("B,S,C0,C1,C2", [(2, 64, 67, 128, 128), (2, 40, 131, 256, 256), (1, 5, 20, 32, 48)])
+@pytest.mark.parametrize("B,S,C0,C1,C2", [(2, 64, 67, 128, 128), (2, 40, 131, 256, 256), (1, 5, 20, 32, 48),
+                                            (4, 64, 68, 128, 128), (2, 80, 132, 256, 256), (3, 50, 64, 64, 128)])
 def test_shared_mlp_max(dev, precision, B, S, C0, C1, C2):
     from puzzlenet_amd import ops
     g = torch.Generator().manual_seed(C0)
@@ -161,7 +173,8 @@ def test_chamfer_identity_and_symmetry(dev):
     assert torch.equal(x1, y2) and torch.equal(x2, y1)         # both passes see bit-identical P
 
 
-@pytest.mark.parametrize("B,N,S,D,C1,C2", [(2, 300, 40, 64, 128, 128), (2, 128, 24, 128, 256, 256), (1, 64, 5, 8, 16, 24)])
+@pytest.mark.parametrize("B,N,S,D,C1,C2", [(2, 300, 40, 64, 128, 128), (2, 128, 24, 128, 256, 256), (1, 64, 5, 8, 16, 24),
+                                              (4, 600, 64, 64, 128, 128), (2, 400, 96, 128, 256, 256)])
 def test_sa_mlp_max_fused_vs_composed(dev, precision, B, N, S, D, C1, C2):
     """Fused set-abstraction path == group -> shared MLP -> max composed from fp64 torch ops."""
     from oracle import point_ops as orc
