@@ -271,6 +271,13 @@ int pzn_attn_bwd_f32(const float* q, const float* k, const float* v,
                      int B, int L, int dk, int dv, float* dq, float* dk_out,
                      float* dv_out, void* workspace, pzn_stream_t stream);
 
+/* torch.optim.Adam step (model5_b.py:1453-1457: Adam(lr), no weight decay, no amsgrad) over flat
+ * buffers of n floats: param, exp_avg, exp_avg_sq updated in place from grad; step = 1, 2, ...
+ * (bias corrections 1 - beta^step).  All four buffers 16-byte aligned. */
+int pzn_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                      size_t n, float lr, float beta1, float beta2, float eps, int step,
+                      pzn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,7 @@ SOURCES = [
     ("poolbwd.hip", []),
     ("wsgemm.hip", []),
     ("dfgemm.hip", []),
+    ("optim.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]

@@ -665,9 +665,11 @@ void choose_splits(GemmArgs& p) {
 PZN_EXPORT int pzn_linear_fwd_f32(const float* x, const float* W, const float* bias, int M, int Kin, int Nout, int relu,
                                   float* y, pzn_stream_t stream) {
   PZN_CHECK_ARG(x && W && y && M > 0 && Kin > 0 && Nout > 0);
-  if (gemm_precision() != 0 && pzn_ws_gemm_supported(M, Nout, Kin, x, Kin, nullptr, false))  // skinny layer: wsgemm.hip
-    return pzn_ws_gemm(x, Kin, W, Kin, 0, y, Nout, M, Nout, Kin, bias, relu, nullptr, nullptr, nullptr, nullptr, 0, 0,
-                       pzn_hip_stream(stream));
+  if (gemm_precision() != 0 && pzn_ws_gemm_supported(M, Nout, Kin, x, Kin, nullptr, false)) {  // skinny layer: wsgemm.hip
+    const int rc = pzn_ws_gemm(x, Kin, W, Kin, 0, y, Nout, M, Nout, Kin, bias, relu, nullptr, nullptr, nullptr, nullptr,
+                               0, 0, pzn_hip_stream(stream));
+    if (rc != PZN_EUNSUPPORTED) return rc;  // e.g. an unaligned bias / output: the general engine takes it
+  }
   GemmArgs p = base_args(M, Nout, Kin);
   p.A = x, p.lda = Kin, p.B = W, p.ldb = Kin, p.C = y, p.ldc = Nout, p.bias = bias, p.relu = relu;
   launch<true, true, EPI_STORE>(p, 1, pzn_hip_stream(stream));
@@ -689,9 +691,11 @@ PZN_EXPORT int pzn_linear_maxpool_fwd_f32(const float* x, const float* W, const 
 PZN_EXPORT int pzn_linear_dgrad_f32(const float* dy, const float* y_relu, const float* W, int M, int Kin, int Nout,
                                     const float* x_relu, float* dx, pzn_stream_t stream) {
   PZN_CHECK_ARG(dy && W && dx && M > 0 && Kin > 0 && Nout > 0);
-  if (gemm_precision() != 0 && pzn_ws_gemm_supported(M, Kin, Nout, dy, Nout, y_relu, false))
-    return pzn_ws_gemm(dy, Nout, W, Kin, 1, dx, Kin, M, Kin, Nout, nullptr, 0, y_relu, x_relu, nullptr, nullptr, 0, 0,
-                       pzn_hip_stream(stream));
+  if (gemm_precision() != 0 && pzn_ws_gemm_supported(M, Kin, Nout, dy, Nout, y_relu, false)) {
+    const int rc = pzn_ws_gemm(dy, Nout, W, Kin, 1, dx, Kin, M, Kin, Nout, nullptr, 0, y_relu, x_relu, nullptr, nullptr,
+                               0, 0, pzn_hip_stream(stream));
+    if (rc != PZN_EUNSUPPORTED) return rc;
+  }
   GemmArgs p = base_args(M, Kin, Nout);
   p.A = dy, p.lda = Nout, p.B = W, p.ldb = Kin, p.C = dx, p.ldc = Kin;
   if (y_relu) p.gen = GEN_RELU, p.genY = y_relu;

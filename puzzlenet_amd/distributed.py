@@ -36,13 +36,15 @@ class FlatGradAllReduce:
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        # every tensor starts on a 16-byte boundary of the bucket (kernels read weights / biases with 16-byte loads)
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4
         ref = self.params[0]
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
         if self.flat.is_cuda:
             # let the weight-gradient kernels add straight into the bucket (ops._GRAD_SINKS)
             from . import ops
@@ -56,6 +58,46 @@ class FlatGradAllReduce:
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
+
+
+class FlatAdam:
+    """torch.optim.Adam(lr) + StepLR(step_size, gamma) (model5_b.py:1453-1457) over flat buffers: the parameters
+    are re-pointed into one contiguous buffer (like their gradients in FlatGradAllReduce), the two moments are
+    flat too, and the whole update is ONE launch of pzn_adam_step_f32.  GPU only; no CPU fallback."""
+
+    def __init__(self, grads, lr, betas=(0.9, 0.999), eps=1e-8, sched_step=50, sched_gamma=0.999):
+        from . import _lib, ops
+        if not grads.flat.is_cuda:
+            raise _lib.PznError("FlatAdam needs parameters on the GPU (puzzlenet_amd has no CPU fallback)")
+        self.grads = grads
+        self.flat = torch.zeros_like(grads.flat)         # same layout as the gradient bucket (16-byte aligned tensors)
+        with torch.no_grad():
+            for p, off in zip(grads.params, grads.offsets):
+                n = p.numel()
+                self.flat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat[off:off + n].view_as(p)
+        # the parameters moved: the weight-gradient sinks are keyed by parameter address
+        ops.clear_grad_sinks()
+        ops.register_grad_sinks(grads.params)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.lr0, self.betas, self.eps = float(lr), betas, float(eps)
+        self.sched_step, self.sched_gamma = int(sched_step), float(sched_gamma)
+        self.t = 0
+
+    @property
+    def lr(self):
+        """StepLR stepped once per batch: lr0 * gamma ** (t // step_size) for the (t+1)-th update."""
+        return self.lr0 * self.sched_gamma ** (self.t // self.sched_step)
+
+    def step(self):
+        from . import _lib
+        lr = self.lr
+        self.t += 1
+        with torch.cuda.device(self.flat.device):
+            _lib.call("pzn_adam_step_f32", self.flat.data_ptr(), self.grads.flat.data_ptr(), self.exp_avg.data_ptr(),
+                      self.exp_avg_sq.data_ptr(), self.flat.numel(), lr, self.betas[0], self.betas[1], self.eps, self.t,
+                      torch.cuda.current_stream().cuda_stream)
 
 
 def broadcast_parameters(module, src=0):

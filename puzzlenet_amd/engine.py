@@ -29,9 +29,12 @@ class TrainStep:
         self.graph = None
         self.opt_in_graph = use_graph and world == 1
         lr_arg = torch.tensor(float(lr), device=dev) if use_graph else lr
-        # fused=True: one multi-tensor Adam kernel chain instead of ~10 foreach passes over 104 tensors (same update rule)
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr_arg, capturable=bool(use_graph), fused=not use_graph)
-        self.sched = torch.optim.lr_scheduler.StepLR(self.opt, 50, 0.999)       # model5_b.py:1453-1457
+        if use_graph:      # experimental path: torch's capturable Adam inside the graph
+            self.opt = torch.optim.Adam(model.parameters(), lr=lr_arg, capturable=True)
+            self.sched = torch.optim.lr_scheduler.StepLR(self.opt, 50, 0.999)   # model5_b.py:1453-1457
+        else:              # Adam + StepLR(50, 0.999) over flat buffers: one launch per step (distributed.FlatAdam)
+            self.opt = pdist.FlatAdam(self.grads, lr, sched_step=50, sched_gamma=0.999)
+            self.sched = None
         self.loss = None
         self.feed = None
         if use_graph:
@@ -80,7 +83,8 @@ class TrainStep:
             if not self.opt_in_graph:
                 self.grads.all_reduce_mean()
                 self.opt.step()
-        self.sched.step()
+        if self.sched is not None:
+            self.sched.step()
         return self.loss
 
     def close(self):

@@ -219,6 +219,10 @@ class TouchedRegraster(_Base):
             cur = torch.cuda.current_stream()
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream()
+                # leaf gradients of Encoder2 are accumulated on the side stream by design
+                _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+                if _quiet is not None:
+                    _quiet(False)
             side = self._side_stream
             side.wait_stream(cur)
             with torch.cuda.stream(side):

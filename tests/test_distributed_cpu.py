@@ -58,7 +58,7 @@ def _worker(rank, world, port, tmp):
     per = 8 // world
     shard = (X[rank * per:(rank + 1) * per], Y[rank * per:(rank + 1) * per])         # rank r gets pairs [r*B/W, (r+1)*B/W)
     grads = pdist.FlatGradAllReduce(model.parameters())
-    assert grads.flat.numel() == sum(p.numel() for p in model.parameters())
+    assert grads.flat.numel() == sum((p.numel() + 3) // 4 * 4 for p in model.parameters())   # 16-byte aligned slots
     assert all(p.grad.data_ptr() >= grads.flat.data_ptr() for p in model.parameters())
     for it in range(2):                           # twice: zero_() must really reset the bucket
         grads.zero_()

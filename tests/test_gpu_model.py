@@ -175,10 +175,35 @@ def test_gradient_sinks_match_autograd_accumulation(golden_loss, dev):
         grads = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in m.parameters()])
         if use_sinks:
             assert len(ops._GRAD_SINKS) == sum(1 for _ in m.parameters())
-            assert torch.equal(grads, bucket.flat)
+            packed = torch.cat([bucket.flat[o:o + p.numel()] for p, o in zip(bucket.params, bucket.offsets)])
+            assert torch.equal(grads, packed)                    # p.grad ARE the (16-byte aligned) bucket slots
         ops.clear_grad_sinks()
         return grads
 
     a, b = run(True), run(False)
     assert float((a - b).norm() / b.norm()) < 2e-3        # (EMD terms in the loss: see test_gpu_emd)
     assert float(a.abs().max()) > 0
+
+
+def test_flat_adam_matches_torch_adam(dev):
+    """distributed.FlatAdam (one pzn_adam_step_f32 launch over flat buffers, StepLR folded in) against
+    torch.optim.Adam + StepLR on CPU, same gradients, 120 steps (crosses two scheduler boundaries)."""
+    from puzzlenet_amd import distributed as pdist
+    torch.manual_seed(3)
+    ref = [torch.nn.Parameter(torch.randn(37, 5)), torch.nn.Parameter(torch.randn(11)), torch.nn.Parameter(torch.randn(4, 4, 3))]
+    mine = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref]
+    grads = pdist.FlatGradAllReduce(mine)
+    opt = pdist.FlatAdam(grads, 1e-3, sched_step=50, sched_gamma=0.999)
+    ropt = torch.optim.Adam(ref, lr=1e-3)
+    rsch = torch.optim.lr_scheduler.StepLR(ropt, 50, 0.999)
+    g = torch.Generator().manual_seed(5)
+    for _ in range(120):
+        for p, q in zip(ref, mine):
+            gr = torch.randn(p.shape, generator=g) * 0.1
+            p.grad = gr.clone()
+            q.grad.copy_(gr.to(dev))
+        ropt.step(); rsch.step()
+        opt.step()
+    for p, q in zip(ref, mine):
+        assert (q.detach().cpu() - p.detach()).abs().max() < 2e-6
+        assert q.data_ptr() >= opt.flat.data_ptr()          # parameters live inside the flat buffer
