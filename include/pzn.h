@@ -271,6 +271,14 @@ int pzn_attn_bwd_f32(const float* q, const float* k, const float* v,
                      int B, int L, int dk, int dv, float* dq, float* dk_out,
                      float* dv_out, void* workspace, pzn_stream_t stream);
 
+/* torch.max(x, dim=1) over the point axis (model5_b.py:475 global feature, :741): out[b,c] =
+ * max_l x[b,l,c], idx[b,c] = its row (the lowest one on ties); backward dx[b,l,c] =
+ * (l == idx[b,c]) ? dout[b,c] : 0, every element of dx written (C % 4 == 0, 16-byte aligned). */
+int pzn_maxpool_points_fwd_f32(const float* x, int B, int L, int C, float* out, int32_t* idx,
+                               pzn_stream_t stream);
+int pzn_maxpool_points_bwd_f32(const float* dout, const int32_t* idx, int B, int L, int C,
+                               float* dx, pzn_stream_t stream);
+
 /* torch.optim.Adam step (model5_b.py:1453-1457: Adam(lr), no weight decay, no amsgrad) over flat
  * buffers of n floats: param, exp_avg, exp_avg_sq updated in place from grad; step = 1, 2, ...
  * (bias corrections 1 - beta^step).  All four buffers 16-byte aligned. */

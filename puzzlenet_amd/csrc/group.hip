@@ -342,3 +342,73 @@ PZN_EXPORT int pzn_group_feat_bwd_f32(const float* rows, const int64_t* idx, int
                      N, S, K, D, total_q, grad_feat);
   PZN_RETURN_LAUNCH_STATUS();
 }
+
+// ------------------------------------------------------- max over the point axis (model5_b.py:475, :741)
+// out[b, c] = max_l x[b, l, c] with the arg-max row (lowest row on ties), and its backward
+// dx[b, l, c] = (l == idx[b, c]) ? dout[b, c] : 0 written as one streaming pass (no separate zero fill).
+namespace {
+
+__global__ __launch_bounds__(1024) void maxpts_fwd_kernel(const float* __restrict__ x, int L, int C,
+                                                          float* __restrict__ out, int32_t* __restrict__ idx) {
+  __shared__ float sv[32][33];
+  __shared__ int si[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int b = blockIdx.y, c = blockIdx.x * 32 + tx;
+  float best = -INFINITY;
+  int bi = 0;
+  if (c < C) {
+    const float* p = x + (size_t)b * L * C + c;
+    for (int l = ty; l < L; l += 32) {
+      const float v = p[(size_t)l * C];
+      if (v > best) best = v, bi = l;  // rows ascend within a thread: the first maximum is kept
+    }
+  }
+  sv[ty][tx] = best, si[ty][tx] = bi;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+#pragma unroll 8
+    for (int r = 1; r < 32; ++r) {
+      const float v = sv[r][tx];
+      const int i = si[r][tx];
+      if (v > best || (v == best && i < bi)) best = v, bi = i;
+    }
+    out[(size_t)b * C + c] = best;
+    idx[(size_t)b * C + c] = bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpts_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ idx,
+                                                         int L, int C, float* __restrict__ dx) {
+  // one thread per 4 consecutive channels of one row (C % 4 == 0), grid-stride over rows
+  const int c4 = C >> 2, b = blockIdx.y;
+  const size_t per_batch = (size_t)L * c4;
+  for (size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x; f < per_batch; f += (size_t)gridDim.x * blockDim.x) {
+    const int l = (int)(f / c4), c = (int)(f % c4) * 4;
+    const int4 a = *reinterpret_cast<const int4*>(idx + (size_t)b * C + c);
+    const float4 g = *reinterpret_cast<const float4*>(dout + (size_t)b * C + c);
+    *reinterpret_cast<float4*>(dx + ((size_t)b * L + l) * C + c) =
+        make_float4(a.x == l ? g.x : 0.f, a.y == l ? g.y : 0.f, a.z == l ? g.z : 0.f, a.w == l ? g.w : 0.f);
+  }
+}
+
+}  // namespace
+
+PZN_EXPORT int pzn_maxpool_points_fwd_f32(const float* x, int B, int L, int C, float* out, int32_t* idx,
+                                          pzn_stream_t stream) {
+  PZN_CHECK_ARG(x && out && idx && B > 0 && B <= 65535 && L > 0 && C > 0);
+  hipLaunchKernelGGL(maxpts_fwd_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)B), dim3(1024), 0, pzn_hip_stream(stream),
+                     x, L, C, out, idx);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+PZN_EXPORT int pzn_maxpool_points_bwd_f32(const float* dout, const int32_t* idx, int B, int L, int C, float* dx,
+                                          pzn_stream_t stream) {
+  PZN_CHECK_ARG(dout && idx && dx && B > 0 && B <= 65535 && L > 0 && C > 0 && (C & 3) == 0);
+  PZN_CHECK_ARG(((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
+  const size_t per_batch = (size_t)L * (C >> 2);
+  size_t gx = (per_batch + 255) / 256;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(maxpts_bwd_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, pzn_hip_stream(stream), dout, idx, L,
+                     C, dx);
+  PZN_RETURN_LAUNCH_STATUS();
+}

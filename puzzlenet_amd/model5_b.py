@@ -153,7 +153,7 @@ class PCTransformer_nonsort(nn.Module):
         attention = attention / 4
         att = torch.cat([att, f2f], dim=-1)
         out = dense.linear(att, self.out.weight, self.out.bias)                                   # :474
-        f_global = torch.max(out, dim=1)[0]                                                       # :475
+        f_global = ops.max_over_points(out)                                                       # :475
         return f_global, x2, attention, out, x_feature
 
 
@@ -244,8 +244,9 @@ class TouchedRegraster(_Base):
         non_sg_ffpc = _run_seq(self.MLPLocalPreFpc, non_sg_ffpc)                    # :738
         non_sg_fmrpc = _run_seq(self.MLPLocalPreRpc, non_sg_fmrpc)                  # :739
         # :741 — the reference takes the max of non_sg_fmrpc for BOTH globals (its bug, kept)
-        non_sg_ffpc_global = torch.max(non_sg_fmrpc, dim=1, keepdim=True)[0].repeat(1, N, 1)
-        non_sg_fmrpc_global = torch.max(non_sg_fmrpc, dim=1, keepdim=True)[0].repeat(1, N, 1)
+        g_max = ops.max_over_points(non_sg_fmrpc).unsqueeze(1)      # one reduction serves both (identical) globals
+        non_sg_ffpc_global = g_max.repeat(1, N, 1)
+        non_sg_fmrpc_global = g_max.repeat(1, N, 1)
         ffpc_feature4seg = torch.cat([non_sg_fmrpc_global, non_sg_ffpc], dim=-1)    # :748
         fmrpc_feature4seg = torch.cat([non_sg_ffpc_global, non_sg_fmrpc], dim=-1)   # :749
         de_fpcb = _run_seq(self.MLPFpcb, ffpc_feature4seg).permute(0, 2, 1)         # :751-752

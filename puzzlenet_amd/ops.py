@@ -161,6 +161,40 @@ def index_points(points, idx):
     return _Gather.apply(points, idx)
 
 
+class _MaxOverPoints(torch.autograd.Function):
+    """torch.max(x, dim=1)[0] for x[B, L, C] (model5_b.py:475, :741): one pass forward (value + arg-max row), one
+    streaming pass backward that writes every element of dx (no zero fill + scatter)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32(x, "x")
+        B, L, C = x.shape
+        out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        idx = torch.empty((B, C), dtype=torch.int32, device=x.device)
+        with torch.cuda.device(x.device):
+            _call("pzn_maxpool_points_fwd_f32", _p(x), B, L, C, _p(out), _p(idx), _stream())
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, L, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        B, L, C = ctx.dims
+        dout = _f32(dout, "dout")
+        dx = torch.empty((B, L, C), dtype=torch.float32, device=dout.device)
+        with torch.cuda.device(dout.device):
+            _call("pzn_maxpool_points_bwd_f32", _p(dout), _p(idx), B, L, C, _p(dx), _stream())
+        return dx
+
+
+def max_over_points(x):
+    """[B, L, C] -> [B, C]"""
+    if x.shape[-1] % 4 != 0:
+        raise _lib.PznError(f"max_over_points: channel count must be a multiple of 4, got {x.shape[-1]}")
+    return _MaxOverPoints.apply(x)
+
+
 class _Group(torch.autograd.Function):
     """pointnet_util.py:123-132: cat(xyz[idx] - new_xyz, feat[idx]) in one kernel."""
 

@@ -249,3 +249,25 @@ def test_knn_group_pad_fused_vs_oracle(dev, B, N, S, D):
     assert np.array_equal(o[..., :3].view(np.uint32), g[..., :3].view(np.uint32))
     assert (o[..., 3] == 0).all()
     assert np.array_equal(o[..., 4:].view(np.uint32), g[..., 3:].view(np.uint32))
+
+
+@pytest.mark.parametrize("B,L,C", [(3, 256, 1024), (2, 2048, 64), (1, 7, 4), (5, 33, 36)])
+def test_max_over_points(B, L, C):
+    """ops.max_over_points == torch.max(x, dim=1)[0] (model5_b.py:475, :741), gradient = one-hot scatter;
+    exact (it is a selection); ties resolve to the lowest row."""
+    from puzzlenet_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 1000 + L + C)
+    x = torch.randn(B, L, C, generator=g)
+    x[:, L // 2] = x[:, 0]                       # duplicate rows: ties between row 0 and row L//2
+    xr = x.clone().requires_grad_(True)
+    ref = torch.max(xr, dim=1)[0]
+    go = torch.randn(B, C, generator=g)
+    xd = x.to(dev).requires_grad_(True)
+    out = ops.max_over_points(xd)
+    assert torch.equal(out.cpu(), ref.detach())
+    out.backward(go.to(dev))
+    # reference gradient with the lowest arg-max row on ties
+    idx = (x == ref.detach().unsqueeze(1)).float().argmax(dim=1)          # first row attaining the max
+    want = torch.zeros_like(x).scatter_(1, idx.unsqueeze(1), go.unsqueeze(1))
+    assert torch.equal(xd.grad.cpu(), want)
