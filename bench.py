@@ -180,14 +180,19 @@ def main():
         d_n = sum(kern.get(k, (0, 0.0))[0] for k in dense_names)
         mfma_achieved = d_fl / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
         roofline = {
-            "bound": "mfma", "kernel": "gemm_kernel<...> (fp32 result; bf16x3 split-precision or fp32 MFMA operands) behind "
-                                       "pzn_linear_* / pzn_sharedmlp_max_fwd / pzn_sa_mlp_max_bwd / pzn_attn_*",
+            "bound": "mfma",
+            "kernel": "the bf16x3 split-precision matrix-core kernels (fp32 result): ws_gemm_kernel (weight-stationary, forward / "
+                      "input gradients of the skinny layers), df_wgrad_kernel (direct-fragment weight gradients), gemm_kernel "
+                      "(general tile engine: wide layers, attention products) behind pzn_linear_* / pzn_sharedmlp_max_fwd / "
+                      "pzn_sa_mlp_max_bwd* / pzn_attn_*; the time also contains the sparse max-pool backward and scatter "
+                      "epilogues of those entry points, the flops do not",
             "achieved": mfma_achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": mfma_achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
             "algorithmic_flops_per_step": d_fl / max(1, prof_steps),
             "ms_per_step": d_ms / max(1, prof_steps), "launches_per_step": d_n / max(1, prof_steps),
-            "note": "peak = dense fp32 MFMA rate (157.3 TFLOP/s); launches also stream their operands from HBM "
-                    "(the skinny K=N=128..256 products are near the HBM ridge), see roofline_knn_group for the HBM-bound stage",
+            "note": "algorithmic fp32 flops / summed launch time; peak = dense fp32 MFMA rate (157.3 TFLOP/s); the skinny "
+                    "K, N = 64..256 products stream 10^5..10^6 rows and sit near the HBM ridge (forward of 1M x 128 x 128 "
+                    "moves 1.07 GB: 0.30 ms at 3.6 TB/s); see roofline_knn_group for the HBM-bound stage",
         }
         # (2) the stage the north star names: kNN + group (HBM-bound), SURVEY 8(d) bytes.
         per_pair = 2 * (knn_group_bytes(N, 512, 32, 64) + knn_group_bytes(512, 256, 32, 128))
