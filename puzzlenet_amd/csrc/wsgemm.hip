@@ -86,9 +86,9 @@ __device__ __forceinline__ float4 relu_mask(float4 x, float4 y) {
 
 // NT = 32-column tiles per wavefront (weight slice = NT*32 columns), MAXPOOL = max over the tile's 32 rows,
 // GENY = ReLU-mask the activation stream with genY.
-// DEEP: two register sets = two double steps in flight (needs nd even and full tiles: every load and store of the
-// walk is then unconditional, which keeps the compiler's vmcnt bookkeeping exact across the unrolled loop).
-template <int NT, bool MAXPOOL, bool GENY, int NW, bool DEEP>
+// FULL: M % 32 == 0 and N % (NT*32) == 0: every store of the walk is unconditional too.
+// D2: two register sets = two 32 x 32 blocks of the stream in flight per wave (needs an even double-step count).
+template <int NT, bool MAXPOOL, bool GENY, int NW, bool FULL, bool D2>
 __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
   constexpr int WS_T = NW * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];  // [nd*2][NT][3][64 lanes][16 B]
@@ -125,53 +125,38 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
   int t = blockIdx.x * NW + wave;
   if (t >= ntiles) return;
 
-  // This lane's stream: row (tile*32 + l31), 16 consecutive floats at k = 32d + 16*half per double step.
-  // One register set: the next 64 bytes are requested right after the current ones have arrived and stay in
-  // flight for a whole double step of MFMAs (this wave's and those of the other waves on the SIMD).
-  float4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;      // A
-  float4 ya0, ya1, ya2, ya3, yb0, yb1, yb2, yb3;      // genY
-  int it = t, id = 0;                                  // issue cursor (tile, double step)
-  // Loads are issued UNCONDITIONALLY (rows past M and k past K are clamped to valid addresses and zeroed at
-  // consumption): a branch around them would make the compiler's vmcnt bookkeeping fall back to vmcnt(0) and
-  // collapse the prefetch distance.
-  const int kmax = p.K - 4;
-  // DEEP walks have no clamps at all, so their loads are buffer loads: descriptor + wave-uniform tile / k offset
-  // (scalar) + a lane offset that never changes: no address arithmetic on the vector ALU.
-  typedef unsigned int u32x4v __attribute__((__vector_size__(16)));
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, -1, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsY =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GENY ? p.genY : p.A), 0, -1, 0x00020000);
-  const int voff = (l31 * p.lda + half * 16) * 4;
-#define WS_BLOAD(rs, o) __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (o), soff_, 0))
-#define WS_ISSUE(x0, x1, x2, x3, y0, y1, y2, y3)                                                          \
-  do {                                                                                                    \
-    if (DEEP) {                                                                                           \
-      const int itc_ = it < ntiles ? it : ntiles - 1;                                                     \
-      const int soff_ = (itc_ * 32 * p.lda + id * 32) * 4;                                                \
-      x0 = WS_BLOAD(rsA, 0), x1 = WS_BLOAD(rsA, 16), x2 = WS_BLOAD(rsA, 32), x3 = WS_BLOAD(rsA, 48);        \
-      if (GENY) y0 = WS_BLOAD(rsY, 0), y1 = WS_BLOAD(rsY, 16), y2 = WS_BLOAD(rsY, 32), y3 = WS_BLOAD(rsY, 48); \
-      if (++id == p.nd) id = 0, it += tstride;                                                            \
-      break;                                                                                              \
-    }                                                                                                     \
-    int row_ = it * 32 + l31;                                                                             \
-    row_ = row_ < p.M ? row_ : p.M - 1;                                                                   \
-    const int kb_ = id * 32 + half * 16;                                                                  \
-    const float* a_ = p.A + (size_t)row_ * p.lda;                                                         \
-    x0 = *reinterpret_cast<const float4*>(a_ + min(kb_, kmax));                                           \
-    x1 = *reinterpret_cast<const float4*>(a_ + min(kb_ + 4, kmax));                                       \
-    x2 = *reinterpret_cast<const float4*>(a_ + min(kb_ + 8, kmax));                                       \
-    x3 = *reinterpret_cast<const float4*>(a_ + min(kb_ + 12, kmax));                                      \
-    if (GENY) {                                                                                           \
-      const float* y_ = p.genY + (size_t)row_ * p.lda;                                                    \
-      y0 = *reinterpret_cast<const float4*>(y_ + min(kb_, kmax));                                         \
-      y1 = *reinterpret_cast<const float4*>(y_ + min(kb_ + 4, kmax));                                     \
-      y2 = *reinterpret_cast<const float4*>(y_ + min(kb_ + 8, kmax));                                     \
-      y3 = *reinterpret_cast<const float4*>(y_ + min(kb_ + 12, kmax));                                    \
-    }                                                                                                     \
-    if (++id == p.nd) id = 0, it += tstride;                                                              \
+  // Activation stream.  A double step needs the wave's 32 rows x 32 k (128 bytes per row).  Fetching them in the
+  // MFMA operand layout (lane = row) makes every load instruction touch 32 different 128-byte lines (measured:
+  // 2.4 TB/s with everything else removed), so the tile is fetched COALESCED — lane l takes 16 bytes at k-offset
+  // (l&7)*4 of rows (l>>3) + 8i: eight lanes per full line — and goes through the wave's private LDS patch
+  // (4 ds_write_b128, 4 ds_read_b128, wave-local: no barrier) to reach the operand layout (row l&31, 16 k at
+  // half*16).  Loads are buffer loads: descriptor + wave-uniform tile / row-group offset (scalar) + a lane offset
+  // that never changes, so there is no address arithmetic on the vector ALU, rows past M read as zero through the
+  // descriptor's size, and every load is unconditional (the compiler's vmcnt bookkeeping stays exact).
+  const __amdgpu_buffer_rsrc_t rsA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)((size_t)p.M * p.lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GENY ? p.genY : p.A), 0,
+                                                                       (int)((size_t)p.M * p.lda * 4), 0x00020000);
+  const int prow = lane >> 3, pcol = (lane & 7) * 4;
+  const int voff = (prow * p.lda + pcol) * 4;
+  const int rstep = 8 * p.lda * 4;  // bytes between the row groups of consecutive load instructions
+  float4 g0, g1, g2, g3, y0, y1, y2, y3;      // set A
+  float4 h0, h1, h2, h3, z0, z1, z2, z3;      // set B (D2)
+  int it = t, id = 0;  // issue cursor (tile, double step)
+#define WS_BLOAD(rs, so) __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, so, 0))
+#define WS_ISSUE(a0, a1, a2, a3, b0, b1, b2, b3)                                                    \
+  do {                                                                                               \
+    const int so_ = (it * 32 * p.lda + id * 32) * 4;                                                 \
+    a0 = WS_BLOAD(rsA, so_), a1 = WS_BLOAD(rsA, so_ + rstep);                                        \
+    a2 = WS_BLOAD(rsA, so_ + 2 * rstep), a3 = WS_BLOAD(rsA, so_ + 3 * rstep);                        \
+    if (GENY) {                                                                                      \
+      b0 = WS_BLOAD(rsY, so_), b1 = WS_BLOAD(rsY, so_ + rstep);                                      \
+      b2 = WS_BLOAD(rsY, so_ + 2 * rstep), b3 = WS_BLOAD(rsY, so_ + 3 * rstep);                      \
+    }                                                                                                \
+    if (++id == p.nd) id = 0, it += tstride;                                                         \
   } while (0)
-  WS_ISSUE(pa0, pa1, pa2, pa3, ya0, ya1, ya2, ya3);
-  if (DEEP) WS_ISSUE(pb0, pb1, pb2, pb3, yb0, yb1, yb2, yb3);
+  WS_ISSUE(g0, g1, g2, g3, y0, y1, y2, y3);
+  if (D2) WS_ISSUE(h0, h1, h2, h3, z0, z1, z2, z3);
 
   floatx16 acc[NT];
 #pragma unroll
@@ -179,13 +164,12 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   float* stage = reinterpret_cast<float*>(wlds + (size_t)p.nd * 2 * NT * 3 * 1024) + wave * (32 * WS_STAGE_LD);
+  const bool ktail = (p.K & 31) != 0;  // D2 walks are launched for K % 32 == 0 only
+  float* pw = stage + prow * WS_STAGE_LD + pcol;             // patch write position (+ 8*i rows)
+  const float* pr = stage + l31 * WS_STAGE_LD + half * 16;   // patch read position (+ 4*q floats)
 
-  auto take = [&](float4 x, float4 y, bool in_k) {
-    if (GENY) x = relu_mask(x, y);
-    return in_k ? x : make_float4(0.f, 0.f, 0.f, 0.f);
-  };
   int d = 0;
-  // one double step: consume a register set, refill it two double steps ahead, 2 x NT x 6 MFMAs
+  // one double step: 2 x NT x 6 MFMAs on the 16 floats of this lane's row
   auto step = [&](float4 c0, float4 c1, float4 c2, float4 c3) {
     const unsigned char* wb = wlds + (size_t)(d * 2) * (NT * 3 * 1024) + lane * 16;
 #pragma unroll
@@ -217,21 +201,6 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
         acc[j] = c;
       }
     }
-    // Issue order for the whole double step (one scheduling region): the refill loads first, the split of the
-    // first 8 floats, then the MFMAs of step 0 with the split of the second 8 floats and the next tile's B
-    // fragments slotted into their gaps (left alone, the scheduler sinks the loads to the end of the block and
-    // runs all the VALU work in front of the first MFMA).
-    __builtin_amdgcn_sched_group_barrier(0x020, GENY ? 8 : 4, 0);  // VMEM reads
-    __builtin_amdgcn_sched_group_barrier(0x002, 52, 0);            // VALU: masks + first split
-    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);             // DS reads: B fragments of (0, 0)
-#pragma unroll
-    for (int b = 0; b < 2 * NT; ++b)
-#pragma unroll
-      for (int m = 0; m < 6; ++m) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (b < NT) __builtin_amdgcn_sched_group_barrier(0x002, NT == 1 ? 8 : (NT == 2 ? 4 : 2), 0);
-        if (m < 3 && b + 1 < 2 * NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
   };
 
   auto epilogue = [&]() {
@@ -257,7 +226,7 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
         const bool take = ob > best || (ob == best && oi < bi);
         best = take ? ob : best;
         bi = take ? oi : bi;
-        if (DEEP) {  // one unconditional store per lane: lower half the value, upper half the index
+        if (FULL) {  // one unconditional store per lane: lower half the value, upper half the index
           float* dst = half ? reinterpret_cast<float*>(p.argmax) : p.C;
           dst[(size_t)t * p.ldc + col] = half ? __int_as_float(bi) : best;
         } else if (half == 0 && col_ok) {
@@ -282,7 +251,7 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
           for (int i = 0; i < 16; ++i) {
             const int rl = 2 * i + half, row = t * 32 + rl, col = n0 + j * 32 + l31;
             const float v = stage[rl * WS_STAGE_LD + l31];
-            if (DEEP || (row < p.M && col < p.N)) {
+            if (FULL || (row < p.M && col < p.N)) {
               const long dst = (long)(row / p.scat_in) * p.scat_out + p.scat[row];
               atomicAdd(p.C + (size_t)dst * p.ldc + col, v);
             }
@@ -293,7 +262,7 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
             const int rl = (lane >> 3) + 8 * i, c4 = (lane & 7) * 4;
             float4 v = *reinterpret_cast<const float4*>(stage + rl * WS_STAGE_LD + c4);
             const int row = t * 32 + rl, col = n0 + j * 32 + c4;
-            if (DEEP || (row < p.M && col + 3 < p.N)) {
+            if (FULL || (row < p.M && col + 3 < p.N)) {
               const size_t o = (size_t)row * p.ldc + col;
               if (p.maskH) v = relu_mask(v, *reinterpret_cast<const float4*>(p.maskH + o));
               *reinterpret_cast<float4*>(p.C + o) = v;
@@ -307,43 +276,44 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
     }
   };
 
+#define WS_CONSUME(a0, a1, a2, a3, b0, b1, b2, b3)                                                            \
+  do {                                                                                                         \
+    float4 x0 = a0, x1 = a1, x2 = a2, x3 = a3;                                                                 \
+    if (GENY) x0 = relu_mask(x0, b0), x1 = relu_mask(x1, b1), x2 = relu_mask(x2, b2), x3 = relu_mask(x3, b3);  \
+    if (!D2 && ktail && d * 32 + pcol >= p.K) x0 = x1 = x2 = x3 = make_float4(0.f, 0.f, 0.f, 0.f); /* k past K */ \
+    *reinterpret_cast<float4*>(pw) = x0;                                                                       \
+    *reinterpret_cast<float4*>(pw + 8 * WS_STAGE_LD) = x1;                                                     \
+    *reinterpret_cast<float4*>(pw + 16 * WS_STAGE_LD) = x2;                                                    \
+    *reinterpret_cast<float4*>(pw + 24 * WS_STAGE_LD) = x3;                                                    \
+    WS_ISSUE(a0, a1, a2, a3, b0, b1, b2, b3); /* refill this set: in flight for one (two with D2) double steps */ \
+    __builtin_amdgcn_wave_barrier();                                                                           \
+    const float4 c0 = *reinterpret_cast<const float4*>(pr), c1 = *reinterpret_cast<const float4*>(pr + 4);     \
+    const float4 c2 = *reinterpret_cast<const float4*>(pr + 8), c3 = *reinterpret_cast<const float4*>(pr + 12); \
+    __builtin_amdgcn_wave_barrier();                                                                           \
+    step(c0, c1, c2, c3);                                                                                      \
+  } while (0)
   for (; t < ntiles; t += tstride) {
-    if (DEEP) {
+    if (D2) {
       for (d = 0; d < p.nd; ++d) {
-        {
-          const float4 c0 = take(pa0, ya0, true), c1 = take(pa1, ya1, true);
-          const float4 c2 = take(pa2, ya2, true), c3 = take(pa3, ya3, true);
-          WS_ISSUE(pa0, pa1, pa2, pa3, ya0, ya1, ya2, ya3);
-          step(c0, c1, c2, c3);
-        }
+        WS_CONSUME(g0, g1, g2, g3, y0, y1, y2, y3);
         ++d;
-        {
-          const float4 c0 = take(pb0, yb0, true), c1 = take(pb1, yb1, true);
-          const float4 c2 = take(pb2, yb2, true), c3 = take(pb3, yb3, true);
-          WS_ISSUE(pb0, pb1, pb2, pb3, yb0, yb1, yb2, yb3);
-          step(c0, c1, c2, c3);
-        }
+        WS_CONSUME(h0, h1, h2, h3, z0, z1, z2, z3);
       }
     } else {
-      for (d = 0; d < p.nd; ++d) {
-        const int kb = d * 32 + half * 16;
-        const float4 c0 = take(pa0, ya0, kb <= kmax), c1 = take(pa1, ya1, kb + 4 <= kmax);
-        const float4 c2 = take(pa2, ya2, kb + 8 <= kmax), c3 = take(pa3, ya3, kb + 12 <= kmax);
-        WS_ISSUE(pa0, pa1, pa2, pa3, ya0, ya1, ya2, ya3);
-        step(c0, c1, c2, c3);
-      }
+      for (d = 0; d < p.nd; ++d) WS_CONSUME(g0, g1, g2, g3, y0, y1, y2, y3);
     }
     epilogue();
   }
+#undef WS_CONSUME
 #undef WS_ISSUE
 #undef WS_BLOAD
 }
 
-size_t stage_bytes(bool maxpool) { return maxpool ? 0 : (size_t)WS_NW * 32 * WS_STAGE_LD * sizeof(float); }
+size_t stage_bytes(bool) { return (size_t)WS_NW * 32 * WS_STAGE_LD * sizeof(float); }  // every wave's 32 x 32 patch
 
-template <int NT, bool MAXPOOL, bool GENY, bool DEEP>
-int launch_nt_d(const WsArgs& p, hipStream_t st) {
-  auto kern = ws_gemm_kernel<NT, MAXPOOL, GENY, WS_NW, DEEP>;
+template <int NT, bool MAXPOOL, bool GENY, bool FULL, bool D2>
+int launch_nt_f(const WsArgs& p, hipStream_t st) {
+  auto kern = ws_gemm_kernel<NT, MAXPOOL, GENY, WS_NW, FULL, D2>;
   const size_t lds = (size_t)p.nd * 2 * NT * 3 * 1024 + stage_bytes(MAXPOOL);
   if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -360,15 +330,12 @@ int launch_nt_d(const WsArgs& p, hipStream_t st) {
 
 template <int NT, bool MAXPOOL, bool GENY>
 int launch_nt(const WsArgs& p, hipStream_t st) {
-  static const bool deep_on = [] { const char* e = getenv("PZN_WS_DEEP"); return !(e && e[0] == '0'); }();  // tuning aid
-  // two double steps in flight when every access of the walk can be unconditional and the registers allow it
-  const bool deep = deep_on && !GENY && (p.nd & 1) == 0 && (p.K & 31) == 0 && (p.M & 31) == 0 &&
-                    p.N % (NT * 32) == 0 && (double)p.M * p.lda * 4.0 < 4294967296.0;
-  if constexpr (GENY) {  // the mask stream doubles the prefetch registers: single set
-    return launch_nt_d<NT, MAXPOOL, GENY, false>(p, st);
-  } else {
-    return deep ? launch_nt_d<NT, MAXPOOL, GENY, true>(p, st) : launch_nt_d<NT, MAXPOOL, GENY, false>(p, st);
+  static const bool d2_on = [] { const char* e = getenv("PZN_WS_D2"); return !(e && e[0] == '0'); }();  // tuning aid
+  const bool full = (p.M & 31) == 0 && p.N % (NT * 32) == 0;
+  if constexpr (!GENY) {  // the mask stream doubles the staging registers: one set there
+    if (full && d2_on && (p.nd & 1) == 0 && (p.K & 31) == 0) return launch_nt_f<NT, MAXPOOL, GENY, true, true>(p, st);
   }
+  return full ? launch_nt_f<NT, MAXPOOL, GENY, true, false>(p, st) : launch_nt_f<NT, MAXPOOL, GENY, false, false>(p, st);
 }
 
 template <bool MAXPOOL, bool GENY>
@@ -397,6 +364,7 @@ bool pzn_ws_gemm_supported(int M, int N, int K, const float* A, int lda, const f
   if (!ws_enabled()) return false;
   if (M < 4096 || N < 32 || (N & 3) || K < 16 || (K & 3) || (lda & 3)) return false;  // small / unaligned: general engine
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(genY) & 15)) return false;
+  if ((double)M * lda * 4.0 >= 2147483648.0 - 4.0e8) return false;  // 32-bit buffer offsets incl. the prefetch overrun
   return pick_nt(N, (K + 31) / 32, maxpool) != 0;
 }
 
