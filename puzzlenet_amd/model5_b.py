@@ -18,13 +18,15 @@ Reference quirks that ARE reproduced: the model5_b.py:741 copy-paste (the fpc gl
 feature is the max of the *mrpc* local feature) and the ``x2[:, idx[:, 0]]`` indexing
 at :940/:942 that yields a [B,B,3] tensor.
 """
+import datetime
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import dense, ops, se3
+from . import dense, metrics, ops, se3
 from . import pointnet_util as pu
 from .PyTorchEMD.emd import earth_mover_distance
 
@@ -410,6 +412,61 @@ class TouchedRegraster(_Base):
             loss = loss + emd_fpcb + emd_mrpcb
         self.log('train_loss', loss)
         return {'loss': loss}
+
+    # ------------------------------------------------------------------ eval path
+    def compute_metrics(self, R, t, igt):
+        """model5_b.py:1426-1440: errors of the predicted (R, t) against the INVERSE of the ground-truth motion
+        igt[B,4,4] -> (r_mse, r_mae, t_mse, t_mae, r_isotropic, t_isotropic), one value per sample."""
+        inv_R, inv_t = metrics.inv_R_t(igt[:, :3, :3], igt[:, :3, 3])
+        r_mse, r_mae = metrics.anisotropic_R_error(R, inv_R)
+        t_mse, t_mae = metrics.anisotropic_t_error(t, inv_t)
+        return r_mse, r_mae, t_mse, t_mae, metrics.isotropic_R_error(R, inv_R), metrics.isotropic_t_error(t, inv_t, inv_R)
+
+    METRIC_NAMES = ('r_mse', 'r_mae', 't_mse', 't_mae', 'r_iso', 't_iso', 'fpc_iou', 'mrpc_iou', 'cd_fpcb', 'cd_rpcb')
+
+    def test_step(self, batch, batch_id):
+        """model5_b.py:1279-1366 -> [1, 10] scores (METRIC_NAMES): registration errors of the predicted pose,
+        IoU of the 128 predicted boundary points of both pieces, chamfer distance of the predicted boundaries.
+        Un-batched samples ([N,3] clouds, [N] labels) are given a batch axis as the reference does; the width of the
+        boundary masks follows the clouds (the reference hard-wires 1024)."""
+        nb = [b.unsqueeze(0) if b.dim() == 2 else b for b in batch[:-2]]
+        nb += [b.unsqueeze(0) if b.dim() == 1 else b for b in batch[-2:]]
+        fpc, mrpc, igt, rpc, fpcb, rpcb, fpc_idx, rpc_idx = nb[:8]
+        B, N = fpc.shape[0], fpc.shape[1]
+
+        out, _, de_fpcb, de_mrpcb = self.predict5(nb, B, training=False, need=False)
+        mat = se3.exp(out).to(fpc)
+        R, t = mat[:, :3, :3], mat[:, :3, 3]
+        scores = [torch.as_tensor(v, dtype=torch.float32).mean().to(fpc.device) for v in self.compute_metrics(R, t, igt)]
+
+        fpc_top = torch.topk(torch.softmax(de_fpcb, dim=1)[:, 1, :], 128, 1)[1]         # [B,128]
+        mrpc_top = torch.topk(torch.softmax(de_mrpcb, dim=1)[:, 1, :], 128, 1)[1]
+        pred_f = torch.zeros((B, N), dtype=fpc_idx.dtype, device=fpc.device).scatter(1, fpc_top, 1)
+        pred_m = torch.zeros((B, N), dtype=fpc_idx.dtype, device=fpc.device).scatter(1, mrpc_top, 1)
+        for pred, gt in ((pred_f, fpc_idx), (pred_m, rpc_idx)):
+            inter = torch.sum(torch.logical_and(pred, gt)).float()
+            union = torch.sum(torch.logical_or(pred, gt)).float()
+            scores.append(inter / union)
+
+        cd1, cd2 = self.chamfer_loss(fpcb, ops.index_points(fpc, fpc_top))
+        scores.append(torch.mean(cd1) + torch.mean(cd2))
+        moved = se3.transform(mat, ops.index_points(rpc, mrpc_top).permute(0, 2, 1)).permute(0, 2, 1)
+        cd1, cd2 = self.chamfer_loss(rpcb, moved)
+        scores.append(torch.mean(cd1) + torch.mean(cd2))
+        return torch.stack([s.float() for s in scores]).unsqueeze(0)
+
+    def test_epoch_end(self, outputs):
+        """model5_b.py:1368-1385: mean of the per-batch score rows, printed and written to
+        <output_path>/<date>metrics.txt in the reference's format (header line, then the ten values)."""
+        s = torch.mean(torch.cat(list(outputs), dim=0), dim=0)
+        for name, v in zip(self.METRIC_NAMES, s):
+            print(f"{name}   {float(v)}")
+        path = os.path.join(self.C.output_path, datetime.datetime.now().strftime('%b%d_%H-%M-%S') + 'metrics.txt')
+        os.makedirs(self.C.output_path, exist_ok=True)
+        with open(path, 'w+') as fout:
+            fout.write('r_mse,   r_mae,   t_mse,    t_mae,    r_iso,    t_iso,  fpc_iou,   mrpc_iou, cd_fpcb, cd_rpcb \n')
+            fout.write(''.join(str(v.detach().cpu().numpy()) + '   ' for v in s) + '\n')
+        return s
 
     def configure_optimizers(self):
         """model5_b.py:1453-1457: Adam + StepLR(50, 0.999) stepped per batch."""

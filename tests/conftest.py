@@ -28,3 +28,8 @@ def golden_model():
 @pytest.fixture(scope="session")
 def golden_loss():
     return np.load(os.path.join(GOLDEN, "loss.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_eval():
+    return np.load(os.path.join(GOLDEN, "eval.npz"))

@@ -1,6 +1,8 @@
 """GPU parity of the model path (puzzlenet_amd.model5_b drop-in) against the reference's
 own outputs (tests/golden/model.npz, loss.npz).  Tolerance: fp32 pose / logits / loss within
 1e-4 relative (BASELINE.json north_star); FPS-selected points bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -207,3 +209,35 @@ def test_flat_adam_matches_torch_adam(dev):
     for p, q in zip(ref, mine):
         assert (q.detach().cpu() - p.detach()).abs().max() < 2e-6
         assert q.data_ptr() >= opt.flat.data_ptr()          # parameters live inside the flat buffer
+
+
+def test_test_step_matches_reference(golden_model, golden_eval, dev, tmp_path):
+    """Eval path: TouchedRegraster.test_step on the seeded B=4, N=1024 batch against the ten scores
+    the reference's own test_step produced on CPU (tests/golden/make_golden_eval.py), and test_epoch_end's file."""
+    from puzzlenet_amd import model5_b as mb
+    G, E = golden_model, golden_eval
+    cfg = mr.Cfg()
+    cfg.output_path = str(tmp_path)
+    m = mb.TouchedRegraster(cfg)
+    mr.fill_params(m)
+    m.to(dev).eval()
+    batch = [_t(G[f"p5_batch{i}"], dev) for i in range(8)]
+    torch.manual_seed(int(E["ts_seed"][0]))
+    with torch.no_grad():
+        scores = m.test_step(batch, 0)
+    assert scores.shape == (1, 10)
+    got, want = scores.cpu().numpy()[0], E["ts_scores"][0]
+    np.testing.assert_allclose(got[:6], want[:6], rtol=2e-4, atol=1e-5)      # pose errors (Euler angles amplify)
+    np.testing.assert_allclose(got[6:8], want[6:8], rtol=0, atol=1e-6)        # IoU of the top-128 boundary picks
+    np.testing.assert_allclose(got[8:], want[8:], rtol=1e-4)                  # boundary chamfer distances
+    # un-batched sample path + the metrics file
+    single = [b[0] for b in batch]
+    with torch.no_grad():
+        s1 = m.test_step(single, 0)
+    assert s1.shape == (1, 10) and torch.isfinite(s1).all()
+    mean = m.test_epoch_end([scores, scores])
+    np.testing.assert_allclose(mean.cpu().numpy(), got, rtol=1e-6)
+    files = [f for f in os.listdir(tmp_path) if f.endswith("metrics.txt")]
+    assert len(files) == 1
+    lines = open(os.path.join(tmp_path, files[0])).read().splitlines()
+    assert lines[0].startswith("r_mse,") and len(lines[1].split()) == 10
