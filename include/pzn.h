@@ -279,6 +279,13 @@ int pzn_maxpool_points_fwd_f32(const float* x, int B, int L, int C, float* out, 
 int pzn_maxpool_points_bwd_f32(const float* dout, const int32_t* idx, int B, int L, int C,
                                float* dx, pzn_stream_t stream);
 
+/* SE(3) exponential of the pose head (se_math/se3.py:57-80 with so3.mat and the Taylor-guarded
+ * sinc1/2/3 of se_math/sinc.py): twist[B,6] = (w, v) -> g[B,4,4]; backward dg[B,4,4] ->
+ * dtwist[B,6] (the last row of dg is ignored: it is constant). */
+int pzn_se3_exp_fwd_f32(const float* twist, int B, float* g, pzn_stream_t stream);
+int pzn_se3_exp_bwd_f32(const float* twist, const float* dg, int B, float* dtwist,
+                        pzn_stream_t stream);
+
 /* torch.optim.Adam step (model5_b.py:1453-1457: Adam(lr), no weight decay, no amsgrad) over flat
  * buffers of n floats: param, exp_avg, exp_avg_sq updated in place from grad; step = 1, 2, ...
  * (bias corrections 1 - beta^step).  All four buffers 16-byte aligned. */

@@ -52,6 +52,8 @@ SIGNATURES = {
     "pzn_sa_mlp_max_bwd_f32": (_c_i, [_c_f] * 7 + [_c_i] * 4 + [_c_f] * 6 + [_c_i, _c_f]),
     "pzn_maxpool_points_fwd_f32": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_maxpool_points_bwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
+    "pzn_se3_exp_fwd_f32": (_c_i, [_c_f, _c_i, _c_f, _c_f]),
+    "pzn_se3_exp_bwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_f, _c_f]),
     "pzn_adam_step_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, _c_i, _c_f]),
     "pzn_sa_mlp_max_bwd_scatter_f32": (_c_i, [_c_f] * 8 + [_c_i] * 6 + [_c_f] * 7 + [_c_i, _c_f]),

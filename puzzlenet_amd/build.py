@@ -29,6 +29,7 @@ SOURCES = [
     ("wsgemm.hip", []),
     ("dfgemm.hip", []),
     ("optim.hip", ["-ffp-contract=off"]),
+    ("se3.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]

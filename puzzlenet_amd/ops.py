@@ -188,6 +188,34 @@ class _MaxOverPoints(torch.autograd.Function):
         return dx
 
 
+class _Se3Exp(torch.autograd.Function):
+    """se3.exp (se_math/se3.py:57-80): twist [B,6] -> [B,4,4], one launch each way."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32(x, "twist")
+        B = x.shape[0]
+        g = torch.empty((B, 4, 4), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _call("pzn_se3_exp_fwd_f32", _p(x), B, _p(g), _stream())
+        ctx.save_for_backward(x)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        (x,) = ctx.saved_tensors
+        dg = _f32(dg, "dg")
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _call("pzn_se3_exp_bwd_f32", _p(x), _p(dg), x.shape[0], _p(dx), _stream())
+        return dx
+
+
+def se3_exp(x):
+    """[B,6] on the GPU -> [B,4,4]"""
+    return _Se3Exp.apply(x)
+
+
 def max_over_points(x):
     """[B, L, C] -> [B, C]"""
     if x.shape[-1] % 4 != 0:

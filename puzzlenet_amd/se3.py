@@ -2,8 +2,9 @@
 (reference: se_math/se3.py:57-80 `exp`, :110-120 `transform`; se_math/so3.py `mat`;
 se_math/sinc.py:6-18, 96-108, 126-138 `sinc1/2/3` with their |t| < 0.01 Taylor branches).
 
-Row (f1) of the scope table: B x 4 x 4 math, a few hundred flops per pair, kept
-as torch tensor ops (autograd included) — it is not a GPU hot spot.
+Row (f1) of the scope table.  `exp` of GPU tensors is one HIP launch each way (csrc/se3.hip): as tensor ops
+it was ~150 launches of 64-element kernels per step (2.3 ms of a 21 ms step).  The tensor-op form below
+serves host tensors (fixtures, synthetic data on the CPU) and documents the formulas.
 """
 import torch
 
@@ -44,6 +45,9 @@ def _so3_mat(w):
 def exp(x):
     """twist [*,6] = (w, v) -> SE(3) [*,4,4]  (se3.py:57-80)"""
     x_ = x.reshape(-1, 6)
+    if x_.is_cuda and x_.dtype == torch.float32:      # one HIP launch each way (csrc/se3.hip) instead of ~150 tensor ops
+        from . import ops
+        return ops.se3_exp(x_).view(*(x.size()[0:-1]), 4, 4)
     w, v = x_[:, 0:3], x_[:, 3:6]
     t = w.norm(p=2, dim=1).view(-1, 1, 1)
     W = _so3_mat(w)

@@ -1,4 +1,5 @@
-"""Which torch ops (not C-ABI kernels) take device time in one training step: torch.profiler table."""
+"""Which torch ops (not C-ABI kernels) take device time in one training step: torch.profiler table grouped by
+operator and input shape."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,13 +11,19 @@ dev = torch.device("cuda:0")
 cfg = Cfg(); cfg.num_points = 2048
 torch.manual_seed(0)
 model = model5_b.TouchedRegraster(cfg).to(dev)
+model.two_streams = False
 batch = synthetic.make_batch(64, 2048, dev, seed=1234)
 runner = engine.TrainStep(model, batch, cfg.lr, world=1, use_graph=False, warmup=2)
 for _ in range(2):
     runner.step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     for _ in range(2):
         runner.step()
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=60))
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::")]
+rows.sort(key=lambda e: -e.self_device_time_total)
+tot = sum(e.self_device_time_total for e in rows) / 2e3
+print("aten self device time per step: %.3f ms" % tot)
+for e in rows[:45]:
+    print("%8.3f ms  x%-4d %-28s %s" % (e.self_device_time_total / 2e3, e.count // 2, e.key, str(e.input_shapes)[:110]))
