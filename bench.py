@@ -112,6 +112,7 @@ def main():
     rank, world, local = pdist.init_from_env()
     if world != args.gpus and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    local = local % max(1, torch.cuda.device_count())     # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -24,7 +24,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
+            # "nccl" IS RCCL on ROCm.  PZN_DIST_BACKEND=gloo rehearses the multi-rank path where RCCL cannot run
+            # (several ranks sharing one GPU, CPU-only hosts).
+            backend = os.environ.get("PZN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 

@@ -61,7 +61,8 @@ class TrainStep:
                 self._fwd_bwd()
                 if i == 0:
                     self.feed.freeze()
-                self.grads.all_reduce_mean()
+                if self.world > 1:
+                    self.grads.all_reduce_mean()
                 self.opt.step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -75,13 +76,15 @@ class TrainStep:
     def step(self):
         if self.graph is None:
             self.loss = self._fwd_bwd()
-            self.grads.all_reduce_mean()
+            if self.world > 1:          # (an extra single-rank runner inside a multi-rank job must not join collectives)
+                self.grads.all_reduce_mean()
             self.opt.step()
         else:
             self.feed.refill()
             self.graph.replay()
             if not self.opt_in_graph:
-                self.grads.all_reduce_mean()
+                if self.world > 1:
+                    self.grads.all_reduce_mean()
                 self.opt.step()
         if self.sched is not None:
             self.sched.step()
