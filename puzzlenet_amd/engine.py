@@ -13,6 +13,8 @@ What makes the step capturable:
   * Adam runs with capturable=True and a device-resident learning rate.
 With more than one rank the gradient all-reduce (RCCL) and the optimizer run after the graph.
 """
+import os
+
 import torch
 
 from . import distributed as pdist
@@ -38,6 +40,8 @@ class TrainStep:
         self.loss = None
         self.feed = None
         if use_graph:
+            if os.environ.get('PZN_GRAPH_STREAMS', '1') != '0' and getattr(model, 'two_streams', False):
+                model.two_streams = 'graph'     # keep the encoder fork / join inside the captured graph
             self._capture(warmup)
 
     # -- one eager step (also the body that gets captured)

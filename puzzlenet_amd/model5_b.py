@@ -214,7 +214,8 @@ class TouchedRegraster(_Base):
         N = fpc.shape[1]
 
         plan_f, plan_m = self._sa_plans(fpc, mrpc)
-        if self.two_streams and fpc.is_cuda and not torch.cuda.is_current_stream_capturing():
+        capturing = fpc.is_cuda and torch.cuda.is_current_stream_capturing()
+        if self.two_streams and fpc.is_cuda and (not capturing or self.two_streams == "graph"):
             # The two encoders are independent (separate weights, separate clouds) and most of their launches
             # are too small to fill 256 CUs: run Encoder2 on a side HIP stream next to Encoder.  Autograd
             # replays each backward node on its forward stream, so the backward passes overlap as well.
@@ -231,9 +232,10 @@ class TouchedRegraster(_Base):
                 fmrpcs = self.Encoder2(mrpc, plan_m)                                # :716
             ffpcs = self.Encoder(fpc, plan_f)                                       # :710
             cur.wait_stream(side)
-            for t in fmrpcs:
-                if isinstance(t, torch.Tensor):
-                    t.record_stream(cur)
+            if not capturing:      # (inside a graph capture the allocator's private pool already orders re-use)
+                for t in fmrpcs:
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(cur)
         else:
             ffpcs = self.Encoder(fpc, plan_f)                                       # :710
             fmrpcs = self.Encoder2(mrpc, plan_m)                                    # :716
