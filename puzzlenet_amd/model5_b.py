@@ -279,7 +279,11 @@ class TouchedRegraster(_Base):
         else:
             d1, d2 = torch.randint(0, N, (B,), dtype=torch.long), torch.randint(0, 512, (B,), dtype=torch.long)
             d3, d4 = torch.randint(0, N, (B,), dtype=torch.long), torch.randint(0, 512, (B,), dtype=torch.long)
-            d1, d2, d3, d4 = (t.to(dev) for t in (d1, d2, d3, d4))
+            # ONE asynchronous upload from pinned memory: a pageable `.to(dev)` blocks the host until everything queued
+            # before it has run (4 of them per step drained the launch queue at every step start)
+            stage = torch.empty((4, B), dtype=torch.long, pin_memory=True)
+            torch.stack((d1, d2, d3, d4), out=stage)
+            d1, d2, d3, d4 = stage.to(dev, non_blocking=True).unbind(0)
         xyz = torch.cat([fpc, mrpc], dim=0)
         f1 = ops.farthest_point_sample(xyz, 512, torch.cat([d1, d3]))
         x1 = ops.index_points(xyz, f1)
