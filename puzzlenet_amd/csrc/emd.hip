@@ -368,6 +368,131 @@ __global__ __launch_bounds__(EMD_T) void emd_grad2_kernel(const float* __restric
   }
 }
 
+// ---- small problems (n, m <= 256: the boundary and key-point terms of the loss, 64 pairs of 128 x 128 or
+// 64 x 64 points): the whole auction of one pair in ONE workgroup, all 10 levels x 3 passes inside the
+// kernel.  Through the general path such a call is 31 launches (+ 3 zero fills) of a few microseconds
+// each; here both clouds and the per-point auction state live in LDS, a row is shared by TPR = 1024 / R
+// adjacent lanes (R = rows rounded up to a power of two) that walk interleaved parts of the other cloud,
+// and cost / gradients accumulate in registers over the levels.  Same formulas as passes A / B / C above.
+constexpr int EMD_SMALL_MAX = 256;
+
+constexpr int EMD_SMALL_T = 1024;  // 16 wavefronts per pair: the walk is a dependent VALU / exp chain per lane
+
+__global__ __launch_bounds__(EMD_SMALL_T) void emd_small_fused_kernel(const float* __restrict__ xyz1,
+                                                              const float* __restrict__ xyz2, int n, int m,
+                                                              float multiL, float multiR, int tpr_shift,
+                                                              float* __restrict__ cost, float* __restrict__ g1,
+                                                              float* __restrict__ g2) {
+  __shared__ float4 p1[EMD_SMALL_MAX];   // {x1, y1, z1, ratioL}
+  __shared__ float4 p2[EMD_SMALL_MAX];   // {x2, y2, z2, remainR}
+  __shared__ float rr[EMD_SMALL_MAX];    // ratioR
+  __shared__ float rl[EMD_SMALL_MAX];    // remainL
+  __shared__ float csum[EMD_SMALL_T / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tpr = 1 << tpr_shift, row = tid >> tpr_shift, part = tid & (tpr - 1);
+  for (int i = tid; i < n; i += EMD_SMALL_T) {
+    const float* q = xyz1 + ((size_t)b * n + i) * 3;
+    p1[i] = make_float4(q[0], q[1], q[2], 0.f);
+    rl[i] = multiL;
+  }
+  for (int i = tid; i < m; i += EMD_SMALL_T) {
+    const float* q = xyz2 + ((size_t)b * m + i) * 3;
+    p2[i] = make_float4(q[0], q[1], q[2], multiR);
+    rr[i] = 0.f;
+  }
+  __syncthreads();
+  // sum over the tpr adjacent lanes that share a row
+  auto row_sum = [&](float v) {
+    for (int o = 1; o < tpr; o <<= 1) v += __shfl_xor(v, o, PZN_WAVE);
+    return v;
+  };
+  float g1x = 0.f, g1y = 0.f, g1z = 0.f, g2x = 0.f, g2y = 0.f, g2z = 0.f, cacc = 0.f;
+  for (int j = 7; j >= -2; --j) {
+    const float level = j == -2 ? 0.f : -powf(4.0f, (float)j);
+    const float c = level * 1.44269504088896340736f;
+    {  // pass A: rows k of xyz1
+      float acc = 0.f;
+      if (row < n) {
+        const float4 me = p1[row];
+#pragma unroll 4
+        for (int l = part; l < m; l += tpr) {  // (unrolled: the loads and exps of four points are in flight together)
+          const float4 o = p2[l];
+          const float dx = o.x - me.x, dy = o.y - me.y, dz = o.z - me.z;
+          acc += __builtin_amdgcn_exp2f((dx * dx + dy * dy + dz * dz) * c) * o.w;
+        }
+      }
+      acc = row_sum(acc);
+      __syncthreads();
+      if (row < n && part == 0) p1[row].w = rl[row] / (1e-9f + acc);
+      __syncthreads();
+    }
+    {  // pass B: rows l of xyz2
+      float ar = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+      float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < m) {
+        me = p2[row];
+#pragma unroll 4
+        for (int k = part; k < n; k += tpr) {
+          const float4 o = p1[k];
+          const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
+          const float e = __builtin_amdgcn_exp2f((dx * dx + dy * dy + dz * dz) * c) * o.w;
+          ar += e, ax += e * dx, ay += e * dy, az += e * dz;
+        }
+      }
+      ar = row_sum(ar), ax = row_sum(ax), ay = row_sum(ay), az = row_sum(az);
+      __syncthreads();
+      if (row < m && part == 0) {
+        const float remainR = me.w;
+        const float sumr = ar * remainR;
+        const float ratioR = fminf(remainR / (sumr + 1e-9f), 1.0f) * remainR;
+        p2[row].w = fmaxf(0.0f, remainR - sumr);
+        rr[row] = ratioR;
+        const float s2 = 2.f * ratioR;
+        g2x += s2 * ax, g2y += s2 * ay, g2z += s2 * az;
+      }
+      __syncthreads();
+    }
+    {  // pass C: rows k of xyz1
+      float al = 0.f, ax = 0.f, ay = 0.f, az = 0.f, ac = 0.f;
+      if (row < n) {
+        const float4 me = p1[row];
+#pragma unroll 4
+        for (int l = part; l < m; l += tpr) {
+          const float4 o = p2[l];
+          const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
+          const float d = dx * dx + dy * dy + dz * dz;
+          const float wv = __builtin_amdgcn_exp2f(d * c) * me.w * rr[l];
+          al += wv, ax += wv * dx, ay += wv * dy, az += wv * dz, ac += wv * d;
+        }
+      }
+      al = row_sum(al), ax = row_sum(ax), ay = row_sum(ay), az = row_sum(az);
+      __syncthreads();
+      if (row < n && part == 0) {
+        rl[row] = fmaxf(0.0f, rl[row] - al);
+        g1x += 2.f * ax, g1y += 2.f * ay, g1z += 2.f * az;
+      }
+      cacc += ac;
+      __syncthreads();
+    }
+  }
+  if (row < n && part == 0) {
+    float* g = g1 + ((size_t)b * n + row) * 3;
+    g[0] = g1x, g[1] = g1y, g[2] = g1z;
+  }
+  if (row < m && part == 0) {
+    float* g = g2 + ((size_t)b * m + row) * 3;
+    g[0] = g2x, g[1] = g2y, g[2] = g2z;
+  }
+  cacc = pzn::wave_sum_f32(cacc);
+  if ((tid & 63) == 0) csum[tid >> 6] = cacc;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int i = 0; i < EMD_SMALL_T / 64; ++i) t += csum[i];
+    cost[b] = t;
+  }
+}
+
 template <bool MATCH, bool FUSED>
 int run_levels(const float* xyz1, const float* xyz2, int B, int n, int m, float* match, float* cost, float* g1,
                float* g2, void* workspace, hipStream_t st) {
@@ -419,6 +544,16 @@ PZN_EXPORT int pzn_emd_fused_f32(const float* xyz1, const float* xyz2, int B, in
                                  float* g2, void* workspace, pzn_stream_t stream) {
   PZN_CHECK_ARG(xyz1 && xyz2 && cost && g1 && g2 && workspace && B > 0 && n > 0 && m > 0 && B <= 65535);
   PZN_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 15) == 0);
+  if (n <= EMD_SMALL_MAX && m <= EMD_SMALL_MAX) {  // one workgroup per pair, one launch for the whole auction
+    const float multiL = n >= m ? 1.f : (float)(m / n), multiR = n >= m ? (float)(n / m) : 1.f;  // :29-35
+    int rows = 1;
+    while (rows < (n > m ? n : m)) rows <<= 1;
+    int shift = 0;
+    while ((rows << shift) < EMD_SMALL_T && shift < 6) ++shift;  // lanes sharing a row stay inside one wavefront
+    hipLaunchKernelGGL(emd_small_fused_kernel, dim3((unsigned)B), dim3(EMD_SMALL_T), 0, pzn_hip_stream(stream), xyz1, xyz2,
+                       n, m, multiL, multiR, shift, cost, g1, g2);
+    PZN_RETURN_LAUNCH_STATUS();
+  }
   return run_levels<false, true>(xyz1, xyz2, B, n, m, nullptr, cost, g1, g2, workspace, pzn_hip_stream(stream));
 }
 
