@@ -175,7 +175,7 @@ def main():
         #     achieved = algorithmic 2*M*N*K of every dense entry point / their summed launch durations.
         dense_names = ("pzn_linear_fwd_f32", "pzn_linear_dgrad_f32", "pzn_linear_wgrad_f32",
                        "pzn_sharedmlp_max_fwd_f32", "pzn_sa_mlp_max_bwd_f32", "pzn_sa_mlp_max_bwd_scatter_f32",
-                       "pzn_attn_fwd_f32", "pzn_attn_bwd_f32")
+                       "pzn_attn_fwd_f32", "pzn_attn_bwd_f32", "pzn_attn_block_fwd_f32", "pzn_attn_block_bwd_f32")
         d_ms = sum(kern.get(k, (0, 0.0))[1] for k in dense_names)
         d_fl = sum(ops.KernelTimer.flops.get(k, 0) for k in dense_names)
         d_n = sum(kern.get(k, (0, 0.0))[0] for k in dense_names)

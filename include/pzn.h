@@ -271,6 +271,26 @@ int pzn_attn_bwd_f32(const float* q, const float* k, const float* v,
                      int B, int L, int dk, int dv, float* dq, float* dk_out,
                      float* dv_out, void* workspace, pzn_stream_t stream);
 
+/* layerAttention as one unit (model5_b.py:83-101): q,k,v = Linear(x[B*L,E]); attn = softmax(q k^T /
+ * sqrt(dk)); r = x - attn v; yo = relu(r Wo^T + bo); out = x + yo.  q[B*L,dk], k, v[B*L,E], attn
+ * [B,L,L], r, yo are outputs the backward needs (attn is also the block's second result).  The
+ * backward takes dout (and d_attn or NULL), returns dx and the eight parameter gradients
+ * (overwritten, or added to when accumulate != 0).  Returns PZN_EUNSUPPORTED for shapes the
+ * weight-stationary kernel does not take: compose the block from the single entry points then. */
+int pzn_attn_block_fwd_f32(const float* x, const float* Wq, const float* bq, const float* Wk,
+                           const float* bk, const float* Wv, const float* bv, const float* Wo,
+                           const float* bo, int B, int L, int E, int dk, float* q, float* k,
+                           float* v, float* attn, float* r, float* yo, float* out,
+                           pzn_stream_t stream);
+size_t pzn_attn_block_bwd_workspace_bytes(int B, int L, int E, int dk);
+int pzn_attn_block_bwd_f32(const float* x, const float* Wq, const float* Wk, const float* Wv,
+                           const float* Wo, const float* q, const float* k, const float* v,
+                           const float* attn, const float* r, const float* yo, const float* dout,
+                           const float* d_attn, int B, int L, int E, int dk, void* workspace,
+                           float* dx, float* dWq, float* dbq, float* dWk, float* dbk, float* dWv,
+                           float* dbv, float* dWo, float* dbo, int accumulate,
+                           pzn_stream_t stream);
+
 /* torch.max(x, dim=1) over the point axis (model5_b.py:475 global feature, :741): out[b,c] =
  * max_l x[b,l,c], idx[b,c] = its row (the lowest one on ties); backward dx[b,l,c] =
  * (l == idx[b,c]) ? dout[b,c] : 0, every element of dx written (C % 4 == 0, 16-byte aligned). */

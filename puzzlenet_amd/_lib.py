@@ -50,6 +50,9 @@ SIGNATURES = {
     "pzn_knn_group_pad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_group_feat_bwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_sa_mlp_max_bwd_f32": (_c_i, [_c_f] * 7 + [_c_i] * 4 + [_c_f] * 6 + [_c_i, _c_f]),
+    "pzn_attn_block_fwd_f32": (_c_i, [_c_f] * 9 + [_c_i] * 4 + [_c_f] * 7 + [_c_f]),
+    "pzn_attn_block_bwd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i]),
+    "pzn_attn_block_bwd_f32": (_c_i, [_c_f] * 13 + [_c_i] * 4 + [_c_f] * 10 + [_c_i, _c_f]),
     "pzn_maxpool_points_fwd_f32": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_maxpool_points_bwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_se3_exp_fwd_f32": (_c_i, [_c_f, _c_i, _c_f, _c_f]),

@@ -87,6 +87,7 @@ struct GemmArgs {
   int relu;
   float alpha;
   const float* maskH;       // multiply C by (maskH[m*ldc + n] > 0)
+  const float* addend;      // EPI_STORE: C = alpha * (A B) + addend (same layout and batch stride as C)
   int32_t* argmax;          // EPI_MAXPOOL: C is out[M/32][N], argmax[M/32][N]
   float* bias_grad;         // "TN" (A k-major) only: bias_grad[m] += sum_k A(m,k), taken from the A tiles as
                             // they stream through the loader of the blockIdx.x == 0 column of workgroups
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
     A += (long)blockIdx.z * p.sA;
     B += (long)blockIdx.z * p.sB;
     C += (long)blockIdx.z * p.sC;
+    if (p.addend) p.addend += (long)blockIdx.z * p.sC;
   }
   const bool a_vec = (p.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
                      (p.gen != GEN_RELU || (reinterpret_cast<uintptr_t>(p.genY) & 15) == 0) &&
@@ -536,6 +538,15 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
         if (row >= p.M || col >= p.N) continue;
         float4 v = *reinterpret_cast<const float4*>(stg + rl * STG_LD + c4);
         const long off = (long)row * p.ldc + col;
+        if (c_vec && col + 3 < p.N && p.addend && (reinterpret_cast<uintptr_t>(p.addend) & 15) == 0) {
+          const float4 a = *reinterpret_cast<const float4*>(p.addend + off);
+          v.x += a.x, v.y += a.y, v.z += a.z, v.w += a.w;
+        } else if (p.addend) {
+          if (col < p.N) v.x += p.addend[off];
+          if (col + 1 < p.N) v.y += p.addend[off + 1];
+          if (col + 2 < p.N) v.z += p.addend[off + 2];
+          if (col + 3 < p.N) v.w += p.addend[off + 3];
+        }
         if (c_vec && col + 3 < p.N) {
           if (p.maskH) {
             float4 h = *reinterpret_cast<const float4*>(p.maskH + off);
@@ -874,6 +885,99 @@ PZN_EXPORT int pzn_attn_bwd_f32(const float* q, const float* k, const float* v, 
   rc = pzn_bgemm_f32(1, ds, k, dq, B, L, dk, L, 1.f, stream);  // dQ = dS K
   if (rc != PZN_OK) return rc;
   return pzn_bgemm_f32(2, ds, q, dk_out, B, L, dk, L, 1.f, stream);  // dK = dS^T Q
+}
+
+// ---- layerAttention as ONE unit (model5_b.py:83-101): q,k,v = Linear(x); (a, attn) = scaled_dot_production(q,k,v);
+//      r = x - a;  out = x + relu(Linear_o(r)).  The two elementwise lines ride in GEMM epilogues (r: addend of the
+//      attn*v product with alpha = -1; out: residual output of the weight-stationary kernel), and in the backward the
+//      five contributions to dx (residual, Linear_o path, q, k, v) are summed by accumulate / residual epilogues
+//      instead of one tensor add each.  Needs shapes the weight-stationary kernel takes (else PZN_EUNSUPPORTED and
+//      the caller composes the block from the single entry points).
+static bool attn_block_ok(int M, int E, int dk, const float* x) {
+  return gemm_precision() != 0 && pzn_ws_gemm_supported(M, E, E, x, E, nullptr, false) &&
+         pzn_ws_gemm_supported(M, E, dk, x, dk, nullptr, false) && pzn_ws_gemm_supported(M, dk, E, x, E, nullptr, false);
+}
+
+PZN_EXPORT int pzn_attn_block_fwd_f32(const float* x, const float* Wq, const float* bq, const float* Wk, const float* bk,
+                                      const float* Wv, const float* bv, const float* Wo, const float* bo, int B, int L,
+                                      int E, int dk, float* q, float* k, float* v, float* attn, float* r, float* yo,
+                                      float* out, pzn_stream_t stream) {
+  PZN_CHECK_ARG(x && Wq && Wk && Wv && Wo && q && k && v && attn && r && yo && out && B > 0 && L > 0 && E > 0 && dk > 0);
+  const int M = B * L;
+  if (!attn_block_ok(M, E, dk, x)) return PZN_EUNSUPPORTED;
+  hipStream_t st = pzn_hip_stream(stream);
+  int rc = pzn_linear_fwd_f32(x, Wq, bq, M, E, dk, 0, q, stream);
+  if (rc == PZN_OK) rc = pzn_linear_fwd_f32(x, Wk, bk, M, E, dk, 0, k, stream);
+  if (rc == PZN_OK) rc = pzn_linear_fwd_f32(x, Wv, bv, M, E, E, 0, v, stream);
+  if (rc == PZN_OK) rc = pzn_bgemm_f32(0, q, k, attn, B, L, L, dk, 1.f, stream);
+  if (rc != PZN_OK) return rc;
+  const long rows = (long)B * L;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, attn, rows, L,
+                     sqrtf((float)dk));
+  if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
+  {  // r = x - attn v
+    GemmArgs p = base_args(L, E, L);
+    p.A = attn, p.lda = L, p.B = v, p.ldb = E, p.C = r, p.ldc = E, p.alpha = -1.f, p.addend = x;
+    p.sA = (long)L * L, p.sB = (long)L * E, p.sC = (long)L * E;
+    launch<true, false, EPI_STORE>(p, B, st);
+    if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
+  }
+  // yo = relu(r Wo^T + bo) (kept for the backward's gate), out = x + yo
+  return pzn_ws_gemm_ex(r, E, Wo, E, 0, yo, E, M, E, E, bo, 1, nullptr, nullptr, nullptr, nullptr, 0, 0, x, out, 0, st);
+}
+
+// workspace: dd[M,E] | ds[B,L,L] | dq[M,dk] | dk[M,dk] | dv[M,E]
+PZN_EXPORT size_t pzn_attn_block_bwd_workspace_bytes(int B, int L, int E, int dk) {
+  if (B <= 0 || L <= 0 || E <= 0 || dk <= 0) return 0;
+  const size_t M = (size_t)B * L;
+  return sizeof(float) * (2 * M * E + (size_t)B * L * L + 2 * M * dk);
+}
+
+PZN_EXPORT int pzn_attn_block_bwd_f32(const float* x, const float* Wq, const float* Wk, const float* Wv, const float* Wo,
+                                      const float* q, const float* k, const float* v, const float* attn, const float* r,
+                                      const float* yo, const float* dout, const float* dattn, int B, int L, int E, int dk,
+                                      void* workspace, float* dx, float* dWq, float* dbq, float* dWk, float* dbk,
+                                      float* dWv, float* dbv, float* dWo, float* dbo, int accumulate,
+                                      pzn_stream_t stream) {
+  PZN_CHECK_ARG(x && Wq && Wk && Wv && Wo && q && k && v && attn && r && yo && dout && workspace && dx && dWq && dbq &&
+                dWk && dbk && dWv && dbv && dWo && dbo && B > 0 && L > 0 && E > 0 && dk > 0);
+  PZN_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (E & 3) == 0 && (dk & 3) == 0 && (L & 3) == 0);
+  const int M = B * L;
+  if (!attn_block_ok(M, E, dk, x)) return PZN_EUNSUPPORTED;
+  hipStream_t st = pzn_hip_stream(stream);
+  float* dd = static_cast<float*>(workspace);
+  float* ds = dd + (size_t)M * E;
+  float* dq = ds + (size_t)B * L * L;
+  float* dkk = dq + (size_t)M * dk;
+  float* dvv = dkk + (size_t)M * dk;
+  // Linear_o: dd = (dout . [yo > 0]) Wo;  dWo, dbo
+  int rc = pzn_linear_dgrad_f32(dout, yo, Wo, M, E, E, nullptr, dd, stream);
+  if (rc == PZN_OK) rc = pzn_linear_wgrad_f32(dout, yo, r, M, E, E, dWo, dbo, accumulate, stream);
+  // attention with d(values) = -dd  (r = x - a)
+  if (rc == PZN_OK) rc = pzn_bgemm_f32(2, attn, dd, dvv, B, L, E, L, -1.f, stream);   // dV = attn^T dO
+  if (rc == PZN_OK) rc = pzn_bgemm_f32(0, dd, v, ds, B, L, L, E, -1.f, stream);        // dAttn = dO V^T
+  if (rc != PZN_OK) return rc;
+  const long rows = (long)B * L;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, attn, ds, dattn, rows, L,
+                     sqrtf((float)dk));
+  if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
+  rc = pzn_bgemm_f32(1, ds, k, dq, B, L, dk, L, 1.f, stream);                           // dQ = dS K
+  if (rc == PZN_OK) rc = pzn_bgemm_f32(2, ds, q, dkk, B, L, dk, L, 1.f, stream);        // dK = dS^T Q
+  // dx = dv Wv + dd;  += dk Wk;  += dq Wq + dout   (no tensor adds)
+  if (rc == PZN_OK)
+    rc = pzn_ws_gemm_ex(dvv, E, Wv, E, 1, dx, E, M, E, E, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, dd, nullptr,
+                        0, st);
+  if (rc == PZN_OK)
+    rc = pzn_ws_gemm_ex(dkk, dk, Wk, E, 1, dx, E, M, E, dk, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr,
+                        nullptr, 1, st);
+  if (rc == PZN_OK)
+    rc = pzn_ws_gemm_ex(dq, dk, Wq, E, 1, dx, E, M, E, dk, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, dout,
+                        nullptr, 1, st);
+  // weight gradients of the three projections
+  if (rc == PZN_OK) rc = pzn_linear_wgrad_f32(dq, nullptr, x, M, E, dk, dWq, dbq, accumulate, stream);
+  if (rc == PZN_OK) rc = pzn_linear_wgrad_f32(dkk, nullptr, x, M, E, dk, dWk, dbk, accumulate, stream);
+  if (rc == PZN_OK) rc = pzn_linear_wgrad_f32(dvv, nullptr, x, M, E, E, dWv, dbv, accumulate, stream);
+  return rc;
 }
 
 // Shared MLP + max over the K = 32 neighbours (model5_b.py:452-454 / 459-461):

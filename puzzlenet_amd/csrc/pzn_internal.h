@@ -19,6 +19,13 @@ int pzn_ws_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor, 
                 const float* bias, int relu, const float* genY, const float* maskH, int32_t* argmax,
                 const int64_t* scat, int scat_in, int scat_out, hipStream_t st);
 
+// same with the extra store-epilogue options: residual != NULL adds residual(m,n) (layout of C) — into C2 when C2 != NULL
+// (C then keeps the value without it), else into C; accumulate != 0 adds to what C holds.
+int pzn_ws_gemm_ex(const float* A, int lda, const float* W, int ldw, int w_kmajor, float* C, int ldc, int M, int N, int K,
+                   const float* bias, int relu, const float* genY, const float* maskH, int32_t* argmax,
+                   const int64_t* scat, int scat_in, int scat_out, const float* residual, float* C2, int accumulate,
+                   hipStream_t st);
+
 // dfgemm.hip: weight gradient dW[N,K'] += dY^T X (+ db += column sums of dY) with MFMA fragments loaded
 // straight from global memory; genY masks dY by genY > 0; skip_col >= 0 drops that column of X from the
 // output (K' = K - 1: the zero pad of the padded group rows).  Accumulates: zero dW / db first if needed.

@@ -52,6 +52,9 @@ struct WsArgs {
   int32_t* argmax;      // max-pool epilogue: C is [M/32, N]
   const int64_t* scat;  // scatter-add epilogue: row m goes to C row (m / scat_in) * scat_out + scat[m], atomically
   int scat_in, scat_out;
+  const float* residual;  // store epilogue: + residual(m,n) (same layout as C) ...
+  float* C2;              // ... into C2 when given (C keeps the value without it), else into C itself
+  int accumulate;         // store epilogue: C(m,n) += value instead of = value
 };
 
 // two floats -> their three bf16 planes, packed (lo = first element)
@@ -265,6 +268,18 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
             if (FULL || (row < p.M && col + 3 < p.N)) {
               const size_t o = (size_t)row * p.ldc + col;
               if (p.maskH) v = relu_mask(v, *reinterpret_cast<const float4*>(p.maskH + o));
+              if (p.residual) {
+                const float4 r = *reinterpret_cast<const float4*>(p.residual + o);
+                const float4 w = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
+                if (p.C2)
+                  *reinterpret_cast<float4*>(p.C2 + o) = w;  // two outputs: C without, C2 with the residual
+                else
+                  v = w;
+              }
+              if (p.accumulate) {
+                const float4 c = *reinterpret_cast<const float4*>(p.C + o);
+                v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
+              }
               *reinterpret_cast<float4*>(p.C + o) = v;
             }
           }
@@ -368,15 +383,25 @@ bool pzn_ws_gemm_supported(int M, int N, int K, const float* A, int lda, const f
   return pick_nt(N, (K + 31) / 32, maxpool) != 0;
 }
 
+int pzn_ws_gemm_ex(const float* A, int lda, const float* W, int ldw, int w_kmajor, float* C, int ldc, int M, int N, int K,
+                   const float* bias, int relu, const float* genY, const float* maskH, int32_t* argmax,
+                   const int64_t* scat, int scat_in, int scat_out, const float* residual, float* C2, int accumulate,
+                   hipStream_t st) {
+  WsArgs p{A, lda, W, ldw, w_kmajor, C, ldc, M, N, K, (K + 31) / 32, bias, relu, genY, maskH, argmax, scat, scat_in, scat_out,
+           residual, C2, accumulate};
+  const int nt = pick_nt(N, p.nd, argmax != nullptr);
+  if (!nt) return PZN_EUNSUPPORTED;
+  if (argmax) return (genY || scat || residual || accumulate) ? PZN_EUNSUPPORTED : launch_mg<true, false>(p, nt, st);
+  if ((ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15) || (reinterpret_cast<uintptr_t>(maskH) & 15) ||
+      (reinterpret_cast<uintptr_t>(bias) & 15) || (reinterpret_cast<uintptr_t>(residual) & 15) ||
+      (reinterpret_cast<uintptr_t>(C2) & 15))
+    return PZN_EUNSUPPORTED;
+  return genY ? launch_mg<false, true>(p, nt, st) : launch_mg<false, false>(p, nt, st);
+}
+
 int pzn_ws_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor, float* C, int ldc, int M, int N, int K,
                 const float* bias, int relu, const float* genY, const float* maskH, int32_t* argmax,
                 const int64_t* scat, int scat_in, int scat_out, hipStream_t st) {
-  WsArgs p{A, lda, W, ldw, w_kmajor, C, ldc, M, N, K, (K + 31) / 32, bias, relu, genY, maskH, argmax, scat, scat_in, scat_out};
-  const int nt = pick_nt(N, p.nd, argmax != nullptr);
-  if (!nt) return PZN_EUNSUPPORTED;
-  if (argmax) return (genY || scat) ? PZN_EUNSUPPORTED : launch_mg<true, false>(p, nt, st);
-  if ((ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15) || (reinterpret_cast<uintptr_t>(maskH) & 15) ||
-      (reinterpret_cast<uintptr_t>(bias) & 15))
-    return PZN_EUNSUPPORTED;
-  return genY ? launch_mg<false, true>(p, nt, st) : launch_mg<false, false>(p, nt, st);
+  return pzn_ws_gemm_ex(A, lda, W, ldw, w_kmajor, C, ldc, M, N, K, bias, relu, genY, maskH, argmax, scat, scat_in, scat_out,
+                        nullptr, nullptr, 0, st);
 }

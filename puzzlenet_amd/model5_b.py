@@ -65,6 +65,11 @@ class layerAttention(nn.Module):
         self.out = nn.Linear(embed_dim, embed_dim)
 
     def forward(self, xyz):
+        if ops.attention_block_supported(xyz, self.mlpq.weight.shape[0]):
+            # the whole block behind one entry point each way: x - a and x + relu(.) ride in GEMM epilogues, the five
+            # gradient contributions to x are summed by accumulate epilogues (csrc/gemm.hip pzn_attn_block_*)
+            return ops.attention_block(xyz, self.mlpq.weight, self.mlpq.bias, self.mlpk.weight, self.mlpk.bias,
+                                       self.mlpv.weight, self.mlpv.bias, self.out.weight, self.out.bias)
         q = dense.linear(xyz, self.mlpq.weight, self.mlpq.bias)
         k = dense.linear(xyz, self.mlpk.weight, self.mlpk.bias)
         v = dense.linear(xyz, self.mlpv.weight, self.mlpv.bias)

@@ -527,6 +527,7 @@ class _Attention(torch.autograd.Function):
             _call("pzn_attn_fwd_f32", _p(q), _p(k), _p(v), B, L, dk, dv, _p(attn), _p(out), _stream(),
                   flops=2 * B * L * L * (dk + dv))
         ctx.save_for_backward(q, k, v, attn)
+        ctx.set_materialize_grads(False)
         return out, attn
 
     @staticmethod
@@ -547,6 +548,70 @@ class _Attention(torch.autograd.Function):
 
 def attention(q, k, v):
     return _Attention.apply(q, k, v)
+
+
+class _AttentionBlock(torch.autograd.Function):
+    """layerAttention as one unit (model5_b.py:83-101) -> (r, attention): the residual / offset lines ride in GEMM
+    epilogues forward, and the five contributions to dx are summed by accumulate epilogues backward."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo):
+        x = _f32(x, "x")
+        ws_ = [_f32(t, "param") for t in (wq, bq, wk, bk, wv, bv, wo, bo)]
+        wq, bq, wk, bk, wv, bv, wo, bo = ws_
+        B, L, E = x.shape
+        dk = wq.shape[0]
+        dev = x.device
+        M = B * L
+        mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        q, k, v = mk(M, dk), mk(M, dk), mk(M, E)
+        attn, r, yo, out = mk(B, L, L), mk(M, E), mk(M, E), mk(M, E)
+        with torch.cuda.device(dev):
+            _call("pzn_attn_block_fwd_f32", _p(x), _p(wq), _p(bq), _p(wk), _p(bk), _p(wv), _p(bv), _p(wo), _p(bo),
+                  B, L, E, dk, _p(q), _p(k), _p(v), _p(attn), _p(r), _p(yo), _p(out), _stream(),
+                  flops=2 * M * E * (2 * dk + 2 * E) + 2 * B * L * L * (dk + E))
+        ctx.save_for_backward(x, wq, wk, wv, wo, q, k, v, attn, r, yo)
+        ctx.set_materialize_grads(False)       # an unused attention map must not cost a zero-filled [B,L,L] gradient
+        ctx.dims = (B, L, E, dk)
+        ctx.param_refs = (wq, bq, wk, bk, wv, bv, wo, bo)
+        return out.view(B, L, E), attn
+
+    @staticmethod
+    def backward(ctx, dout, dattn):
+        x, wq, wk, wv, wo, q, k, v, attn, r, yo = ctx.saved_tensors
+        B, L, E, dk = ctx.dims
+        dev = x.device
+        M = B * L
+        dout = torch.zeros((M, E), dtype=torch.float32, device=dev) if dout is None else _f32(dout, "dout").reshape(M, E)
+        dattn = None if dattn is None else _f32(dattn, "dattn")
+        sinks = [_sink(t, ctx.needs_input_grad[1 + i]) for i, t in enumerate(ctx.param_refs)]
+        direct = all(s_ is not None for s_ in sinks)
+        if direct:
+            grads = sinks
+        else:
+            grads = [torch.empty_like(t) for t in ctx.param_refs]
+        dx = torch.empty((M, E), dtype=torch.float32, device=dev)
+        nbytes = _lib.load().pzn_attn_block_bwd_workspace_bytes(B, L, E, dk)
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+        gq, gbq, gk, gbk, gv, gbv, go, gbo = grads
+        with torch.cuda.device(dev):
+            _call("pzn_attn_block_bwd_f32", _p(x), _p(wq), _p(wk), _p(wv), _p(wo), _p(q), _p(k), _p(v), _p(attn), _p(r),
+                  _p(yo), _p(dout), _p(dattn), B, L, E, dk, _p(ws), _p(dx), _p(gq), _p(gbq), _p(gk), _p(gbk), _p(gv),
+                  _p(gbv), _p(go), _p(gbo), int(direct), _stream(),
+                  flops=2 * (2 * M * E * (2 * dk + 2 * E)) + 2 * B * L * L * (2 * dk + 2 * E))
+        if direct:
+            return (dx.view(B, L, E),) + (None,) * 8
+        return (dx.view(B, L, E),) + tuple(grads)
+
+
+def attention_block_supported(x, dk):
+    """Shapes the fused block takes (the weight-stationary kernel's domain): else compose it from linear + attention."""
+    return x.is_cuda and x.dim() == 3 and x.shape[0] * x.shape[1] >= 4096 and x.shape[2] % 32 == 0 and dk % 32 == 0 \
+        and x.shape[1] % 4 == 0 and _lib.load().pzn_gemm_get_precision() != 0
+
+
+def attention_block(x, wq, bq, wk, bk, wv, bv, wo, bo):
+    return _AttentionBlock.apply(x, wq, bq, wk, bk, wv, bv, wo, bo)
 
 
 class _SaMlpMax(torch.autograd.Function):

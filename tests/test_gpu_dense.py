@@ -212,3 +212,46 @@ def test_sa_mlp_max_fused_vs_composed(dev, precision, B, N, S, D, C1, C2):
         assert torch.equal(y2, y)
         (y2 * go.to(dev)).sum().backward()
         assert _rel(f2.grad, featr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("sinks", [False, True])
+def test_attention_block_fused_vs_composed(dev, sinks):
+    """pzn_attn_block_* (layerAttention behind one entry point each way, residual / offset lines and the dx sums
+    in GEMM epilogues) against the block composed from linear + attention + tensor ops, outputs and every
+    gradient, also with the attention map receiving a gradient and with the parameter gradients going straight
+    into registered sinks (accumulate epilogues)."""
+    from puzzlenet_amd import dense, ops
+    B, L, E, dk = 20, 256, 256, 64            # 5120 rows: inside the weight-stationary kernel's domain
+    g = torch.Generator().manual_seed(3)
+    x0 = (0.5 * torch.randn(B, L, E, generator=g)).to(dev)
+    shapes = [(dk, E), (dk,), (dk, E), (dk,), (E, E), (E,), (E, E), (E,)]
+    params0 = [(torch.randn(*s, generator=g) / (math.sqrt(E) if len(s) == 2 else 4)).to(dev) for s in shapes]
+    wr, wa = torch.randn(B, L, E, generator=g).to(dev), torch.randn(B, L, L, generator=g).to(dev)
+
+    def run(fused):
+        x = x0.clone().requires_grad_(True)
+        ps = [p.clone().requires_grad_(True) for p in params0]
+        ops.clear_grad_sinks()
+        if sinks:
+            for p in ps:
+                p.grad = torch.full_like(p, 0.25)          # pre-existing content: the kernels must ADD to it
+            ops.register_grad_sinks(ps)
+        assert ops.attention_block_supported(x, dk)
+        if fused:
+            r, a = ops.attention_block(x, *ps)
+        else:
+            wq, bq, wk, bk, wv, bv, wo, bo = ps
+            q, k, v = dense.linear(x, wq, bq), dense.linear(x, wk, bk), dense.linear(x, wv, bv)
+            t, a = ops.attention(q, k, v)
+            r = x + dense.linear(x - t, wo, bo, relu=True)
+        ((r * wr).sum() + (a * wa).sum()).backward()
+        ops.clear_grad_sinks()
+        return r.detach(), a.detach(), x.grad, [p.grad for p in ps]
+
+    rf, af, gxf, gpf = run(True)
+    rc, ac, gxc, gpc = run(False)
+    assert _rel(rf, rc) < 1e-5 and _rel(af, ac) < 1e-5
+    assert _rel(gxf, gxc) < 1e-4
+    for a_, b_ in zip(gpf, gpc):
+        # (the key bias has a mathematically zero gradient — softmax is shift-invariant — so it gets an absolute floor)
+        assert float((a_ - b_).abs().max()) < 2e-4 * max(float(b_.abs().max()), 5e-2)
