@@ -49,6 +49,13 @@ struct DfArgs {
   int types_per_wg;   // wave types handled by one workgroup (blockIdx.y selects the group)
   int reps;           // replicas per type in a workgroup
   int steps_per_wg;   // 16-row steps per workgroup
+  // up to three dY / dW / db triples that share X (the q, k, v projections of an attention block): the N axis is
+  // the concatenation of the segments (each a multiple of 64 columns), one launch instead of three
+  int nseg;
+  const float* sdy[3];
+  int sn[3];
+  float* sdw[3];
+  float* sdb[3];
 };
 
 __device__ __forceinline__ void split_pair(v2f x, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
@@ -86,7 +93,19 @@ __global__ __launch_bounds__(768) void df_wgrad_kernel(DfArgs p) {
   const int tl = wave / p.reps, rep = wave - tl * p.reps;
   const int type = blockIdx.y * p.types_per_wg + tl;
   const int ti = type / p.types_k, tj = type - ti * p.types_k;
-  const int n0 = ti * (TI * 32), k0 = tj * (TJ * 32);
+  int n0 = ti * (TI * 32);
+  const int k0 = tj * (TJ * 32);
+  if (p.nseg) {  // wave-uniform choice of the segment this tile block belongs to
+    const int e0 = p.sn[0], e1 = e0 + p.sn[1];
+    const int sg = n0 < e0 ? 0 : (n0 < e1 ? 1 : 2);
+    n0 -= sg == 0 ? 0 : (sg == 1 ? e0 : e1);
+    p.dy = sg == 0 ? p.sdy[0] : (sg == 1 ? p.sdy[1] : p.sdy[2]);
+    p.N = sg == 0 ? p.sn[0] : (sg == 1 ? p.sn[1] : p.sn[2]);
+    p.ldy = p.N;
+    p.dW = sg == 0 ? p.sdw[0] : (sg == 1 ? p.sdw[1] : p.sdw[2]);
+    p.db = sg == 0 ? p.sdb[0] : (sg == 1 ? p.sdb[1] : p.sdb[2]);
+    if (sg >= p.nseg) n0 = p.N;  // padding type
+  }
   const bool active = n0 < p.N;  // false: padding type of the last group
 
   // This lane's columns.  Columns past N / K are clamped for the loads and NOT zeroed: they only feed output
@@ -217,8 +236,13 @@ int launch_ij(DfArgs p, hipStream_t st) {
   const int groups = (types + cap - 1) / cap;
   p.types_per_wg = (types + groups - 1) / groups;
   p.reps = MAXW / p.types_per_wg;
+  if (p.types_per_wg <= 2 && p.reps > 2 * p.types_per_wg) p.reps = p.types_per_wg == 1 ? 2 : 3;  // few, long-running waves:
+  // every wave ends with TI*TJ*4 KB of atomics, and with one or two tile blocks those dominated (131072 x 64 x 64: 69 -> 47 us)
+  static const int reps_cap = [] { const char* e = getenv("PZN_DF_REPS"); return e ? atoi(e) : 0; }();  // tuning aid
+  if (reps_cap > 0 && p.reps > reps_cap) p.reps = reps_cap;
   int wgs = 256;
-  const int max_by_steps = nsteps / (8 * p.reps);
+  static const int min_steps = [] { const char* e = getenv("PZN_DF_MINSTEPS"); return e ? atoi(e) : 8; }();  // tuning aid
+  const int max_by_steps = nsteps / (min_steps * p.reps);
   if (wgs > max_by_steps) wgs = max_by_steps;
   if (forced) wgs = forced;
   if (wgs < 1) wgs = 1;
@@ -254,10 +278,23 @@ bool pzn_df_wgrad_supported(int M, int N, int K) {
 
 int pzn_df_wgrad(const float* dy, int ldy, const float* genY, const float* x, int ldx, int M, int N, int K, float* dW,
                  int ldw, float* db, int skip_col, hipStream_t st) {
-  DfArgs p{dy, ldy, genY, x, ldx, dW, ldw, db, M, N, K, skip_col, 0, 0, 0, 0};
+  DfArgs p{dy, ldy, genY, x, ldx, dW, ldw, db, M, N, K, skip_col, 0, 0, 0, 0, 0, {nullptr, nullptr, nullptr}, {0, 0, 0},
+           {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   const int tn = (N + 31) / 32, tk = (K + 31) / 32;
   if (tn >= 2 && tk >= 2) return launch_ij<2, 2>(p, st);
   if (tn >= 2) return launch_ij<2, 1>(p, st);
   if (tk >= 2) return launch_ij<1, 2>(p, st);
   return launch_ij<1, 1>(p, st);
+}
+
+// Three weight gradients that share X in one launch (the q, k, v projections): dW_i[N_i, K] += dY_i^T X,
+// db_i += column sums; every N_i a multiple of 64, dY_i dense [M, N_i].
+int pzn_df_wgrad3(const float* const dy[3], const int n[3], float* const dW[3], float* const db[3], const float* x, int ldx,
+                  int M, int K, hipStream_t st) {
+  if (!pzn_df_wgrad_supported(M, n[0] + n[1] + n[2], K) || (n[0] & 63) || (n[1] & 63) || (n[2] & 63) || !db[0] || !db[1] ||
+      !db[2])
+    return PZN_EUNSUPPORTED;
+  DfArgs p{dy[0], n[0], nullptr, x, ldx, dW[0], K, db[0], M, n[0] + n[1] + n[2], K, -1, 0, 0, 0, 0, 3,
+           {dy[0], dy[1], dy[2]}, {n[0], n[1], n[2]}, {dW[0], dW[1], dW[2]}, {db[0], db[1], db[2]}};
+  return (K + 31) / 32 >= 2 ? launch_ij<2, 2>(p, st) : launch_ij<2, 1>(p, st);
 }

@@ -973,10 +973,25 @@ PZN_EXPORT int pzn_attn_block_bwd_f32(const float* x, const float* Wq, const flo
   if (rc == PZN_OK)
     rc = pzn_ws_gemm_ex(dq, dk, Wq, E, 1, dx, E, M, E, dk, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, dout,
                         nullptr, 1, st);
-  // weight gradients of the three projections
-  if (rc == PZN_OK) rc = pzn_linear_wgrad_f32(dq, nullptr, x, M, E, dk, dWq, dbq, accumulate, stream);
-  if (rc == PZN_OK) rc = pzn_linear_wgrad_f32(dkk, nullptr, x, M, E, dk, dWk, dbk, accumulate, stream);
-  if (rc == PZN_OK) rc = pzn_linear_wgrad_f32(dvv, nullptr, x, M, E, E, dWv, dbv, accumulate, stream);
+  if (rc != PZN_OK) return rc;
+  // weight gradients of the three projections: they share x, so one launch over the concatenated N axis
+  {
+    const float* const dys[3] = {dq, dkk, dvv};
+    const int ns[3] = {dk, dk, E};
+    float* const dWs[3] = {dWq, dWk, dWv};
+    float* const dbs[3] = {dbq, dbk, dbv};
+    if (!accumulate) {
+      for (int i = 0; i < 3; ++i) {
+        if (pzn_zero_async(dWs[i], (size_t)ns[i] * E, st) != PZN_OK) return PZN_ELAUNCH;
+        if (pzn_zero_async(dbs[i], (size_t)ns[i], st) != PZN_OK) return PZN_ELAUNCH;
+      }
+    }
+    rc = pzn_df_wgrad3(dys, ns, dWs, dbs, x, E, M, E, st);
+    if (rc != PZN_EUNSUPPORTED) return rc;
+  }
+  rc = pzn_linear_wgrad_f32(dq, nullptr, x, M, E, dk, dWq, dbq, 1, stream);   // (already zeroed when not accumulating)
+  if (rc == PZN_OK) rc = pzn_linear_wgrad_f32(dkk, nullptr, x, M, E, dk, dWk, dbk, 1, stream);
+  if (rc == PZN_OK) rc = pzn_linear_wgrad_f32(dvv, nullptr, x, M, E, E, dWv, dbv, 1, stream);
   return rc;
 }
 

@@ -32,3 +32,6 @@ int pzn_ws_gemm_ex(const float* A, int lda, const float* W, int ldw, int w_kmajo
 bool pzn_df_wgrad_supported(int M, int N, int K);
 int pzn_df_wgrad(const float* dy, int ldy, const float* genY, const float* x, int ldx, int M, int N, int K, float* dW,
                  int ldw, float* db, int skip_col, hipStream_t st);
+// three weight gradients sharing X in one launch: dW_i[N_i,K] += dY_i^T X, db_i += sums; N_i % 64 == 0, dY_i dense
+int pzn_df_wgrad3(const float* const dy[3], const int n[3], float* const dW[3], float* const db[3], const float* x, int ldx,
+                  int M, int K, hipStream_t st);
