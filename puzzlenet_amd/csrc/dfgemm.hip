@@ -236,8 +236,8 @@ int launch_ij(DfArgs p, hipStream_t st) {
   const int groups = (types + cap - 1) / cap;
   p.types_per_wg = (types + groups - 1) / groups;
   p.reps = MAXW / p.types_per_wg;
-  if (p.types_per_wg <= 2 && p.reps > 2 * p.types_per_wg) p.reps = p.types_per_wg == 1 ? 2 : 3;  // few, long-running waves:
-  // every wave ends with TI*TJ*4 KB of atomics, and with one or two tile blocks those dominated (131072 x 64 x 64: 69 -> 47 us)
+  if (p.reps > 2) p.reps = 2;  // measured: 2 replicas beat 3 / 6 / 12 (every wave ends with TI*TJ*4 KB of atomics, and
+  // 8 resident waves stream as well as 12): 131072 x 64 x 64 69 -> 47 us, 1M x 128 x 128 0.45 -> 0.33 ms
   static const int reps_cap = [] { const char* e = getenv("PZN_DF_REPS"); return e ? atoi(e) : 0; }();  // tuning aid
   if (reps_cap > 0 && p.reps > reps_cap) p.reps = reps_cap;
   int wgs = 256;
