@@ -324,12 +324,12 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
 #undef WS_BLOAD
 }
 
-size_t stage_bytes(bool) { return (size_t)WS_NW * 32 * WS_STAGE_LD * sizeof(float); }  // every wave's 32 x 32 patch
+size_t stage_bytes(bool, int nw = WS_NW) { return (size_t)nw * 32 * WS_STAGE_LD * sizeof(float); }  // every wave's 32 x 32 patch
 
-template <int NT, bool MAXPOOL, bool GENY, bool FULL, bool D2>
-int launch_nt_f(const WsArgs& p, hipStream_t st) {
-  auto kern = ws_gemm_kernel<NT, MAXPOOL, GENY, WS_NW, FULL, D2>;
-  const size_t lds = (size_t)p.nd * 2 * NT * 3 * 1024 + stage_bytes(MAXPOOL);
+template <int NT, bool MAXPOOL, bool GENY, bool FULL, bool D2, int NW>
+int launch_nt_fw(const WsArgs& p, hipStream_t st) {
+  auto kern = ws_gemm_kernel<NT, MAXPOOL, GENY, NW, FULL, D2>;
+  const size_t lds = (size_t)p.nd * 2 * NT * 3 * 1024 + stage_bytes(MAXPOOL, NW);
   if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PZN_ELAUNCH;
@@ -337,10 +337,18 @@ int launch_nt_f(const WsArgs& p, hipStream_t st) {
   const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
   int gx = (256 * per_cu) / nslices;
   gx = gx < 8 ? 8 : (gx / 8) * 8;  // multiple of 8: the slices of one row range land on one XCD (shared L2)
-  const int ntiles = (p.M + 31) / 32, need = (ntiles + WS_NW - 1) / WS_NW;
+  const int ntiles = (p.M + 31) / 32, need = (ntiles + NW - 1) / NW;
   if (gx > need) gx = need;
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nslices), dim3(WS_NW * 64), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nslices), dim3(NW * 64), lds, st, p);
   PZN_RETURN_LAUNCH_STATUS();
+}
+
+// 12 wavefronts per workgroup for the long streams; 8 when there are fewer row tiles than 12 x 256 (more workgroups,
+// i.e. more CUs busy: 16384 x 256 x 256 runs 29 -> 25 us forward, 27 -> 20 us input gradient)
+template <int NT, bool MAXPOOL, bool GENY, bool FULL, bool D2>
+int launch_nt_f(const WsArgs& p, hipStream_t st) {
+  return (p.M + 31) / 32 < 12 * 256 ? launch_nt_fw<NT, MAXPOOL, GENY, FULL, D2, 8>(p, st)
+                                     : launch_nt_fw<NT, MAXPOOL, GENY, FULL, D2, 12>(p, st);
 }
 
 template <int NT, bool MAXPOOL, bool GENY>
