@@ -906,9 +906,19 @@ PZN_EXPORT int pzn_attn_block_fwd_f32(const float* x, const float* Wq, const flo
   const int M = B * L;
   if (!attn_block_ok(M, E, dk, x)) return PZN_EUNSUPPORTED;
   hipStream_t st = pzn_hip_stream(stream);
-  int rc = pzn_linear_fwd_f32(x, Wq, bq, M, E, dk, 0, q, stream);
-  if (rc == PZN_OK) rc = pzn_linear_fwd_f32(x, Wk, bk, M, E, dk, 0, k, stream);
-  if (rc == PZN_OK) rc = pzn_linear_fwd_f32(x, Wv, bv, M, E, E, 0, v, stream);
+  int rc = PZN_EUNSUPPORTED;
+  if (bq && bk && bv) {  // the three projections share x: one launch over the concatenated column slices
+    const float* const Ws[3] = {Wq, Wk, Wv};
+    const float* const bs[3] = {bq, bk, bv};
+    float* const Cs[3] = {q, k, v};
+    const int Ns[3] = {dk, dk, E};
+    rc = pzn_ws_gemm3(x, E, Ws, bs, Cs, Ns, M, E, st);
+  }
+  if (rc == PZN_EUNSUPPORTED) {
+    rc = pzn_linear_fwd_f32(x, Wq, bq, M, E, dk, 0, q, stream);
+    if (rc == PZN_OK) rc = pzn_linear_fwd_f32(x, Wk, bk, M, E, dk, 0, k, stream);
+    if (rc == PZN_OK) rc = pzn_linear_fwd_f32(x, Wv, bv, M, E, E, 0, v, stream);
+  }
   if (rc == PZN_OK) rc = pzn_bgemm_f32(0, q, k, attn, B, L, L, dk, 1.f, stream);
   if (rc != PZN_OK) return rc;
   const long rows = (long)B * L;

@@ -35,3 +35,6 @@ int pzn_df_wgrad(const float* dy, int ldy, const float* genY, const float* x, in
 // three weight gradients sharing X in one launch: dW_i[N_i,K] += dY_i^T X, db_i += sums; N_i % 64 == 0, dY_i dense
 int pzn_df_wgrad3(const float* const dy[3], const int n[3], float* const dW[3], float* const db[3], const float* x, int ldx,
                   int M, int K, hipStream_t st);
+// three linear layers sharing their input in one launch: C_i[M,N_i] = A W_i^T + b_i (N_i % 64 == 0, dense C_i)
+int pzn_ws_gemm3(const float* A, int lda, const float* const W[3], const float* const bias[3], float* const C[3],
+                 const int N[3], int M, int K, hipStream_t st);

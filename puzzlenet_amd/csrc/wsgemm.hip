@@ -55,6 +55,13 @@ struct WsArgs {
   const float* residual;  // store epilogue: + residual(m,n) (same layout as C) ...
   float* C2;              // ... into C2 when given (C keeps the value without it), else into C itself
   int accumulate;         // store epilogue: C(m,n) += value instead of = value
+  // up to three (W, bias, C) triples that share A (the q, k, v projections of an attention block): blockIdx.y runs
+  // over the column slices of all of them, one launch instead of three
+  int nseg;
+  const float* sW[3];
+  const float* sbias[3];
+  float* sC[3];
+  int sN[3];
 };
 
 // two floats -> their three bf16 planes, packed (lo = first element)
@@ -98,7 +105,18 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: tile offsets must be provably uniform
   const int l31 = lane & 31, half = lane >> 5;
-  const int n0 = blockIdx.y * (NT * 32);
+  int slice = blockIdx.y;
+  if (p.nseg) {  // workgroup-uniform choice of the segment this column slice belongs to
+    const int c0 = (p.sN[0] + NT * 32 - 1) / (NT * 32), c1 = c0 + (p.sN[1] + NT * 32 - 1) / (NT * 32);
+    const int sg = slice < c0 ? 0 : (slice < c1 ? 1 : 2);
+    slice -= sg == 0 ? 0 : (sg == 1 ? c0 : c1);
+    p.W = sg == 0 ? p.sW[0] : (sg == 1 ? p.sW[1] : p.sW[2]);
+    p.bias = sg == 0 ? p.sbias[0] : (sg == 1 ? p.sbias[1] : p.sbias[2]);
+    p.C = sg == 0 ? p.sC[0] : (sg == 1 ? p.sC[1] : p.sC[2]);
+    p.N = sg == 0 ? p.sN[0] : (sg == 1 ? p.sN[1] : p.sN[2]);
+    p.ldc = p.N;
+  }
+  const int n0 = slice * (NT * 32);
 
   // ---- prologue: this slice of W -> three bf16 planes in fragment order (k permuted: lane half h of
   //      double step d holds k = 32d + 16h + 8s + 0..7 in MFMA step s)
@@ -396,7 +414,8 @@ int pzn_ws_gemm_ex(const float* A, int lda, const float* W, int ldw, int w_kmajo
                    const int64_t* scat, int scat_in, int scat_out, const float* residual, float* C2, int accumulate,
                    hipStream_t st) {
   WsArgs p{A, lda, W, ldw, w_kmajor, C, ldc, M, N, K, (K + 31) / 32, bias, relu, genY, maskH, argmax, scat, scat_in, scat_out,
-           residual, C2, accumulate};
+           residual, C2, accumulate, 0, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr},
+           {0, 0, 0}};
   const int nt = pick_nt(N, p.nd, argmax != nullptr);
   if (!nt) return PZN_EUNSUPPORTED;
   if (argmax) return (genY || scat || residual || accumulate) ? PZN_EUNSUPPORTED : launch_mg<true, false>(p, nt, st);
@@ -412,4 +431,18 @@ int pzn_ws_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor, 
                 const int64_t* scat, int scat_in, int scat_out, hipStream_t st) {
   return pzn_ws_gemm_ex(A, lda, W, ldw, w_kmajor, C, ldc, M, N, K, bias, relu, genY, maskH, argmax, scat, scat_in, scat_out,
                         nullptr, nullptr, 0, st);
+}
+
+// Three linear layers that share their input in one launch (the q, k, v projections): C_i[M, N_i] = A W_i^T + b_i,
+// W_i[N_i, K] row-major, C_i dense; every N_i a multiple of 64 and 16-byte aligned pointers.
+int pzn_ws_gemm3(const float* A, int lda, const float* const W[3], const float* const bias[3], float* const C[3],
+                 const int N[3], int M, int K, hipStream_t st) {
+  const int ntot = N[0] + N[1] + N[2];
+  if (!pzn_ws_gemm_supported(M, 64, K, A, lda, nullptr, false) || (N[0] & 63) || (N[1] & 63) || (N[2] & 63)) return PZN_EUNSUPPORTED;
+  for (int i = 0; i < 3; ++i)
+    if ((reinterpret_cast<uintptr_t>(C[i]) & 15) || (reinterpret_cast<uintptr_t>(bias[i]) & 15)) return PZN_EUNSUPPORTED;
+  WsArgs p{A, lda, W[0], K, 0, C[0], N[0], M, ntot, K, (K + 31) / 32, bias[0], 0, nullptr, nullptr, nullptr, nullptr, 0, 0,
+           nullptr, nullptr, 0, 3, {W[0], W[1], W[2]}, {bias[0], bias[1], bias[2]}, {C[0], C[1], C[2]}, {N[0], N[1], N[2]}};
+  if (pick_nt(64, p.nd, false) < 2) return PZN_EUNSUPPORTED;
+  return launch_nt<2, false, false>(p, st);  // 64-column slices: q and k are one slice each
 }
