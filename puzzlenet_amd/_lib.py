@@ -73,6 +73,11 @@ class PznError(RuntimeError):
     pass
 
 
+class PznUnsupported(PznError):
+    """status PZN_EUNSUPPORTED (-3): the entry point does not take this shape / alignment; composed entry points
+    document the alternative path."""
+
+
 def load():
     """Load libpzn.so (raises if it has not been built)."""
     global _lib
@@ -97,7 +102,7 @@ def load():
 def check(status, what):
     if status != 0:
         msg = load().pzn_strerror(status).decode()
-        raise PznError(f"{what} failed: {msg} (status {status})")
+        raise (PznUnsupported if status == -3 else PznError)(f"{what} failed: {msg} (status {status})")
 
 
 def call(name, *args):

@@ -26,7 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import dense, metrics, ops, se3
+from . import _lib, dense, metrics, ops, se3
 from . import pointnet_util as pu
 from .PyTorchEMD.emd import earth_mover_distance
 
@@ -68,8 +68,11 @@ class layerAttention(nn.Module):
         if ops.attention_block_supported(xyz, self.mlpq.weight.shape[0]):
             # the whole block behind one entry point each way: x - a and x + relu(.) ride in GEMM epilogues, the five
             # gradient contributions to x are summed by accumulate epilogues (csrc/gemm.hip pzn_attn_block_*)
-            return ops.attention_block(xyz, self.mlpq.weight, self.mlpq.bias, self.mlpk.weight, self.mlpk.bias,
-                                       self.mlpv.weight, self.mlpv.bias, self.out.weight, self.out.bias)
+            try:
+                return ops.attention_block(xyz, self.mlpq.weight, self.mlpq.bias, self.mlpk.weight, self.mlpk.bias,
+                                           self.mlpv.weight, self.mlpv.bias, self.out.weight, self.out.bias)
+            except _lib.PznUnsupported:      # a shape / alignment the fused block does not take: compose it below
+                pass
         q = dense.linear(xyz, self.mlpq.weight, self.mlpq.bias)
         k = dense.linear(xyz, self.mlpk.weight, self.mlpk.bias)
         v = dense.linear(xyz, self.mlpv.weight, self.mlpv.bias)
