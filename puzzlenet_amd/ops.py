@@ -4,6 +4,8 @@ torch is used for device memory, the current HIP stream and autograd plumbing
 only: every computation below is a call into libpzn.so with raw device
 pointers.  Inputs must live on a HIP device; there is no CPU path.
 """
+import weakref
+
 import torch
 
 from . import _lib
@@ -395,13 +397,13 @@ def chamfer(a, b):
 # input: no zero-fill launch, no temporary dW, no separate AccumulateGrad "grad += dW" kernel
 # (~280 small launches per training step).  distributed.FlatGradAllReduce registers the views of its flat
 # bucket; without sinks the Functions return ordinary gradient tensors.
-_GRAD_SINKS = {}
+_GRAD_SINKS = {}      # parameter address -> (weak reference to the parameter, its gradient buffer)
 
 
 def register_grad_sinks(params):
     for p_ in params:
         if p_.grad is not None:
-            _GRAD_SINKS[p_.data_ptr()] = p_.grad
+            _GRAD_SINKS[p_.data_ptr()] = (weakref.ref(p_), p_.grad)
 
 
 def clear_grad_sinks():
@@ -409,7 +411,20 @@ def clear_grad_sinks():
 
 
 def _sink(t, needed):
-    return _GRAD_SINKS.get(t.data_ptr()) if (needed and t is not None) else None
+    """The registered gradient buffer of parameter tensor `t`, or None.  An entry only counts while its parameter is
+    alive, still sits at that address and has this shape (a freed parameter's address is re-used by the allocator:
+    a stale entry must never capture the gradient of an unrelated tensor)."""
+    if not needed or t is None:
+        return None
+    ent = _GRAD_SINKS.get(t.data_ptr())
+    if ent is None:
+        return None
+    owner, grad = ent
+    o = owner()
+    if o is None or o.data_ptr() != t.data_ptr() or o.shape != t.shape or o.grad is not grad:
+        _GRAD_SINKS.pop(t.data_ptr(), None)
+        return None
+    return grad
 
 class _Linear(torch.autograd.Function):
     """nn.Linear (+ReLU) on the fp32 matrix-core engine: y = act(x W^T + b)."""
