@@ -271,7 +271,7 @@ bool df_enabled() {
 
 bool pzn_df_wgrad_supported(int M, int N, int K) {
   if (!df_enabled() || M < 2048 || (M & 15) || N < 16 || K < 16) return false;
-  if ((double)M * (N > K ? N : K) * 4.0 >= 4294967296.0) return false;  // 32-bit buffer offsets
+  if ((double)M * (N > K ? N : K) * 4.0 >= 2147483648.0) return false;  // buffer offsets are computed in (signed) int
   const int tn = (N + 63) / 64, tk = (K + 63) / 64;
   return tn * tk <= 64;
 }
