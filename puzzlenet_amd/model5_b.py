@@ -158,10 +158,9 @@ class PCTransformer_nonsort(nn.Module):
         att2, attention2 = self.atten2(att1)
         att3, attention3 = self.atten3(att2)
         att4, attention4 = self.atten4(att3)
-        att = torch.cat([att1, att2, att3, att4], dim=-1)
         attention = attention1 + attention2 + attention3 + attention4
         attention = attention / 4
-        att = torch.cat([att, f2f], dim=-1)
+        att = torch.cat([att1, att2, att3, att4, f2f], dim=-1)       # (:466, :470 as one copy instead of two)
         out = dense.linear(att, self.out.weight, self.out.bias)                                   # :474
         f_global = ops.max_over_points(out)                                                       # :475
         return f_global, x2, attention, out, x_feature
