@@ -198,6 +198,37 @@ __global__ __launch_bounds__(768) void df_wgrad_kernel(DfArgs p) {
       }
   }
 
+  // two replicas per tile block: the second hands its tiles to the first through LDS (lane-major images, one
+  // barrier), so a tile block issues ONE set of atomics per workgroup instead of two
+  if (p.reps == 2) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    float* mine = red + (size_t)tl * (TI * TJ * 1024) + lane;
+    if (rep == 1) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) mine[((i * TJ + j) * 16 + q) * 64] = acc[i][j][q];
+    }
+    __syncthreads();
+    if (rep == 1) {
+      if (WITH_DB && tj == 0 && active) {  // only the bias sums are left for this replica
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          float t = dbacc[i] + __shfl_xor(dbacc[i], 32, PZN_WAVE);
+          if (half == 0 && nok[i]) atomicAdd(p.db + n0 + i * 32 + l31, t);
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] += mine[((i * TJ + j) * 16 + q) * 64];
+  }
   if (!active) return;
 
   // epilogue: C element r of lane l = row n = (r&3) + 8*(r>>2) + 4*half of tile i, column k = l31 of tile j
@@ -232,7 +263,11 @@ int launch_ij(DfArgs p, hipStream_t st) {
   // all types of a row range in one workgroup (they re-read the same rows out of L1 / L2); >= 8 steps per wave.
   // (One type per workgroup with 12 replicas meeting in LDS was tried for the short row counts: slower.)
   static const int tpw_cap = [] { const char* e = getenv("PZN_DF_TPW"); return e ? atoi(e) : 12; }();  // tuning aid (12 = all types together measured best)
-  const int cap = tpw_cap < MAXW ? tpw_cap : MAXW;
+  // short row counts are bound by latency and by the epilogue atomics: four tile blocks x two replicas per workgroup
+  // (pair-reduced in LDS) halve the atomics (16384 x 256 x 256: 50 -> 35 us); long streams keep every tile block of a
+  // row range together (L1 / L2 re-use of the rows)
+  const int want = p.M <= 65536 ? 4 : tpw_cap;
+  const int cap = want < MAXW ? want : MAXW;
   const int groups = (types + cap - 1) / cap;
   p.types_per_wg = (types + groups - 1) / groups;
   p.reps = MAXW / p.types_per_wg;
@@ -249,7 +284,12 @@ int launch_ij(DfArgs p, hipStream_t st) {
   const int waves = p.types_per_wg * p.reps;
   p.steps_per_wg = (nsteps + wgs - 1) / wgs;
   wgs = (nsteps + p.steps_per_wg - 1) / p.steps_per_wg;
-  const size_t lds = 0;  // replicas meet in the epilogue atomics (an LDS round per replica was slower)
+  const size_t lds = p.reps == 2 ? (size_t)p.types_per_wg * TI * TJ * 4096 : 0;  // pair reduction of the replicas
+  if (lds > 64 * 1024) {
+    const void* fn = p.genY ? (p.db ? (const void*)df_wgrad_kernel<TI, TJ, true, true> : (const void*)df_wgrad_kernel<TI, TJ, true, false>)
+                            : (p.db ? (const void*)df_wgrad_kernel<TI, TJ, false, true> : (const void*)df_wgrad_kernel<TI, TJ, false, false>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PZN_ELAUNCH;
+  }
   const dim3 grid((unsigned)wgs, (unsigned)groups), block(waves * 64);
   if (p.genY && p.db)
     hipLaunchKernelGGL((df_wgrad_kernel<TI, TJ, true, true>), grid, block, lds, st, p);
