@@ -122,6 +122,46 @@ typedef float v2f __attribute__((ext_vector_type(2)));
     }                                                                         \
   } while (0)
 
+// Same walk over TWO packed arrays of the same points that differ in their weight ({x,y,z,wa} and {x,y,z,wb}):
+// tile of three float4 per point pair — {x0,x1,y0,y1} {z0,z1,wa0,wa1} {wb0,wb1,-,-} — for the fused C + next-A pass.
+#define EMD_WALK2(PTRA, PTRB, CNT, EVAL2)                                     \
+  do {                                                                        \
+    __shared__ float4 emd_tile2_[2][EMD_TL / 2 * 3];                          \
+    const int cnt_ = (CNT);                                                   \
+    const int wq_ = threadIdx.x >> 6;                                         \
+    const int ntile_ = (cnt_ + EMD_TL - 1) / EMD_TL;                          \
+    auto stage_ = [&](int buf, int base) {                                    \
+      const int q = threadIdx.x;                                              \
+      const int i0 = base + 2 * q;                                            \
+      if (i0 < cnt_) {                                                        \
+        float4 a = (PTRA)[i0];                                                \
+        float wb0 = (PTRB)[i0].w;                                             \
+        float4 b = make_float4(a.x, a.y, a.z, 0.f);                           \
+        float wb1 = 0.f;                                                      \
+        if (i0 + 1 < cnt_) b = (PTRA)[i0 + 1], wb1 = (PTRB)[i0 + 1].w;        \
+        emd_tile2_[buf][3 * q] = make_float4(a.x, b.x, a.y, b.y);             \
+        emd_tile2_[buf][3 * q + 1] = make_float4(a.z, b.z, a.w, b.w);         \
+        emd_tile2_[buf][3 * q + 2] = make_float4(wb0, wb1, 0.f, 0.f);         \
+      }                                                                       \
+    };                                                                        \
+    stage_(0, 0);                                                             \
+    __syncthreads();                                                          \
+    for (int t_ = 0; t_ < ntile_; ++t_) {                                     \
+      const int base_ = t_ * EMD_TL;                                          \
+      const int npair_ = (min(EMD_TL, cnt_ - base_) + 1) >> 1;                \
+      if (t_ + 1 < ntile_) stage_((t_ + 1) & 1, base_ + EMD_TL);              \
+      const float4* tp_ = emd_tile2_[t_ & 1];                                 \
+      const int per_ = (npair_ + 3) >> 2;                                     \
+      int q_ = min(npair_, wq_ * per_);                                       \
+      const int end_ = min(npair_, q_ + per_);                                \
+      for (; q_ < end_; ++q_) {                                               \
+        float4 a0_ = tp_[3 * q_], b0_ = tp_[3 * q_ + 1], c0_ = tp_[3 * q_ + 2]; \
+        EVAL2((v2f){a0_.x, a0_.y}, (v2f){a0_.z, a0_.w}, (v2f){b0_.x, b0_.y}, (v2f){b0_.z, b0_.w}, (v2f){c0_.x, c0_.y}); \
+      }                                                                       \
+      __syncthreads();                                                        \
+    }                                                                         \
+  } while (0)
+
 __device__ __forceinline__ v2f exp2_pair(v2f t) { return (v2f){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)}; }
 
 // sum over the 4 wavefronts of a workgroup, lane by lane (all threads get the total)
@@ -267,6 +307,56 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_c_kernel(int n, int m, float c
     }
   }
   if (FUSED && threadIdx.x < 64) {  // one wavefront holds the 64 row totals
+    sc = k < n ? sc : 0.f;
+    sc = pzn::wave_sum_f32(sc);
+    if (threadIdx.x == 0) atomicAdd(cost + b, sc);
+  }
+}
+
+// Pass C of one level fused with pass A of the NEXT level (fused entry point only): both walk cloud 2 for the rows k
+// of cloud 1, so the differences and the squared distance of a pair are computed once for the two exponentials
+// (6 of the 20 packed instructions of the pair of passes), one launch and one tile staging are saved per level.
+// Pass A needs nothing of pass C but the row's own remainL_k, which this thread has just updated.  Arithmetic per
+// pass is unchanged, so the results are those of the separate kernels.
+__global__ __launch_bounds__(EMD_T) void emd_pass_ca_kernel(int n, int m, float c, float c_next, EmdWs w,
+                                                            float* __restrict__ cost, float* __restrict__ g1) {
+  __shared__ float red[EMD_T];
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * EMD_ROWS + (threadIdx.x & 63);
+  const float4* __restrict__ oa = w.pk2a + (size_t)b * m;  // {x2, y2, z2, remainR}   (pass A of the next level)
+  const float4* __restrict__ ob = w.pk2b + (size_t)b * m;  // {.., ratioR}            (pass C of this level)
+  float4 me = k < n ? w.pk1[(size_t)b * n + k] : make_float4(0, 0, 0, 0);
+  const float rl = me.w;  // :139
+  v2f al = {0.f, 0.f}, ax = al, ay = al, az = al, ac = al, aa = al;
+  auto eval = [&](v2f X, v2f Y, v2f Z, v2f WA, v2f WB) {
+    v2f dx = me.x - X, dy = me.y - Y, dz = me.z - Z;
+    v2f d = dx * dx + dy * dy + dz * dz;
+    v2f wv = exp2_pair(d * c) * rl * WB;  // :145
+    al += wv;                             // :147
+    ax += wv * dx;
+    ay += wv * dy;
+    az += wv * dz;
+    ac += wv * d;
+    aa += exp2_pair(d * c_next) * WA;     // :77-78 of the next level (same d: (x-y)^2 == (y-x)^2 exactly)
+  };
+  EMD_WALK2(oa, ob, m, eval);
+  const float suml = cross_wave_sum(al.x + al.y, red);
+  const float sx = cross_wave_sum(ax.x + ax.y, red), sy = cross_wave_sum(ay.x + ay.y, red);
+  const float sz = cross_wave_sum(az.x + az.y, red);
+  float sc = cross_wave_sum(ac.x + ac.y, red);
+  const float sa = 1e-9f + cross_wave_sum(aa.x + aa.y, red);  // :59
+  if (k < n && threadIdx.x < 64) {
+    float* r = w.remainL + (size_t)b * n + k;
+    const float rem = fmaxf(0.0f, *r - suml);  // :153
+    *r = rem;
+    float* g = g1 + ((size_t)b * n + k) * 3;
+    g[0] += 2.f * sx;
+    g[1] += 2.f * sy;
+    g[2] += 2.f * sz;
+    me.w = rem / sa;  // :83 of the next level
+    w.pk1[(size_t)b * n + k] = me;
+  }
+  if (threadIdx.x < 64) {  // one wavefront holds the 64 row totals
     sc = k < n ? sc : 0.f;
     sc = pzn::wave_sum_f32(sc);
     if (threadIdx.x == 0) atomicAdd(cost + b, sc);
@@ -514,9 +604,23 @@ int run_levels(const float* xyz1, const float* xyz2, int B, int n, int m, float*
     if (pzn_zero_async(g1, (size_t)B * n * 3, st) != PZN_OK) return PZN_ELAUNCH;
     if (pzn_zero_async(g2, (size_t)B * m * 3, st) != PZN_OK) return PZN_ELAUNCH;
   }
+  auto cof = [](int j) {                                         // :47-50, * log2(e)
+    const float level = j == -2 ? 0.f : -powf(4.0f, (float)j);
+    return level * 1.44269504088896340736f;
+  };
+  if (FUSED && !MATCH) {  // A(7); then per level B, and C fused with the next level's A; the last level ends with a plain C
+    hipLaunchKernelGGL(emd_pass_a_kernel, gk, dim3(EMD_T), 0, st, n, m, cof(7), w);
+    for (int j = 7; j >= -2; --j) {
+      hipLaunchKernelGGL((emd_pass_b_kernel<FUSED>), gl, dim3(EMD_T), 0, st, n, m, cof(j), w, g2);
+      if (j > -2)
+        hipLaunchKernelGGL(emd_pass_ca_kernel, gk, dim3(EMD_T), 0, st, n, m, cof(j), cof(j - 1), w, cost, g1);
+      else
+        hipLaunchKernelGGL((emd_pass_c_kernel<MATCH, FUSED>), gk, dim3(EMD_T), 0, st, n, m, cof(j), w, match, cost, g1);
+    }
+    PZN_RETURN_LAUNCH_STATUS();
+  }
   for (int j = 7; j >= -2; --j) {                                // :46
-    float level = j == -2 ? 0.f : -powf(4.0f, (float)j);         // :47-50
-    float c = level * 1.44269504088896340736f;                   // * log2(e)
+    const float c = cof(j);
     hipLaunchKernelGGL(emd_pass_a_kernel, gk, dim3(EMD_T), 0, st, n, m, c, w);
     hipLaunchKernelGGL((emd_pass_b_kernel<FUSED>), gl, dim3(EMD_T), 0, st, n, m, c, w, g2);
     hipLaunchKernelGGL((emd_pass_c_kernel<MATCH, FUSED>), gk, dim3(EMD_T), 0, st, n, m, c, w, match, cost, g1);
