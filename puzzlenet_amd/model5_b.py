@@ -141,9 +141,14 @@ class PCTransformer_nonsort(nn.Module):
             new_xyz, idx = plan
         return new_xyz, dense.sa_mlp_max(xyz, feat, new_xyz, idx, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias)
 
-    def forward(self, xyz, sa_plan=None):
+    def local_features(self, xyz):
+        """:447-448, the per-point MLP in front of the set abstraction (does not need the sampling plan)."""
         x_feature = F.relu(self.bn1(dense.linear(xyz, self.mlp1.weight, self.mlp1.bias)))          # :447
-        x_feature = F.relu(self.bn2(dense.linear(x_feature, self.mlp2.weight, self.mlp2.bias)))   # :448
+        return F.relu(self.bn2(dense.linear(x_feature, self.mlp2.weight, self.mlp2.bias)))        # :448
+
+    def forward(self, xyz, sa_plan=None, x_feature=None):
+        if x_feature is None:
+            x_feature = self.local_features(xyz)
         if self.fused_sa and not xyz.requires_grad:
             # :449-461 with the grouping folded into the shared MLP (same FPS draw order as sample_and_group)
             p1, p2 = sa_plan if sa_plan is not None else (None, None)
@@ -220,8 +225,39 @@ class TouchedRegraster(_Base):
             mrpc = mrpc.unsqueeze(0)
         N = fpc.shape[1]
 
-        plan_f, plan_m = self._sa_plans(fpc, mrpc)
         capturing = fpc.is_cuda and torch.cuda.is_current_stream_capturing()
+        if self.two_streams and fpc.is_cuda and not capturing:
+            # FPS is a latency-bound chain on 128 workgroups: it runs on the side stream while this one computes the
+            # per-point features of both clouds, which do not depend on it; then Encoder stays here, Encoder2 goes
+            # to the side stream (the two are independent and most of their launches do not fill 256 CUs; autograd
+            # replays each backward node on its forward stream, so the backward passes overlap as well).
+            cur = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream()
+                _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+                if _quiet is not None:
+                    _quiet(False)
+            side = self._side_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                plan_f, plan_m = self._sa_plans(fpc, mrpc)
+            xf_f = self.Encoder.local_features(fpc)
+            xf_m = self.Encoder2.local_features(mrpc)
+            cur.wait_stream(side)          # plans -> this stream
+            side.wait_stream(cur)          # xf_m -> side stream
+            if plan_f is not None:
+                for lvl in plan_f:
+                    lvl[0].record_stream(cur)
+            xf_m.record_stream(side)
+            with torch.cuda.stream(side):
+                fmrpcs = self.Encoder2(mrpc, plan_m, xf_m)                          # :716
+            ffpcs = self.Encoder(fpc, plan_f, xf_f)                                 # :710
+            cur.wait_stream(side)
+            for t in fmrpcs:
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(cur)
+            return self._heads(ffpcs, fmrpcs, N, need)
+        plan_f, plan_m = self._sa_plans(fpc, mrpc)
         if self.two_streams and fpc.is_cuda and (not capturing or self.two_streams == "graph"):
             # The two encoders are independent (separate weights, separate clouds) and most of their launches
             # are too small to fill 256 CUs: run Encoder2 on a side HIP stream next to Encoder.  Autograd
@@ -246,6 +282,10 @@ class TouchedRegraster(_Base):
         else:
             ffpcs = self.Encoder(fpc, plan_f)                                       # :710
             fmrpcs = self.Encoder2(mrpc, plan_m)                                    # :716
+        return self._heads(ffpcs, fmrpcs, N, need)
+
+    def _heads(self, ffpcs, fmrpcs, N, need):
+        """:723-759: pose head on the two global features, boundary heads on the per-point features."""
         ffpc, non_sg_ffpc = ffpcs[0], ffpcs[4]
         fmrpc, non_sg_fmrpc = fmrpcs[0], fmrpcs[4]
 
