@@ -669,6 +669,26 @@ void choose_splits(GemmArgs& p) {
   p.splits = (int)((p.K + p.k_chunk - 1) / p.k_chunk);
 }
 
+// Few-row layers (the pose head: 64 rows through 2048->1024->512->512->256): one 128-row tile per 128 output
+// columns leaves the grid at 2-16 workgroups walking the whole K range, so the launch is latency-bound
+// (176 us for 64x2048x1024).  Split K across the chip instead and finish bias / ReLU in a second tiny launch.
+bool few_rows(int M, int K) { return M <= 128 && K >= 256; }
+
+void few_rows_splits(GemmArgs& p) {
+  const long ksteps = (p.K + BK - 1) / BK;
+  long per = 8;  // 128 K elements per workgroup
+  p.k_chunk = (int)(per * BK);
+  p.splits = (int)((ksteps + per - 1) / per);
+  if (p.splits < 2) p.splits = 2, p.k_chunk = (int)(((ksteps + 1) / 2) * BK);
+}
+
+__global__ void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, long total, int N, int relu) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  float v = y[i] + (bias ? bias[i % N] : 0.f);
+  y[i] = relu ? fmaxf(v, 0.f) : v;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------- C ABI ----
@@ -683,6 +703,18 @@ PZN_EXPORT int pzn_linear_fwd_f32(const float* x, const float* W, const float* b
   }
   GemmArgs p = base_args(M, Nout, Kin);
   p.A = x, p.lda = Kin, p.B = W, p.ldb = Kin, p.C = y, p.ldc = Nout, p.bias = bias, p.relu = relu;
+  if (few_rows(M, Kin)) {
+    hipStream_t st = pzn_hip_stream(stream);
+    if (pzn_zero_async(y, (size_t)M * Nout, st) != PZN_OK) return PZN_ELAUNCH;
+    few_rows_splits(p);
+    launch<true, true, EPI_ATOMIC>(p, 1, st);
+    if (bias || relu) {
+      const long total = (long)M * Nout;
+      hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, y, bias, total, Nout,
+                         relu);
+    }
+    PZN_RETURN_LAUNCH_STATUS();
+  }
   launch<true, true, EPI_STORE>(p, 1, pzn_hip_stream(stream));
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -711,6 +743,13 @@ PZN_EXPORT int pzn_linear_dgrad_f32(const float* dy, const float* y_relu, const 
   p.A = dy, p.lda = Nout, p.B = W, p.ldb = Kin, p.C = dx, p.ldc = Kin;
   if (y_relu) p.gen = GEN_RELU, p.genY = y_relu;
   p.maskH = x_relu;
+  if (!x_relu && few_rows(M, Nout)) {
+    hipStream_t st = pzn_hip_stream(stream);
+    if (pzn_zero_async(dx, (size_t)M * Kin, st) != PZN_OK) return PZN_ELAUNCH;
+    few_rows_splits(p);
+    launch<true, false, EPI_ATOMIC>(p, 1, st);
+    PZN_RETURN_LAUNCH_STATUS();
+  }
   launch<true, false, EPI_STORE>(p, 1, pzn_hip_stream(stream));
   PZN_RETURN_LAUNCH_STATUS();
 }

@@ -43,7 +43,9 @@ def _rel(a, b):
     # tails, one / two / four 32-column tiles per wave, the two-sets-in-flight walk (16384 x 256 x 256)
     (4100, 68, 96, True, True), (6000, 132, 256, True, True), (4096, 128, 32, False, True),
     (8192, 256, 64, True, False), (16384, 256, 256, True, True), (4128, 96, 160, False, True),
-    (4112, 67, 128, True, True), (8192, 131, 256, False, True), (4096, 64, 64, True, True)])
+    (4112, 67, 128, True, True), (8192, 131, 256, False, True), (4096, 64, 64, True, True),
+    # few rows, long K (the pose head): K split across workgroups, atomic epilogue, bias / ReLU in a second launch
+    (64, 1024, 512, True, True), (100, 300, 70, True, True), (128, 520, 256, False, False), (7, 257, 33, True, False)])
 def test_linear_fwd_bwd(dev, precision, M, K, N, relu, bias):
     from puzzlenet_amd import ops
     g = torch.Generator().manual_seed(M + K + N)
