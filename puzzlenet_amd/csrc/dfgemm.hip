@@ -198,36 +198,38 @@ __global__ __launch_bounds__(768) void df_wgrad_kernel(DfArgs p) {
       }
   }
 
-  // two replicas per tile block: the second hands its tiles to the first through LDS (lane-major images, one
-  // barrier), so a tile block issues ONE set of atomics per workgroup instead of two
-  if (p.reps == 2) {
+  // 2 / 4 / 8 replicas per tile block meet in LDS (lane-major images, halving rounds), so a tile block issues ONE
+  // set of atomics per workgroup however many wavefronts streamed its rows
+  if (p.reps > 1) {
     extern __shared__ __attribute__((aligned(16))) float red[];
-    float* mine = red + (size_t)tl * (TI * TJ * 1024) + lane;
-    if (rep == 1) {
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) mine[((i * TJ + j) * 16 + q) * 64] = acc[i][j][q];
-    }
-    __syncthreads();
-    if (rep == 1) {
-      if (WITH_DB && tj == 0 && active) {  // only the bias sums are left for this replica
+    constexpr int SLOT = TI * TJ * 1024 + TI * 64;
+    for (int h = p.reps >> 1; h >= 1; h >>= 1) {
+      if (rep >= h && rep < 2 * h) {
+        float* mine = red + ((size_t)tl * (p.reps >> 1) + (rep - h)) * SLOT + lane;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
-          float t = dbacc[i] + __shfl_xor(dbacc[i], 32, PZN_WAVE);
-          if (half == 0 && nok[i]) atomicAdd(p.db + n0 + i * 32 + l31, t);
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) mine[((i * TJ + j) * 16 + q) * 64] = acc[i][j][q];
+          if (WITH_DB) mine[TI * TJ * 1024 + i * 64] = dbacc[i];
         }
       }
-      return;
+      __syncthreads();
+      if (rep < h) {
+        const float* other = red + ((size_t)tl * (p.reps >> 1) + rep) * SLOT + lane;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] += other[((i * TJ + j) * 16 + q) * 64];
+          if (WITH_DB) dbacc[i] += other[TI * TJ * 1024 + i * 64];
+        }
+      }
+      if (h > 1) __syncthreads();  // the next round writes the slots this one read
     }
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int j = 0; j < TJ; ++j)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[i][j][q] += mine[((i * TJ + j) * 16 + q) * 64];
+    if (rep != 0) return;
   }
   if (!active) return;
 
@@ -270,21 +272,23 @@ int launch_ij(DfArgs p, hipStream_t st) {
   const int cap = want < MAXW ? want : MAXW;
   const int groups = (types + cap - 1) / cap;
   p.types_per_wg = (types + groups - 1) / groups;
-  p.reps = MAXW / p.types_per_wg;
-  if (p.reps > 2) p.reps = 2;  // measured: 2 replicas beat 3 / 6 / 12 (every wave ends with TI*TJ*4 KB of atomics, and
-  // 8 resident waves stream as well as 12): 131072 x 64 x 64 69 -> 47 us, 1M x 128 x 128 0.45 -> 0.33 ms
+  // replicas (a power of two, they meet in LDS): as many as fit while every wave keeps >= 4 steps of rows.  One or two
+  // tile blocks (131072 x 64 x 64, 131072 x 128 x 64) would otherwise leave 2-4 waves per CU to hide the HBM latency.
+  const int rmax = MAXW / p.types_per_wg;
+  p.reps = rmax >= 8 ? 8 : (rmax >= 4 ? 4 : (rmax >= 2 ? 2 : 1));
+  while (p.reps > 2 && nsteps / (256 * p.reps) < 4) p.reps >>= 1;
   static const int reps_cap = [] { const char* e = getenv("PZN_DF_REPS"); return e ? atoi(e) : 0; }();  // tuning aid
-  if (reps_cap > 0 && p.reps > reps_cap) p.reps = reps_cap;
+  while (reps_cap > 0 && p.reps > reps_cap) p.reps >>= 1;
   int wgs = 256;
   static const int min_steps = [] { const char* e = getenv("PZN_DF_MINSTEPS"); return e ? atoi(e) : 8; }();  // tuning aid
-  const int max_by_steps = nsteps / (min_steps * p.reps);
+  const int max_by_steps = nsteps / ((p.reps > 2 ? 4 : min_steps) * p.reps);
   if (wgs > max_by_steps) wgs = max_by_steps;
   if (forced) wgs = forced;
   if (wgs < 1) wgs = 1;
   const int waves = p.types_per_wg * p.reps;
   p.steps_per_wg = (nsteps + wgs - 1) / wgs;
   wgs = (nsteps + p.steps_per_wg - 1) / p.steps_per_wg;
-  const size_t lds = p.reps == 2 ? (size_t)p.types_per_wg * TI * TJ * 4096 : 0;  // pair reduction of the replicas
+  const size_t lds = p.reps > 1 ? (size_t)p.types_per_wg * (p.reps / 2) * (TI * TJ * 1024 + TI * 64) * 4 : 0;  // replica reduction
   if (lds > 64 * 1024) {
     const void* fn = p.genY ? (p.db ? (const void*)df_wgrad_kernel<TI, TJ, true, true> : (const void*)df_wgrad_kernel<TI, TJ, true, false>)
                             : (p.db ? (const void*)df_wgrad_kernel<TI, TJ, false, true> : (const void*)df_wgrad_kernel<TI, TJ, false, false>);
@@ -310,7 +314,7 @@ bool df_enabled() {
 }  // namespace
 
 bool pzn_df_wgrad_supported(int M, int N, int K) {
-  if (!df_enabled() || M < 2048 || (M & 15) || N < 16 || K < 16) return false;
+  if (!df_enabled() || M < 2048 || (M & 15) || N < 1 || K < 1) return false;  // narrow N / K: clamped column loads
   if ((double)M * (N > K ? N : K) * 4.0 >= 2147483648.0) return false;  // buffer offsets are computed in (signed) int
   const int tn = (N + 63) / 64, tk = (K + 63) / 64;
   return tn * tk <= 64;

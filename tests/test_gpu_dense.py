@@ -45,7 +45,11 @@ def _rel(a, b):
     (8192, 256, 64, True, False), (16384, 256, 256, True, True), (4128, 96, 160, False, True),
     (4112, 67, 128, True, True), (8192, 131, 256, False, True), (4096, 64, 64, True, True),
     # few rows, long K (the pose head): K split across workgroups, atomic epilogue, bias / ReLU in a second launch
-    (64, 1024, 512, True, True), (100, 300, 70, True, True), (128, 520, 256, False, False), (7, 257, 33, True, False)])
+    (64, 1024, 512, True, True), (100, 300, 70, True, True), (128, 520, 256, False, False), (7, 257, 33, True, False),
+    # the per-point heads: one or two tile blocks of the weight gradient (4 / 8 row replicas meeting in LDS), narrow
+    # N / K (clamped column loads of the direct-fragment kernel)
+    (131072, 64, 64, True, True), (131072, 128, 64, True, True), (131072, 3, 64, False, True),
+    (131072, 32, 2, False, True), (8192, 5, 7, True, True), (32768, 64, 32, True, True)])
 def test_linear_fwd_bwd(dev, precision, M, K, N, relu, bias):
     from puzzlenet_amd import ops
     g = torch.Generator().manual_seed(M + K + N)

@@ -1,4 +1,5 @@
-"""Few-row layers of the pose head (64 rows): forward / input-gradient / weight-gradient launch times."""
+"""Few-row layers of the pose head (64 rows) and the narrow per-point heads (131072 rows): forward / input-gradient /
+weight-gradient launch times."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from puzzlenet_amd import _lib
@@ -14,7 +15,8 @@ def timeit(fn, name, iters=20):
     for _ in range(iters): fn()
     b.record(); torch.cuda.synchronize()
     print('%-40s %8.1f us' % (name, a.elapsed_time(b) / iters * 1e3), flush=True)
-for (M, K, N) in [(64, 2048, 1024), (64, 1024, 512), (64, 512, 512), (64, 512, 256), (64, 256, 6)]:
+for (M, K, N) in [(64, 2048, 1024), (64, 1024, 512), (64, 512, 512), (64, 512, 256), (64, 256, 6),
+                  (131072, 64, 64), (131072, 128, 64), (131072, 64, 32), (131072, 3, 64), (131072, 32, 2)]:
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
     y = torch.empty(M, N, device=dev); dy = torch.randn(M, N, device=dev); dx = torch.empty(M, K, device=dev)
     dW = torch.empty(N, K, device=dev); db = torch.empty(N, device=dev)
