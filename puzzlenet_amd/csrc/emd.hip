@@ -38,6 +38,8 @@ struct EmdWs {
   float4* pk2a;    // [B*m] {x2,y2,z2, remainR}
   float4* pk2b;    // [B*m] {x2,y2,z2, ratioR}
   float* remainL;  // [B*n]
+  int* act[2];     // [B*m] each: ascending indices l of the points of cloud 2 that still hold mass (remainR_l > 0)
+  int* cnt[2];     // [B] each: how many
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -52,6 +54,15 @@ EmdWs carve(void* ws, int B, int n, int m) {
   w.pk2b = reinterpret_cast<float4*>(p);
   p += align_up(sizeof(float4) * (size_t)B * m, 256);
   w.remainL = reinterpret_cast<float*>(p);
+  p += align_up(sizeof(float) * (size_t)B * n, 256);
+  for (int i = 0; i < 2; ++i) {
+    w.act[i] = reinterpret_cast<int*>(p);
+    p += align_up(sizeof(int) * (size_t)B * m, 256);
+  }
+  for (int i = 0; i < 2; ++i) {
+    w.cnt[i] = reinterpret_cast<int*>(p);
+    p += align_up(sizeof(int) * (size_t)B, 256);
+  }
   return w;
 }
 
@@ -83,7 +94,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // walked points per instruction with the packed fp32 ALU ops (v_pk_add/mul/fma_f32): ~8 issues per
 // (row, point) instead of ~21 for the float4-per-point form (whose pairs the compiler had to assemble
 // with v_mov).  An odd tail point is paired with a zero-weight copy of itself.
-#define EMD_WALK(PTR, CNT, EVAL2)                                             \
+#define EMD_WALK(PTR, IX, CNT, EVAL2)                                           \
   do {                                                                        \
     __shared__ float4 emd_tile_[2][EMD_TL];                                   \
     const int cnt_ = (CNT);                                                   \
@@ -93,8 +104,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
       const int q = threadIdx.x; /* pair index inside the tile: EMD_T == EMD_TL / 2 */ \
       const int i0 = base + 2 * q;                                            \
       if (i0 < cnt_) {                                                        \
-        float4 a = (PTR)[i0];                                                 \
-        float4 b = i0 + 1 < cnt_ ? (PTR)[i0 + 1] : make_float4(a.x, a.y, a.z, 0.f); \
+        float4 a = (PTR)[IX(i0)];                                             \
+        float4 b = i0 + 1 < cnt_ ? (PTR)[IX(i0 + 1)] : make_float4(a.x, a.y, a.z, 0.f); \
         emd_tile_[buf][2 * q] = make_float4(a.x, b.x, a.y, b.y);              \
         emd_tile_[buf][2 * q + 1] = make_float4(a.z, b.z, a.w, b.w);          \
       }                                                                       \
@@ -124,7 +135,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Same walk over TWO packed arrays of the same points that differ in their weight ({x,y,z,wa} and {x,y,z,wb}):
 // tile of three float4 per point pair — {x0,x1,y0,y1} {z0,z1,wa0,wa1} {wb0,wb1,-,-} — for the fused C + next-A pass.
-#define EMD_WALK2(PTRA, PTRB, CNT, EVAL2)                                     \
+#define EMD_WALK2(PTRA, PTRB, IX, CNT, EVAL2)                                   \
   do {                                                                        \
     __shared__ float4 emd_tile2_[2][EMD_TL / 2 * 3];                          \
     const int cnt_ = (CNT);                                                   \
@@ -134,11 +145,15 @@ typedef float v2f __attribute__((ext_vector_type(2)));
       const int q = threadIdx.x;                                              \
       const int i0 = base + 2 * q;                                            \
       if (i0 < cnt_) {                                                        \
-        float4 a = (PTRA)[i0];                                                \
-        float wb0 = (PTRB)[i0].w;                                             \
+        const int j0 = IX(i0);                                                \
+        float4 a = (PTRA)[j0];                                                \
+        float wb0 = (PTRB)[j0].w;                                             \
         float4 b = make_float4(a.x, a.y, a.z, 0.f);                           \
         float wb1 = 0.f;                                                      \
-        if (i0 + 1 < cnt_) b = (PTRA)[i0 + 1], wb1 = (PTRB)[i0 + 1].w;        \
+        if (i0 + 1 < cnt_) {                                                  \
+          const int j1 = IX(i0 + 1);                                          \
+          b = (PTRA)[j1], wb1 = (PTRB)[j1].w;                                 \
+        }                                                                     \
         emd_tile2_[buf][3 * q] = make_float4(a.x, b.x, a.y, b.y);             \
         emd_tile2_[buf][3 * q + 1] = make_float4(a.z, b.z, a.w, b.w);         \
         emd_tile2_[buf][3 * q + 2] = make_float4(wb0, wb1, 0.f, 0.f);         \
@@ -176,9 +191,22 @@ __device__ __forceinline__ float cross_wave_sum(float v, float* red) {
 
 __global__ __launch_bounds__(EMD_T) void emd_init_kernel(const float* __restrict__ xyz1,
                                                          const float* __restrict__ xyz2, int n, int m,
-                                                         float multiL, float multiR, EmdWs w) {
+                                                         float multiL, float multiR, EmdWs w,
+                                                         float* __restrict__ cost, float* __restrict__ g1,
+                                                         float* __restrict__ g2) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * EMD_T + threadIdx.x;
+  if (cost) {  // fused entry point: the accumulators start at zero (no separate fills)
+    if (i == 0) cost[b] = 0.f;
+    if (i < n) {
+      float* g = g1 + ((size_t)b * n + i) * 3;
+      g[0] = 0.f, g[1] = 0.f, g[2] = 0.f;
+    }
+    if (i < m) {
+      float* g = g2 + ((size_t)b * m + i) * 3;
+      g[0] = 0.f, g[1] = 0.f, g[2] = 0.f;
+    }
+  }
   if (i < n) {
     const float* p = xyz1 + ((size_t)b * n + i) * 3;
     w.pk1[(size_t)b * n + i] = make_float4(p[0], p[1], p[2], 0.f);
@@ -188,7 +216,44 @@ __global__ __launch_bounds__(EMD_T) void emd_init_kernel(const float* __restrict
     const float* p = xyz2 + ((size_t)b * m + i) * 3;
     w.pk2a[(size_t)b * m + i] = make_float4(p[0], p[1], p[2], multiR);  // :43-44
     w.pk2b[(size_t)b * m + i] = make_float4(p[0], p[1], p[2], 0.f);
+    w.act[0][(size_t)b * m + i] = i;  // every point of cloud 2 starts with mass
+    if (i == 0) w.cnt[0][b] = m;
   }
+}
+
+// Active list of cloud 2 for the next level.  remainR_l == 0 is absorbing (pass B: s_l *= remainR_l -> 0, ratioR_l = 0,
+// remainR_l stays 0) and such a point contributes exactly +0 to every sum of passes A and C, so the three passes of
+// a level only need the points that still hold mass: 57 % of them at level 5, 21 % at level 3, 2 % at level 0 on
+// uniform clouds — the ten levels together cost about 3.2 full ones.  One workgroup per pair; the list is in
+// ascending index order (deterministic), two lists alternate between levels.
+constexpr int EMD_CT = 1024;
+__global__ __launch_bounds__(EMD_CT) void emd_compact_kernel(int m, EmdWs w, int buf) {
+  __shared__ int wsum[EMD_CT / 64];
+  __shared__ int base_s;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float4* __restrict__ src = w.pk2a + (size_t)b * m;
+  int* __restrict__ dst = w.act[buf] + (size_t)b * m;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < m; i0 += EMD_CT) {
+    const int l = i0 + tid;
+    const bool on = l < m && src[l].w > 0.f;
+    const uint64_t bal = __ballot(on);
+    const int before = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wv] = __builtin_popcountll(bal);
+    __syncthreads();
+    int off = base_s, tot = 0;
+    for (int q = 0; q < EMD_CT / 64; ++q) {
+      const int c = wsum[q];
+      off += q < wv ? c : 0;
+      tot += c;
+    }
+    if (on) dst[off + before] = l;
+    __syncthreads();
+    if (tid == 0) base_s += tot;
+    __syncthreads();
+  }
+  if (tid == 0) w.cnt[buf][b] = base_s;
 }
 
 // Pass A: rows = points k of xyz1.
@@ -204,7 +269,8 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_a_kernel(int n, int m, float c
     v2f d = dx * dx + dy * dy + dz * dz;       // :76
     acc += exp2_pair(d * c) * Wt;              // :77-78
   };
-  EMD_WALK(other, m, eval);
+  auto ix = [](int i) { return i; };
+  EMD_WALK(other, ix, m, eval);
   float suml = 1e-9f + cross_wave_sum(acc.x + acc.y, red);  // :59
   if (k < n && threadIdx.x < 64) {
     me.w = w.remainL[(size_t)b * n + k] / suml;  // :83
@@ -232,7 +298,8 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_b_kernel(int n, int m, float c
       az += e * dz;
     }
   };
-  EMD_WALK(other, n, eval);
+  auto ix = [](int i) { return i; };
+  EMD_WALK(other, ix, n, eval);
   float sumr = cross_wave_sum(ar.x + ar.y, red), sx = 0.f, sy = 0.f, sz = 0.f;
   if (FUSED) {
     sx = cross_wave_sum(ax.x + ax.y, red);
@@ -257,11 +324,106 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_b_kernel(int n, int m, float c
   }
 }
 
+// Pass B of the fused entry point: the rows are the ACTIVE points of cloud 2 (list `buf`, see emd_compact_kernel).
+// A workgroup that walks all of cloud 1 for its rows takes ~70 us however few rows are left, so the fewer rows a
+// pair has, the more lanes share one: SUB = 1 / 4 / 16 adjacent lanes per row (64 / 16 / 4 rows per workgroup), each
+// taking every SUB-th point pair of its wavefront's quarter tile; they meet by lane shuffles, the four wavefronts
+// through LDS as before.  The grid is the full one ((m+63)/64 workgroups per pair: cnt*SUB <= m rows-times-lanes
+// always fit); workgroups past the end of the list leave at once.  Same formulas as emd_pass_b_kernel<true>.
+template <int SUB>
+__device__ __forceinline__ void emd_pass_b_rows(int n, int m, float c, const EmdWs& w, float* __restrict__ g2, int buf,
+                                                int cnt, float4 (*tile)[EMD_TL], float* red) {
+  constexpr int RPB = EMD_ROWS / SUB;
+  if ((int)blockIdx.x * RPB >= cnt) return;  // workgroup-uniform
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+  const int sub = lane & (SUB - 1), r = blockIdx.x * RPB + lane / SUB;
+  const int l = r < cnt ? w.act[buf][(size_t)b * m + r] : m;
+  const float4* __restrict__ other = w.pk1 + (size_t)b * n;
+  float4 me = l < m ? w.pk2a[(size_t)b * m + l] : make_float4(0, 0, 0, 0);
+  v2f ar = {0.f, 0.f}, ax = ar, ay = ar, az = ar;
+  auto eval = [&](float4 a, float4 bb) {  // a = {x0,x1,y0,y1}, bb = {z0,z1,w0,w1}
+    v2f dx = me.x - (v2f){a.x, a.y}, dy = me.y - (v2f){a.z, a.w}, dz = me.z - (v2f){bb.x, bb.y};
+    v2f e = exp2_pair((dx * dx + dy * dy + dz * dz) * c) * (v2f){bb.z, bb.w};  // :108
+    ar += e;                                                                    // :109
+    ax += e * dx;
+    ay += e * dy;
+    az += e * dz;
+  };
+  auto stage = [&](int tb, int base) {
+    const int q = threadIdx.x, i0 = base + 2 * q;
+    if (i0 < n) {
+      const float4 a = other[i0];
+      const float4 bb = i0 + 1 < n ? other[i0 + 1] : make_float4(a.x, a.y, a.z, 0.f);
+      tile[tb][2 * q] = make_float4(a.x, bb.x, a.y, bb.y);
+      tile[tb][2 * q + 1] = make_float4(a.z, bb.z, a.w, bb.w);
+    }
+  };
+  const int ntile = (n + EMD_TL - 1) / EMD_TL;
+  stage(0, 0);
+  __syncthreads();
+  for (int t = 0; t < ntile; ++t) {
+    const int base = t * EMD_TL;
+    const int npair = (min(EMD_TL, n - base) + 1) >> 1;
+    if (t + 1 < ntile) stage((t + 1) & 1, base + EMD_TL);
+    const float4* tp = tile[t & 1];
+    const int per = (npair + 3) >> 2;
+    const int q0 = min(npair, wq * per), end = min(npair, q0 + per);
+    int q = q0 + sub;
+    for (; q + SUB < end; q += 2 * SUB) {
+      const float4 a0 = tp[2 * q], b0 = tp[2 * q + 1], a1 = tp[2 * (q + SUB)], b1 = tp[2 * (q + SUB) + 1];
+      eval(a0, b0);
+      eval(a1, b1);
+    }
+    if (q < end) eval(tp[2 * q], tp[2 * q + 1]);
+    __syncthreads();
+  }
+  float sr = ar.x + ar.y, sx = ax.x + ax.y, sy = ay.x + ay.y, sz = az.x + az.y;
+#pragma unroll
+  for (int o = 1; o < SUB; o <<= 1) {
+    sr += __shfl_xor(sr, o, PZN_WAVE);
+    sx += __shfl_xor(sx, o, PZN_WAVE);
+    sy += __shfl_xor(sy, o, PZN_WAVE);
+    sz += __shfl_xor(sz, o, PZN_WAVE);
+  }
+  float sumr = cross_wave_sum(sr, red);
+  sx = cross_wave_sum(sx, red);
+  sy = cross_wave_sum(sy, red);
+  sz = cross_wave_sum(sz, red);
+  if (l < m && threadIdx.x < 64 && sub == 0) {
+    const float remainR = me.w;
+    sumr *= remainR;                                                    // :114
+    const float consumption = fminf(remainR / (sumr + 1e-9f), 1.0f);    // :115
+    const float ratioR = consumption * remainR;                         // :116
+    me.w = fmaxf(0.0f, remainR - sumr);                                 // :117
+    w.pk2a[(size_t)b * m + l] = me;
+    w.pk2b[(size_t)b * m + l].w = ratioR;
+    float* g = g2 + ((size_t)b * m + l) * 3;
+    const float s = 2.f * ratioR;
+    g[0] += s * sx;
+    g[1] += s * sy;
+    g[2] += s * sz;
+  }
+}
+
+__global__ __launch_bounds__(EMD_T) void emd_pass_b_list_kernel(int n, int m, float c, EmdWs w, float* __restrict__ g2,
+                                                                int buf) {
+  __shared__ float4 tile[2][EMD_TL];
+  __shared__ float red[EMD_T];
+  const int cnt = w.cnt[buf][blockIdx.y];
+  if (cnt * 16 <= m)
+    emd_pass_b_rows<16>(n, m, c, w, g2, buf, cnt, tile, red);
+  else if (cnt * 4 <= m)
+    emd_pass_b_rows<4>(n, m, c, w, g2, buf, cnt, tile, red);
+  else
+    emd_pass_b_rows<1>(n, m, c, w, g2, buf, cnt, tile, red);
+}
+
 // Pass C: rows = points k of xyz1.  MATCH writes match[b][l][k] += w (API-parity path);
 // FUSED accumulates cost_b += sum_l d_kl w_kl and grad1_k += 2 sum_l w_kl (x1_k - x2_l).
-template <bool MATCH, bool FUSED>
+// LIST (not with MATCH): walk only the active points of cloud 2 (list `buf`).
+template <bool MATCH, bool FUSED, bool LIST>
 __global__ __launch_bounds__(EMD_T) void emd_pass_c_kernel(int n, int m, float c, EmdWs w, float* __restrict__ match,
-                                                           float* __restrict__ cost, float* __restrict__ g1) {
+                                                           float* __restrict__ cost, float* __restrict__ g1, int buf) {
   __shared__ float red[EMD_T];
   const int b = blockIdx.y;
   const int k = blockIdx.x * EMD_ROWS + (threadIdx.x & 63);
@@ -288,7 +450,9 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_c_kernel(int n, int m, float c
       ac += wv * d;
     }
   };
-  EMD_WALK(other, m, eval);
+  const int* __restrict__ act = w.act[buf] + (size_t)b * m;
+  auto ix = [&](int i) { return LIST ? act[i] : i; };
+  EMD_WALK(other, ix, LIST ? w.cnt[buf][b] : m, eval);
   float suml = cross_wave_sum(al.x + al.y, red), sx = 0.f, sy = 0.f, sz = 0.f, sc = 0.f;
   if (FUSED) {
     sx = cross_wave_sum(ax.x + ax.y, red);
@@ -318,8 +482,10 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_c_kernel(int n, int m, float c
 // (6 of the 20 packed instructions of the pair of passes), one launch and one tile staging are saved per level.
 // Pass A needs nothing of pass C but the row's own remainL_k, which this thread has just updated.  Arithmetic per
 // pass is unchanged, so the results are those of the separate kernels.
+// The walk covers the active list of THIS level (`buf`): ratioR of pass C is non-zero exactly there, and the points that
+// pass B has just exhausted carry remainR = 0 into the next level's sum.
 __global__ __launch_bounds__(EMD_T) void emd_pass_ca_kernel(int n, int m, float c, float c_next, EmdWs w,
-                                                            float* __restrict__ cost, float* __restrict__ g1) {
+                                                            float* __restrict__ cost, float* __restrict__ g1, int buf) {
   __shared__ float red[EMD_T];
   const int b = blockIdx.y;
   const int k = blockIdx.x * EMD_ROWS + (threadIdx.x & 63);
@@ -339,7 +505,9 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_ca_kernel(int n, int m, float 
     ac += wv * d;
     aa += exp2_pair(d * c_next) * WA;     // :77-78 of the next level (same d: (x-y)^2 == (y-x)^2 exactly)
   };
-  EMD_WALK2(oa, ob, m, eval);
+  const int* __restrict__ act = w.act[buf] + (size_t)b * m;
+  auto ix = [&](int i) { return act[i]; };
+  EMD_WALK2(oa, ob, ix, w.cnt[buf][b], eval);
   const float suml = cross_wave_sum(al.x + al.y, red);
   const float sx = cross_wave_sum(ax.x + ax.y, red), sy = cross_wave_sum(ay.x + ay.y, red);
   const float sz = cross_wave_sum(az.x + az.y, red);
@@ -597,25 +765,24 @@ int run_levels(const float* xyz1, const float* xyz2, int B, int n, int m, float*
   }
   const int mx = n > m ? n : m;
   dim3 gi((mx + EMD_T - 1) / EMD_T, B), gk((n + EMD_ROWS - 1) / EMD_ROWS, B), gl((m + EMD_ROWS - 1) / EMD_ROWS, B);
-  hipLaunchKernelGGL(emd_init_kernel, gi, dim3(EMD_T), 0, st, xyz1, xyz2, n, m, multiL, multiR, w);
+  hipLaunchKernelGGL(emd_init_kernel, gi, dim3(EMD_T), 0, st, xyz1, xyz2, n, m, multiL, multiR, w, FUSED ? cost : nullptr,
+                     g1, g2);
   if (MATCH && pzn_zero_async(match, (size_t)B * n * m, st) != PZN_OK) return PZN_ELAUNCH;  // :39-40
-  if (FUSED) {
-    if (pzn_zero_async(cost, (size_t)B, st) != PZN_OK) return PZN_ELAUNCH;
-    if (pzn_zero_async(g1, (size_t)B * n * 3, st) != PZN_OK) return PZN_ELAUNCH;
-    if (pzn_zero_async(g2, (size_t)B * m * 3, st) != PZN_OK) return PZN_ELAUNCH;
-  }
   auto cof = [](int j) {                                         // :47-50, * log2(e)
     const float level = j == -2 ? 0.f : -powf(4.0f, (float)j);
     return level * 1.44269504088896340736f;
   };
   if (FUSED && !MATCH) {  // A(7); then per level B, and C fused with the next level's A; the last level ends with a plain C
     hipLaunchKernelGGL(emd_pass_a_kernel, gk, dim3(EMD_T), 0, st, n, m, cof(7), w);
-    for (int j = 7; j >= -2; --j) {
-      hipLaunchKernelGGL((emd_pass_b_kernel<FUSED>), gl, dim3(EMD_T), 0, st, n, m, cof(j), w, g2);
-      if (j > -2)
-        hipLaunchKernelGGL(emd_pass_ca_kernel, gk, dim3(EMD_T), 0, st, n, m, cof(j), cof(j - 1), w, cost, g1);
-      else
-        hipLaunchKernelGGL((emd_pass_c_kernel<MATCH, FUSED>), gk, dim3(EMD_T), 0, st, n, m, cof(j), w, match, cost, g1);
+    for (int j = 7, buf = 0; j >= -2; --j, buf ^= 1) {  // list `buf` = points of cloud 2 with mass at the start of level j
+      hipLaunchKernelGGL(emd_pass_b_list_kernel, gl, dim3(EMD_T), 0, st, n, m, cof(j), w, g2, buf);
+      if (j > -2) {
+        hipLaunchKernelGGL(emd_compact_kernel, dim3(B), dim3(EMD_CT), 0, st, m, w, buf ^ 1);  // for level j - 1
+        hipLaunchKernelGGL(emd_pass_ca_kernel, gk, dim3(EMD_T), 0, st, n, m, cof(j), cof(j - 1), w, cost, g1, buf);
+      } else {
+        hipLaunchKernelGGL((emd_pass_c_kernel<false, FUSED, true>), gk, dim3(EMD_T), 0, st, n, m, cof(j), w, match, cost,
+                           g1, buf);
+      }
     }
     PZN_RETURN_LAUNCH_STATUS();
   }
@@ -623,7 +790,7 @@ int run_levels(const float* xyz1, const float* xyz2, int B, int n, int m, float*
     const float c = cof(j);
     hipLaunchKernelGGL(emd_pass_a_kernel, gk, dim3(EMD_T), 0, st, n, m, c, w);
     hipLaunchKernelGGL((emd_pass_b_kernel<FUSED>), gl, dim3(EMD_T), 0, st, n, m, c, w, g2);
-    hipLaunchKernelGGL((emd_pass_c_kernel<MATCH, FUSED>), gk, dim3(EMD_T), 0, st, n, m, c, w, match, cost, g1);
+    hipLaunchKernelGGL((emd_pass_c_kernel<MATCH, FUSED, false>), gk, dim3(EMD_T), 0, st, n, m, c, w, match, cost, g1, 0);
   }
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -633,7 +800,8 @@ int run_levels(const float* xyz1, const float* xyz2, int B, int n, int m, float*
 PZN_EXPORT size_t pzn_emd_workspace_bytes(int B, int n, int m) {
   if (B <= 0 || n <= 0 || m <= 0) return 0;
   return align_up(sizeof(float4) * (size_t)B * n, 256) + 2 * align_up(sizeof(float4) * (size_t)B * m, 256) +
-         align_up(sizeof(float) * (size_t)B * n, 256);
+         align_up(sizeof(float) * (size_t)B * n, 256) + 2 * align_up(sizeof(int) * (size_t)B * m, 256) +
+         2 * align_up(sizeof(int) * (size_t)B, 256);
 }
 
 PZN_EXPORT int pzn_emd_approxmatch_f32(const float* xyz1, const float* xyz2, int B, int n, int m, float* match,
