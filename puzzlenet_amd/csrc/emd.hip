@@ -27,6 +27,11 @@
 //                ratioR_l = min(remainR_l/(s_l+1e-9), 1) remainR_l;  remainR_l = max(0, remainR_l - s_l)
 //   C (:121-154) w_kl = e_kl ratioL_k ratioR_l;  match_lk += w_kl;  remainL_k = max(0, remainL_k - sum_l w_kl)
 // with e_kl = exp(level * d_kl), level = -4^j for j = 7..-1 and 0 for the last.
+//
+// Fused entry point, large clouds: A(7); per level B over the ACTIVE points of cloud 2 (emd_pass_b_list_kernel), the
+// next level's active list (emd_compact_kernel), then C fused with the next level's A, walking the active list
+// (emd_pass_ca_kernel).  A point with remainR_l == 0 stays at 0 (:114-117) and contributes exactly +0 to the sums
+// of A and C, so leaving it out changes nothing but the summation order.
 #include "pzn_common.h"
 
 namespace {
@@ -326,10 +331,12 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_b_kernel(int n, int m, float c
 
 // Pass B of the fused entry point: the rows are the ACTIVE points of cloud 2 (list `buf`, see emd_compact_kernel).
 // A workgroup that walks all of cloud 1 for its rows takes ~70 us however few rows are left, so the fewer rows a
-// pair has, the more lanes share one: SUB = 1 / 4 / 16 adjacent lanes per row (64 / 16 / 4 rows per workgroup), each
+// pair has, the more lanes share one: SUB = 1 ... 16 adjacent lanes per row (64 ... 4 rows per workgroup), each
 // taking every SUB-th point pair of its wavefront's quarter tile; they meet by lane shuffles, the four wavefronts
-// through LDS as before.  The grid is the full one ((m+63)/64 workgroups per pair: cnt*SUB <= m rows-times-lanes
-// always fit); workgroups past the end of the list leave at once.  Same formulas as emd_pass_b_kernel<true>.
+// through LDS as before.  SUB = 1 / 2 / 4 / 8 / 16 for cnt <= m, 3m/4, m/2, m/4, m/8 (measured at n = m = 2048, 64
+// pairs: with 64 rows per workgroup the pass took 80 us at 35 % of the rows as at 100 %).  The grid is (m+31)/32 workgroups per
+// pair (cnt*SUB <= 2m always fits); workgroups past the end of the list leave at once.  Same formulas as
+// emd_pass_b_kernel<true>.
 template <int SUB>
 __device__ __forceinline__ void emd_pass_b_rows(int n, int m, float c, const EmdWs& w, float* __restrict__ g2, int buf,
                                                 int cnt, float4 (*tile)[EMD_TL], float* red) {
@@ -410,11 +417,15 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_b_list_kernel(int n, int m, fl
   __shared__ float4 tile[2][EMD_TL];
   __shared__ float red[EMD_T];
   const int cnt = w.cnt[buf][blockIdx.y];
-  if (cnt * 16 <= m)
+  if (cnt * 8 <= m)
     emd_pass_b_rows<16>(n, m, c, w, g2, buf, cnt, tile, red);
   else if (cnt * 4 <= m)
+    emd_pass_b_rows<8>(n, m, c, w, g2, buf, cnt, tile, red);
+  else if (cnt * 2 <= m)
     emd_pass_b_rows<4>(n, m, c, w, g2, buf, cnt, tile, red);
-  else
+  else if (cnt * 4 <= m * 3)
+    emd_pass_b_rows<2>(n, m, c, w, g2, buf, cnt, tile, red);
+  else  // (nearly) every row: the pass is bound by the vector ALU, sharing rows only adds workgroups
     emd_pass_b_rows<1>(n, m, c, w, g2, buf, cnt, tile, red);
 }
 
@@ -775,7 +786,7 @@ int run_levels(const float* xyz1, const float* xyz2, int B, int n, int m, float*
   if (FUSED && !MATCH) {  // A(7); then per level B, and C fused with the next level's A; the last level ends with a plain C
     hipLaunchKernelGGL(emd_pass_a_kernel, gk, dim3(EMD_T), 0, st, n, m, cof(7), w);
     for (int j = 7, buf = 0; j >= -2; --j, buf ^= 1) {  // list `buf` = points of cloud 2 with mass at the start of level j
-      hipLaunchKernelGGL(emd_pass_b_list_kernel, gl, dim3(EMD_T), 0, st, n, m, cof(j), w, g2, buf);
+      hipLaunchKernelGGL(emd_pass_b_list_kernel, dim3((m + 31) / 32, B), dim3(EMD_T), 0, st, n, m, cof(j), w, g2, buf);
       if (j > -2) {
         hipLaunchKernelGGL(emd_compact_kernel, dim3(B), dim3(EMD_CT), 0, st, m, w, buf ^ 1);  // for level j - 1
         hipLaunchKernelGGL(emd_pass_ca_kernel, gk, dim3(EMD_T), 0, st, n, m, cof(j), cof(j - 1), w, cost, g1, buf);

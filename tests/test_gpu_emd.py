@@ -92,7 +92,8 @@ def test_three_call_path_vs_oracle(dev, B, n, m):
 
 
 @pytest.mark.parametrize("near", [False, True])
-@pytest.mark.parametrize("B,n,m", [(3, 128, 128), (4, 64, 64), (2, 256, 128), (2, 100, 300), (2, 1024, 1024), (1, 2048, 2048)])
+@pytest.mark.parametrize("B,n,m", [(3, 128, 128), (4, 64, 64), (2, 256, 128), (2, 100, 300), (2, 1024, 1024), (1, 2048, 2048),
+                                   (1, 513, 200), (2, 300, 1000)])
 def test_fused_path_vs_oracle(dev, B, n, m, near):
     """near=False: independent uniform clouds (what an untrained model produces), cost to 1e-4.
     near=True: xyz2 is a jittered permutation of xyz1 (a converged registration): the optimum is a
@@ -113,6 +114,29 @@ def test_fused_path_vs_oracle(dev, B, n, m, near):
     assert _rel(cost.detach().cpu().numpy(), ocost) < (1e-3 if near else RTOL)
     gc = rng.standard_normal(B).astype(np.float32)
     (cost * _t(gc, dev)).sum().backward()
+    o1, o2 = orc.emd_matchcost_grad(gc, x1, x2, omatch)
+    assert _grad_close(t1.grad.cpu().numpy(), o1)
+    assert _grad_close(t2.grad.cpu().numpy(), o2)
+
+
+def test_fused_path_exhausted_points(dev):
+    """The general path walks only the points of cloud 2 that still hold mass (emd.hip, emd_compact_kernel).  Clouds
+    built so that the active list shrinks unevenly: cloud 2 = a few tight clusters (whole clusters run out of mass at
+    the sharp levels) plus duplicates of single points, and one pair whose cloud 2 is ONE point repeated."""
+    from puzzlenet_amd import ops
+    rng = np.random.default_rng(77)
+    B, n, m = 3, 640, 384
+    x1 = rng.random((B, n, 3), dtype=np.float32)
+    centres = rng.random((B, 6, 3), dtype=np.float32)
+    x2 = (centres[:, rng.integers(0, 6, m)] + 0.003 * rng.standard_normal((B, m, 3))).astype(np.float32)
+    x2[:, 100:140] = x2[:, 100:101]          # 40 copies of one point
+    x2[2] = x2[2, :1]                        # a degenerate cloud
+    t1, t2 = _t(x1, dev).requires_grad_(True), _t(x2, dev).requires_grad_(True)
+    cost = ops.emd_fused(t1, t2)
+    ocost, omatch = orc.earth_mover_distance(x1, x2)
+    assert _rel(cost.detach().cpu().numpy(), ocost) < RTOL
+    gc = np.ones(B, np.float32)
+    cost.sum().backward()
     o1, o2 = orc.emd_matchcost_grad(gc, x1, x2, omatch)
     assert _grad_close(t1.grad.cpu().numpy(), o1)
     assert _grad_close(t2.grad.cpu().numpy(), o2)
