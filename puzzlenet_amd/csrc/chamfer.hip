@@ -9,9 +9,8 @@
 // following the same formula keeps the mean of the minima within 1e-4.
 //
 // Layout: one launch packs both clouds to float4 {x, y, z, |p|^2}; then one
-// thread owns one point of the "row" cloud and walks the other cloud with a
-// wave-uniform index, so the walked points arrive through the scalar cache as
-// SGPR operands (s_load_dwordx16 = 4 points) — no LDS.  The same kernel runs
+// lane owns one point of the "row" cloud and walks the other cloud with a
+// wave-uniform index out of LDS tiles.  The same kernel runs
 // twice with the roles swapped; a*b and (ra+rb) are commutative, so both passes
 // see bit-identical P entries.  arg-mins are kept for the backward.
 #include "pzn_common.h"
@@ -35,26 +34,67 @@ __global__ __launch_bounds__(CH_T) void chamfer_pack_kernel(const float* __restr
 }
 
 // rows[B,nr], cols[B,nc]: out_min[b,r] = min_c P(r,c), out_arg[b,r] = first arg-min.
+// A workgroup = 4 wavefronts that own the SAME 64 rows; the walked cloud goes through LDS in 512-point tiles
+// (double-buffered, one barrier per tile) and each wavefront scans one quarter of every tile with a wave-uniform
+// index (broadcast ds_read_b128), keeping its first minimum; the four candidates meet in LDS, ties to the lower
+// index.  (The first version — one thread per row, the walked points as SGPR operands through the scalar cache —
+// ran 2 waves per SIMD and every wave of a pair streamed the same 32 KB through that small shared cache: 180 us
+// per direction at 64 x 2048 x 2048 against ~55 us of vector issue.)
+constexpr int CH_TL = 512;   // points per tile
+constexpr int CH_ROWS = 64;  // rows per workgroup
 __global__ __launch_bounds__(CH_T) void chamfer_rowmin_kernel(const float4* __restrict__ rows,
                                                               const float4* __restrict__ cols, int nr, int nc,
                                                               float* __restrict__ out_min,
                                                               int32_t* __restrict__ out_arg) {
-  const int b = blockIdx.y;
-  const int r = blockIdx.x * CH_T + threadIdx.x;
+  __shared__ float4 tile[2][CH_TL];
+  __shared__ float rmin[CH_T];
+  __shared__ int ridx[CH_T];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+  const int r = blockIdx.x * CH_ROWS + lane;
   const float4* __restrict__ other = cols + (size_t)b * nc;
-  float4 me = r < nr ? rows[(size_t)b * nr + r] : make_float4(0, 0, 0, 0);
+  const float4 me = r < nr ? rows[(size_t)b * nr + r] : make_float4(0, 0, 0, 0);
   float best = INFINITY;
   int bi = 0;
+  auto stage = [&](int tb, int base) {
+#pragma unroll
+    for (int i = 0; i < CH_TL / CH_T; ++i) {
+      const int c = base + i * CH_T + threadIdx.x;
+      if (c < nc) tile[tb][i * CH_T + threadIdx.x] = other[c];
+    }
+  };
+  const int ntile = (nc + CH_TL - 1) / CH_TL;
+  stage(0, 0);
+  __syncthreads();
+  for (int t = 0; t < ntile; ++t) {
+    const int base = t * CH_TL;
+    const int cnt = min(CH_TL, nc - base);
+    if (t + 1 < ntile) stage((t + 1) & 1, base + CH_TL);
+    const float4* tp = tile[t & 1];
+    const int per = (cnt + 3) >> 2;
+    const int q0 = min(cnt, wq * per), q1 = min(cnt, q0 + per);
 #pragma unroll 4
-  for (int c = 0; c < nc; ++c) {
-    float4 o = other[c];
-    float zz = fmaf(me.z, o.z, fmaf(me.y, o.y, me.x * o.x));
-    float P = fmaf(-2.f, zz, me.w + o.w);
-    bool lt = P < best;
-    best = lt ? P : best;
-    bi = lt ? c : bi;
+    for (int q = q0; q < q1; ++q) {
+      const float4 o = tp[q];
+      const float zz = fmaf(me.z, o.z, fmaf(me.y, o.y, me.x * o.x));
+      const float P = fmaf(-2.f, zz, me.w + o.w);
+      const bool lt = P < best;
+      best = lt ? P : best;
+      bi = lt ? base + q : bi;
+    }
+    __syncthreads();
   }
-  if (r < nr) {
+  rmin[threadIdx.x] = best;
+  ridx[threadIdx.x] = bi;
+  __syncthreads();
+  if (wq == 0 && r < nr) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float v = rmin[w * 64 + lane];
+      const int vi = ridx[w * 64 + lane];
+      const bool take = v < best || (v == best && vi < bi);
+      best = take ? v : best;
+      bi = take ? vi : bi;
+    }
     out_min[(size_t)b * nr + r] = best;
     out_arg[(size_t)b * nr + r] = bi;
   }
@@ -116,10 +156,10 @@ PZN_EXPORT int pzn_chamfer_fwd_f32(const float* a, const float* b, int B, int n,
   hipLaunchKernelGGL(chamfer_pack_kernel, dim3((unsigned)((mx + CH_T - 1) / CH_T)), dim3(CH_T), 0, st, a, b, na, nb, pa,
                      pb);
   // torch.min(P, 2): per a-point, min over b
-  hipLaunchKernelGGL(chamfer_rowmin_kernel, dim3((n + CH_T - 1) / CH_T, B), dim3(CH_T), 0, st, pa, pb, n, m,
+  hipLaunchKernelGGL(chamfer_rowmin_kernel, dim3((n + CH_ROWS - 1) / CH_ROWS, B), dim3(CH_T), 0, st, pa, pb, n, m,
                      min_over_b, arg_over_b);
   // torch.min(P, 1): per b-point, min over a
-  hipLaunchKernelGGL(chamfer_rowmin_kernel, dim3((m + CH_T - 1) / CH_T, B), dim3(CH_T), 0, st, pb, pa, m, n,
+  hipLaunchKernelGGL(chamfer_rowmin_kernel, dim3((m + CH_ROWS - 1) / CH_ROWS, B), dim3(CH_T), 0, st, pb, pa, m, n,
                      min_over_a, arg_over_a);
   PZN_RETURN_LAUNCH_STATUS();
 }
