@@ -865,6 +865,76 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ io
   for (int c = lane; c < cols; c += 64) x[c] = x[c] / s;
 }
 
+// Rows of up to 64*PER columns stay in registers: one read and one write of the row (same arithmetic, same order).
+template <int PER>
+__global__ __launch_bounds__(256) void softmax_fwd_reg_kernel(float* __restrict__ io, long rows, int cols, float div) {
+  const int lane = threadIdx.x & 63;
+  long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float* x = io + r * cols;
+  float v[PER];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < cols ? x[c] / div : -INFINITY;
+    m = fmaxf(m, v[i]);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < cols ? expf(v[i] - m) : 0.f;
+    s += v[i];
+  }
+  s = pzn::wave_sum_f32(s);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = lane + 64 * i;
+    if (c < cols) x[c] = v[i] / s;
+  }
+}
+
+template <int PER>
+__global__ __launch_bounds__(256) void softmax_bwd_reg_kernel(const float* __restrict__ attn, float* __restrict__ io,
+                                                              const float* __restrict__ extra, long rows, int cols,
+                                                              float div) {
+  const int lane = threadIdx.x & 63;
+  long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* a = attn + r * cols;
+  float* d = io + r * cols;
+  const float* e = extra ? extra + r * cols : nullptr;
+  float g[PER], av[PER];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = lane + 64 * i;
+    const bool ok = c < cols;
+    av[i] = ok ? a[c] : 0.f;
+    g[i] = ok ? d[c] + (e ? e[c] : 0.f) : 0.f;
+    s += g[i] * av[i];
+  }
+  s = pzn::wave_sum_f32(s);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = lane + 64 * i;
+    if (c < cols) d[c] = av[i] * (g[i] - s) / div;
+  }
+}
+
+void launch_softmax_fwd(float* io, long rows, int cols, float div, hipStream_t st) {
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (cols <= 256)
+    hipLaunchKernelGGL(softmax_fwd_reg_kernel<4>, grid, block, 0, st, io, rows, cols, div);
+  else if (cols <= 512)
+    hipLaunchKernelGGL(softmax_fwd_reg_kernel<8>, grid, block, 0, st, io, rows, cols, div);
+  else
+    hipLaunchKernelGGL(softmax_fwd_kernel, grid, block, 0, st, io, rows, cols, div);
+}
+
 // bwd: io[r,:] (= dAttn, optionally + extra) -> dLogits = attn * (dAttn - sum(dAttn * attn)) / div
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ attn, float* __restrict__ io,
                                                           const float* __restrict__ extra, long rows, int cols,
@@ -885,6 +955,17 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   for (int c = lane; c < cols; c += 64) d[c] = a[c] * (d[c] - s) / div;
 }
 
+void launch_softmax_bwd(const float* attn, float* io, const float* extra, long rows, int cols, float div,
+                        hipStream_t st) {
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (cols <= 256)
+    hipLaunchKernelGGL(softmax_bwd_reg_kernel<4>, grid, block, 0, st, attn, io, extra, rows, cols, div);
+  else if (cols <= 512)
+    hipLaunchKernelGGL(softmax_bwd_reg_kernel<8>, grid, block, 0, st, attn, io, extra, rows, cols, div);
+  else
+    hipLaunchKernelGGL(softmax_bwd_kernel, grid, block, 0, st, attn, io, extra, rows, cols, div);
+}
+
 }  // namespace
 
 // scaled_dot_production (model5_b.py:67-75): attn[B,L,L] = softmax(q k^T / sqrt(dk)), out[B,L,dv] = attn v
@@ -894,8 +975,7 @@ PZN_EXPORT int pzn_attn_fwd_f32(const float* q, const float* k, const float* v, 
   int rc = pzn_bgemm_f32(0, q, k, attn, B, L, L, dk, 1.f, stream);
   if (rc != PZN_OK) return rc;
   long rows = (long)B * L;
-  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, pzn_hip_stream(stream), attn,
-                     rows, L, sqrtf((float)dk));
+  launch_softmax_fwd(attn, rows, L, sqrtf((float)dk), pzn_hip_stream(stream));
   if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
   return pzn_bgemm_f32(1, attn, v, out, B, L, dv, L, 1.f, stream);
 }
@@ -918,8 +998,7 @@ PZN_EXPORT int pzn_attn_bwd_f32(const float* q, const float* k, const float* v, 
   rc = pzn_bgemm_f32(0, d_out, v, ds, B, L, L, dv, 1.f, stream);  // dAttn = dO V^T
   if (rc != PZN_OK) return rc;
   long rows = (long)B * L;
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, pzn_hip_stream(stream), attn,
-                     ds, d_attn, rows, L, sqrtf((float)dk));
+  launch_softmax_bwd(attn, ds, d_attn, rows, L, sqrtf((float)dk), pzn_hip_stream(stream));
   if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
   rc = pzn_bgemm_f32(1, ds, k, dq, B, L, dk, L, 1.f, stream);  // dQ = dS K
   if (rc != PZN_OK) return rc;
@@ -961,8 +1040,7 @@ PZN_EXPORT int pzn_attn_block_fwd_f32(const float* x, const float* Wq, const flo
   if (rc == PZN_OK) rc = pzn_bgemm_f32(0, q, k, attn, B, L, L, dk, 1.f, stream);
   if (rc != PZN_OK) return rc;
   const long rows = (long)B * L;
-  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, attn, rows, L,
-                     sqrtf((float)dk));
+  launch_softmax_fwd(attn, rows, L, sqrtf((float)dk), st);
   if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
   {  // r = x - attn v
     GemmArgs p = base_args(L, E, L);
@@ -1007,8 +1085,7 @@ PZN_EXPORT int pzn_attn_block_bwd_f32(const float* x, const float* Wq, const flo
   if (rc == PZN_OK) rc = pzn_bgemm_f32(0, dd, v, ds, B, L, L, E, -1.f, stream);        // dAttn = dO V^T
   if (rc != PZN_OK) return rc;
   const long rows = (long)B * L;
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, attn, ds, dattn, rows, L,
-                     sqrtf((float)dk));
+  launch_softmax_bwd(attn, ds, dattn, rows, L, sqrtf((float)dk), st);
   if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
   rc = pzn_bgemm_f32(1, ds, k, dq, B, L, dk, L, 1.f, stream);                           // dQ = dS K
   if (rc == PZN_OK) rc = pzn_bgemm_f32(2, ds, q, dkk, B, L, dk, L, 1.f, stream);        // dK = dS^T Q
