@@ -30,6 +30,7 @@ SOURCES = [
     ("dfgemm.hip", []),
     ("optim.hip", ["-ffp-contract=off"]),
     ("se3.hip", []),
+    ("sapoint.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]

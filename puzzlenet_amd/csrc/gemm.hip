@@ -1150,6 +1150,13 @@ static int pool_layer_bwd(const float* dout, const int32_t* argmax, const float*
   return pzn_linear_maxpool_wgrad_f32(dout, argmax, out, h, R, C1, C2, dW2, db2, accumulate, stream);
 }
 
+PZN_EXPORT int pzn_pooled_layer_bwd_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
+                                        const float* h, int R, int C1, int C2, float* dh, float* dW2, float* db2,
+                                        int accumulate, pzn_stream_t stream) {
+  PZN_CHECK_ARG(dout && argmax && out && W2 && h && dh && dW2 && db2 && R > 0 && C1 > 0 && C2 > 0);
+  return pool_layer_bwd(dout, argmax, out, W2, h, R, C1, C2, dh, dW2, db2, accumulate, stream);
+}
+
 // Backward: dh_ws is [R*32, C1] scratch; dx may be NULL.  dW*, db* are overwritten.
 PZN_EXPORT int pzn_sharedmlp_max_bwd_f32(const float* x, const float* W1, const float* W2, const float* h,
                                          const float* out, const int32_t* argmax, const float* dout, int R, int C0,

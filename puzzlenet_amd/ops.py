@@ -4,6 +4,7 @@ torch is used for device memory, the current HIP stream and autograd plumbing
 only: every computation below is a call into libpzn.so with raw device
 pointers.  Inputs must live on a HIP device; there is no CPU path.
 """
+import os
 import weakref
 
 import torch
@@ -709,5 +710,92 @@ class _SaMlpMax(torch.autograd.Function):
         return None, dfeat, None, None, dW1, db1, dW2, db2
 
 
+class _SaMlpMaxPoint(torch.autograd.Function):
+    """The same set-abstraction level (model5_b.py:449-454 / :456-461) with the first shared-MLP layer computed per
+    POINT (csrc/sapoint.hip): a grouped row is {xyz[j] - centre, feat[j]}, so W1 row = W1[:,0:3] (xyz[j] - centre) +
+    (feat W1[:,3:]^T)[j]: the feature product runs on B*N rows instead of B*S*32, the grouped tensor is never written
+    and the layer becomes a gather of per-point rows; backward sums dh over each point's inverse neighbour list.
+    Same result as _SaMlpMax up to the order of the fp32 sum."""
+
+    @staticmethod
+    def forward(ctx, xyz, feat, new_xyz, idx, w1, b1, w2, b2):
+        xyz, feat, new_xyz = _f32(xyz, "xyz"), _f32(feat, "points"), _f32(new_xyz, "new_xyz")
+        idx = None if idx is None else _i64(idx, "idx")
+        w1, b1, w2, b2 = _f32(w1, "w1"), _f32(b1, "b1"), _f32(w2, "w2"), _f32(b2, "b2")
+        B, N, _ = xyz.shape
+        S = new_xyz.shape[1]
+        D = feat.shape[-1]
+        C1, C2 = w1.shape[0], w2.shape[0]
+        dev = xyz.device
+        R = B * S
+        w_f = w1[:, 3:].contiguous()
+        P = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
+        h = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
+        out = torch.empty((R, C2), dtype=torch.float32, device=dev)
+        arg = torch.empty((R, C2), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _call("pzn_linear_fwd_f32", _p(feat), _p(w_f), None, B * N, D, C1, 0, _p(P), _stream(),
+                  flops=2 * B * N * D * C1)
+            if idx is None:
+                idx = torch.empty((B, S, 32), dtype=torch.int64, device=dev)
+                _call("pzn_knn_f32", _p(xyz), _p(new_xyz), B, N, S, 32, _p(idx), _stream())
+            _call("pzn_sa_point_l1_fwd_f32", _p(xyz), _p(new_xyz), _p(idx), _p(P), _p(w1), _p(b1), B, N, S, D, C1,
+                  _p(h), _stream())
+            _call("pzn_linear_maxpool_fwd_f32", _p(h), _p(w2), _p(b2), R, C1, C2, _p(out), _p(arg), _stream(),
+                  flops=2 * R * 32 * C1 * C2)
+        ctx.save_for_backward(xyz, feat, new_xyz, idx, w1, w_f, w2, h, out, arg)
+        ctx.dims = (B, N, S, D, R, C1, C2)
+        ctx.param_refs = (w1, b1, w2, b2)
+        return out.reshape(B, S, C2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xyz, feat, new_xyz, idx, w1, w_f, w2, h, out, arg = ctx.saved_tensors
+        B, N, S, D, R, C1, C2 = ctx.dims
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            raise _lib.PznError("sa_mlp_max: gradients w.r.t. point coordinates are not provided on the fused "
+                                "encoder path; use pointnet_util.sample_and_group + dense.shared_mlp_max")
+        dout = _f32(dout, "dout").reshape(R, C2)
+        dev = dout.device
+        need_feat = ctx.needs_input_grad[1]
+        sinks = [_sink(t, ctx.needs_input_grad[4 + i]) for i, t in enumerate(ctx.param_refs)]
+        direct = all(s_ is not None for s_ in sinks)
+        if direct:
+            dW1, db1, dW2, db2 = sinks
+        else:
+            dW1 = torch.zeros((C1, 3 + D), dtype=torch.float32, device=dev)    # the per-point kernel adds into these
+            db1 = torch.zeros((C1,), dtype=torch.float32, device=dev)
+            dW2 = torch.empty_like(w2)
+            db2 = torch.empty((C2,), dtype=torch.float32, device=dev)
+        dh = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
+        off = torch.empty((B * (N + 1),), dtype=torch.int32, device=dev)
+        rows = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
+        dP = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
+        dwf = torch.empty((C1, D), dtype=torch.float32, device=dev)
+        dfeat = None
+        with torch.cuda.device(dev):
+            _call("pzn_pooled_layer_bwd_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(h), R, C1, C2, _p(dh), _p(dW2), _p(db2),
+                  int(direct), _stream(), flops=2 * R * (2 * C1 * C2))
+            _call("pzn_knn_inverse_lists", _p(idx), B, N, S, 32, _p(off), _p(rows), _stream())
+            _call("pzn_sa_point_l1_bwd_f32", _p(dh), _p(xyz), _p(new_xyz), _p(off), _p(rows), B, N, S, D, C1, _p(dP),
+                  _p(dW1), _p(db1), _stream())
+            if need_feat:
+                dfeat = torch.empty((B, N, D), dtype=torch.float32, device=dev)
+                _call("pzn_linear_dgrad_f32", _p(dP), None, _p(w_f), B * N, D, C1, None, _p(dfeat), _stream(),
+                      flops=2 * B * N * D * C1)
+            _call("pzn_linear_wgrad_f32", _p(dP), None, _p(feat), B * N, D, C1, _p(dwf), None, 0, _stream(),
+                  flops=2 * B * N * D * C1)
+        dW1[:, 3:].add_(dwf)
+        if direct:
+            return None, dfeat, None, None, None, None, None, None
+        return None, dfeat, None, None, dW1, db1, dW2, db2
+
+
+_SA_POINT = os.environ.get("PZN_SA_POINT", "1") != "0"     # tuning aid: 0 = the grouped-row path (_SaMlpMax)
+
+
 def sa_mlp_max(xyz, feat, new_xyz, idx, w1, b1, w2, b2):
+    K = 32 if idx is None else idx.shape[2]
+    if _SA_POINT and K == 32 and w1.shape[0] in (64, 128, 256) and w1.shape[1] == 3 + feat.shape[-1]:
+        return _SaMlpMaxPoint.apply(xyz, feat, new_xyz, idx, w1, b1, w2, b2)
     return _SaMlpMax.apply(xyz, feat, new_xyz, idx, w1, b1, w2, b2)
