@@ -51,6 +51,37 @@ def knn_group_bytes(N, S, K, D):
     return 12 * N + 4 * N * D + 12 * S + 8 * S * K + 4 * S * K * (D + 3)
 
 
+def time_knn_group_api(batch, dev, reps):
+    """The drop-in grouping stage (pointnet_util.sample_and_group on the encoder's two levels: neighbour search +
+    materialised grouped tensor, one launch each) timed on its own on the step's clouds: the model's fused path no
+    longer materialises the grouped tensor (csrc/sapoint.hip), the API does.  Returns KernelTimer records for
+    `reps` step-equivalents (2 encoders x 2 levels each)."""
+    from puzzlenet_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(7)
+    clouds = [batch[0], batch[1]]
+    work = []
+    for xyz in clouds:
+        xyz = xyz.contiguous()
+        Bc, Nc, _ = xyz.shape
+        for (n, s, d) in ((Nc, 512, 64), (512, 256, 128)):
+            x = xyz[:, :n].contiguous()
+            feat = torch.randn(Bc, n, d, generator=g).to(dev)
+            new_xyz = x[:, :s].contiguous()
+            idx = torch.empty((Bc, s, 32), dtype=torch.int64, device=dev)
+            xg = torch.empty((Bc * s * 32, 4 + d), dtype=torch.float32, device=dev)
+            work.append((x, feat, new_xyz, Bc, n, s, d, idx, xg))
+    def run():
+        for (x, feat, new_xyz, Bc, n, s, d, idx, xg) in work:
+            ops._call("pzn_knn_group_pad_f32", ops._p(x), ops._p(feat), ops._p(new_xyz), Bc, n, s, d, ops._p(idx),
+                      ops._p(xg), ops._stream())
+    run()
+    torch.cuda.synchronize()
+    ops.KernelTimer.start()
+    for _ in range(reps):
+        run()
+    return ops.KernelTimer.stop()
+
+
 def cpu_baseline(N, pairs, iters):
     """The reference's algorithm on the host cores: oracle/model_ref.py (torch CPU ops in the
     reference's own sequence) + the C EMD restatement.  Bounded sample of the same workload."""
@@ -169,24 +200,28 @@ def main():
         for _ in range(prof_steps):
             eager.step()
         kern = ops.KernelTimer.stop()
+        kern_flops = dict(ops.KernelTimer.flops)
+        kern_api = time_knn_group_api(batch, dev, prof_steps)
 
     if rank == 0:
         # (1) the dominant kernel of the step: the matrix-core tile engine (csrc/gemm.hip), MFMA-bound.
         #     achieved = algorithmic 2*M*N*K of every dense entry point / their summed launch durations.
         dense_names = ("pzn_linear_fwd_f32", "pzn_linear_dgrad_f32", "pzn_linear_wgrad_f32",
+                       "pzn_linear_maxpool_fwd_f32", "pzn_pooled_layer_bwd_f32",
                        "pzn_sharedmlp_max_fwd_f32", "pzn_sa_mlp_max_bwd_f32", "pzn_sa_mlp_max_bwd_scatter_f32",
                        "pzn_attn_fwd_f32", "pzn_attn_bwd_f32", "pzn_attn_block_fwd_f32", "pzn_attn_block_bwd_f32")
         d_ms = sum(kern.get(k, (0, 0.0))[1] for k in dense_names)
-        d_fl = sum(ops.KernelTimer.flops.get(k, 0) for k in dense_names)
+        d_fl = sum(kern_flops.get(k, 0) for k in dense_names)
         d_n = sum(kern.get(k, (0, 0.0))[0] for k in dense_names)
         mfma_achieved = d_fl / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
         roofline = {
             "bound": "mfma",
             "kernel": "the bf16x3 split-precision matrix-core kernels (fp32 result): ws_gemm_kernel (weight-stationary, forward / "
                       "input gradients of the skinny layers), df_wgrad_kernel (direct-fragment weight gradients), gemm_kernel "
-                      "(general tile engine: wide layers, attention products) behind pzn_linear_* / pzn_sharedmlp_max_fwd / "
-                      "pzn_sa_mlp_max_bwd* / pzn_attn_*; the time also contains the sparse max-pool backward and scatter "
-                      "epilogues of those entry points, the flops do not",
+                      "(general tile engine: wide layers, attention products) behind pzn_linear_* / pzn_linear_maxpool_fwd / "
+                      "pzn_pooled_layer_bwd / pzn_attn_*; the time also contains the sparse max-pool backward kernels of "
+                      "pzn_pooled_layer_bwd, the flops do not; the first set-abstraction layer is counted as the per-point "
+                      "product it now is (B*N rows, csrc/sapoint.hip), not as the B*S*32-row product of the reference",
             "achieved": mfma_achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": mfma_achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
             "algorithmic_flops_per_step": d_fl / max(1, prof_steps),
@@ -197,9 +232,15 @@ def main():
         }
         # (2) the stage the north star names: kNN + group (HBM-bound), SURVEY 8(d) bytes.
         per_pair = 2 * (knn_group_bytes(N, 512, 32, 64) + knn_group_bytes(512, 256, 32, 128))
-        if "pzn_knn_group_pad_f32" in kern:       # kNN + group fused into one launch (the model path)
+        if "pzn_knn_group_pad_f32" in kern:       # kNN + group fused into one launch (PZN_SA_POINT=0: the grouped-row model path)
             n_st, ms_st = kern["pzn_knn_group_pad_f32"]
             stage_names = "knn_group_pad_kernel (pzn_knn_group_pad_f32: neighbour search + group write in one launch, 4 launches/step)"
+            avg_launch = {"knn_group_pad_kernel": ms_st / max(1, n_st)}
+        elif "pzn_knn_group_pad_f32" in kern_api:  # the drop-in stage, timed on its own (the model path gathers per-point rows instead)
+            n_st, ms_st = kern_api["pzn_knn_group_pad_f32"]
+            stage_names = ("knn_group_pad_kernel (pzn_knn_group_pad_f32: neighbour search + group write in one launch), the "
+                           "sample_and_group drop-in stage timed ON ITS OWN on the step's clouds (4 launches per step-equivalent); "
+                           "the training step itself no longer materialises the grouped tensor, see roofline_sa_gather")
             avg_launch = {"knn_group_pad_kernel": ms_st / max(1, n_st)}
         else:
             n_knn, ms_knn = kern.get("pzn_knn_f32", (0, 0.0))
@@ -220,6 +261,27 @@ def main():
             "algorithmic_bytes_per_step": per_pair * B,
             "avg_launch_ms": avg_launch,
         }
+        # (3) the HBM-bound stage of the model path: first set-abstraction layer as a gather of per-point rows.
+        #     bytes per level and cloud: forward h write + P read + idx; backward dh read + dP write + inverse lists.
+        def gather_bytes(n, s, c1):
+            rows = s * 32
+            fwd = 4 * rows * c1 + 4 * n * c1 + 8 * rows + 12 * (n + s)
+            bwd = 4 * rows * c1 + 4 * n * c1 + 4 * rows + 4 * (n + 1) + 12 * (n + s)
+            return fwd, bwd
+        gf1, gb1 = gather_bytes(N, 512, 128)
+        gf2, gb2 = gather_bytes(512, 256, 256)
+        g_bytes = 2 * B * (gf1 + gb1 + gf2 + gb2)
+        n_gf, ms_gf = kern.get("pzn_sa_point_l1_fwd_f32", (0, 0.0))
+        n_gb, ms_gb = kern.get("pzn_sa_point_l1_bwd_f32", (0, 0.0))
+        g_ms = (ms_gf + ms_gb) / max(1, prof_steps)
+        g_ach = g_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+        roofline_sa_gather = {
+            "bound": "hbm", "kernel": "sa_point_l1_fwd_kernel / sa_point_l1_bwd_kernel (pzn_sa_point_l1_{fwd,bwd}_f32: first "
+                                      "set-abstraction layer as a gather of per-point rows / a sum over inverse neighbour lists)",
+            "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g_ach / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_step": g_bytes,
+            "avg_launch_ms": {"sa_point_l1_fwd_kernel": ms_gf / max(1, n_gf), "sa_point_l1_bwd_kernel": ms_gb / max(1, n_gb)},
+        }
         stages = {k: {"launches_per_step": n / prof_steps, "ms_per_step": ms / prof_steps} for k, (n, ms) in sorted(kern.items())}
         out = {
             "metric": "point-cloud pairs/sec (fwd+bwd) at N=2048, B=64; FPS/kNN idx bit-exact",
@@ -231,6 +293,7 @@ def main():
                        "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "hip_graph": use_graph, "encoder_streams": 2},
             "roofline": roofline,
             "roofline_knn_group": roofline_knn_group,
+            "roofline_sa_gather": roofline_sa_gather,
             "stages": stages,
             "loss": loss_val,
         }

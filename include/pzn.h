@@ -264,8 +264,9 @@ int pzn_sa_mlp_max_bwd_scatter_f32(const float* xg, const float* W1p, const floa
  * tensor is never materialised.  Same result up to the order of the fp32 sum.  K = 32, C1 in {64,128,256}.
  *   fwd:  h[B*S*32, C1] = relu(W1[:,0:3] (xyz[idx] - new_xyz) + P[idx] + b1);  W1 in the PARAMETER layout
  *         [C1, 3+D] (only its first three columns are read), P[B*N, C1], idx[B,S,32] from pzn_knn_f32.
- *   pzn_knn_inverse_lists: off[B, N+1], rows[B, S*K]: for every point the in-cloud rows (s*K + k) that
- *         gathered it (index_points backward without atomics on rows).
+ *   pzn_knn_inverse_lists: the B*S*K (row, point) pairs of idx sorted by point, per cloud: rows[B, S*K] = in-cloud
+ *         row numbers (s*K + k), pts[B, S*K] = the point each gathered (may be NULL), off[B, N+1] = where every
+ *         point's rows start (index_points backward without atomics on rows).
  *   bwd:  dP[B*N, C1] = sum of dh over the rows that gathered each point;  dW1[:,0:3] += dh^T (xyz[idx] -
  *         new_xyz), db1 += column sums (both ADDED to; db1 may be NULL).  dfeat = dP W1[:,3:] and
  *         dW1[:,3:] += dP^T feat are plain pzn_linear_dgrad / wgrad calls on B*N rows. */
@@ -273,9 +274,9 @@ int pzn_sa_point_l1_fwd_f32(const float* xyz, const float* new_xyz, const int64_
                             const float* P, const float* W1, const float* b1, int B, int N,
                             int S, int D, int C1, float* h, pzn_stream_t stream);
 int pzn_knn_inverse_lists(const int64_t* idx, int B, int N, int S, int K, int32_t* off,
-                          int32_t* rows, pzn_stream_t stream);
+                          int32_t* rows, int32_t* pts, pzn_stream_t stream);
 int pzn_sa_point_l1_bwd_f32(const float* dh, const float* xyz, const float* new_xyz,
-                            const int32_t* off, const int32_t* rows, int B, int N, int S, int D,
+                            const int32_t* rows, const int32_t* pts, int B, int N, int S, int D,
                             int C1, float* dP, float* dW1, float* db1, pzn_stream_t stream);
 /* Second (pooled) layer backward alone (model5_b.py:453-454 / :460-461): dh[R*32,C1] = ReLU-masked (by h)
  * gradient of the first layer's output, dW2[C2,C1], db2[C2] (overwritten, or added to when accumulate). */

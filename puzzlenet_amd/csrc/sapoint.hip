@@ -12,6 +12,8 @@
 //     dfeat = dP W1[:,3:],   dW1[:,3:] += dP^T feat                               (two per-point GEMMs, callers)
 // The HBM bill of the layer: forward 1 write of h; backward 1 read of dh.  (The grouped-row path: forward reads
 // the grouped rows and writes h; backward reads dh twice, the grouped rows once, and scatter-adds B*S*32*D floats.)
+#include <stdlib.h>
+
 #include "pzn_common.h"
 
 namespace {
@@ -122,7 +124,8 @@ __global__ __launch_bounds__(SP_T) void sa_point_l1_fwd_kernel(const float* __re
 constexpr int INV_T = 1024;
 __global__ __launch_bounds__(INV_T) void sa_inverse_lists_kernel(const int64_t* __restrict__ idx, int N, int SK,
                                                                  int32_t* __restrict__ off,
-                                                                 int32_t* __restrict__ rows) {
+                                                                 int32_t* __restrict__ rows,
+                                                                 int32_t* __restrict__ pts) {
   extern __shared__ int cnt[];  // [N] counters, then [INV_T] scan scratch
   int* scan = cnt + N;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -155,23 +158,31 @@ __global__ __launch_bounds__(INV_T) void sa_inverse_lists_kernel(const int64_t* 
   if (tid == INV_T - 1) ob[N] = scan[INV_T - 1];
   __syncthreads();
   int32_t* rb = rows + (size_t)b * SK;
+  int32_t* pb = pts ? pts + (size_t)b * SK : nullptr;
   for (int i = tid; i < SK; i += INV_T) {
-    const int pos = atomicAdd(&cnt[(int)ib[i]], 1);
+    const int j = (int)ib[i];
+    const int pos = atomicAdd(&cnt[j], 1);
     rb[pos] = i;
+    if (pb) pb[pos] = j;
   }
 }
 
-// dP and the xyz / bias part of the first layer's gradients.  A wavefront per point: the rows that gathered it come
-// out of the inverse list 64 at a time (lane l holds row l and its centre offset), then one coalesced read of
-// dh[row, :] per row, all lanes on the C1 = 64*V channels.  The four per-channel sums for dW1[:,0:3] and db1 stay in
-// registers over all points of the wavefront and meet in LDS at the end: one set of atomics per workgroup.
-template <int V>
+// dP and the xyz / bias part of the first layer's gradients.  The inverse lists are one array of B*S*32 entries
+// (row, point) sorted by point; a wavefront takes 64 consecutive entries: lane l fetches entry l (row, point, the
+// row's centre offset) up front, then the dh rows are read one after the other, all lanes on the C1 = 64*V
+// channels (coalesced), and summed until the point changes.  Points wholly inside the wavefront's range are
+// stored, the first and last one (their lists may continue in the neighbouring ranges) are added atomically into
+// the zero-initialised dP.  The four per-channel sums for dW1[:,0:3] and db1 stay in registers over the whole
+// range and meet in LDS at the end: one set of atomics per workgroup.
+// (A first version walked point by point: off -> rows -> centre -> dh is a chain of dependent loads per point,
+// 0.30 ms for the 537 MB of dh at level 2.)
+template <int V, int G>
 __global__ __launch_bounds__(SP_T) void sa_point_l1_bwd_kernel(const float* __restrict__ dh,
                                                                const float* __restrict__ xyz,
                                                                const float* __restrict__ new_xyz,
-                                                               const int32_t* __restrict__ off,
-                                                               const int32_t* __restrict__ rows, int N, int S,
-                                                               long npoints, float* __restrict__ dP,
+                                                               const int32_t* __restrict__ rows,
+                                                               const int32_t* __restrict__ pts, int N, int S,
+                                                               long entries, float* __restrict__ dP,
                                                                float* __restrict__ dW1, int ldw,
                                                                float* __restrict__ db1) {
   constexpr int C1 = 64 * V;
@@ -182,56 +193,67 @@ __global__ __launch_bounds__(SP_T) void sa_point_l1_bwd_kernel(const float* __re
   float ax[V], ay[V], az[V], ab[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) ax[i] = ay[i] = az[i] = ab[i] = 0.f;
-  for (long p = gw; p < npoints; p += nw) {
-    const long b = p / N;
-    const int j = (int)(p - b * N);
-    const int32_t* ob = off + (size_t)b * (N + 1) + j;
-    const int o0 = ob[0], o1 = ob[1];
-    const float px = xyz[(size_t)p * 3], py = xyz[(size_t)p * 3 + 1], pz = xyz[(size_t)p * 3 + 2];
+  const long nbatch = (entries + 63) >> 6;
+  for (long bt = gw; bt < nbatch; bt += nw) {
+    const long e = bt * 64 + lane;
+    int grow = 0, gp = -1;  // global row of dh, global point
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (e < entries) {
+      const long b = e / SK;
+      const int rid = rows[e], pj = pts[e];
+      grow = (int)(b * SK + rid);
+      gp = (int)(b * N + pj);
+      const float* q = xyz + (size_t)gp * 3;
+      const float* c = new_xyz + ((size_t)b * S + (rid >> 5)) * 3;
+      dx = q[0] - c[0], dy = q[1] - c[1], dz = q[2] - c[2];
+    }
+    const int nr = (int)min((long)64, entries - bt * 64);
+    const int first = __builtin_amdgcn_readlane(gp, 0), last = __builtin_amdgcn_readlane(gp, nr - 1);
+    int cur = first;
     float acc[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) acc[i] = 0.f;
-    for (int base = o0; base < o1; base += 64) {
-      const int m = min(64, o1 - base);
-      int rid = 0;
-      float dx = 0.f, dy = 0.f, dz = 0.f;
-      if (lane < m) {
-        rid = rows[(size_t)b * SK + base + lane];
-        const float* c = new_xyz + ((size_t)b * S + (rid >> 5)) * 3;
-        dx = px - c[0], dy = py - c[1], dz = pz - c[2];
-      }
-      auto take = [&](const float (&g)[V], int r) {
-        const float rx = bcast(dx, r), ry = bcast(dy, r), rz = bcast(dz, r);
+    auto flush = [&](int point) {
+      float* o = dP + (size_t)point * C1 + lane * V;
+      if (point == first || point == last) {
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-          acc[i] += g[i];
-          ax[i] = fmaf(g[i], rx, ax[i]);
-          ay[i] = fmaf(g[i], ry, ay[i]);
-          az[i] = fmaf(g[i], rz, az[i]);
-        }
-      };
-      const float* dhb = dh + (size_t)b * SK * C1 + lane * V;
-      int r = 0;
-      for (; r + 4 <= m; r += 4) {  // four dh rows in flight
-        float g0[V], g1[V], g2[V], g3[V];
-        load_vec<V>(dhb + (size_t)__builtin_amdgcn_readlane(rid, r) * C1, g0);
-        load_vec<V>(dhb + (size_t)__builtin_amdgcn_readlane(rid, r + 1) * C1, g1);
-        load_vec<V>(dhb + (size_t)__builtin_amdgcn_readlane(rid, r + 2) * C1, g2);
-        load_vec<V>(dhb + (size_t)__builtin_amdgcn_readlane(rid, r + 3) * C1, g3);
-        take(g0, r);
-        take(g1, r + 1);
-        take(g2, r + 2);
-        take(g3, r + 3);
+        for (int i = 0; i < V; ++i) atomicAdd(o + i, acc[i]);
+      } else {
+        store_vec<V>(o, acc);
       }
-      for (; r < m; ++r) {
-        float g0[V];
-        load_vec<V>(dhb + (size_t)__builtin_amdgcn_readlane(rid, r) * C1, g0);
-        take(g0, r);
+#pragma unroll
+      for (int i = 0; i < V; ++i) ab[i] += acc[i], acc[i] = 0.f;
+    };
+    auto take = [&](const float (&g)[V], int r) {
+      const int pj = __builtin_amdgcn_readlane(gp, r);
+      if (pj != cur) {  // wave-uniform
+        flush(cur);
+        cur = pj;
       }
+      const float rx = bcast(dx, r), ry = bcast(dy, r), rz = bcast(dz, r);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        acc[i] += g[i];
+        ax[i] = fmaf(g[i], rx, ax[i]);
+        ay[i] = fmaf(g[i], ry, ay[i]);
+        az[i] = fmaf(g[i], rz, az[i]);
+      }
+    };
+    const float* dhl = dh + lane * V;
+    int r = 0;
+    for (; r + G <= nr; r += G) {  // G dh rows in flight
+      float g[G][V];
+#pragma unroll
+      for (int u = 0; u < G; ++u) load_vec<V>(dhl + (size_t)__builtin_amdgcn_readlane(grow, r + u) * C1, g[u]);
+#pragma unroll
+      for (int u = 0; u < G; ++u) take(g[u], r + u);
     }
-#pragma unroll
-    for (int i = 0; i < V; ++i) ab[i] += acc[i];
-    store_vec<V>(dP + (size_t)p * C1 + lane * V, acc);
+    for (; r < nr; ++r) {
+      float g0[V];
+      load_vec<V>(dhl + (size_t)__builtin_amdgcn_readlane(grow, r) * C1, g0);
+      take(g0, r);
+    }
+    flush(cur);
   }
 #pragma unroll
   for (int i = 0; i < V; ++i) {
@@ -264,8 +286,12 @@ PZN_EXPORT int pzn_sa_point_l1_fwd_f32(const float* xyz, const float* new_xyz, c
   if ((reinterpret_cast<uintptr_t>(P) & 15) || (reinterpret_cast<uintptr_t>(h) & 15)) return PZN_EUNSUPPORTED;
   const long rows = (long)B * S * 32;
   const long nbatch = (rows + 63) / 64;
+  // Few wavefronts with many rows in flight each: ~8 (4) wavefronts per CU at 512-byte (1-KB) rows measured best
+  // (0.18 -> 0.16 ms, 0.15 -> 0.14 ms against 16 per CU): more concurrent random row streams only lengthen the queues.
+  static const long fcap = [] { const char* e = getenv("PZN_SP_FGRID"); return e ? atol(e) : 0L; }();  // tuning aid
   long blocks = (nbatch + 3) / 4;
-  if (blocks > 4096) blocks = 4096;
+  const long want = fcap ? fcap : (C1 == 256 ? 256 : 512);
+  if (blocks > want) blocks = want;
   hipStream_t st = pzn_hip_stream(stream);
   const dim3 grid((unsigned)blocks), block(SP_T);
   const int ldw = 3 + D;
@@ -279,7 +305,7 @@ PZN_EXPORT int pzn_sa_point_l1_fwd_f32(const float* xyz, const float* new_xyz, c
 }
 
 PZN_EXPORT int pzn_knn_inverse_lists(const int64_t* idx, int B, int N, int S, int K, int32_t* off, int32_t* rows,
-                                     pzn_stream_t stream) {
+                                     int32_t* pts, pzn_stream_t stream) {
   PZN_CHECK_ARG(idx && off && rows && B > 0 && N > 0 && S > 0 && K > 0 && B <= 65535);
   PZN_CHECK_ARG((long)S * K < 2147483647L);
   const size_t lds = sizeof(int) * ((size_t)N + INV_T);
@@ -289,31 +315,40 @@ PZN_EXPORT int pzn_knn_inverse_lists(const int64_t* idx, int B, int N, int S, in
           hipSuccess)
     return PZN_ELAUNCH;
   hipLaunchKernelGGL(sa_inverse_lists_kernel, dim3((unsigned)B), dim3(INV_T), lds, pzn_hip_stream(stream), idx, N, S * K,
-                     off, rows);
+                     off, rows, pts);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
-PZN_EXPORT int pzn_sa_point_l1_bwd_f32(const float* dh, const float* xyz, const float* new_xyz, const int32_t* off,
-                                       const int32_t* rows, int B, int N, int S, int D, int C1, float* dP, float* dW1,
+PZN_EXPORT int pzn_sa_point_l1_bwd_f32(const float* dh, const float* xyz, const float* new_xyz, const int32_t* rows,
+                                       const int32_t* pts, int B, int N, int S, int D, int C1, float* dP, float* dW1,
                                        float* db1, pzn_stream_t stream) {
-  PZN_CHECK_ARG(dh && xyz && new_xyz && off && rows && dP && dW1 && B > 0 && N > 0 && S > 0 && D >= 0);
+  PZN_CHECK_ARG(dh && xyz && new_xyz && rows && pts && dP && dW1 && B > 0 && N > 0 && S > 0 && D >= 0);
+  PZN_CHECK_ARG((long)B * N < 2147483647L && (long)B * S * 32 < 2147483647L);
   if (C1 != 64 && C1 != 128 && C1 != 256) return PZN_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(dP) & 15) || (reinterpret_cast<uintptr_t>(dh) & 15)) return PZN_EUNSUPPORTED;
-  const long npoints = (long)B * N;
-  long blocks = (npoints + 15) / 16;  // >= 4 points per wavefront
-  if (blocks > 2048) blocks = 2048;
-  if (blocks < 1) blocks = 1;
   hipStream_t st = pzn_hip_stream(stream);
+  if (pzn_zero_async(dP, (size_t)B * N * C1, st) != PZN_OK) return PZN_ELAUNCH;  // points nobody gathered; list ends add
+  const long entries = (long)B * S * 32;
+  const long nbatch = (entries + 63) / 64;
+  // ~64 KB of dh rows in flight per CU measured best: 16 rows per wavefront, 8 (4) wavefronts per CU at 512-byte
+  // (1-KB) rows: 0.14 ms for the 537 MB of either level; 32 wavefronts per CU with 4 rows each took 0.21 / 0.29 ms.
+  static const long cap = [] { const char* e = getenv("PZN_SP_GRID"); return e ? atol(e) : 0L; }();  // tuning aid
+  static const int g8 = [] { const char* e = getenv("PZN_SP_G"); return e ? atoi(e) : 16; }();       // tuning aid
+  long blocks = (nbatch + 3) / 4;
+  const long want = cap ? cap : (C1 == 256 ? 256 : (C1 == 128 ? 512 : 1024));
+  if (blocks > want) blocks = want;
   const dim3 grid((unsigned)blocks), block(SP_T);
   const int ldw = 3 + D;
-  if (C1 == 64)
-    hipLaunchKernelGGL(sa_point_l1_bwd_kernel<1>, grid, block, 0, st, dh, xyz, new_xyz, off, rows, N, S, npoints, dP, dW1,
-                       ldw, db1);
-  else if (C1 == 128)
-    hipLaunchKernelGGL(sa_point_l1_bwd_kernel<2>, grid, block, 0, st, dh, xyz, new_xyz, off, rows, N, S, npoints, dP, dW1,
-                       ldw, db1);
-  else
-    hipLaunchKernelGGL(sa_point_l1_bwd_kernel<4>, grid, block, 0, st, dh, xyz, new_xyz, off, rows, N, S, npoints, dP, dW1,
-                       ldw, db1);
+#define PZN_SP_BWD(VV, GG)                                                                                              \
+  hipLaunchKernelGGL((sa_point_l1_bwd_kernel<VV, GG>), grid, block, 0, st, dh, xyz, new_xyz, rows, pts, N, S, entries, dP, \
+                     dW1, ldw, db1)
+  if (C1 == 64) {
+    if (g8 == 16) PZN_SP_BWD(1, 16); else if (g8 == 8) PZN_SP_BWD(1, 8); else PZN_SP_BWD(1, 4);
+  } else if (C1 == 128) {
+    if (g8 == 16) PZN_SP_BWD(2, 16); else if (g8 == 8) PZN_SP_BWD(2, 8); else PZN_SP_BWD(2, 4);
+  } else {
+    if (g8 == 16) PZN_SP_BWD(4, 16); else if (g8 == 8) PZN_SP_BWD(4, 8); else PZN_SP_BWD(4, 4);
+  }
+#undef PZN_SP_BWD
   PZN_RETURN_LAUNCH_STATUS();
 }

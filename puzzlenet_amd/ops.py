@@ -770,14 +770,15 @@ class _SaMlpMaxPoint(torch.autograd.Function):
         dh = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
         off = torch.empty((B * (N + 1),), dtype=torch.int32, device=dev)
         rows = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
+        pts = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
         dP = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
         dwf = torch.empty((C1, D), dtype=torch.float32, device=dev)
         dfeat = None
         with torch.cuda.device(dev):
             _call("pzn_pooled_layer_bwd_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(h), R, C1, C2, _p(dh), _p(dW2), _p(db2),
                   int(direct), _stream(), flops=2 * R * (2 * C1 * C2))
-            _call("pzn_knn_inverse_lists", _p(idx), B, N, S, 32, _p(off), _p(rows), _stream())
-            _call("pzn_sa_point_l1_bwd_f32", _p(dh), _p(xyz), _p(new_xyz), _p(off), _p(rows), B, N, S, D, C1, _p(dP),
+            _call("pzn_knn_inverse_lists", _p(idx), B, N, S, 32, _p(off), _p(rows), _p(pts), _stream())
+            _call("pzn_sa_point_l1_bwd_f32", _p(dh), _p(xyz), _p(new_xyz), _p(rows), _p(pts), B, N, S, D, C1, _p(dP),
                   _p(dW1), _p(db1), _stream())
             if need_feat:
                 dfeat = torch.empty((B, N, D), dtype=torch.float32, device=dev)
