@@ -284,6 +284,20 @@ int pzn_pooled_layer_bwd_f32(const float* dout, const int32_t* argmax, const flo
                              const float* W2, const float* h, int R, int C1, int C2, float* dh,
                              float* dW2, float* db2, int accumulate, pzn_stream_t stream);
 
+/* relu(BatchNorm1d(num_points)(x)) of the per-point feature MLP (model5_b.py:424, :447-448): x[B,N,C], the BN
+ * "channel" axis is the POINT index, statistics over the B*C values of a point.  training != 0: batch statistics
+ * (biased variance), running_mean / running_var updated in place as torch does (momentum, unbiased variance; may be
+ * NULL); else the running statistics normalise.  save_mean / save_invstd [N] feed the backward.
+ * bwd: dx[B,N,C] (may be NULL), dweight[N] / dbias[N] ADDED to (may be NULL); the ReLU gate is recomputed from x. */
+int pzn_bn_points_relu_fwd_f32(const float* x, const float* weight, const float* bias,
+                               float* running_mean, float* running_var, int training,
+                               float momentum, float eps, int B, int N, int C, float* y,
+                               float* save_mean, float* save_invstd, pzn_stream_t stream);
+int pzn_bn_points_relu_bwd_f32(const float* x, const float* dy, const float* weight,
+                               const float* bias, const float* save_mean,
+                               const float* save_invstd, int training, int B, int N, int C,
+                               float* dx, float* dweight, float* dbias, pzn_stream_t stream);
+
 /* scaled_dot_production of layerAttention, model5_b.py:67-75:
  * attn[B,L,L] = softmax(q[B,L,dk] k[B,L,dk]^T / sqrt(dk)), out[B,L,dv] = attn v.
  * attn is an output because the reference returns it (model5_b.py:97,101). */

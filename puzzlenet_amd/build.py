@@ -31,6 +31,7 @@ SOURCES = [
     ("optim.hip", ["-ffp-contract=off"]),
     ("se3.hip", []),
     ("sapoint.hip", []),
+    ("bnpoints.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]

@@ -143,6 +143,9 @@ class PCTransformer_nonsort(nn.Module):
 
     def local_features(self, xyz):
         """:447-448, the per-point MLP in front of the set abstraction (does not need the sampling plan)."""
+        if xyz.is_cuda and _BN_FUSED:      # BatchNorm + ReLU as one launch each way (csrc/bnpoints.hip)
+            x_feature = ops.bn_points_relu(dense.linear(xyz, self.mlp1.weight, self.mlp1.bias), self.bn1)   # :447
+            return ops.bn_points_relu(dense.linear(x_feature, self.mlp2.weight, self.mlp2.bias), self.bn2)  # :448
         x_feature = F.relu(self.bn1(dense.linear(xyz, self.mlp1.weight, self.mlp1.bias)))          # :447
         return F.relu(self.bn2(dense.linear(x_feature, self.mlp2.weight, self.mlp2.bias)))        # :448
 
@@ -169,6 +172,9 @@ class PCTransformer_nonsort(nn.Module):
         out = dense.linear(att, self.out.weight, self.out.bias)                                   # :474
         f_global = ops.max_over_points(out)                                                       # :475
         return f_global, x2, attention, out, x_feature
+
+
+_BN_FUSED = os.environ.get("PZN_BN_FUSED", "1") != "0"     # tuning aid
 
 
 def _seq(*dims):

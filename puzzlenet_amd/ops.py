@@ -710,6 +710,62 @@ class _SaMlpMax(torch.autograd.Function):
         return None, dfeat, None, None, dW1, db1, dW2, db2
 
 
+class _BnPointsRelu(torch.autograd.Function):
+    """relu(BatchNorm1d(num_points)(x)) for x[B, N, C] (model5_b.py:424, :447-448: the BN channel axis is the point
+    index) as one launch each way (csrc/bnpoints.hip) instead of BN + clamp and their two backward kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps):
+        x = _f32(x, "x")
+        B, N, C = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        mean = torch.empty((N,), dtype=torch.float32, device=dev)
+        invstd = torch.empty((N,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _call("pzn_bn_points_relu_fwd_f32", _p(x), _p(weight), _p(bias), _p(running_mean), _p(running_var),
+                  int(bool(training)), float(momentum), float(eps), B, N, C, _p(y), _p(mean), _p(invstd), _stream())
+        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        ctx.training = bool(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, mean, invstd = ctx.saved_tensors
+        B, N, C = x.shape
+        dy = _f32(dy, "dy")
+        dev = dy.device
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        need_w = weight is not None and ctx.needs_input_grad[1]
+        need_b = bias is not None and ctx.needs_input_grad[2]
+        sw, sb = _sink(weight, need_w), _sink(bias, need_b)
+        direct = (sw is not None or not need_w) and (sb is not None or not need_b)
+        if direct:
+            dw, db = sw, sb
+        else:
+            dw = torch.zeros((N,), dtype=torch.float32, device=dev) if need_w else None
+            db = torch.zeros((N,), dtype=torch.float32, device=dev) if need_b else None
+        with torch.cuda.device(dev):
+            _call("pzn_bn_points_relu_bwd_f32", _p(x), _p(dy), _p(weight), _p(bias), _p(mean), _p(invstd),
+                  int(ctx.training), B, N, C, _p(dx), _p(dw), _p(db), _stream())
+        if direct:
+            return dx, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
+
+
+def bn_points_relu(x, bn):
+    """relu(bn(x)) for an nn.BatchNorm1d(num_points) applied to x[B, N, C] on the GPU: batch statistics and running
+    buffers exactly as the module keeps them (momentum must be a number, as in the reference)."""
+    if x.dim() != 3 or x.shape[1] != bn.num_features or bn.momentum is None:
+        raise _lib.PznError(f"bn_points_relu: x{tuple(x.shape)} vs BatchNorm1d({bn.num_features}), momentum={bn.momentum}")
+    use_batch = bn.training or not bn.track_running_stats
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BnPointsRelu.apply(x, bn.weight, bn.bias, rm, rv, use_batch, bn.momentum, bn.eps)
+
+
 class _SaMlpMaxPoint(torch.autograd.Function):
     """The same set-abstraction level (model5_b.py:449-454 / :456-461) with the first shared-MLP layer computed per
     POINT (csrc/sapoint.hip): a grouped row is {xyz[j] - centre, feat[j]}, so W1 row = W1[:,0:3] (xyz[j] - centre) +

@@ -271,3 +271,56 @@ def test_max_over_points(B, L, C):
     idx = (x == ref.detach().unsqueeze(1)).float().argmax(dim=1)          # first row attaining the max
     want = torch.zeros_like(x).scatter_(1, idx.unsqueeze(1), go.unsqueeze(1))
     assert torch.equal(xd.grad.cpu(), want)
+
+
+@pytest.mark.parametrize("B,N,C", [(8, 96, 64), (5, 33, 20), (64, 256, 64), (3, 7, 130)])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_points_relu_vs_torch(B, N, C, training):
+    """relu(BatchNorm1d(num_points)(x)) as one HIP launch each way (csrc/bnpoints.hip) vs torch's BatchNorm + relu in
+    fp64: output, input / weight / bias gradients, running statistics, batch counter; train and eval mode."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from puzzlenet_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 100 + N)
+    x = torch.randn(B, N, C, generator=g) * 2 + 0.5
+    go = torch.randn(B, N, C, generator=g)
+    ref = nn.BatchNorm1d(N).double()
+    with torch.no_grad():
+        ref.weight.copy_(1 + 0.3 * torch.randn(N, generator=g))
+        ref.bias.copy_(0.2 * torch.randn(N, generator=g))
+        ref.running_mean.copy_(0.1 * torch.randn(N, generator=g))
+        ref.running_var.copy_(1 + 0.2 * torch.rand(N, generator=g))
+    mine = nn.BatchNorm1d(N)
+    mine.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in ref.state_dict().items()})
+    mine = mine.to(dev)
+    ref.train(training), mine.train(training)
+    xr = x.double().requires_grad_(True)
+    xd = x.to(dev).requires_grad_(True)
+    yr = F.relu(ref(xr))
+    y = ops.bn_points_relu(xd, mine)
+    # a pre-activation within rounding of zero may gate differently: take the gate from the device output
+    gate = (y.detach().cpu() > 0)
+    assert int((gate != (yr.detach() > 0)).sum()) <= 2
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 2e-5
+    (torch.where(gate, ref(xr), torch.zeros_like(yr)) * go.double()).sum().backward()
+    (y * go.to(dev)).sum().backward()
+    def rel(a, b):
+        return float((a.detach().cpu().double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert rel(xd.grad, xr.grad) < 1e-4
+    assert rel(mine.weight.grad, ref.weight.grad) < 1e-4
+    assert rel(mine.bias.grad, ref.bias.grad) < 1e-4
+    # ref(xr) ran twice (two momentum updates): the expected running statistics come from a fresh module updated once
+    init = nn.BatchNorm1d(N).double()
+    g2 = torch.Generator().manual_seed(B * 100 + N)
+    _ = torch.randn(B, N, C, generator=g2), torch.randn(B, N, C, generator=g2)
+    with torch.no_grad():
+        init.weight.copy_(1 + 0.3 * torch.randn(N, generator=g2))
+        init.bias.copy_(0.2 * torch.randn(N, generator=g2))
+        init.running_mean.copy_(0.1 * torch.randn(N, generator=g2))
+        init.running_var.copy_(1 + 0.2 * torch.rand(N, generator=g2))
+    init.train(training)
+    init(x.double())
+    assert rel(mine.running_mean, init.running_mean) < 1e-5
+    assert rel(mine.running_var, init.running_var) < 1e-5
+    assert int(mine.num_batches_tracked) == int(init.num_batches_tracked)
