@@ -275,10 +275,13 @@ def main():
         n_gb, ms_gb = kern.get("pzn_sa_point_l1_bwd_f32", (0, 0.0))
         g_ms = (ms_gf + ms_gb) / max(1, prof_steps)
         g_ach = g_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+        g_traffic = None
+        if os.path.exists(tpath) and (B, N) == (64, 2048):
+            g_traffic = json.load(open(tpath)).get("sa_gather_stage_bytes_per_step")
         roofline_sa_gather = {
             "bound": "hbm", "kernel": "sa_point_l1_fwd_kernel / sa_point_l1_bwd_kernel (pzn_sa_point_l1_{fwd,bwd}_f32: first "
                                       "set-abstraction layer as a gather of per-point rows / a sum over inverse neighbour lists)",
-            "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g_ach / HBM_PEAK_GBS, "traffic": None,
+            "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g_ach / HBM_PEAK_GBS, "traffic": g_traffic,
             "algorithmic_bytes_per_step": g_bytes,
             "avg_launch_ms": {"sa_point_l1_fwd_kernel": ms_gf / max(1, n_gf), "sa_point_l1_bwd_kernel": ms_gb / max(1, n_gb)},
         }

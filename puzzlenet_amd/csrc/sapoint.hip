@@ -64,7 +64,7 @@ __global__ __launch_bounds__(SP_T) void sa_point_l1_fwd_kernel(const float* __re
                                                                const float* __restrict__ P,
                                                                const float* __restrict__ W1, int ldw,
                                                                const float* __restrict__ b1, int N, int S, long rows,
-                                                               float* __restrict__ h) {
+                                                               float* __restrict__ h, int xcd_map) {
   constexpr int C1 = 64 * V;
   const int lane = threadIdx.x & 63;
   const long gw = (long)blockIdx.x * (SP_T / 64) + (threadIdx.x >> 6), nw = (long)gridDim.x * (SP_T / 64);
@@ -76,7 +76,19 @@ __global__ __launch_bounds__(SP_T) void sa_point_l1_fwd_kernel(const float* __re
     bb[i] = b1 ? b1[c] : 0.f;
   }
   const long nbatch = (rows + 63) >> 6;
-  for (long bt = gw; bt < nbatch; bt += nw) {
+  // Workgroups go to the 8 XCDs round-robin and each XCD has its own 4 MB L2.  A cloud's P rows (N*C1 floats: 0.5-1 MB)
+  // are gathered 8-16 times each, so every XCD works through its OWN clouds (b = xcd, xcd + 8, ...) in order: one or
+  // two clouds' P stay L2-resident per XCD instead of eight clouds' thrashing it (PMC: 391 -> ~60 MB fetched per
+  // launch).  Needs whole batches per cloud and a grid that is a multiple of 8; else the plain strided walk.
+  const int bpc = (S * 32) >> 6;  // batches per cloud
+  const bool by_xcd = xcd_map && ((S * 32) & 63) == 0 && (gridDim.x & 7) == 0;
+  const int xcd = blockIdx.x & 7;
+  const long B_ = rows / ((long)S * 32);
+  const long ncl = by_xcd ? (B_ - xcd + 7) / 8 : 0;          // clouds of this XCD
+  const long lw = (long)(blockIdx.x >> 3) * (SP_T / 64) + (threadIdx.x >> 6), nlw = (long)(gridDim.x >> 3) * (SP_T / 64);
+  const long q_end = by_xcd ? ncl * bpc : nbatch;
+  for (long q = by_xcd ? lw : gw; q < q_end; q += by_xcd ? nlw : nw) {
+    const long bt = by_xcd ? ((long)xcd + 8 * (q / bpc)) * bpc + q % bpc : q;
     const long row = bt * 64 + lane;
     float dx = 0.f, dy = 0.f, dz = 0.f;
     int prow = 0;  // row of P (b*N + j); fits 32 bits: B*N*C1 floats are addressed through size_t below
@@ -84,9 +96,9 @@ __global__ __launch_bounds__(SP_T) void sa_point_l1_fwd_kernel(const float* __re
       const long grp = row >> 5;         // b*S + s
       const long b = grp / S;
       const int j = (int)idx[row];
-      const float* q = xyz + ((size_t)b * N + j) * 3;
+      const float* pq = xyz + ((size_t)b * N + j) * 3;
       const float* c = new_xyz + (size_t)grp * 3;
-      dx = q[0] - c[0], dy = q[1] - c[1], dz = q[2] - c[2];  // pointnet_util.py:124
+      dx = pq[0] - c[0], dy = pq[1] - c[1], dz = pq[2] - c[2];  // pointnet_util.py:124
       prow = (int)(b * N + j);
     }
     const int nr = (int)min((long)64, rows - bt * 64);
@@ -293,14 +305,16 @@ PZN_EXPORT int pzn_sa_point_l1_fwd_f32(const float* xyz, const float* new_xyz, c
   const long want = fcap ? fcap : (C1 == 256 ? 256 : 512);
   if (blocks > want) blocks = want;
   hipStream_t st = pzn_hip_stream(stream);
+  static const int xmap = [] { const char* e = getenv("PZN_SP_XCD"); return e ? atoi(e) : 1; }();  // tuning aid
+  if (blocks >= 8) blocks &= ~7L;
   const dim3 grid((unsigned)blocks), block(SP_T);
   const int ldw = 3 + D;
   if (C1 == 64)
-    hipLaunchKernelGGL(sa_point_l1_fwd_kernel<1>, grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h);
+    hipLaunchKernelGGL(sa_point_l1_fwd_kernel<1>, grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h, xmap);
   else if (C1 == 128)
-    hipLaunchKernelGGL(sa_point_l1_fwd_kernel<2>, grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h);
+    hipLaunchKernelGGL(sa_point_l1_fwd_kernel<2>, grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h, xmap);
   else
-    hipLaunchKernelGGL(sa_point_l1_fwd_kernel<4>, grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h);
+    hipLaunchKernelGGL(sa_point_l1_fwd_kernel<4>, grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h, xmap);
   PZN_RETURN_LAUNCH_STATUS();
 }
 

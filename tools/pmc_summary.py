@@ -47,14 +47,22 @@ def main():
         stage = round(k["hbm_bytes_per_launch"] * 4)
     elif "knn32_reg_kernel" in per and "group_pad_direct_kernel" in per:
         stage = 2 * per["knn32_reg_kernel"]["hbm_bytes_per_launch"] + 4 * per["group_pad_direct_kernel"]["hbm_bytes_per_launch"]
+    # first set-abstraction layer of the model path (csrc/sapoint.hip): gather forward + list-sum backward, 4 launches
+    # each per step (2 clouds x 2 levels)
+    sa = None
+    if "sa_point_l1_fwd_kernel" in per and "sa_point_l1_bwd_kernel" in per:
+        sa = round(4 * (per["sa_point_l1_fwd_kernel"]["hbm_bytes_per_launch"] + per["sa_point_l1_bwd_kernel"]["hbm_bytes_per_launch"]))
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, python bench.py --steps 2 --warmup 1 "
                      "--no-cpu-baseline (B=64, N=2048)",
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE half-count, MI355X_MICROARCH.md)",
            "knn_group_stage_bytes_per_step": stage,
            "knn_group_stage_algorithmic_bytes_per_step": 1242431488,
+           "sa_gather_stage_bytes_per_step": sa,
+           "sa_gather_stage_algorithmic_bytes_per_step": 4746904576,
            "per_kernel": {k: v for k, v in per.items() if not k.startswith("at::") and "rocclr" not in k}}
     json.dump(doc, open(out, "w"), indent=1)
-    print(json.dumps({k: doc[k] for k in ("knn_group_stage_bytes_per_step", "knn_group_stage_algorithmic_bytes_per_step")}))
+    print(json.dumps({k: doc[k] for k in ("knn_group_stage_bytes_per_step", "knn_group_stage_algorithmic_bytes_per_step",
+                                          "sa_gather_stage_bytes_per_step", "sa_gather_stage_algorithmic_bytes_per_step")}))
 
 
 if __name__ == "__main__":
