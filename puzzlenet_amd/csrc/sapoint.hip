@@ -143,8 +143,20 @@ __global__ __launch_bounds__(INV_T) void sa_inverse_lists_kernel(const int64_t* 
   const int b = blockIdx.x, tid = threadIdx.x;
   const int64_t* ib = idx + (size_t)b * SK;
   for (int j = tid; j < N; j += INV_T) cnt[j] = 0;
+  // this thread's entries i = tid, tid + 1024, ...: the first INV_R of them are kept in registers for the fill pass
+  // (all loads of the pass in flight at once; 16 x 1024 covers the model's 512 x 32 rows per cloud)
+  constexpr int INV_R = 16;
+  int mine[INV_R];
+#pragma unroll
+  for (int u = 0; u < INV_R; ++u) {
+    const int i = tid + u * INV_T;
+    mine[u] = i < SK ? (int)ib[i] : -1;
+  }
   __syncthreads();
-  for (int i = tid; i < SK; i += INV_T) atomicAdd(&cnt[(int)ib[i]], 1);
+#pragma unroll
+  for (int u = 0; u < INV_R; ++u)
+    if (mine[u] >= 0) atomicAdd(&cnt[mine[u]], 1);
+  for (int i = tid + INV_R * INV_T; i < SK; i += INV_T) atomicAdd(&cnt[(int)ib[i]], 1);
   __syncthreads();
   // exclusive scan of cnt[0..N): thread t owns the contiguous chunk [t*per, (t+1)*per)
   const int per = (N + INV_T - 1) / INV_T;
@@ -171,7 +183,16 @@ __global__ __launch_bounds__(INV_T) void sa_inverse_lists_kernel(const int64_t* 
   __syncthreads();
   int32_t* rb = rows + (size_t)b * SK;
   int32_t* pb = pts ? pts + (size_t)b * SK : nullptr;
-  for (int i = tid; i < SK; i += INV_T) {
+#pragma unroll
+  for (int u = 0; u < INV_R; ++u) {
+    const int j = mine[u];
+    if (j >= 0) {
+      const int pos = atomicAdd(&cnt[j], 1);
+      rb[pos] = tid + u * INV_T;
+      if (pb) pb[pos] = j;
+    }
+  }
+  for (int i = tid + INV_R * INV_T; i < SK; i += INV_T) {
     const int j = (int)ib[i];
     const int pos = atomicAdd(&cnt[j], 1);
     rb[pos] = i;
