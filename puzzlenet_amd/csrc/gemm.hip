@@ -635,6 +635,15 @@ void launch_cfg(const GemmArgs& p, int batch, hipStream_t st) {
 
 template <bool A_KC, bool B_KC, int EPI>
 void launch(const GemmArgs& p, int batch, hipStream_t st) {
+  if constexpr (EPI == EPI_STORE) {
+    // batched small products (the attention maps: 64 x (256 x 256 x 64..256)): 128 x 128 tiles give one 4-wave
+    // workgroup per CU, i.e. nothing to hide a load behind; 64 x 128 tiles double the resident wavefronts
+    static const bool small_tiles = [] { const char* e = getenv("PZN_BGEMM_SMALL"); return !(e && e[0] == '0'); }();
+    if (small_tiles && batch > 1 && p.N > 64 && p.M <= 512 && p.splits <= 1) {
+      launch_cfg<64, 128, 2, 2, A_KC, B_KC, EPI>(p, batch, st);
+      return;
+    }
+  }
   if (p.N > 64)
     launch_cfg<128, 128, 2, 2, A_KC, B_KC, EPI>(p, batch, st);
   else
