@@ -175,7 +175,7 @@ class PCTransformer_nonsort(nn.Module):
 
 
 _BN_FUSED = os.environ.get("PZN_BN_FUSED", "1") != "0"     # tuning aid
-_EMD_SIDE = os.environ.get("PZN_EMD_SIDE", "1") != "0"     # tuning aid: 0 = the N x N EMD on the main stream
+_EMD_SIDE = int(os.environ.get("PZN_EMD_SIDE", "2"))     # tuning aid: 0 = the N x N EMD on the main stream, 1 = forked right after the pose head, 2 = after the heads (measured best)
 
 
 def _seq(*dims):
@@ -222,8 +222,9 @@ class TouchedRegraster(_Base):
         self._side_stream = None
 
     # ------------------------------------------------------------------ forward
-    def predict5(self, batch, batch_indic, need=False, training=False):
-        """model5_b.py:672-759."""
+    def predict5(self, batch, batch_indic, need=False, training=False, pose_hook=None):
+        """model5_b.py:672-759.  pose_hook(out): called as soon as the pose head has produced `out`, before the boundary
+        heads are enqueued (training_step starts the N x N EMD on the side stream from it)."""
         for m in (self.Encoder, self.Encoder2, self.tfMLP, self.fpc_decoder, self.rpc_decoder):
             m.train(training)                                                       # :677-690
         fpc, mrpc = batch[0], batch[1]
@@ -263,7 +264,7 @@ class TouchedRegraster(_Base):
             for t in fmrpcs:
                 if isinstance(t, torch.Tensor):
                     t.record_stream(cur)
-            return self._heads(ffpcs, fmrpcs, N, need)
+            return self._heads(ffpcs, fmrpcs, N, need, pose_hook)
         plan_f, plan_m = self._sa_plans(fpc, mrpc)
         if self.two_streams and fpc.is_cuda and (not capturing or self.two_streams == "graph"):
             # The two encoders are independent (separate weights, separate clouds) and most of their launches
@@ -289,15 +290,17 @@ class TouchedRegraster(_Base):
         else:
             ffpcs = self.Encoder(fpc, plan_f)                                       # :710
             fmrpcs = self.Encoder2(mrpc, plan_m)                                    # :716
-        return self._heads(ffpcs, fmrpcs, N, need)
+        return self._heads(ffpcs, fmrpcs, N, need, pose_hook)
 
-    def _heads(self, ffpcs, fmrpcs, N, need):
+    def _heads(self, ffpcs, fmrpcs, N, need, pose_hook=None):
         """:723-759: pose head on the two global features, boundary heads on the per-point features."""
         ffpc, non_sg_ffpc = ffpcs[0], ffpcs[4]
         fmrpc, non_sg_fmrpc = fmrpcs[0], fmrpcs[4]
 
         f = torch.cat([ffpc, fmrpc], dim=-1)                                        # :723
         out = _run_seq(self.tfMLP, f)                                               # :725
+        if pose_hook is not None:
+            pose_hook(out)
 
         non_sg_ffpc = _run_seq(self.MLPLocalPreFpc, non_sg_ffpc)                    # :738
         non_sg_fmrpc = _run_seq(self.MLPLocalPreRpc, non_sg_fmrpc)                  # :739
@@ -368,16 +371,40 @@ class TouchedRegraster(_Base):
         N = fpc.shape[1]
         C = self.C
 
+        # The N x N EMD (:1002) is ~1.7 ms of vector-ALU work that needs nothing but the pose, and nothing needs its
+        # value until the loss terms are summed: on the GPU it is started on the side stream as soon as the pose head
+        # is done (pose_hook), and the boundary heads, their losses and the other small launches run beside it.
+        pose = {}
+
+        def fork_emd(o):
+            if _EMD_SIDE and self.two_streams and o.is_cuda and self._side_stream is not None and \
+                    not torch.cuda.is_current_stream_capturing():
+                cur = torch.cuda.current_stream()
+                side = self._side_stream
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    pose['emd'] = earth_mover_distance(pose['de_mrpc'], rpc, transpose=False)
+                pose['de_mrpc'].record_stream(side)
+                rpc.record_stream(side)
+                pose['side'] = side
+
+        def pose_hook(o):
+            pose['mat'] = se3.exp(o).to(mrpc)                                       # :947
+            pose['de_mrpc'] = se3.transform(pose['mat'], mrpc.permute(0, 2, 1)).permute(0, 2, 1)
+            if _EMD_SIDE == 1:
+                fork_emd(o)
+
         out, t, x2, attention, mrpc_x2, mrpc_attention, de_fpcb, de_mrpcb = self.predict5(
-            batch, batch_size, training=True, need=True)                            # :933
+            batch, batch_size, training=True, need=True, pose_hook=pose_hook)      # :933
+        if _EMD_SIDE == 2:
+            fork_emd(out)
 
         att1 = attention.mean(dim=1)                                                # :937-942
         att2 = mrpc_attention.mean(dim=1)
         x2att1 = x2[:, torch.topk(att1, 32)[1][:, 0]]
         x2att2 = mrpc_x2[:, torch.topk(att2, 32)[1][:, 0]]
 
-        mat = se3.exp(out).to(mrpc)                                                 # :947-952
-        de_mrpc = se3.transform(mat, mrpc.permute(0, 2, 1)).permute(0, 2, 1)
+        mat, de_mrpc = pose['mat'], pose['de_mrpc']                                 # :947-952 (computed in pose_hook)
         R = mat[:, :3, :3]
         t = mat[:, :3, 3]
 
@@ -395,21 +422,10 @@ class TouchedRegraster(_Base):
         self.log('train/loss_g', loss_g)
 
         dg_att1_dist1, dg_att1_dist2 = self.chamfer_loss(x2att1, x2att2)            # :1001
-        # :1002 — the N x N EMD is ~1.7 ms of vector-ALU work that nothing below needs until the terms are summed: on
-        # the GPU it goes to the side stream and the boundary terms (small launches) run beside it.  The terms are
-        # then added in the reference's order (:1016-1151), so the loss value is the one of the sequential code.
-        emd_side = None
-        if _EMD_SIDE and self.two_streams and de_mrpc.is_cuda and self._side_stream is not None and \
-                not torch.cuda.is_current_stream_capturing():
-            cur = torch.cuda.current_stream()
-            emd_side = self._side_stream
-            emd_side.wait_stream(cur)
-            with torch.cuda.stream(emd_side):
-                emd = earth_mover_distance(de_mrpc, rpc, transpose=False)
-            de_mrpc.record_stream(emd_side)
-            rpc.record_stream(emd_side)
-        else:
-            emd = earth_mover_distance(de_mrpc, rpc, transpose=False)
+        # :1002 — the N x N EMD: already running on the side stream (pose_hook), else here.  The terms are added in the
+        # reference's order further down (:1016-1151), so the loss value is the one of the sequential code.
+        emd_side = pose.get('side')
+        emd = pose['emd'] if emd_side is not None else earth_mover_distance(de_mrpc, rpc, transpose=False)
         if C.loss_sum:
             loss_cd2 = torch.sum(dg_att1_dist1) + torch.sum(dg_att1_dist2)
         else:
