@@ -39,6 +39,7 @@ class TrainStep:
             self.sched = None
         self.loss = None
         self.feed = None
+        model.defer_emd_loss = not use_graph
         if use_graph:
             if os.environ.get('PZN_GRAPH_STREAMS', '1') != '0' and getattr(model, 'two_streams', False):
                 model.two_streams = 'graph'     # keep the encoder fork / join inside the captured graph
@@ -47,9 +48,21 @@ class TrainStep:
     # -- one eager step (also the body that gets captured)
     def _fwd_bwd(self):
         self.grads.zero_()
-        loss = self.model.training_step(self.batch, 0)["loss"]
-        loss.backward()
-        return loss
+        out = self.model.training_step(self.batch, 0)
+        if "loss" in out:
+            loss = out["loss"]
+            loss.backward()
+            return loss
+        # the N x N EMD term is still running on the side stream: both parts are backward roots, so the backward of the
+        # boundary terms and heads starts without waiting for it; the engine's end-of-backward sync joins the streams
+        terms = list(out["loss_terms"])
+        torch.autograd.backward(terms)
+        if out.get("join_stream") is not None:
+            torch.cuda.current_stream().wait_stream(out["join_stream"])
+        loss = terms[0]
+        for t in terms[1:]:
+            loss = loss + t
+        return loss.detach()
 
     def _capture(self, warmup):
         self.feed = pu.StartIndexFeed()

@@ -220,6 +220,7 @@ class TouchedRegraster(_Base):
         self.MLPFpcb = _seq(128, 64, 32, 2)
         self.two_streams = True        # Encoder2 on a side stream (GPU only); False = everything on the current stream
         self._side_stream = None
+        self.defer_emd_loss = False    # see training_step: the EMD term as a separate backward root (engine.TrainStep)
 
     # ------------------------------------------------------------------ forward
     def predict5(self, batch, batch_indic, need=False, training=False, pose_hook=None):
@@ -471,23 +472,32 @@ class TouchedRegraster(_Base):
         self.log('train/loss_emd_fpcb', emd_fpcb)
         self.log('train/loss_emc_mrpcb', emd_mrpcb)
 
-        if emd_side is not None:     # join: from here on the N x N cost is used on this stream
+        # defer_emd_loss (set by engine.TrainStep in eager mode): the EMD term stays a separate backward root, so that the
+        # backward of everything that does not hang off the pose (boundary terms, heads) is not queued behind the
+        # join with the side stream; the caller adds the two parts after the backward has been enqueued.
+        uses_emd = C.loss_mode in (1, 2, 3, 4)
+        defer = emd_side is not None and uses_emd and getattr(self, 'defer_emd_loss', False)
+        if emd_side is not None and not defer:     # join: from here on the N x N cost is used on this stream
             torch.cuda.current_stream().wait_stream(emd_side)
             emd.record_stream(torch.cuda.current_stream())
-        loss_emd = torch.sum(emd) if C.loss_sum else torch.mean(emd)                # :1003-1010
+        if defer:
+            with torch.cuda.stream(emd_side):
+                loss_emd = torch.sum(emd) if C.loss_sum else torch.mean(emd)        # :1003-1010
+        else:
+            loss_emd = torch.sum(emd) if C.loss_sum else torch.mean(emd)            # :1003-1010
         self.log('train/loss_emd', loss_emd)
 
         mode = C.loss_mode                                                          # :1016-1029
         if mode == 0:
             loss = loss_recoversy + loss_g
         elif mode == 1:
-            loss = loss_recoversy + loss_g + loss_emd
+            loss = loss_recoversy + loss_g if defer else loss_recoversy + loss_g + loss_emd
         elif mode == 2:
-            loss = loss_emd
+            loss = None if defer else loss_emd
         elif mode == 3:
-            loss = loss_emd + loss_g
+            loss = loss_g if defer else loss_emd + loss_g
         elif mode == 4:
-            loss = loss_emd + loss_recoversy
+            loss = loss_recoversy if defer else loss_emd + loss_recoversy
         elif mode == 5:
             loss = loss_g
         elif mode == 6:
@@ -495,13 +505,15 @@ class TouchedRegraster(_Base):
         else:
             raise ValueError(f"loss_mode {mode}")
         if C.use_emd2:                                                              # :1033-1036
-            loss = loss + emd2
+            loss = emd2 if loss is None else loss + emd2
         if C.use_cd2:
-            loss = loss + loss_cd2
-        loss = loss + loss_fpcb_cel + loss_rpcb_cel                                 # :1065
+            loss = loss_cd2 if loss is None else loss + loss_cd2
+        loss = loss_fpcb_cel + loss_rpcb_cel if loss is None else loss + loss_fpcb_cel + loss_rpcb_cel   # :1065
         loss = loss + loss_mrpcb + loss_fpcb                                        # :1146-1151
         if C.use_emd3:
             loss = loss + emd_fpcb + emd_mrpcb
+        if defer:
+            return {'loss_terms': (loss, loss_emd), 'join_stream': emd_side}
         self.log('train_loss', loss)
         return {'loss': loss}
 

@@ -187,6 +187,47 @@ def test_gradient_sinks_match_autograd_accumulation(golden_loss, dev):
     assert float(a.abs().max()) > 0
 
 
+def test_emd_side_stream_and_deferred_root(golden_loss, dev):
+    """training_step runs the N x N EMD on the side stream; with `defer_emd_loss` (engine.TrainStep, eager mode) the EMD
+    term is a separate backward root and the caller sums the parts.  Loss and gradients must be those of the
+    sequential step (one stream, one root)."""
+    from puzzlenet_amd import model5_b as mb
+    from puzzlenet_amd import ops
+    G = golden_loss
+    batch = [_t(G[f"ts_batch{i}"], dev) for i in range(8)]
+
+    def run(two_streams, defer):
+        m = mb.TouchedRegraster(mr.Cfg(loss_mode=1, use_emd2=True, use_cd2=True, use_emd3=True))
+        mr.fill_params(m)
+        m.to(dev)
+        ops.clear_grad_sinks()
+        m.two_streams = two_streams
+        m.defer_emd_loss = defer
+        torch.manual_seed(5)
+        out = m.training_step(batch, 0)
+        if "loss" in out:
+            assert not defer
+            out["loss"].backward()
+            loss = out["loss"].detach()
+        else:
+            assert defer and two_streams
+            terms = list(out["loss_terms"])
+            torch.autograd.backward(terms)
+            torch.cuda.current_stream().wait_stream(out["join_stream"])
+            loss = (terms[0] + terms[1]).detach()
+        torch.cuda.synchronize()
+        grads = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in m.parameters()])
+        return float(loss), grads
+
+    l0, g0 = run(False, False)
+    l1, g1 = run(True, False)
+    l2, g2 = run(True, True)
+    assert abs(l1 - l0) <= 1e-6 * abs(l0) and abs(l2 - l0) <= 1e-5 * abs(l0)
+    # (gradients carry the run-to-run rounding of the atomic weight-gradient sums; EMD terms: see test_gpu_emd)
+    assert float((g1 - g0).norm() / g0.norm()) < 2e-3
+    assert float((g2 - g0).norm() / g0.norm()) < 2e-3
+
+
 def test_flat_adam_matches_torch_adam(dev):
     """distributed.FlatAdam (one pzn_adam_step_f32 launch over flat buffers, StepLR folded in) against
     torch.optim.Adam + StepLR on CPU, same gradients, 120 steps (crosses two scheduler boundaries)."""
