@@ -70,10 +70,17 @@ def time_knn_group_api(batch, dev, reps):
             idx = torch.empty((Bc, s, 32), dtype=torch.int64, device=dev)
             xg = torch.empty((Bc * s * 32, 4 + d), dtype=torch.float32, device=dev)
             work.append((x, feat, new_xyz, Bc, n, s, d, idx, xg))
+    from puzzlenet_amd import _lib
+
     def run():
         for (x, feat, new_xyz, Bc, n, s, d, idx, xg) in work:
-            ops._call("pzn_knn_group_pad_f32", ops._p(x), ops._p(feat), ops._p(new_xyz), Bc, n, s, d, ops._p(idx),
-                      ops._p(xg), ops._stream())
+            try:
+                ops._call("pzn_knn_group_pad_f32", ops._p(x), ops._p(feat), ops._p(new_xyz), Bc, n, s, d, ops._p(idx),
+                          ops._p(xg), ops._stream())
+            except _lib.PznUnsupported:      # N > 4096: search and padded group write as two launches
+                ops._call("pzn_knn_f32", ops._p(x), ops._p(new_xyz), Bc, n, s, 32, ops._p(idx), ops._stream())
+                ops._call("pzn_group_pad_fwd_f32", ops._p(x), ops._p(feat), ops._p(new_xyz), ops._p(idx), Bc, n, s, 32, d,
+                          ops._p(xg), ops._stream())
     run()
     torch.cuda.synchronize()
     ops.KernelTimer.start()
@@ -243,8 +250,8 @@ def main():
                            "the training step itself no longer materialises the grouped tensor, see roofline_sa_gather")
             avg_launch = {"knn_group_pad_kernel": ms_st / max(1, n_st)}
         else:
-            n_knn, ms_knn = kern.get("pzn_knn_f32", (0, 0.0))
-            n_grp, ms_grp = kern.get("pzn_group_pad_fwd_f32", kern.get("pzn_group_fwd_f32", (0, 0.0)))
+            n_knn, ms_knn = kern_api.get("pzn_knn_f32", kern.get("pzn_knn_f32", (0, 0.0)))
+            n_grp, ms_grp = kern_api.get("pzn_group_pad_fwd_f32", kern.get("pzn_group_pad_fwd_f32", kern.get("pzn_group_fwd_f32", (0, 0.0))))
             ms_st = ms_knn + ms_grp
             stage_names = "knn32_reg_kernel (pzn_knn_f32) + group_pad_direct_kernel (pzn_group_pad_fwd_f32)"
             avg_launch = {"knn32_reg_kernel": ms_knn / max(1, n_knn), "group_pad_direct_kernel": ms_grp / max(1, n_grp)}
