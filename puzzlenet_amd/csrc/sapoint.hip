@@ -55,9 +55,10 @@ __device__ __forceinline__ float bcast(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
-// h rows.  A wavefront takes 64 consecutive rows: lane l fetches the index / offset of row l, then the rows are
-// written one after the other, all 64 lanes on the C1 = 64*V channels of one row (coalesced P read, h write).
-template <int V>
+// h rows.  A wavefront takes 64 consecutive rows: lane l fetches the index / offset of row l, then the rows are written
+// RPI at a time: 64 / RPI lanes per row, 16 bytes (V = 4 channels) per lane, so every load / store instruction moves
+// 1 KB whatever C1 = 256 / RPI is (coalesced P read, h write; 8-byte accesses at C1 = 128 ran at 3.3 TB/s against 3.9).
+template <int V, int RPI>
 __global__ __launch_bounds__(SP_T) void sa_point_l1_fwd_kernel(const float* __restrict__ xyz,
                                                                const float* __restrict__ new_xyz,
                                                                const int64_t* __restrict__ idx,
@@ -65,13 +66,15 @@ __global__ __launch_bounds__(SP_T) void sa_point_l1_fwd_kernel(const float* __re
                                                                const float* __restrict__ W1, int ldw,
                                                                const float* __restrict__ b1, int N, int S, long rows,
                                                                float* __restrict__ h, int xcd_map) {
-  constexpr int C1 = 64 * V;
+  constexpr int LPR = 64 / RPI;  // lanes per row
+  constexpr int C1 = LPR * V;
   const int lane = threadIdx.x & 63;
+  const int cl = lane % LPR, sub = lane / LPR;
   const long gw = (long)blockIdx.x * (SP_T / 64) + (threadIdx.x >> 6), nw = (long)gridDim.x * (SP_T / 64);
   float wx[V], wy[V], wz[V], bb[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) {
-    const int c = lane * V + i;
+    const int c = cl * V + i;
     wx[i] = W1[(size_t)c * ldw], wy[i] = W1[(size_t)c * ldw + 1], wz[i] = W1[(size_t)c * ldw + 2];
     bb[i] = b1 ? b1[c] : 0.f;
   }
@@ -102,30 +105,40 @@ __global__ __launch_bounds__(SP_T) void sa_point_l1_fwd_kernel(const float* __re
       prow = (int)(b * N + j);
     }
     const int nr = (int)min((long)64, rows - bt * 64);
+    // value of a per-row quantity for the row this lane works on in step r (row r + sub)
+    auto pick_i = [&](int x, int r) {
+      if constexpr (RPI == 1) return __builtin_amdgcn_readlane(x, r);
+      else return __shfl(x, r + sub, PZN_WAVE);
+    };
+    auto pick_f = [&](float x, int r) { return __builtin_bit_cast(float, pick_i(__builtin_bit_cast(int, x), r)); };
     auto finish = [&](float (&v)[V], int r) {
-      const float rx = bcast(dx, r), ry = bcast(dy, r), rz = bcast(dz, r);
+      const float rx = pick_f(dx, r), ry = pick_f(dy, r), rz = pick_f(dz, r);
 #pragma unroll
       for (int i = 0; i < V; ++i) {
         const float t = fmaf(wz[i], rz, fmaf(wy[i], ry, wx[i] * rx)) + v[i] + bb[i];
         v[i] = t > 0.f ? t : 0.f;
       }
-      store_vec<V>(h + ((size_t)bt * 64 + r) * C1 + lane * V, v);
+      if (RPI == 1 || r + sub < nr) store_vec<V>(h + ((size_t)bt * 64 + r + sub) * C1 + cl * V, v);
+    };
+    auto fetch = [&](float (&v)[V], int r) {
+      const int pr = pick_i(prow, RPI == 1 ? r : min(r, 63 - sub));   // (rows past the end re-read a valid row)
+      load_vec<V>(P + (size_t)pr * C1 + cl * V, v);
     };
     int r = 0;
-    for (; r + 4 <= nr; r += 4) {  // four P rows in flight
+    for (; r + 4 * RPI <= nr; r += 4 * RPI) {  // four row groups in flight
       float v0[V], v1[V], v2[V], v3[V];
-      load_vec<V>(P + (size_t)__builtin_amdgcn_readlane(prow, r) * C1 + lane * V, v0);
-      load_vec<V>(P + (size_t)__builtin_amdgcn_readlane(prow, r + 1) * C1 + lane * V, v1);
-      load_vec<V>(P + (size_t)__builtin_amdgcn_readlane(prow, r + 2) * C1 + lane * V, v2);
-      load_vec<V>(P + (size_t)__builtin_amdgcn_readlane(prow, r + 3) * C1 + lane * V, v3);
+      fetch(v0, r);
+      fetch(v1, r + RPI);
+      fetch(v2, r + 2 * RPI);
+      fetch(v3, r + 3 * RPI);
       finish(v0, r);
-      finish(v1, r + 1);
-      finish(v2, r + 2);
-      finish(v3, r + 3);
+      finish(v1, r + RPI);
+      finish(v2, r + 2 * RPI);
+      finish(v3, r + 3 * RPI);
     }
-    for (; r < nr; ++r) {
+    for (; r < nr; r += RPI) {
       float v0[V];
-      load_vec<V>(P + (size_t)__builtin_amdgcn_readlane(prow, r) * C1 + lane * V, v0);
+      fetch(v0, r);
       finish(v0, r);
     }
   }
@@ -319,11 +332,12 @@ PZN_EXPORT int pzn_sa_point_l1_fwd_f32(const float* xyz, const float* new_xyz, c
   if ((reinterpret_cast<uintptr_t>(P) & 15) || (reinterpret_cast<uintptr_t>(h) & 15)) return PZN_EUNSUPPORTED;
   const long rows = (long)B * S * 32;
   const long nbatch = (rows + 63) / 64;
-  // Few wavefronts with many rows in flight each: ~8 (4) wavefronts per CU at 512-byte (1-KB) rows measured best
-  // (0.18 -> 0.16 ms, 0.15 -> 0.14 ms against 16 per CU): more concurrent random row streams only lengthen the queues.
+  // Few wavefronts with many rows in flight each: 16 (4) wavefronts per CU at 512-byte (1-KB) rows measured best
+  // (level 1: 0.137 ms at 1024 workgroups, 0.163 at 512, 0.170 at 4096; level 2: 0.115 at 256-1024, 0.124 at 2048+):
+  // more concurrent random row streams only lengthen the queues.
   static const long fcap = [] { const char* e = getenv("PZN_SP_FGRID"); return e ? atol(e) : 0L; }();  // tuning aid
   long blocks = (nbatch + 3) / 4;
-  const long want = fcap ? fcap : (C1 == 256 ? 256 : 512);
+  const long want = fcap ? fcap : (C1 == 256 ? 256 : 1024);
   if (blocks > want) blocks = want;
   hipStream_t st = pzn_hip_stream(stream);
   static const int xmap = [] { const char* e = getenv("PZN_SP_XCD"); return e ? atoi(e) : 1; }();  // tuning aid
@@ -331,11 +345,14 @@ PZN_EXPORT int pzn_sa_point_l1_fwd_f32(const float* xyz, const float* new_xyz, c
   const dim3 grid((unsigned)blocks), block(SP_T);
   const int ldw = 3 + D;
   if (C1 == 64)
-    hipLaunchKernelGGL(sa_point_l1_fwd_kernel<1>, grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h, xmap);
+    hipLaunchKernelGGL((sa_point_l1_fwd_kernel<4, 4>), grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h,
+                       xmap);
   else if (C1 == 128)
-    hipLaunchKernelGGL(sa_point_l1_fwd_kernel<2>, grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h, xmap);
+    hipLaunchKernelGGL((sa_point_l1_fwd_kernel<4, 2>), grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h,
+                       xmap);
   else
-    hipLaunchKernelGGL(sa_point_l1_fwd_kernel<4>, grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h, xmap);
+    hipLaunchKernelGGL((sa_point_l1_fwd_kernel<4, 1>), grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h,
+                       xmap);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
