@@ -324,3 +324,29 @@ def test_bn_points_relu_vs_torch(B, N, C, training):
     assert rel(mine.running_mean, init.running_mean) < 1e-5
     assert rel(mine.running_var, init.running_var) < 1e-5
     assert int(mine.num_batches_tracked) == int(init.num_batches_tracked)
+
+
+@pytest.mark.parametrize("B,N,S", [(3, 97, 33), (2, 2048, 512), (5, 64, 64), (1, 8192, 16)])
+def test_knn_inverse_lists(B, N, S):
+    """pzn_knn_inverse_lists: the B*S*32 (row, point) pairs of a neighbour index sorted by point, per cloud — every row
+    exactly once, under the point it gathered, `off` the exclusive prefix of the reference counts."""
+    from puzzlenet_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N + S)
+    idx = torch.randint(0, N, (B, S, 32), generator=g, dtype=torch.int64)
+    idx[0, 0, :] = 0                      # a hub point: many rows under one point
+    d = idx.to(dev)
+    off = torch.empty(B * (N + 1), dtype=torch.int32, device=dev)
+    rows = torch.empty(B * S * 32, dtype=torch.int32, device=dev)
+    pts = torch.empty_like(rows)
+    ops._call("pzn_knn_inverse_lists", ops._p(d), B, N, S, 32, ops._p(off), ops._p(rows), ops._p(pts), ops._stream())
+    torch.cuda.synchronize()
+    off, rows, pts = off.cpu().view(B, N + 1), rows.cpu().view(B, S * 32), pts.cpu().view(B, S * 32)
+    flat = idx.view(B, -1)
+    for b in range(B):
+        counts = torch.bincount(flat[b], minlength=N)
+        assert torch.equal(off[b, 1:].long(), torch.cumsum(counts, 0))
+        assert int(off[b, 0]) == 0
+        assert torch.equal(torch.sort(rows[b].long())[0], torch.arange(S * 32))      # a permutation of the rows
+        assert torch.equal(flat[b][rows[b].long()], pts[b].long())                    # each row under its point
+        assert bool((pts[b, 1:] >= pts[b, :-1]).all())                                # grouped by point, ascending
