@@ -298,6 +298,15 @@ int pzn_bn_points_relu_bwd_f32(const float* x, const float* dy, const float* wei
                                const float* save_invstd, int training, int B, int N, int C,
                                float* dx, float* dweight, float* dbias, pzn_stream_t stream);
 
+/* pzn_pooled_layer_bwd_f32 behind the per-point first layer: h is a pure function of P, idx and the centre offsets
+ * (pzn_sa_point_l1_fwd_f32), so the input-gradient pass regenerates the ReLU gate of every row from those (L2-resident)
+ * with the forward's own expression instead of reading h[B*S*32, C1] from HBM; the weight-gradient pass reads h. */
+int pzn_sa_pooled_layer_bwd_f32(const float* dout, const int32_t* argmax, const float* out,
+                                const float* W2, const float* h, const float* P, const int64_t* idx,
+                                const float* xyz, const float* new_xyz, const float* W1,
+                                const float* b1, int B, int N, int S, int D, int C1, int C2, float* dh,
+                                float* dW2, float* db2, int accumulate, pzn_stream_t stream);
+
 /* scaled_dot_production of layerAttention, model5_b.py:67-75:
  * attn[B,L,L] = softmax(q[B,L,dk] k[B,L,dk]^T / sqrt(dk)), out[B,L,dv] = attn v.
  * attn is an output because the reference returns it (model5_b.py:97,101). */

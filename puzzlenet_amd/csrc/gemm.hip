@@ -1145,14 +1145,14 @@ PZN_EXPORT int pzn_sharedmlp_max_fwd_f32(const float* x, const float* W1, const 
 // shape allows (poolbwd.hip), else the two generated-operand GEMMs.
 static int pool_layer_bwd(const float* dout, const int32_t* argmax, const float* out, const float* W2, const float* h,
                           int R, int C1, int C2, float* dh_ws, float* dW2, float* db2, int accumulate,
-                          pzn_stream_t stream) {
+                          pzn_stream_t stream, const PznGateSource* gs = nullptr) {
   if (pzn_pool_bwd_supported(C1, C2, W2, h, dh_ws)) {
     hipStream_t st = pzn_hip_stream(stream);
     if (!accumulate) {
       if (pzn_zero_async(dW2, (size_t)C2 * C1, st) != PZN_OK) return PZN_ELAUNCH;
       if (pzn_zero_async(db2, (size_t)C2, st) != PZN_OK) return PZN_ELAUNCH;
     }
-    return pzn_pool_bwd_sparse(dout, argmax, out, W2, h, dh_ws, dW2, db2, R, C1, C2, st);
+    return pzn_pool_bwd_sparse(dout, argmax, out, W2, h, dh_ws, dW2, db2, R, C1, C2, st, gs);
   }
   int rc = pzn_linear_maxpool_dgrad_f32(dout, argmax, out, W2, R, C1, C2, h, dh_ws, stream);
   if (rc != PZN_OK) return rc;
@@ -1164,6 +1164,19 @@ PZN_EXPORT int pzn_pooled_layer_bwd_f32(const float* dout, const int32_t* argmax
                                         int accumulate, pzn_stream_t stream) {
   PZN_CHECK_ARG(dout && argmax && out && W2 && h && dh && dW2 && db2 && R > 0 && C1 > 0 && C2 > 0);
   return pool_layer_bwd(dout, argmax, out, W2, h, R, C1, C2, dh, dW2, db2, accumulate, stream);
+}
+
+// The same pass behind the per-point first layer (csrc/sapoint.hip): the ReLU gate of h is regenerated from P, idx and
+// the centre offsets (L2-resident) instead of read from h.
+PZN_EXPORT int pzn_sa_pooled_layer_bwd_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
+                                           const float* h, const float* P, const int64_t* idx, const float* xyz,
+                                           const float* new_xyz, const float* W1, const float* b1, int B, int N, int S,
+                                           int D, int C1, int C2, float* dh, float* dW2, float* db2, int accumulate,
+                                           pzn_stream_t stream) {
+  PZN_CHECK_ARG(dout && argmax && out && W2 && h && P && idx && xyz && new_xyz && W1 && dh && dW2 && db2);
+  PZN_CHECK_ARG(B > 0 && N > 0 && S > 0 && D >= 0 && C1 > 0 && C2 > 0 && (long)B * N < 2147483647L);
+  const PznGateSource gs{P, idx, xyz, new_xyz, W1, b1, 3 + D, N, S};
+  return pool_layer_bwd(dout, argmax, out, W2, h, B * S, C1, C2, dh, dW2, db2, accumulate, stream, &gs);
 }
 
 // Backward: dh_ws is [R*32, C1] scratch; dx may be NULL.  dW*, db* are overwritten.

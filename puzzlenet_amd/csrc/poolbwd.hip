@@ -45,6 +45,16 @@ struct PoolBwdArgs {
   float* dW;              // [C2, C1] += ...    (WGRAD)
   float* db;              // [C2] += ...        (WGRAD, may be NULL)
   int G, C1, C2;
+  // DGRAD, per-point first layer (csrc/sapoint.hip): h[r,:] = relu(W1[:,0:3] (xyz[idx[r]] - centre) + P[idx[r],:] + b1) is
+  // a pure function of L2-resident data, so the ReLU gate is REGENERATED with the forward's own expression instead
+  // of streaming h from HBM (537 MB per launch).  gP == NULL: the gate comes from h.
+  const float* gP;        // [B*N, C1]
+  const int64_t* gidx;    // [G*32]
+  const float* gxyz;      // [B*N, 3]
+  const float* gnew;      // [G, 3]
+  const float* gW1;       // [C1, gldw] (columns 0..2)
+  const float* gb1;       // [C1] (may be NULL)
+  int gldw, gN, gS;
 };
 
 template <int CPW>
@@ -131,6 +141,14 @@ __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
   __syncthreads();  // the only barrier: from here on every wavefront walks its own groups
 
   const int gw = blockIdx.x * (PD_T / 64) + wave, nw = gridDim.x * (PD_T / 64);
+  float gwx0 = 0.f, gwy0 = 0.f, gwz0 = 0.f, gbb0 = 0.f, gwx1 = 0.f, gwy1 = 0.f, gwz1 = 0.f, gbb1 = 0.f;
+  if (p.gP) {  // first-layer xyz weights and bias of this lane's two columns
+    const int c = col0 + 2 * lane;
+    gwx0 = p.gW1[(size_t)c * p.gldw], gwy0 = p.gW1[(size_t)c * p.gldw + 1], gwz0 = p.gW1[(size_t)c * p.gldw + 2];
+    gwx1 = p.gW1[(size_t)(c + 1) * p.gldw], gwy1 = p.gW1[(size_t)(c + 1) * p.gldw + 1];
+    gwz1 = p.gW1[(size_t)(c + 1) * p.gldw + 2];
+    if (p.gb1) gbb0 = p.gb1[c], gbb1 = p.gb1[c + 1];
+  }
   int av_n[NQ];
   float gv_n[NQ];
 #define PD_PREFETCH(gg)                                             \
@@ -151,10 +169,39 @@ __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
     for (int q = 0; q < NQ; ++q) av[q] = av_n[q], gv[q] = gv_n[q];
     if (g + nw < p.G) PD_PREFETCH(g + nw);
     const size_t row0 = ((size_t)g * 32) * p.C1 + col0 + 2 * lane;
-    v2f hm = p.h ? *reinterpret_cast<const v2f*>(p.h + row0) : v2f{1.f, 1.f};
+    // regenerated gate: lane l (mod 32) fetches row l's point and centre offset once per group
+    int gprow = 0;
+    float gdx = 0.f, gdy = 0.f, gdz = 0.f;
+    if (p.gP) {
+      const int rl = lane & 31;
+      const long b = g / p.gS;
+      const int j = (int)p.gidx[(size_t)g * 32 + rl];
+      const float* pq = p.gxyz + ((size_t)b * p.gN + j) * 3;
+      const float* c = p.gnew + (size_t)g * 3;
+      gdx = pq[0] - c[0], gdy = pq[1] - c[1], gdz = pq[2] - c[2];
+      gprow = (int)(b * p.gN + j);
+    }
+    auto gate_src = [&](int k) {  // the two P values of row k for this lane's columns
+      const int pr = __builtin_amdgcn_readlane(gprow, k);
+      return *reinterpret_cast<const v2f*>(p.gP + (size_t)pr * p.C1 + col0 + 2 * lane);
+    };
+    auto gate_of = [&](v2f pv, int k) {  // same expression as sa_point_l1_fwd_kernel: the sign is the forward's
+      const float rx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gdx), k));
+      const float ry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gdy), k));
+      const float rz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gdz), k));
+      const float t0 = fmaf(gwz0, rz, fmaf(gwy0, ry, gwx0 * rx)) + pv.x + gbb0;
+      const float t1 = fmaf(gwz1, rz, fmaf(gwy1, ry, gwx1 * rx)) + pv.y + gbb1;
+      return v2f{t0, t1};
+    };
+    v2f hm = p.gP ? gate_src(0) : (p.h ? *reinterpret_cast<const v2f*>(p.h + row0) : v2f{1.f, 1.f});
     for (int k = 0; k < 32; ++k) {  // rows of the group in turn: exactly C2 hits per group, whatever the arg-max skew
       v2f hm_next = v2f{1.f, 1.f};
-      if (p.h && k + 1 < 32) hm_next = *reinterpret_cast<const v2f*>(p.h + row0 + (size_t)(k + 1) * p.C1);
+      if (p.gP) {
+        if (k + 1 < 32) hm_next = gate_src(k + 1);
+        hm = gate_of(hm, k);
+      } else if (p.h && k + 1 < 32) {
+        hm_next = *reinterpret_cast<const v2f*>(p.h + row0 + (size_t)(k + 1) * p.C1);
+      }
       v2f acc0 = v2f{0.f, 0.f}, acc1 = acc0;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
@@ -233,8 +280,12 @@ bool pzn_pool_bwd_supported(int C1, int C2, const float* W, const float* h, cons
 }
 
 int pzn_pool_bwd_sparse(const float* dout, const int32_t* argmax, const float* out, const float* W, const float* h,
-                        float* dh, float* dW, float* db, int G, int C1, int C2, hipStream_t st) {
-  PoolBwdArgs p{dout, argmax, out, W, h, dh, dW, db, G, C1, C2};
+                        float* dh, float* dW, float* db, int G, int C1, int C2, hipStream_t st, const PznGateSource* gs) {
+  PoolBwdArgs p{dout, argmax, out, W, h, dh, dW, db, G, C1, C2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+  if (gs && gs->P) {
+    p.gP = gs->P, p.gidx = gs->idx, p.gxyz = gs->xyz, p.gnew = gs->new_xyz, p.gW1 = gs->W1, p.gb1 = gs->b1;
+    p.gldw = gs->ldw, p.gN = gs->N, p.gS = gs->S;
+  }
   if (!dh && !dW) return PZN_EINVAL;
   if (dW) {
     int rc = launch_wgrad(p, st);

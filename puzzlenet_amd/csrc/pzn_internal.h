@@ -7,8 +7,18 @@
 //   dh != NULL: dh[G*32, C1] = scatter(dout) W, ReLU-masked by h when h != NULL (overwritten)
 //   dW != NULL: dW[C2, C1] += scatter(dout)^T h,  db[C2] += column sums (db may be NULL)
 bool pzn_pool_bwd_supported(int C1, int C2, const float* W, const float* h, const float* dh);
+// where the sparse input-gradient pass can regenerate the first layer's ReLU gate from (per-point first layer)
+struct PznGateSource {
+  const float* P;
+  const int64_t* idx;
+  const float* xyz;
+  const float* new_xyz;
+  const float* W1;
+  const float* b1;
+  int ldw, N, S;
+};
 int pzn_pool_bwd_sparse(const float* dout, const int32_t* argmax, const float* out, const float* W, const float* h,
-                        float* dh, float* dW, float* db, int G, int C1, int C2, hipStream_t st);
+                        float* dh, float* dW, float* db, int G, int C1, int C2, hipStream_t st, const PznGateSource* gs = nullptr);
 
 // wsgemm.hip: weight-stationary bf16x3 GEMM for skinny layers.  C[M,N] = epi(A[M,K] W^T), W[n*ldw+k]
 // (w_kmajor = 0) or W[k*ldw+n] (w_kmajor = 1); genY masks A by genY > 0, maskH masks C, argmax != NULL

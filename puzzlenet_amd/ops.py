@@ -799,14 +799,14 @@ class _SaMlpMaxPoint(torch.autograd.Function):
                   _p(h), _stream())
             _call("pzn_linear_maxpool_fwd_f32", _p(h), _p(w2), _p(b2), R, C1, C2, _p(out), _p(arg), _stream(),
                   flops=2 * R * 32 * C1 * C2)
-        ctx.save_for_backward(xyz, feat, new_xyz, idx, w1, w_f, w2, h, out, arg)
+        ctx.save_for_backward(xyz, feat, new_xyz, idx, w1, w_f, w2, h, out, arg, P, b1)
         ctx.dims = (B, N, S, D, R, C1, C2)
         ctx.param_refs = (w1, b1, w2, b2)
         return out.reshape(B, S, C2)
 
     @staticmethod
     def backward(ctx, dout):
-        xyz, feat, new_xyz, idx, w1, w_f, w2, h, out, arg = ctx.saved_tensors
+        xyz, feat, new_xyz, idx, w1, w_f, w2, h, out, arg, P, b1 = ctx.saved_tensors
         B, N, S, D, R, C1, C2 = ctx.dims
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
             raise _lib.PznError("sa_mlp_max: gradients w.r.t. point coordinates are not provided on the fused "
@@ -831,8 +831,13 @@ class _SaMlpMaxPoint(torch.autograd.Function):
         dwf = torch.empty((C1, D), dtype=torch.float32, device=dev)
         dfeat = None
         with torch.cuda.device(dev):
-            _call("pzn_pooled_layer_bwd_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(h), R, C1, C2, _p(dh), _p(dW2), _p(db2),
-                  int(direct), _stream(), flops=2 * R * (2 * C1 * C2))
+            if _SA_REGEN:    # the ReLU gate of h regenerated from P / idx (L2) instead of read from h (HBM)
+                _call("pzn_sa_pooled_layer_bwd_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(h), _p(P), _p(idx), _p(xyz),
+                      _p(new_xyz), _p(w1), _p(b1), B, N, S, D, C1, C2, _p(dh), _p(dW2), _p(db2), int(direct), _stream(),
+                      flops=2 * R * (2 * C1 * C2))
+            else:
+                _call("pzn_pooled_layer_bwd_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(h), R, C1, C2, _p(dh), _p(dW2),
+                      _p(db2), int(direct), _stream(), flops=2 * R * (2 * C1 * C2))
             _call("pzn_knn_inverse_lists", _p(idx), B, N, S, 32, _p(off), _p(rows), _p(pts), _stream())
             _call("pzn_sa_point_l1_bwd_f32", _p(dh), _p(xyz), _p(new_xyz), _p(rows), _p(pts), B, N, S, D, C1, _p(dP),
                   _p(dW1), _p(db1), _stream())
@@ -848,6 +853,7 @@ class _SaMlpMaxPoint(torch.autograd.Function):
         return None, dfeat, None, None, dW1, db1, dW2, db2
 
 
+_SA_REGEN = os.environ.get("PZN_SA_REGEN", "1") != "0"     # tuning aid: 0 = the pooled backward reads its gate from h
 _SA_POINT = os.environ.get("PZN_SA_POINT", "1") != "0"     # tuning aid: 0 = the grouped-row path (_SaMlpMax)
 
 
