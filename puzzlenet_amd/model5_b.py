@@ -307,8 +307,8 @@ class TouchedRegraster(_Base):
         non_sg_fmrpc = _run_seq(self.MLPLocalPreRpc, non_sg_fmrpc)                  # :739
         # :741 — the reference takes the max of non_sg_fmrpc for BOTH globals (its bug, kept)
         g_max = ops.max_over_points(non_sg_fmrpc).unsqueeze(1)      # one reduction serves both (identical) globals
-        non_sg_ffpc_global = g_max.repeat(1, N, 1)
-        non_sg_fmrpc_global = g_max.repeat(1, N, 1)
+        non_sg_ffpc_global = g_max.expand(-1, N, -1)      # (:745-746 repeat(1, N, 1): the concat below reads the broadcast view)
+        non_sg_fmrpc_global = non_sg_ffpc_global
         ffpc_feature4seg = torch.cat([non_sg_fmrpc_global, non_sg_ffpc], dim=-1)    # :748
         fmrpc_feature4seg = torch.cat([non_sg_ffpc_global, non_sg_fmrpc], dim=-1)   # :749
         de_fpcb = _run_seq(self.MLPFpcb, ffpc_feature4seg).permute(0, 2, 1)         # :751-752
