@@ -222,7 +222,8 @@ def test_emd_side_stream_and_deferred_root(golden_loss, dev):
     l0, g0 = run(False, False)
     l1, g1 = run(True, False)
     l2, g2 = run(True, True)
-    assert abs(l1 - l0) <= 1e-6 * abs(l0) and abs(l2 - l0) <= 1e-5 * abs(l0)
+    # (the pose head's few-row layers sum their K splits with atomics: the forward itself repeats to ~1e-6 only)
+    assert abs(l1 - l0) <= 2e-5 * abs(l0) and abs(l2 - l0) <= 2e-5 * abs(l0)
     # (gradients carry the run-to-run rounding of the atomic weight-gradient sums; EMD terms: see test_gpu_emd)
     assert float((g1 - g0).norm() / g0.norm()) < 2e-3
     assert float((g2 - g0).norm() / g0.norm()) < 2e-3
