@@ -214,7 +214,7 @@ def main():
         # (1) the dominant kernel of the step: the matrix-core tile engine (csrc/gemm.hip), MFMA-bound.
         #     achieved = algorithmic 2*M*N*K of every dense entry point / their summed launch durations.
         dense_names = ("pzn_linear_fwd_f32", "pzn_linear_dgrad_f32", "pzn_linear_wgrad_f32",
-                       "pzn_linear_maxpool_fwd_f32", "pzn_pooled_layer_bwd_f32",
+                       "pzn_linear_maxpool_fwd_f32", "pzn_pooled_layer_bwd_f32", "pzn_sa_pooled_layer_bwd_f32",
                        "pzn_sharedmlp_max_fwd_f32", "pzn_sa_mlp_max_bwd_f32", "pzn_sa_mlp_max_bwd_scatter_f32",
                        "pzn_attn_fwd_f32", "pzn_attn_bwd_f32", "pzn_attn_block_fwd_f32", "pzn_attn_block_bwd_f32")
         d_ms = sum(kern.get(k, (0, 0.0))[1] for k in dense_names)
@@ -226,8 +226,8 @@ def main():
             "kernel": "the bf16x3 split-precision matrix-core kernels (fp32 result): ws_gemm_kernel (weight-stationary, forward / "
                       "input gradients of the skinny layers), df_wgrad_kernel (direct-fragment weight gradients), gemm_kernel "
                       "(general tile engine: wide layers, attention products) behind pzn_linear_* / pzn_linear_maxpool_fwd / "
-                      "pzn_pooled_layer_bwd / pzn_attn_*; the time also contains the sparse max-pool backward kernels of "
-                      "pzn_pooled_layer_bwd, the flops do not; the first set-abstraction layer is counted as the per-point "
+                      "pzn_(sa_)pooled_layer_bwd / pzn_attn_*; the time also contains the sparse max-pool backward kernels of "
+                      "pzn_(sa_)pooled_layer_bwd (vector-ALU passes, 1.6 ms per step), their flops are the 2*R*2*C1*C2 they execute; the first set-abstraction layer is counted as the per-point "
                       "product it now is (B*N rows, csrc/sapoint.hip), not as the B*S*32-row product of the reference",
             "achieved": mfma_achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": mfma_achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
