@@ -33,3 +33,9 @@ def golden_loss():
 @pytest.fixture(scope="session")
 def golden_eval():
     return np.load(os.path.join(GOLDEN, "eval.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_data():
+    """tests/golden/data.npz: the reference's data-pipeline functions on seeded clouds (make_golden_data.py)."""
+    return np.load(os.path.join(GOLDEN, "data.npz"))
