@@ -135,8 +135,8 @@ def cpu_baseline(N, pairs, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU")
     ap.add_argument("--points", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
