@@ -49,3 +49,25 @@ def test_rows_that_need_a_new_cut_are_flagged(golden_data):
     z[1] = 10.0                      # everything lands on one side of the plane
     _, ok = datapipe.make_pairs(b["raw"], b["normal"], z, b["s_up"], torch.zeros_like(b["s_down"]), b["twist"], n=int(G["N"]))
     assert ok.tolist() == [True, False, True, True]
+
+
+def test_pairs_feed_a_training_step(golden_data):
+    """The 8-tuple of datapipe.make_pairs is the batch contract of model5_b.training_step (dataset.py:98-105): one
+    eager training step on it runs through every kernel and leaves finite loss and gradients."""
+    from oracle import model_ref as mr
+    from puzzlenet_amd import datapipe, engine
+    from puzzlenet_amd import model5_b as mb
+    G = golden_data
+    dev = torch.device("cuda:0")
+    b = _batch(G, dev)
+    batch, ok = datapipe.make_pairs(b["raw"], b["normal"], b["z"], b["s_up"], b["s_down"], b["twist"], n=int(G["N"]))
+    assert bool(ok.all())
+    cfg = mr.Cfg(loss_mode=1, num_points=int(G["N"]))
+    torch.manual_seed(0)
+    model = mb.TouchedRegraster(cfg).to(dev)
+    runner = engine.TrainStep(model, list(batch), cfg.lr, world=1, use_graph=False)
+    l0 = float(runner.step())
+    l1 = float(runner.step())
+    assert np.isfinite(l0) and np.isfinite(l1)
+    assert bool(torch.isfinite(runner.grads.flat).all()) and float(runner.grads.flat.abs().max()) > 0
+    runner.close()
