@@ -221,6 +221,10 @@ def main():
         d_fl = sum(kern_flops.get(k, 0) for k in dense_names)
         d_n = sum(kern.get(k, (0, 0.0))[0] for k in dense_names)
         mfma_achieved = d_fl / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
+        mfma_traffic = None      # HBM bytes per step of these kernels from the committed PMC passes (tools/pmc_summary.py)
+        tpath0 = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(tpath0) and (B, N) == (64, 2048):
+            mfma_traffic = json.load(open(tpath0)).get("mfma_family_bytes_per_step")
         roofline = {
             "bound": "mfma",
             "kernel": "the bf16x3 split-precision matrix-core kernels (fp32 result): ws_gemm_kernel (weight-stationary, forward / "
@@ -230,7 +234,7 @@ def main():
                       "pzn_(sa_)pooled_layer_bwd (vector-ALU passes, 1.6 ms per step), their flops are the 2*R*2*C1*C2 they execute; the first set-abstraction layer is counted as the per-point "
                       "product it now is (B*N rows, csrc/sapoint.hip), not as the B*S*32-row product of the reference",
             "achieved": mfma_achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": mfma_achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+            "frac": mfma_achieved / MFMA_F32_PEAK_TFLOPS, "traffic": mfma_traffic,
             "algorithmic_flops_per_step": d_fl / max(1, prof_steps),
             "ms_per_step": d_ms / max(1, prof_steps), "launches_per_step": d_n / max(1, prof_steps),
             "note": "algorithmic fp32 flops / summed launch time; peak = dense fp32 MFMA rate (157.3 TFLOP/s); the skinny "

@@ -52,11 +52,17 @@ def main():
     sa = None
     if "sa_point_l1_fwd_kernel" in per and "sa_point_l1_bwd_kernel" in per:
         sa = round(4 * (per["sa_point_l1_fwd_kernel"]["hbm_bytes_per_launch"] + per["sa_point_l1_bwd_kernel"]["hbm_bytes_per_launch"]))
+    # the matrix-core family behind bench.py's `roofline` (+ the sparse pooled passes its time includes): bytes per
+    # training step = sum over launches / passes in the trace (1 warm-up + 2 timed + 1 + 3 instrumented = 7)
+    passes = 7
+    fam = ("ws_gemm_kernel", "df_wgrad_kernel", "gemm_kernel", "pool_dgrad_kernel", "pool_wgrad_kernel")
+    mfma = round(sum(per[k]["hbm_bytes_per_launch"] * per[k]["launches"] for k in fam if k in per) / passes) or None
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, python bench.py --steps 2 --warmup 1 "
                      "--no-cpu-baseline (B=64, N=2048)",
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE half-count, MI355X_MICROARCH.md)",
            "knn_group_stage_bytes_per_step": stage,
            "knn_group_stage_algorithmic_bytes_per_step": 1242431488,
+           "mfma_family_bytes_per_step": mfma,
            "sa_gather_stage_bytes_per_step": sa,
            "sa_gather_stage_algorithmic_bytes_per_step": 4746904576,
            "per_kernel": {k: v for k, v in per.items() if not k.startswith("at::") and "rocclr" not in k}}
