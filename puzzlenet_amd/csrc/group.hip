@@ -74,11 +74,11 @@ __global__ __launch_bounds__(GRP_WAVES* PZN_WAVE) void group_fwd_vec_kernel(
       chunk[k * W + c] = __fsub_rn(p, ctr[c]);  // pointnet_util.py:125
       if (grouped_xyz) grouped_xyz[qi * K * 3 + t] = p;
     }
-    __builtin_amdgcn_wave_barrier();
+    pzn::wave_lds_sync();
     float4* o4 = reinterpret_cast<float4*>(out + qi * K * W);
     const float4* c4 = reinterpret_cast<const float4*>(chunk);
     for (int t = lane; t < (K * W) >> 2; t += PZN_WAVE) o4[t] = c4[t];
-    __builtin_amdgcn_wave_barrier();
+    pzn::wave_lds_sync();
   }
 }
 

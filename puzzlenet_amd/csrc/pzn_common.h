@@ -114,4 +114,15 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (PZN_WAVE - 1); }
 
+// Lanes of ONE wavefront exchanging data through LDS: the hardware executes a wave's LDS instructions in order, so no
+// s_barrier is needed, but the COMPILER must be told that other lanes wrote memory: llvm.amdgcn.wave.barrier alone is
+// declared without memory effects, and a load hoisted or re-used across it reads a stale value (seen: lanes 32..63
+// of a merge loop kept the previous iteration's keys).  The wavefront-scope fence is the IR-level memory barrier
+// (it emits no instruction beyond the wait for outstanding LDS operations); the wave barrier pins the schedule.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
 }  // namespace pzn

@@ -16,18 +16,27 @@ import torch.distributed as dist
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*.
-    Returns (rank, world, local_rank). world == 1 -> no process group."""
+    Returns (rank, world, local_rank). world == 1 -> no process group.  With a GPU the rank's device is selected
+    BEFORE the process group exists and handed to it (`device_id`), so the RCCL communicator is bound to that device
+    eagerly instead of to whatever device is current at the first collective."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    on_gpu = torch.cuda.is_available()
+    if on_gpu:
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))   # (rehearsals with more ranks than GPUs share one)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            raise RuntimeError("WORLD_SIZE > 1 needs MASTER_PORT (torch.distributed.run sets it)")
         if backend is None:
             # "nccl" IS RCCL on ROCm.  PZN_DIST_BACKEND=gloo rehearses the multi-rank path where RCCL cannot run
             # (several ranks sharing one GPU, CPU-only hosts).
-            backend = os.environ.get("PZN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            backend = os.environ.get("PZN_DIST_BACKEND") or ("nccl" if on_gpu else "gloo")
+        kw = {}
+        if backend == "nccl" and on_gpu:
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 

@@ -234,8 +234,7 @@ class TouchedRegraster(_Base):
             mrpc = mrpc.unsqueeze(0)
         N = fpc.shape[1]
 
-        capturing = fpc.is_cuda and torch.cuda.is_current_stream_capturing()
-        if self.two_streams and fpc.is_cuda and not capturing:
+        if self.two_streams and fpc.is_cuda:
             # FPS is a latency-bound chain on 128 workgroups: it runs on the side stream while this one computes the
             # per-point features of both clouds, which do not depend on it; then Encoder stays here, Encoder2 goes
             # to the side stream (the two are independent and most of their launches do not fill 256 CUs; autograd
@@ -267,30 +266,8 @@ class TouchedRegraster(_Base):
                     t.record_stream(cur)
             return self._heads(ffpcs, fmrpcs, N, need, pose_hook)
         plan_f, plan_m = self._sa_plans(fpc, mrpc)
-        if self.two_streams and fpc.is_cuda and (not capturing or self.two_streams == "graph"):
-            # The two encoders are independent (separate weights, separate clouds) and most of their launches
-            # are too small to fill 256 CUs: run Encoder2 on a side HIP stream next to Encoder.  Autograd
-            # replays each backward node on its forward stream, so the backward passes overlap as well.
-            cur = torch.cuda.current_stream()
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream()
-                # leaf gradients of Encoder2 are accumulated on the side stream by design
-                _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-                if _quiet is not None:
-                    _quiet(False)
-            side = self._side_stream
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                fmrpcs = self.Encoder2(mrpc, plan_m)                                # :716
-            ffpcs = self.Encoder(fpc, plan_f)                                       # :710
-            cur.wait_stream(side)
-            if not capturing:      # (inside a graph capture the allocator's private pool already orders re-use)
-                for t in fmrpcs:
-                    if isinstance(t, torch.Tensor):
-                        t.record_stream(cur)
-        else:
-            ffpcs = self.Encoder(fpc, plan_f)                                       # :710
-            fmrpcs = self.Encoder2(mrpc, plan_m)                                    # :716
+        ffpcs = self.Encoder(fpc, plan_f)                                           # :710
+        fmrpcs = self.Encoder2(mrpc, plan_m)                                        # :716
         return self._heads(ffpcs, fmrpcs, N, need, pose_hook)
 
     def _heads(self, ffpcs, fmrpcs, N, need, pose_hook=None):
@@ -331,17 +308,13 @@ class TouchedRegraster(_Base):
             return None, None
         B, N, _ = fpc.shape
         dev = fpc.device
-        if pu._FEED is not None:
-            d1, d2 = pu._FEED.next(B, N, dev), pu._FEED.next(B, 512, dev)
-            d3, d4 = pu._FEED.next(B, N, dev), pu._FEED.next(B, 512, dev)
-        else:
-            d1, d2 = torch.randint(0, N, (B,), dtype=torch.long), torch.randint(0, 512, (B,), dtype=torch.long)
-            d3, d4 = torch.randint(0, N, (B,), dtype=torch.long), torch.randint(0, 512, (B,), dtype=torch.long)
-            # ONE asynchronous upload from pinned memory: a pageable `.to(dev)` blocks the host until everything queued
-            # before it has run (4 of them per step drained the launch queue at every step start)
-            stage = torch.empty((4, B), dtype=torch.long, pin_memory=True)
-            torch.stack((d1, d2, d3, d4), out=stage)
-            d1, d2, d3, d4 = stage.to(dev, non_blocking=True).unbind(0)
+        d1, d2 = torch.randint(0, N, (B,), dtype=torch.long), torch.randint(0, 512, (B,), dtype=torch.long)
+        d3, d4 = torch.randint(0, N, (B,), dtype=torch.long), torch.randint(0, 512, (B,), dtype=torch.long)
+        # ONE asynchronous upload from pinned memory: a pageable `.to(dev)` blocks the host until everything queued
+        # before it has run (4 of them per step drained the launch queue at every step start)
+        stage = torch.empty((4, B), dtype=torch.long, pin_memory=True)
+        torch.stack((d1, d2, d3, d4), out=stage)
+        d1, d2, d3, d4 = stage.to(dev, non_blocking=True).unbind(0)
         xyz = torch.cat([fpc, mrpc], dim=0)
         f1 = ops.farthest_point_sample(xyz, 512, torch.cat([d1, d3]))
         x1 = ops.index_points(xyz, f1)
@@ -378,8 +351,7 @@ class TouchedRegraster(_Base):
         pose = {}
 
         def fork_emd(o):
-            if _EMD_SIDE and self.two_streams and o.is_cuda and self._side_stream is not None and \
-                    not torch.cuda.is_current_stream_capturing():
+            if _EMD_SIDE and self.two_streams and o.is_cuda and self._side_stream is not None:
                 cur = torch.cuda.current_stream()
                 side = self._side_stream
                 side.wait_stream(cur)

@@ -227,29 +227,41 @@ def max_over_points(x):
 
 
 class _Group(torch.autograd.Function):
-    """pointnet_util.py:123-132: cat(xyz[idx] - new_xyz, feat[idx]) in one kernel."""
+    """pointnet_util.py:123-132: cat(xyz[idx] - new_xyz, feat[idx]) in one kernel.  idx=None: the K = 32 neighbour
+    search of pointnet_util.py:118-119 runs in the same launch (pzn_knn_group_f32) and idx becomes an output."""
 
     @staticmethod
     def forward(ctx, xyz, feat, new_xyz, idx, want_grouped_xyz):
-        xyz, new_xyz, idx = _f32(xyz, "xyz"), _f32(new_xyz, "new_xyz"), _i64(idx, "idx")
+        xyz, new_xyz = _f32(xyz, "xyz"), _f32(new_xyz, "new_xyz")
         B, N, _ = xyz.shape
-        _, S, K = idx.shape
+        S = new_xyz.shape[1]
+        fuse_knn = idx is None
+        if fuse_knn:
+            K = 32
+            idx = torch.empty((B, S, K), dtype=torch.int64, device=xyz.device)
+        else:
+            idx = _i64(idx, "idx")
+            K = idx.shape[2]
         D = 0 if feat is None else feat.shape[-1]
         feat_c = None if feat is None else _f32(feat, "points")
         out = torch.empty((B, S, K, 3 + D), dtype=torch.float32, device=xyz.device)
         gx = torch.empty((B, S, K, 3), dtype=torch.float32, device=xyz.device) if want_grouped_xyz else None
         with torch.cuda.device(xyz.device):
-            _call("pzn_group_fwd_f32", _p(xyz), _p(feat_c), _p(new_xyz), _p(idx), B, N, S, K, D,
+            if fuse_knn:
+                _call("pzn_knn_group_f32", _p(xyz), _p(feat_c), _p(new_xyz), B, N, S, D, _p(idx), _p(out), _p(gx), _stream())
+            else:
+                _call("pzn_group_fwd_f32", _p(xyz), _p(feat_c), _p(new_xyz), _p(idx), B, N, S, K, D,
                       _p(out), _p(gx), _stream())
         ctx.save_for_backward(idx)
         ctx.dims = (B, N, S, K, D)
         ctx.has_feat = feat is not None
+        ctx.mark_non_differentiable(idx)
         if gx is not None:
             ctx.mark_non_differentiable(gx)
-        return out, gx
+        return out, gx, idx
 
     @staticmethod
-    def backward(ctx, grad_out, _grad_gx):
+    def backward(ctx, grad_out, _grad_gx, _grad_idx):
         (idx,) = ctx.saved_tensors
         B, N, S, K, D = ctx.dims
         need_xyz, need_feat, need_new = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
@@ -268,8 +280,19 @@ class _Group(torch.autograd.Function):
 
 
 def group(xyz, feat, new_xyz, idx, want_grouped_xyz=False):
-    out, gx = _Group.apply(xyz, feat, new_xyz, idx, want_grouped_xyz)
+    out, gx, _ = _Group.apply(xyz, feat, new_xyz, idx, want_grouped_xyz)
     return (out, gx) if want_grouped_xyz else out
+
+
+def knn_group_supported(xyz, feat, nsample):
+    """Shapes pzn_knn_group_f32 takes (include/pzn.h): K = 32, 64 <= N <= 4096, a feature table with D % 4 == 0."""
+    return nsample == 32 and feat is not None and feat.shape[-1] > 0 and feat.shape[-1] % 4 == 0 and \
+        64 <= xyz.shape[1] <= 4096
+
+
+def knn_group(xyz, feat, new_xyz, want_grouped_xyz=False):
+    """Neighbour search (K = 32) + grouping in one launch -> (new_points[B,S,32,3+D], grouped_xyz or None, idx)."""
+    return _Group.apply(xyz, feat, new_xyz, None, want_grouped_xyz)
 
 
 # --------------------------------------------------------------------------- EMD

@@ -13,55 +13,9 @@ Differences a caller can observe:
 """
 import torch
 
-from . import ops
+from . import _lib, ops
 
-__all__ = ["square_distance", "index_points", "farthest_point_sample", "query_ball_point", "sample_and_group",
-           "StartIndexFeed", "set_start_index_feed"]
-
-
-class StartIndexFeed:
-    """Stages the FPS start indices through static device buffers.
-
-    The reference draws the first centroid with ``torch.randint(0, N, (B,))`` on the CPU generator
-    at every call (pointnet_util.py:65).  A host draw + host-to-device copy cannot live inside a
-    HIP graph, so when a whole training step is captured the draws are made by ``refill()`` *before*
-    each replay — same generator, same order, same values as the eager path — into buffers the
-    captured FPS kernels read.
-    """
-
-    def __init__(self):
-        self.slots = []          # (device tensor, N) in call order
-        self.cursor = 0
-        self.recording = True    # first pass (capture): create slots; afterwards: slots are fixed
-
-    def next(self, B, N, device):
-        if self.recording:
-            t = torch.randint(0, N, (B,), dtype=torch.long).to(device)
-            self.slots.append((t, N))
-            return t
-        t, n = self.slots[self.cursor]
-        assert n == N and t.shape[0] == B, "FPS call sequence changed since capture"
-        self.cursor += 1
-        return t
-
-    def freeze(self):
-        self.recording = False
-        self.cursor = 0
-
-    def refill(self):
-        """Draw fresh start indices for every recorded FPS call (call before each graph replay)."""
-        self.cursor = 0
-        for t, n in self.slots:
-            t.copy_(torch.randint(0, n, (t.shape[0],), dtype=torch.long), non_blocking=False)
-
-
-_FEED = None
-
-
-def set_start_index_feed(feed):
-    """Install (or clear with None) a StartIndexFeed used by farthest_point_sample."""
-    global _FEED
-    _FEED = feed
+__all__ = ["square_distance", "index_points", "farthest_point_sample", "query_ball_point", "sample_and_group"]
 
 
 def square_distance(src, dst):
@@ -83,8 +37,6 @@ def farthest_point_sample(xyz, npoint, start_idx=None):
     """
     B, N, _ = xyz.shape
     if start_idx is None:
-        if _FEED is not None:
-            return ops.farthest_point_sample(xyz, npoint, _FEED.next(B, N, xyz.device))
         start_idx = torch.randint(0, N, (B,), dtype=torch.long)
     return ops.farthest_point_sample(xyz, npoint, start_idx.to(xyz.device))
 
@@ -99,6 +51,13 @@ def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, knn=
     (+ grouped_xyz[B,S,K,3], fps_idx[B,S] when returnfps)."""
     fps_idx = farthest_point_sample(xyz, npoint)                      # :113
     new_xyz = ops.index_points(xyz, fps_idx)                          # :115
+    if knn and ops.knn_group_supported(xyz, points, nsample):
+        # :117-132 in ONE launch (pzn_knn_group_f32): search and reference-layout group write by the same wavefront
+        try:
+            new_points, grouped_xyz, _ = ops.knn_group(xyz, points, new_xyz, want_grouped_xyz=returnfps)
+            return (new_xyz, new_points, grouped_xyz, fps_idx) if returnfps else (new_xyz, new_points)
+        except _lib.PznUnsupported:      # e.g. rows too wide for the LDS pieces: the two single launches below
+            pass
     if knn:
         idx = ops.knn(xyz, new_xyz.detach(), nsample)                 # :118-119
     else:

@@ -103,21 +103,3 @@ def test_init_from_env_single_process(monkeypatch):
     pdist.broadcast_parameters(m)                                  # no-op without a process group
     fg = pdist.FlatGradAllReduce(m.parameters())
     fg.all_reduce_mean()                                           # likewise
-
-
-def test_start_index_feed_replays_the_reference_draws():
-    """StartIndexFeed.refill() makes the same torch.randint draws, in the same order, as the eager path."""
-    sys.path.insert(0, ROOT)
-    from puzzlenet_amd import pointnet_util as pu
-    feed = pu.StartIndexFeed()
-    torch.manual_seed(3)
-    a = [feed.next(4, 2048, "cpu").clone(), feed.next(4, 512, "cpu").clone()]
-    torch.manual_seed(3)
-    b = [torch.randint(0, 2048, (4,), dtype=torch.long), torch.randint(0, 512, (4,), dtype=torch.long)]
-    assert all(torch.equal(x, y) for x, y in zip(a, b))
-    feed.freeze()
-    torch.manual_seed(9)
-    feed.refill()
-    torch.manual_seed(9)
-    c = [torch.randint(0, 2048, (4,), dtype=torch.long), torch.randint(0, 512, (4,), dtype=torch.long)]
-    assert torch.equal(feed.next(4, 2048, "cpu"), c[0]) and torch.equal(feed.next(4, 512, "cpu"), c[1])

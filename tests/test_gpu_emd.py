@@ -70,6 +70,33 @@ def test_known_answer_from_reference_test(dev):
         np.testing.assert_allclose(t2.grad.cpu().numpy(), g2, rtol=1e-3, atol=1e-4)
 
 
+def test_hand_derived_capacity_vectors(dev):
+    """tests/emd_vectors.py: clustered clouds whose matching can be written down by hand; they exercise the
+    integer capacities multiL / multiR of emd_kernel.cu:29-35 (n = 6, m = 4 -> 1, not 1.5) and n != m on the
+    three-call path (match itself), the fused path and the drop-in autograd function."""
+    from puzzlenet_amd import emd_cuda, ops
+    from puzzlenet_amd.PyTorchEMD.emd import earth_mover_distance
+    from tests import emd_vectors as ev
+    for case in ev.CASES:
+        x1, x2, match, cost = case()
+        t1, t2 = _t(x1, dev), _t(x2, dev)
+        m = emd_cuda.approxmatch_forward(t1, t2)
+        np.testing.assert_allclose(m.cpu().numpy()[0], match, atol=5e-5, err_msg=case.__name__)
+        c3 = emd_cuda.matchcost_forward(t1, t2, m)
+        np.testing.assert_allclose(c3.cpu().numpy(), [cost], rtol=RTOL, err_msg=case.__name__)
+        w1, w2 = ev.gradients(x1, x2, match, 1.5)
+        g1, g2 = emd_cuda.matchcost_backward(_t(np.array([1.5], np.float32), dev), t1, t2, m)
+        np.testing.assert_allclose(g1.cpu().numpy(), w1, rtol=1e-4, atol=2e-4, err_msg=case.__name__)
+        np.testing.assert_allclose(g2.cpu().numpy(), w2, rtol=1e-4, atol=2e-4, err_msg=case.__name__)
+        for fn in (ops.emd_fused, lambda a, b: earth_mover_distance(a, b, transpose=False)):
+            a, b = t1.clone().requires_grad_(True), t2.clone().requires_grad_(True)
+            c = fn(a, b)
+            np.testing.assert_allclose(c.detach().cpu().numpy(), [cost], rtol=RTOL, err_msg=case.__name__)
+            (1.5 * c).sum().backward()
+            np.testing.assert_allclose(a.grad.cpu().numpy(), w1, rtol=1e-4, atol=2e-4, err_msg=case.__name__)
+            np.testing.assert_allclose(b.grad.cpu().numpy(), w2, rtol=1e-4, atol=2e-4, err_msg=case.__name__)
+
+
 @pytest.mark.parametrize("B,n,m", [(3, 128, 128), (2, 64, 64), (2, 256, 128), (2, 100, 300), (1, 513, 200), (2, 1024, 1024)])
 def test_three_call_path_vs_oracle(dev, B, n, m):
     from puzzlenet_amd import emd_cuda
@@ -147,7 +174,7 @@ def test_invariants_full_size(dev):
     what must hold for any correct auction."""
     from puzzlenet_amd import emd_cuda, ops
     g = torch.Generator().manual_seed(1)
-    B, n = 8, 2048
+    B, n = 64, 2048
     x1 = torch.rand(B, n, 3, generator=g).to(dev)
     x2 = torch.rand(B, n, 3, generator=g).to(dev)
     match = emd_cuda.approxmatch_forward(x1, x2)

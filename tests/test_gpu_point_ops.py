@@ -162,9 +162,22 @@ def test_knn_adversarial_layouts(dev):
     lanes = rng.random((1, N, 3), dtype=np.float32) + 5.0
     lanes[0, 3::64] = rng.random((N // 64, 3), dtype=np.float32) * 0.01     # lane 3 holds every near point
     lanes[0, 7::64] = rng.random((N // 64, 3), dtype=np.float32) * 0.01
-    for xyz in (same, desc, lanes):
+    # 100 copies of one point next to the first query: 65..128 candidates pass the first bound (the reduce-after-
+    # collect path of select32), and 40 + 40 copies of two points: ties straddling the 32nd slot
+    dup = rng.random((1, N, 3), dtype=np.float32)
+    dup[0, 300:400] = np.float32([0.31, 0.41, 0.51])
+    dup2 = rng.random((1, N, 3), dtype=np.float32)
+    dup2[0, 100:140] = np.float32([0.3, 0.4, 0.52])
+    dup2[0, 1000:1040] = np.float32([0.3, 0.4, 0.48])
+    for xyz in (same, desc, lanes, dup, dup2):
         got = ops.knn(_t(xyz, dev), _t(q, dev), K).cpu().numpy()
         assert np.array_equal(got, orc.knn(xyz, q, K))
+        # the fused search + group launch on the same clouds (reference layout)
+        feat = rng.standard_normal((1, N, 8)).astype(np.float32)
+        new_points, gx, idx = ops.knn_group(_t(xyz, dev), _t(feat, dev), _t(q, dev), want_grouped_xyz=True)
+        want_idx = orc.knn(xyz, q, K)
+        assert np.array_equal(idx.cpu().numpy(), want_idx)
+        assert np.array_equal(new_points.cpu().numpy().view(np.uint32), orc.group(xyz, feat, q, want_idx).view(np.uint32))
 
 
 def test_group_backward_vs_oracle(dev):
@@ -249,6 +262,42 @@ def test_knn_group_pad_fused_vs_oracle(dev, B, N, S, D):
     assert np.array_equal(o[..., :3].view(np.uint32), g[..., :3].view(np.uint32))
     assert (o[..., 3] == 0).all()
     assert np.array_equal(o[..., 4:].view(np.uint32), g[..., 3:].view(np.uint32))
+
+
+@pytest.mark.parametrize("B,N,S,D", [(3, 2048, 512, 64), (2, 512, 256, 128), (2, 200, 33, 8), (1, 4096, 64, 16),
+                                     (2, 64, 10, 4), (1, 1000, 77, 12), (2, 130, 130, 20), (1, 3000, 19, 256)])
+def test_knn_group_fused_vs_oracle(dev, B, N, S, D):
+    """pzn_knn_group_f32 (search + group in one launch, REFERENCE layout [B,S,32,3+D]) == oracle kNN (bit-exact idx)
+    + oracle group, incl. grouped_xyz; D / 4 a power of two or not, piece heights 32 / 16 / 8 / 4."""
+    from puzzlenet_amd import ops
+    rng = np.random.default_rng(N + D)
+    xyz = rng.random((B, N, 3), dtype=np.float32)
+    xyz[:, 5:15] = xyz[:, 40:50]                                    # duplicates: ties
+    feat = rng.standard_normal((B, N, D)).astype(np.float32)
+    q = xyz[:, rng.permutation(N)[:S]].copy()
+    new_points, gx, idx = ops.knn_group(_t(xyz, dev), _t(feat, dev), _t(q, dev), want_grouped_xyz=True)
+    want_idx = orc.knn(xyz, q, 32)
+    assert np.array_equal(idx.cpu().numpy(), want_idx)
+    g = orc.group(xyz, feat, q, want_idx)                            # [B,S,32,3+D]
+    assert np.array_equal(new_points.cpu().numpy().view(np.uint32), g.view(np.uint32))
+    want_gx = np.take_along_axis(xyz, want_idx.reshape(B, -1, 1), axis=1).reshape(B, S, 32, 3)
+    assert np.array_equal(gx.cpu().numpy(), want_gx)
+    # the drop-in call takes this path and keeps its autograd (pointnet_util.py:123-132)
+    import puzzlenet_amd.pointnet_util as pu
+    tf = _t(feat, dev).requires_grad_(True)
+    tx = _t(xyz, dev).requires_grad_(True)
+    torch.manual_seed(3)
+    new_xyz, npts = pu.sample_and_group(S, 0, 32, tx, tf, knn=True)
+    torch.manual_seed(3)
+    fps = pu.farthest_point_sample(tx.detach(), S)
+    idx2 = ops.knn(tx.detach(), ops.index_points(tx.detach(), fps), 32)
+    tf2, tx2 = _t(feat, dev).requires_grad_(True), _t(xyz, dev).requires_grad_(True)
+    ref = ops.group(tx2, tf2, ops.index_points(tx2, fps), idx2)
+    assert torch.equal(npts, ref)
+    w = torch.randn(npts.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+    (npts * w).sum().backward()
+    (ref * w).sum().backward()
+    assert torch.allclose(tf.grad, tf2.grad, rtol=1e-5, atol=1e-5) and torch.allclose(tx.grad, tx2.grad, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("B,L,C", [(3, 256, 1024), (2, 2048, 64), (1, 7, 4), (5, 33, 36)])

@@ -33,3 +33,19 @@ def test_fp32_agrees_with_fp64_and_invariants():
     x = rng.random((1, 40, 3), dtype=np.float32)
     c, _ = orc.earth_mover_distance(x, x[:, rng.permutation(40)])
     assert c[0] < 1e-4
+
+
+def test_hand_derived_capacity_vectors():
+    """tests/emd_vectors.py: clustered clouds whose matching can be written down; they exercise the integer
+    capacities multiL / multiR (emd_kernel.cu:29-35) and n != m, which the reference's 2-point vector does not."""
+    from tests import emd_vectors as ev
+    for case in ev.CASES:
+        x1, x2, match, cost = case()
+        c, m = orc.earth_mover_distance(x1, x2)
+        assert m.shape == (1,) + match.shape
+        np.testing.assert_allclose(m[0], match, atol=2e-5, err_msg=case.__name__)
+        np.testing.assert_allclose(c[0], cost, rtol=1e-5, err_msg=case.__name__)
+        g1, g2 = orc.emd_matchcost_grad(np.array([1.5], np.float32), x1, x2, m)
+        w1, w2 = ev.gradients(x1, x2, match, 1.5)
+        np.testing.assert_allclose(g1, w1, rtol=1e-4, atol=1e-4, err_msg=case.__name__)
+        np.testing.assert_allclose(g2, w2, rtol=1e-4, atol=1e-4, err_msg=case.__name__)
