@@ -547,7 +547,7 @@ __device__ __forceinline__ void piece_load(float* __restrict__ val, __amdgpu_buf
   }
 }
 
-template <int D, int KP>
+template <int D, int KP, bool NT>
 __device__ __forceinline__ void piece_finish(const float* __restrict__ val, float* __restrict__ chunk, int k0, int lane,
                                              float ex, float ey, float ez, float* __restrict__ outp) {
   constexpr int W = 3 + D;
@@ -567,9 +567,18 @@ __device__ __forceinline__ void piece_finish(const float* __restrict__ val, floa
 #pragma unroll
   for (int i = 0; i < FULL; ++i) r[i] = c4[i * 64 + lane];
   if (TAIL) r[FULL] = c4[FULL * 64 + (lane < TAIL ? lane : 0)];
+  if constexpr (NT) {
 #pragma unroll
-  for (int i = 0; i < FULL; ++i) o4[i * 64 + lane] = r[i];
-  if (TAIL && lane < TAIL) o4[FULL * 64 + lane] = r[FULL];
+    for (int i = 0; i < FULL; ++i)
+      __builtin_nontemporal_store(*reinterpret_cast<const pzn_f4v*>(&r[i]), reinterpret_cast<pzn_f4v*>(&o4[i * 64 + lane]));
+    if (TAIL && lane < TAIL)
+      __builtin_nontemporal_store(*reinterpret_cast<const pzn_f4v*>(&r[FULL]),
+                                  reinterpret_cast<pzn_f4v*>(&o4[FULL * 64 + lane]));
+  } else {
+#pragma unroll
+    for (int i = 0; i < FULL; ++i) o4[i * 64 + lane] = r[i];
+    if (TAIL && lane < TAIL) o4[FULL * 64 + lane] = r[FULL];
+  }
   pzn::wave_lds_sync();
 }
 
@@ -597,11 +606,11 @@ __device__ __forceinline__ void group_piece_any(float* __restrict__ chunk, const
   pzn::wave_lds_sync();
 }
 
-template <int R, int WAVES, bool GROUP, int DT, int KPT>
+template <int R, int WAVES, bool GROUP, int DT, int KPT, bool NT>
 __global__ __launch_bounds__(WAVES* PZN_WAVE) __attribute__((amdgpu_waves_per_eu(R <= 32 ? 4 : 3, 8))) void knn_select_kernel(
     const float* __restrict__ xyz, const float* __restrict__ feat, const float* __restrict__ new_xyz, int N, int S, int K,
     int D, int dshift, int kp, int q_per_block, int blocks_per_cloud, int64_t* __restrict__ idx,
-    float* __restrict__ out, float* __restrict__ grouped_xyz, int stagger) {
+    float* __restrict__ out, float* __restrict__ grouped_xyz) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int NP = 64 * R;
   const int W = 3 + D;
@@ -626,11 +635,6 @@ __global__ __launch_bounds__(WAVES* PZN_WAVE) __attribute__((amdgpu_waves_per_eu
   const int s_end = min(S, s_begin + q_per_block);
   const float* cfs = GROUP ? feat + (size_t)b * N * D : nullptr;
 
-  if (stagger) {  // EXPERIMENT: odd waves (bit 0) / odd blocks (bit 1) start late
-    const bool late = ((stagger & 1) && (wave & 1)) || ((stagger & 2) && (blockIdx.x & 8));
-    if (late)
-      for (int i = 0; i < (stagger >> 2); ++i) __builtin_amdgcn_s_sleep(127);
-  }
   if constexpr (GROUP && DT > 0) {
     // Software pipeline per wavefront: the feature rows of query i are requested (PF pieces = 32 loads per lane in
     // flight), the selection of query i+1 runs while they travel, then query i is assembled and streamed out.  The
@@ -672,12 +676,12 @@ __global__ __launch_bounds__(WAVES* PZN_WAVE) __attribute__((amdgpu_waves_per_eu
       float* oq = out + qi * 32 * (3 + DT);
 #pragma unroll
       for (int pc = 0; pc < PF; ++pc)
-        piece_finish<DT, KPT>(val + pc * NV, chunk, pc * KPT, lane, cx, cy, cz, oq + pc * KPT * (3 + DT));
+        piece_finish<DT, KPT, NT>(val + pc * NV, chunk, pc * KPT, lane, cx, cy, cz, oq + pc * KPT * (3 + DT));
 #pragma unroll
       for (int pc = PF; pc < PIECES; ++pc) {
         float v2[NV];
         piece_load<DT, KPT>(v2, rs, cj, pc * KPT, lane);
-        piece_finish<DT, KPT>(v2, chunk, pc * KPT, lane, cx, cy, cz, oq + pc * KPT * (3 + DT));
+        piece_finish<DT, KPT, NT>(v2, chunk, pc * KPT, lane, cx, cy, cz, oq + pc * KPT * (3 + DT));
       }
     }
   } else {
@@ -840,7 +844,7 @@ namespace {
 constexpr int SEL_WAVES = 8;
 
 // Launch of knn_select_kernel: R = 2 * ceil(N / 128) rounded up to a power of two (<= 64), 8 wavefronts per
-// workgroup, at least ~1024 workgroups, a multiple of 8 of them when possible (XCD-aware order).  GROUP: the piece
+// workgroup, ~512 workgroups (two per CU, one round), a multiple of 8 of them when possible (XCD-aware order).  GROUP: the piece
 // height kp (rows assembled in LDS per pass) is the largest of 32 / 16 / 8 / 4 that lets two workgroups share a CU.
 template <bool GROUP>
 int launch_select(const float* xyz, const float* feat, const float* new_xyz, int B, int N, int S, int K, int D,
@@ -866,30 +870,37 @@ int launch_select(const float* xyz, const float* feat, const float* new_xyz, int
   if (GROUP && D == 64 && fixed + (size_t)SEL_WAVES * 16 * W * sizeof(float) <= 150 * 1024) dt = 64, kp = 16;
   if (GROUP && D == 128 && fixed + (size_t)SEL_WAVES * 8 * W * sizeof(float) <= 150 * 1024) dt = 128, kp = 8;
   const size_t lds = fixed + (GROUP ? (size_t)SEL_WAVES * kp * W * sizeof(float) : 0);
+  // ~2 workgroups per CU in ONE round (512 measured better than 1024 for the fused launch); PZN_KG_BLOCKS: tuning aid
   static const int target = [] { const char* e = getenv("PZN_KG_BLOCKS"); return e ? atoi(e) : 512; }();
-  static const int stagger = [] { const char* e = getenv("PZN_KG_STAGGER"); return e ? atoi(e) : 0; }();
   int qpb = 64;
   while (qpb > SEL_WAVES && (long)B * ((S + qpb - 1) / qpb) < target) qpb >>= 1;
   const int bpc = (S + qpb - 1) / qpb;
   const long nb = (long)B * bpc;
   if (nb > 0x7fffffffL) return PZN_EINVAL;
+  // Streaming (non-temporal) row stores when the feature tables of the clouds resident on one XCD (32 CUs x 2
+  // workgroups, whole clouds per XCD) fill its 4 MB L2: the write stream then evicts the tables it is gathering from
+  // (measured at N = 2048, D = 64: 0.082 -> 0.075 ms per launch; at N = 512, D = 128 the tables fit and plain stores win)
+  const long clouds_per_xcd = (64 + bpc - 1) / bpc;
+  const bool nt = GROUP && clouds_per_xcd * (long)N * D * 4 > 3L * 1024 * 1024;
   int dshift = -1;  // log2(D) when D is a power of two
   if (GROUP && D > 0 && (D & (D - 1)) == 0) dshift = __builtin_ctz((unsigned)D);
-#define PZN_SEL_K(RR, DTT, KPP)                                                                                       \
+#define PZN_SEL_K(RR, DTT, KPP, NTT)                                                                                      \
   do {                                                                                                                \
-    if (set_lds(&knn_select_kernel<RR, SEL_WAVES, GROUP, DTT, KPP>, lds) != PZN_OK) return PZN_ELAUNCH;               \
-    hipLaunchKernelGGL((knn_select_kernel<RR, SEL_WAVES, GROUP, DTT, KPP>), dim3((unsigned)nb),                       \
+    if (set_lds(&knn_select_kernel<RR, SEL_WAVES, GROUP, DTT, KPP, NTT>, lds) != PZN_OK) return PZN_ELAUNCH;               \
+    hipLaunchKernelGGL((knn_select_kernel<RR, SEL_WAVES, GROUP, DTT, KPP, NTT>), dim3((unsigned)nb),                       \
                        dim3(SEL_WAVES * PZN_WAVE), lds, st, xyz, feat, new_xyz, N, S, K, D, dshift, kp, qpb, bpc, idx, \
-                       out, grouped_xyz, stagger);                                                                    \
+                       out, grouped_xyz);                                                                             \
   } while (0)
 #define PZN_SEL(RR)                    \
   do {                                 \
-    if (GROUP && dt == 64)             \
-      PZN_SEL_K(RR, (GROUP ? 64 : 0), (GROUP ? 16 : 0));  \
+    if (GROUP && dt == 64 && nt)       \
+      PZN_SEL_K(RR, (GROUP ? 64 : 0), (GROUP ? 16 : 0), GROUP);  \
+    else if (GROUP && dt == 64)        \
+      PZN_SEL_K(RR, (GROUP ? 64 : 0), (GROUP ? 16 : 0), false);  \
     else if (GROUP && dt == 128)       \
-      PZN_SEL_K(RR, (GROUP ? 128 : 0), (GROUP ? 8 : 0));  \
+      PZN_SEL_K(RR, (GROUP ? 128 : 0), (GROUP ? 8 : 0), false);  \
     else                               \
-      PZN_SEL_K(RR, 0, 0);             \
+      PZN_SEL_K(RR, 0, 0, false);      \
   } while (0)
   switch (R) {
     case 2: PZN_SEL(2); break;
