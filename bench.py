@@ -11,9 +11,10 @@ Workload = BASELINE.json configs[1]: N=2048 points, 64 pairs per GPU, fp32.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline`
-(kNN + group stage, HBM-bound; algorithmic bytes from SURVEY §8(d)) and `cpu_baseline`
-(the torch-CPU + C restatement in oracle/, kind "port", timed on the host cores).
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (the max-pool variant of the
+weight-stationary matrix-core kernel, priced against the bf16 pipe it issues on), `roofline_knn_group` (the stage the
+north star names: the drop-in sample_and_group's search + group launch, HBM-bound, SURVEY 8(d) bytes), further
+per-stage rooflines, and `cpu_baseline` (the torch-CPU + C restatement in oracle/, kind "port", on the host cores).
 """
 import argparse
 import json
@@ -29,7 +30,11 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
-MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix rate (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input matrix rate (v_mfma_f32_32x32x2_f32; MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix rate (v_mfma_f32_32x32x16_bf16)
+# Every hot matrix-core kernel issues SIX bf16 MFMAs per fp32 product (bf16x3 split precision: fp32-GEMM accuracy),
+# so the ceiling of its fp32-equivalent rate is the bf16 pipe / 6:
+MFMA_X3_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
 
 
 class Cfg:
@@ -52,41 +57,51 @@ def knn_group_bytes(N, S, K, D):
 
 
 def time_knn_group_api(batch, dev, reps):
-    """The drop-in grouping stage (pointnet_util.sample_and_group on the encoder's two levels: neighbour search +
-    materialised grouped tensor, one launch each) timed on its own on the step's clouds: the model's fused path no
-    longer materialises the grouped tensor (csrc/sapoint.hip), the API does.  Returns KernelTimer records for
-    `reps` step-equivalents (2 encoders x 2 levels each)."""
+    """The drop-in grouping stage as a caller of pointnet_util runs it: sample_and_group(npoint, 0, 32, xyz, points,
+    knn=True) on the encoder's two levels of both clouds (the model's fused path does not materialise the grouped
+    tensor, csrc/sapoint.hip; the API does).  Two measurements:
+      * `api`: every C-ABI launch inside one pass of the four drop-in calls, each bracketed by its own event pair
+        (FPS, centroid gather, search + group);
+      * `stage`: the launch the north star names — search + group (pzn_knn_group_f32; ops.knn_group is literally what
+        sample_and_group calls after FPS) — replayed `reps` times back to back per level and cloud between ONE event
+        pair, so that the average is the kernel's own duration (what rocprofv3 reports), not duration + the idle gap
+        an event pair around a single short launch adds.
+    Returns (api records, [(ms per launch, launches)] per (cloud, level), launches per step-equivalent)."""
+    import puzzlenet_amd.pointnet_util as pu
     from puzzlenet_amd import ops
     g = torch.Generator(device="cpu").manual_seed(7)
-    clouds = [batch[0], batch[1]]
     work = []
-    for xyz in clouds:
+    for xyz in (batch[0], batch[1]):
         xyz = xyz.contiguous()
         Bc, Nc, _ = xyz.shape
-        for (n, s, d) in ((Nc, 512, 64), (512, 256, 128)):
-            x = xyz[:, :n].contiguous()
-            feat = torch.randn(Bc, n, d, generator=g).to(dev)
-            new_xyz = x[:, :s].contiguous()
-            idx = torch.empty((Bc, s, 32), dtype=torch.int64, device=dev)
-            xg = torch.empty((Bc * s * 32, 4 + d), dtype=torch.float32, device=dev)
-            work.append((x, feat, new_xyz, Bc, n, s, d, idx, xg))
-    from puzzlenet_amd import _lib
-
-    def run():
-        for (x, feat, new_xyz, Bc, n, s, d, idx, xg) in work:
-            try:
-                ops._call("pzn_knn_group_pad_f32", ops._p(x), ops._p(feat), ops._p(new_xyz), Bc, n, s, d, ops._p(idx),
-                          ops._p(xg), ops._stream())
-            except _lib.PznUnsupported:      # N > 4096: search and padded group write as two launches
-                ops._call("pzn_knn_f32", ops._p(x), ops._p(new_xyz), Bc, n, s, 32, ops._p(idx), ops._stream())
-                ops._call("pzn_group_pad_fwd_f32", ops._p(x), ops._p(feat), ops._p(new_xyz), ops._p(idx), Bc, n, s, 32, d,
-                          ops._p(xg), ops._stream())
-    run()
-    torch.cuda.synchronize()
-    ops.KernelTimer.start()
-    for _ in range(reps):
-        run()
-    return ops.KernelTimer.stop()
+        lvl1 = torch.randn(Bc, Nc, 64, generator=g).to(dev)
+        x2 = xyz[:, :512].contiguous()
+        lvl2 = torch.randn(Bc, 512, 128, generator=g).to(dev)
+        work.append((512, xyz, lvl1))
+        work.append((256, x2, lvl2))
+    with torch.no_grad():
+        for (s, x, f) in work:                       # warm-up of the whole drop-in call
+            pu.sample_and_group(s, 0, 32, x, f, False, True)
+        torch.cuda.synchronize()
+        ops.KernelTimer.start()
+        for (s, x, f) in work:
+            pu.sample_and_group(s, 0, 32, x, f, False, True)
+        api = ops.KernelTimer.stop()
+        stage = []
+        for (s, x, f) in work:
+            new_xyz = ops.index_points(x, pu.farthest_point_sample(x, s)).contiguous()
+            fused = ops.knn_group_supported(x, f, 32)
+            call = (lambda: ops.knn_group(x, f, new_xyz)) if fused else (lambda: ops.group(x, f, new_xyz, ops.knn(x, new_xyz, 32)))
+            call()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                call()
+            b.record()
+            torch.cuda.synchronize()
+            stage.append((a.elapsed_time(b) / reps, 1 if fused else 2))
+    return api, stage
 
 
 def cpu_baseline(N, pairs, iters):
@@ -132,6 +147,34 @@ def cpu_baseline(N, pairs, iters):
     }
 
 
+def build_id():
+    """Hash of the sources libpzn.so is built from (csrc/*, include/pzn.h): PMC byte counts collected on another build
+    are not attached to this run's numbers."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "puzzlenet_amd", "csrc")
+    for f in sorted(os.listdir(base)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(base, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "pzn.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(key, B, N):
+    """HBM bytes per step of a kernel / stage from the committed PMC passes (tools/pmc_summary.py, collected with
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` in separate runs of this same command): only when they were taken
+    on THIS build and on this workload; otherwise null.  -> (bytes or None, provenance string)."""
+    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, "no PMC summary committed for this round"
+    doc = json.load(open(path))
+    if doc.get("build_id") != build_id():
+        return None, f"profiles/r2_pmc_traffic.json was collected on build {doc.get('build_id')}, this is {build_id()}"
+    if (doc.get("batch"), doc.get("points")) != (B, N):
+        return None, "profiles/r2_pmc_traffic.json was collected on another workload"
+    return doc.get(key), f"profiles/r2_pmc_traffic.json (build {doc.get('build_id')}, separate --pmc passes of bench.py)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,23 +182,24 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU")
     ap.add_argument("--points", type=int, default=2048)
+    ap.add_argument("--attn", choices=("f32", "bf16"), default="f32",
+                    help="attention products: f32 = the default split-precision path (fp32 results), bf16 = single bf16 "
+                         "MFMAs with fp32 softmax / accumulation (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="EXPERIMENTAL: replay the step as one HIP graph (see DESIGN.md: small memset nodes misreplay on this ROCm)")
-    ap.add_argument("--cpu-pairs", type=int, default=4)
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-pairs", type=int, default=8)
+    ap.add_argument("--cpu-iters", type=int, default=3)
     args = ap.parse_args()
 
     from puzzlenet_amd import distributed as pdist
-    rank, world, local = pdist.init_from_env()
+    rank, world, local = pdist.init_from_env()        # selects the rank's device before the process group exists
     if world != args.gpus and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    local = local % max(1, torch.cuda.device_count())     # (rehearsals with more ranks than GPUs share a device)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", torch.cuda.current_device())
 
     from puzzlenet_amd import _lib, engine, model5_b, ops, synthetic
     _lib.check(_lib.load().pzn_device_check(), "pzn_device_check")      # fail loudly off-gfx950
+    if args.attn == "bf16":
+        _lib.check(_lib.load().pzn_attn_set_precision(1), "pzn_attn_set_precision")
 
     cfg = Cfg()
     cfg.num_points = args.points
@@ -166,10 +210,9 @@ def main():
     batch = synthetic.make_batch(B, N, dev, seed=1234 + rank)           # inputs resident in HBM before timing
     torch.manual_seed(1000 + rank)                                        # FPS start indices (pointnet_util.py:65)
 
-    use_graph = bool(args.graph)
-    runner = engine.TrainStep(model, batch, cfg.lr, world=world, use_graph=use_graph, warmup=max(1, args.warmup))
+    runner = engine.TrainStep(model, batch, cfg.lr, world=world)
     if rank == 0:
-        print(f"[bench] runner ready (hip graph: {use_graph})", file=sys.stderr, flush=True)
+        print("[bench] runner ready", file=sys.stderr, flush=True)
 
     def fence():
         torch.cuda.synchronize()
@@ -200,77 +243,86 @@ def main():
     kern, prof_steps = {}, 3
     if rank == 0:
         model.two_streams = False      # price kernels one at a time (the timed loop overlaps the two encoders)
-        eager = engine.TrainStep(model, batch, cfg.lr, world=1, use_graph=False)
+        eager = engine.TrainStep(model, batch, cfg.lr, world=1)
         eager.step()
         torch.cuda.synchronize()
         ops.KernelTimer.start()
+        ops.EMD_WALK_STATS = []
         for _ in range(prof_steps):
             eager.step()
         kern = ops.KernelTimer.stop()
+        emd_walk, ops.EMD_WALK_STATS = ops.EMD_WALK_STATS, None
         kern_flops = dict(ops.KernelTimer.flops)
-        kern_api = time_knn_group_api(batch, dev, prof_steps)
+        eager.close()
+        kern_api, stage_kg = time_knn_group_api(batch, dev, 20)
 
     if rank == 0:
-        # (1) the dominant kernel of the step: the matrix-core tile engine (csrc/gemm.hip), MFMA-bound.
-        #     achieved = algorithmic 2*M*N*K of every dense entry point / their summed launch durations.
-        dense_names = ("pzn_linear_fwd_f32", "pzn_linear_dgrad_f32", "pzn_linear_wgrad_f32",
-                       "pzn_linear_maxpool_fwd_f32", "pzn_pooled_layer_bwd_f32", "pzn_sa_pooled_layer_bwd_f32",
-                       "pzn_sharedmlp_max_fwd_f32", "pzn_sa_mlp_max_bwd_f32", "pzn_sa_mlp_max_bwd_scatter_f32",
-                       "pzn_attn_fwd_f32", "pzn_attn_bwd_f32", "pzn_attn_block_fwd_f32", "pzn_attn_block_bwd_f32")
-        d_ms = sum(kern.get(k, (0, 0.0))[1] for k in dense_names)
-        d_fl = sum(kern_flops.get(k, 0) for k in dense_names)
-        d_n = sum(kern.get(k, (0, 0.0))[0] for k in dense_names)
-        mfma_achieved = d_fl / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
-        mfma_traffic = None      # HBM bytes per step of these kernels from the committed PMC passes (tools/pmc_summary.py)
-        tpath0 = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.exists(tpath0) and (B, N) == (64, 2048):
-            mfma_traffic = json.load(open(tpath0)).get("mfma_family_bytes_per_step")
+        def per_step(name, table=None):
+            n, ms = (table or kern).get(name, (0, 0.0))
+            return n / prof_steps, ms / prof_steps
+
+        # (1) `roofline`: ONE named kernel, the largest single matrix-core launch of the step: ws_gemm_kernel in its
+        #     max-pool variant (pzn_linear_maxpool_fwd_f32: second shared-MLP layer + ReLU + max over the 32 neighbours,
+        #     model5_b.py:453-454 / :460-461; 4 launches per step).  It issues v_mfma_f32_32x32x16_bf16 six times per
+        #     fp32 product, so it is priced against the bf16 pipe / 6, with the fp32-input MFMA rate beside it.
+        n_mp, ms_mp = per_step("pzn_linear_maxpool_fwd_f32")
+        fl_mp = kern_flops.get("pzn_linear_maxpool_fwd_f32", 0) / prof_steps
+        mp_ach = fl_mp / (ms_mp * 1e-3) / 1e12 if ms_mp > 0 else 0.0
+        mp_traffic, mp_src = pmc_traffic("ws_gemm_maxpool_bytes_per_step", B, N)
         roofline = {
             "bound": "mfma",
-            "kernel": "the bf16x3 split-precision matrix-core kernels (fp32 result): ws_gemm_kernel (weight-stationary, forward / "
-                      "input gradients of the skinny layers), df_wgrad_kernel (direct-fragment weight gradients), gemm_kernel "
-                      "(general tile engine: wide layers, attention products) behind pzn_linear_* / pzn_linear_maxpool_fwd / "
-                      "pzn_(sa_)pooled_layer_bwd / pzn_attn_*; the time also contains the sparse max-pool backward kernels of "
-                      "pzn_(sa_)pooled_layer_bwd (vector-ALU passes, 1.6 ms per step), their flops are the 2*R*2*C1*C2 they execute; the first set-abstraction layer is counted as the per-point "
-                      "product it now is (B*N rows, csrc/sapoint.hip), not as the B*S*32-row product of the reference",
-            "achieved": mfma_achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": mfma_achieved / MFMA_F32_PEAK_TFLOPS, "traffic": mfma_traffic,
-            "algorithmic_flops_per_step": d_fl / max(1, prof_steps),
-            "ms_per_step": d_ms / max(1, prof_steps), "launches_per_step": d_n / max(1, prof_steps),
-            "note": "algorithmic fp32 flops / summed launch time; peak = dense fp32 MFMA rate (157.3 TFLOP/s); the skinny "
-                    "K, N = 64..256 products stream 10^5..10^6 rows and sit near the HBM ridge (forward of 1M x 128 x 128 "
-                    "moves 1.07 GB: 0.30 ms at 3.6 TB/s); see roofline_knn_group for the HBM-bound stage",
+            "kernel": "ws_gemm_kernel<4, true, ...> (csrc/wsgemm.hip, weight-stationary bf16x3 kernel, max-pool epilogue) behind "
+                      "pzn_linear_maxpool_fwd_f32",
+            "achieved": mp_ach, "peak": MFMA_X3_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mp_ach / MFMA_X3_PEAK_TFLOPS,
+            "traffic": mp_traffic, "traffic_source": mp_src,
+            "peak_note": "dense bf16 MFMA rate (2500 TFLOP/s) / 6 issued bf16 MFMAs per fp32 product; against the fp32-input "
+                         f"MFMA rate ({MFMA_F32_PEAK_TFLOPS} TFLOP/s) the same number reads {mp_ach / MFMA_F32_PEAK_TFLOPS:.3f}",
+            "algorithmic_flops_per_step": fl_mp, "ms_per_step": ms_mp, "launches_per_step": n_mp,
+            "avg_launch_ms": ms_mp / max(1.0, n_mp),
         }
-        # (2) the stage the north star names: kNN + group (HBM-bound), SURVEY 8(d) bytes.
+        # (1b) every dense matrix-core entry point together (no sparse vector-ALU passes in the sum)
+        dense_names = ("pzn_linear_fwd_f32", "pzn_linear_dgrad_f32", "pzn_linear_wgrad_f32", "pzn_linear_maxpool_fwd_f32",
+                       "pzn_sharedmlp_max_fwd_f32", "pzn_attn_fwd_f32", "pzn_attn_bwd_f32", "pzn_attn_block_fwd_f32",
+                       "pzn_attn_block_bwd_f32", "pzn_sa_level_fwd_f32")
+        d_ms = sum(kern.get(k, (0, 0.0))[1] for k in dense_names) / prof_steps
+        d_fl = sum(kern_flops.get(k, 0) for k in dense_names) / prof_steps
+        d_n = sum(kern.get(k, (0, 0.0))[0] for k in dense_names) / prof_steps
+        fam_ach = d_fl / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
+        fam_traffic, fam_src = pmc_traffic("mfma_family_bytes_per_step", B, N)
+        roofline_mfma_family = {
+            "bound": "mfma",
+            "kernel": "all dense matrix-core launches of the step (ws_gemm_kernel, df_wgrad_kernel, gemm_kernel behind "
+                      "pzn_linear_* / pzn_attn_block_*): algorithmic 2*M*N*K over summed launch time; the sparse vector-ALU "
+                      "passes of the pooled backward (pool_dgrad / pool_wgrad) are NOT in this sum",
+            "achieved": fam_ach, "peak": MFMA_X3_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fam_ach / MFMA_X3_PEAK_TFLOPS,
+            "traffic": fam_traffic, "traffic_source": fam_src,
+            "algorithmic_flops_per_step": d_fl, "ms_per_step": d_ms, "launches_per_step": d_n,
+        }
+        # (2) the stage the north star names: kNN + group (HBM-bound), SURVEY 8(d) bytes, on the launch the drop-in
+        #     sample_and_group really makes; the model path's own search (indices only) is listed beside it.
         per_pair = 2 * (knn_group_bytes(N, 512, 32, 64) + knn_group_bytes(512, 256, 32, 128))
-        if "pzn_knn_group_pad_f32" in kern:       # kNN + group fused into one launch (PZN_SA_POINT=0: the grouped-row model path)
-            n_st, ms_st = kern["pzn_knn_group_pad_f32"]
-            stage_names = "knn_group_pad_kernel (pzn_knn_group_pad_f32: neighbour search + group write in one launch, 4 launches/step)"
-            avg_launch = {"knn_group_pad_kernel": ms_st / max(1, n_st)}
-        elif "pzn_knn_group_pad_f32" in kern_api:  # the drop-in stage, timed on its own (the model path gathers per-point rows instead)
-            n_st, ms_st = kern_api["pzn_knn_group_pad_f32"]
-            stage_names = ("knn_group_pad_kernel (pzn_knn_group_pad_f32: neighbour search + group write in one launch), the "
-                           "sample_and_group drop-in stage timed ON ITS OWN on the step's clouds (4 launches per step-equivalent); "
-                           "the training step itself no longer materialises the grouped tensor, see roofline_sa_gather")
-            avg_launch = {"knn_group_pad_kernel": ms_st / max(1, n_st)}
-        else:
-            n_knn, ms_knn = kern_api.get("pzn_knn_f32", kern.get("pzn_knn_f32", (0, 0.0)))
-            n_grp, ms_grp = kern_api.get("pzn_group_pad_fwd_f32", kern.get("pzn_group_pad_fwd_f32", kern.get("pzn_group_fwd_f32", (0, 0.0))))
-            ms_st = ms_knn + ms_grp
-            stage_names = "knn32_reg_kernel (pzn_knn_f32) + group_pad_direct_kernel (pzn_group_pad_fwd_f32)"
-            avg_launch = {"knn32_reg_kernel": ms_knn / max(1, n_knn), "group_pad_direct_kernel": ms_grp / max(1, n_grp)}
-        stage_ms_per_step = ms_st / max(1, prof_steps)
-        achieved = per_pair * B / (stage_ms_per_step * 1e-3) / 1e9 if stage_ms_per_step > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.exists(tpath) and (B, N) == (64, 2048):
-            traffic = json.load(open(tpath)).get("knn_group_stage_bytes_per_step")
+        ms_kg = sum(ms for ms, _ in stage_kg)                 # one step-equivalent: 2 clouds x 2 levels
+        n_kg = sum(k for _, k in stage_kg)
+        if n_kg == len(stage_kg):
+            stage_names = ("knn_select_kernel<R, 8, true, D, kp, nt> behind pzn_knn_group_f32: what pointnet_util."
+                           "sample_and_group(npoint, 0, 32, xyz, points, knn=True) launches after FPS (search + "
+                           "reference-layout [B,S,32,3+D] group write in one launch), 4 launches per step-equivalent "
+                           "(2 clouds x 2 levels), each replayed 20x back to back on the step's clouds")
+        else:      # shapes the fused launch does not take (N > 4096): the two single launches
+            stage_names = "knn kernels (pzn_knn_f32) + group_fwd_vec_kernel (pzn_group_fwd_f32): N > 4096"
+        achieved = per_pair * B / (ms_kg * 1e-3) / 1e9 if ms_kg > 0 else 0.0
+        kg_traffic, kg_src = pmc_traffic("knn_group_stage_bytes_per_step", B, N)
+        n_mk, ms_mk = per_step("pzn_knn_f32")
         roofline_knn_group = {
             "bound": "hbm", "kernel": stage_names,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "algorithmic_bytes_per_step": per_pair * B,
-            "avg_launch_ms": avg_launch,
+            "traffic": kg_traffic, "traffic_source": kg_src,
+            "algorithmic_bytes_per_step": per_pair * B, "ms_per_step": ms_kg, "launches_per_step": n_kg,
+            "avg_launch_ms": ms_kg / max(1, n_kg),
+            "launch_ms": {"cloud0_level1": stage_kg[0][0], "cloud0_level2": stage_kg[1][0], "cloud1_level1": stage_kg[2][0],
+                          "cloud1_level2": stage_kg[3][0]},
+            "model_path_knn": {"entry": "pzn_knn_f32 (indices only; the encoder gathers per-point rows instead of "
+                                        "materialising groups)", "launches_per_step": n_mk, "ms_per_step": ms_mk},
         }
         # (3) the HBM-bound stage of the model path: first set-abstraction layer as a gather of per-point rows.
         #     bytes per level and cloud: forward h write + P read + idx; backward dh read + dP write + inverse lists.
@@ -281,34 +333,79 @@ def main():
             return fwd, bwd
         gf1, gb1 = gather_bytes(N, 512, 128)
         gf2, gb2 = gather_bytes(512, 256, 256)
-        g_bytes = 2 * B * (gf1 + gb1 + gf2 + gb2)
-        n_gf, ms_gf = kern.get("pzn_sa_point_l1_fwd_f32", (0, 0.0))
-        n_gb, ms_gb = kern.get("pzn_sa_point_l1_bwd_f32", (0, 0.0))
-        g_ms = (ms_gf + ms_gb) / max(1, prof_steps)
+        n_gf, ms_gf = per_step("pzn_sa_point_l1_fwd_f32")
+        n_gb, ms_gb = per_step("pzn_sa_point_l1_bwd_f32")
+        g_bytes = 2 * B * ((gf1 + gf2 if n_gf else 0) + (gb1 + gb2 if n_gb else 0))
+        g_ms = ms_gf + ms_gb
         g_ach = g_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
-        g_traffic = None
-        if os.path.exists(tpath) and (B, N) == (64, 2048):
-            g_traffic = json.load(open(tpath)).get("sa_gather_stage_bytes_per_step")
+        g_traffic, g_src = pmc_traffic("sa_gather_stage_bytes_per_step", B, N)
         roofline_sa_gather = {
             "bound": "hbm", "kernel": "sa_point_l1_fwd_kernel / sa_point_l1_bwd_kernel (pzn_sa_point_l1_{fwd,bwd}_f32: first "
                                       "set-abstraction layer as a gather of per-point rows / a sum over inverse neighbour lists)",
-            "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g_ach / HBM_PEAK_GBS, "traffic": g_traffic,
+            "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g_ach / HBM_PEAK_GBS,
+            "traffic": g_traffic, "traffic_source": g_src,
             "algorithmic_bytes_per_step": g_bytes,
-            "avg_launch_ms": {"sa_point_l1_fwd_kernel": ms_gf / max(1, n_gf), "sa_point_l1_bwd_kernel": ms_gb / max(1, n_gb)},
+            "avg_launch_ms": {"sa_point_l1_fwd_kernel": ms_gf / max(1.0, n_gf), "sa_point_l1_bwd_kernel": ms_gb / max(1.0, n_gb)},
+        }
+        # (4) EMD: vector-ALU / transcendental bound.  The reference's schedule is 10 levels x 3 passes x n*m pair
+        #     evaluations (emd_kernel.cu:46-154); the fused path walks only the cloud-2 points that still hold mass, and
+        #     leaves the lengths of those lists behind (pzn_emd_walk_counter_offset), so the evaluations EXECUTED are
+        #     known: 3 n (B m + sum of list lengths) on the general path, 30 n m on the single-workgroup path.  The walks
+        #     are packed (v_pk_*: two evaluations per instruction): per TWO evaluations 3 differences, 3 square / sum,
+        #     1 scale, 2 v_exp_f32 (8 cycles = two issue slots each), 1 weight, 1-5 accumulations (pass C also sums cost
+        #     and gradient) = 14.5 issue slots on average, i.e. 7.25 vector issue slots per evaluation.
+        #     Peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-slots/s (one wave64 instruction per 4 cycles).
+        n_e, ms_e = per_step("pzn_emd_fused_f32")
+        ev_exec, ev_ref = 0.0, 0.0
+        for ctr, eb, en, em in emd_walk:
+            ev_ref += 30.0 * eb * en * em
+            ev_exec += 30.0 * eb * en * em if ctr is None else 3.0 * en * (eb * em + float(ctr.item()))
+        ev_exec, ev_ref = ev_exec / prof_steps, ev_ref / prof_steps
+        LANE_OPS = 7.25
+        e_ach = ev_exec * LANE_OPS / (ms_e * 1e-3) / 1e12 if ms_e > 0 else 0.0
+        roofline_emd = {
+            "bound": "valu", "kernel": "emd_pass_b_list_kernel / emd_pass_ca_kernel / emd_pass_a_kernel / emd_small_fused_kernel behind "
+                                       "pzn_emd_fused_f32 (4 calls per step: N x N, B x B, 2 x 128 x 128)",
+            "achieved": e_ach, "peak": 39.3, "unit": "T lane-slot/s", "frac": e_ach / 39.3, "traffic": None,
+            "pair_evaluations_executed_per_step": ev_exec, "pair_evaluations_reference_schedule_per_step": ev_ref,
+            "issue_slots_per_evaluation": LANE_OPS, "ms_per_step": ms_e, "launches_per_step": n_e,
+            "note": "executed evaluations from the device-side active-list counter; the reference's schedule (30 n m per pair) "
+                    f"would be {ev_ref / max(ev_exec, 1.0):.2f}x as many",
+        }
+        # (5) the attention blocks (4 per encoder): projections on the fp32-accurate bf16x3 path, contractions in --attn
+        n_af, ms_af = per_step("pzn_attn_block_fwd_f32")
+        n_ab, ms_ab = per_step("pzn_attn_block_bwd_f32")
+        fl_at = (kern_flops.get("pzn_attn_block_fwd_f32", 0) + kern_flops.get("pzn_attn_block_bwd_f32", 0)) / prof_steps
+        at_ach = fl_at / ((ms_af + ms_ab) * 1e-3) / 1e12 if ms_af + ms_ab > 0 else 0.0
+        roofline_attention = {
+            "bound": "mfma", "kernel": "pzn_attn_block_{fwd,bwd}_f32: layerAttention (model5_b.py:83-101), 8 + 8 launches per step; "
+                                       f"contractions q k^T / attn v and their backward in {'single bf16 MFMAs, fp32 softmax' if args.attn == 'bf16' else 'bf16x3 split precision (fp32 results)'}",
+            "achieved": at_ach, "peak": MFMA_X3_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": at_ach / MFMA_X3_PEAK_TFLOPS,
+            "traffic": None, "algorithmic_flops_per_step": fl_at, "ms_per_step": ms_af + ms_ab,
+            "note": "256 tokens per cloud whatever N: 64 x (256 x 256 x 64..256) products, latency- and launch-bound rather than "
+                    "pipe-bound; with --attn bf16 the contractions issue one MFMA per product instead of six",
         }
         stages = {k: {"launches_per_step": n / prof_steps, "ms_per_step": ms / prof_steps} for k, (n, ms) in sorted(kern.items())}
+        stages_api = {k: {"launches": n, "ms": ms} for k, (n, ms) in sorted(kern_api.items())}
         out = {
-            "metric": "point-cloud pairs/sec (fwd+bwd) at N=2048, B=64; FPS/kNN idx bit-exact",
+            "metric": f"point-cloud pairs/sec (fwd+bwd) at N={N}, B={B}; FPS/kNN idx bit-exact",
             "value": world * B * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1] shape: N={N} points, {B} pairs/GPU, fp32 train step "
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.attn == "f32" else "f32 (attention contractions bf16)",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{1 if (B, N) == (64, 2048) else ('4' if N == 8192 else '3' if N == 4096 else '-')}] shape: N={N} points, {B} pairs/GPU, fp32 train step "
                                    f"(predict5 + loss_mode 1 losses incl. 4x EMD + backward + Adam)",
-                       "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "hip_graph": use_graph, "encoder_streams": 2},
+                       "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "encoder_streams": 2,
+                       "matrix_core_path": "bf16x3 split precision (fp32 results; six bf16 MFMAs per product)",
+                       "attention": args.attn, "build_id": build_id()},
             "roofline": roofline,
+            "roofline_mfma_family": roofline_mfma_family,
             "roofline_knn_group": roofline_knn_group,
             "roofline_sa_gather": roofline_sa_gather,
+            "roofline_emd": roofline_emd,
+            "roofline_attention": roofline_attention,
             "stages": stages,
+            "stages_sample_and_group_dropin": stages_api,
             "loss": loss_val,
         }
         if not args.no_cpu_baseline and world == 1:

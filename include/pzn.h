@@ -139,6 +139,11 @@ int pzn_emd_fused_f32(const float* xyz1, const float* xyz2, int B, int n, int m,
                       float* cost, float* g1, float* g2, void* workspace,
                       pzn_stream_t stream);
 
+/* Measurement aid (bench.py's EMD roofline): byte offset inside the workspace of a uint64 the fused entry point leaves
+ * behind — the sum over pairs and levels 6..-2 of the cloud-2 points still holding mass (level 7 walks all m), so that
+ * 3 n (B m + counter) pair evaluations were executed by the call; (size_t)-1 on the single-workgroup path (n, m <= 256). */
+size_t pzn_emd_walk_counter_offset(int B, int n, int m);
+
 /* ------------------------------------------------------------------------ */
 /* Loss tail: model5_b.py:1495-1505 chamfer_loss                            */
 /* ------------------------------------------------------------------------ */
@@ -207,6 +212,12 @@ int pzn_linear_maxpool_wgrad_f32(const float* dout, const int32_t* argmax,
  * Process-wide; also PZN_GEMM_PRECISION=f32|x3|auto in the environment. */
 int pzn_gemm_set_precision(int mode);
 int pzn_gemm_get_precision(void);
+/* Precision of the attention contractions (model5_b.py:67-75: q k^T, attn v, and their four backward products) inside
+ * pzn_attn_* / pzn_attn_block_*: 0 (default) = the matrix-core path selected above (fp32 results), 1 = operands rounded
+ * to bf16 once and ONE v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation, fp32 softmax (BASELINE configs[4] "bf16
+ * attn with MFMA").  The q / k / v / out projections keep the fp32-accurate path.  Also PZN_ATTN_PRECISION=bf16. */
+int pzn_attn_set_precision(int mode);
+int pzn_attn_get_precision(void);
 /* Batched C[b] = alpha op(A[b]) op(B[b]), dense row-major.
  * mode 0 "NT": A[M,K] B[N,K];  1 "NN": A[M,K] B[K,N];  2 "TN": A[K,M] B[K,N]. */
 int pzn_bgemm_f32(int mode, const float* A, const float* B, float* C, int batch,

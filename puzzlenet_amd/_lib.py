@@ -29,6 +29,7 @@ SIGNATURES = {
     "pzn_group_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_group_bwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f]),
     "pzn_emd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),
+    "pzn_emd_walk_counter_offset": (_c_sz, [_c_i, _c_i, _c_i]),
     "pzn_emd_approxmatch_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_emd_matchcost_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_emd_matchcost_grad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
@@ -43,6 +44,8 @@ SIGNATURES = {
     "pzn_linear_maxpool_wgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_i, _c_f]),
     "pzn_gemm_set_precision": (_c_i, [_c_i]),
     "pzn_gemm_get_precision": (_c_i, []),
+    "pzn_attn_set_precision": (_c_i, [_c_i]),
+    "pzn_attn_get_precision": (_c_i, []),
     "pzn_bgemm_f32": (_c_i, [_c_i, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_fl, _c_f]),
     "pzn_sharedmlp_max_fwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 4 + [_c_f] * 4),
     "pzn_sharedmlp_max_bwd_f32": (_c_i, [_c_f] * 7 + [_c_i] * 4 + [_c_f] * 6 + [_c_i, _c_f]),

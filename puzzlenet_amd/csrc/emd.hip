@@ -37,6 +37,7 @@
 namespace {
 
 constexpr int EMD_T = 256;  // threads per workgroup (4 wavefronts)
+constexpr int EMD_SMALL_MAX = 256;  // n, m up to here: the whole auction of a pair in one workgroup (emd_small_fused_kernel)
 
 struct EmdWs {
   float4* pk1;     // [B*n] {x1,y1,z1, ratioL}
@@ -45,6 +46,8 @@ struct EmdWs {
   float* remainL;  // [B*n]
   int* act[2];     // [B*m] each: ascending indices l of the points of cloud 2 that still hold mass (remainR_l > 0)
   int* cnt[2];     // [B] each: how many
+  unsigned long long* walk;  // one counter: sum over pairs and levels 6..-2 of the active-list lengths of the last fused
+                             // call (measurement only: bench.py derives the pair evaluations really executed from it)
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -68,6 +71,7 @@ EmdWs carve(void* ws, int B, int n, int m) {
     w.cnt[i] = reinterpret_cast<int*>(p);
     p += align_up(sizeof(int) * (size_t)B, 256);
   }
+  w.walk = reinterpret_cast<unsigned long long*>(p);
   return w;
 }
 
@@ -203,6 +207,7 @@ __global__ __launch_bounds__(EMD_T) void emd_init_kernel(const float* __restrict
   const int i = blockIdx.x * EMD_T + threadIdx.x;
   if (cost) {  // fused entry point: the accumulators start at zero (no separate fills)
     if (i == 0) cost[b] = 0.f;
+    if (i == 0 && b == 0) *w.walk = 0ull;
     if (i < n) {
       float* g = g1 + ((size_t)b * n + i) * 3;
       g[0] = 0.f, g[1] = 0.f, g[2] = 0.f;
@@ -258,7 +263,10 @@ __global__ __launch_bounds__(EMD_CT) void emd_compact_kernel(int m, EmdWs w, int
     if (tid == 0) base_s += tot;
     __syncthreads();
   }
-  if (tid == 0) w.cnt[buf][b] = base_s;
+  if (tid == 0) {
+    w.cnt[buf][b] = base_s;
+    atomicAdd(w.walk, (unsigned long long)base_s);
+  }
 }
 
 // Pass A: rows = points k of xyz1.
@@ -643,7 +651,6 @@ __global__ __launch_bounds__(EMD_T) void emd_grad2_kernel(const float* __restric
 // each; here both clouds and the per-point auction state live in LDS, a row is shared by TPR = 1024 / R
 // adjacent lanes (R = rows rounded up to a power of two) that walk interleaved parts of the other cloud,
 // and cost / gradients accumulate in registers over the levels.  Same formulas as passes A / B / C above.
-constexpr int EMD_SMALL_MAX = 256;
 
 constexpr int EMD_SMALL_T = 1024;  // 16 wavefronts per pair: the walk is a dependent VALU / exp chain per lane
 
@@ -812,7 +819,16 @@ PZN_EXPORT size_t pzn_emd_workspace_bytes(int B, int n, int m) {
   if (B <= 0 || n <= 0 || m <= 0) return 0;
   return align_up(sizeof(float4) * (size_t)B * n, 256) + 2 * align_up(sizeof(float4) * (size_t)B * m, 256) +
          align_up(sizeof(float) * (size_t)B * n, 256) + 2 * align_up(sizeof(int) * (size_t)B * m, 256) +
-         2 * align_up(sizeof(int) * (size_t)B, 256);
+         2 * align_up(sizeof(int) * (size_t)B, 256) + 256;
+}
+
+// Byte offset, inside the workspace, of a uint64 that the fused entry point leaves behind: the sum over pairs and over
+// levels 6..-2 of the number of cloud-2 points still holding mass (level 7 walks all m).  The passes of a level walk
+// n * (that many) pairs three times, so 3 n (B m + counter) pair evaluations were executed; (size_t)-1 when the call
+// takes the single-workgroup path (n, m <= 256), which walks everything.
+PZN_EXPORT size_t pzn_emd_walk_counter_offset(int B, int n, int m) {
+  if (B <= 0 || n <= 0 || m <= 0 || (n <= EMD_SMALL_MAX && m <= EMD_SMALL_MAX)) return (size_t)-1;
+  return pzn_emd_workspace_bytes(B, n, m) - 256;
 }
 
 PZN_EXPORT int pzn_emd_approxmatch_f32(const float* xyz1, const float* xyz2, int B, int n, int m, float* match,

@@ -66,6 +66,7 @@ enum { GEN_NONE = 0, GEN_RELU = 1, GEN_MAXPOOL = 2 };
 enum { EPI_STORE = 0, EPI_MAXPOOL = 1, EPI_ATOMIC = 2 };
 
 struct GemmArgs {
+  int plain_bf16;  // EPI_STORE launches only: operands rounded to bf16 once, ONE MFMA per product (opt-in attention mode)
   // logical problem: C[M,N] = sum_k A(m,k) B(k,n)
   int M, N, K;
   const float* A;  // A_KC: A[m*lda + k]   else: A[k*lda + m]
@@ -244,6 +245,8 @@ struct Loader {
   // bf16x3 image: three planes of BR x 16 bf16, each in MFMA-fragment order: the 16-byte chunk of
   // (row r, k-half h) sits at chunk index (r/32 * 2 + h) * 32 + r % 32, so a wave's fragment read for one
   // 32-row tile is 64 consecutive chunks (lane = h*32 + r%32): conflict-free ds_read_b128, no padding.
+  // ONE: plain bf16 operands (the opt-in attention mode): only the first plane is produced
+  template <bool ONE = false>
   __device__ __forceinline__ void store_x3(unsigned char* img, int tid) const {
     constexpr int PLANE = KC ? BR * 32 : 16 * (BR + 32) * 2;  // bytes
 #pragma unroll
@@ -252,11 +255,17 @@ struct Loader {
       float t[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
       uint32_t a[4], b[4], c[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) split3(t[e], a[e], b[e], c[e]);
+      for (int e = 0; e < 4; ++e) {
+        if (ONE)
+          a[e] = f2bf(t[e]), b[e] = c[e] = 0;
+        else
+          split3(t[e], a[e], b[e], c[e]);
+      }
       if (KC) {  // 4 consecutive k of one row: one 8-byte store per plane
         int r = f / (BK / 4), kq = (f % (BK / 4)) * 4;
         int off = (((r >> 5) * 2 + (kq >> 3)) * 32 + (r & 31)) * 16 + (kq & 7) * 2;
         *reinterpret_cast<uint2*>(img + off) = make_uint2(a[0] | (a[1] << 16), a[2] | (a[3] << 16));
+        if (ONE) continue;
         *reinterpret_cast<uint2*>(img + PLANE + off) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
         *reinterpret_cast<uint2*>(img + 2 * PLANE + off) = make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16));
       } else {  // 4 consecutive rows at one k: k-major plane [16][BR+32] bf16, one 8-byte store per plane;
@@ -264,6 +273,7 @@ struct Loader {
         int k = f / (BR / 4), r0 = (f % (BR / 4)) * 4;
         int off = (k * (BR + 32) + r0) * 2;
         *reinterpret_cast<uint2*>(img + off) = make_uint2(a[0] | (a[1] << 16), a[2] | (a[3] << 16));
+        if (ONE) continue;
         *reinterpret_cast<uint2*>(img + PLANE + off) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
         *reinterpret_cast<uint2*>(img + 2 * PLANE + off) = make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16));
       }
@@ -303,7 +313,7 @@ struct Loader {
   }
 };
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, bool X3>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, bool X3, bool ONE = false>
 __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(WM * WN == GT / PZN_WAVE, "4 waves");
@@ -365,8 +375,8 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
   unsigned char* imgA = reinterpret_cast<unsigned char*>(smem);               // bf16x3: [2][3][A_PLANE]
   unsigned char* imgB = reinterpret_cast<unsigned char*>(smem + A_ELEMS);     //         [2][3][B_PLANE]
   if (X3) {
-    la.store_x3(imgA, tid);
-    lb.store_x3(imgB, tid);
+    la.template store_x3<ONE>(imgA, tid);
+    lb.template store_x3<ONE>(imgB, tid);
   } else {
     la.store(As[0], tid);
     lb.store(Bs[0], tid);
@@ -391,33 +401,38 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs p) {
     auto mma_tile = [&](int cur, bool convert_next, Loader<BM, A_KC>& ca_regs, Loader<BN, B_KC>& cb_regs) {
       const unsigned char* ca = imgA + cur * (3 * A_PLANE);
       const unsigned char* cb = imgB + cur * (3 * B_PLANE);
-      bf16x8 af[TM][3], bf[TN][3];
+      constexpr int NPL = ONE ? 1 : 3;
+      bf16x8 af[TM][NPL], bf[TN][NPL];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) af[i][q] = Loader<BM, A_KC>::read_frag(ca + q * A_PLANE, wm * (BM / WM) + i * 32, lane);
+        for (int q = 0; q < NPL; ++q) af[i][q] = Loader<BM, A_KC>::read_frag(ca + q * A_PLANE, wm * (BM / WM) + i * 32, lane);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) bf[j][q] = Loader<BN, B_KC>::read_frag(cb + q * B_PLANE, wn * (BN / WN) + j * 32, lane);
+        for (int q = 0; q < NPL; ++q) bf[j][q] = Loader<BN, B_KC>::read_frag(cb + q * B_PLANE, wn * (BN / WN) + j * 32, lane);
       if (convert_next) {  // compile-time constant at every call site: no branch inside the scheduled region
-        ca_regs.store_x3(imgA + (cur ^ 1) * (3 * A_PLANE), tid);
-        cb_regs.store_x3(imgB + (cur ^ 1) * (3 * B_PLANE), tid);
+        ca_regs.template store_x3<ONE>(imgA + (cur ^ 1) * (3 * A_PLANE), tid);
+        cb_regs.template store_x3<ONE>(imgB + (cur ^ 1) * (3 * B_PLANE), tid);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           floatx16 c = acc[i][j];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);  // small terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+          if constexpr (ONE) {  // plain bf16 operands, fp32 accumulation: one product
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+          } else {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);  // small terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+          }
           acc[i][j] = c;
         }
-      if (convert_next) {
+      if (convert_next && !ONE) {
 #pragma unroll
         for (int g = 0; g < TM * TN * 6; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
@@ -627,6 +642,12 @@ void launch_cfg(const GemmArgs& p, int batch, hipStream_t st) {
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splits > 1 ? p.splits : batch);
   const int mode = gemm_precision();
   const bool x3 = mode != 0;  // auto == bf16x3 on every product (the split-K grid is sized for it, choose_splits)
+  if constexpr (EPI == EPI_STORE) {
+    if (x3 && p.plain_bf16) {
+      hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI, true, true>), grid, dim3(GT), 0, st, p);
+      return;
+    }
+  }
   if (x3)
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI, true>), grid, dim3(GT), 0, st, p);
   else
@@ -831,13 +852,24 @@ PZN_EXPORT int pzn_linear_maxpool_wgrad_f32(const float* dout, const int32_t* ar
 
 // Batched C[b] = alpha * op(A[b]) op(B[b]);  mode 0 = "NT": A[M,K] B[N,K];  1 = "NN": A[M,K] B[K,N];
 // 2 = "TN": A[K,M] B[K,N].  Row-major, dense (leading dimension = row length).
-PZN_EXPORT int pzn_bgemm_f32(int mode, const float* A, const float* B, float* C, int batch, int M, int N, int K,
-                             float alpha, pzn_stream_t stream) {
-  PZN_CHECK_ARG(A && B && C && batch > 0 && batch <= 65535 && M > 0 && N > 0 && K > 0 && mode >= 0 && mode <= 2);
+namespace {
+// Attention contraction precision (model5_b.py:67-75 QK^T, attn V and their backward products): 0 = follow the matrix-core
+// path of pzn_gemm_set_precision (default: fp32 results), 1 = operands rounded to bf16 once, ONE bf16 MFMA per product,
+// fp32 accumulation and fp32 softmax (the "bf16 attn with MFMA" configuration of BASELINE configs[4]).
+int g_attn_precision = -1;
+int attn_precision() {
+  if (g_attn_precision < 0) {
+    const char* e = getenv("PZN_ATTN_PRECISION");
+    g_attn_precision = (e && (e[0] == 'b' || e[0] == 'B')) ? 1 : 0;
+  }
+  return g_attn_precision;
+}
+
+int bgemm_impl(int mode, const float* A, const float* B, float* C, int batch, int M, int N, int K, float alpha, int plain,
+               hipStream_t st) {
   GemmArgs p = base_args(M, N, K);
-  p.A = A, p.B = B, p.C = C, p.ldc = N, p.alpha = alpha;
+  p.A = A, p.B = B, p.C = C, p.ldc = N, p.alpha = alpha, p.plain_bf16 = plain;
   p.sA = (long)M * K, p.sB = (long)N * K, p.sC = (long)M * N;
-  hipStream_t st = pzn_hip_stream(stream);
   if (mode == 0) {
     p.lda = K, p.ldb = K;
     launch<true, true, EPI_STORE>(p, batch, st);
@@ -849,6 +881,26 @@ PZN_EXPORT int pzn_bgemm_f32(int mode, const float* A, const float* B, float* C,
     launch<false, false, EPI_STORE>(p, batch, st);
   }
   PZN_RETURN_LAUNCH_STATUS();
+}
+
+// the batched products of the attention entry points
+int attn_bgemm(int mode, const float* A, const float* B, float* C, int batch, int M, int N, int K, float alpha,
+               pzn_stream_t stream) {
+  return bgemm_impl(mode, A, B, C, batch, M, N, K, alpha, attn_precision() == 1, pzn_hip_stream(stream));
+}
+}  // namespace
+
+PZN_EXPORT int pzn_attn_set_precision(int mode) {
+  PZN_CHECK_ARG(mode == 0 || mode == 1);
+  g_attn_precision = mode;
+  return PZN_OK;
+}
+PZN_EXPORT int pzn_attn_get_precision(void) { return attn_precision(); }
+
+PZN_EXPORT int pzn_bgemm_f32(int mode, const float* A, const float* B, float* C, int batch, int M, int N, int K,
+                             float alpha, pzn_stream_t stream) {
+  PZN_CHECK_ARG(A && B && C && batch > 0 && batch <= 65535 && M > 0 && N > 0 && K > 0 && mode >= 0 && mode <= 2);
+  return bgemm_impl(mode, A, B, C, batch, M, N, K, alpha, 0, pzn_hip_stream(stream));
 }
 
 // ------------------------------------------------------------------ softmax rows (attention) --
@@ -981,12 +1033,12 @@ void launch_softmax_bwd(const float* attn, float* io, const float* extra, long r
 PZN_EXPORT int pzn_attn_fwd_f32(const float* q, const float* k, const float* v, int B, int L, int dk, int dv,
                                 float* attn, float* out, pzn_stream_t stream) {
   PZN_CHECK_ARG(q && k && v && attn && out && B > 0 && L > 0 && dk > 0 && dv > 0);
-  int rc = pzn_bgemm_f32(0, q, k, attn, B, L, L, dk, 1.f, stream);
+  int rc = attn_bgemm(0, q, k, attn, B, L, L, dk, 1.f, stream);
   if (rc != PZN_OK) return rc;
   long rows = (long)B * L;
   launch_softmax_fwd(attn, rows, L, sqrtf((float)dk), pzn_hip_stream(stream));
   if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
-  return pzn_bgemm_f32(1, attn, v, out, B, L, dv, L, 1.f, stream);
+  return attn_bgemm(1, attn, v, out, B, L, dv, L, 1.f, stream);
 }
 
 PZN_EXPORT size_t pzn_attn_bwd_workspace_bytes(int B, int L, int dk, int dv) {
@@ -1002,16 +1054,16 @@ PZN_EXPORT int pzn_attn_bwd_f32(const float* q, const float* k, const float* v, 
   PZN_CHECK_ARG(q && k && v && attn && d_out && dq && dk_out && dv_out && workspace && B > 0 && L > 0 && dk > 0 &&
                 dv > 0);
   float* ds = static_cast<float*>(workspace);
-  int rc = pzn_bgemm_f32(2, attn, d_out, dv_out, B, L, dv, L, 1.f, stream);  // dV = attn^T dO
+  int rc = attn_bgemm(2, attn, d_out, dv_out, B, L, dv, L, 1.f, stream);  // dV = attn^T dO
   if (rc != PZN_OK) return rc;
-  rc = pzn_bgemm_f32(0, d_out, v, ds, B, L, L, dv, 1.f, stream);  // dAttn = dO V^T
+  rc = attn_bgemm(0, d_out, v, ds, B, L, L, dv, 1.f, stream);  // dAttn = dO V^T
   if (rc != PZN_OK) return rc;
   long rows = (long)B * L;
   launch_softmax_bwd(attn, ds, d_attn, rows, L, sqrtf((float)dk), pzn_hip_stream(stream));
   if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
-  rc = pzn_bgemm_f32(1, ds, k, dq, B, L, dk, L, 1.f, stream);  // dQ = dS K
+  rc = attn_bgemm(1, ds, k, dq, B, L, dk, L, 1.f, stream);  // dQ = dS K
   if (rc != PZN_OK) return rc;
-  return pzn_bgemm_f32(2, ds, q, dk_out, B, L, dk, L, 1.f, stream);  // dK = dS^T Q
+  return attn_bgemm(2, ds, q, dk_out, B, L, dk, L, 1.f, stream);  // dK = dS^T Q
 }
 
 // ---- layerAttention as ONE unit (model5_b.py:83-101): q,k,v = Linear(x); (a, attn) = scaled_dot_production(q,k,v);
@@ -1046,7 +1098,7 @@ PZN_EXPORT int pzn_attn_block_fwd_f32(const float* x, const float* Wq, const flo
     if (rc == PZN_OK) rc = pzn_linear_fwd_f32(x, Wk, bk, M, E, dk, 0, k, stream);
     if (rc == PZN_OK) rc = pzn_linear_fwd_f32(x, Wv, bv, M, E, E, 0, v, stream);
   }
-  if (rc == PZN_OK) rc = pzn_bgemm_f32(0, q, k, attn, B, L, L, dk, 1.f, stream);
+  if (rc == PZN_OK) rc = attn_bgemm(0, q, k, attn, B, L, L, dk, 1.f, stream);
   if (rc != PZN_OK) return rc;
   const long rows = (long)B * L;
   launch_softmax_fwd(attn, rows, L, sqrtf((float)dk), st);
@@ -1055,6 +1107,7 @@ PZN_EXPORT int pzn_attn_block_fwd_f32(const float* x, const float* Wq, const flo
     GemmArgs p = base_args(L, E, L);
     p.A = attn, p.lda = L, p.B = v, p.ldb = E, p.C = r, p.ldc = E, p.alpha = -1.f, p.addend = x;
     p.sA = (long)L * L, p.sB = (long)L * E, p.sC = (long)L * E;
+    p.plain_bf16 = attn_precision() == 1;
     launch<true, false, EPI_STORE>(p, B, st);
     if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
   }
@@ -1090,14 +1143,14 @@ PZN_EXPORT int pzn_attn_block_bwd_f32(const float* x, const float* Wq, const flo
   int rc = pzn_linear_dgrad_f32(dout, yo, Wo, M, E, E, nullptr, dd, stream);
   if (rc == PZN_OK) rc = pzn_linear_wgrad_f32(dout, yo, r, M, E, E, dWo, dbo, accumulate, stream);
   // attention with d(values) = -dd  (r = x - a)
-  if (rc == PZN_OK) rc = pzn_bgemm_f32(2, attn, dd, dvv, B, L, E, L, -1.f, stream);   // dV = attn^T dO
-  if (rc == PZN_OK) rc = pzn_bgemm_f32(0, dd, v, ds, B, L, L, E, -1.f, stream);        // dAttn = dO V^T
+  if (rc == PZN_OK) rc = attn_bgemm(2, attn, dd, dvv, B, L, E, L, -1.f, stream);   // dV = attn^T dO
+  if (rc == PZN_OK) rc = attn_bgemm(0, dd, v, ds, B, L, L, E, -1.f, stream);        // dAttn = dO V^T
   if (rc != PZN_OK) return rc;
   const long rows = (long)B * L;
   launch_softmax_bwd(attn, ds, dattn, rows, L, sqrtf((float)dk), st);
   if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
-  rc = pzn_bgemm_f32(1, ds, k, dq, B, L, dk, L, 1.f, stream);                           // dQ = dS K
-  if (rc == PZN_OK) rc = pzn_bgemm_f32(2, ds, q, dkk, B, L, dk, L, 1.f, stream);        // dK = dS^T Q
+  rc = attn_bgemm(1, ds, k, dq, B, L, dk, L, 1.f, stream);                           // dQ = dS K
+  if (rc == PZN_OK) rc = attn_bgemm(2, ds, q, dkk, B, L, dk, L, 1.f, stream);        // dK = dS^T Q
   // dx = dv Wv + dd;  += dk Wk;  += dq Wq + dout   (no tensor adds)
   if (rc == PZN_OK)
     rc = pzn_ws_gemm_ex(dvv, E, Wv, E, 1, dx, E, M, E, E, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, dd, nullptr,

@@ -252,3 +252,37 @@ def test_sa_level_production_shape(dev):
         want = torch.relu(h @ w2.double().t() + b2.double()).max(dim=0)[0]
         got = o0[b, s].cpu().double()
         assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-5
+
+
+def test_training_step_n8192_bf16_attention(dev):
+    """configs[4] (N = 8192, bf16 attention contractions): a whole training_step in the opt-in mode
+    (pzn_attn_set_precision(1)) beside the default one on the same draws — the FPS picks do not depend on the mode
+    (bit-exact), the loss moves by bf16 rounding only, every gradient is finite."""
+    from puzzlenet_amd import _lib, synthetic
+    N, B = 8192, 2
+    cfg = mr.Cfg(num_points=N, loss_mode=1)
+    lib = _lib.load()
+    batch = synthetic.make_batch(B, N, dev, seed=8192)
+    old = lib.pzn_attn_get_precision()
+    res = {}
+    try:
+        for mode in (0, 1):
+            _lib.check(lib.pzn_attn_set_precision(mode), "pzn_attn_set_precision")
+            model, _ = _pair(cfg, dev)
+            torch.manual_seed(9)
+            with torch.no_grad():
+                picks = model.predict5(batch, B, need=True, training=True)
+            model, _ = _pair(cfg, dev)
+            torch.manual_seed(9)
+            loss = model.training_step(batch, 0)["loss"]
+            loss.backward()
+            torch.cuda.synchronize()
+            finite = all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+            res[mode] = (float(loss), picks[2].cpu(), picks[4].cpu(), picks[0].cpu(), finite)
+    finally:
+        lib.pzn_attn_set_precision(old)
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert res[0][4] and res[1][4]
+    assert abs(res[1][0] - res[0][0]) <= 2e-2 * abs(res[0][0]), (res[0][0], res[1][0])
+    assert res[1][0] != res[0][0]                                   # the mode is really on
+    np.testing.assert_allclose(res[1][3].numpy(), res[0][3].numpy(), rtol=5e-2, atol=5e-3)      # pose twist

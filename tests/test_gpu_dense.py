@@ -265,3 +265,90 @@ def test_attention_block_fused_vs_composed(dev, sinks):
     for a_, b_ in zip(gpf, gpc):
         # (the key bias has a mathematically zero gradient — softmax is shift-invariant — so it gets an absolute floor)
         assert float((a_ - b_).abs().max()) < 2e-4 * max(float(b_.abs().max()), 5e-2)
+
+
+# Stated tolerance of the opt-in bf16 attention mode (pzn_attn_set_precision(1)): operands are rounded to bf16 (8
+# significant bits: relative step 2^-8, rounding error <= 2^-9 = 2e-3 per operand), products and sums are fp32.  A logit
+# q.k / sqrt(dk) with |q|, |k| ~ sqrt(dk) then carries an absolute error of ~3e-3, which softmax turns into the same
+# relative error of the map; values and gradients add the rounding of their own operands.  Held to 2e-2 of the
+# tensor's largest magnitude forward and 4e-2 backward, and to 1e-2 in the relative L2 norm.
+BF16_FWD_TOL, BF16_BWD_TOL, BF16_L2_TOL = 2e-2, 4e-2, 1e-2
+
+
+@pytest.fixture
+def attn_bf16():
+    from puzzlenet_amd import _lib
+    lib = _lib.load()
+    old = lib.pzn_attn_get_precision()
+    _lib.check(lib.pzn_attn_set_precision(1), "pzn_attn_set_precision")
+    yield
+    lib.pzn_attn_set_precision(old)
+
+
+def _l2(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("B,L,dk,dv", [(3, 256, 64, 256), (2, 100, 16, 40)])
+def test_attention_bf16_mode(dev, attn_bf16, B, L, dk, dv):
+    """scaled_dot_production (model5_b.py:67-75) with the contractions as single bf16 MFMAs, fp32 softmax, against the
+    fp64 composition at the stated bf16 tolerance; the mode must really be a different (coarser) result than the
+    default path, and the default path must be untouched once the mode is switched back."""
+    from puzzlenet_amd import _lib, ops
+    g = torch.Generator().manual_seed(L)
+    q, k, v = torch.randn(B, L, dk, generator=g), torch.randn(B, L, dk, generator=g), torch.randn(B, L, dv, generator=g)
+    go = torch.randn(B, L, dv, generator=g)
+    ref = [t.double().requires_grad_(True) for t in (q, k, v)]
+    attn_r = F.softmax(ref[0] @ ref[1].transpose(-2, -1) / math.sqrt(dk), dim=-1)
+    out_r = attn_r @ ref[2]
+    (out_r * go.double()).sum().backward()
+    d = [t.to(dev).requires_grad_(True) for t in (q, k, v)]
+    out, attn = ops.attention(*d)
+    assert _rel(out, out_r) < BF16_FWD_TOL and _rel(attn, attn_r) < BF16_FWD_TOL
+    assert _l2(out, out_r) < BF16_L2_TOL and _l2(attn, attn_r) < BF16_L2_TOL
+    assert _rel(out, out_r) > 1e-4            # it IS the bf16 path (the default agrees to 1e-5)
+    (out * go.to(dev)).sum().backward()
+    for a, r, name in zip(d, ref, "qkv"):
+        assert _rel(a.grad, r.grad) < BF16_BWD_TOL and _l2(a.grad, r.grad) < 2 * BF16_L2_TOL, name
+    lib = _lib.load()
+    lib.pzn_attn_set_precision(0)
+    out32, _ = ops.attention(*[t.to(dev) for t in (q, k, v)])
+    lib.pzn_attn_set_precision(1)
+    assert _rel(out32, out_r) < 1e-5
+
+
+def test_attention_block_bf16_mode(dev, attn_bf16):
+    """layerAttention behind pzn_attn_block_* in the bf16 attention mode: projections stay fp32-accurate, the four
+    contractions are bf16; outputs and gradients against an fp64 restatement of model5_b.py:83-101."""
+    from puzzlenet_amd import ops
+    B, L, E, dk = 20, 256, 256, 64
+    g = torch.Generator().manual_seed(3)
+    x0 = 0.5 * torch.randn(B, L, E, generator=g)
+    shapes = [(dk, E), (dk,), (dk, E), (dk,), (E, E), (E,), (E, E), (E,)]
+    params0 = [torch.randn(*s, generator=g) / (math.sqrt(E) if len(s) == 2 else 4) for s in shapes]
+    wr = torch.randn(B, L, E, generator=g)
+    xr = x0.double().requires_grad_(True)
+    pr = [p.double().requires_grad_(True) for p in params0]
+    wq, bq, wk, bk, wv, bv, wo, bo = pr
+    qr, kr, vr = xr @ wq.t() + bq, xr @ wk.t() + bk, xr @ wv.t() + bv
+    ar = F.softmax(qr @ kr.transpose(-2, -1) / math.sqrt(dk), dim=-1)
+    rr = xr + torch.relu((xr - ar @ vr) @ wo.t() + bo)
+    (rr * wr.double()).sum().backward()
+    x = x0.to(dev).requires_grad_(True)
+    ps = [p.to(dev).requires_grad_(True) for p in params0]
+    ops.clear_grad_sinks()
+    assert ops.attention_block_supported(x, dk)
+    r, a = ops.attention_block(x, *ps)
+    assert _rel(r, rr) < BF16_FWD_TOL and _rel(a, ar) < BF16_FWD_TOL and _l2(r, rr) < BF16_L2_TOL
+    (r * wr.to(dev)).sum().backward()
+    # dx passes through the ReLU of the output projection: a gate whose pre-activation sits within the bf16 error of
+    # zero flips and moves single entries by a whole term, so dx is held in L2 and by the share of deviating entries
+    dxe = (x.grad.cpu().double() - xr.grad).abs()
+    assert _l2(x.grad, xr.grad) < 2 * BF16_L2_TOL
+    assert float((dxe > BF16_BWD_TOL * xr.grad.abs().max()).double().mean()) < 1e-3
+    for p_, q_ in zip(ps, pr):
+        assert _l2(p_.grad, q_.grad) < 2 * BF16_L2_TOL or float(q_.grad.abs().max()) < 5e-2
+        # (the key bias has a mathematically zero gradient — softmax is shift-invariant — and collects the bf16 rounding
+        # noise of 5120 rows instead: absolute floor)
+        assert float((p_.grad.cpu().double() - q_.grad).abs().max()) < 2 * BF16_BWD_TOL * max(float(q_.grad.abs().max()), 0.25)
