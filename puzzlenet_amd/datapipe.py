@@ -1,5 +1,6 @@
-"""Training-pair construction on the GPU: the single-cut path of the reference's `CADDataset`
-(dataset.py:1165-1190) + `MovedCADDataset2.__getitem__` (:98-105), batched, on the kernels of the hot path.
+"""Training-pair construction on the GPU: the reference's `CADDataset` — single cut
+(dataset.py:1165-1190) and the double-cut variants of `__getitem__` (:1203-1355) — and `BuildingDataset` (:1370-1429),
+each followed by `MovedCADDataset2.__getitem__` (:98-105), batched, on the kernels of the hot path.
 
     raw cloud [M,3]  --plane cut (dataset.py:761-775)-->  up / down  --numpy FPS to N (:1147-1163)-->  N-point pieces
         --get_boundary (:1357-1367: chamfer both ways, the 128 points nearest to the other piece + 0/1 masks)-->
@@ -13,8 +14,11 @@ reference's), the boundary is `pzn_chamfer_fwd_f32` + top-k, the motion `pzn_se3
 
 Randomness stays OUTSIDE: the caller passes the draws (plane normal / offset, FPS start indices, unit twists) — e.g.
 `draws_like_reference` replays numpy / torch generators in the reference's order — so results can be compared draw for
-draw with the reference's functions (tests/golden/make_golden_data.py -> data.npz).  The mesh-based cuts (sphere,
-cylinder, cone: dataset.py:716-758) go through open3d ray casting and are out of scope (no open3d here).
+draw with the reference's functions (tests/golden/make_golden_data.py -> data.npz).  The double-cut variants are the
+same machinery on REGIONS of two planes (`make_pairs_regions`; `plan_double_cut_like_reference` replays the
+reference's branch decisions and draws); `building_pairs` is the item contract of `BuildingDataset` (two given pieces).
+The mesh-based cuts (sphere, cylinder, cone: dataset.py:716-758) go through open3d ray casting and are out of scope
+(no open3d here).
 """
 import numpy as np
 import torch
@@ -109,7 +113,7 @@ def make_pairs(raw, normal, z, start_up, start_down, twist, n=1024, k=128, cap=N
     mask = plane_cut_mask(raw, normal, z)
     up_piece, n_up = _compact(raw, mask, cap)
     down_piece, n_down = _compact(raw, ~mask, cap)
-    ok = (n_up >= n) & (n_down >= n)
+    ok = (n_up >= n) & (n_down >= n) & (n_up <= cap) & (n_down <= cap)      # (a piece larger than `cap` would be truncated)
     # one FPS launch for both pieces of every sample (a workgroup per piece: 2B workgroups instead of 2 x B)
     both = fps_to_n(torch.cat([up_piece, down_piece], 0), torch.cat([n_up, n_down], 0),
                     torch.cat([start_up.reshape(-1), start_down.reshape(-1)], 0), n)
@@ -117,3 +121,163 @@ def make_pairs(raw, normal, z, start_up, start_down, twist, n=1024, k=128, cap=N
     downb, upb, down_mask, up_mask = boundary(down, up, k)
     moved, igt = move(up, twist)
     return (down, moved, igt, up, downb, upb, down_mask, up_mask), ok
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Double-cut variants (dataset.py:1203-1355) and BuildingDataset (:1370-1429)
+#
+# Every pair the reference's `CADDataset.__getitem__` can return is (U, D) = two point sets defined by the sides of at
+# most two planes: plane 1 cuts the cloud into up / down (:1208), plane 2 cuts `up` (slice_seed 1) or `down`
+# (slice_seed 2) into uppc / downpc (:1222, :1296).  A REGION is a set of (side of plane 1, side of plane 2) cells,
+# written as a 4-bit table with bit 2*s1 + s2 (s = 1: dis >= 0); a piece is an ordered list of up to two regions
+# (np.vstack((other, down)) at :1237 keeps `other` first: the order decides which point a start index names).
+UP, DOWN = 0b1100, 0b0011                      # sides of plane 1, either side of plane 2
+UP_UPPC, UP_DOWNPC = 0b1000, 0b0100            # plane 2 inside `up`
+DOWN_UPPC, DOWN_DOWNPC = 0b0010, 0b0001        # plane 2 inside `down`
+
+
+def _compact_segments(raw, seg, cap):
+    """Rows with seg 0, then rows with seg 1 (original order inside each), padded to `cap` with copies of the first
+    kept row; seg 2 = left out.  -> (packed [B,cap,3], count [B])"""
+    count = (seg < 2).sum(1)
+    order = torch.sort(seg.to(torch.int8), dim=1, stable=True)[1]
+    packed = torch.gather(raw, 1, order[:, :cap].unsqueeze(-1).expand(-1, -1, 3))
+    pos = torch.arange(cap, device=raw.device).unsqueeze(0)
+    first = packed[:, :1, :]
+    return torch.where((pos < count.unsqueeze(1)).unsqueeze(-1), packed, first.expand(-1, cap, -1)).contiguous(), count
+
+
+def _segments(code, tab):
+    """code [B,M] in 0..3, tab [B,2] region tables -> segment id 0 / 1 / 2 (left out) per point."""
+    in0 = (tab[:, 0:1] >> code) & 1
+    in1 = (tab[:, 1:2] >> code) & 1
+    return torch.where(in0 == 1, torch.zeros_like(code), torch.where(in1 == 1, torch.ones_like(code), torch.full_like(code, 2)))
+
+
+def pairs_from_pieces(U, D, twist, k=128):
+    """(U, D) N-point pieces -> the 8-tuple of MovedCADDataset2.__getitem__ (:98-105) on top of get_boundary(D, U)
+    (:1357-1367): (D, moved U, igt, U, D boundary, U boundary, D mask, U mask)."""
+    Db, Ub, Dm, Um = boundary(D, U, k)
+    moved, igt = move(U, twist)
+    return D, moved, igt, U, Db, Ub, Dm, Um
+
+
+def make_pairs_regions(raw, normal1, z1, normal2, z2, u_tab, d_tab, start_u, start_d, twist, n=1024, k=128, cap=None):
+    """The general form of make_pairs: raw [B,M,3] on the GPU, two planes per sample, and for each of the two pieces an
+    ordered pair of region tables (u_tab, d_tab: int64 [B,2]; a second table of 0 = single region).  U = FPS(n) of the
+    points of u_tab from start_u, D likewise; -> (8-tuple, ok [B]).  The single cut is u_tab = (UP, 0), d_tab = (DOWN, 0)."""
+    if not raw.is_cuda:
+        raise _lib.PznError("datapipe.make_pairs_regions runs on the GPU (puzzlenet_amd has no CPU fallback)")
+    raw = raw.to(torch.float32).contiguous()
+    B, M, _ = raw.shape
+    cap = M if cap is None else int(cap)
+    s1 = plane_cut_mask(raw, normal1, z1)
+    s2 = plane_cut_mask(raw, normal2, z2)
+    code = 2 * s1.to(torch.int64) + s2.to(torch.int64)
+    u_piece, n_u = _compact_segments(raw, _segments(code, u_tab.to(raw.device)), cap)
+    d_piece, n_d = _compact_segments(raw, _segments(code, d_tab.to(raw.device)), cap)
+    ok = (n_u >= n) & (n_d >= n) & (n_u <= cap) & (n_d <= cap)
+    both = fps_to_n(torch.cat([u_piece, d_piece], 0), torch.cat([n_u, n_d], 0),
+                    torch.cat([start_u.reshape(-1), start_d.reshape(-1)], 0), n)
+    U, D = both[:B].contiguous(), both[B:].contiguous()
+    return pairs_from_pieces(U, D, twist, k), ok
+
+
+def building_pairs(fpcs, rpcs, twist, k=128):
+    """BuildingDataset.__getitem__ (:1423-1429) for a batch: the item is (rpc, fpc, get_boundary(fpc, rpc)), i.e. U = the
+    roof cloud, D = the facade cloud, both given (no cut, no sampling); -> the 8-tuple of MovedCADDataset2 on top."""
+    if not (fpcs.is_cuda and rpcs.is_cuda):
+        raise _lib.PznError("datapipe.building_pairs runs on the GPU (puzzlenet_amd has no CPU fallback)")
+    return pairs_from_pieces(rpcs.to(torch.float32).contiguous(), fpcs.to(torch.float32).contiguous(), twist, k)
+
+
+def _plane_draw():
+    return np.random.rand(3, 1), np.random.rand(1) / 3          # dataset.py:767-769 (z=None)
+
+
+def _side(pts, normal, z):
+    return (np.dot(pts, normal) + z >= 0).reshape(-1)            # :770-771
+
+
+def plan_double_cut_like_reference(raw, accept, n=1024, mag=0.8):
+    """The branch decisions and random draws of ONE `CADDataset.__getitem__` call with split_twice=True
+    (dataset.py:1203-1355) followed by MovedCADDataset2 (:98-105), made from numpy's and torch's GLOBAL generators in the
+    reference's order (seed them as the reference run would), as a recipe for make_pairs_regions.
+      raw     [M,3] float32 numpy array (host side: piece sizes steer the branches and the start-index ranges)
+      accept  callable(recipe without motion) -> float: the chamfer distance of the two boundaries of the candidate pair —
+              the one decision of the reference that needs the pieces themselves (:1250-1253, :1322-1325: the pair is
+              kept when it is <= 0.015).  Called at most once.
+    -> dict(kind, normal1, z1, normal2, z2, u_tab, d_tab, s_u, s_d, twist)"""
+    raw = np.asarray(raw, dtype=np.float32)
+    none = (np.zeros((3, 1)), np.zeros(1))
+
+    def recipe(kind, planes, u_tab, d_tab, s_u, s_d):
+        (n1, z1), (n2, z2) = planes
+        return dict(kind=kind, normal1=n1.reshape(3), z1=z1.reshape(1), normal2=n2.reshape(3), z2=z2.reshape(1),
+                    u_tab=np.array(u_tab, np.int64), d_tab=np.array(d_tab, np.int64), s_u=int(s_u), s_d=int(s_d))
+
+    def single(p1, s1):                                          # self.slice(pc, None, up, down), :1192-1201
+        while int(s1.sum()) < n or int((~s1).sum()) < n:
+            p1 = _plane_draw()
+            s1 = _side(raw, *p1)
+        s_u = np.random.randint(0, int(s1.sum()))
+        s_d = np.random.randint(0, int((~s1).sum()))
+        return recipe("single", (p1, none), (UP, 0), (DOWN, 0), s_u, s_d)
+
+    def item():
+        slice_seed = int(torch.randint(0, 3, (1,)))              # :1206-1207
+        p1 = _plane_draw()                                       # :1208
+        s1 = _side(raw, *p1)
+        n_up, n_down = int(s1.sum()), int((~s1).sum())
+        if slice_seed == 1 and n_up < 3000:                      # :1211-1214
+            slice_seed = 2
+        if slice_seed == 2 and n_down < 3000:
+            slice_seed = 1
+        if slice_seed == 0:
+            return single(p1, s1)
+        inner = s1 if slice_seed == 1 else ~s1                   # the piece that is cut again
+        n_other = n_down if slice_seed == 1 else n_up            # the piece that is not
+        sub = raw[inner]
+        p2 = _plane_draw()                                       # :1222 / :1296
+        s2 = _side(sub, *p2)
+        tries = 0
+        while tries <= 5 and (int(s2.sum()) < n or int((~s2).sum()) < n):
+            p2 = _plane_draw()
+            s2 = _side(sub, *p2)
+            tries += 1
+        n_a, n_b = int(s2.sum()), int((~s2).sum())               # uppc, downpc
+        if n_a < n or n_b < n:                                   # :1226-1227
+            return single(p1, s1)
+        A, Bt = (UP_UPPC, UP_DOWNPC) if slice_seed == 1 else (DOWN_UPPC, DOWN_DOWNPC)
+        OTHER = DOWN if slice_seed == 1 else UP
+        se = int(torch.randint(0, 3, (1,)))                      # :1229 / :1302
+        if se == 0 or n_other < n:                               # U = one half, D = the other half + the other piece
+            choice = int(torch.randint(0, 2, (1,)))
+            first, second = (A, Bt) if choice == 0 else (Bt, A)
+            n_first, n_second = (n_a, n_b) if choice == 0 else (n_b, n_a)
+            s_u = np.random.randint(0, n_first)
+            s_d = np.random.randint(0, n_second + n_other)
+            return recipe("half_vs_rest", (p1, p2), (first, 0), (second, OTHER), s_u, s_d)
+        if se == 1:                                              # U = one half, D = the other PIECE, kept if they touch
+            choice = int(torch.randint(0, 2, (1,)))
+            first = A if choice == 0 else Bt
+            s_u = np.random.randint(0, n_a if choice == 0 else n_b)
+            s_d = np.random.randint(0, n_other)
+            cand = recipe("half_vs_other", (p1, p2), (first, 0), (OTHER, 0), s_u, s_d)
+            if float(accept(cand)) > 0.015:                      # :1250-1253 / :1322-1325
+                return single(p1, s1)
+            return cand
+        s_u = np.random.randint(0, n_a)                          # se == 2: the two halves, :1255-1256 / :1326-1327
+        s_d = np.random.randint(0, n_b)
+        re_now = np.random.rand(1)                               # :1260 / :1330
+        if not (re_now > (0.7 if slice_seed == 1 else 0.6)) and n_other >= 1200:
+            np.random.randint(0, n_other + n)                    # :1281 / :1350: two more FPS runs whose results the
+            np.random.randint(0, n)                              # reference overwrites (:1282-1283, :1351-1352)
+        return recipe("halves", (p1, p2), (A, 0), (Bt, 0), s_u, s_d)
+
+    rec = item()
+    x = torch.randn(1, 6)                                        # MovedCADDataset2: rigid_transform(up), transforms.py:163-168
+    x = x / x.norm(p=2, dim=1, keepdim=True) * mag
+    torch.randn(1, 6)                                            # rigid_transform(upb), dataset.py:101: drawn, result unused
+    rec["twist"] = x.reshape(6).numpy()
+    return rec

@@ -39,3 +39,15 @@ def golden_eval():
 def golden_data():
     """tests/golden/data.npz: the reference's data-pipeline functions on seeded clouds (make_golden_data.py)."""
     return np.load(os.path.join(GOLDEN, "data.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_data2():
+    """tests/golden/data2.npz: the reference's double-cut CADDataset item and BuildingDataset item (make_golden_data2.py)."""
+    return np.load(os.path.join(GOLDEN, "data2.npz"))
+
+
+def golden_cloud(seed, M):
+    """The raw cloud of a data2.npz case, regenerated from its seed exactly as make_golden_data2.py made it."""
+    rng = np.random.default_rng(50_000 + int(seed))
+    return (rng.random((int(M), 3), dtype=np.float32) - np.float32(0.5)).astype(np.float32)

@@ -57,3 +57,54 @@ def test_draws_follow_the_reference_order(golden_data):
         assert np.array_equal(d["normal"], G[f"c{c}_normal"]) and np.array_equal(d["z"], G[f"c{c}_z"])
         assert d["s_up"] == int(G[f"c{c}_s_up"]) and d["s_down"] == int(G[f"c{c}_s_down"])
         assert np.array_equal(d["twist"], G[f"c{c}_twist"])
+
+
+def _region_points(raw, rec, tab):
+    s1 = (np.dot(raw, np.asarray(rec["normal1"]).reshape(3, 1)) + rec["z1"] >= 0).reshape(-1)
+    s2 = (np.dot(raw, np.asarray(rec["normal2"]).reshape(3, 1)) + rec["z2"] >= 0).reshape(-1)
+    code = 2 * s1.astype(np.int64) + s2.astype(np.int64)
+    return np.vstack([raw[((int(t) >> code) & 1) == 1] for t in tab if int(t)])
+
+
+def _oracle_accept(raw):
+    """chamfer distance of the two 128-point boundaries of a candidate pair, with the oracle's FPS and chamfer
+    (dataset.py:1250-1253: the pair is kept when this is <= 0.015)."""
+    def accept(rec):
+        U = _region_points(raw, rec, rec["u_tab"])
+        D = _region_points(raw, rec, rec["d_tab"])
+        U = U[orc.farthest_point_sample(U[None], 1024, np.array([rec["s_u"]], np.int64))[0]]
+        D = D[orc.farthest_point_sample(D[None], 1024, np.array([rec["s_d"]], np.int64))[0]]
+        over_u, _, over_d, _ = orc.chamfer(D[None], U[None])          # min over D per U-point, min over U per D-point
+        ub = U[np.argsort(over_u[0], kind="stable")[:128]]
+        db = D[np.argsort(over_d[0], kind="stable")[:128]]
+        c1, _, c2, _ = orc.chamfer(db[None], ub[None])
+        return float(c1.mean() + c2.mean())
+    return accept
+
+
+def test_double_cut_planner_follows_the_reference(golden_data2):
+    """datapipe.plan_double_cut_like_reference, seeded as make_golden_data2.py seeded the reference's
+    MovedCADDataset2(CADDataset(split_twice=True)).__getitem__, takes the same branch and makes the same draws: one case
+    per kind of pair (single cut, half vs rest, half vs the other piece, the two halves; upper and lower piece; and a
+    candidate the reference rejected).  The pieces the recipe names, sampled by the oracle FPS, are the reference's."""
+    import torch
+    from puzzlenet_amd import datapipe
+    from tests.conftest import golden_cloud
+    G = golden_data2
+    kinds = set()
+    for seed in G["seeds"].tolist():
+        raw = golden_cloud(seed, G["M"])
+        k = f"s{seed}_"
+        np.random.seed(3000 + seed)
+        torch.manual_seed(9000 + seed)
+        rec = datapipe.plan_double_cut_like_reference(raw, _oracle_accept(raw), n=int(G["N"]), mag=0.8)
+        for name in ("normal1", "z1", "normal2", "z2", "u_tab", "d_tab", "twist"):
+            assert np.array_equal(np.asarray(rec[name]), G[k + name]), (seed, name)
+        assert rec["s_u"] == int(G[k + "s_u"]) and rec["s_d"] == int(G[k + "s_d"])
+        U = _region_points(raw, rec, rec["u_tab"])
+        D = _region_points(raw, rec, rec["d_tab"])
+        assert np.array_equal(U[orc.farthest_point_sample(U[None], 1024, np.array([rec["s_u"]], np.int64))[0]], G[k + "up"])
+        assert np.array_equal(D[orc.farthest_point_sample(D[None], 1024, np.array([rec["s_d"]], np.int64))[0]], G[k + "down"])
+        kinds.add(str(G[k + "kind"]))
+    assert {"single", "single_after_rejection", "half_vs_rest", "half_vs_rest_lower", "half_vs_other", "half_vs_other_lower",
+            "halves", "halves_lower"} <= kinds

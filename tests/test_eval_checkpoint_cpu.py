@@ -81,3 +81,35 @@ def test_lightning_checkpoint_round_trip(tmp_path):
         raise AssertionError("missing key accepted")
     except RuntimeError:
         pass
+
+
+def test_save_reference_checkpoint_round_trip(tmp_path):
+    """checkpoint.save_reference_checkpoint writes what the reference's load_from_checkpoint reads (state_dict with the
+    reference's keys + hyper_parameters.config as an argparse.Namespace); the file loads back under weights_only=True."""
+    src = mb.TouchedRegraster(mr.Cfg(num_points=1024, m="saved"))
+    mr.fill_params(src)
+    path = checkpoint.save_reference_checkpoint(src, src.C, os.path.join(tmp_path, "out.ckpt"), epoch=2, global_step=40)
+    raw = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(raw) >= {"state_dict", "hyper_parameters", "epoch", "global_step"}
+    assert isinstance(raw["hyper_parameters"]["config"], argparse.Namespace)
+    assert not hasattr(raw["hyper_parameters"]["config"], "num_points") and raw["hyper_parameters"]["config"].m == "saved"
+    assert raw["hyper_parameters"]["config"].loss_mode == 1 and raw["hyper_parameters"]["config"].lr == 0.9e-3
+    assert list(raw["state_dict"].keys()) == list(src.state_dict().keys())
+    built = checkpoint.build_from_reference_checkpoint(path)                 # the safe (weights_only) reader
+    for (k, a), (_, b) in zip(src.state_dict().items(), built.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+class Payload:
+    pass
+
+
+def test_untrusted_pickles_are_refused(tmp_path):
+    """A checkpoint that smuggles an arbitrary class is not unpickled unless the caller says the file is trusted."""
+    path = os.path.join(tmp_path, "evil.ckpt")
+    torch.save({"state_dict": {}, "hyper_parameters": {"config": Payload()}}, path)
+    try:
+        checkpoint.read_reference_checkpoint(path)
+        raise AssertionError("arbitrary class unpickled")
+    except Exception as e:      # noqa: BLE001
+        assert "Payload" in str(e) or "Unsupported" in str(e) or "weights_only" in str(e), e

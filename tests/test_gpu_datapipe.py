@@ -65,9 +65,59 @@ def test_pairs_feed_a_training_step(golden_data):
     cfg = mr.Cfg(loss_mode=1, num_points=int(G["N"]))
     torch.manual_seed(0)
     model = mb.TouchedRegraster(cfg).to(dev)
-    runner = engine.TrainStep(model, list(batch), cfg.lr, world=1, use_graph=False)
+    runner = engine.TrainStep(model, list(batch), cfg.lr, world=1)
     l0 = float(runner.step())
     l1 = float(runner.step())
     assert np.isfinite(l0) and np.isfinite(l1)
     assert bool(torch.isfinite(runner.grads.flat).all()) and float(runner.grads.flat.abs().max()) > 0
     runner.close()
+
+
+def _check_item(out, G, k, c):
+    down, moved, igt, up, downb, upb, down_mask, up_mask = out
+    assert np.array_equal(up[c].cpu().numpy(), G[k + "up"]) and np.array_equal(down[c].cpu().numpy(), G[k + "down"])
+    np.testing.assert_allclose(igt[c].cpu().numpy(), G[k + "igt"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(moved[c].cpu().numpy(), G[k + "mup"], rtol=1e-5, atol=1e-6)
+    for mine, ref, pts, piece in ((down_mask, "fpc_idx", downb, down), (up_mask, "rpc_idx", upb, up)):
+        m = mine[c].cpu().numpy()
+        assert int(m.sum()) == 128
+        assert int((m != G[k + ref]).sum()) <= 4          # (a near-tie at the 128th distance: one swapped pair)
+        assert {tuple(r) for r in pts[c].cpu().numpy()} == {tuple(r) for r in piece[c][mine[c] > 0].cpu().numpy()}
+
+
+def test_double_cut_pairs_match_reference(golden_data2):
+    """datapipe.make_pairs_regions on the recipes of tests/golden/data2.npz (the reference's double-cut
+    CADDataset.__getitem__ + MovedCADDataset2 run on CPU, one case per kind of pair): all cases as ONE batch."""
+    from puzzlenet_amd import datapipe
+    from tests.conftest import golden_cloud
+    G = golden_data2
+    dev = torch.device("cuda:0")
+    seeds = G["seeds"].tolist()
+    st = lambda name, dt: torch.stack([torch.from_numpy(np.asarray(G[f"s{s}_{name}"])) for s in seeds]).to(dt).to(dev)
+    raw = torch.stack([torch.from_numpy(golden_cloud(s, G["M"])) for s in seeds]).to(dev)
+    out, ok = datapipe.make_pairs_regions(raw, st("normal1", torch.float64), st("z1", torch.float64).reshape(-1),
+                                          st("normal2", torch.float64), st("z2", torch.float64).reshape(-1),
+                                          st("u_tab", torch.int64), st("d_tab", torch.int64), st("s_u", torch.int64),
+                                          st("s_d", torch.int64), st("twist", torch.float32), n=int(G["N"]))
+    assert bool(ok.all())
+    for c, s in enumerate(seeds):
+        _check_item(out, G, f"s{s}_", c)
+    # the chamfer distance of the boundaries that decides the reference's half-vs-other branch (dataset.py:1250-1253)
+    from puzzlenet_amd import ops
+    c1, c2 = ops.chamfer(out[4], out[5])
+    cd = (c1.mean(1) + c2.mean(1)).cpu().numpy()
+    for c, s in enumerate(seeds):
+        if str(G[f"s{s}_kind"]).startswith("half_vs_other"):
+            np.testing.assert_allclose(cd[c], float(G[f"s{s}_cd"]), rtol=2e-2)
+            assert cd[c] <= 0.015
+
+
+def test_building_pairs_match_reference(golden_data2):
+    """datapipe.building_pairs == MovedCADDataset2(BuildingDataset).__getitem__ (dataset.py:1370-1429, :92-105)."""
+    from puzzlenet_amd import datapipe
+    G = golden_data2
+    dev = torch.device("cuda:0")
+    twist = torch.stack([torch.from_numpy(G[f"b{i}_twist"]) for i in range(3)]).to(dev)
+    out = datapipe.building_pairs(torch.from_numpy(G["b_fpcs"]).to(dev), torch.from_numpy(G["b_rpcs"]).to(dev), twist)
+    for i in range(3):
+        _check_item(out, G, f"b{i}_", i)
