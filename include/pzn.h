@@ -165,7 +165,8 @@ int pzn_chamfer_bwd_f32(const float* a, const float* b, int B, int n, int m,
                         float* grad_a, float* grad_b, pzn_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
-/* Dense path on the matrix cores (exact fp32: v_mfma_f32_32x32x2_f32)      */
+/* Dense path on the matrix cores (fp32 results; default operand path = bf16x3 */
+/* split precision, exact-fp32 MFMA on request: pzn_gemm_set_precision)       */
 /* ------------------------------------------------------------------------ */
 
 /* nn.Linear as used throughout model5_b.py (e.g. :417-422, :559-599):
@@ -374,6 +375,34 @@ int pzn_maxpool_points_bwd_f32(const float* dout, const int32_t* idx, int B, int
 int pzn_se3_exp_fwd_f32(const float* twist, int B, float* g, pzn_stream_t stream);
 int pzn_se3_exp_bwd_f32(const float* twist, const float* dg, int B, float* dtwist,
                         pzn_stream_t stream);
+
+/* se3.transform on points (se_math/se3.py:110-120 as model5_b.py:948-952, :1116 use it): out[b,n,:] = R_b p[b,n,:] + t_b
+ * with g[B,4,4] = [[R, t], [0 0 0 1]] and p[B,N,3].  bwd: dp[B,N,3] = R^T dout (may be NULL), dg[B,4,4] (may be NULL;
+ * overwritten: dR = sum_n dout p^T, dt = sum_n dout, last row 0). */
+int pzn_se3_transform_fwd_f32(const float* g, const float* p, int B, int N, float* out, pzn_stream_t stream);
+int pzn_se3_transform_bwd_f32(const float* g, const float* p, const float* dout, int B, int N, float* dp,
+                              float* dg, pzn_stream_t stream);
+/* TouchedRegraster.comp (model5_b.py:1512-1519): loss[0] = 16 * mean((g igt - I)^2) over [B,4,4];
+ * bwd: dg[B,4,4] = dloss[0] * d loss / d g (igt is data). */
+int pzn_comp_fwd_f32(const float* g, const float* igt, int B, float* loss, pzn_stream_t stream);
+int pzn_comp_bwd_f32(const float* g, const float* igt, const float* dloss, int B, float* dg, pzn_stream_t stream);
+/* Boundary head losses (model5_b.py:1063-1064 F.cross_entropy(logits[B,2,N], labels) with mean reduction, and :1085-1090
+ * softmax(logits, dim=1)[:, 1, :]): labels[B,N] hold 0 / 1 as floats (dataset.py:1363-1366).  fwd: prob1[B,N] (class-1
+ * probability, what the top-128 selection ranks by), loss[0] (overwritten).  bwd: dlogits[B,2,N] = dloss[0] * d loss / d logits. */
+int pzn_boundary_ce_fwd_f32(const float* logits, const float* labels, int B, int N, float* prob1, float* loss,
+                            pzn_stream_t stream);
+int pzn_boundary_ce_bwd_f32(const float* logits, const float* labels, const float* dloss, int B, int N,
+                            float* dlogits, pzn_stream_t stream);
+/* torch.topk(x[R,N], K, dim=1)[1] (model5_b.py:1089-1091): indices of the K largest entries of every row, value
+ * descending, equal values by ascending index.  K <= 256, N <= 16384 (PZN_EUNSUPPORTED beyond). */
+int pzn_topk_rows_f32(const float* x, int R, int N, int K, int64_t* idx, pzn_stream_t stream);
+/* (((a + b) + c) + d) / 4 elementwise (model5_b.py:468-469: the mean of the four attention maps); n % 4 == 0, 16-byte
+ * aligned pointers (PZN_EUNSUPPORTED otherwise). */
+int pzn_avg4_f32(const float* a, const float* b, const float* c, const float* d, size_t n, float* out,
+                 pzn_stream_t stream);
+/* a[B,R,C] -> mean[B,C] = a.mean(dim=1) and arg[B] = index of its largest entry (the lowest on ties): model5_b.py:937-942,
+ * `x2[:, topk(attention.mean(dim=1), 32)[1][:, 0]]` needs only the first of the 32.  C <= 1024. */
+int pzn_colmean_argmax_f32(const float* a, int B, int R, int C, float* mean, int64_t* arg, pzn_stream_t stream);
 
 /* torch.optim.Adam step (model5_b.py:1453-1457: Adam(lr), no weight decay, no amsgrad) over flat
  * buffers of n floats: param, exp_avg, exp_avg_sq updated in place from grad; step = 1, 2, ...

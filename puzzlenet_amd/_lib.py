@@ -61,6 +61,15 @@ SIGNATURES = {
     "pzn_maxpool_points_bwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_se3_exp_fwd_f32": (_c_i, [_c_f, _c_i, _c_f, _c_f]),
     "pzn_se3_exp_bwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_f, _c_f]),
+    "pzn_se3_transform_fwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_f, _c_f]),
+    "pzn_se3_transform_bwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_comp_fwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_f, _c_f]),
+    "pzn_comp_bwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_f, _c_f]),
+    "pzn_boundary_ce_fwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_boundary_ce_bwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_f, _c_f]),
+    "pzn_topk_rows_f32": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
+    "pzn_avg4_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, ctypes.c_size_t, _c_f, _c_f]),
+    "pzn_colmean_argmax_f32": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_adam_step_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, _c_i, _c_f]),
     "pzn_bn_points_relu_fwd_f32": (_c_i, [_c_f] * 5 + [_c_i, _c_fl, _c_fl, _c_i, _c_i, _c_i] + [_c_f] * 4),

@@ -32,6 +32,7 @@ SOURCES = [
     ("se3.hip", []),
     ("sapoint.hip", []),
     ("bnpoints.hip", []),
+    ("losstail.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]

@@ -15,11 +15,14 @@
 //
 // Data layout: points are repacked once per call to float4 {x, y, z, weight}
 // where `weight` is the per-point state the NEXT pass multiplies by
-// (remainR / ratioL / ratioR).  The inner loop of each pass walks the OTHER
-// cloud with a wave-uniform index, so those float4 come through the scalar
-// cache (s_load_dwordx4..x16) and feed the VALU as SGPR operands: no LDS, no
-// bank conflicts, ~10 VALU issues per (k,l) pair: 3 sub, 3 mul/fma, 1 mul,
-// v_exp_f32, 1-2 fma.
+// (remainR / ratioL / ratioR).  A workgroup = 4 wavefronts that own the SAME 64
+// rows; the OTHER cloud is staged through LDS in 512-point tiles as a pair-SoA
+// image {x0,x1,y0,y1}{z0,z1,w0,w1}, every wavefront walks a quarter of each tile
+// with a wave-uniform index (broadcast ds_read_b128) and packed fp32 arithmetic
+// (v_pk_add / v_pk_mul / v_pk_fma: two (k,l) pairs per instruction), and the four
+// partial sums meet through LDS.  (The first version fed the walked points to the
+// VALU as SGPR operands through the scalar cache; that cache thrashed at ~10
+// cycles per VALU issue.)
 //
 // Pass structure per level (emd_kernel.cu line numbers):
 //   A (:51-84)   ratioL_k  = remainL_k / (1e-9 + sum_l e_kl remainR_l)

@@ -1,9 +1,10 @@
 """Dense pieces of the encoder / heads / loss tail: the functional forms the model calls.
 
-All four run as hand-written gfx950 kernels behind the C ABI (include/pzn.h):
-  linear          nn.Linear (+bias +ReLU) fwd / dgrad / wgrad       exact-fp32 MFMA tile engine (csrc/gemm.hip)
-  shared_mlp_max  two shared-MLP layers + max over the K=32 axis    same engine, max-pool as a register epilogue
-  attention       softmax(q k^T / sqrt(dk)) v, returns the map too  batched engine + wave-per-row softmax
+All run as hand-written gfx950 kernels behind the C ABI (include/pzn.h); results are fp32, the matrix-core operand path
+is bf16x3 split precision by default (exact-fp32 MFMA on request, pzn_gemm_set_precision):
+  linear          nn.Linear (+bias +ReLU) fwd / dgrad / wgrad       weight-stationary / direct-fragment / tile kernels
+  shared_mlp_max  two shared-MLP layers + max over the K=32 axis    max-pool as a register epilogue
+  attention       softmax(q k^T / sqrt(dk)) v, returns the map too  batched tile engine + wave-per-row softmax
   chamfer         min-both-ways of |a|^2+|b|^2-2ab without P[B,n,m] csrc/chamfer.hip
 """
 from . import ops

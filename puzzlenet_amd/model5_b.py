@@ -166,8 +166,11 @@ class PCTransformer_nonsort(nn.Module):
         att2, attention2 = self.atten2(att1)
         att3, attention3 = self.atten3(att2)
         att4, attention4 = self.atten4(att3)
-        attention = attention1 + attention2 + attention3 + attention4
-        attention = attention / 4
+        if attention1.is_cuda:
+            attention = ops.avg4(attention1, attention2, attention3, attention4)     # :468-469, one launch
+        else:
+            attention = attention1 + attention2 + attention3 + attention4
+            attention = attention / 4
         att = torch.cat([att1, att2, att3, att4, f2f], dim=-1)       # (:466, :470 as one copy instead of two)
         out = dense.linear(att, self.out.weight, self.out.bias)                                   # :474
         f_global = ops.max_over_points(out)                                                       # :475
@@ -333,6 +336,8 @@ class TouchedRegraster(_Base):
         assert g.size(0) == igt.size(0)
         assert g.size(1) == igt.size(1) and g.size(1) == 4
         assert g.size(2) == igt.size(2) and g.size(2) == 4
+        if g.is_cuda and g.dtype == torch.float32:
+            return ops.comp_loss(g, igt.to(g))        # one launch each way (csrc/losstail.hip)
         A = g.matmul(igt)
         I = torch.eye(4, dtype=A.dtype, device=A.device).view(1, 4, 4).repeat(A.size(0), 1, 1)
         return F.mse_loss(A, I, reduction='mean') * 16
@@ -363,7 +368,7 @@ class TouchedRegraster(_Base):
 
         def pose_hook(o):
             pose['mat'] = se3.exp(o).to(mrpc)                                       # :947
-            pose['de_mrpc'] = se3.transform(pose['mat'], mrpc.permute(0, 2, 1)).permute(0, 2, 1)
+            pose['de_mrpc'] = se3.transform_points(pose['mat'], mrpc)               # :948-952 (transform of the transposed view)
             if _EMD_SIDE == 1:
                 fork_emd(o)
 
@@ -372,10 +377,14 @@ class TouchedRegraster(_Base):
         if _EMD_SIDE == 2:
             fork_emd(out)
 
-        att1 = attention.mean(dim=1)                                                # :937-942
-        att2 = mrpc_attention.mean(dim=1)
-        x2att1 = x2[:, torch.topk(att1, 32)[1][:, 0]]
-        x2att2 = mrpc_x2[:, torch.topk(att2, 32)[1][:, 0]]
+        if attention.is_cuda:      # :937-942: only the FIRST of the 32 top-k indices is used: mean over rows + arg-max, one launch
+            x2att1 = x2[:, ops.colmean_argmax(attention)[1]]
+            x2att2 = mrpc_x2[:, ops.colmean_argmax(mrpc_attention)[1]]
+        else:
+            att1 = attention.mean(dim=1)
+            att2 = mrpc_attention.mean(dim=1)
+            x2att1 = x2[:, torch.topk(att1, 32)[1][:, 0]]
+            x2att2 = mrpc_x2[:, torch.topk(att2, 32)[1][:, 0]]
 
         mat, de_mrpc = pose['mat'], pose['de_mrpc']                                 # :947-952 (computed in pose_hook)
         R = mat[:, :3, :3]
@@ -387,10 +396,8 @@ class TouchedRegraster(_Base):
         else:
             loss_recoversy = torch.mean(dg_mrpc_dist1) + torch.mean(dg_mrpc_dist2)
 
-        g = torch.eye(4, dtype=R.dtype, device=R.device).unsqueeze(0).repeat(R.shape[0], 1, 1)   # :963-967
-        g[:, :3, :3] = R
-        g[:, :3, 3] = t
-        loss_g = self.comp(g, igt)
+        # :963-967 rebuild g from R and t: mat already IS [[R, t], [0 0 0 1]] (se3.exp), so comp takes it as it stands
+        loss_g = self.comp(mat, igt)
         self.log('train/loss_re', loss_recoversy)
         self.log('train/loss_g', loss_g)
 
@@ -408,23 +415,30 @@ class TouchedRegraster(_Base):
         emd2 = torch.sum(emd2)                                                      # :1033
         self.log('train_emd2', emd2)
 
-        loss_fpcb_cel = F.cross_entropy(de_fpcb, fpc_idx.squeeze().long())          # :1063-1064
-        loss_rpcb_cel = F.cross_entropy(de_mrpcb, rpc_idx.squeeze().long())
+        if de_fpcb.is_cuda:
+            # :1063-1064 cross entropy and :1085-1090 class-1 probability in one launch per head, :1089-1091 top-128 as
+            # one radix-select launch per head (csrc/losstail.hip)
+            loss_fpcb_cel, de_fpcb_idx_sig = ops.boundary_ce(de_fpcb, fpc_idx.reshape(batch_size, N))
+            loss_rpcb_cel, de_mrpcb_idx_sig = ops.boundary_ce(de_mrpcb, rpc_idx.reshape(batch_size, N))
+            de_fpcb_idx = ops.topk_rows(de_fpcb_idx_sig, 128)
+            de_mrpcb_idx = ops.topk_rows(de_mrpcb_idx_sig, 128)
+        else:
+            loss_fpcb_cel = F.cross_entropy(de_fpcb, fpc_idx.squeeze().long())      # :1063-1064
+            loss_rpcb_cel = F.cross_entropy(de_mrpcb, rpc_idx.squeeze().long())
+            de_fpcb_idx_sig = torch.softmax(de_fpcb, dim=1)[:, 1, :]                # :1085-1091
+            de_fpcb_idx = torch.topk(de_fpcb_idx_sig, 128, 1)[1]
+            de_mrpcb_idx_sig = torch.softmax(de_mrpcb, dim=1)[:, 1, :]
+            de_mrpcb_idx = torch.topk(de_mrpcb_idx_sig, 128, 1)[1]
         self.log('train/loss_fpcb_cel', loss_fpcb_cel)
         self.log('train/loss_rpcb_cel', loss_rpcb_cel)
 
-        de_fpcb_idx_sig = torch.softmax(de_fpcb, dim=1)[:, 1, :]                    # :1085-1091
-        de_fpcb_idx = torch.topk(de_fpcb_idx_sig, 128, 1)[1]
-        de_mrpcb_idx_sig = torch.softmax(de_mrpcb, dim=1)[:, 1, :]
-        de_mrpcb_idx = torch.topk(de_mrpcb_idx_sig, 128, 1)[1]
-
         with torch.no_grad():                                                       # :1094-1105 (IoU, logged only)
-            pred_1_fpc = torch.zeros_like(fpc_idx).scatter(1, de_fpcb_idx, 1)
-            pred_1_mrpc = torch.zeros_like(fpc_idx).scatter(1, de_mrpcb_idx, 1)
-            fpc_iou = torch.sum(torch.logical_and(pred_1_fpc, fpc_idx)).float() / \
-                torch.sum(torch.logical_or(pred_1_fpc, fpc_idx)).float()
-            mrpcb_iou = torch.sum(torch.logical_and(pred_1_mrpc, rpc_idx)).float() / \
-                torch.sum(torch.logical_or(pred_1_mrpc, rpc_idx)).float()
+            # |pred AND gt| = the labels gathered at the 128 picks; |pred OR gt| = 128 per cloud + |gt| - |pred AND gt|
+            def _iou(idx, gt):
+                inter = torch.gather(gt, 1, idx).sum()
+                return inter / (float(idx.numel()) + gt.sum() - inter)
+            fpc_iou = _iou(de_fpcb_idx, fpc_idx)
+            mrpcb_iou = _iou(de_mrpcb_idx, rpc_idx)
         self.log('train/fpc_iou', fpc_iou)
         self.log('train/mrpcb_iou', mrpcb_iou)
 
@@ -434,7 +448,7 @@ class TouchedRegraster(_Base):
         cd_fpcb1, cd_fpcb2 = self.chamfer_loss(de_fpcb_pts, fpcb)                   # :1112-1113
         loss_fpcb = torch.mean(cd_fpcb1) + torch.mean(cd_fpcb2)
         self.log('train/loss_fpcb', loss_fpcb)
-        inverse_de_mrpcb = se3.transform(se3.exp(out).to(mrpc), de_mrpcb_pts.permute(0, 2, 1)).permute(0, 2, 1)  # :1116
+        inverse_de_mrpcb = se3.transform_points(se3.exp(out).to(mrpc), de_mrpcb_pts)      # :1116
         cd_mrpcb1, cd_mrpcb2 = self.chamfer_loss(inverse_de_mrpcb, rpcb)            # :1119-1120
         loss_mrpcb = torch.mean(cd_mrpcb1) + torch.mean(cd_mrpcb2)
         self.log('train/loss_rpcb', loss_mrpcb)

@@ -214,6 +214,142 @@ class _Se3Exp(torch.autograd.Function):
         return dx
 
 
+class _Se3Transform(torch.autograd.Function):
+    """se3.transform (se_math/se3.py:110-120) on points: out[b,n,:] = R_b p[b,n,:] + t_b, one launch each way."""
+
+    @staticmethod
+    def forward(ctx, g, p):
+        g, p = _f32(g, "g"), _f32(p, "points")
+        B, N, _ = p.shape
+        out = torch.empty_like(p)
+        with torch.cuda.device(p.device):
+            _call("pzn_se3_transform_fwd_f32", _p(g), _p(p), B, N, _p(out), _stream())
+        ctx.save_for_backward(g, p)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g, p = ctx.saved_tensors
+        B, N, _ = p.shape
+        dout = _f32(dout, "dout")
+        dg = torch.empty_like(g) if ctx.needs_input_grad[0] else None
+        dp = torch.empty_like(p) if ctx.needs_input_grad[1] else None
+        if dg is None and dp is None:
+            return None, None
+        with torch.cuda.device(p.device):
+            _call("pzn_se3_transform_bwd_f32", _p(g), _p(p), _p(dout), B, N, _p(dp), _p(dg), _stream())
+        return dg, dp
+
+
+def se3_transform_points(g, p):
+    """g [B,4,4], p [B,N,3] on the GPU -> [B,N,3]"""
+    if g.dim() != 3 or p.dim() != 3 or g.shape[0] != p.shape[0] or p.shape[2] != 3 or tuple(g.shape[1:]) != (4, 4):
+        raise _lib.PznError(f"se3_transform_points expects g[B,4,4], p[B,N,3]; got {tuple(g.shape)}, {tuple(p.shape)}")
+    return _Se3Transform.apply(g, p)
+
+
+class _CompLoss(torch.autograd.Function):
+    """TouchedRegraster.comp (model5_b.py:1512-1519): 16 * mean((g igt - I)^2), one launch each way."""
+
+    @staticmethod
+    def forward(ctx, g, igt):
+        g, igt = _f32(g, "g"), _f32(igt, "igt")
+        loss = torch.empty((1,), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _call("pzn_comp_fwd_f32", _p(g), _p(igt), g.shape[0], _p(loss), _stream())
+        ctx.save_for_backward(g, igt)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        g, igt = ctx.saved_tensors
+        dl = _f32(dloss, "dloss").reshape(1)
+        dg = torch.empty_like(g)
+        with torch.cuda.device(g.device):
+            _call("pzn_comp_bwd_f32", _p(g), _p(igt), _p(dl), g.shape[0], _p(dg), _stream())
+        return dg, None
+
+
+def comp_loss(g, igt):
+    return _CompLoss.apply(g, igt)
+
+
+class _BoundaryCE(torch.autograd.Function):
+    """F.cross_entropy(logits[B,2,N], labels[B,N]) (model5_b.py:1063-1064) together with softmax(logits, 1)[:, 1, :]
+    (:1085-1090) -> (loss, prob1); prob1 only feeds the (non-differentiable) top-128 selection."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logits, labels = _f32(logits, "logits"), _f32(labels, "labels")
+        B, C, N = logits.shape
+        if C != 2 or tuple(labels.shape) != (B, N):
+            raise _lib.PznError(f"boundary_ce expects logits[B,2,N], labels[B,N]; got {tuple(logits.shape)}, {tuple(labels.shape)}")
+        prob1 = torch.empty((B, N), dtype=torch.float32, device=logits.device)
+        loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+        with torch.cuda.device(logits.device):
+            _call("pzn_boundary_ce_fwd_f32", _p(logits), _p(labels), B, N, _p(prob1), _p(loss), _stream())
+        ctx.save_for_backward(logits, labels)
+        ctx.mark_non_differentiable(prob1)
+        return loss.reshape(()), prob1
+
+    @staticmethod
+    def backward(ctx, dloss, _dprob):
+        logits, labels = ctx.saved_tensors
+        B, _, N = logits.shape
+        dl = _f32(dloss, "dloss").reshape(1)
+        dlogits = torch.empty_like(logits)
+        with torch.cuda.device(logits.device):
+            _call("pzn_boundary_ce_bwd_f32", _p(logits), _p(labels), _p(dl), B, N, _p(dlogits), _stream())
+        return dlogits, None
+
+
+def boundary_ce(logits, labels):
+    """-> (cross-entropy loss, class-1 probability [B,N])"""
+    return _BoundaryCE.apply(logits, labels)
+
+
+def topk_rows(x, k):
+    """torch.topk(x, k, dim=1)[1] for x[R,N] on the GPU (value descending, ties by ascending index)."""
+    x = _f32(x.detach(), "x")
+    R, N = x.shape
+    idx = torch.empty((R, int(k)), dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        _call("pzn_topk_rows_f32", _p(x), R, N, int(k), _p(idx), _stream())
+    return idx
+
+
+class _Avg4(torch.autograd.Function):
+    """(((a + b) + c) + d) / 4 (model5_b.py:468-469) in one launch."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, d):
+        a, b, c, d = (_f32(t, "map") for t in (a, b, c, d))
+        out = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            _call("pzn_avg4_f32", _p(a), _p(b), _p(c), _p(d), a.numel(), _p(out), _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = dout / 4
+        return g, g, g, g
+
+
+def avg4(a, b, c, d):
+    return _Avg4.apply(a, b, c, d)
+
+
+def colmean_argmax(a):
+    """a[B,R,C] on the GPU -> (a.mean(dim=1) [B,C], index of its largest entry [B] int64); no gradient (it feeds an index)."""
+    a = _f32(a.detach(), "a")
+    B, R, C = a.shape
+    mean = torch.empty((B, C), dtype=torch.float32, device=a.device)
+    arg = torch.empty((B,), dtype=torch.int64, device=a.device)
+    with torch.cuda.device(a.device):
+        _call("pzn_colmean_argmax_f32", _p(a), B, R, C, _p(mean), _p(arg), _stream())
+    return mean, arg
+
+
 def se3_exp(x):
     """[B,6] on the GPU -> [B,4,4]"""
     return _Se3Exp.apply(x)

@@ -62,8 +62,22 @@ def exp(x):
     return g.view(*(x.size()[0:-1]), 4, 4)
 
 
+def transform_points(g, pts):
+    """g [B,4,4], pts [B,N,3] -> R pts + p, i.e. transform(g, pts^T)^T without the two transposes: one HIP launch each
+    way on the GPU (csrc/losstail.hip), the tensor form of `transform` otherwise."""
+    if pts.is_cuda and pts.dtype == torch.float32 and g.dim() == 3 and pts.dim() == 3:
+        from . import ops
+        return ops.se3_transform_points(g.to(pts), pts)
+    return transform(g, pts.transpose(-1, -2)).transpose(-1, -2)
+
+
 def transform(g, a):
     """g [*,4,4], a [*,3,N] (or [*,3]) -> R a + p  (se3.py:110-120)"""
+    if a.is_cuda and a.dtype == torch.float32 and g.dim() == 3 and a.dim() == 3 and a.shape[1] == 3 \
+            and a.transpose(1, 2).is_contiguous():
+        # the caller's a is a [B,N,3] point tensor seen as [B,3,N] (model5_b.py:948-952): same kernel, no copies
+        from . import ops
+        return ops.se3_transform_points(g.to(a), a.transpose(1, 2)).transpose(1, 2)
     g_ = g.view(-1, 4, 4)
     R = g_[:, 0:3, 0:3].contiguous().view(*(g.size()[0:-2]), 3, 3)
     p = g_[:, 0:3, 3].contiguous().view(*(g.size()[0:-2]), 3)
