@@ -262,17 +262,18 @@ def main():
             return n / prof_steps, ms / prof_steps
 
         # (1) `roofline`: ONE named kernel, the largest single matrix-core launch of the step: ws_gemm_kernel in its
-        #     max-pool variant (pzn_linear_maxpool_fwd_f32: second shared-MLP layer + ReLU + max over the 32 neighbours,
-        #     model5_b.py:453-454 / :460-461; 4 launches per step).  It issues v_mfma_f32_32x32x16_bf16 six times per
+        #     max-pool variant (pzn_sa_level_fwd_f32: second shared-MLP layer + ReLU + max over the 32 neighbours on the
+        #     generated rows of the first, model5_b.py:452-454 / :459-461; 4 launches per step).  It issues v_mfma_f32_32x32x16_bf16 six times per
         #     fp32 product, so it is priced against the bf16 pipe / 6, with the fp32-input MFMA rate beside it.
-        n_mp, ms_mp = per_step("pzn_linear_maxpool_fwd_f32")
-        fl_mp = kern_flops.get("pzn_linear_maxpool_fwd_f32", 0) / prof_steps
+        mp_entry = "pzn_sa_level_fwd_f32" if "pzn_sa_level_fwd_f32" in kern else "pzn_linear_maxpool_fwd_f32"
+        n_mp, ms_mp = per_step(mp_entry)
+        fl_mp = kern_flops.get(mp_entry, 0) / prof_steps
         mp_ach = fl_mp / (ms_mp * 1e-3) / 1e12 if ms_mp > 0 else 0.0
         mp_traffic, mp_src = pmc_traffic("ws_gemm_maxpool_bytes_per_step", B, N)
         roofline = {
             "bound": "mfma",
-            "kernel": "ws_gemm_kernel<4, true, ...> (csrc/wsgemm.hip, weight-stationary bf16x3 kernel, max-pool epilogue) behind "
-                      "pzn_linear_maxpool_fwd_f32",
+            "kernel": "ws_gemm_kernel<NT, MAXPOOL=true, ..., GATH> (csrc/wsgemm.hip: weight-stationary bf16x3 kernel, max-pool epilogue; "
+                      "GATH: the first layer's rows relu(P'[idx] + Q) are generated in its operand loader) behind " + mp_entry,
             "achieved": mp_ach, "peak": MFMA_X3_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mp_ach / MFMA_X3_PEAK_TFLOPS,
             "traffic": mp_traffic, "traffic_source": mp_src,
             "peak_note": "dense bf16 MFMA rate (2500 TFLOP/s) / 6 issued bf16 MFMAs per fp32 product; against the fp32-input "
@@ -340,8 +341,9 @@ def main():
         g_ach = g_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
         g_traffic, g_src = pmc_traffic("sa_gather_stage_bytes_per_step", B, N)
         roofline_sa_gather = {
-            "bound": "hbm", "kernel": "sa_point_l1_fwd_kernel / sa_point_l1_bwd_kernel (pzn_sa_point_l1_{fwd,bwd}_f32: first "
-                                      "set-abstraction layer as a gather of per-point rows / a sum over inverse neighbour lists)",
+            "bound": "hbm", "kernel": "sa_point_l1_bwd_kernel (pzn_sa_point_l1_bwd_f32: the per-point sums of dh over inverse neighbour "
+                                      "lists)" + (" + sa_point_l1_fwd_kernel (rows written: PZN_SA_FUSED=0)" if n_gf else
+                                                  "; the forward writes no rows any more (generated inside the matrix-core kernel)"),
             "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g_ach / HBM_PEAK_GBS,
             "traffic": g_traffic, "traffic_source": g_src,
             "algorithmic_bytes_per_step": g_bytes,

@@ -305,6 +305,26 @@ int pzn_pooled_layer_bwd_f32(const float* dout, const int32_t* argmax, const flo
                              const float* W2, const float* h, int R, int C1, int C2, float* dh,
                              float* dW2, float* db2, int accumulate, pzn_stream_t stream);
 
+/* The same level with the first layer's rows NEVER in memory (what model5_b's encoder runs by default).  The coordinate
+ * term is split:  W1[:,0:3] (xyz[j] - centre) = W1[:,0:3] xyz[j] - W1[:,0:3] centre,  so with
+ *   Pp[B*N, C1] = feat W1[:,3:]^T + W1[:,0:3] xyz      (pzn_linear_fwd_f32, then pzn_sa_prep_f32 adds the xyz term in place)
+ *   Q [B*S, C1] = b1 - W1[:,0:3] new_xyz                (pzn_sa_prep_f32)
+ * a grouped row of the first layer is relu(Pp[idx] + Q[group]) — generated inside the operand loader of the
+ * weight-stationary matrix-core kernel (fwd) and inside both sparse backward passes; same result as the forms above up to
+ * the order of the fp32 sum.  K = 32, C1 % 128 == 0 backward (C1 % 32 == 0 forward), C2 in {64,128,256}.
+ *   fwd:  out[B*S, C2] = max_k relu(relu(Pp[idx[.,k]] + Q) W2^T + b2), argmax[B*S, C2]
+ *   bwd:  dh[B*S*32, C1] (ReLU-masked gradient of the generated rows, written for pzn_sa_point_l1_bwd_f32 — called with
+ *         new_xyz = NULL: the factor of dW1[:,0:3] is then the point itself), dW2 / db2 (overwritten, or added to when
+ *         accumulate), and dW1[:,0:3] -= dq^T new_xyz, db1 += column sums of dq, dq[g] = sum_k dh[g,k] (ADDED to). */
+int pzn_sa_prep_f32(const float* xyz, const float* new_xyz, const float* W1, const float* b1, int B, int N, int S,
+                    int D, int C1, float* P, float* Q, pzn_stream_t stream);
+int pzn_sa_level_fwd_f32(const float* Pp, const float* Q, const int64_t* idx, const float* W2, const float* b2,
+                         int B, int N, int S, int C1, int C2, float* out, int32_t* argmax, pzn_stream_t stream);
+int pzn_sa_level_bwd_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
+                         const float* Pp, const float* Q, const int64_t* idx, const float* new_xyz, int B, int N,
+                         int S, int D, int C1, int C2, float* dh, float* dW2, float* db2, float* dW1, float* db1,
+                         int accumulate, pzn_stream_t stream);
+
 /* relu(BatchNorm1d(num_points)(x)) of the per-point feature MLP (model5_b.py:424, :447-448): x[B,N,C], the BN
  * "channel" axis is the POINT index, statistics over the B*C values of a point.  training != 0: batch statistics
  * (biased variance), running_mean / running_var updated in place as torch does (momentum, unbiased variance; may be
@@ -401,8 +421,11 @@ int pzn_topk_rows_f32(const float* x, int R, int N, int K, int64_t* idx, pzn_str
 int pzn_avg4_f32(const float* a, const float* b, const float* c, const float* d, size_t n, float* out,
                  pzn_stream_t stream);
 /* a[B,R,C] -> mean[B,C] = a.mean(dim=1) and arg[B] = index of its largest entry (the lowest on ties): model5_b.py:937-942,
- * `x2[:, topk(attention.mean(dim=1), 32)[1][:, 0]]` needs only the first of the 32.  C <= 1024. */
-int pzn_colmean_argmax_f32(const float* a, int B, int R, int C, float* mean, int64_t* arg, pzn_stream_t stream);
+ * `x2[:, topk(attention.mean(dim=1), 32)[1][:, 0]]` needs only the first of the 32.  C <= 1024; workspace of
+ * pzn_colmean_workspace_bytes(B, C) bytes (partial column sums, fixed summation order). */
+size_t pzn_colmean_workspace_bytes(int B, int C);
+int pzn_colmean_argmax_f32(const float* a, int B, int R, int C, float* mean, int64_t* arg, void* workspace,
+                           pzn_stream_t stream);
 
 /* torch.optim.Adam step (model5_b.py:1453-1457: Adam(lr), no weight decay, no amsgrad) over flat
  * buffers of n floats: param, exp_avg, exp_avg_sq updated in place from grad; step = 1, 2, ...

@@ -69,11 +69,15 @@ SIGNATURES = {
     "pzn_boundary_ce_bwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_f, _c_f]),
     "pzn_topk_rows_f32": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_avg4_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, ctypes.c_size_t, _c_f, _c_f]),
-    "pzn_colmean_argmax_f32": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_colmean_workspace_bytes": (_c_sz, [_c_i, _c_i]),
+    "pzn_colmean_argmax_f32": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f]),
     "pzn_adam_step_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, _c_i, _c_f]),
     "pzn_bn_points_relu_fwd_f32": (_c_i, [_c_f] * 5 + [_c_i, _c_fl, _c_fl, _c_i, _c_i, _c_i] + [_c_f] * 4),
     "pzn_bn_points_relu_bwd_f32": (_c_i, [_c_f] * 6 + [_c_i] * 4 + [_c_f] * 4),
+    "pzn_sa_prep_f32": (_c_i, [_c_f] * 4 + [_c_i] * 5 + [_c_f] * 3),
+    "pzn_sa_level_fwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 5 + [_c_f] * 3),
+    "pzn_sa_level_bwd_f32": (_c_i, [_c_f] * 8 + [_c_i] * 6 + [_c_f] * 5 + [_c_i, _c_f]),
     "pzn_sa_point_l1_fwd_f32": (_c_i, [_c_f] * 6 + [_c_i] * 5 + [_c_f, _c_f]),
     "pzn_knn_inverse_lists": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f]),
     "pzn_sa_point_l1_bwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 5 + [_c_f] * 4),

@@ -1232,6 +1232,39 @@ PZN_EXPORT int pzn_sa_pooled_layer_bwd_f32(const float* dout, const int32_t* arg
   return pool_layer_bwd(dout, argmax, out, W2, h, B * S, C1, C2, dh, dW2, db2, accumulate, stream, &gs);
 }
 
+// Set-abstraction level with the first layer per point AND never in memory (model5_b.py:449-454 / :456-461): the
+// activation rows relu(Pp[idx] + Q[g]) are generated inside the matrix-core kernel's operand loader (wsgemm.hip, GATH).
+//   Pp[B*N, C1] = feat W1[:,3:]^T + W1[:,0:3] xyz,  Q[B*S, C1] = b1 - W1[:,0:3] new_xyz   (pzn_sa_prep_f32)
+//   out[B*S, C2] = max_k relu(relu(Pp[idx[., k]] + Q) W2^T + b2),  argmax[B*S, C2]
+PZN_EXPORT int pzn_sa_level_fwd_f32(const float* Pp, const float* Q, const int64_t* idx, const float* W2, const float* b2,
+                                    int B, int N, int S, int C1, int C2, float* out, int32_t* argmax,
+                                    pzn_stream_t stream) {
+  PZN_CHECK_ARG(Pp && Q && idx && W2 && out && argmax && B > 0 && N > 0 && S > 0 && C1 > 0 && C2 > 0);
+  PZN_CHECK_ARG((long)B * S * 32 < 2147483647L);
+  if (gemm_precision() == 0) return PZN_EUNSUPPORTED;      // (the exact-fp32 engine has no generated-operand loader)
+  return pzn_ws_gemm_gather_maxpool(Pp, Q, idx, W2, b2, B * S, N, S, C1, C2, out, argmax, pzn_hip_stream(stream));
+}
+
+// Backward of the pooled layer behind pzn_sa_level_fwd_f32: dh[B*S*32, C1] (the ReLU-masked gradient of the generated
+// rows: written, the per-point sum pzn_sa_point_l1_bwd_f32 reads it), dW2, db2 (overwritten, or added to when
+// accumulate), and what flows through Q: dW1[:, 0:3] -= dq^T new_xyz, db1 += column sums of dq (dq[g] = sum_k dh[g,k]);
+// dW1[C1, 3+D] and db1[C1] are ADDED to.  Both sparse passes regenerate the rows from Pp / Q / idx: h does not exist.
+PZN_EXPORT int pzn_sa_level_bwd_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
+                                    const float* Pp, const float* Q, const int64_t* idx, const float* new_xyz, int B,
+                                    int N, int S, int D, int C1, int C2, float* dh, float* dW2, float* db2, float* dW1,
+                                    float* db1, int accumulate, pzn_stream_t stream) {
+  PZN_CHECK_ARG(dout && argmax && out && W2 && Pp && Q && idx && new_xyz && dh && dW2 && db2 && dW1);
+  PZN_CHECK_ARG(B > 0 && N > 0 && S > 0 && D >= 0 && C1 > 0 && C2 > 0 && (long)B * N < 2147483647L);
+  if (!pzn_pool_bwd_supported(C1, C2, W2, nullptr, dh)) return PZN_EUNSUPPORTED;
+  hipStream_t st = pzn_hip_stream(stream);
+  if (!accumulate) {
+    if (pzn_zero_async(dW2, (size_t)C2 * C1, st) != PZN_OK) return PZN_ELAUNCH;
+    if (pzn_zero_async(db2, (size_t)C2, st) != PZN_OK) return PZN_ELAUNCH;
+  }
+  PznGateSource gs{Pp, idx, nullptr, new_xyz, nullptr, nullptr, 3 + D, N, S, Q, dW1, db1};
+  return pzn_pool_bwd_sparse(dout, argmax, out, W2, nullptr, dh, dW2, db2, B * S, C1, C2, st, &gs);
+}
+
 // Backward: dh_ws is [R*32, C1] scratch; dx may be NULL.  dW*, db* are overwritten.
 PZN_EXPORT int pzn_sharedmlp_max_bwd_f32(const float* x, const float* W1, const float* W2, const float* h,
                                          const float* out, const int32_t* argmax, const float* dout, int R, int C0,

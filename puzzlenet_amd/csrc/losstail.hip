@@ -277,17 +277,32 @@ __global__ __launch_bounds__(256) void avg4_kernel(const float4* __restrict__ a,
 }
 
 // ------------------------------------------------------------------------------------ column mean + argmax
-// a [B, R, C] -> mean[b, c] = (sum_r a[b, r, c]) / R;  arg[b] = first index of the largest mean.  One workgroup per b,
-// thread per column (C <= 1024).
-__global__ __launch_bounds__(1024) void colmean_argmax_kernel(const float* __restrict__ a, int R, int C,
+// a [B, R, C] -> mean[b, c] = (sum_r a[b, r, c]) / R;  arg[b] = first index of the largest mean.  Two launches so that
+// the 16.8 MB of a [64,256,256] map are read by 8 workgroups per cloud instead of one (108 -> ~15 us): partial column
+// sums of CM_CHUNKS row ranges (no atomics: the order of the sum is fixed), then one workgroup per b adds the partials
+// in order, divides, stores the mean and reduces the arg-max.  Thread per column (C <= 1024).
+constexpr int CM_CHUNKS = 8;
+
+__global__ __launch_bounds__(1024) void colsum_partial_kernel(const float* __restrict__ a, int R, int C,
+                                                              float* __restrict__ part) {
+  const int b = blockIdx.x, ch = blockIdx.y, c = threadIdx.x;
+  if (c >= C) return;
+  const int per = (R + CM_CHUNKS - 1) / CM_CHUNKS, r0 = ch * per, r1 = min(R, r0 + per);
+  const float* p = a + (size_t)b * R * C + c;
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += p[(size_t)r * C];
+  part[((size_t)b * CM_CHUNKS + ch) * C + c] = s;
+}
+
+__global__ __launch_bounds__(1024) void colmean_argmax_kernel(const float* __restrict__ part, int R, int C,
                                                               float* __restrict__ mean, int64_t* __restrict__ arg) {
   __shared__ float sv[16];
   __shared__ int si[16];
   const int b = blockIdx.x, c = threadIdx.x;
   float s = 0.f;
   if (c < C) {
-    const float* p = a + (size_t)b * R * C + c;
-    for (int r = 0; r < R; ++r) s += p[(size_t)r * C];
+#pragma unroll
+    for (int ch = 0; ch < CM_CHUNKS; ++ch) s += part[((size_t)b * CM_CHUNKS + ch) * C + c];
     s /= (float)R;
     mean[(size_t)b * C + c] = s;
   }
@@ -385,11 +400,18 @@ PZN_EXPORT int pzn_avg4_f32(const float* a, const float* b, const float* c, cons
   PZN_RETURN_LAUNCH_STATUS();
 }
 
-PZN_EXPORT int pzn_colmean_argmax_f32(const float* a, int B, int R, int C, float* mean, int64_t* arg, pzn_stream_t stream) {
-  PZN_CHECK_ARG(a && mean && arg && B > 0 && R > 0 && C > 0);
+PZN_EXPORT size_t pzn_colmean_workspace_bytes(int B, int C) {
+  return B > 0 && C > 0 ? sizeof(float) * (size_t)B * CM_CHUNKS * C : 0;
+}
+
+PZN_EXPORT int pzn_colmean_argmax_f32(const float* a, int B, int R, int C, float* mean, int64_t* arg, void* workspace,
+                                      pzn_stream_t stream) {
+  PZN_CHECK_ARG(a && mean && arg && workspace && B > 0 && B <= 65535 && R > 0 && C > 0);
   if (C > 1024) return PZN_EUNSUPPORTED;
   const int threads = ((C + 63) / 64) * 64;
-  hipLaunchKernelGGL(colmean_argmax_kernel, dim3((unsigned)B), dim3((unsigned)threads), 0, pzn_hip_stream(stream), a, R, C,
-                     mean, arg);
+  hipStream_t st = pzn_hip_stream(stream);
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)B, CM_CHUNKS), dim3((unsigned)threads), 0, st, a, R, C, part);
+  hipLaunchKernelGGL(colmean_argmax_kernel, dim3((unsigned)B), dim3((unsigned)threads), 0, st, part, R, C, mean, arg);
   PZN_RETURN_LAUNCH_STATUS();
 }

@@ -55,7 +55,17 @@ struct PoolBwdArgs {
   const float* gW1;       // [C1, gldw] (columns 0..2)
   const float* gb1;       // [C1] (may be NULL)
   int gldw, gN, gS;
+  // second form (pzn_sa_prep_f32): h[(g,k),:] = relu(gP[(g / gS) * gN + gidx[g*32+k], :] + gQ[g,:]).  WGRAD regenerates its
+  // rows from it (h == NULL); DGRAD its gate, and accumulates what flows through Q: gdW1x[c,0:3] -= dq[g,c] centre_g,
+  // gdb1[c] += dq[g,c], dq[g,:] = sum_k dh[(g,k),:]
+  const float* gQ;        // [G, C1]
+  float* gdW1x;           // [C1, gldw] or NULL
+  float* gdb1;            // [C1] or NULL
 };
+
+__device__ __forceinline__ float4 pb_add_relu(float4 a, float4 q) {
+  return make_float4(fmaxf(a.x + q.x, 0.f), fmaxf(a.y + q.y, 0.f), fmaxf(a.z + q.z, 0.f), fmaxf(a.w + q.w, 0.f));
+}
 
 template <int CPW>
 __global__ __launch_bounds__(PB_T) void pool_wgrad_kernel(PoolBwdArgs p) {
@@ -74,29 +84,48 @@ __global__ __launch_bounds__(PB_T) void pool_wgrad_kernel(PoolBwdArgs p) {
   // Two register sets = two groups in flight.  The loads are unconditional (group index clamped) and the
   // loop is unrolled by the two sets so that the compiler's vmcnt bookkeeping stays exact (a branch around
   // a load makes it fall back to vmcnt(0), i.e. to a prefetch distance of nothing).
-  float4 pa0, pa1, pb0, pb1;
+  float4 pa0, pa1, pb0, pb1, qa, qb;
   int ava, avb;
   float gva, gvb;
-#define PB_ISSUE(gg, x0, x1, av_, gv_)                                              \
+  // regenerated rows (p.gQ): the point indices of this thread's two rows, looked up one round ahead of the row loads
+  // they address (a dependent idx -> row chain inside one round would cost a memory latency per group)
+  int ja0 = 0, ja1 = 0, jb0 = 0, jb1 = 0;
+  const bool regen = p.gQ != nullptr;
+#define PB_IDX(gg, j0_, j1_)                                                         \
   do {                                                                              \
     const int g_ = (gg) < p.G ? (gg) : p.G - 1;                                     \
-    const float* hp = p.h + ((size_t)g_ * 32 + srow) * p.C1 + col0 + scol;          \
-    x0 = *reinterpret_cast<const float4*>(hp);                                      \
-    x1 = *reinterpret_cast<const float4*>(hp + (size_t)16 * p.C1);                  \
+    const int64_t* ip = p.gidx + (size_t)g_ * 32 + srow;                            \
+    j0_ = (int)ip[0], j1_ = (int)ip[16];                                            \
+  } while (0)
+#define PB_ISSUE(gg, x0, x1, q_, av_, gv_, j0_, j1_)                                \
+  do {                                                                              \
+    const int g_ = (gg) < p.G ? (gg) : p.G - 1;                                     \
+    if (regen) {                                                                    \
+      const size_t pb_ = (size_t)(g_ / p.gS) * p.gN;                                \
+      x0 = *reinterpret_cast<const float4*>(p.gP + (pb_ + j0_) * p.C1 + col0 + scol); \
+      x1 = *reinterpret_cast<const float4*>(p.gP + (pb_ + j1_) * p.C1 + col0 + scol); \
+      q_ = *reinterpret_cast<const float4*>(p.gQ + (size_t)g_ * p.C1 + col0 + scol); \
+    } else {                                                                        \
+      const float* hp = p.h + ((size_t)g_ * 32 + srow) * p.C1 + col0 + scol;        \
+      x0 = *reinterpret_cast<const float4*>(hp);                                    \
+      x1 = *reinterpret_cast<const float4*>(hp + (size_t)16 * p.C1);                \
+    }                                                                               \
     const size_t o = (size_t)g_ * p.C2 + ch;                                        \
     const int a = p.argmax[o];                                                      \
     const float go = p.out[o], gd = p.dout[o];                                      \
     av_ = a & 31;                                                                   \
     gv_ = (lane < CPW && go > 0.f) ? gd : 0.f;                                      \
   } while (0)
-#define PB_GROUP(buf, x0, x1, av_, gv_, gnext)                                      \
+#define PB_GROUP(buf, x0, x1, q_, av_, gv_, j0_, j1_, gnext)                        \
   do {                                                                              \
+    if (regen) x0 = pb_add_relu(x0, q_), x1 = pb_add_relu(x1, q_);                        \
     *reinterpret_cast<float4*>(&hbuf[buf][srow][scol]) = x0;                        \
     *reinterpret_cast<float4*>(&hbuf[buf][srow + 16][scol]) = x1;                   \
     const int av = av_;                                                             \
     const float gv = gv_;                                                           \
     __syncthreads(); /* one barrier per group: the tile two groups back is free again by construction */ \
-    PB_ISSUE(gnext, x0, x1, av_, gv_);                                              \
+    PB_ISSUE(gnext, x0, x1, q_, av_, gv_, j0_, j1_);  /* rows of gnext: their indices arrived a round ago */ \
+    if (regen) PB_IDX((gnext) + 2 * gs_, j0_, j1_);   /* indices for the round after */ \
     dbacc += gv;                                                                    \
     _Pragma("unroll") for (int c = 0; c < CPW; ++c) {                               \
       const int a = __builtin_amdgcn_readlane(av, c);                               \
@@ -106,15 +135,24 @@ __global__ __launch_bounds__(PB_T) void pool_wgrad_kernel(PoolBwdArgs p) {
     }                                                                               \
   } while (0)
   const int gs_ = gridDim.x;
-  PB_ISSUE((int)blockIdx.x, pa0, pa1, ava, gva);
-  PB_ISSUE((int)blockIdx.x + gs_, pb0, pb1, avb, gvb);
+  if (regen) {
+    PB_IDX((int)blockIdx.x, ja0, ja1);
+    PB_IDX((int)blockIdx.x + gs_, jb0, jb1);
+  }
+  PB_ISSUE((int)blockIdx.x, pa0, pa1, qa, ava, gva, ja0, ja1);
+  PB_ISSUE((int)blockIdx.x + gs_, pb0, pb1, qb, avb, gvb, jb0, jb1);
+  if (regen) {
+    PB_IDX((int)blockIdx.x + 2 * gs_, ja0, ja1);
+    PB_IDX((int)blockIdx.x + 3 * gs_, jb0, jb1);
+  }
   for (int g = blockIdx.x; g < p.G; g += 2 * gs_) {
-    PB_GROUP(0, pa0, pa1, ava, gva, g + 2 * gs_);
+    PB_GROUP(0, pa0, pa1, qa, ava, gva, ja0, ja1, g + 2 * gs_);
     if (g + gs_ >= p.G) break;
-    PB_GROUP(1, pb0, pb1, avb, gvb, g + 3 * gs_);
+    PB_GROUP(1, pb0, pb1, qb, avb, gvb, jb0, jb1, g + 3 * gs_);
   }
 #undef PB_GROUP
 #undef PB_ISSUE
+#undef PB_IDX
 
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {
@@ -141,14 +179,18 @@ __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
   __syncthreads();  // the only barrier: from here on every wavefront walks its own groups
 
   const int gw = blockIdx.x * (PD_T / 64) + wave, nw = gridDim.x * (PD_T / 64);
+  const bool qform = p.gQ != nullptr;      // h = relu(P'[idx] + Q[g]) (pzn_sa_prep_f32); else the round-1 expression
   float gwx0 = 0.f, gwy0 = 0.f, gwz0 = 0.f, gbb0 = 0.f, gwx1 = 0.f, gwy1 = 0.f, gwz1 = 0.f, gbb1 = 0.f;
-  if (p.gP) {  // first-layer xyz weights and bias of this lane's two columns
+  if (p.gP && !qform) {  // first-layer xyz weights and bias of this lane's two columns
     const int c = col0 + 2 * lane;
     gwx0 = p.gW1[(size_t)c * p.gldw], gwy0 = p.gW1[(size_t)c * p.gldw + 1], gwz0 = p.gW1[(size_t)c * p.gldw + 2];
     gwx1 = p.gW1[(size_t)(c + 1) * p.gldw], gwy1 = p.gW1[(size_t)(c + 1) * p.gldw + 1];
     gwz1 = p.gW1[(size_t)(c + 1) * p.gldw + 2];
     if (p.gb1) gbb0 = p.gb1[c], gbb1 = p.gb1[c + 1];
   }
+  // what flows through Q = b1 - W1x centre: sums over this wave's groups, met in LDS at the end (one set of atomics per
+  // workgroup): dW1x[c, :] -= dq[g, c] centre_g, db1[c] += dq[g, c]
+  v2f sq_b = v2f{0.f, 0.f}, sq_x = sq_b, sq_y = sq_b, sq_z = sq_b;
   int av_n[NQ];
   float gv_n[NQ];
 #define PD_PREFETCH(gg)                                             \
@@ -169,23 +211,32 @@ __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
     for (int q = 0; q < NQ; ++q) av[q] = av_n[q], gv[q] = gv_n[q];
     if (g + nw < p.G) PD_PREFETCH(g + nw);
     const size_t row0 = ((size_t)g * 32) * p.C1 + col0 + 2 * lane;
-    // regenerated gate: lane l (mod 32) fetches row l's point and centre offset once per group
+    // regenerated gate: lane l (mod 32) fetches row l's point (and centre offset) once per group
     int gprow = 0;
     float gdx = 0.f, gdy = 0.f, gdz = 0.f;
+    v2f qv = v2f{0.f, 0.f};
+    float cgx = 0.f, cgy = 0.f, cgz = 0.f;
     if (p.gP) {
       const int rl = lane & 31;
       const long b = g / p.gS;
       const int j = (int)p.gidx[(size_t)g * 32 + rl];
-      const float* pq = p.gxyz + ((size_t)b * p.gN + j) * 3;
-      const float* c = p.gnew + (size_t)g * 3;
-      gdx = pq[0] - c[0], gdy = pq[1] - c[1], gdz = pq[2] - c[2];
       gprow = (int)(b * p.gN + j);
+      if (qform) {
+        qv = *reinterpret_cast<const v2f*>(p.gQ + (size_t)g * p.C1 + col0 + 2 * lane);
+        const float* c = p.gnew + (size_t)g * 3;
+        cgx = c[0], cgy = c[1], cgz = c[2];
+      } else {
+        const float* pq = p.gxyz + ((size_t)b * p.gN + j) * 3;
+        const float* c = p.gnew + (size_t)g * 3;
+        gdx = pq[0] - c[0], gdy = pq[1] - c[1], gdz = pq[2] - c[2];
+      }
     }
     auto gate_src = [&](int k) {  // the two P values of row k for this lane's columns
       const int pr = __builtin_amdgcn_readlane(gprow, k);
       return *reinterpret_cast<const v2f*>(p.gP + (size_t)pr * p.C1 + col0 + 2 * lane);
     };
-    auto gate_of = [&](v2f pv, int k) {  // same expression as sa_point_l1_fwd_kernel: the sign is the forward's
+    auto gate_of = [&](v2f pv, int k) {  // same expression as the forward: the sign is the forward's
+      if (qform) return pv + qv;
       const float rx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gdx), k));
       const float ry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gdy), k));
       const float rz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gdz), k));
@@ -193,6 +244,7 @@ __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
       const float t1 = fmaf(gwz1, rz, fmaf(gwy1, ry, gwx1 * rx)) + pv.y + gbb1;
       return v2f{t0, t1};
     };
+    v2f dq = v2f{0.f, 0.f};
     v2f hm = p.gP ? gate_src(0) : (p.h ? *reinterpret_cast<const v2f*>(p.h + row0) : v2f{1.f, 1.f});
     for (int k = 0; k < 32; ++k) {  // rows of the group in turn: exactly C2 hits per group, whatever the arg-max skew
       v2f hm_next = v2f{1.f, 1.f};
@@ -226,10 +278,31 @@ __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
       acc.x = hm.x > 0.f ? acc.x : 0.f;
       acc.y = hm.y > 0.f ? acc.y : 0.f;
       *reinterpret_cast<v2f*>(p.dh + row0 + (size_t)k * p.C1) = acc;
+      dq += acc;
       hm = hm_next;
     }
+    if (qform) sq_b += dq, sq_x += cgx * dq, sq_y += cgy * dq, sq_z += cgz * dq;
   }
 #undef PD_PREFETCH
+  if (qform && (p.gdW1x || p.gdb1)) {  // the W slice in LDS is not needed any more: its first 4 x 128 floats take the sums
+    __syncthreads();
+    for (int f = tid; f < 4 * PB_COLS; f += PD_T) wlds[f] = 0.f;
+    __syncthreads();
+    atomicAdd(&wlds[0 * PB_COLS + 2 * lane], sq_b.x), atomicAdd(&wlds[0 * PB_COLS + 2 * lane + 1], sq_b.y);
+    atomicAdd(&wlds[1 * PB_COLS + 2 * lane], sq_x.x), atomicAdd(&wlds[1 * PB_COLS + 2 * lane + 1], sq_x.y);
+    atomicAdd(&wlds[2 * PB_COLS + 2 * lane], sq_y.x), atomicAdd(&wlds[2 * PB_COLS + 2 * lane + 1], sq_y.y);
+    atomicAdd(&wlds[3 * PB_COLS + 2 * lane], sq_z.x), atomicAdd(&wlds[3 * PB_COLS + 2 * lane + 1], sq_z.y);
+    __syncthreads();
+    for (int f = tid; f < 4 * PB_COLS; f += PD_T) {
+      const int q = f / PB_COLS, c = col0 + f % PB_COLS;
+      const float v = wlds[f];
+      if (q == 0) {
+        if (p.gdb1) atomicAdd(p.gdb1 + c, v);
+      } else if (p.gdW1x) {
+        atomicAdd(p.gdW1x + (size_t)c * p.gldw + (q - 1), -v);
+      }
+    }
+  }
 }
 
 int launch_wgrad(const PoolBwdArgs& p, hipStream_t st) {
@@ -276,16 +349,19 @@ bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 
 
 bool pzn_pool_bwd_supported(int C1, int C2, const float* W, const float* h, const float* dh) {
   return C1 > 0 && C1 % PB_COLS == 0 && (C2 == 64 || C2 == 128 || C2 == 256) && aligned16(W) && aligned16(h) &&
-         aligned16(dh);
+         aligned16(dh);      // (h may be NULL: rows regenerated from the gate source)
 }
 
 int pzn_pool_bwd_sparse(const float* dout, const int32_t* argmax, const float* out, const float* W, const float* h,
                         float* dh, float* dW, float* db, int G, int C1, int C2, hipStream_t st, const PznGateSource* gs) {
-  PoolBwdArgs p{dout, argmax, out, W, h, dh, dW, db, G, C1, C2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+  PoolBwdArgs p{dout, argmax, out, W, h, dh, dW, db, G, C1, C2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
+                nullptr, nullptr, nullptr};
   if (gs && gs->P) {
     p.gP = gs->P, p.gidx = gs->idx, p.gxyz = gs->xyz, p.gnew = gs->new_xyz, p.gW1 = gs->W1, p.gb1 = gs->b1;
     p.gldw = gs->ldw, p.gN = gs->N, p.gS = gs->S;
+    p.gQ = gs->Q, p.gdW1x = gs->dW1x, p.gdb1 = gs->db1;
   }
+  if (dW && !h && !p.gQ) return PZN_EINVAL;      // the weight-gradient pass needs the rows or their source
   if (!dh && !dW) return PZN_EINVAL;
   if (dW) {
     int rc = launch_wgrad(p, st);

@@ -7,7 +7,13 @@
 //   dh != NULL: dh[G*32, C1] = scatter(dout) W, ReLU-masked by h when h != NULL (overwritten)
 //   dW != NULL: dW[C2, C1] += scatter(dout)^T h,  db[C2] += column sums (db may be NULL)
 bool pzn_pool_bwd_supported(int C1, int C2, const float* W, const float* h, const float* dh);
-// where the sparse input-gradient pass can regenerate the first layer's ReLU gate from (per-point first layer)
+// Where the sparse passes can regenerate the first layer's rows from (per-point first layer, csrc/sapoint.hip):
+//   h[(g, k), :] = relu(P[(g / S) * N + idx[g*32 + k], :] + Q[g, :])
+// Q == NULL: the round-1 form  relu(W1[:,0:3] (xyz[idx] - centre) + P[idx] + b1)  (gate of the input-gradient pass only).
+// Q != NULL: P is the per-point table WITH the coordinate term folded in and Q = b1 - W1[:,0:3] centre (pzn_sa_prep_f32):
+//   the input-gradient pass regenerates its gate, the weight-gradient pass regenerates the rows themselves (h == NULL),
+//   and the input-gradient pass also accumulates the gradients that flow through Q: dW1x[c, 0:3] -= sum_g dq[g,c] centre_g,
+//   db1[c] += sum_g dq[g,c] with dq[g,:] = sum_k dh[(g,k),:] (both may be NULL).
 struct PznGateSource {
   const float* P;
   const int64_t* idx;
@@ -16,6 +22,9 @@ struct PznGateSource {
   const float* W1;
   const float* b1;
   int ldw, N, S;
+  const float* Q;
+  float* dW1x;   // [C1, ldw] (columns 0..2 are added to)
+  float* db1;    // [C1]
 };
 int pzn_pool_bwd_sparse(const float* dout, const int32_t* argmax, const float* out, const float* W, const float* h,
                         float* dh, float* dW, float* db, int G, int C1, int C2, hipStream_t st, const PznGateSource* gs = nullptr);
@@ -35,6 +44,10 @@ int pzn_ws_gemm_ex(const float* A, int lda, const float* W, int ldw, int w_kmajo
                    const float* bias, int relu, const float* genY, const float* maskH, int32_t* argmax,
                    const int64_t* scat, int scat_in, int scat_out, const float* residual, float* C2, int accumulate,
                    hipStream_t st);
+
+// max-pool variant on a generated activation stream (first set-abstraction layer per point): see wsgemm.hip
+int pzn_ws_gemm_gather_maxpool(const float* Pp, const float* Q, const int64_t* idx, const float* W2, const float* b2, int G,
+                               int N, int S, int C1, int C2, float* out, int32_t* argmax, hipStream_t st);
 
 // dfgemm.hip: weight gradient dW[N,K'] += dY^T X (+ db += column sums of dY) with MFMA fragments loaded
 // straight from global memory; genY masks dY by genY > 0; skip_col >= 0 drops that column of X from the

@@ -250,8 +250,12 @@ __global__ __launch_bounds__(SP_T) void sa_point_l1_bwd_kernel(const float* __re
       grow = (int)(b * SK + rid);
       gp = (int)(b * N + pj);
       const float* q = xyz + (size_t)gp * 3;
-      const float* c = new_xyz + ((size_t)b * S + (rid >> 5)) * 3;
-      dx = q[0] - c[0], dy = q[1] - c[1], dz = q[2] - c[2];
+      if (new_xyz) {
+        const float* c = new_xyz + ((size_t)b * S + (rid >> 5)) * 3;
+        dx = q[0] - c[0], dy = q[1] - c[1], dz = q[2] - c[2];
+      } else {  // coordinate term folded into the per-point table (pzn_sa_prep_f32): the factor is the point itself
+        dx = q[0], dy = q[1], dz = q[2];
+      }
     }
     const int nr = (int)min((long)64, entries - bt * 64);
     const int first = __builtin_amdgcn_readlane(gp, 0), last = __builtin_amdgcn_readlane(gp, nr - 1);
@@ -321,7 +325,60 @@ __global__ __launch_bounds__(SP_T) void sa_point_l1_bwd_kernel(const float* __re
   }
 }
 
+// P[row, :] += W1[:, 0:3] xyz[row]  (rows = B*N points)   and   Q[g, :] = b1 - W1[:, 0:3] new_xyz[g]  (g = B*S groups):
+// with the coordinate term split this way a generated row is relu(P[idx] + Q[g]) — one add and one max per element
+// where the round-1 form needed three fmas with per-row broadcasts.  Thread = 4 channels of one row / group.
+__global__ __launch_bounds__(256) void sa_prep_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                      const float* __restrict__ W1, int ldw, const float* __restrict__ b1,
+                                                      long prow, long groups, int C1, float* __restrict__ P,
+                                                      float* __restrict__ Q) {
+  const int c4 = C1 >> 2;
+  const long total = (prow + groups) * c4;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / c4;
+    const int c = (int)(e - r * c4) * 4;
+    float wx[4], wy[4], wz[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      wx[i] = W1[(size_t)(c + i) * ldw], wy[i] = W1[(size_t)(c + i) * ldw + 1], wz[i] = W1[(size_t)(c + i) * ldw + 2];
+    if (r < prow) {
+      const float* q = xyz + (size_t)r * 3;
+      const float x = q[0], y = q[1], z = q[2];
+      float4* o = reinterpret_cast<float4*>(P + (size_t)r * C1 + c);
+      float4 v = *o;
+      v.x += fmaf(wz[0], z, fmaf(wy[0], y, wx[0] * x));
+      v.y += fmaf(wz[1], z, fmaf(wy[1], y, wx[1] * x));
+      v.z += fmaf(wz[2], z, fmaf(wy[2], y, wx[2] * x));
+      v.w += fmaf(wz[3], z, fmaf(wy[3], y, wx[3] * x));
+      *o = v;
+    } else {
+      const long g = r - prow;
+      const float* q = new_xyz + (size_t)g * 3;
+      const float x = q[0], y = q[1], z = q[2];
+      float4 v;
+      v.x = (b1 ? b1[c] : 0.f) - fmaf(wz[0], z, fmaf(wy[0], y, wx[0] * x));
+      v.y = (b1 ? b1[c + 1] : 0.f) - fmaf(wz[1], z, fmaf(wy[1], y, wx[1] * x));
+      v.z = (b1 ? b1[c + 2] : 0.f) - fmaf(wz[2], z, fmaf(wy[2], y, wx[2] * x));
+      v.w = (b1 ? b1[c + 3] : 0.f) - fmaf(wz[3], z, fmaf(wy[3], y, wx[3] * x));
+      *reinterpret_cast<float4*>(Q + (size_t)g * C1 + c) = v;
+    }
+  }
+}
+
 }  // namespace
+
+PZN_EXPORT int pzn_sa_prep_f32(const float* xyz, const float* new_xyz, const float* W1, const float* b1, int B, int N, int S,
+                               int D, int C1, float* P, float* Q, pzn_stream_t stream) {
+  PZN_CHECK_ARG(xyz && new_xyz && W1 && P && Q && B > 0 && N > 0 && S > 0 && D >= 0 && C1 > 0);
+  if ((C1 & 3) || (reinterpret_cast<uintptr_t>(P) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15)) return PZN_EUNSUPPORTED;
+  const long prow = (long)B * N, groups = (long)B * S;
+  const long total = (prow + groups) * (C1 >> 2);
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sa_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, pzn_hip_stream(stream), xyz, new_xyz, W1, 3 + D, b1,
+                     prow, groups, C1, P, Q);
+  PZN_RETURN_LAUNCH_STATUS();
+}
 
 PZN_EXPORT int pzn_sa_point_l1_fwd_f32(const float* xyz, const float* new_xyz, const int64_t* idx, const float* P,
                                        const float* W1, const float* b1, int B, int N, int S, int D, int C1, float* h,
@@ -374,7 +431,7 @@ PZN_EXPORT int pzn_knn_inverse_lists(const int64_t* idx, int B, int N, int S, in
 PZN_EXPORT int pzn_sa_point_l1_bwd_f32(const float* dh, const float* xyz, const float* new_xyz, const int32_t* rows,
                                        const int32_t* pts, int B, int N, int S, int D, int C1, float* dP, float* dW1,
                                        float* db1, pzn_stream_t stream) {
-  PZN_CHECK_ARG(dh && xyz && new_xyz && rows && pts && dP && dW1 && B > 0 && N > 0 && S > 0 && D >= 0);
+  PZN_CHECK_ARG(dh && xyz && rows && pts && dP && dW1 && B > 0 && N > 0 && S > 0 && D >= 0);      // (new_xyz may be NULL)
   PZN_CHECK_ARG((long)B * N < 2147483647L && (long)B * S * 32 < 2147483647L);
   if (C1 != 64 && C1 != 128 && C1 != 256) return PZN_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(dP) & 15) || (reinterpret_cast<uintptr_t>(dh) & 15)) return PZN_EUNSUPPORTED;

@@ -57,6 +57,14 @@ struct WsArgs {
   int accumulate;         // store epilogue: C(m,n) += value instead of = value
   // up to three (W, bias, C) triples that share A (the q, k, v projections of an attention block): blockIdx.y runs
   // over the column slices of all of them, one launch instead of three
+  // GATHER (max-pool variant only): the activation stream is never in memory.  Row (g, k) of group g is
+  //   relu(A[gbase(g) + gidx[g*32 + k], :] + gQ[g, :])   with A = the per-point table P' and gbase(g) = (g / gS) * gN
+  // (the first set-abstraction layer per point, see pzn_sa_level_fwd_f32): the loads of a row group carry per-lane row
+  // offsets looked up one tile ahead, the group's Q slice rides along as a fifth load, add + ReLU happen in registers
+  // on the way into the wave's LDS patch.
+  const int64_t* gidx;
+  const float* gQ;
+  int gN, gS;
   int nseg;
   const float* sW[3];
   const float* sbias[3];
@@ -90,6 +98,10 @@ __device__ __forceinline__ void split8(float4 lo, float4 hi, bf16x8& p1, bf16x8&
   p3 = __builtin_bit_cast(bf16x8, c);
 }
 
+__device__ __forceinline__ float4 add_relu(float4 x, float4 q) {  // relu(x + q): the first layer's row from P' and Q
+  return make_float4(fmaxf(x.x + q.x, 0.f), fmaxf(x.y + q.y, 0.f), fmaxf(x.z + q.z, 0.f), fmaxf(x.w + q.w, 0.f));
+}
+
 __device__ __forceinline__ float4 relu_mask(float4 x, float4 y) {
   return make_float4(y.x > 0.f ? x.x : 0.f, y.y > 0.f ? x.y : 0.f, y.z > 0.f ? x.z : 0.f, y.w > 0.f ? x.w : 0.f);
 }
@@ -98,7 +110,7 @@ __device__ __forceinline__ float4 relu_mask(float4 x, float4 y) {
 // GENY = ReLU-mask the activation stream with genY.
 // FULL: M % 32 == 0 and N % (NT*32) == 0: every store of the walk is unconditional too.
 // D2: two register sets = two 32 x 32 blocks of the stream in flight per wave (needs an even double-step count).
-template <int NT, bool MAXPOOL, bool GENY, int NW, bool FULL, bool D2>
+template <int NT, bool MAXPOOL, bool GENY, int NW, bool FULL, bool D2, bool GATH = false>
 __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
   constexpr int WS_T = NW * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];  // [nd*2][NT][3][64 lanes][16 B]
@@ -154,27 +166,62 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
   // half*16).  Loads are buffer loads: descriptor + wave-uniform tile / row-group offset (scalar) + a lane offset
   // that never changes, so there is no address arithmetic on the vector ALU, rows past M read as zero through the
   // descriptor's size, and every load is unconditional (the compiler's vmcnt bookkeeping stays exact).
+  // GATH: A is the per-point table (its row count is not M): the descriptor spans what the caller says it holds
+  const size_t a_rows = GATH ? (size_t)p.gN * ((size_t)(p.M / 32 + p.gS - 1) / p.gS) : (size_t)p.M;
   const __amdgpu_buffer_rsrc_t rsA =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)((size_t)p.M * p.lda * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GENY ? p.genY : p.A), 0,
-                                                                       (int)((size_t)p.M * p.lda * 4), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)(a_rows * p.lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(GENY ? p.genY : (GATH ? p.gQ : p.A)), 0,
+      GATH ? (int)((size_t)(p.M / 32) * p.lda * 4) : (int)((size_t)p.M * p.lda * 4), 0x00020000);
   const int prow = lane >> 3, pcol = (lane & 7) * 4;
   const int voff = (prow * p.lda + pcol) * 4;
   const int rstep = 8 * p.lda * 4;  // bytes between the row groups of consecutive load instructions
   float4 g0, g1, g2, g3, y0, y1, y2, y3;      // set A
   float4 h0, h1, h2, h3, z0, z1, z2, z3;      // set B (D2)
   int it = t, id = 0;  // issue cursor (tile, double step)
+  // GATH: byte offsets of this lane's four rows (prow + 8i) of the tile the issue cursor is in, and the point indices
+  // of the NEXT tile of this wave (fetched a whole tile ahead, so that the offsets are there when the cursor wraps)
+  int vo0 = 0, vo1 = 0, vo2 = 0, vo3 = 0, jn0 = 0, jn1 = 0, jn2 = 0, jn3 = 0;
+  auto gath_fetch_idx = [&](int tile) {
+    const int tc = tile < ntiles ? tile : ntiles - 1;
+    const int64_t* ip = p.gidx + (size_t)tc * 32 + prow;
+    jn0 = (int)ip[0], jn1 = (int)ip[8], jn2 = (int)ip[16], jn3 = (int)ip[24];
+  };
+  auto gath_offsets = [&](int tile) {
+    const int tc = tile < ntiles ? tile : ntiles - 1;
+    const int base = (tc / p.gS) * p.gN;
+    vo0 = ((base + jn0) * p.lda + pcol) * 4, vo1 = ((base + jn1) * p.lda + pcol) * 4;
+    vo2 = ((base + jn2) * p.lda + pcol) * 4, vo3 = ((base + jn3) * p.lda + pcol) * 4;
+  };
+  if (GATH) {
+    gath_fetch_idx(t);
+    gath_offsets(t);
+    gath_fetch_idx(t + tstride);
+  }
 #define WS_BLOAD(rs, so) __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, so, 0))
+#define WS_GLOAD(vo, so) __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, so, 0))
 #define WS_ISSUE(a0, a1, a2, a3, b0, b1, b2, b3)                                                    \
   do {                                                                                               \
-    const int so_ = (it * 32 * p.lda + id * 32) * 4;                                                 \
-    a0 = WS_BLOAD(rsA, so_), a1 = WS_BLOAD(rsA, so_ + rstep);                                        \
-    a2 = WS_BLOAD(rsA, so_ + 2 * rstep), a3 = WS_BLOAD(rsA, so_ + 3 * rstep);                        \
-    if (GENY) {                                                                                      \
-      b0 = WS_BLOAD(rsY, so_), b1 = WS_BLOAD(rsY, so_ + rstep);                                      \
-      b2 = WS_BLOAD(rsY, so_ + 2 * rstep), b3 = WS_BLOAD(rsY, so_ + 3 * rstep);                      \
+    if (GATH) {                                                                                      \
+      const int sd_ = id * 32 * 4;                                                                   \
+      a0 = WS_GLOAD(vo0, sd_), a1 = WS_GLOAD(vo1, sd_), a2 = WS_GLOAD(vo2, sd_), a3 = WS_GLOAD(vo3, sd_); \
+      const int tq_ = it < ntiles ? it : ntiles - 1;                                                 \
+      b0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsY, pcol * 4, (tq_ * p.lda + id * 32) * 4, 0)); \
+      if (++id == p.nd) {                                                                            \
+        id = 0, it += tstride;                                                                       \
+        gath_offsets(it);            /* from the indices fetched a tile ago */                       \
+        gath_fetch_idx(it + tstride);                                                                \
+      }                                                                                              \
+    } else {                                                                                         \
+      const int so_ = (it * 32 * p.lda + id * 32) * 4;                                               \
+      a0 = WS_BLOAD(rsA, so_), a1 = WS_BLOAD(rsA, so_ + rstep);                                      \
+      a2 = WS_BLOAD(rsA, so_ + 2 * rstep), a3 = WS_BLOAD(rsA, so_ + 3 * rstep);                      \
+      if (GENY) {                                                                                    \
+        b0 = WS_BLOAD(rsY, so_), b1 = WS_BLOAD(rsY, so_ + rstep);                                    \
+        b2 = WS_BLOAD(rsY, so_ + 2 * rstep), b3 = WS_BLOAD(rsY, so_ + 3 * rstep);                    \
+      }                                                                                              \
+      if (++id == p.nd) id = 0, it += tstride;                                                       \
     }                                                                                                \
-    if (++id == p.nd) id = 0, it += tstride;                                                         \
   } while (0)
   WS_ISSUE(g0, g1, g2, g3, y0, y1, y2, y3);
   if (D2) WS_ISSUE(h0, h1, h2, h3, z0, z1, z2, z3);
@@ -313,6 +360,7 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
   do {                                                                                                         \
     float4 x0 = a0, x1 = a1, x2 = a2, x3 = a3;                                                                 \
     if (GENY) x0 = relu_mask(x0, b0), x1 = relu_mask(x1, b1), x2 = relu_mask(x2, b2), x3 = relu_mask(x3, b3);  \
+    if (GATH) x0 = add_relu(x0, b0), x1 = add_relu(x1, b0), x2 = add_relu(x2, b0), x3 = add_relu(x3, b0);      \
     if (!D2 && ktail && d * 32 + pcol >= p.K) x0 = x1 = x2 = x3 = make_float4(0.f, 0.f, 0.f, 0.f); /* k past K */ \
     *reinterpret_cast<float4*>(pw) = x0;                                                                       \
     *reinterpret_cast<float4*>(pw + 8 * WS_STAGE_LD) = x1;                                                     \
@@ -340,13 +388,14 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
 #undef WS_CONSUME
 #undef WS_ISSUE
 #undef WS_BLOAD
+#undef WS_GLOAD
 }
 
 size_t stage_bytes(bool, int nw = WS_NW) { return (size_t)nw * 32 * WS_STAGE_LD * sizeof(float); }  // every wave's 32 x 32 patch
 
-template <int NT, bool MAXPOOL, bool GENY, bool FULL, bool D2, int NW>
+template <int NT, bool MAXPOOL, bool GENY, bool FULL, bool D2, int NW, bool GATH = false>
 int launch_nt_fw(const WsArgs& p, hipStream_t st) {
-  auto kern = ws_gemm_kernel<NT, MAXPOOL, GENY, NW, FULL, D2>;
+  auto kern = ws_gemm_kernel<NT, MAXPOOL, GENY, NW, FULL, D2, GATH>;
   const size_t lds = (size_t)p.nd * 2 * NT * 3 * 1024 + stage_bytes(MAXPOOL, NW);
   if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -377,6 +426,15 @@ int launch_nt(const WsArgs& p, hipStream_t st) {
     if (full && d2_on && (p.nd & 1) == 0 && (p.K & 31) == 0) return launch_nt_f<NT, MAXPOOL, GENY, true, true>(p, st);
   }
   return full ? launch_nt_f<NT, MAXPOOL, GENY, true, false>(p, st) : launch_nt_f<NT, MAXPOOL, GENY, false, false>(p, st);
+}
+
+// max-pool variant with the gathered / generated activation stream (WsArgs::gidx): full tiles only
+template <int NT>
+int launch_gather_nt(const WsArgs& p, hipStream_t st) {
+  const bool small = (p.M + 31) / 32 < 12 * 256;
+  if ((p.nd & 1) == 0)
+    return small ? launch_nt_fw<NT, true, false, true, true, 8, true>(p, st) : launch_nt_fw<NT, true, false, true, true, 12, true>(p, st);
+  return small ? launch_nt_fw<NT, true, false, true, false, 8, true>(p, st) : launch_nt_fw<NT, true, false, true, false, 12, true>(p, st);
 }
 
 template <bool MAXPOOL, bool GENY>
@@ -414,8 +472,8 @@ int pzn_ws_gemm_ex(const float* A, int lda, const float* W, int ldw, int w_kmajo
                    const int64_t* scat, int scat_in, int scat_out, const float* residual, float* C2, int accumulate,
                    hipStream_t st) {
   WsArgs p{A, lda, W, ldw, w_kmajor, C, ldc, M, N, K, (K + 31) / 32, bias, relu, genY, maskH, argmax, scat, scat_in, scat_out,
-           residual, C2, accumulate, 0, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr},
-           {0, 0, 0}};
+           residual, C2, accumulate, nullptr, nullptr, 0, 0, 0, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr},
+           {nullptr, nullptr, nullptr}, {0, 0, 0}};
   const int nt = pick_nt(N, p.nd, argmax != nullptr);
   if (!nt) return PZN_EUNSUPPORTED;
   if (argmax) return (genY || scat || residual || accumulate) ? PZN_EUNSUPPORTED : launch_mg<true, false>(p, nt, st);
@@ -433,6 +491,27 @@ int pzn_ws_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor, 
                         nullptr, nullptr, 0, st);
 }
 
+// Second shared-MLP layer + ReLU + max over the 32 neighbours on a GENERATED activation stream: row (g, k) =
+// relu(Pp[(g / S) * N + idx[g*32 + k], :] + Q[g, :]) (the first layer per point, csrc/sapoint.hip), never written to
+// memory.  out[G, C2], argmax[G, C2].  C1 % 32 == 0, C2 % 32 == 0 (full tiles), 16-byte aligned tables.
+int pzn_ws_gemm_gather_maxpool(const float* Pp, const float* Q, const int64_t* idx, const float* W2, const float* b2, int G,
+                               int N, int S, int C1, int C2, float* out, int32_t* argmax, hipStream_t st) {
+  if (!ws_enabled() || (C1 & 31) || (C2 & 31) || G <= 0 || (reinterpret_cast<uintptr_t>(Pp) & 15) ||
+      (reinterpret_cast<uintptr_t>(Q) & 15))
+    return PZN_EUNSUPPORTED;
+  const size_t prow = (size_t)N * ((size_t)(G + S - 1) / S);
+  if ((double)prow * C1 * 4.0 >= 2147483648.0 - 4.0e8 || (double)G * C1 * 4.0 >= 2147483648.0 - 4.0e8) return PZN_EUNSUPPORTED;
+  WsArgs p{Pp, C1, W2, C1, 0, out, C2, G * 32, C2, C1, C1 / 32, b2, 1, nullptr, nullptr, argmax, nullptr, 0, 0,
+           nullptr, nullptr, 0, idx, Q, N, S, 0, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr},
+           {nullptr, nullptr, nullptr}, {0, 0, 0}};
+  int nt = pick_nt(C2, p.nd, true);
+  while (nt > 1 && C2 % (nt * 32)) nt >>= 1;
+  if (!nt || C2 % (nt * 32)) return PZN_EUNSUPPORTED;
+  if (nt == 4) return launch_gather_nt<4>(p, st);
+  if (nt == 2) return launch_gather_nt<2>(p, st);
+  return launch_gather_nt<1>(p, st);
+}
+
 // Three linear layers that share their input in one launch (the q, k, v projections): C_i[M, N_i] = A W_i^T + b_i,
 // W_i[N_i, K] row-major, C_i dense; every N_i a multiple of 64 and 16-byte aligned pointers.
 int pzn_ws_gemm3(const float* A, int lda, const float* const W[3], const float* const bias[3], float* const C[3],
@@ -442,7 +521,8 @@ int pzn_ws_gemm3(const float* A, int lda, const float* const W[3], const float* 
   for (int i = 0; i < 3; ++i)
     if ((reinterpret_cast<uintptr_t>(C[i]) & 15) || (reinterpret_cast<uintptr_t>(bias[i]) & 15)) return PZN_EUNSUPPORTED;
   WsArgs p{A, lda, W[0], K, 0, C[0], N[0], M, ntot, K, (K + 31) / 32, bias[0], 0, nullptr, nullptr, nullptr, nullptr, 0, 0,
-           nullptr, nullptr, 0, 3, {W[0], W[1], W[2]}, {bias[0], bias[1], bias[2]}, {C[0], C[1], C[2]}, {N[0], N[1], N[2]}};
+           nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 3, {W[0], W[1], W[2]}, {bias[0], bias[1], bias[2]}, {C[0], C[1], C[2]},
+           {N[0], N[1], N[2]}};
   if (pick_nt(64, p.nd, false) < 2) return PZN_EUNSUPPORTED;
   return launch_nt<2, false, false>(p, st);  // 64-column slices: q and k are one slice each
 }

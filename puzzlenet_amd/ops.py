@@ -345,8 +345,9 @@ def colmean_argmax(a):
     B, R, C = a.shape
     mean = torch.empty((B, C), dtype=torch.float32, device=a.device)
     arg = torch.empty((B,), dtype=torch.int64, device=a.device)
+    ws = torch.empty((_lib.load().pzn_colmean_workspace_bytes(B, C) + 3) // 4, dtype=torch.float32, device=a.device)
     with torch.cuda.device(a.device):
-        _call("pzn_colmean_argmax_f32", _p(a), B, R, C, _p(mean), _p(arg), _stream())
+        _call("pzn_colmean_argmax_f32", _p(a), B, R, C, _p(mean), _p(arg), _p(ws), _stream())
     return mean, arg
 
 
@@ -1019,12 +1020,99 @@ class _SaMlpMaxPoint(torch.autograd.Function):
         return None, dfeat, None, None, dW1, db1, dW2, db2
 
 
+class _SaLevelFused(torch.autograd.Function):
+    """The set-abstraction level (model5_b.py:449-454 / :456-461) with the first layer per point and its rows never in
+    memory: W1[:,0:3] (xyz[j] - centre) is split into a per-point and a per-group part, so a grouped row is
+    relu(Pp[idx] + Q[group]) with Pp = feat W1[:,3:]^T + W1[:,0:3] xyz and Q = b1 - W1[:,0:3] centre; the rows are generated
+    inside the matrix-core kernel's operand loader forward (pzn_sa_level_fwd_f32) and inside both sparse passes backward
+    (pzn_sa_level_bwd_f32).  Same result as _SaMlpMaxPoint / _SaMlpMax up to the order of the fp32 sum; no h tensor
+    (537 MB per level and cloud at B = 64)."""
+
+    @staticmethod
+    def forward(ctx, xyz, feat, new_xyz, idx, w1, b1, w2, b2):
+        xyz, feat, new_xyz = _f32(xyz, "xyz"), _f32(feat, "points"), _f32(new_xyz, "new_xyz")
+        idx = None if idx is None else _i64(idx, "idx")
+        w1, b1, w2, b2 = _f32(w1, "w1"), _f32(b1, "b1"), _f32(w2, "w2"), _f32(b2, "b2")
+        B, N, _ = xyz.shape
+        S = new_xyz.shape[1]
+        D = feat.shape[-1]
+        C1, C2 = w1.shape[0], w2.shape[0]
+        dev = xyz.device
+        R = B * S
+        w_f = w1[:, 3:].contiguous()
+        P = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
+        Q = torch.empty((R, C1), dtype=torch.float32, device=dev)
+        out = torch.empty((R, C2), dtype=torch.float32, device=dev)
+        arg = torch.empty((R, C2), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _call("pzn_linear_fwd_f32", _p(feat), _p(w_f), None, B * N, D, C1, 0, _p(P), _stream(),
+                  flops=2 * B * N * D * C1)
+            if idx is None:
+                idx = torch.empty((B, S, 32), dtype=torch.int64, device=dev)
+                _call("pzn_knn_f32", _p(xyz), _p(new_xyz), B, N, S, 32, _p(idx), _stream())
+            _call("pzn_sa_prep_f32", _p(xyz), _p(new_xyz), _p(w1), _p(b1), B, N, S, D, C1, _p(P), _p(Q), _stream())
+            _call("pzn_sa_level_fwd_f32", _p(P), _p(Q), _p(idx), _p(w2), _p(b2), B, N, S, C1, C2, _p(out), _p(arg), _stream(),
+                  flops=2 * R * 32 * C1 * C2)
+        ctx.save_for_backward(xyz, feat, new_xyz, idx, w1, w_f, w2, out, arg, P, Q)
+        ctx.dims = (B, N, S, D, R, C1, C2)
+        ctx.param_refs = (w1, b1, w2, b2)
+        return out.reshape(B, S, C2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xyz, feat, new_xyz, idx, w1, w_f, w2, out, arg, P, Q = ctx.saved_tensors
+        B, N, S, D, R, C1, C2 = ctx.dims
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            raise _lib.PznError("sa_mlp_max: gradients w.r.t. point coordinates are not provided on the fused "
+                                "encoder path; use pointnet_util.sample_and_group + dense.shared_mlp_max")
+        dout = _f32(dout, "dout").reshape(R, C2)
+        dev = dout.device
+        need_feat = ctx.needs_input_grad[1]
+        sinks = [_sink(t, ctx.needs_input_grad[4 + i]) for i, t in enumerate(ctx.param_refs)]
+        direct = all(s_ is not None for s_ in sinks)
+        if direct:
+            dW1, db1, dW2, db2 = sinks
+        else:
+            dW1 = torch.zeros((C1, 3 + D), dtype=torch.float32, device=dev)    # the kernels add into these
+            db1 = torch.zeros((C1,), dtype=torch.float32, device=dev)
+            dW2 = torch.empty_like(w2)
+            db2 = torch.empty((C2,), dtype=torch.float32, device=dev)
+        dh = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
+        off = torch.empty((B * (N + 1),), dtype=torch.int32, device=dev)
+        rows = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
+        pts = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
+        dP = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
+        dwf = torch.empty((C1, D), dtype=torch.float32, device=dev)
+        dfeat = None
+        with torch.cuda.device(dev):
+            _call("pzn_sa_level_bwd_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(P), _p(Q), _p(idx), _p(new_xyz), B, N, S, D,
+                  C1, C2, _p(dh), _p(dW2), _p(db2), _p(dW1), _p(db1), int(direct), _stream(), flops=2 * R * (2 * C1 * C2))
+            _call("pzn_knn_inverse_lists", _p(idx), B, N, S, 32, _p(off), _p(rows), _p(pts), _stream())
+            # dP = per-point sums of dh; dW1[:,0:3] += dh^T xyz[idx] (centres = NULL: their part went through Q above)
+            _call("pzn_sa_point_l1_bwd_f32", _p(dh), _p(xyz), None, _p(rows), _p(pts), B, N, S, D, C1, _p(dP),
+                  _p(dW1), None, _stream())
+            if need_feat:
+                dfeat = torch.empty((B, N, D), dtype=torch.float32, device=dev)
+                _call("pzn_linear_dgrad_f32", _p(dP), None, _p(w_f), B * N, D, C1, None, _p(dfeat), _stream(),
+                      flops=2 * B * N * D * C1)
+            _call("pzn_linear_wgrad_f32", _p(dP), None, _p(feat), B * N, D, C1, _p(dwf), None, 0, _stream(),
+                  flops=2 * B * N * D * C1)
+        dW1[:, 3:].add_(dwf)
+        if direct:
+            return None, dfeat, None, None, None, None, None, None
+        return None, dfeat, None, None, dW1, db1, dW2, db2
+
+
 _SA_REGEN = os.environ.get("PZN_SA_REGEN", "1") != "0"     # tuning aid: 0 = the pooled backward reads its gate from h
 _SA_POINT = os.environ.get("PZN_SA_POINT", "1") != "0"     # tuning aid: 0 = the grouped-row path (_SaMlpMax)
+_SA_FUSED = os.environ.get("PZN_SA_FUSED", "1") != "0"     # tuning aid: 0 = per-point first layer WITH its rows in memory (_SaMlpMaxPoint)
 
 
 def sa_mlp_max(xyz, feat, new_xyz, idx, w1, b1, w2, b2):
     K = 32 if idx is None else idx.shape[2]
     if _SA_POINT and K == 32 and w1.shape[0] in (64, 128, 256) and w1.shape[1] == 3 + feat.shape[-1]:
+        if _SA_FUSED and w1.shape[0] % 128 == 0 and w2.shape[0] in (64, 128, 256) and w2.shape[1] == w1.shape[0] \
+                and _lib.load().pzn_gemm_get_precision() != 0:
+            return _SaLevelFused.apply(xyz, feat, new_xyz, idx, w1, b1, w2, b2)
         return _SaMlpMaxPoint.apply(xyz, feat, new_xyz, idx, w1, b1, w2, b2)
     return _SaMlpMax.apply(xyz, feat, new_xyz, idx, w1, b1, w2, b2)

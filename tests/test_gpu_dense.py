@@ -182,13 +182,16 @@ def test_chamfer_identity_and_symmetry(dev):
 @pytest.mark.parametrize("B,N,S,D,C1,C2", [(2, 300, 40, 64, 128, 128), (2, 128, 24, 128, 256, 256), (1, 64, 5, 8, 16, 24),
                                               (4, 600, 64, 64, 128, 128), (2, 400, 96, 128, 256, 256),
                                               (3, 97, 33, 12, 64, 40)])
-@pytest.mark.parametrize("per_point", [False, True])
-def test_sa_mlp_max_fused_vs_composed(dev, precision, monkeypatch, per_point, B, N, S, D, C1, C2):
-    """Fused set-abstraction path == group -> shared MLP -> max composed from fp64 torch ops; per_point: the first
-    layer as a per-point product + gather (csrc/sapoint.hip, C1 in {64,128,256}) instead of on grouped rows."""
+@pytest.mark.parametrize("path", ["rows", "point", "fused"])
+def test_sa_mlp_max_fused_vs_composed(dev, precision, monkeypatch, path, B, N, S, D, C1, C2):
+    """Set-abstraction level == group -> shared MLP -> max composed from fp64 torch ops, on its three kernel paths:
+    "rows" = the first layer on grouped rows; "point" = as a per-point product + gather that writes its rows
+    (csrc/sapoint.hip, C1 in {64,128,256}); "fused" = the rows generated inside the matrix-core kernel and the sparse
+    backward passes, never in memory (the default where C1 % 128 == 0; other shapes fall back to "point")."""
     from oracle import point_ops as orc
     from puzzlenet_amd import ops
-    monkeypatch.setattr(ops, "_SA_POINT", per_point)
+    monkeypatch.setattr(ops, "_SA_POINT", path != "rows")
+    monkeypatch.setattr(ops, "_SA_FUSED", path == "fused")
     rng = np.random.default_rng(D + S)
     xyz = rng.random((B, N, 3), dtype=np.float32)
     feat = rng.standard_normal((B, N, D)).astype(np.float32)
