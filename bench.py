@@ -350,9 +350,9 @@ def main():
             "avg_launch_ms": {"sa_point_l1_fwd_kernel": ms_gf / max(1.0, n_gf), "sa_point_l1_bwd_kernel": ms_gb / max(1.0, n_gb)},
         }
         # (4) EMD: vector-ALU / transcendental bound.  The reference's schedule is 10 levels x 3 passes x n*m pair
-        #     evaluations (emd_kernel.cu:46-154); the fused path walks only the cloud-2 points that still hold mass, and
-        #     leaves the lengths of those lists behind (pzn_emd_walk_counter_offset), so the evaluations EXECUTED are
-        #     known: 3 n (B m + sum of list lengths) on the general path, 30 n m on the single-workgroup path.  The walks
+        #     evaluations (emd_kernel.cu:46-154); the fused path walks only the cloud-2 points that still hold mass and lie
+        #     inside the level's x window, and counts what it evaluates (pzn_emd_walk_counter_offset: 1024 counters in
+        #     units of 64 evaluations), so the evaluations EXECUTED are known (30 n m on the single-workgroup path).  The walks
         #     are packed (v_pk_*: two evaluations per instruction): per TWO evaluations 3 differences, 3 square / sum,
         #     1 scale, 2 v_exp_f32 (8 cycles = two issue slots each), 1 weight, 1-5 accumulations (pass C also sums cost
         #     and gradient) = 14.5 issue slots on average, i.e. 7.25 vector issue slots per evaluation.
@@ -361,7 +361,7 @@ def main():
         ev_exec, ev_ref = 0.0, 0.0
         for ctr, eb, en, em in emd_walk:
             ev_ref += 30.0 * eb * en * em
-            ev_exec += 30.0 * eb * en * em if ctr is None else 3.0 * en * (eb * em + float(ctr.item()))
+            ev_exec += 30.0 * eb * en * em if ctr is None else 64.0 * float(ctr.sum().item())
         ev_exec, ev_ref = ev_exec / prof_steps, ev_ref / prof_steps
         LANE_OPS = 7.25
         e_ach = ev_exec * LANE_OPS / (ms_e * 1e-3) / 1e12 if ms_e > 0 else 0.0
@@ -371,7 +371,7 @@ def main():
             "achieved": e_ach, "peak": 39.3, "unit": "T lane-slot/s", "frac": e_ach / 39.3, "traffic": None,
             "pair_evaluations_executed_per_step": ev_exec, "pair_evaluations_reference_schedule_per_step": ev_ref,
             "issue_slots_per_evaluation": LANE_OPS, "ms_per_step": ms_e, "launches_per_step": n_e,
-            "note": "executed evaluations from the device-side active-list counter; the reference's schedule (30 n m per pair) "
+            "note": "executed evaluations counted on the device (active lists + x windows); the reference's schedule (30 n m per pair) "
                     f"would be {ev_ref / max(ev_exec, 1.0):.2f}x as many",
         }
         # (5) the attention blocks (4 per encoder): projections on the fp32-accurate bf16x3 path, contractions in --attn

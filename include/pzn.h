@@ -139,9 +139,9 @@ int pzn_emd_fused_f32(const float* xyz1, const float* xyz2, int B, int n, int m,
                       float* cost, float* g1, float* g2, void* workspace,
                       pzn_stream_t stream);
 
-/* Measurement aid (bench.py's EMD roofline): byte offset inside the workspace of a uint64 the fused entry point leaves
- * behind — the sum over pairs and levels 6..-2 of the cloud-2 points still holding mass (level 7 walks all m), so that
- * 3 n (B m + counter) pair evaluations were executed by the call; (size_t)-1 on the single-workgroup path (n, m <= 256). */
+/* Measurement aid (bench.py's EMD roofline): byte offset inside the workspace of 1024 uint64 counters the fused entry
+ * point leaves behind; their sum x 64 = the (row, point) pair evaluations its passes executed (points without mass and
+ * points outside a level's x window are not walked); (size_t)-1 on the single-workgroup path (n, m <= 256: 30 n m). */
 size_t pzn_emd_walk_counter_offset(int B, int n, int m);
 
 /* ------------------------------------------------------------------------ */

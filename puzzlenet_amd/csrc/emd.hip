@@ -49,9 +49,11 @@ struct EmdWs {
   float* remainL;  // [B*n]
   int* act[2];     // [B*m] each: ascending indices l of the points of cloud 2 that still hold mass (remainR_l > 0)
   int* cnt[2];     // [B] each: how many
-  unsigned long long* walk;  // one counter: sum over pairs and levels 6..-2 of the active-list lengths of the last fused
-                             // call (measurement only: bench.py derives the pair evaluations really executed from it)
+  int* perm[2];    // [B*n], [B*m]: x-sorted position -> original index (fused entry point: clouds are walked in x order)
+  unsigned long long* walk;  // EMD_WALK_SLOTS counters (measurement only): units of 64 (row, point) evaluations executed
+                             // by the last fused call, one slot per (workgroup, wavefront) modulo the slot count
 };
+constexpr int EMD_WALK_SLOTS = 1024;
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -74,6 +76,10 @@ EmdWs carve(void* ws, int B, int n, int m) {
     w.cnt[i] = reinterpret_cast<int*>(p);
     p += align_up(sizeof(int) * (size_t)B, 256);
   }
+  w.perm[0] = reinterpret_cast<int*>(p);
+  p += align_up(sizeof(int) * (size_t)B * n, 256);
+  w.perm[1] = reinterpret_cast<int*>(p);
+  p += align_up(sizeof(int) * (size_t)B * m, 256);
   w.walk = reinterpret_cast<unsigned long long*>(p);
   return w;
 }
@@ -106,7 +112,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // walked points per instruction with the packed fp32 ALU ops (v_pk_add/mul/fma_f32): ~8 issues per
 // (row, point) instead of ~21 for the float4-per-point form (whose pairs the compiler had to assemble
 // with v_mov).  An odd tail point is paired with a zero-weight copy of itself.
-#define EMD_WALK(PTR, IX, CNT, EVAL2)                                           \
+// X window: the fused entry point walks both clouds in ascending x (emd_sort_x_kernel), and a walked point farther
+// than `win` from the workgroup's rows along x contributes exp2(c d^2) with c d^2 <= -150, i.e. exactly +0 in fp32: a
+// wavefront whose quarter of the tile lies wholly outside [XLO, XHI] skips it (half the time of a 2048 x 2048 call is
+// spent in the two sharpest levels, where > 98 % of the exponentials underflow).  XLO > XHI never happens; pass
+// (-INFINITY, INFINITY) for "no window".  NEV counts the point pairs this wavefront really evaluated.
+#define EMD_WALK(PTR, IX, CNT, EVAL2, XLO, XHI, NEV)                            \
   do {                                                                        \
     __shared__ float4 emd_tile_[2][EMD_TL];                                   \
     const int cnt_ = (CNT);                                                   \
@@ -132,14 +143,17 @@ typedef float v2f __attribute__((ext_vector_type(2)));
       const int per_ = (npair_ + 3) >> 2;                                     \
       int q_ = min(npair_, wq_ * per_);                                       \
       const int end_ = min(npair_, q_ + per_);                                \
-      for (; q_ + 1 < end_; q_ += 2) {                                        \
-        float4 a0_ = tp_[2 * q_], b0_ = tp_[2 * q_ + 1], a1_ = tp_[2 * q_ + 2], b1_ = tp_[2 * q_ + 3]; \
-        EVAL2((v2f){a0_.x, a0_.y}, (v2f){a0_.z, a0_.w}, (v2f){b0_.x, b0_.y}, (v2f){b0_.z, b0_.w}, base_ + 2 * q_); \
-        EVAL2((v2f){a1_.x, a1_.y}, (v2f){a1_.z, a1_.w}, (v2f){b1_.x, b1_.y}, (v2f){b1_.z, b1_.w}, base_ + 2 * q_ + 2); \
-      }                                                                       \
-      for (; q_ < end_; ++q_) {                                               \
-        float4 a0_ = tp_[2 * q_], b0_ = tp_[2 * q_ + 1];                      \
-        EVAL2((v2f){a0_.x, a0_.y}, (v2f){a0_.z, a0_.w}, (v2f){b0_.x, b0_.y}, (v2f){b0_.z, b0_.w}, base_ + 2 * q_); \
+      if (q_ < end_ && !(tp_[2 * (end_ - 1)].y < (XLO) || tp_[2 * q_].x > (XHI))) { \
+        NEV += end_ - q_;                                                     \
+        for (; q_ + 1 < end_; q_ += 2) {                                      \
+          float4 a0_ = tp_[2 * q_], b0_ = tp_[2 * q_ + 1], a1_ = tp_[2 * q_ + 2], b1_ = tp_[2 * q_ + 3]; \
+          EVAL2((v2f){a0_.x, a0_.y}, (v2f){a0_.z, a0_.w}, (v2f){b0_.x, b0_.y}, (v2f){b0_.z, b0_.w}, base_ + 2 * q_); \
+          EVAL2((v2f){a1_.x, a1_.y}, (v2f){a1_.z, a1_.w}, (v2f){b1_.x, b1_.y}, (v2f){b1_.z, b1_.w}, base_ + 2 * q_ + 2); \
+        }                                                                     \
+        for (; q_ < end_; ++q_) {                                             \
+          float4 a0_ = tp_[2 * q_], b0_ = tp_[2 * q_ + 1];                    \
+          EVAL2((v2f){a0_.x, a0_.y}, (v2f){a0_.z, a0_.w}, (v2f){b0_.x, b0_.y}, (v2f){b0_.z, b0_.w}, base_ + 2 * q_); \
+        }                                                                     \
       }                                                                       \
       __syncthreads();                                                        \
     }                                                                         \
@@ -147,7 +161,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Same walk over TWO packed arrays of the same points that differ in their weight ({x,y,z,wa} and {x,y,z,wb}):
 // tile of three float4 per point pair — {x0,x1,y0,y1} {z0,z1,wa0,wa1} {wb0,wb1,-,-} — for the fused C + next-A pass.
-#define EMD_WALK2(PTRA, PTRB, IX, CNT, EVAL2)                                   \
+#define EMD_WALK2(PTRA, PTRB, IX, CNT, EVAL2, XLO, XHI, NEV)                    \
   do {                                                                        \
     __shared__ float4 emd_tile2_[2][EMD_TL / 2 * 3];                          \
     const int cnt_ = (CNT);                                                   \
@@ -181,15 +195,69 @@ typedef float v2f __attribute__((ext_vector_type(2)));
       const int per_ = (npair_ + 3) >> 2;                                     \
       int q_ = min(npair_, wq_ * per_);                                       \
       const int end_ = min(npair_, q_ + per_);                                \
-      for (; q_ < end_; ++q_) {                                               \
-        float4 a0_ = tp_[3 * q_], b0_ = tp_[3 * q_ + 1], c0_ = tp_[3 * q_ + 2]; \
-        EVAL2((v2f){a0_.x, a0_.y}, (v2f){a0_.z, a0_.w}, (v2f){b0_.x, b0_.y}, (v2f){b0_.z, b0_.w}, (v2f){c0_.x, c0_.y}); \
+      if (q_ < end_ && !(tp_[3 * (end_ - 1)].y < (XLO) || tp_[3 * q_].x > (XHI))) { \
+        NEV += end_ - q_;                                                     \
+        for (; q_ < end_; ++q_) {                                             \
+          float4 a0_ = tp_[3 * q_], b0_ = tp_[3 * q_ + 1], c0_ = tp_[3 * q_ + 2]; \
+          EVAL2((v2f){a0_.x, a0_.y}, (v2f){a0_.z, a0_.w}, (v2f){b0_.x, b0_.y}, (v2f){b0_.z, b0_.w}, (v2f){c0_.x, c0_.y}); \
+        }                                                                     \
       }                                                                       \
       __syncthreads();                                                        \
     }                                                                         \
   } while (0)
 
 __device__ __forceinline__ v2f exp2_pair(v2f t) { return (v2f){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)}; }
+
+// x range of the workgroup's rows +- win (rows are consecutive x-sorted points: the first and the last valid lane hold
+// the extremes); win = INFINITY or unsorted clouds (sorted == 0): no window
+__device__ __forceinline__ void row_window(float myx, int nvalid, float win, float& xlo, float& xhi) {
+  const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myx), 0));
+  const int last = nvalid > 0 ? nvalid - 1 : 0;
+  const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myx), last & 63));
+  xlo = x0 - win, xhi = x1 + win;
+}
+
+__device__ __forceinline__ void count_walk(const EmdWs& w, int pairs) {  // `pairs` point pairs x 64 rows evaluated by this wave
+  if ((threadIdx.x & 63) == 0 && pairs > 0) {
+    const unsigned slot = ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) & (EMD_WALK_SLOTS - 1);
+    atomicAdd(w.walk + slot, (unsigned long long)(2 * pairs));
+  }
+}
+
+// Ascending-x order of one cloud of one pair per workgroup: perm[b][i] = original index of the i-th point by
+// (x, index) — a bitonic sort of u64 keys (orderable x bits << 32 | index) in LDS.  grid (2, B): cloud 1 / cloud 2.
+constexpr int EMD_ST = 1024;
+__global__ __launch_bounds__(EMD_ST) void emd_sort_x_kernel(const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                            int n, int m, int npow, int mpow, EmdWs w) {
+  extern __shared__ unsigned long long skeys[];
+  const int which = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int cnt = which ? m : n, pw = which ? mpow : npow;
+  const float* src = (which ? xyz2 : xyz1) + (size_t)b * cnt * 3;
+  for (int i = tid; i < pw; i += EMD_ST) {
+    unsigned long long k = ~0ull;
+    if (i < cnt) {
+      uint32_t u = __float_as_uint(src[(size_t)i * 3]);
+      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+      k = ((unsigned long long)u << 32) | (uint32_t)i;
+    }
+    skeys[i] = k;
+  }
+  __syncthreads();
+  for (int k2 = 2; k2 <= pw; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < pw; i += EMD_ST) {
+        const int p = i ^ j;
+        if (p > i) {
+          const unsigned long long a = skeys[i], c = skeys[p];
+          const bool up = (i & k2) == 0;
+          if ((a > c) == up) skeys[i] = c, skeys[p] = a;
+        }
+      }
+      __syncthreads();
+    }
+  int* perm = w.perm[which] + (size_t)b * cnt;
+  for (int i = tid; i < cnt; i += EMD_ST) perm[i] = (int)(uint32_t)skeys[i];
+}
 
 // sum over the 4 wavefronts of a workgroup, lane by lane (all threads get the total)
 __device__ __forceinline__ float cross_wave_sum(float v, float* red) {
@@ -205,12 +273,13 @@ __global__ __launch_bounds__(EMD_T) void emd_init_kernel(const float* __restrict
                                                          const float* __restrict__ xyz2, int n, int m,
                                                          float multiL, float multiR, EmdWs w,
                                                          float* __restrict__ cost, float* __restrict__ g1,
-                                                         float* __restrict__ g2) {
+                                                         float* __restrict__ g2, int sorted) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * EMD_T + threadIdx.x;
   if (cost) {  // fused entry point: the accumulators start at zero (no separate fills)
     if (i == 0) cost[b] = 0.f;
-    if (i == 0 && b == 0) *w.walk = 0ull;
+    if (b == 0 && blockIdx.x == 0)
+      for (int s_ = threadIdx.x; s_ < EMD_WALK_SLOTS; s_ += EMD_T) w.walk[s_] = 0ull;
     if (i < n) {
       float* g = g1 + ((size_t)b * n + i) * 3;
       g[0] = 0.f, g[1] = 0.f, g[2] = 0.f;
@@ -221,12 +290,12 @@ __global__ __launch_bounds__(EMD_T) void emd_init_kernel(const float* __restrict
     }
   }
   if (i < n) {
-    const float* p = xyz1 + ((size_t)b * n + i) * 3;
+    const float* p = xyz1 + ((size_t)b * n + (sorted ? w.perm[0][(size_t)b * n + i] : i)) * 3;
     w.pk1[(size_t)b * n + i] = make_float4(p[0], p[1], p[2], 0.f);
     w.remainL[(size_t)b * n + i] = multiL;  // :41-42
   }
   if (i < m) {
-    const float* p = xyz2 + ((size_t)b * m + i) * 3;
+    const float* p = xyz2 + ((size_t)b * m + (sorted ? w.perm[1][(size_t)b * m + i] : i)) * 3;
     w.pk2a[(size_t)b * m + i] = make_float4(p[0], p[1], p[2], multiR);  // :43-44
     w.pk2b[(size_t)b * m + i] = make_float4(p[0], p[1], p[2], 0.f);
     w.act[0][(size_t)b * m + i] = i;  // every point of cloud 2 starts with mass
@@ -266,19 +335,19 @@ __global__ __launch_bounds__(EMD_CT) void emd_compact_kernel(int m, EmdWs w, int
     if (tid == 0) base_s += tot;
     __syncthreads();
   }
-  if (tid == 0) {
-    w.cnt[buf][b] = base_s;
-    atomicAdd(w.walk, (unsigned long long)base_s);
-  }
+  if (tid == 0) w.cnt[buf][b] = base_s;
 }
 
 // Pass A: rows = points k of xyz1.
-__global__ __launch_bounds__(EMD_T) void emd_pass_a_kernel(int n, int m, float c, EmdWs w) {
+__global__ __launch_bounds__(EMD_T) void emd_pass_a_kernel(int n, int m, float c, EmdWs w, float win) {
   __shared__ float red[EMD_T];
   const int b = blockIdx.y;
   const int k = blockIdx.x * EMD_ROWS + (threadIdx.x & 63);
   const float4* __restrict__ other = w.pk2a + (size_t)b * m;
   float4 me = k < n ? w.pk1[(size_t)b * n + k] : make_float4(0, 0, 0, 0);
+  float xlo, xhi;
+  row_window(me.x, min(EMD_ROWS, n - (int)blockIdx.x * EMD_ROWS), win, xlo, xhi);
+  int nev = 0;
   v2f acc = {0.f, 0.f};
   auto eval = [&](v2f X, v2f Y, v2f Z, v2f Wt, int) {
     v2f dx = X - me.x, dy = Y - me.y, dz = Z - me.z;
@@ -286,7 +355,8 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_a_kernel(int n, int m, float c
     acc += exp2_pair(d * c) * Wt;              // :77-78
   };
   auto ix = [](int i) { return i; };
-  EMD_WALK(other, ix, m, eval);
+  EMD_WALK(other, ix, m, eval, xlo, xhi, nev);
+  count_walk(w, nev);
   float suml = 1e-9f + cross_wave_sum(acc.x + acc.y, red);  // :59
   if (k < n && threadIdx.x < 64) {
     me.w = w.remainL[(size_t)b * n + k] / suml;  // :83
@@ -315,7 +385,8 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_b_kernel(int n, int m, float c
     }
   };
   auto ix = [](int i) { return i; };
-  EMD_WALK(other, ix, n, eval);
+  int nev = 0;
+  EMD_WALK(other, ix, n, eval, -INFINITY, INFINITY, nev);
   float sumr = cross_wave_sum(ar.x + ar.y, red), sx = 0.f, sy = 0.f, sz = 0.f;
   if (FUSED) {
     sx = cross_wave_sum(ax.x + ax.y, red);
@@ -350,7 +421,7 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_b_kernel(int n, int m, float c
 // emd_pass_b_kernel<true>.
 template <int SUB>
 __device__ __forceinline__ void emd_pass_b_rows(int n, int m, float c, const EmdWs& w, float* __restrict__ g2, int buf,
-                                                int cnt, float4 (*tile)[EMD_TL], float* red) {
+                                                int cnt, float4 (*tile)[EMD_TL], float* red, float win) {
   constexpr int RPB = EMD_ROWS / SUB;
   if ((int)blockIdx.x * RPB >= cnt) return;  // workgroup-uniform
   const int b = blockIdx.y, lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
@@ -358,6 +429,9 @@ __device__ __forceinline__ void emd_pass_b_rows(int n, int m, float c, const Emd
   const int l = r < cnt ? w.act[buf][(size_t)b * m + r] : m;
   const float4* __restrict__ other = w.pk1 + (size_t)b * n;
   float4 me = l < m ? w.pk2a[(size_t)b * m + l] : make_float4(0, 0, 0, 0);
+  float xlo, xhi;      // the workgroup's rows are consecutive list entries (ascending x): lanes 0 and (last row) * SUB
+  row_window(me.x, min(RPB, cnt - (int)blockIdx.x * RPB) * SUB - (SUB - 1), win, xlo, xhi);
+  int nev = 0;
   v2f ar = {0.f, 0.f}, ax = ar, ay = ar, az = ar;
   auto eval = [&](float4 a, float4 bb) {  // a = {x0,x1,y0,y1}, bb = {z0,z1,w0,w1}
     v2f dx = me.x - (v2f){a.x, a.y}, dy = me.y - (v2f){a.z, a.w}, dz = me.z - (v2f){bb.x, bb.y};
@@ -386,14 +460,21 @@ __device__ __forceinline__ void emd_pass_b_rows(int n, int m, float c, const Emd
     const float4* tp = tile[t & 1];
     const int per = (npair + 3) >> 2;
     const int q0 = min(npair, wq * per), end = min(npair, q0 + per);
-    int q = q0 + sub;
-    for (; q + SUB < end; q += 2 * SUB) {
-      const float4 a0 = tp[2 * q], b0 = tp[2 * q + 1], a1 = tp[2 * (q + SUB)], b1 = tp[2 * (q + SUB) + 1];
-      eval(a0, b0);
-      eval(a1, b1);
+    if (q0 < end && !(tp[2 * (end - 1)].y < xlo || tp[2 * q0].x > xhi)) {  // else: every product underflows to +0
+      nev += end - q0;
+      int q = q0 + sub;
+      for (; q + SUB < end; q += 2 * SUB) {
+        const float4 a0 = tp[2 * q], b0 = tp[2 * q + 1], a1 = tp[2 * (q + SUB)], b1 = tp[2 * (q + SUB) + 1];
+        eval(a0, b0);
+        eval(a1, b1);
+      }
+      if (q < end) eval(tp[2 * q], tp[2 * q + 1]);
     }
-    if (q < end) eval(tp[2 * q], tp[2 * q + 1]);
     __syncthreads();
+  }
+  if ((threadIdx.x & 63) == 0 && nev > 0) {  // units of 64 (row, point) evaluations: RPB rows x 2 nev points
+    const unsigned slot = ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) & (EMD_WALK_SLOTS - 1);
+    atomicAdd(w.walk + slot, (unsigned long long)((2 * nev + SUB - 1) / SUB));
   }
   float sr = ar.x + ar.y, sx = ax.x + ax.y, sy = ay.x + ay.y, sz = az.x + az.y;
 #pragma unroll
@@ -415,7 +496,7 @@ __device__ __forceinline__ void emd_pass_b_rows(int n, int m, float c, const Emd
     me.w = fmaxf(0.0f, remainR - sumr);                                 // :117
     w.pk2a[(size_t)b * m + l] = me;
     w.pk2b[(size_t)b * m + l].w = ratioR;
-    float* g = g2 + ((size_t)b * m + l) * 3;
+    float* g = g2 + ((size_t)b * m + w.perm[1][(size_t)b * m + l]) * 3;      // (the list path runs on x-sorted clouds)
     const float s = 2.f * ratioR;
     g[0] += s * sx;
     g[1] += s * sy;
@@ -424,20 +505,20 @@ __device__ __forceinline__ void emd_pass_b_rows(int n, int m, float c, const Emd
 }
 
 __global__ __launch_bounds__(EMD_T) void emd_pass_b_list_kernel(int n, int m, float c, EmdWs w, float* __restrict__ g2,
-                                                                int buf) {
+                                                                int buf, float win) {
   __shared__ float4 tile[2][EMD_TL];
   __shared__ float red[EMD_T];
   const int cnt = w.cnt[buf][blockIdx.y];
   if (cnt * 8 <= m)
-    emd_pass_b_rows<16>(n, m, c, w, g2, buf, cnt, tile, red);
+    emd_pass_b_rows<16>(n, m, c, w, g2, buf, cnt, tile, red, win);
   else if (cnt * 4 <= m)
-    emd_pass_b_rows<8>(n, m, c, w, g2, buf, cnt, tile, red);
+    emd_pass_b_rows<8>(n, m, c, w, g2, buf, cnt, tile, red, win);
   else if (cnt * 2 <= m)
-    emd_pass_b_rows<4>(n, m, c, w, g2, buf, cnt, tile, red);
+    emd_pass_b_rows<4>(n, m, c, w, g2, buf, cnt, tile, red, win);
   else if (cnt * 4 <= m * 3)
-    emd_pass_b_rows<2>(n, m, c, w, g2, buf, cnt, tile, red);
+    emd_pass_b_rows<2>(n, m, c, w, g2, buf, cnt, tile, red, win);
   else  // (nearly) every row: the pass is bound by the vector ALU, sharing rows only adds workgroups
-    emd_pass_b_rows<1>(n, m, c, w, g2, buf, cnt, tile, red);
+    emd_pass_b_rows<1>(n, m, c, w, g2, buf, cnt, tile, red, win);
 }
 
 // Pass C: rows = points k of xyz1.  MATCH writes match[b][l][k] += w (API-parity path);
@@ -445,7 +526,8 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_b_list_kernel(int n, int m, fl
 // LIST (not with MATCH): walk only the active points of cloud 2 (list `buf`).
 template <bool MATCH, bool FUSED, bool LIST>
 __global__ __launch_bounds__(EMD_T) void emd_pass_c_kernel(int n, int m, float c, EmdWs w, float* __restrict__ match,
-                                                           float* __restrict__ cost, float* __restrict__ g1, int buf) {
+                                                           float* __restrict__ cost, float* __restrict__ g1, int buf,
+                                                           float win) {
   __shared__ float red[EMD_T];
   const int b = blockIdx.y;
   const int k = blockIdx.x * EMD_ROWS + (threadIdx.x & 63);
@@ -474,7 +556,11 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_c_kernel(int n, int m, float c
   };
   const int* __restrict__ act = w.act[buf] + (size_t)b * m;
   auto ix = [&](int i) { return LIST ? act[i] : i; };
-  EMD_WALK(other, ix, LIST ? w.cnt[buf][b] : m, eval);
+  float xlo = -INFINITY, xhi = INFINITY;
+  if (LIST) row_window(me.x, min(EMD_ROWS, n - (int)blockIdx.x * EMD_ROWS), win, xlo, xhi);   // (the list path is x-sorted)
+  int nev = 0;
+  EMD_WALK(other, ix, LIST ? w.cnt[buf][b] : m, eval, xlo, xhi, nev);
+  if (LIST) count_walk(w, nev);
   float suml = cross_wave_sum(al.x + al.y, red), sx = 0.f, sy = 0.f, sz = 0.f, sc = 0.f;
   if (FUSED) {
     sx = cross_wave_sum(ax.x + ax.y, red);
@@ -486,7 +572,7 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_c_kernel(int n, int m, float c
     float* r = w.remainL + (size_t)b * n + k;
     *r = fmaxf(0.0f, *r - suml);  // :153
     if (FUSED) {
-      float* g = g1 + ((size_t)b * n + k) * 3;
+      float* g = g1 + ((size_t)b * n + (LIST ? w.perm[0][(size_t)b * n + k] : k)) * 3;
       g[0] += 2.f * sx;
       g[1] += 2.f * sy;
       g[2] += 2.f * sz;
@@ -507,7 +593,8 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_c_kernel(int n, int m, float c
 // The walk covers the active list of THIS level (`buf`): ratioR of pass C is non-zero exactly there, and the points that
 // pass B has just exhausted carry remainR = 0 into the next level's sum.
 __global__ __launch_bounds__(EMD_T) void emd_pass_ca_kernel(int n, int m, float c, float c_next, EmdWs w,
-                                                            float* __restrict__ cost, float* __restrict__ g1, int buf) {
+                                                            float* __restrict__ cost, float* __restrict__ g1, int buf,
+                                                            float win) {
   __shared__ float red[EMD_T];
   const int b = blockIdx.y;
   const int k = blockIdx.x * EMD_ROWS + (threadIdx.x & 63);
@@ -529,7 +616,11 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_ca_kernel(int n, int m, float 
   };
   const int* __restrict__ act = w.act[buf] + (size_t)b * m;
   auto ix = [&](int i) { return act[i]; };
-  EMD_WALK2(oa, ob, ix, w.cnt[buf][b], eval);
+  float xlo, xhi;      // window of the SOFTER of the two levels (c_next): outside it both exponentials are +0
+  row_window(me.x, min(EMD_ROWS, n - (int)blockIdx.x * EMD_ROWS), win, xlo, xhi);
+  int nev = 0;
+  EMD_WALK2(oa, ob, ix, w.cnt[buf][b], eval, xlo, xhi, nev);
+  count_walk(w, nev);
   const float suml = cross_wave_sum(al.x + al.y, red);
   const float sx = cross_wave_sum(ax.x + ax.y, red), sy = cross_wave_sum(ay.x + ay.y, red);
   const float sz = cross_wave_sum(az.x + az.y, red);
@@ -539,7 +630,7 @@ __global__ __launch_bounds__(EMD_T) void emd_pass_ca_kernel(int n, int m, float 
     float* r = w.remainL + (size_t)b * n + k;
     const float rem = fmaxf(0.0f, *r - suml);  // :153
     *r = rem;
-    float* g = g1 + ((size_t)b * n + k) * 3;
+    float* g = g1 + ((size_t)b * n + w.perm[0][(size_t)b * n + k]) * 3;
     g[0] += 2.f * sx;
     g[1] += 2.f * sy;
     g[2] += 2.f * sz;
@@ -786,32 +877,53 @@ int run_levels(const float* xyz1, const float* xyz2, int B, int n, int m, float*
   }
   const int mx = n > m ? n : m;
   dim3 gi((mx + EMD_T - 1) / EMD_T, B), gk((n + EMD_ROWS - 1) / EMD_ROWS, B), gl((m + EMD_ROWS - 1) / EMD_ROWS, B);
+  constexpr bool LISTED = FUSED && !MATCH;      // the fused entry point: x-sorted clouds, active lists, x windows
+  if (LISTED) {
+    int npow = 1, mpow = 1;
+    while (npow < n) npow <<= 1;
+    while (mpow < m) mpow <<= 1;
+    const size_t lds = sizeof(unsigned long long) * (size_t)(npow > mpow ? npow : mpow);
+    if (lds > 150 * 1024) return PZN_EUNSUPPORTED;      // (> 16384 points per cloud)
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(emd_sort_x_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return PZN_ELAUNCH;
+    hipLaunchKernelGGL(emd_sort_x_kernel, dim3(2, B), dim3(EMD_ST), lds, st, xyz1, xyz2, n, m, npow, mpow, w);
+  }
   hipLaunchKernelGGL(emd_init_kernel, gi, dim3(EMD_T), 0, st, xyz1, xyz2, n, m, multiL, multiR, w, FUSED ? cost : nullptr,
-                     g1, g2);
+                     g1, g2, LISTED ? 1 : 0);
   if (MATCH && pzn_zero_async(match, (size_t)B * n * m, st) != PZN_OK) return PZN_ELAUNCH;  // :39-40
   auto cof = [](int j) {                                         // :47-50, * log2(e)
     const float level = j == -2 ? 0.f : -powf(4.0f, (float)j);
     return level * 1.44269504088896340736f;
   };
-  if (FUSED && !MATCH) {  // A(7); then per level B, and C fused with the next level's A; the last level ends with a plain C
-    hipLaunchKernelGGL(emd_pass_a_kernel, gk, dim3(EMD_T), 0, st, n, m, cof(7), w);
+  // x window of a level: exp2(c d^2) with c d^2 <= -150 is exactly +0 in fp32 (below the smallest denormal), and
+  // d^2 >= (x distance)^2: points farther than sqrt(150 / -c) along x are not walked (level 0: no window)
+  auto winf = [&](int j) {
+    const float c = cof(j);
+    return c < 0.f ? sqrtf(150.f / -c) : INFINITY;
+  };
+  if (LISTED) {  // A(7); then per level B, and C fused with the next level's A; the last level ends with a plain C
+    hipLaunchKernelGGL(emd_pass_a_kernel, gk, dim3(EMD_T), 0, st, n, m, cof(7), w, winf(7));
     for (int j = 7, buf = 0; j >= -2; --j, buf ^= 1) {  // list `buf` = points of cloud 2 with mass at the start of level j
-      hipLaunchKernelGGL(emd_pass_b_list_kernel, dim3((m + 31) / 32, B), dim3(EMD_T), 0, st, n, m, cof(j), w, g2, buf);
+      hipLaunchKernelGGL(emd_pass_b_list_kernel, dim3((m + 31) / 32, B), dim3(EMD_T), 0, st, n, m, cof(j), w, g2, buf,
+                         winf(j));
       if (j > -2) {
         hipLaunchKernelGGL(emd_compact_kernel, dim3(B), dim3(EMD_CT), 0, st, m, w, buf ^ 1);  // for level j - 1
-        hipLaunchKernelGGL(emd_pass_ca_kernel, gk, dim3(EMD_T), 0, st, n, m, cof(j), cof(j - 1), w, cost, g1, buf);
+        hipLaunchKernelGGL(emd_pass_ca_kernel, gk, dim3(EMD_T), 0, st, n, m, cof(j), cof(j - 1), w, cost, g1, buf,
+                           winf(j - 1));
       } else {
         hipLaunchKernelGGL((emd_pass_c_kernel<false, FUSED, true>), gk, dim3(EMD_T), 0, st, n, m, cof(j), w, match, cost,
-                           g1, buf);
+                           g1, buf, winf(j));
       }
     }
     PZN_RETURN_LAUNCH_STATUS();
   }
   for (int j = 7; j >= -2; --j) {                                // :46
     const float c = cof(j);
-    hipLaunchKernelGGL(emd_pass_a_kernel, gk, dim3(EMD_T), 0, st, n, m, c, w);
+    hipLaunchKernelGGL(emd_pass_a_kernel, gk, dim3(EMD_T), 0, st, n, m, c, w, INFINITY);
     hipLaunchKernelGGL((emd_pass_b_kernel<FUSED>), gl, dim3(EMD_T), 0, st, n, m, c, w, g2);
-    hipLaunchKernelGGL((emd_pass_c_kernel<MATCH, FUSED, false>), gk, dim3(EMD_T), 0, st, n, m, c, w, match, cost, g1, 0);
+    hipLaunchKernelGGL((emd_pass_c_kernel<MATCH, FUSED, false>), gk, dim3(EMD_T), 0, st, n, m, c, w, match, cost, g1, 0,
+                       INFINITY);
   }
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -822,16 +934,17 @@ PZN_EXPORT size_t pzn_emd_workspace_bytes(int B, int n, int m) {
   if (B <= 0 || n <= 0 || m <= 0) return 0;
   return align_up(sizeof(float4) * (size_t)B * n, 256) + 2 * align_up(sizeof(float4) * (size_t)B * m, 256) +
          align_up(sizeof(float) * (size_t)B * n, 256) + 2 * align_up(sizeof(int) * (size_t)B * m, 256) +
-         2 * align_up(sizeof(int) * (size_t)B, 256) + 256;
+         2 * align_up(sizeof(int) * (size_t)B, 256) + align_up(sizeof(int) * (size_t)B * n, 256) +
+         align_up(sizeof(int) * (size_t)B * m, 256) + sizeof(unsigned long long) * EMD_WALK_SLOTS;
 }
 
-// Byte offset, inside the workspace, of a uint64 that the fused entry point leaves behind: the sum over pairs and over
-// levels 6..-2 of the number of cloud-2 points still holding mass (level 7 walks all m).  The passes of a level walk
-// n * (that many) pairs three times, so 3 n (B m + counter) pair evaluations were executed; (size_t)-1 when the call
-// takes the single-workgroup path (n, m <= 256), which walks everything.
+// Byte offset, inside the workspace, of 1024 uint64 counters that the fused entry point leaves behind: their sum x 64 is
+// the number of (row, point) pair evaluations its passes executed (points of exhausted mass and points outside the
+// level's x window are not walked); (size_t)-1 when the call takes the single-workgroup path (n, m <= 256), which
+// evaluates all 30 n m.
 PZN_EXPORT size_t pzn_emd_walk_counter_offset(int B, int n, int m) {
   if (B <= 0 || n <= 0 || m <= 0 || (n <= EMD_SMALL_MAX && m <= EMD_SMALL_MAX)) return (size_t)-1;
-  return pzn_emd_workspace_bytes(B, n, m) - 256;
+  return pzn_emd_workspace_bytes(B, n, m) - sizeof(unsigned long long) * EMD_WALK_SLOTS;
 }
 
 PZN_EXPORT int pzn_emd_approxmatch_f32(const float* xyz1, const float* xyz2, int B, int n, int m, float* match,
