@@ -195,6 +195,18 @@ int pzn_linear_dgrad_f32(const float* dy, const float* y_relu, const float* W,
 int pzn_linear_wgrad_f32(const float* dy, const float* y_relu, const float* x,
                          int M, int Kin, int Nout, float* dW, float* db,
                          int accumulate, pzn_stream_t stream);
+/* The three products of nn.Linear on a COLUMN SLICE of a wider weight matrix: W points at column k0 of
+ * W_full[Nout, ldw] and is Kin columns wide.  cat(x_1 .. x_n) W_full^T (model5_b.py:466-474) then is sum_i x_i W_i^T + b
+ * without the concatenation ever being built, and a weight gradient can be added straight into a slice of a parameter.
+ *   fwd:   y[M,Nout] = x[M,Kin] W^T + bias   (accumulate == 0)   or   y += x W^T   (accumulate != 0, bias ignored)
+ *   dgrad: dx[M,Kin] = dy[M,Nout] W (+ addend[M,Kin] when non-NULL)
+ *   wgrad: dW[Nout, ldw-strided, Kin columns] += dy^T x,  db[Nout] += column sums of dy (db may be NULL) */
+int pzn_linear_slice_fwd_f32(const float* x, const float* W, int ldw, const float* bias, int M, int Kin,
+                             int Nout, int accumulate, float* y, pzn_stream_t stream);
+int pzn_linear_slice_dgrad_f32(const float* dy, const float* W, int ldw, int M, int Kin, int Nout,
+                               const float* addend, float* dx, pzn_stream_t stream);
+int pzn_linear_slice_wgrad_f32(const float* dy, const float* x, int M, int Kin, int Nout, float* dW, int ldw,
+                               float* db, pzn_stream_t stream);
 /* Backward through the max-pool epilogue: the [R*32,Nout] gradient
  * dy[g*32+k, c] = (argmax[g,c]==k && out[g,c]>0) ? dout[g,c] : 0 is generated
  * inside the operand loader, never materialised. */

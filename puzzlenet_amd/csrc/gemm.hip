@@ -800,11 +800,11 @@ PZN_EXPORT int pzn_linear_maxpool_dgrad_f32(const float* dout, const int32_t* ar
 
 // dW[Nout,Kin] = dY^T X, db[Nout] = column sums of dY (row sums of the streamed A tiles): both overwritten.
 static int wgrad_common(GemmArgs p, int Kin, int Nout, const float* x, float* dW, float* db, int accumulate,
-                        hipStream_t st) {
+                        hipStream_t st, int ldw = 0) {
   // logical C[Nout, Kin] = sum_r dY[r][n] * X[r][k];  db[n] = sum_r dY[r][n] from the A tiles.
   // accumulate != 0: add into dW / db as they are (e.g. straight into the flat gradient bucket, which the
   // step zeroes once) — no zero-fill launches here and no separate "grad += dW" pass afterwards.
-  p.B = x, p.ldb = Kin, p.C = dW, p.ldc = Kin;
+  p.B = x, p.ldb = Kin, p.C = dW, p.ldc = ldw ? ldw : Kin;
   if (db) {
     p.bias_grad = db;
     if (!accumulate && pzn_zero_async(db, (size_t)Nout, st) != PZN_OK) return PZN_ELAUNCH;
@@ -831,6 +831,47 @@ PZN_EXPORT int pzn_linear_wgrad_f32(const float* dy, const float* y_relu, const 
   p.A = dy, p.lda = Nout;
   if (y_relu) p.gen = GEN_RELU, p.genY = y_relu;
   return wgrad_common(p, Kin, Nout, x, dW, db, accumulate, pzn_hip_stream(stream));
+}
+
+// ---- the same three products on a COLUMN SLICE of a wider weight matrix: W points at column k0 of W_full[Nout, ldw]
+// (Kin columns wide).  What cat(x_1 .. x_n) W_full^T needs when the concatenation is never built (model5_b.py:466-474:
+// y = sum_i x_i W_i^T + b), and what adds a weight gradient straight into a slice of a parameter (the feature block
+// of the first set-abstraction layer).  fwd: accumulate != 0 adds to y (bias then ignored).  dgrad: dx = dy W (+ addend).
+// wgrad: ADDS into dW (the slice's other columns are not touched) and into db when non-NULL.
+PZN_EXPORT int pzn_linear_slice_fwd_f32(const float* x, const float* W, int ldw, const float* bias, int M, int Kin, int Nout,
+                                        int accumulate, float* y, pzn_stream_t stream) {
+  PZN_CHECK_ARG(x && W && y && M > 0 && Kin > 0 && Nout > 0 && ldw >= Kin);
+  hipStream_t st = pzn_hip_stream(stream);
+  if (gemm_precision() != 0 && pzn_ws_gemm_supported(M, Nout, Kin, x, Kin, nullptr, false)) {
+    const int rc = pzn_ws_gemm_ex(x, Kin, W, ldw, 0, y, Nout, M, Nout, Kin, accumulate ? nullptr : bias, 0, nullptr, nullptr,
+                                  nullptr, nullptr, 0, 0, nullptr, nullptr, accumulate, st);
+    if (rc != PZN_EUNSUPPORTED) return rc;
+  }
+  GemmArgs p = base_args(M, Nout, Kin);
+  p.A = x, p.lda = Kin, p.B = W, p.ldb = ldw, p.C = y, p.ldc = Nout, p.bias = accumulate ? nullptr : bias;
+  if (accumulate) p.addend = y;      // EPI_STORE: C = A B + addend, element for element
+  launch<true, true, EPI_STORE>(p, 1, st);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+PZN_EXPORT int pzn_linear_slice_dgrad_f32(const float* dy, const float* W, int ldw, int M, int Kin, int Nout,
+                                          const float* addend, float* dx, pzn_stream_t stream) {
+  PZN_CHECK_ARG(dy && W && dx && M > 0 && Kin > 0 && Nout > 0 && ldw >= Kin);
+  GemmArgs p = base_args(M, Kin, Nout);
+  p.A = dy, p.lda = Nout, p.B = W, p.ldb = ldw, p.C = dx, p.ldc = Kin, p.addend = addend;
+  launch<true, false, EPI_STORE>(p, 1, pzn_hip_stream(stream));
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+PZN_EXPORT int pzn_linear_slice_wgrad_f32(const float* dy, const float* x, int M, int Kin, int Nout, float* dW, int ldw,
+                                          float* db, pzn_stream_t stream) {
+  PZN_CHECK_ARG(dy && x && dW && M > 0 && Kin > 0 && Nout > 0 && ldw >= Kin);
+  hipStream_t st = pzn_hip_stream(stream);
+  if (gemm_precision() != 0 && pzn_df_wgrad_supported(M, Nout, Kin))
+    return pzn_df_wgrad(dy, Nout, nullptr, x, Kin, M, Nout, Kin, dW, ldw, db, -1, st);
+  GemmArgs p = base_args(Nout, Kin, M);
+  p.A = dy, p.lda = Nout;
+  return wgrad_common(p, Kin, Nout, x, dW, db, 1, st, ldw);
 }
 
 PZN_EXPORT int pzn_linear_maxpool_wgrad_f32(const float* dout, const int32_t* argmax, const float* out, const float* x,

@@ -881,7 +881,8 @@ int launch_select(const float* xyz, const float* feat, const float* new_xyz, int
   // workgroups, whole clouds per XCD) fill its 4 MB L2: the write stream then evicts the tables it is gathering from
   // (measured at N = 2048, D = 64: 0.082 -> 0.075 ms per launch; at N = 512, D = 128 the tables fit and plain stores win)
   const long clouds_per_xcd = (64 + bpc - 1) / bpc;
-  const bool nt = GROUP && clouds_per_xcd * (long)N * D * 4 > 3L * 1024 * 1024;
+  static const int nt_force = [] { const char* e = getenv("PZN_KG_NT"); return e ? atoi(e) : -1; }();  // tuning aid
+  const bool nt = GROUP && (nt_force >= 0 ? nt_force != 0 : clouds_per_xcd * (long)N * D * 4 > 3L * 1024 * 1024);
   int dshift = -1;  // log2(D) when D is a power of two
   if (GROUP && D > 0 && (D & (D - 1)) == 0) dshift = __builtin_ctz((unsigned)D);
 #define PZN_SEL_K(RR, DTT, KPP, NTT)                                                                                      \

@@ -162,22 +162,30 @@ class PCTransformer_nonsort(nn.Module):
             f1f = dense.shared_mlp_max(f1, self.mlp3.weight, self.mlp3.bias, self.mlp4.weight, self.mlp4.bias)  # :452-454
             x2, f2 = self.sg2(256, 0, 32, x, f1f, False, True)                                    # :456
             f2f = dense.shared_mlp_max(f2, self.mlp5.weight, self.mlp5.bias, self.mlp6.weight, self.mlp6.bias)  # :459-461
-        att1, attention1 = self.atten1(f2f)
-        att2, attention2 = self.atten2(att1)
-        att3, attention3 = self.atten3(att2)
-        att4, attention4 = self.atten4(att3)
-        if attention1.is_cuda:
-            attention = ops.avg4(attention1, attention2, attention3, attention4)     # :468-469, one launch
+        blocks = (self.atten1, self.atten2, self.atten3, self.atten4)
+        if _ATTN_CHAIN and f2f.is_cuda and ops.attention_chain_supported(f2f, self.atten1.mlpq.weight.shape[0], self.out.weight):
+            # :462-474 as one autograd node: no concatenation, no gradient-accumulation adds between the blocks
+            out, attention = ops.attention_chain_out(
+                f2f, [(a.mlpq.weight, a.mlpq.bias, a.mlpk.weight, a.mlpk.bias, a.mlpv.weight, a.mlpv.bias, a.out.weight,
+                       a.out.bias) for a in blocks], self.out.weight, self.out.bias)
         else:
-            attention = attention1 + attention2 + attention3 + attention4
-            attention = attention / 4
-        att = torch.cat([att1, att2, att3, att4, f2f], dim=-1)       # (:466, :470 as one copy instead of two)
-        out = dense.linear(att, self.out.weight, self.out.bias)                                   # :474
+            att1, attention1 = self.atten1(f2f)
+            att2, attention2 = self.atten2(att1)
+            att3, attention3 = self.atten3(att2)
+            att4, attention4 = self.atten4(att3)
+            if attention1.is_cuda:
+                attention = ops.avg4(attention1, attention2, attention3, attention4)     # :468-469, one launch
+            else:
+                attention = attention1 + attention2 + attention3 + attention4
+                attention = attention / 4
+            att = torch.cat([att1, att2, att3, att4, f2f], dim=-1)       # (:466, :470 as one copy instead of two)
+            out = dense.linear(att, self.out.weight, self.out.bias)                                   # :474
         f_global = ops.max_over_points(out)                                                       # :475
         return f_global, x2, attention, out, x_feature
 
 
 _BN_FUSED = os.environ.get("PZN_BN_FUSED", "1") != "0"     # tuning aid
+_ATTN_CHAIN = os.environ.get("PZN_ATTN_CHAIN", "1") != "0"     # tuning aid: 0 = four autograd nodes + cat + linear
 _EMD_SIDE = int(os.environ.get("PZN_EMD_SIDE", "2"))     # tuning aid: 0 = the N x N EMD on the main stream, 1 = forked right after the pose head, 2 = after the heads (measured best)
 
 

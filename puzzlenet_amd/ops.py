@@ -797,6 +797,111 @@ def attention_block(x, wq, bq, wk, bk, wv, bv, wo, bo):
     return _AttentionBlock.apply(x, wq, bq, wk, bk, wv, bv, wo, bo)
 
 
+class _AttnChainOut(torch.autograd.Function):
+    """model5_b.py:462-474 as ONE autograd node: the four chained layerAttention blocks, the mean of their four maps, and
+    the out projection of cat([att1, att2, att3, att4, f2f]).  The concatenation is never built — out = sum_i x_i W_i^T + b
+    over the five 256-column slices of W_out (pzn_linear_slice_fwd / _wgrad) — and the backward forms dy W_out once and
+    adds each block's input gradient to its slice (one add per block instead of autograd's narrow copies + accumulations).
+    inputs: x[B,L,E], 4 x (wq,bq,wk,bk,wv,bv,wo,bo), w_out[Nout, 5E], b_out -> (out[B,L,Nout], attention[B,L,L])"""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        x = _f32(x, "x")
+        ps = [_f32(t, "param") for t in params]
+        blocks = [ps[8 * i: 8 * i + 8] for i in range(4)]
+        w_out, b_out = ps[32], ps[33]
+        B, L, E = x.shape
+        dk = blocks[0][0].shape[0]
+        Nout = w_out.shape[0]
+        dev = x.device
+        M = B * L
+        mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        saved, cur = [], x.reshape(M, E)
+        with torch.cuda.device(dev):
+            for (wq, bq, wk, bk, wv, bv, wo, bo) in blocks:
+                q, k, v = mk(M, dk), mk(M, dk), mk(M, E)
+                attn, r, yo, out = mk(B, L, L), mk(M, E), mk(M, E), mk(M, E)
+                _call("pzn_attn_block_fwd_f32", _p(cur), _p(wq), _p(bq), _p(wk), _p(bk), _p(wv), _p(bv), _p(wo), _p(bo),
+                      B, L, E, dk, _p(q), _p(k), _p(v), _p(attn), _p(r), _p(yo), _p(out), _stream(),
+                      flops=2 * M * E * (2 * dk + 2 * E) + 2 * B * L * L * (dk + E))
+                saved.append((cur, q, k, v, attn, r, yo))
+                cur = out
+            attention = mk(B, L, L)
+            _call("pzn_avg4_f32", _p(saved[0][4]), _p(saved[1][4]), _p(saved[2][4]), _p(saved[3][4]), attention.numel(),
+                  _p(attention), _stream())
+            y = mk(M, Nout)
+            xs = [saved[1][0], saved[2][0], saved[3][0], cur, x.reshape(M, E)]      # att1 .. att4, f2f (cat order, :466)
+            for i, xi in enumerate(xs):
+                _call("pzn_linear_slice_fwd_f32", _p(xi), w_out.data_ptr() + 4 * E * i, 5 * E, _p(b_out), M, E, Nout,
+                      int(i > 0), _p(y), _stream(), flops=2 * M * E * Nout)
+        ctx.save_for_backward(*([t for blk in saved for t in blk] + [cur] + ps))
+        ctx.dims = (B, L, E, dk, Nout)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(attention)      # (it only feeds an arg-max; its gradient would be zero)
+        return y.view(B, L, Nout), attention
+
+    @staticmethod
+    def backward(ctx, dy, _dattention):
+        B, L, E, dk, Nout = ctx.dims
+        t = ctx.saved_tensors
+        saved = [t[7 * i: 7 * i + 7] for i in range(4)]
+        att4 = t[28]
+        ps = t[29:]
+        blocks = [ps[8 * i: 8 * i + 8] for i in range(4)]
+        w_out, b_out = ps[32], ps[33]
+        dev = att4.device
+        M = B * L
+        mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        if dy is None:
+            dy = torch.zeros((M, Nout), dtype=torch.float32, device=dev)
+        dy = _f32(dy, "dy").reshape(M, Nout)
+        xs = [saved[1][0], saved[2][0], saved[3][0], att4, saved[0][0]]           # inputs of the five slice products
+        sink_w, sink_b = _sink(w_out, ctx.needs_input_grad[33]), _sink(b_out, ctx.needs_input_grad[34])
+        direct_out = sink_w is not None and sink_b is not None
+        dW_out = sink_w if direct_out else torch.zeros_like(w_out)
+        db_out = sink_b if direct_out else torch.zeros_like(b_out)
+        grads = [None] * 34
+        nbytes = _lib.load().pzn_attn_block_bwd_workspace_bytes(B, L, E, dk)
+        ws = mk((nbytes + 3) // 4)
+        with torch.cuda.device(dev):
+            for i, xi in enumerate(xs):      # dW_out[:, slice i] += dy^T x_i;  db_out += column sums (once)
+                _call("pzn_linear_slice_wgrad_f32", _p(dy), _p(xi), M, E, Nout, dW_out.data_ptr() + 4 * E * i, 5 * E,
+                      _p(db_out) if i == 0 else None, _stream(), flops=2 * M * E * Nout)
+            # dy W_out for all five slices in ONE product (a product per slice would stream dy five times)
+            G = mk(M, 5 * E)
+            _call("pzn_linear_dgrad_f32", _p(dy), None, _p(w_out), M, 5 * E, Nout, None, _p(G), _stream(),
+                  flops=2 * M * 5 * E * Nout)
+            g = G[:, 3 * E: 4 * E].contiguous()      # gradient of att4: its slice of the projection only
+            for i in (3, 2, 1, 0):
+                xin, q, k, v, attn, r, yo = saved[i]
+                wq, bq, wk, bk, wv, bv, wo, bo = blocks[i]
+                sinks = [_sink(p_, ctx.needs_input_grad[1 + 8 * i + j]) for j, p_ in enumerate(blocks[i])]
+                direct = all(s_ is not None for s_ in sinks)
+                gp = sinks if direct else [torch.empty_like(p_) for p_ in blocks[i]]
+                dx = mk(M, E)
+                _call("pzn_attn_block_bwd_f32", _p(xin), _p(wq), _p(wk), _p(wv), _p(wo), _p(q), _p(k), _p(v), _p(attn), _p(r),
+                      _p(yo), _p(g), None, B, L, E, dk, _p(ws), _p(dx), *[_p(z) for z in gp], int(direct), _stream(),
+                      flops=2 * (2 * M * E * (2 * dk + 2 * E)) + 2 * B * L * L * (2 * dk + 2 * E))
+                if not direct:
+                    grads[8 * i: 8 * i + 8] = gp
+                # gradient of this block's input = its slice of the projection + what the block passed back
+                sl = i - 1 if i > 0 else 4            # att_i sits in slice i-1, f2f in slice 4
+                g = torch.add(G[:, sl * E: (sl + 1) * E], dx)
+        if not direct_out:
+            grads[32], grads[33] = dW_out, db_out
+        return (g.view(B, L, E),) + tuple(grads)
+
+
+def attention_chain_out(x, blocks, w_out, b_out):
+    """blocks: four 8-tuples (wq, bq, wk, bk, wv, bv, wo, bo) -> (out[B,L,Nout], mean attention map[B,L,L])"""
+    flat = [p_ for blk in blocks for p_ in blk]
+    return _AttnChainOut.apply(x, *flat, w_out, b_out)
+
+
+def attention_chain_supported(x, dk, w_out):
+    return attention_block_supported(x, dk) and w_out.shape[1] == 5 * x.shape[2] and x.shape[2] % 4 == 0
+
+
 class _SaMlpMax(torch.autograd.Function):
     """Set abstraction as the encoder runs it (model5_b.py:449-454 / :456-461): group the K=32 neighbours
     (pointnet_util.py:123-132), two shared-MLP layers, max over K — on padded rows {dx,dy,dz,0,f...}, with
@@ -995,7 +1100,6 @@ class _SaMlpMaxPoint(torch.autograd.Function):
         rows = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
         pts = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
         dP = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
-        dwf = torch.empty((C1, D), dtype=torch.float32, device=dev)
         dfeat = None
         with torch.cuda.device(dev):
             if _SA_REGEN:    # the ReLU gate of h regenerated from P / idx (L2) instead of read from h (HBM)
@@ -1012,9 +1116,9 @@ class _SaMlpMaxPoint(torch.autograd.Function):
                 dfeat = torch.empty((B, N, D), dtype=torch.float32, device=dev)
                 _call("pzn_linear_dgrad_f32", _p(dP), None, _p(w_f), B * N, D, C1, None, _p(dfeat), _stream(),
                       flops=2 * B * N * D * C1)
-            _call("pzn_linear_wgrad_f32", _p(dP), None, _p(feat), B * N, D, C1, _p(dwf), None, 0, _stream(),
+            # dW1[:, 3:] += dP^T feat, straight into the parameter's column slice (no temporary, no tensor add)
+            _call("pzn_linear_slice_wgrad_f32", _p(dP), _p(feat), B * N, D, C1, dW1.data_ptr() + 12, 3 + D, None, _stream(),
                   flops=2 * B * N * D * C1)
-        dW1[:, 3:].add_(dwf)
         if direct:
             return None, dfeat, None, None, None, None, None, None
         return None, dfeat, None, None, dW1, db1, dW2, db2
@@ -1082,7 +1186,6 @@ class _SaLevelFused(torch.autograd.Function):
         rows = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
         pts = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
         dP = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
-        dwf = torch.empty((C1, D), dtype=torch.float32, device=dev)
         dfeat = None
         with torch.cuda.device(dev):
             _call("pzn_sa_level_bwd_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(P), _p(Q), _p(idx), _p(new_xyz), B, N, S, D,
@@ -1095,9 +1198,9 @@ class _SaLevelFused(torch.autograd.Function):
                 dfeat = torch.empty((B, N, D), dtype=torch.float32, device=dev)
                 _call("pzn_linear_dgrad_f32", _p(dP), None, _p(w_f), B * N, D, C1, None, _p(dfeat), _stream(),
                       flops=2 * B * N * D * C1)
-            _call("pzn_linear_wgrad_f32", _p(dP), None, _p(feat), B * N, D, C1, _p(dwf), None, 0, _stream(),
+            # dW1[:, 3:] += dP^T feat, straight into the parameter's column slice (no temporary, no tensor add)
+            _call("pzn_linear_slice_wgrad_f32", _p(dP), _p(feat), B * N, D, C1, dW1.data_ptr() + 12, 3 + D, None, _stream(),
                   flops=2 * B * N * D * C1)
-        dW1[:, 3:].add_(dwf)
         if direct:
             return None, dfeat, None, None, None, None, None, None
         return None, dfeat, None, None, dW1, db1, dW2, db2

@@ -355,3 +355,88 @@ def test_attention_block_bf16_mode(dev, attn_bf16):
         # (the key bias has a mathematically zero gradient — softmax is shift-invariant — and collects the bf16 rounding
         # noise of 5120 rows instead: absolute floor)
         assert float((p_.grad.cpu().double() - q_.grad).abs().max()) < 2 * BF16_BWD_TOL * max(float(q_.grad.abs().max()), 0.25)
+
+
+@pytest.mark.parametrize("sinks", [False, True])
+def test_attention_chain_node_vs_composed(dev, sinks):
+    """ops.attention_chain_out (model5_b.py:462-474 as one autograd node: four blocks, mean of the maps, out projection
+    of the never-built concatenation) against the same thing composed from attention_block + avg4 + cat + linear:
+    outputs and every gradient (35 tensors), also with the parameter gradients going into registered sinks."""
+    from puzzlenet_amd import dense, ops
+    B, L, E, dk, Nout = 20, 256, 256, 64, 1024
+    g = torch.Generator().manual_seed(7)
+    x0 = (0.5 * torch.randn(B, L, E, generator=g)).to(dev)
+    shapes = [(dk, E), (dk,), (dk, E), (dk,), (E, E), (E,), (E, E), (E,)]
+    blocks0 = [[(torch.randn(*s, generator=g) / (math.sqrt(E) if len(s) == 2 else 4)).to(dev) for s in shapes] for _ in range(4)]
+    w0 = (torch.randn(Nout, 5 * E, generator=g) / math.sqrt(5 * E)).to(dev)
+    b0 = (0.1 * torch.randn(Nout, generator=g)).to(dev)
+    wy = torch.randn(B, L, Nout, generator=g).to(dev)
+
+    def run(chain):
+        x = x0.clone().requires_grad_(True)
+        blocks = [[p.clone().requires_grad_(True) for p in blk] for blk in blocks0]
+        w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        flat = [p for blk in blocks for p in blk] + [w, b]
+        ops.clear_grad_sinks()
+        if sinks:
+            for p in flat:
+                p.grad = torch.full_like(p, 0.125)          # pre-existing content: the kernels must ADD to it
+            ops.register_grad_sinks(flat)
+        if chain:
+            assert ops.attention_chain_supported(x, dk, w)
+            y, a = ops.attention_chain_out(x, blocks, w, b)
+        else:
+            cur, maps, outs = x, [], []
+            for blk in blocks:
+                cur, m = ops.attention_block(cur, *blk)
+                maps.append(m)
+                outs.append(cur)
+            a = ops.avg4(*maps)
+            y = dense.linear(torch.cat(outs + [x], dim=-1), w, b)
+        (y * wy).sum().backward()
+        ops.clear_grad_sinks()
+        return y.detach(), a.detach(), x.grad, [p.grad for p in flat]
+
+    yc, ac, gxc, gpc = run(True)
+    yr, ar, gxr, gpr = run(False)
+    assert _rel(yc, yr) < 1e-5 and torch.equal(ac, ar)
+    assert _rel(gxc, gxr) < 1e-4
+    for a_, b_ in zip(gpc, gpr):
+        assert float((a_ - b_).abs().max()) < 2e-4 * max(float(b_.abs().max()), 5e-2)
+
+
+@pytest.mark.parametrize("M,E,Nout,nsl", [(16384, 256, 1024, 5), (1000, 64, 96, 3), (4096, 128, 128, 2)])
+def test_linear_slice_entry_points(dev, M, E, Nout, nsl):
+    """pzn_linear_slice_{fwd,dgrad,wgrad}_f32: products on a column slice W[:, a:a+E] of a wider weight (row stride ldw),
+    against float64 matmuls of the same slice; fwd also in accumulate mode, dgrad with an addend, wgrad adding into
+    the slice of a pre-filled gradient buffer (the neighbouring columns must stay untouched)."""
+    from puzzlenet_amd import _lib
+    g = torch.Generator().manual_seed(M + E)
+    ldw = nsl * E
+    W = (torch.randn(Nout, ldw, generator=g) / math.sqrt(E)).to(dev)
+    bias = torch.randn(Nout, generator=g).to(dev)
+    xs = [torch.randn(M, E, generator=g).to(dev) for _ in range(nsl)]
+    dy = torch.randn(M, Nout, generator=g).to(dev)
+    add = torch.randn(M, E, generator=g).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    y = torch.empty(M, Nout, device=dev)
+    for i, x in enumerate(xs):
+        _lib.call("pzn_linear_slice_fwd_f32", x.data_ptr(), W.data_ptr() + 4 * E * i, ldw, bias.data_ptr(), M, E, Nout,
+                  int(i > 0), y.data_ptr(), st)
+    ref = torch.cat(xs, 1).double() @ W.double().t() + bias.double()
+    assert _rel(y, ref.float()) < 1e-5
+    sl = nsl - 1
+    dx = torch.empty(M, E, device=dev)
+    _lib.call("pzn_linear_slice_dgrad_f32", dy.data_ptr(), W.data_ptr() + 4 * E * sl, ldw, M, E, Nout, add.data_ptr(),
+              dx.data_ptr(), st)
+    ref = dy.double() @ W[:, sl * E:(sl + 1) * E].double() + add.double()
+    assert _rel(dx, ref.float()) < 1e-5
+    dW = torch.full((Nout, ldw), 0.5, device=dev)
+    db = torch.full((Nout,), -1.0, device=dev)
+    _lib.call("pzn_linear_slice_wgrad_f32", dy.data_ptr(), xs[sl].data_ptr(), M, E, Nout, dW.data_ptr() + 4 * E * sl, ldw,
+              db.data_ptr(), st)
+    ref = torch.full((Nout, ldw), 0.5, dtype=torch.float64, device=dev)
+    ref[:, sl * E:(sl + 1) * E] += dy.double().t() @ xs[sl].double()
+    assert _rel(dW, ref.float()) < 1e-5
+    assert torch.equal(dW[:, :sl * E], torch.full((Nout, sl * E), 0.5, device=dev))
+    assert _rel(db, (-1.0 + dy.double().sum(0)).float()) < 1e-5
