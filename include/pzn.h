@@ -401,6 +401,21 @@ int pzn_maxpool_points_fwd_f32(const float* x, int B, int L, int C, float* out, 
 int pzn_maxpool_points_bwd_f32(const float* dout, const int32_t* idx, int B, int L, int C,
                                float* dx, pzn_stream_t stream);
 
+/* Backward of "linear, then max over the points" (model5_b.py:474-475: out = self.out(att); f_global = max over
+ * dim 1) when only the maximum is used downstream (predict5, model5_b.py:723): the gradient of the [B*L, Nout]
+ * product has one non-zero per (cloud, channel), at row arg[b,c] (pzn_maxpool_points_fwd_f32's idx), so both
+ * products are B*Nout row operations instead of B*L*Nout*Kin multiply-adds:
+ *   dgrad:  dx[b,l,:] = sum over {c: arg[b,c]==l} dg[b,c] W[c,:]        (every element of dx written; Kin % 64 == 0,
+ *           L <= 600, W[Nout,Kin] dense)
+ *   wgrad:  dW[c, s*seg_cols + k] += sum_b dg[b,c] x_s[b, arg[b,c], k],  db[c] += sum_b dg[b,c]  (db may be NULL);
+ *           x is given as nseg <= 8 separate [B*L, seg_cols] tensors — the column blocks of a concatenation that
+ *           need not exist (x_segs: HOST array of nseg device pointers; seg_cols % 4 == 0; dW[Nout, nseg*seg_cols]).
+ * PZN_EUNSUPPORTED outside these shapes (callers then take pzn_maxpool_points_bwd_f32 + the dense products). */
+int pzn_linear_maxpts_dgrad_f32(const float* dg, const int32_t* arg, const float* W, int B, int L, int Kin,
+                                int Nout, float* dx, pzn_stream_t stream);
+int pzn_linear_maxpts_wgrad_f32(const float* dg, const int32_t* arg, const float* const* x_segs, int nseg,
+                                int seg_cols, int B, int L, int Nout, float* dW, float* db, pzn_stream_t stream);
+
 /* SE(3) exponential of the pose head (se_math/se3.py:57-80 with so3.mat and the Taylor-guarded
  * sinc1/2/3 of se_math/sinc.py): twist[B,6] = (w, v) -> g[B,4,4]; backward dg[B,4,4] ->
  * dtwist[B,6] (the last row of dg is ignored: it is constant). */

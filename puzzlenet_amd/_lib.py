@@ -40,6 +40,9 @@ SIGNATURES = {
     "pzn_linear_maxpool_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_linear_dgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_linear_wgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_i, _c_f]),
+    "pzn_linear_maxpts_dgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),
+    "pzn_linear_maxpts_wgrad_f32": (_c_i, [_c_f, _c_f, ctypes.POINTER(ctypes.c_void_p), _c_i, _c_i, _c_i, _c_i, _c_i, _c_f,
+                                    _c_f, _c_f]),
     "pzn_linear_slice_fwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_linear_slice_dgrad_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_linear_slice_wgrad_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_i, _c_f, _c_f]),

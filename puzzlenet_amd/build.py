@@ -26,6 +26,7 @@ SOURCES = [
     ("chamfer.hip", []),
     ("gemm.hip", []),
     ("poolbwd.hip", []),
+    ("maxptsbwd.hip", []),
     ("wsgemm.hip", []),
     ("dfgemm.hip", []),
     ("optim.hip", ["-ffp-contract=off"]),

@@ -165,9 +165,10 @@ class PCTransformer_nonsort(nn.Module):
         blocks = (self.atten1, self.atten2, self.atten3, self.atten4)
         if _ATTN_CHAIN and f2f.is_cuda and ops.attention_chain_supported(f2f, self.atten1.mlpq.weight.shape[0], self.out.weight):
             # :462-474 as one autograd node: no concatenation, no gradient-accumulation adds between the blocks
-            out, attention = ops.attention_chain_out(
+            out, attention, f_global = ops.attention_chain_out(
                 f2f, [(a.mlpq.weight, a.mlpq.bias, a.mlpk.weight, a.mlpk.bias, a.mlpv.weight, a.mlpv.bias, a.out.weight,
                        a.out.bias) for a in blocks], self.out.weight, self.out.bias)
+            return f_global, x2, attention, out, x_feature                                       # (:475 inside the node)
         else:
             att1, attention1 = self.atten1(f2f)
             att2, attention2 = self.atten2(att1)

@@ -4,6 +4,7 @@ torch is used for device memory, the current HIP stream and autograd plumbing
 only: every computation below is a call into libpzn.so with raw device
 pointers.  Inputs must live on a HIP device; there is no CPU path.
 """
+import ctypes
 import os
 import weakref
 
@@ -802,7 +803,11 @@ class _AttnChainOut(torch.autograd.Function):
     the out projection of cat([att1, att2, att3, att4, f2f]).  The concatenation is never built — out = sum_i x_i W_i^T + b
     over the five 256-column slices of W_out (pzn_linear_slice_fwd / _wgrad) — and the backward forms dy W_out once and
     adds each block's input gradient to its slice (one add per block instead of autograd's narrow copies + accumulations).
-    inputs: x[B,L,E], 4 x (wq,bq,wk,bk,wv,bv,wo,bo), w_out[Nout, 5E], b_out -> (out[B,L,Nout], attention[B,L,L])"""
+    The max over the points (:475) is part of the node: when `out` itself carries no gradient — the case in predict5,
+    which uses only the maximum — the projection's backward is one non-zero per (cloud, channel) and runs as sparse row
+    operations (pzn_linear_maxpts_*: 168 MFLOP instead of 2 x 43 GFLOP per encoder).
+    inputs: x[B,L,E], 4 x (wq,bq,wk,bk,wv,bv,wo,bo), w_out[Nout, 5E], b_out
+    -> (out[B,L,Nout], attention[B,L,L], f_global[B,Nout])"""
 
     @staticmethod
     def forward(ctx, x, *params):
@@ -834,27 +839,42 @@ class _AttnChainOut(torch.autograd.Function):
             for i, xi in enumerate(xs):
                 _call("pzn_linear_slice_fwd_f32", _p(xi), w_out.data_ptr() + 4 * E * i, 5 * E, _p(b_out), M, E, Nout,
                       int(i > 0), _p(y), _stream(), flops=2 * M * E * Nout)
-        ctx.save_for_backward(*([t for blk in saved for t in blk] + [cur] + ps))
+            f_global = mk(B, Nout)                                                  # :475 torch.max(out, dim=1)[0]
+            arg = torch.empty((B, Nout), dtype=torch.int32, device=dev)
+            _call("pzn_maxpool_points_fwd_f32", _p(y), B, L, Nout, _p(f_global), _p(arg), _stream())
+        ctx.save_for_backward(*([t for blk in saved for t in blk] + [cur] + ps + [arg]))
         ctx.dims = (B, L, E, dk, Nout)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(attention)      # (it only feeds an arg-max; its gradient would be zero)
-        return y.view(B, L, Nout), attention
+        return y.view(B, L, Nout), attention, f_global
 
     @staticmethod
-    def backward(ctx, dy, _dattention):
+    def backward(ctx, dy, _dattention, dfg):
         B, L, E, dk, Nout = ctx.dims
         t = ctx.saved_tensors
         saved = [t[7 * i: 7 * i + 7] for i in range(4)]
         att4 = t[28]
-        ps = t[29:]
+        ps = t[29:63]
+        arg = t[63]
         blocks = [ps[8 * i: 8 * i + 8] for i in range(4)]
         w_out, b_out = ps[32], ps[33]
         dev = att4.device
         M = B * L
         mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
-        if dy is None:
-            dy = torch.zeros((M, Nout), dtype=torch.float32, device=dev)
-        dy = _f32(dy, "dy").reshape(M, Nout)
+        # Only f_global used downstream (predict5, model5_b.py:723): the gradient of `out` has one non-zero per
+        # (cloud, channel) and both products of the out projection are sparse row operations (csrc/maxptsbwd.hip).
+        sparse = dy is None and dfg is not None and (5 * E) % 64 == 0 and L <= 600
+        if sparse:
+            dfg = _f32(dfg, "df_global")
+        else:
+            if dfg is not None:      # `out` itself carries a gradient too: dense products on the summed gradient
+                dmax = mk(B, L, Nout)
+                with torch.cuda.device(dev):
+                    _call("pzn_maxpool_points_bwd_f32", _p(_f32(dfg, "df_global")), _p(arg), B, L, Nout, _p(dmax), _stream())
+                dy = dmax if dy is None else dy + dmax
+            if dy is None:
+                dy = torch.zeros((M, Nout), dtype=torch.float32, device=dev)
+            dy = _f32(dy, "dy").reshape(M, Nout)
         xs = [saved[1][0], saved[2][0], saved[3][0], att4, saved[0][0]]           # inputs of the five slice products
         sink_w, sink_b = _sink(w_out, ctx.needs_input_grad[33]), _sink(b_out, ctx.needs_input_grad[34])
         direct_out = sink_w is not None and sink_b is not None
@@ -864,13 +884,18 @@ class _AttnChainOut(torch.autograd.Function):
         nbytes = _lib.load().pzn_attn_block_bwd_workspace_bytes(B, L, E, dk)
         ws = mk((nbytes + 3) // 4)
         with torch.cuda.device(dev):
-            for i, xi in enumerate(xs):      # dW_out[:, slice i] += dy^T x_i;  db_out += column sums (once)
-                _call("pzn_linear_slice_wgrad_f32", _p(dy), _p(xi), M, E, Nout, dW_out.data_ptr() + 4 * E * i, 5 * E,
-                      _p(db_out) if i == 0 else None, _stream(), flops=2 * M * E * Nout)
-            # dy W_out for all five slices in ONE product (a product per slice would stream dy five times)
             G = mk(M, 5 * E)
-            _call("pzn_linear_dgrad_f32", _p(dy), None, _p(w_out), M, 5 * E, Nout, None, _p(G), _stream(),
-                  flops=2 * M * 5 * E * Nout)
+            if sparse:
+                segs = (ctypes.c_void_p * 5)(*[_p(xi) for xi in xs])
+                _call("pzn_linear_maxpts_wgrad_f32", _p(dfg), _p(arg), segs, 5, E, B, L, Nout, _p(dW_out), _p(db_out), _stream())
+                _call("pzn_linear_maxpts_dgrad_f32", _p(dfg), _p(arg), _p(w_out), B, L, 5 * E, Nout, _p(G), _stream())
+            else:
+                for i, xi in enumerate(xs):      # dW_out[:, slice i] += dy^T x_i;  db_out += column sums (once)
+                    _call("pzn_linear_slice_wgrad_f32", _p(dy), _p(xi), M, E, Nout, dW_out.data_ptr() + 4 * E * i, 5 * E,
+                          _p(db_out) if i == 0 else None, _stream(), flops=2 * M * E * Nout)
+                # dy W_out for all five slices in ONE product (a product per slice would stream dy five times)
+                _call("pzn_linear_dgrad_f32", _p(dy), None, _p(w_out), M, 5 * E, Nout, None, _p(G), _stream(),
+                      flops=2 * M * 5 * E * Nout)
             g = G[:, 3 * E: 4 * E].contiguous()      # gradient of att4: its slice of the projection only
             for i in (3, 2, 1, 0):
                 xin, q, k, v, attn, r, yo = saved[i]
@@ -893,7 +918,8 @@ class _AttnChainOut(torch.autograd.Function):
 
 
 def attention_chain_out(x, blocks, w_out, b_out):
-    """blocks: four 8-tuples (wq, bq, wk, bk, wv, bv, wo, bo) -> (out[B,L,Nout], mean attention map[B,L,L])"""
+    """blocks: four 8-tuples (wq, bq, wk, bk, wv, bv, wo, bo)
+    -> (out[B,L,Nout], mean attention map[B,L,L], f_global[B,Nout] = max of out over the points)"""
     flat = [p_ for blk in blocks for p_ in blk]
     return _AttnChainOut.apply(x, *flat, w_out, b_out)
 

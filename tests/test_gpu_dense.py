@@ -357,11 +357,14 @@ def test_attention_block_bf16_mode(dev, attn_bf16):
         assert float((p_.grad.cpu().double() - q_.grad).abs().max()) < 2 * BF16_BWD_TOL * max(float(q_.grad.abs().max()), 0.25)
 
 
+@pytest.mark.parametrize("use", ["max", "out", "both"])
 @pytest.mark.parametrize("sinks", [False, True])
-def test_attention_chain_node_vs_composed(dev, sinks):
+def test_attention_chain_node_vs_composed(dev, sinks, use):
     """ops.attention_chain_out (model5_b.py:462-474 as one autograd node: four blocks, mean of the maps, out projection
     of the never-built concatenation) against the same thing composed from attention_block + avg4 + cat + linear:
-    outputs and every gradient (35 tensors), also with the parameter gradients going into registered sinks."""
+    outputs and every gradient (35 tensors), also with the parameter gradients going into registered sinks.
+    use = "max": only f_global = max over the points carries a gradient, as in predict5 — the out projection's backward
+    then runs as sparse row operations (csrc/maxptsbwd.hip); "out" / "both": the dense products."""
     from puzzlenet_amd import dense, ops
     B, L, E, dk, Nout = 20, 256, 256, 64, 1024
     g = torch.Generator().manual_seed(7)
@@ -371,6 +374,7 @@ def test_attention_chain_node_vs_composed(dev, sinks):
     w0 = (torch.randn(Nout, 5 * E, generator=g) / math.sqrt(5 * E)).to(dev)
     b0 = (0.1 * torch.randn(Nout, generator=g)).to(dev)
     wy = torch.randn(B, L, Nout, generator=g).to(dev)
+    wg = torch.randn(B, Nout, generator=g).to(dev)
 
     def run(chain):
         x = x0.clone().requires_grad_(True)
@@ -384,7 +388,7 @@ def test_attention_chain_node_vs_composed(dev, sinks):
             ops.register_grad_sinks(flat)
         if chain:
             assert ops.attention_chain_supported(x, dk, w)
-            y, a = ops.attention_chain_out(x, blocks, w, b)
+            y, a, fg = ops.attention_chain_out(x, blocks, w, b)
         else:
             cur, maps, outs = x, [], []
             for blk in blocks:
@@ -393,13 +397,19 @@ def test_attention_chain_node_vs_composed(dev, sinks):
                 outs.append(cur)
             a = ops.avg4(*maps)
             y = dense.linear(torch.cat(outs + [x], dim=-1), w, b)
-        (y * wy).sum().backward()
+            fg = ops.max_over_points(y)
+        loss = 0
+        if use in ("max", "both"):
+            loss = loss + (fg * wg).sum()
+        if use in ("out", "both"):
+            loss = loss + (y * wy).sum()
+        loss.backward()
         ops.clear_grad_sinks()
-        return y.detach(), a.detach(), x.grad, [p.grad for p in flat]
+        return y.detach(), a.detach(), x.grad, [p.grad for p in flat], fg.detach()
 
-    yc, ac, gxc, gpc = run(True)
-    yr, ar, gxr, gpr = run(False)
-    assert _rel(yc, yr) < 1e-5 and torch.equal(ac, ar)
+    yc, ac, gxc, gpc, fc = run(True)
+    yr, ar, gxr, gpr, fr = run(False)
+    assert _rel(yc, yr) < 1e-5 and torch.equal(ac, ar) and _rel(fc, fr) < 1e-5
     assert _rel(gxc, gxr) < 1e-4
     for a_, b_ in zip(gpc, gpr):
         assert float((a_ - b_).abs().max()) < 2e-4 * max(float(b_.abs().max()), 5e-2)
@@ -440,3 +450,37 @@ def test_linear_slice_entry_points(dev, M, E, Nout, nsl):
     assert _rel(dW, ref.float()) < 1e-5
     assert torch.equal(dW[:, :sl * E], torch.full((Nout, sl * E), 0.5, device=dev))
     assert _rel(db, (-1.0 + dy.double().sum(0)).float()) < 1e-5
+
+
+@pytest.mark.parametrize("B,L,seg_cols,nseg,Nout", [(64, 256, 256, 5, 1024), (7, 100, 64, 3, 70), (5, 33, 320, 1, 129)])
+def test_linear_maxpts_sparse_backward(dev, B, L, seg_cols, nseg, Nout):
+    """pzn_linear_maxpts_{dgrad,wgrad}_f32 (backward of linear + max over the points with one non-zero per (cloud,
+    channel)) against the dense float64 products on the scattered gradient; rows hit by many channels and rows hit by
+    none, dW / db pre-filled (the kernels add), x given as separate column blocks."""
+    import ctypes
+    from puzzlenet_amd import _lib
+    g = torch.Generator().manual_seed(B * L + Nout)
+    Kin = nseg * seg_cols
+    W = torch.randn(Nout, Kin, generator=g).to(dev)
+    xs = [torch.randn(B * L, seg_cols, generator=g).to(dev) for _ in range(nseg)]
+    dg = torch.randn(B, Nout, generator=g).to(dev)
+    arg = torch.randint(0, L, (B, Nout), generator=g).to(torch.int32)
+    arg[:, : Nout // 2] = arg[:, : Nout // 2] % 3          # half of the channels pile onto three rows
+    arg = arg.to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    dout = torch.zeros(B, L, Nout, dtype=torch.float64, device=dev)
+    dout.scatter_(1, arg.long().unsqueeze(1), dg.double().unsqueeze(1))
+    dx = torch.full((B * L, Kin), float("nan"), device=dev)
+    _lib.call("pzn_linear_maxpts_dgrad_f32", dg.data_ptr(), arg.data_ptr(), W.data_ptr(), B, L, Kin, Nout, dx.data_ptr(), st)
+    ref = dout.reshape(B * L, Nout) @ W.double()
+    assert _rel(dx, ref.float()) < 1e-5
+    never = (dout != 0).sum(dim=2).reshape(-1) == 0
+    assert bool((dx[never] == 0).all())                    # rows no channel selected: exact zeros
+    dW = torch.full((Nout, Kin), 0.25, device=dev)
+    db = torch.full((Nout,), -2.0, device=dev)
+    segs = (ctypes.c_void_p * nseg)(*[x.data_ptr() for x in xs])
+    _lib.call("pzn_linear_maxpts_wgrad_f32", dg.data_ptr(), arg.data_ptr(), segs, nseg, seg_cols, B, L, Nout, dW.data_ptr(),
+              db.data_ptr(), st)
+    ref = 0.25 + dout.reshape(B * L, Nout).t() @ torch.cat(xs, 1).double()
+    assert _rel(dW, ref.float()) < 1e-5
+    assert _rel(db, (-2.0 + dg.double().sum(0)).float()) < 1e-5
