@@ -406,13 +406,16 @@ int pzn_maxpool_points_bwd_f32(const float* dout, const int32_t* idx, int B, int
  * product has one non-zero per (cloud, channel), at row arg[b,c] (pzn_maxpool_points_fwd_f32's idx), so both
  * products are B*Nout row operations instead of B*L*Nout*Kin multiply-adds:
  *   dgrad:  dx[b,l,:] = sum over {c: arg[b,c]==l} dg[b,c] W[c,:]        (every element of dx written; Kin % 64 == 0,
- *           L <= 600, W[Nout,Kin] dense)
+ *           L <= 600, Nout <= 16384, W[Nout,Kin] dense; workspace of pzn_linear_maxpts_workspace_bytes(B, Nout)
+ *           bytes, 16-byte aligned: the channels of each cloud sorted by selected row; summation order is fixed,
+ *           results are reproducible)
  *   wgrad:  dW[c, s*seg_cols + k] += sum_b dg[b,c] x_s[b, arg[b,c], k],  db[c] += sum_b dg[b,c]  (db may be NULL);
  *           x is given as nseg <= 8 separate [B*L, seg_cols] tensors — the column blocks of a concatenation that
  *           need not exist (x_segs: HOST array of nseg device pointers; seg_cols % 4 == 0; dW[Nout, nseg*seg_cols]).
  * PZN_EUNSUPPORTED outside these shapes (callers then take pzn_maxpool_points_bwd_f32 + the dense products). */
+size_t pzn_linear_maxpts_workspace_bytes(int B, int Nout);
 int pzn_linear_maxpts_dgrad_f32(const float* dg, const int32_t* arg, const float* W, int B, int L, int Kin,
-                                int Nout, float* dx, pzn_stream_t stream);
+                                int Nout, void* workspace, float* dx, pzn_stream_t stream);
 int pzn_linear_maxpts_wgrad_f32(const float* dg, const int32_t* arg, const float* const* x_segs, int nseg,
                                 int seg_cols, int B, int L, int Nout, float* dW, float* db, pzn_stream_t stream);
 

@@ -40,7 +40,8 @@ SIGNATURES = {
     "pzn_linear_maxpool_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_linear_dgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_linear_wgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_i, _c_f]),
-    "pzn_linear_maxpts_dgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),
+    "pzn_linear_maxpts_workspace_bytes": (_c_sz, [_c_i, _c_i]),
+    "pzn_linear_maxpts_dgrad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_linear_maxpts_wgrad_f32": (_c_i, [_c_f, _c_f, ctypes.POINTER(ctypes.c_void_p), _c_i, _c_i, _c_i, _c_i, _c_i, _c_f,
                                     _c_f, _c_f]),
     "pzn_linear_slice_fwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),

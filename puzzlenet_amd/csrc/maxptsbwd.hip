@@ -17,71 +17,107 @@ constexpr int MD_COLS = 64;      // columns of dx per workgroup (one per lane)
 constexpr int MD_THREADS = 1024;  // 16 wavefronts share the channel loop
 constexpr int MD_LDS_LIMIT = 150 * 1024;
 
-// dgrad: workgroup = (cloud, 64-column chunk), clouds on the fast grid axis (the workgroups resident at any time share
-// one or two 256-KB column chunks of W, which stay in every XCD's L2).  The [L][64] slab of dx lives in LDS.  Rows are
-// OWNED by wavefronts (row % 16 == wave), so the slab is updated with plain read-add-write — LDS operations of one
-// wavefront execute in order — and in a fixed order (ascending channel): the result is reproducible bit for bit.
-// (First version: every wavefront took every 16th channel and added with ds_add_f32; 425 us per launch, slower than
-// the dense product.)  Channels are bucketed by owner first: each wavefront finds its channels with a ballot per 64
-// (count pass, offsets by a 16-entry scan, fill pass: ascending lists in LDS), then walks its list eight channels at a
-// time: eight coalesced 256-byte reads of W[c, chunk] in flight, scaled by dg[b,c], added to row arg[b,c].  The slab is
-// streamed out whole, so rows nobody selected are written as zeros and dx needs no zero fill.
+// dgrad, step 1: per cloud, the channels sorted by (selected row, channel): keys (row << 16 | c) are unique, so a
+// bitonic sort in LDS gives the stable order; one workgroup per cloud, 55 compare-exchange stages for 1024 channels.
+__global__ __launch_bounds__(1024) void maxpts_sort_kernel(const int32_t* __restrict__ arg, int L, int Nout, int npad,
+                                                           uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t keys[];  // [npad]
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < npad; c += blockDim.x)
+    keys[c] = c < Nout ? ((uint32_t)min(max(arg[(size_t)b * Nout + c], 0), L - 1) << 16) | (uint32_t)c : 0xFFFFFFFFu;
+  __syncthreads();
+  for (int k = 2; k <= npad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+        const int p = i ^ j;
+        if (p > i) {
+          const uint32_t x = keys[i], y = keys[p];
+          if ((x > y) == ((i & k) == 0)) keys[i] = y, keys[p] = x;
+        }
+      }
+      __syncthreads();
+    }
+  for (int c = threadIdx.x; c < Nout; c += blockDim.x) sorted[(size_t)b * Nout + c] = keys[c];
+}
+
+// dgrad, step 2: workgroup = (cloud, 64-column chunk), clouds on the fast grid axis (the workgroups resident at any
+// time share one or two 256-KB column chunks of W, which stay in every XCD's L2).  The [L][64] slab of dx lives in LDS.
+// The sorted channel list is cut into 16 equal segments, one per wavefront, whatever the rows are — arg-max rows pile
+// up (in the training step most channels of a cloud select a handful of points), so ownership by row would leave one
+// wavefront with most of the work.  A wavefront walks its segment eight channels at a time (eight coalesced 256-byte
+// reads of W[c, chunk] in flight), sums runs of equal row in registers and stores a finished run to the slab; only its
+// first and last run can continue in a neighbour's segment: those go to a side buffer and one wavefront adds them in
+// segment order afterwards.  No atomics (ds_add_f32 made a first version 7x slower than this), and a fixed summation
+// order: results are reproducible bit for bit.  The slab is streamed out whole, so rows nobody selected are written as
+// zeros and dx needs no zero fill.
 __global__ __launch_bounds__(MD_THREADS) void maxpts_lin_dgrad_kernel(const float* __restrict__ dg,
-                                                                      const int32_t* __restrict__ arg,
+                                                                      const uint32_t* __restrict__ sorted,
                                                                       const float* __restrict__ W, int L, int Kin, int Nout,
                                                                       float* __restrict__ dx) {
-  extern __shared__ float slab[];  // [L][MD_COLS], then arg[Nout], dg[Nout], list[Nout]
+  extern __shared__ float slab[];  // [L][MD_COLS]
   constexpr int NW = MD_THREADS / 64;
-  __shared__ int cnt[NW];
-  int* sa = reinterpret_cast<int*>(slab + (size_t)L * MD_COLS);
-  float* sg = reinterpret_cast<float*>(sa + Nout);
-  int* list = reinterpret_cast<int*>(sg + Nout);
+  __shared__ float bnd[NW][2][MD_COLS];
+  __shared__ int bnd_row[NW][2];
   const int b = blockIdx.x, col0 = blockIdx.y * MD_COLS;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int i = threadIdx.x; i < L * MD_COLS; i += MD_THREADS) slab[i] = 0.f;
-  for (int c = threadIdx.x; c < Nout; c += MD_THREADS) {
-    sa[c] = min(max(arg[(size_t)b * Nout + c], 0), L - 1);      // (clamp: a bad index must not leave the slab)
-    sg[c] = dg[(size_t)b * Nout + c];
-  }
+  if (lane < 2) bnd_row[wave][lane] = -1;
   __syncthreads();
-  int mine = 0;
-  for (int c0 = 0; c0 < Nout; c0 += 64) {
-    const int c = c0 + lane;
-    const bool hit = c < Nout && (sa[c] & (NW - 1)) == wave;
-    mine += __popcll(__ballot(hit));
-  }
-  if (lane == 0) cnt[wave] = mine;
-  __syncthreads();
-  int off = 0;
-  for (int v = 0; v < wave; ++v) off += cnt[v];
-  int fill = off;
-  for (int c0 = 0; c0 < Nout; c0 += 64) {
-    const int c = c0 + lane;
-    const bool hit = c < Nout && (sa[c] & (NW - 1)) == wave;
-    const uint64_t m = __ballot(hit);
-    if (hit) list[fill + __popcll(m & ((1ull << lane) - 1ull))] = c;
-    fill += __popcll(m);
-  }
-  pzn::wave_lds_sync();      // the list segment is read by this wavefront only
+  const int seg = (Nout + NW - 1) / NW;
+  const int i0 = wave * seg, i1 = min(Nout, i0 + seg);
   const float* w = W + col0 + lane;
-  constexpr int U = 8;
-  int i = off;
-  const int end = off + mine;
-  for (; i + U <= end; i += U) {
-    float wv[U], gv[U];
-    int av[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int c = __builtin_amdgcn_readfirstlane(list[i + u]);
-      wv[u] = w[(size_t)c * Kin], gv[u] = sg[c], av[u] = sa[c];
+  int cur = -1, runs = 0;
+  float acc = 0.f;
+  for (int base = i0; base < i1; base += 64) {
+    const int n = min(64, i1 - base);
+    uint32_t key = 0;
+    float gl = 0.f;
+    if (lane < n) {
+      key = sorted[(size_t)b * Nout + base + lane];
+      gl = dg[(size_t)b * Nout + (key & 0xFFFFu)];
     }
+    for (int t0 = 0; t0 < n; t0 += 8) {
+      float wv[8];
 #pragma unroll
-    for (int u = 0; u < U; ++u) slab[av[u] * MD_COLS + lane] += gv[u] * wv[u];
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t ku = (uint32_t)__builtin_amdgcn_readlane((int)key, min(t0 + u, n - 1));
+        wv[u] = w[(size_t)(ku & 0xFFFFu) * Kin];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (t0 + u < n) {
+          const uint32_t ku = (uint32_t)__builtin_amdgcn_readlane((int)key, t0 + u);
+          const float gu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gl), t0 + u));
+          const int row = (int)(ku >> 16);
+          if (row != cur) {
+            if (cur >= 0) {
+              if (runs == 0) {      // the segment's first run may have begun in the previous segment
+                bnd[wave][0][lane] = acc;
+                if (lane == 0) bnd_row[wave][0] = cur;
+              } else {
+                slab[cur * MD_COLS + lane] = acc;
+              }
+              ++runs;
+            }
+            cur = row, acc = 0.f;
+          }
+          acc += gu * wv[u];
+        }
+      }
+    }
   }
-  for (; i < end; ++i) {
-    const int c = __builtin_amdgcn_readfirstlane(list[i]);
-    slab[sa[c] * MD_COLS + lane] += sg[c] * w[(size_t)c * Kin];
+  if (cur >= 0) {      // the last run may continue in the next segment (it is also the first one when runs == 0)
+    bnd[wave][runs == 0 ? 0 : 1][lane] = acc;
+    if (lane == 0) bnd_row[wave][runs == 0 ? 0 : 1] = cur;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    for (int v = 0; v < NW; ++v)
+      for (int e = 0; e < 2; ++e) {
+        const int r = bnd_row[v][e];
+        if (r >= 0) slab[r * MD_COLS + lane] += bnd[v][e][lane];
+      }
   }
   __syncthreads();
   // 16 lanes x 16 bytes = one 256-byte row segment; 64 rows per pass of the workgroup
@@ -157,11 +193,19 @@ __global__ __launch_bounds__(256) void maxpts_lin_wgrad_kernel(const float* __re
 
 }  // namespace
 
+PZN_EXPORT size_t pzn_linear_maxpts_workspace_bytes(int B, int Nout) {
+  return B > 0 && Nout > 0 ? (size_t)B * Nout * sizeof(uint32_t) : 0;
+}
+
 PZN_EXPORT int pzn_linear_maxpts_dgrad_f32(const float* dg, const int32_t* arg, const float* W, int B, int L, int Kin,
-                                           int Nout, float* dx, pzn_stream_t stream) {
-  PZN_CHECK_ARG(dg && arg && W && dx && B > 0 && B <= 65535 && L > 0 && Kin > 0 && Nout > 0);
-  const size_t lds = (size_t)L * MD_COLS * sizeof(float) + (size_t)Nout * 12;
-  if (Kin % MD_COLS != 0 || lds > (size_t)MD_LDS_LIMIT || (reinterpret_cast<uintptr_t>(dx) & 15) != 0) return PZN_EUNSUPPORTED;
+                                           int Nout, void* workspace, float* dx, pzn_stream_t stream) {
+  PZN_CHECK_ARG(dg && arg && W && dx && workspace && B > 0 && B <= 65535 && L > 0 && Kin > 0 && Nout > 0);
+  const size_t lds = (size_t)L * MD_COLS * sizeof(float);
+  int npad = 64;
+  while (npad < Nout) npad <<= 1;
+  if (Kin % MD_COLS != 0 || lds > (size_t)MD_LDS_LIMIT || L > 65535 || Nout > 16384 ||
+      ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0)
+    return PZN_EUNSUPPORTED;
   static bool attr_set = false;      // (benign race: the attribute is idempotent)
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(maxpts_lin_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -169,8 +213,12 @@ PZN_EXPORT int pzn_linear_maxpts_dgrad_f32(const float* dg, const int32_t* arg, 
       return PZN_ELAUNCH;
     attr_set = true;
   }
+  uint32_t* sorted = static_cast<uint32_t*>(workspace);
+  hipLaunchKernelGGL(maxpts_sort_kernel, dim3((unsigned)B), dim3(1024), (size_t)npad * sizeof(uint32_t), pzn_hip_stream(stream),
+                     arg, L, Nout, npad, sorted);
+  if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
   hipLaunchKernelGGL(maxpts_lin_dgrad_kernel, dim3((unsigned)B, (unsigned)(Kin / MD_COLS)), dim3(MD_THREADS), lds,
-                     pzn_hip_stream(stream), dg, arg, W, L, Kin, Nout, dx);
+                     pzn_hip_stream(stream), dg, sorted, W, L, Kin, Nout, dx);
   PZN_RETURN_LAUNCH_STATUS();
 }
 

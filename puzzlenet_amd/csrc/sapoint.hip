@@ -328,6 +328,33 @@ __global__ __launch_bounds__(SP_T) void sa_point_l1_bwd_kernel(const float* __re
 // P[row, :] += W1[:, 0:3] xyz[row]  (rows = B*N points)   and   Q[g, :] = b1 - W1[:, 0:3] new_xyz[g]  (g = B*S groups):
 // with the coordinate term split this way a generated row is relu(P[idx] + Q[g]) — one add and one max per element
 // where the round-1 form needed three fmas with per-row broadcasts.  Thread = 4 channels of one row / group.
+// One multiply-add of the coordinate term kept out of the packed-fp32 unit.  Under plain -O3 the compiler pairs the four
+// channels of a thread into v_pk_mul_f32 / v_pk_fma_f32 with op_sel modifiers (one coordinate against two weights).
+// Measured on MI355X: while a workgroup of the general matrix-core engine (gemm_kernel) or of the generated-row kernel
+// shares the CU — the other encoder's stream — that packed form returned sums with the y term missing in lanes 48-63
+// (a few rows per launch, 0.1-0.2 absolute in P; tests/test_gpu_concurrency.py reproduces it).  The same arithmetic as
+// single v_fma_f32 / v_mul_f32 (bit-identical results) is not affected, and this kernel is bound by its row traffic anyway.
+__device__ __forceinline__ float prep_mul(float a, float b) {
+  float r;
+  asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float prep_fma(float a, float b, float c) {
+  float r;
+  asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float prep_add(float a, float b) {
+  float r;
+  asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float prep_sub(float a, float b) {
+  float r;
+  asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __global__ __launch_bounds__(256) void sa_prep_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                       const float* __restrict__ W1, int ldw, const float* __restrict__ b1,
                                                       long prow, long groups, int C1, float* __restrict__ P,
@@ -337,30 +364,25 @@ __global__ __launch_bounds__(256) void sa_prep_kernel(const float* __restrict__ 
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const long r = e / c4;
     const int c = (int)(e - r * c4) * 4;
-    float wx[4], wy[4], wz[4];
+    const bool point = r < prow;
+    const float* q = point ? xyz + (size_t)r * 3 : new_xyz + (size_t)(r - prow) * 3;
+    const float x = q[0], y = q[1], z = q[2];
+    float t[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      wx[i] = W1[(size_t)(c + i) * ldw], wy[i] = W1[(size_t)(c + i) * ldw + 1], wz[i] = W1[(size_t)(c + i) * ldw + 2];
-    if (r < prow) {
-      const float* q = xyz + (size_t)r * 3;
-      const float x = q[0], y = q[1], z = q[2];
+    for (int i = 0; i < 4; ++i) {      // fmaf(wz, z, fmaf(wy, y, wx * x))
+      const float* w = W1 + (size_t)(c + i) * ldw;
+      t[i] = prep_fma(w[2], z, prep_fma(w[1], y, prep_mul(w[0], x)));
+    }
+    if (point) {
       float4* o = reinterpret_cast<float4*>(P + (size_t)r * C1 + c);
       float4 v = *o;
-      v.x += fmaf(wz[0], z, fmaf(wy[0], y, wx[0] * x));
-      v.y += fmaf(wz[1], z, fmaf(wy[1], y, wx[1] * x));
-      v.z += fmaf(wz[2], z, fmaf(wy[2], y, wx[2] * x));
-      v.w += fmaf(wz[3], z, fmaf(wy[3], y, wx[3] * x));
+      v.x = prep_add(v.x, t[0]), v.y = prep_add(v.y, t[1]), v.z = prep_add(v.z, t[2]), v.w = prep_add(v.w, t[3]);
       *o = v;
     } else {
-      const long g = r - prow;
-      const float* q = new_xyz + (size_t)g * 3;
-      const float x = q[0], y = q[1], z = q[2];
       float4 v;
-      v.x = (b1 ? b1[c] : 0.f) - fmaf(wz[0], z, fmaf(wy[0], y, wx[0] * x));
-      v.y = (b1 ? b1[c + 1] : 0.f) - fmaf(wz[1], z, fmaf(wy[1], y, wx[1] * x));
-      v.z = (b1 ? b1[c + 2] : 0.f) - fmaf(wz[2], z, fmaf(wy[2], y, wx[2] * x));
-      v.w = (b1 ? b1[c + 3] : 0.f) - fmaf(wz[3], z, fmaf(wy[3], y, wx[3] * x));
-      *reinterpret_cast<float4*>(Q + (size_t)g * C1 + c) = v;
+      v.x = prep_sub(b1 ? b1[c] : 0.f, t[0]), v.y = prep_sub(b1 ? b1[c + 1] : 0.f, t[1]);
+      v.z = prep_sub(b1 ? b1[c + 2] : 0.f, t[2]), v.w = prep_sub(b1 ? b1[c + 3] : 0.f, t[3]);
+      *reinterpret_cast<float4*>(Q + (size_t)(r - prow) * C1 + c) = v;
     }
   }
 }

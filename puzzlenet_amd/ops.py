@@ -888,7 +888,8 @@ class _AttnChainOut(torch.autograd.Function):
             if sparse:
                 segs = (ctypes.c_void_p * 5)(*[_p(xi) for xi in xs])
                 _call("pzn_linear_maxpts_wgrad_f32", _p(dfg), _p(arg), segs, 5, E, B, L, Nout, _p(dW_out), _p(db_out), _stream())
-                _call("pzn_linear_maxpts_dgrad_f32", _p(dfg), _p(arg), _p(w_out), B, L, 5 * E, Nout, _p(G), _stream())
+                mws = torch.empty((_lib.load().pzn_linear_maxpts_workspace_bytes(B, Nout) + 3) // 4, dtype=torch.int32, device=dev)
+                _call("pzn_linear_maxpts_dgrad_f32", _p(dfg), _p(arg), _p(w_out), B, L, 5 * E, Nout, _p(mws), _p(G), _stream())
             else:
                 for i, xi in enumerate(xs):      # dW_out[:, slice i] += dy^T x_i;  db_out += column sums (once)
                     _call("pzn_linear_slice_wgrad_f32", _p(dy), _p(xi), M, E, Nout, dW_out.data_ptr() + 4 * E * i, 5 * E,

@@ -1,0 +1,85 @@
+"""Kernels that share the chip with another stream's kernels must give the results they give alone.
+
+The training step runs the two encoders on two HIP streams, so workgroups of different kernels sit on the same CU.  This
+caught a real fault: the packed-fp32 form of the set-abstraction prep kernel (v_pk_fma_f32 with op_sel modifiers) returned
+sums with one term missing in lanes 48-63 while the general matrix-core engine ran beside it (csrc/sapoint.hip).  Every
+deterministic forward kernel family is run alone (reference, checked to be bit-reproducible) and then 40 times while an
+aggressor kernel is kept busy on a second stream; outputs must be bit-identical."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPS = 40
+
+
+@pytest.fixture(scope="module")
+def rig():
+    from puzzlenet_amd import dense, ops
+    from puzzlenet_amd.ops import _call, _p
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    B, N, S, D, C1, C2 = 8, 2048, 512, 64, 128, 128
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    feat = torch.randn(B, N, D, generator=g).to(dev)
+    new_xyz = ops.index_points(xyz, ops.farthest_point_sample(xyz, S, torch.zeros(B, dtype=torch.long, device=dev)))
+    w1 = (torch.randn(C1, 3 + D, generator=g) / 8).to(dev)
+    b1 = torch.randn(C1, generator=g).to(dev)
+    w2 = (torch.randn(C2, C1, generator=g) / 11).to(dev)
+    b2 = torch.randn(C2, generator=g).to(dev)
+    a_pts, b_pts = torch.rand(16, 512, 3, generator=g).to(dev), torch.rand(16, 512, 3, generator=g).to(dev)
+    xa = (0.5 * torch.randn(16, 256, 256, generator=g)).to(dev)
+    aw = [(torch.randn(*s, generator=g) / (16 if len(s) == 2 else 4)).to(dev)
+          for s in [(64, 256), (64,), (64, 256), (64,), (256, 256), (256,), (256, 256), (256,)]]
+    xl = torch.randn(32768, 64, generator=g).to(dev)
+    wl, bl = (torch.randn(64, 64, generator=g) / 8).to(dev), torch.randn(64, generator=g).to(dev)
+    xg = torch.randn(4096, 1280, generator=g).to(dev)
+    wg = (torch.randn(1024, 1280, generator=g) / 30).to(dev)
+    yg = torch.empty(4096, 1024, device=dev)
+    side = torch.cuda.Stream()
+    victims = {
+        "knn": lambda: ops.knn(xyz, new_xyz, 32),
+        "knn_group": lambda: ops.knn_group(xyz, feat, new_xyz)[0],
+        "fps": lambda: ops.farthest_point_sample(xyz, 256, torch.zeros(B, dtype=torch.long, device=dev)),
+        "ball_query": lambda: ops.ball_query(0.2, 32, xyz, new_xyz),
+        "sa_level": lambda: ops.sa_mlp_max(xyz, feat, new_xyz, None, w1, b1, w2, b2),
+        "chamfer": lambda: torch.cat([t.reshape(-1).float() for t in ops.chamfer(a_pts, b_pts)]),
+        "attention_block": lambda: ops.attention_block(xa, *aw)[0],
+        "linear_weight_stationary": lambda: dense.linear(xl, wl, bl, relu=True),
+        "linear_general_engine": lambda: dense.linear(xg, wg, None),
+        "max_over_points": lambda: ops.max_over_points(xa),
+    }
+
+    def agg_general():
+        _call("pzn_linear_fwd_f32", _p(xg), _p(wg), None, 4096, 1280, 1024, 0, _p(yg), side.cuda_stream)
+
+    def agg_level():
+        with torch.cuda.stream(side):
+            ops.sa_mlp_max(xyz, feat, new_xyz, None, w1, b1, w2, b2)
+
+    def agg_attention():
+        with torch.cuda.stream(side):
+            ops.attention_block(xa, *aw)
+
+    return dev, side, victims, {"general_engine": agg_general, "sa_level": agg_level, "attention_block": agg_attention}
+
+
+@pytest.mark.parametrize("aggressor", ["general_engine", "sa_level", "attention_block"])
+def test_results_do_not_depend_on_the_other_stream(rig, aggressor):
+    dev, side, victims, aggressors = rig
+    ag = aggressors[aggressor]
+    report = {}
+    with torch.no_grad():
+        for name, fn in victims.items():
+            ref, again = fn(), fn()
+            torch.cuda.synchronize()
+            assert torch.equal(ref, again), f"{name} is not reproducible even alone"
+            bad = torch.zeros((), dtype=torch.int64, device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            for _ in range(REPS):
+                ag()
+                ag()
+                bad += (fn() != ref).sum()
+            torch.cuda.synchronize()
+            if int(bad):
+                report[name] = int(bad)
+    assert not report, f"wrong elements over {REPS} launches beside {aggressor}: {report}"

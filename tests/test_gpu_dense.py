@@ -471,7 +471,13 @@ def test_linear_maxpts_sparse_backward(dev, B, L, seg_cols, nseg, Nout):
     dout = torch.zeros(B, L, Nout, dtype=torch.float64, device=dev)
     dout.scatter_(1, arg.long().unsqueeze(1), dg.double().unsqueeze(1))
     dx = torch.full((B * L, Kin), float("nan"), device=dev)
-    _lib.call("pzn_linear_maxpts_dgrad_f32", dg.data_ptr(), arg.data_ptr(), W.data_ptr(), B, L, Kin, Nout, dx.data_ptr(), st)
+    ws = torch.empty(_lib.load().pzn_linear_maxpts_workspace_bytes(B, Nout) // 4, dtype=torch.int32, device=dev)
+    _lib.call("pzn_linear_maxpts_dgrad_f32", dg.data_ptr(), arg.data_ptr(), W.data_ptr(), B, L, Kin, Nout, ws.data_ptr(),
+              dx.data_ptr(), st)
+    dx2 = torch.empty_like(dx)
+    _lib.call("pzn_linear_maxpts_dgrad_f32", dg.data_ptr(), arg.data_ptr(), W.data_ptr(), B, L, Kin, Nout, ws.data_ptr(),
+              dx2.data_ptr(), st)
+    assert torch.equal(dx, dx2)                            # fixed summation order: reproducible bit for bit
     ref = dout.reshape(B * L, Nout) @ W.double()
     assert _rel(dx, ref.float()) < 1e-5
     never = (dout != 0).sum(dim=2).reshape(-1) == 0

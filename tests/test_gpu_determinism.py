@@ -1,0 +1,113 @@
+"""Forward reproducibility: with the same inputs and the same FPS start indices the forward pass must give the same
+outputs run after run — bit-identical where no kernel sums with atomics (point ops, set abstraction, attention), within
+summation-order noise (1e-6 of the largest entry) where split-K epilogues add atomically (the few-row pose head).  A larger
+difference means a race between wavefronts or streams.  The stages are checked separately so that a failure names its
+kernel."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref as mr
+
+pytestmark = pytest.mark.gpu
+REPS = 12
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _same(a, b):
+    if isinstance(a, torch.Tensor):
+        return torch.equal(a, b)
+    return all(_same(x, y) for x, y in zip(a, b))
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def test_knn_and_group_repeatable(golden_model, dev):
+    from puzzlenet_amd import ops
+    G = golden_model
+    xyz = _t(G["p5_batch0"], dev)
+    g = torch.Generator().manual_seed(5)
+    feat = torch.randn(xyz.shape[0], xyz.shape[1], 64, generator=g).to(dev)
+    new_xyz = xyz[:, ::2].contiguous()
+    first = None
+    for _ in range(REPS):
+        idx = ops.knn(xyz, new_xyz, 32)
+        out, gx, idx2 = ops.knn_group(xyz, feat, new_xyz)
+        cur = tuple(t for t in (idx, out, gx, idx2) if t is not None)
+        first = first or cur
+        assert _same(cur, first)
+        assert torch.equal(idx, idx2)
+
+
+@pytest.mark.parametrize("two_streams", [False, True])
+def test_predict5_forward_repeatable(golden_model, dev, two_streams):
+    from puzzlenet_amd import model5_b as mb
+    G = golden_model
+    m = mb.TouchedRegraster(mr.Cfg())
+    mr.fill_params(m)
+    m.to(dev)
+    m.two_streams = two_streams
+    batch = [_t(G[f"p5_batch{i}"], dev) for i in range(8)]
+    first = None
+    names = ["pose", "x2", "attention", "mrpc_x2", "mrpc_attention", "de_fpcb", "de_mrpcb"]
+    for r in range(REPS):
+        torch.manual_seed(2024)
+        with torch.no_grad():
+            out = m.predict5(batch, 4, need=True, training=True)
+        cur = [out[0], out[2], out[3], out[4], out[5], out[6], out[7]]
+        torch.cuda.synchronize()
+        if first is None:
+            first = [t.clone() for t in cur]
+            continue
+        rel = {n: _rel(a, b) for n, a, b in zip(names, cur, first)}
+        bad = {n: v for n, v in rel.items() if v > (1e-6 if n in ("pose", "de_fpcb", "de_mrpcb") else 0.0)}
+        assert not bad, f"run {r}: {bad} differ from run 0"
+
+
+def test_encoder_stages_repeatable(golden_model, dev):
+    """the encoder's stages one by one on the same inputs: set abstraction (search + P'/Q + generated-row max-pool kernel),
+    attention chain node"""
+    from puzzlenet_amd import dense, model5_b as mb, ops
+    G = golden_model
+    m = mb.TouchedRegraster(mr.Cfg())
+    mr.fill_params(m)
+    m.to(dev)
+    enc = m.Encoder
+    xyz = _t(G["p5_batch0"], dev)
+    with torch.no_grad():
+        xf = enc.local_features(xyz)
+        f1 = ops.farthest_point_sample(xyz, 512, torch.zeros(xyz.shape[0], dtype=torch.long, device=dev))
+        x1 = ops.index_points(xyz, f1)
+        f2 = ops.farthest_point_sample(x1, 256, torch.zeros(xyz.shape[0], dtype=torch.long, device=dev))
+        x2 = ops.index_points(x1, f2)
+        first = None
+        for r in range(REPS):
+            xf_r = enc.local_features(xyz)
+            a = dense.sa_mlp_max(xyz, xf, x1, None, enc.mlp3.weight, enc.mlp3.bias, enc.mlp4.weight, enc.mlp4.bias)
+            b = dense.sa_mlp_max(x1, a, x2, None, enc.mlp5.weight, enc.mlp5.bias, enc.mlp6.weight, enc.mlp6.bias)
+            cur = {"local_features": xf_r, "sa1": a, "sa2": b}
+            x = b
+            for i, blk in enumerate((enc.atten1, enc.atten2, enc.atten3, enc.atten4)):
+                x, amap = blk(x)
+                cur[f"att{i + 1}"], cur[f"map{i + 1}"] = x, amap
+            cur["out"] = dense.linear(torch.cat([cur["att1"], cur["att2"], cur["att3"], cur["att4"], b], dim=-1),
+                                      enc.out.weight, enc.out.bias)
+            cur["max"] = ops.max_over_points(cur["out"])
+            torch.cuda.synchronize()
+            if first is None:
+                first = {k: v.clone() for k, v in cur.items()}
+                continue
+            bad = {k: _rel(cur[k], first[k]) for k in cur if not torch.equal(cur[k], first[k])}
+            assert not bad, f"run {r}: {bad} differ from run 0"

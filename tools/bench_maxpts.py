@@ -38,9 +38,11 @@ def main():
     dW = torch.zeros(Nout, Kin, device=dev)
     db = torch.zeros(Nout, device=dev)
     segs = (ctypes.c_void_p * nseg)(*[x.data_ptr() for x in xs])
-    t = timeit(lambda: _lib.call("pzn_linear_maxpts_dgrad_f32", dg.data_ptr(), arg.data_ptr(), W.data_ptr(), B, L, Kin, Nout,
-                                 dx.data_ptr(), st))
-    print(f"sparse dgrad  {t:8.1f} us   (dx write {dx.numel() * 4 / t / 1e6:.2f} TB/s)")
+    ws = torch.empty(_lib.load().pzn_linear_maxpts_workspace_bytes(B, Nout) // 4, dtype=torch.int32, device=dev)
+    for name, a in (("spread", arg), ("piled up", (arg % 3).contiguous()), ("one row", torch.zeros_like(arg))):
+        t = timeit(lambda: _lib.call("pzn_linear_maxpts_dgrad_f32", dg.data_ptr(), a.data_ptr(), W.data_ptr(), B, L, Kin, Nout,
+                                     ws.data_ptr(), dx.data_ptr(), st))
+        print(f"sparse dgrad ({name:8s}) {t:8.1f} us   (dx write {dx.numel() * 4 / t / 1e6:.2f} TB/s)")
     t = timeit(lambda: _lib.call("pzn_linear_maxpts_wgrad_f32", dg.data_ptr(), arg.data_ptr(), segs, nseg, E, B, L, Nout,
                                  dW.data_ptr(), db.data_ptr(), st))
     print(f"sparse wgrad  {t:8.1f} us")
