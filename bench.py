@@ -148,7 +148,7 @@ def cpu_baseline(N, pairs, iters):
 
 
 def build_id():
-    """Hash of the sources libpzn.so is built from (csrc/*, include/pzn.h): PMC byte counts collected on another build
+    """Hash of the sources libpzn.so is built from (csrc/*, include/pzn.h, build.py): PMC byte counts collected on another build
     are not attached to this run's numbers."""
     import hashlib
     h = hashlib.sha256()
@@ -157,6 +157,7 @@ def build_id():
         if f.endswith((".hip", ".h")):
             h.update(open(os.path.join(base, f), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "pzn.h"), "rb").read())
+    h.update(open(os.path.join(ROOT, "puzzlenet_amd", "build.py"), "rb").read())      # (compiler flags)
     return h.hexdigest()[:16]
 
 

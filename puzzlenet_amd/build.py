@@ -17,24 +17,34 @@ LIB = os.path.join(HERE, "libpzn.so")
 # (source, extra flags).  The point-op kernels use explicitly rounded
 # arithmetic (__f*_rn) where bit-exactness matters; -ffp-contract=off on those
 # files is belt and braces.
+# NOSLP: no SLP vectorisation.  Under plain -O3 the compiler pairs adjacent scalar fp32 operations into v_pk_*_f32 with
+# op_sel modifiers; that form (a) gave wrong sums in the set-abstraction prep kernel while workgroups of the matrix-core
+# engine shared the CU (two-stream training step; tests/test_gpu_concurrency.py), and (b) costs extra cycles beside MFMAs
+# (MI355X_MICROARCH.md, "packed f32 VALU").  Explicitly written packed math (knn.hip, emd.hip, chamfer.hip: float2
+# vector types) is not touched by the flag.  wsgemm / dfgemm / poolbwd keep the default: their code has no op_sel
+# packed forms (checked in the ISA) and the generated-row max-pool kernel measured 3-5 % slower without the pairing.
+NOSLP = ["-fno-slp-vectorize"]
+_OFF = os.environ.get("PZN_BUILD_SLP", "") == "1"      # tuning aid: build with the compiler's default again
 SOURCES = [
-    ("core.hip", []),
-    ("fps.hip", ["-ffp-contract=off"]),
+    ("core.hip", NOSLP),
+    ("fps.hip", ["-ffp-contract=off"] + NOSLP),
     ("knn.hip", ["-ffp-contract=off"]),
-    ("group.hip", ["-ffp-contract=off"]),
-    ("emd.hip", []),
-    ("chamfer.hip", []),
-    ("gemm.hip", []),
+    ("group.hip", ["-ffp-contract=off"] + NOSLP),
+    ("emd.hip", NOSLP),
+    ("chamfer.hip", NOSLP),
+    ("gemm.hip", NOSLP),
     ("poolbwd.hip", []),
-    ("maxptsbwd.hip", []),
+    ("maxptsbwd.hip", NOSLP),
     ("wsgemm.hip", []),
     ("dfgemm.hip", []),
-    ("optim.hip", ["-ffp-contract=off"]),
-    ("se3.hip", []),
-    ("sapoint.hip", []),
-    ("bnpoints.hip", []),
-    ("losstail.hip", []),
+    ("optim.hip", ["-ffp-contract=off"] + NOSLP),
+    ("se3.hip", NOSLP),
+    ("sapoint.hip", NOSLP),
+    ("bnpoints.hip", NOSLP),
+    ("losstail.hip", NOSLP),
 ]
+if _OFF:
+    SOURCES = [(f, [x for x in fl if x not in NOSLP]) for f, fl in SOURCES]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
