@@ -71,7 +71,7 @@ int pzn_knn_f32(const float* xyz, const float* new_xyz, int B, int N, int S,
 /* pointnet_util.py:117-132 (knn=True, nsample = 32) in ONE launch and in the reference's layout: the
  * neighbour search of pzn_knn_f32 followed, per query and in the same wavefront, by the grouping of
  * pzn_group_fwd_f32: idx[B,S,32] and out[B,S,32,3+D] = cat(xyz[idx] - new_xyz, feat[idx]); grouped_xyz
- * [B,S,32,3] is written when non-NULL (returnfps=True).  64 <= N <= 4096, D > 0, D % 4 == 0, feat and out
+ * [B,S,32,3] is written when non-NULL (returnfps=True).  64 <= N <= 8192, D > 0, D % 4 == 0, feat and out
  * 16-byte aligned; PZN_EUNSUPPORTED otherwise (compose the two single entry points then). */
 int pzn_knn_group_f32(const float* xyz, const float* feat, const float* new_xyz, int B, int N,
                       int S, int D, int64_t* idx, float* out, float* grouped_xyz,

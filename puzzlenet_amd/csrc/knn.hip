@@ -607,7 +607,7 @@ __device__ __forceinline__ void group_piece_any(float* __restrict__ chunk, const
 }
 
 template <int R, int WAVES, bool GROUP, int DT, int KPT, bool NT>
-__global__ __launch_bounds__(WAVES* PZN_WAVE) __attribute__((amdgpu_waves_per_eu(R <= 32 ? 4 : 3, 8))) void knn_select_kernel(
+__global__ __launch_bounds__(WAVES* PZN_WAVE) __attribute__((amdgpu_waves_per_eu(R <= 32 ? 4 : (R <= 64 ? 3 : 2), 8))) void knn_select_kernel(
     const float* __restrict__ xyz, const float* __restrict__ feat, const float* __restrict__ new_xyz, int N, int S, int K,
     int D, int dshift, int kp, int q_per_block, int blocks_per_cloud, int64_t* __restrict__ idx,
     float* __restrict__ out, float* __restrict__ grouped_xyz) {
@@ -843,14 +843,14 @@ namespace {
 
 constexpr int SEL_WAVES = 8;
 
-// Launch of knn_select_kernel: R = 2 * ceil(N / 128) rounded up to a power of two (<= 64), 8 wavefronts per
+// Launch of knn_select_kernel: R = 2 * ceil(N / 128) rounded up to a power of two (<= 128: N <= 8192), 8 wavefronts per
 // workgroup, ~512 workgroups (two per CU, one round), a multiple of 8 of them when possible (XCD-aware order).  GROUP: the piece
 // height kp (rows assembled in LDS per pass) is the largest of 32 / 16 / 8 / 4 that lets two workgroups share a CU.
 template <bool GROUP>
 int launch_select(const float* xyz, const float* feat, const float* new_xyz, int B, int N, int S, int K, int D,
                   int64_t* idx, float* out, float* grouped_xyz, hipStream_t st) {
   const int rows = (N + PZN_WAVE - 1) / PZN_WAVE;
-  if (N < 64 || rows > 64) return PZN_EUNSUPPORTED;
+  if (N < 64 || rows > 128) return PZN_EUNSUPPORTED;      // (N <= 8192: the lane's R distances stay in registers)
   int R = 2;
   while (R < rows) R <<= 1;
   const size_t cloud = (size_t)3 * 64 * R * sizeof(float);
@@ -909,7 +909,8 @@ int launch_select(const float* xyz, const float* feat, const float* new_xyz, int
     case 8: PZN_SEL(8); break;
     case 16: PZN_SEL(16); break;
     case 32: PZN_SEL(32); break;
-    default: PZN_SEL(64); break;
+    case 64: PZN_SEL(64); break;
+    default: PZN_SEL(128); break;
   }
 #undef PZN_SEL_K
 #undef PZN_SEL
@@ -923,7 +924,7 @@ PZN_EXPORT int pzn_knn_f32(const float* xyz, const float* new_xyz, int B, int N,
   PZN_CHECK_ARG(xyz && new_xyz && idx && B > 0 && N > 0 && S > 0 && K > 0 && K <= N && B <= 65535);
   hipStream_t st = pzn_hip_stream(stream);
   if (K <= 32) {
-    if (K <= N && N >= 64 && N <= 4096 && !pzn_knn_legacy()) {
+    if (K <= N && N >= 64 && N <= 8192 && !pzn_knn_legacy()) {
       int rc = launch_select<false>(xyz, nullptr, new_xyz, B, N, S, K, 0, idx, nullptr, nullptr, st);
       if (rc != PZN_EUNSUPPORTED) return rc;
     }

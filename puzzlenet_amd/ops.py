@@ -423,9 +423,9 @@ def group(xyz, feat, new_xyz, idx, want_grouped_xyz=False):
 
 
 def knn_group_supported(xyz, feat, nsample):
-    """Shapes pzn_knn_group_f32 takes (include/pzn.h): K = 32, 64 <= N <= 4096, a feature table with D % 4 == 0."""
+    """Shapes pzn_knn_group_f32 takes (include/pzn.h): K = 32, 64 <= N <= 8192, a feature table with D % 4 == 0."""
     return nsample == 32 and feat is not None and feat.shape[-1] > 0 and feat.shape[-1] % 4 == 0 and \
-        64 <= xyz.shape[1] <= 4096
+        64 <= xyz.shape[1] <= 8192
 
 
 def knn_group(xyz, feat, new_xyz, want_grouped_xyz=False):

@@ -265,7 +265,8 @@ def test_knn_group_pad_fused_vs_oracle(dev, B, N, S, D):
 
 
 @pytest.mark.parametrize("B,N,S,D", [(3, 2048, 512, 64), (2, 512, 256, 128), (2, 200, 33, 8), (1, 4096, 64, 16),
-                                     (2, 64, 10, 4), (1, 1000, 77, 12), (2, 130, 130, 20), (1, 3000, 19, 256)])
+                                     (2, 64, 10, 4), (1, 1000, 77, 12), (2, 130, 130, 20), (1, 3000, 19, 256),
+                                     (1, 8192, 96, 64), (1, 6000, 50, 128)])
 def test_knn_group_fused_vs_oracle(dev, B, N, S, D):
     """pzn_knn_group_f32 (search + group in one launch, REFERENCE layout [B,S,32,3+D]) == oracle kNN (bit-exact idx)
     + oracle group, incl. grouped_xyz; D / 4 a power of two or not, piece heights 32 / 16 / 8 / 4."""
