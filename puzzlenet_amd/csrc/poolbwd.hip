@@ -11,7 +11,7 @@
 //
 // Two kernels, both walking groups g = blockIdx.x, += gridDim.x over a 128-column slice (blockIdx.y) of the
 // C1 hidden columns, lane l holding columns 2l, 2l+1:
-//  * pool_wgrad_kernel: 8 wavefronts, wave w owns CPW = C2/8 channels whose dW accumulators stay in registers
+//  * pool_wgrad_kernel: 16 (or 8) wavefronts, wave w owns CPW = C2/16 channels whose dW accumulators stay in registers
 //    for the whole walk.  Per group the 32 x 128 tile of h is staged in LDS (double-buffered, next tile
 //    prefetched into registers), the wave's CPW (argmax, gradient) pairs are read as one vector and
 //    broadcast with v_readlane, then per channel: one ds_read_b64 of the arg-max row + one packed fma.
@@ -67,8 +67,14 @@ __device__ __forceinline__ float4 pb_add_relu(float4 a, float4 q) {
   return make_float4(fmaxf(a.x + q.x, 0.f), fmaxf(a.y + q.y, 0.f), fmaxf(a.z + q.z, 0.f), fmaxf(a.w + q.w, 0.f));
 }
 
-template <int CPW>
-__global__ __launch_bounds__(PB_T) void pool_wgrad_kernel(PoolBwdArgs p) {
+// NWV wavefronts per workgroup (8 or 16), wave w owns CPW = C2 / NWV channels.  16 wavefronts: the whole 32 x 128 tile is
+// staged in one pass (one 16-byte piece per thread) and four wavefronts per SIMD hide the LDS latency of the hit loop
+// (8 wavefronts = 2 per SIMD waited on a dependent ds_read 37 % of the time); the workgroup count, and with it the
+// number of atomic adds at the end, stays the same.
+template <int CPW, int NWV>
+__global__ __launch_bounds__(NWV * 64) void pool_wgrad_kernel(PoolBwdArgs p) {
+  constexpr int T = NWV * 64;
+  constexpr bool TWO = NWV == 8;      // two staging rows per thread
   __shared__ __attribute__((aligned(16))) float hbuf[2][32][PB_COLS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col0 = blockIdx.y * PB_COLS;
@@ -79,15 +85,15 @@ __global__ __launch_bounds__(PB_T) void pool_wgrad_kernel(PoolBwdArgs p) {
   for (int c = 0; c < CPW; ++c) acc[c] = v2f{0.f, 0.f};
   float dbacc = 0.f;
 
-  // staging map for the 32 x 128 tile: rows srow and srow + 16, 16-byte column scol
+  // staging map for the 32 x 128 tile: row srow (and srow + 16 with 8 wavefronts), 16-byte column scol
   const int srow = tid >> 5, scol = (tid & 31) * 4;
   // Two register sets = two groups in flight.  The loads are unconditional (group index clamped) and the
   // loop is unrolled by the two sets so that the compiler's vmcnt bookkeeping stays exact (a branch around
   // a load makes it fall back to vmcnt(0), i.e. to a prefetch distance of nothing).
-  float4 pa0, pa1, pb0, pb1, qa, qb;
+  float4 pa0, pa1 = make_float4(0.f, 0.f, 0.f, 0.f), pb0, pb1 = pa1, qa = pa1, qb = pa1;
   int ava, avb;
   float gva, gvb;
-  // regenerated rows (p.gQ): the point indices of this thread's two rows, looked up one round ahead of the row loads
+  // regenerated rows (p.gQ): the point indices of this thread's rows, looked up one round ahead of the row loads
   // they address (a dependent idx -> row chain inside one round would cost a memory latency per group)
   int ja0 = 0, ja1 = 0, jb0 = 0, jb1 = 0;
   const bool regen = p.gQ != nullptr;
@@ -95,7 +101,8 @@ __global__ __launch_bounds__(PB_T) void pool_wgrad_kernel(PoolBwdArgs p) {
   do {                                                                              \
     const int g_ = (gg) < p.G ? (gg) : p.G - 1;                                     \
     const int64_t* ip = p.gidx + (size_t)g_ * 32 + srow;                            \
-    j0_ = (int)ip[0], j1_ = (int)ip[16];                                            \
+    j0_ = (int)ip[0];                                                               \
+    if (TWO) j1_ = (int)ip[16];                                                     \
   } while (0)
 #define PB_ISSUE(gg, x0, x1, q_, av_, gv_, j0_, j1_)                                \
   do {                                                                              \
@@ -103,12 +110,12 @@ __global__ __launch_bounds__(PB_T) void pool_wgrad_kernel(PoolBwdArgs p) {
     if (regen) {                                                                    \
       const size_t pb_ = (size_t)(g_ / p.gS) * p.gN;                                \
       x0 = *reinterpret_cast<const float4*>(p.gP + (pb_ + j0_) * p.C1 + col0 + scol); \
-      x1 = *reinterpret_cast<const float4*>(p.gP + (pb_ + j1_) * p.C1 + col0 + scol); \
+      if (TWO) x1 = *reinterpret_cast<const float4*>(p.gP + (pb_ + j1_) * p.C1 + col0 + scol); \
       q_ = *reinterpret_cast<const float4*>(p.gQ + (size_t)g_ * p.C1 + col0 + scol); \
     } else {                                                                        \
       const float* hp = p.h + ((size_t)g_ * 32 + srow) * p.C1 + col0 + scol;        \
       x0 = *reinterpret_cast<const float4*>(hp);                                    \
-      x1 = *reinterpret_cast<const float4*>(hp + (size_t)16 * p.C1);                \
+      if (TWO) x1 = *reinterpret_cast<const float4*>(hp + (size_t)16 * p.C1);       \
     }                                                                               \
     const size_t o = (size_t)g_ * p.C2 + ch;                                        \
     const int a = p.argmax[o];                                                      \
@@ -118,9 +125,12 @@ __global__ __launch_bounds__(PB_T) void pool_wgrad_kernel(PoolBwdArgs p) {
   } while (0)
 #define PB_GROUP(buf, x0, x1, q_, av_, gv_, j0_, j1_, gnext)                        \
   do {                                                                              \
-    if (regen) x0 = pb_add_relu(x0, q_), x1 = pb_add_relu(x1, q_);                        \
+    if (regen) {                                                                    \
+      x0 = pb_add_relu(x0, q_);                                                     \
+      if (TWO) x1 = pb_add_relu(x1, q_);                                            \
+    }                                                                               \
     *reinterpret_cast<float4*>(&hbuf[buf][srow][scol]) = x0;                        \
-    *reinterpret_cast<float4*>(&hbuf[buf][srow + 16][scol]) = x1;                   \
+    if (TWO) *reinterpret_cast<float4*>(&hbuf[buf][(srow + 16) & 31][scol]) = x1;   \
     const int av = av_;                                                             \
     const float gv = gv_;                                                           \
     __syncthreads(); /* one barrier per group: the tile two groups back is free again by construction */ \
@@ -161,6 +171,7 @@ __global__ __launch_bounds__(PB_T) void pool_wgrad_kernel(PoolBwdArgs p) {
     atomicAdd(o + 1, acc[c].y);
   }
   if (p.db && blockIdx.y == 0 && lane < CPW) atomicAdd(p.db + wave * CPW + lane, dbacc);
+  (void)T;
 }
 
 constexpr int PD_T = 1024;  // dgrad: 16 wavefronts, each walking whole groups
@@ -310,14 +321,26 @@ int launch_wgrad(const PoolBwdArgs& p, hipStream_t st) {
   static const int total = [] { const char* e = getenv("PZN_POOL_WGRAD_GRID"); return e ? atoi(e) : 256; }();  // tuning aid (one workgroup per CU measured best)
   int gx = total / ny;  // workgroups in flight; each ends with C2*128 atomic adds into dW
   if (gx > p.G) gx = p.G;
-  dim3 grid((unsigned)gx, (unsigned)ny), block(PB_T);
+  static const int w16 = [] { const char* e = getenv("PZN_POOL_WGRAD_W16"); return e ? atoi(e) : 1; }();  // tuning aid
+  const dim3 grid((unsigned)gx, (unsigned)ny);
+  if (w16 && p.C2 % 16 == 0 && p.C2 / 16 >= 4) {      // 16 wavefronts, C2 / 16 channels each
+    const int cpw = p.C2 / 16;
+    if (cpw == 4)
+      hipLaunchKernelGGL((pool_wgrad_kernel<4, 16>), grid, dim3(1024), 0, st, p);
+    else if (cpw == 8)
+      hipLaunchKernelGGL((pool_wgrad_kernel<8, 16>), grid, dim3(1024), 0, st, p);
+    else
+      hipLaunchKernelGGL((pool_wgrad_kernel<16, 16>), grid, dim3(1024), 0, st, p);
+    PZN_RETURN_LAUNCH_STATUS();
+  }
+  const dim3 block(PB_T);
   const int cpw = p.C2 / PB_W;
   if (cpw == 8)
-    hipLaunchKernelGGL((pool_wgrad_kernel<8>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((pool_wgrad_kernel<8, 8>), grid, block, 0, st, p);
   else if (cpw == 16)
-    hipLaunchKernelGGL((pool_wgrad_kernel<16>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((pool_wgrad_kernel<16, 8>), grid, block, 0, st, p);
   else
-    hipLaunchKernelGGL((pool_wgrad_kernel<32>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((pool_wgrad_kernel<32, 8>), grid, block, 0, st, p);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
