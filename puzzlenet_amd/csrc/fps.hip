@@ -22,14 +22,19 @@
 
 namespace {
 
-template <int T, int PPT>
+constexpr int FPS_OUT_CHUNK = 256;      // picks buffered in LDS between write-outs (power of two)
+
+// LDS: the cloud's SoA image fits in LDS (compile-time: with a run-time choice the centroid fetch became three flat_load
+// instructions waited for with vmcnt(0) lgkmcnt(0) in the middle of every round's dependent chain)
+template <int T, int PPT, bool use_lds>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int N, int npoint,
                                                 const int64_t* __restrict__ start,
-                                                int64_t* __restrict__ out, int use_lds) {
+                                                int64_t* __restrict__ out) {
   constexpr int W = T / PZN_WAVE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t* slots = reinterpret_cast<uint64_t*>(smem_raw);             // [2][W]
-  float* sx = reinterpret_cast<float*>(smem_raw + 2 * W * sizeof(uint64_t));
+  int* sout = reinterpret_cast<int*>(smem_raw + 2 * W * sizeof(uint64_t));      // [FPS_OUT_CHUNK] picks not yet written out
+  float* sx = reinterpret_cast<float*>(smem_raw + 2 * W * sizeof(uint64_t) + FPS_OUT_CHUNK * sizeof(int));
   float* sy = sx + N;
   float* sz = sy + N;
 
@@ -69,7 +74,15 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
   int64_t* o = out + (size_t)b * npoint;
 
   for (int i = 0; i < npoint; ++i) {
-    if (tid == 0) o[i] = far;  // :68
+    // :68 — the pick goes to LDS and leaves in chunks: a global store inside the loop keeps a vector-memory operation
+    // outstanding at every barrier (__syncthreads waits for it: several hundred cycles per round on wave 0)
+    if (tid == 0) sout[i & (FPS_OUT_CHUNK - 1)] = far;
+    if ((i & (FPS_OUT_CHUNK - 1)) == FPS_OUT_CHUNK - 1 || i == npoint - 1) {
+      __syncthreads();
+      const int base = i & ~(FPS_OUT_CHUNK - 1);
+      for (int t = tid; t <= i - base; t += T) o[base + t] = (int64_t)sout[t];
+      __syncthreads();      // (sout is rewritten next round)
+    }
     float cx, cy, cz;          // :69
     if (use_lds) {
       cx = sx[far];
@@ -109,15 +122,18 @@ template <int T, int PPT>
 int launch(const float* xyz, int B, int N, int npoint, const int64_t* start, int64_t* out, hipStream_t st) {
   constexpr int W = T / PZN_WAVE;
   size_t lds_xyz = (size_t)3 * N * sizeof(float);
-  size_t lds = 2 * W * sizeof(uint64_t);
+  size_t lds = 2 * W * sizeof(uint64_t) + FPS_OUT_CHUNK * sizeof(int);
   int use_lds = lds + lds_xyz <= 150 * 1024;
   if (use_lds) lds += lds_xyz;
-  if (lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_kernel<T, PPT>),
+  if (use_lds) {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_kernel<T, PPT, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return PZN_ELAUNCH;
+    hipLaunchKernelGGL((fps_kernel<T, PPT, true>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out);
+  } else {
+    hipLaunchKernelGGL((fps_kernel<T, PPT, false>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out);
   }
-  hipLaunchKernelGGL((fps_kernel<T, PPT>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out, use_lds);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
@@ -127,19 +143,28 @@ PZN_EXPORT int pzn_fps_f32(const float* xyz, int B, int N, int npoint, const int
                            int64_t* out_idx, pzn_stream_t stream) {
   PZN_CHECK_ARG(xyz && start_idx && out_idx && B > 0 && N > 0 && npoint > 0);
   hipStream_t st = pzn_hip_stream(stream);
+  // Fewer, fatter wavefronts: the round is a dependent chain (fetch the pick, update, wave reduction, barrier, re-reduce
+  // the per-wave slots), and the cross-wave part grows with the wave count while the per-thread update is cheap
+  // (PZN_FPS_T: tuning aid).  Measured per round at N = 2048: 1024 threads 1.35 us, 512 0.75, 256 0.62, 128 see tools/bench_fps.py
+  static const int tsel = [] { const char* e = getenv("PZN_FPS_T"); return e ? atoi(e) : 0; }();
   if (N <= 64) return launch<64, 1>(xyz, B, N, npoint, start_idx, out_idx, st);
   if (N <= 128) return launch<128, 1>(xyz, B, N, npoint, start_idx, out_idx, st);
-  if (N <= 256) return launch<256, 1>(xyz, B, N, npoint, start_idx, out_idx, st);
-  if (N <= 512) return launch<256, 2>(xyz, B, N, npoint, start_idx, out_idx, st);
-  if (N <= 1024) return launch<256, 4>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 256) return tsel == 128 ? launch<128, 2>(xyz, B, N, npoint, start_idx, out_idx, st)
+                                   : launch<256, 1>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 512) return tsel == 128 ? launch<128, 4>(xyz, B, N, npoint, start_idx, out_idx, st)
+                                   : launch<256, 2>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 1024) return tsel == 128 ? launch<128, 8>(xyz, B, N, npoint, start_idx, out_idx, st)
+                                    : launch<256, 4>(xyz, B, N, npoint, start_idx, out_idx, st);
   if (N <= 2048) {
-    static const int tsel = [] { const char* e = getenv("PZN_FPS_T"); return e ? atoi(e) : 0; }();  // tuning aid
-    if (tsel == 256) return launch<256, 8>(xyz, B, N, npoint, start_idx, out_idx, st);
+    if (tsel == 128) return launch<128, 16>(xyz, B, N, npoint, start_idx, out_idx, st);
+    if (tsel == 512) return launch<512, 4>(xyz, B, N, npoint, start_idx, out_idx, st);
     if (tsel == 1024) return launch<1024, 2>(xyz, B, N, npoint, start_idx, out_idx, st);
-    return launch<512, 4>(xyz, B, N, npoint, start_idx, out_idx, st);
+    return launch<256, 8>(xyz, B, N, npoint, start_idx, out_idx, st);
   }
-  if (N <= 4096) return launch<512, 8>(xyz, B, N, npoint, start_idx, out_idx, st);
-  if (N <= 8192) return launch<1024, 8>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 4096) return tsel == 512 ? launch<512, 8>(xyz, B, N, npoint, start_idx, out_idx, st)
+                                    : launch<256, 16>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 8192) return tsel == 1024 ? launch<1024, 8>(xyz, B, N, npoint, start_idx, out_idx, st)
+                                     : launch<512, 16>(xyz, B, N, npoint, start_idx, out_idx, st);
   if (N <= 16384) return launch<1024, 16>(xyz, B, N, npoint, start_idx, out_idx, st);
   if (N <= 32768) return launch<1024, 32>(xyz, B, N, npoint, start_idx, out_idx, st);
   return PZN_EUNSUPPORTED;
