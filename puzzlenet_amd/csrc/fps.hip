@@ -69,6 +69,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     dist[p] = 1e10f;  // pointnet_util.py:64
   }
 
+  const bool full = N == T * PPT;      // every thread's every point exists: no bounds tests in the rounds
   int far = (int)start[b];  // pointnet_util.py:65 (the caller's randint draw)
   far = far < 0 ? 0 : (far >= N ? N - 1 : far);
   int64_t* o = out + (size_t)b * npoint;
@@ -93,18 +94,48 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
       cy = g[(size_t)far * 3 + 1];
       cz = g[(size_t)far * 3 + 2];
     }
-    uint64_t best = 0;  // below every real key: real keys have ~j >= 1
+    uint64_t best;
+    if constexpr (PPT <= 4) {
+      // arg-max in two parts: the 32-bit distance pattern (>= 0, so monotonic as an integer) goes through the wave
+      // reduction alone — six v_max_u32 with DPP operands instead of six 64-bit compare-and-select steps — and the index
+      // is resolved afterwards: one lane holds the maximum almost always (ballot + readlane); on a tie the lowest index
+      // wins (as torch.max on CPU), found by a second reduction only then.
+      uint32_t bd = 0, bj = 0x7fffffffu;      // (a thread without a valid point keeps the sentinel and never ties)
+  #pragma unroll
+      for (int p = 0; p < PPT; ++p) {
+        int j = tid + p * T;
+        float d = pzn::sqdist3(px[p], py[p], pz[p], cx, cy, cz);  // :70
+        float nd = d < dist[p] ? d : dist[p];                     // :71
+        dist[p] = nd;
+        const uint32_t nb = __float_as_uint(nd);
+        // strict >: the lower index of equal distances stays (j ascends with p); the thread's first point is always taken
+        const bool take = p == 0 ? (full || j < N) : ((full || j < N) && nb > bd);
+        bd = take ? nb : bd;
+        bj = take ? (uint32_t)j : bj;
+      }
+      const uint32_t wm = pzn::wave_max_u32_dpp(bd);
+      const bool tied = bd == wm && (full || bj != 0x7fffffffu);
+      const unsigned long long tmask = __ballot(tied);
+      uint32_t wj;
+      if (__popcll(tmask) == 1)
+        wj = (uint32_t)__builtin_amdgcn_readlane((int)bj, __builtin_ctzll(tmask));
+      else
+        wj = pzn::wave_min_u32_dpp(tied ? bj : 0xffffffffu);
+      best = ((uint64_t)wm << 32) | (uint32_t)(~wj);
+    } else {      // many points per thread: the 64-bit key (distance, ~index) per point measured faster there
+      best = 0;  // below every real key: real keys have ~j >= 1
 #pragma unroll
-    for (int p = 0; p < PPT; ++p) {
-      int j = tid + p * T;
-      float d = pzn::sqdist3(px[p], py[p], pz[p], cx, cy, cz);  // :70
-      float nd = d < dist[p] ? d : dist[p];                     // :71
-      dist[p] = nd;
-      uint64_t key = ((uint64_t)__float_as_uint(nd) << 32) | (uint32_t)(~(uint32_t)j);
-      key = j < N ? key : 0ull;
-      best = key > best ? key : best;
+      for (int p = 0; p < PPT; ++p) {
+        int j = tid + p * T;
+        float d = pzn::sqdist3(px[p], py[p], pz[p], cx, cy, cz);  // :70
+        float nd = d < dist[p] ? d : dist[p];                     // :71
+        dist[p] = nd;
+        uint64_t key = ((uint64_t)__float_as_uint(nd) << 32) | (uint32_t)(~(uint32_t)j);
+        key = j < N ? key : 0ull;
+        best = key > best ? key : best;
+      }
+      best = pzn::wave_max_u64_dpp(best);
     }
-    best = pzn::wave_max_u64_dpp(best);
     uint64_t* sl = slots + (i & 1) * W;
     if (lane == 0) sl[wave] = best;
     __syncthreads();

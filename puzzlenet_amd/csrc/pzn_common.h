@@ -81,6 +81,28 @@ __device__ __forceinline__ uint64_t wave_max_u64_dpp(uint64_t v) {
   return v;
 }
 
+// 64-lane max / min of a dword (the compiler folds the DPP move into v_max_u32_dpp / v_min_u32_dpp where it can)
+__device__ __forceinline__ uint32_t wave_max_u32_dpp(uint32_t v) {
+  uint32_t o;
+  o = xor_lane<1>(v), v = o > v ? o : v;
+  o = xor_lane<2>(v), v = o > v ? o : v;
+  o = xor_lane<4>(v), v = o > v ? o : v;
+  o = xor_lane<8>(v), v = o > v ? o : v;
+  o = xor_lane<16>(v), v = o > v ? o : v;
+  o = xor_lane<32>(v), v = o > v ? o : v;
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32_dpp(uint32_t v) {
+  uint32_t o;
+  o = xor_lane<1>(v), v = o < v ? o : v;
+  o = xor_lane<2>(v), v = o < v ? o : v;
+  o = xor_lane<4>(v), v = o < v ? o : v;
+  o = xor_lane<8>(v), v = o < v ? o : v;
+  o = xor_lane<16>(v), v = o < v ? o : v;
+  o = xor_lane<32>(v), v = o < v ? o : v;
+  return v;
+}
+
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
   uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
   lo = __shfl_xor(lo, mask, PZN_WAVE);
