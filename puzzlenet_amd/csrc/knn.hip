@@ -92,9 +92,10 @@ __device__ __forceinline__ void stage_cloud(const float* __restrict__ g, int N, 
 }
 
 // ---------------------------------------------------------------- K <= 32 --
+template <bool use_lds>
 __global__ __launch_bounds__(KNN_WAVES* PZN_WAVE) void knn32_kernel(
     const float* __restrict__ xyz, const float* __restrict__ new_xyz, int N, int S, int K,
-    int q_per_block, int64_t* __restrict__ idx, int use_lds) {
+    int q_per_block, int64_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t* cand_all = reinterpret_cast<uint64_t*>(smem_raw);  // [KNN_WAVES][KNN_CAND_CAP]
   float* sx = reinterpret_cast<float*>(smem_raw + KNN_WAVES * KNN_CAND_CAP * sizeof(uint64_t));
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(KNN_WAVES* PZN_WAVE) void knn32_kernel(
   const int wave = tid / PZN_WAVE;
   const float* g = xyz + (size_t)b * N * 3;
   CloudView cv;
-  if (use_lds) {
+  if constexpr (use_lds) {
     stage_cloud(g, N, sx, KNN_WAVES * PZN_WAVE, tid);
     __syncthreads();
     cv = CloudView{sx, sx + N, sx + 2 * N, 1};
@@ -708,9 +709,10 @@ __global__ __launch_bounds__(WAVES* PZN_WAVE) __attribute__((amdgpu_waves_per_eu
 
 // ------------------------------------------------------------- any K <= N --
 // K rounds of "smallest key greater than the last one taken".
+template <bool use_lds>
 __global__ __launch_bounds__(KNN_WAVES* PZN_WAVE) void knn_any_kernel(
     const float* __restrict__ xyz, const float* __restrict__ new_xyz, int N, int S, int K,
-    int q_per_block, int64_t* __restrict__ idx, int use_lds) {
+    int q_per_block, int64_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* sx = reinterpret_cast<float*>(smem_raw);
   const int b = blockIdx.y;
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(KNN_WAVES* PZN_WAVE) void knn_any_kernel(
   const int wave = tid / PZN_WAVE;
   const float* g = xyz + (size_t)b * N * 3;
   CloudView cv;
-  if (use_lds) {
+  if constexpr (use_lds) {
     stage_cloud(g, N, sx, KNN_WAVES * PZN_WAVE, tid);
     __syncthreads();
     cv = CloudView{sx, sx + N, sx + 2 * N, 1};
@@ -756,9 +758,10 @@ __global__ __launch_bounds__(KNN_WAVES* PZN_WAVE) void knn_any_kernel(
 // ------------------------------------------------------------ ball query --
 // pointnet_util.py:89-95: indices with d <= r^2 in ascending order, first
 // `nsample` of them, the rest padded with the first hit (N when no hit).
+template <bool use_lds>
 __global__ __launch_bounds__(KNN_WAVES* PZN_WAVE) void ball_kernel(
     const float* __restrict__ xyz, const float* __restrict__ new_xyz, int N, int S, int nsample,
-    float radius2, int q_per_block, int64_t* __restrict__ idx, int use_lds) {
+    float radius2, int q_per_block, int64_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* sx = reinterpret_cast<float*>(smem_raw);
   const int b = blockIdx.y;
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(KNN_WAVES* PZN_WAVE) void ball_kernel(
   const int wave = tid / PZN_WAVE;
   const float* g = xyz + (size_t)b * N * 3;
   CloudView cv;
-  if (use_lds) {
+  if constexpr (use_lds) {
     stage_cloud(g, N, sx, KNN_WAVES * PZN_WAVE, tid);
     __syncthreads();
     cv = CloudView{sx, sx + N, sx + 2 * N, 1};
@@ -945,16 +948,26 @@ PZN_EXPORT int pzn_knn_f32(const float* xyz, const float* new_xyz, int B, int N,
     else if (g.use_lds && N >= 64 && rows <= 64)
       PZN_KNN_REG(64);
     else {
-      if (set_lds(&knn32_kernel, g.lds) != PZN_OK) return PZN_ELAUNCH;
-      hipLaunchKernelGGL(knn32_kernel, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
-                         g.q_per_block, idx, g.use_lds);
+      if (g.use_lds) {
+        if (set_lds(&knn32_kernel<true>, g.lds) != PZN_OK) return PZN_ELAUNCH;
+        hipLaunchKernelGGL(knn32_kernel<true>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
+                           g.q_per_block, idx);
+      } else {
+        hipLaunchKernelGGL(knn32_kernel<false>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
+                           g.q_per_block, idx);
+      }
     }
 #undef PZN_KNN_REG
   } else {
     Geometry g = geometry(B, N, S, 0);
-    if (set_lds(&knn_any_kernel, g.lds) != PZN_OK) return PZN_ELAUNCH;
-    hipLaunchKernelGGL(knn_any_kernel, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
-                       g.q_per_block, idx, g.use_lds);
+    if (g.use_lds) {
+      if (set_lds(&knn_any_kernel<true>, g.lds) != PZN_OK) return PZN_ELAUNCH;
+      hipLaunchKernelGGL(knn_any_kernel<true>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
+                         g.q_per_block, idx);
+    } else {
+      hipLaunchKernelGGL(knn_any_kernel<false>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
+                         g.q_per_block, idx);
+    }
   }
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -976,9 +989,14 @@ PZN_EXPORT int pzn_ball_query_f32(float radius2, int nsample, const float* xyz, 
   PZN_CHECK_ARG(xyz && new_xyz && idx && B > 0 && N > 0 && S > 0 && nsample > 0 && B <= 65535);
   hipStream_t st = pzn_hip_stream(stream);
   Geometry g = geometry(B, N, S, 0);
-  if (set_lds(&ball_kernel, g.lds) != PZN_OK) return PZN_ELAUNCH;
-  hipLaunchKernelGGL(ball_kernel, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, nsample, radius2,
-                     g.q_per_block, idx, g.use_lds);
+  if (g.use_lds) {      // (compile-time variants: a run-time choice of address space turns every point fetch into a flat load)
+    if (set_lds(&ball_kernel<true>, g.lds) != PZN_OK) return PZN_ELAUNCH;
+    hipLaunchKernelGGL(ball_kernel<true>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, nsample,
+                       radius2, g.q_per_block, idx);
+  } else {
+    hipLaunchKernelGGL(ball_kernel<false>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, nsample,
+                       radius2, g.q_per_block, idx);
+  }
   PZN_RETURN_LAUNCH_STATUS();
 }
 
