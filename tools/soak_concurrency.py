@@ -1,0 +1,94 @@
+"""Extended cross-stream soak (the matrix behind tests/test_gpu_concurrency.py): every deterministic forward kernel family
+run REPS times beside each of eight aggressor kernels on a second stream; prints the number of elements that differ from
+the result obtained alone (all zeros on the current build):  python tools/soak_concurrency.py [REPS]"""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+
+from puzzlenet_amd import dense, ops
+from puzzlenet_amd.ops import _call, _p
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(3)
+B, N, S, D, C1, C2 = 8, 2048, 512, 64, 128, 128
+xyz = torch.rand(B, N, 3, generator=g).to(dev)
+feat = torch.randn(B, N, D, generator=g).to(dev)
+new_xyz = ops.index_points(xyz, ops.farthest_point_sample(xyz, S, torch.zeros(B, dtype=torch.long, device=dev)))
+w1 = (torch.randn(C1, 3 + D, generator=g) / 8).to(dev)
+b1 = torch.randn(C1, generator=g).to(dev)
+w2 = (torch.randn(C2, C1, generator=g) / 11).to(dev)
+b2 = torch.randn(C2, generator=g).to(dev)
+a_pts, b_pts = torch.rand(16, 512, 3, generator=g).to(dev), torch.rand(16, 512, 3, generator=g).to(dev)
+xa = (0.5 * torch.randn(16, 256, 256, generator=g)).to(dev)
+aw = [(torch.randn(*s, generator=g) / (16 if len(s) == 2 else 4)).to(dev)
+      for s in [(64, 256), (64,), (64, 256), (64,), (256, 256), (256,), (256, 256), (256,)]]
+xl = torch.randn(32768, 64, generator=g).to(dev)
+wl, bl = (torch.randn(64, 64, generator=g) / 8).to(dev), torch.randn(64, generator=g).to(dev)
+xg = torch.randn(4096, 1280, generator=g).to(dev)
+wg = (torch.randn(1024, 1280, generator=g) / 30).to(dev)
+yg = torch.empty(4096, 1024, device=dev)
+side = torch.cuda.Stream()
+victims = {
+    "knn": lambda: ops.knn(xyz, new_xyz, 32),
+    "knn_group": lambda: ops.knn_group(xyz, feat, new_xyz)[0],
+    "fps": lambda: ops.farthest_point_sample(xyz, 256, torch.zeros(B, dtype=torch.long, device=dev)),
+    "ball_query": lambda: ops.ball_query(0.2, 32, xyz, new_xyz),
+    "sa_level": lambda: ops.sa_mlp_max(xyz, feat, new_xyz, None, w1, b1, w2, b2),
+    "chamfer": lambda: torch.cat([t.reshape(-1).float() for t in ops.chamfer(a_pts, b_pts)]),
+    "attention_block": lambda: ops.attention_block(xa, *aw)[0],
+    "linear_weight_stationary": lambda: dense.linear(xl, wl, bl, relu=True),
+    "linear_general_engine": lambda: dense.linear(xg, wg, None),
+    "max_over_points": lambda: ops.max_over_points(xa),
+}
+
+def agg_general():
+    _call("pzn_linear_fwd_f32", _p(xg), _p(wg), None, 4096, 1280, 1024, 0, _p(yg), side.cuda_stream)
+
+def agg_level():
+    with torch.cuda.stream(side):
+        ops.sa_mlp_max(xyz, feat, new_xyz, None, w1, b1, w2, b2)
+
+def agg_attention():
+    with torch.cuda.stream(side):
+        ops.attention_block(xa, *aw)
+
+aggs = {"general_engine": agg_general, "sa_level": agg_level, "attention_block": agg_attention}
+
+
+
+def agg_emd():
+    with torch.cuda.stream(side):
+        ops.emd_fused(a_pts, b_pts)
+def agg_knn_group():
+    with torch.cuda.stream(side):
+        ops.knn_group(xyz, feat, new_xyz)
+def agg_fps():
+    with torch.cuda.stream(side):
+        ops.farthest_point_sample(xyz, 128, torch.zeros(B, dtype=torch.long, device=dev))
+def agg_chamfer():
+    with torch.cuda.stream(side):
+        ops.chamfer(a_pts, b_pts)
+fr = feat.clone().requires_grad_(True)
+def agg_sa_backward():
+    with torch.cuda.stream(side):
+        y = ops.sa_mlp_max(xyz, fr, new_xyz, None, w1, b1, w2, b2)
+        y.sum().backward()
+        fr.grad = None
+aggs.update(emd=agg_emd, knn_group=agg_knn_group, fps=agg_fps, chamfer=agg_chamfer, sa_backward=agg_sa_backward)
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+print("victim \\ aggressor".ljust(28) + "".join(a[:14].rjust(15) for a in aggs))
+for name, fn in victims.items():
+    with torch.no_grad():
+        ref = fn(); again = fn()
+    torch.cuda.synchronize()
+    assert torch.equal(ref, again), name
+    cells = []
+    for an, ag in aggs.items():
+        bad = torch.zeros((), dtype=torch.int64, device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        for _ in range(REPS):
+            ag(); ag()
+            with torch.no_grad():
+                bad += (fn() != ref).sum()
+        torch.cuda.synchronize()
+        cells.append(int(bad))
+    print(name.ljust(28) + "".join(str(c).rjust(15) for c in cells), flush=True)
