@@ -42,6 +42,14 @@ __device__ __forceinline__ void load_vec(const float* p, float (&v)[V]) {
 #pragma unroll
   for (int i = 0; i < V; ++i) v[i] = f[i];
 }
+// the same, as a streaming (non-temporal) load: rows that are read exactly once
+template <int V>
+__device__ __forceinline__ void load_vec_nt(const float* p, float (&v)[V]) {
+  typedef float vt __attribute__((ext_vector_type(V)));
+  const vt t = __builtin_nontemporal_load(reinterpret_cast<const vt*>(p));
+#pragma unroll
+  for (int i = 0; i < V; ++i) v[i] = t[i];
+}
 template <int V>
 __device__ __forceinline__ void store_vec(float* p, const float (&v)[V]) {
   typename VecT<V>::type t;
@@ -294,13 +302,13 @@ __global__ __launch_bounds__(SP_T) void sa_point_l1_bwd_kernel(const float* __re
     for (; r + G <= nr; r += G) {  // G dh rows in flight
       float g[G][V];
 #pragma unroll
-      for (int u = 0; u < G; ++u) load_vec<V>(dhl + (size_t)__builtin_amdgcn_readlane(grow, r + u) * C1, g[u]);
+      for (int u = 0; u < G; ++u) load_vec_nt<V>(dhl + (size_t)__builtin_amdgcn_readlane(grow, r + u) * C1, g[u]);
 #pragma unroll
       for (int u = 0; u < G; ++u) take(g[u], r + u);
     }
     for (; r < nr; ++r) {
       float g0[V];
-      load_vec<V>(dhl + (size_t)__builtin_amdgcn_readlane(grow, r) * C1, g0);
+      load_vec_nt<V>(dhl + (size_t)__builtin_amdgcn_readlane(grow, r) * C1, g0);
       take(g0, r);
     }
     flush(cur);
