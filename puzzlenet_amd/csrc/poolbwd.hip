@@ -175,6 +175,10 @@ __global__ __launch_bounds__(NWV * 64) void pool_wgrad_kernel(PoolBwdArgs p) {
 }
 
 constexpr int PD_T = 1024;  // dgrad: 16 wavefronts, each walking whole groups
+#ifndef PD_ROWS_N
+#define PD_ROWS_N 4
+#endif
+constexpr int PD_ROWS = PD_ROWS_N;  // rows of a group per trip of the row loop (gate rows in flight, independent hit loops)
 
 template <int NQ>  // C2 = 64 * NQ
 __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
@@ -284,30 +288,36 @@ __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
       }
       return acc0 + acc1;
     };
-    // Rows in pairs: lane l owns columns 2l, 2l+1 of every row; after two rows the lanes of a pair (2i, 2i+1) swap one
+    // Rows in fours, stored in pairs: lane l owns columns 2l, 2l+1 of every row; after two rows the lanes of a pair (2i, 2i+1) swap one
     // half each, so that the even lane holds four consecutive columns of row k and the odd lane those of row k+1 — the
     // row stores are 16 bytes per lane instead of 8 (8-byte stores run at 0.54-0.70 of the 16-byte rate; without the
     // store the level-1 launch takes 0.122 of its 0.192 ms).
-    v2f hm = gate_raw(0);
     const int odd = lane & 1;
     float* drow = p.dh + ((size_t)g * 32 + odd) * p.C1 + col0 + 4 * (lane >> 1);
-    for (int k = 0; k < 32; k += 2) {
-      v2f h0 = hm, h1 = gate_raw(k + 1);
-      const v2f hm_next = k + 2 < 32 ? gate_raw(k + 2) : v2f{1.f, 1.f};
-      if (p.gP) h0 = gate_of(h0, k), h1 = gate_of(h1, k + 1);
-      v2f a0 = row_acc(k), a1 = row_acc(k + 1);
-      a0.x = h0.x > 0.f ? a0.x : 0.f, a0.y = h0.y > 0.f ? a0.y : 0.f;
-      a1.x = h1.x > 0.f ? a1.x : 0.f, a1.y = h1.y > 0.f ? a1.y : 0.f;
-      dq += a0 + a1;
-      // the half the partner lane stores goes across; the other half stays
-      const float sx_ = odd ? a0.x : a1.x, sy_ = odd ? a0.y : a1.y;
-      const float rx_ = __builtin_bit_cast(float, pzn::xor_lane<1>(__builtin_bit_cast(uint32_t, sx_)));
-      const float ry_ = __builtin_bit_cast(float, pzn::xor_lane<1>(__builtin_bit_cast(uint32_t, sy_)));
-      float4 o4;
-      o4.x = odd ? rx_ : a0.x, o4.y = odd ? ry_ : a0.y;      // even lane: row k, columns 4i..4i+3 = own pair + partner's
-      o4.z = odd ? a1.x : rx_, o4.w = odd ? a1.y : ry_;      // odd lane: row k+1, partner's pair + own
-      *reinterpret_cast<float4*>(drow + (size_t)k * p.C1) = o4;
-      hm = hm_next;
+    for (int k = 0; k < 32; k += PD_ROWS) {  // PD_ROWS rows per trip: their gate rows are requested first and arrive under the hit loops
+      v2f hg[PD_ROWS], ar[PD_ROWS];
+#pragma unroll
+      for (int u = 0; u < PD_ROWS; ++u) hg[u] = gate_raw(k + u);
+#pragma unroll
+      for (int u = 0; u < PD_ROWS; ++u) ar[u] = row_acc(k + u);
+#pragma unroll
+      for (int u = 0; u < PD_ROWS; ++u) {
+        if (p.gP) hg[u] = gate_of(hg[u], k + u);
+        ar[u].x = hg[u].x > 0.f ? ar[u].x : 0.f, ar[u].y = hg[u].y > 0.f ? ar[u].y : 0.f;
+        dq += ar[u];
+      }
+#pragma unroll
+      for (int u = 0; u < PD_ROWS; u += 2) {
+        const v2f a0 = ar[u], a1 = ar[u + 1];
+        // the half the partner lane stores goes across; the other half stays
+        const float sx_ = odd ? a0.x : a1.x, sy_ = odd ? a0.y : a1.y;
+        const float rx_ = __builtin_bit_cast(float, pzn::xor_lane<1>(__builtin_bit_cast(uint32_t, sx_)));
+        const float ry_ = __builtin_bit_cast(float, pzn::xor_lane<1>(__builtin_bit_cast(uint32_t, sy_)));
+        float4 o4;
+        o4.x = odd ? rx_ : a0.x, o4.y = odd ? ry_ : a0.y;      // even lane: row k, columns 4i..4i+3 = own pair + partner's
+        o4.z = odd ? a1.x : rx_, o4.w = odd ? a1.y : ry_;      // odd lane: row k+1, partner's pair + own
+        *reinterpret_cast<float4*>(drow + (size_t)(k + u) * p.C1) = o4;
+      }
     }
     if (qform) sq_b += dq, sq_x += cgx * dq, sq_y += cgy * dq, sq_z += cgz * dq;
   }
