@@ -348,32 +348,60 @@ PZN_EXPORT int pzn_group_feat_bwd_f32(const float* rows, const int64_t* idx, int
 // dx[b, l, c] = (l == idx[b, c]) ? dout[b, c] : 0 written as one streaming pass (no separate zero fill).
 namespace {
 
-__global__ __launch_bounds__(1024) void maxpts_fwd_kernel(const float* __restrict__ x, int L, int C,
-                                                          float* __restrict__ out, int32_t* __restrict__ idx) {
-  __shared__ float sv[32][33];
-  __shared__ int si[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int b = blockIdx.y, c = blockIdx.x * 32 + tx;
-  float best = -INFINITY;
-  int bi = 0;
-  if (c < C) {
+// One workgroup = 128 channels of one cloud: thread (row lane r = tid / 32, channel group q = tid % 32) walks rows r, r + 8,
+// ... reading 16 bytes (4 channels) per row — 32 threads fetch 512 contiguous bytes of a row (the first version read 128-byte
+// pieces at a 4-KB stride and took 84 us per launch inside the step for the 67 MB encoder output).  Rows ascend within a
+// thread, so a strict > keeps the first maximum; the eight row lanes meet in LDS, ties to the lower row.
+constexpr int MAXPTS_T = 256, MAXPTS_RL = MAXPTS_T / 32;
+__global__ __launch_bounds__(MAXPTS_T) void maxpts_fwd_kernel(const float* __restrict__ x, int L, int C,
+                                                              float* __restrict__ out, int32_t* __restrict__ idx) {
+  __shared__ float sv[MAXPTS_RL][128];
+  __shared__ int si[MAXPTS_RL][128];
+  const int q = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int b = blockIdx.y, c = blockIdx.x * 128 + 4 * q;
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int bi[4] = {0, 0, 0, 0};
+  if (c < C) {      // (C % 4 == 0: a thread's four channels are all inside or all outside)
     const float* p = x + (size_t)b * L * C + c;
-    for (int l = ty; l < L; l += 32) {
-      const float v = p[(size_t)l * C];
-      if (v > best) best = v, bi = l;  // rows ascend within a thread: the first maximum is kept
+    int l = r;
+    for (; l + 3 * MAXPTS_RL < L; l += 4 * MAXPTS_RL) {      // four rows in flight
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(l + u * MAXPTS_RL) * C);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ll = l + u * MAXPTS_RL;
+        if (v[u].x > best[0]) best[0] = v[u].x, bi[0] = ll;
+        if (v[u].y > best[1]) best[1] = v[u].y, bi[1] = ll;
+        if (v[u].z > best[2]) best[2] = v[u].z, bi[2] = ll;
+        if (v[u].w > best[3]) best[3] = v[u].w, bi[3] = ll;
+      }
+    }
+    for (; l < L; l += MAXPTS_RL) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (size_t)l * C);
+      if (v.x > best[0]) best[0] = v.x, bi[0] = l;
+      if (v.y > best[1]) best[1] = v.y, bi[1] = l;
+      if (v.z > best[2]) best[2] = v.z, bi[2] = l;
+      if (v.w > best[3]) best[3] = v.w, bi[3] = l;
     }
   }
-  sv[ty][tx] = best, si[ty][tx] = bi;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sv[r][4 * q + i] = best[i], si[r][4 * q + i] = bi[i];
   __syncthreads();
-  if (ty == 0 && c < C) {
-#pragma unroll 8
-    for (int r = 1; r < 32; ++r) {
-      const float v = sv[r][tx];
-      const int i = si[r][tx];
-      if (v > best || (v == best && i < bi)) best = v, bi = i;
+  if (threadIdx.x < 128) {
+    const int cc = blockIdx.x * 128 + threadIdx.x;
+    if (cc < C) {
+      float bv = sv[0][threadIdx.x];
+      int bl = si[0][threadIdx.x];
+#pragma unroll
+      for (int rr = 1; rr < MAXPTS_RL; ++rr) {
+        const float v = sv[rr][threadIdx.x];
+        const int i = si[rr][threadIdx.x];
+        if (v > bv || (v == bv && i < bl)) bv = v, bl = i;
+      }
+      out[(size_t)b * C + cc] = bv;
+      idx[(size_t)b * C + cc] = bl;
     }
-    out[(size_t)b * C + c] = best;
-    idx[(size_t)b * C + c] = bi;
   }
 }
 
@@ -395,9 +423,10 @@ __global__ __launch_bounds__(256) void maxpts_bwd_kernel(const float* __restrict
 
 PZN_EXPORT int pzn_maxpool_points_fwd_f32(const float* x, int B, int L, int C, float* out, int32_t* idx,
                                           pzn_stream_t stream) {
-  PZN_CHECK_ARG(x && out && idx && B > 0 && B <= 65535 && L > 0 && C > 0);
-  hipLaunchKernelGGL(maxpts_fwd_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)B), dim3(1024), 0, pzn_hip_stream(stream),
-                     x, L, C, out, idx);
+  PZN_CHECK_ARG(x && out && idx && B > 0 && B <= 65535 && L > 0 && C > 0 && (C & 3) == 0);
+  PZN_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  hipLaunchKernelGGL(maxpts_fwd_kernel, dim3((unsigned)((C + 127) / 128), (unsigned)B), dim3(MAXPTS_T), 0,
+                     pzn_hip_stream(stream), x, L, C, out, idx);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
