@@ -367,6 +367,14 @@ __global__ __launch_bounds__(256) void sa_prep_kernel(const float* __restrict__ 
                                                       const float* __restrict__ W1, int ldw, const float* __restrict__ b1,
                                                       long prow, long groups, int C1, float* __restrict__ P,
                                                       float* __restrict__ Q) {
+  // the three coordinate columns of W1 (and b1), once per workgroup, as planes {wx[C1], wy[C1], wz[C1], b[C1]}: a thread
+  // then reads its four channels of each plane with one 16-byte LDS load instead of twelve scattered global dwords
+  extern __shared__ __attribute__((aligned(16))) float sw[];
+  for (int t = threadIdx.x; t < C1; t += blockDim.x) {
+    const float* w = W1 + (size_t)t * ldw;
+    sw[t] = w[0], sw[C1 + t] = w[1], sw[2 * C1 + t] = w[2], sw[3 * C1 + t] = b1 ? b1[t] : 0.f;
+  }
+  __syncthreads();
   const int c4 = C1 >> 2;
   const long total = (prow + groups) * c4;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -375,21 +383,22 @@ __global__ __launch_bounds__(256) void sa_prep_kernel(const float* __restrict__ 
     const bool point = r < prow;
     const float* q = point ? xyz + (size_t)r * 3 : new_xyz + (size_t)(r - prow) * 3;
     const float x = q[0], y = q[1], z = q[2];
-    float t[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {      // fmaf(wz, z, fmaf(wy, y, wx * x))
-      const float* w = W1 + (size_t)(c + i) * ldw;
-      t[i] = prep_fma(w[2], z, prep_fma(w[1], y, prep_mul(w[0], x)));
-    }
+    const float4 wx = *reinterpret_cast<const float4*>(sw + c), wy = *reinterpret_cast<const float4*>(sw + C1 + c);
+    const float4 wz = *reinterpret_cast<const float4*>(sw + 2 * C1 + c);
+    float t[4];      // fmaf(wz, z, fmaf(wy, y, wx * x))
+    t[0] = prep_fma(wz.x, z, prep_fma(wy.x, y, prep_mul(wx.x, x)));
+    t[1] = prep_fma(wz.y, z, prep_fma(wy.y, y, prep_mul(wx.y, x)));
+    t[2] = prep_fma(wz.z, z, prep_fma(wy.z, y, prep_mul(wx.z, x)));
+    t[3] = prep_fma(wz.w, z, prep_fma(wy.w, y, prep_mul(wx.w, x)));
     if (point) {
       float4* o = reinterpret_cast<float4*>(P + (size_t)r * C1 + c);
       float4 v = *o;
       v.x = prep_add(v.x, t[0]), v.y = prep_add(v.y, t[1]), v.z = prep_add(v.z, t[2]), v.w = prep_add(v.w, t[3]);
       *o = v;
     } else {
+      const float4 bb = *reinterpret_cast<const float4*>(sw + 3 * C1 + c);
       float4 v;
-      v.x = prep_sub(b1 ? b1[c] : 0.f, t[0]), v.y = prep_sub(b1 ? b1[c + 1] : 0.f, t[1]);
-      v.z = prep_sub(b1 ? b1[c + 2] : 0.f, t[2]), v.w = prep_sub(b1 ? b1[c + 3] : 0.f, t[3]);
+      v.x = prep_sub(bb.x, t[0]), v.y = prep_sub(bb.y, t[1]), v.z = prep_sub(bb.z, t[2]), v.w = prep_sub(bb.w, t[3]);
       *reinterpret_cast<float4*>(Q + (size_t)(r - prow) * C1 + c) = v;
     }
   }
@@ -405,8 +414,10 @@ PZN_EXPORT int pzn_sa_prep_f32(const float* xyz, const float* new_xyz, const flo
   const long total = (prow + groups) * (C1 >> 2);
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(sa_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, pzn_hip_stream(stream), xyz, new_xyz, W1, 3 + D, b1,
-                     prow, groups, C1, P, Q);
+  if (C1 > 4096) return PZN_EUNSUPPORTED;      // (4 planes of C1 floats in LDS)
+  if (blocks > 1024) blocks = 1024;             // a few rows per thread: the LDS prologue is paid per workgroup
+  hipLaunchKernelGGL(sa_prep_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * C1 * sizeof(float), pzn_hip_stream(stream),
+                     xyz, new_xyz, W1, 3 + D, b1, prow, groups, C1, P, Q);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
