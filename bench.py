@@ -285,7 +285,8 @@ def main():
         # (1b) every dense matrix-core entry point together (no sparse vector-ALU passes in the sum)
         dense_names = ("pzn_linear_fwd_f32", "pzn_linear_dgrad_f32", "pzn_linear_wgrad_f32", "pzn_linear_maxpool_fwd_f32",
                        "pzn_sharedmlp_max_fwd_f32", "pzn_attn_fwd_f32", "pzn_attn_bwd_f32", "pzn_attn_block_fwd_f32",
-                       "pzn_attn_block_bwd_f32", "pzn_sa_level_fwd_f32")
+                       "pzn_attn_block_bwd_f32", "pzn_sa_level_fwd_f32", "pzn_attn_fused_proj", "pzn_attn_fused_fwd",
+                       "pzn_attn_fused_bwd_q", "pzn_attn_fused_bwd_k", "pzn_attn_fused_wgrads", "pzn_linear_slice_fwd_f32")
         d_ms = sum(kern.get(k, (0, 0.0))[1] for k in dense_names) / prof_steps
         d_fl = sum(kern_flops.get(k, 0) for k in dense_names) / prof_steps
         d_n = sum(kern.get(k, (0, 0.0))[0] for k in dense_names) / prof_steps
@@ -376,17 +377,24 @@ def main():
                     f"would be {ev_ref / max(ev_exec, 1.0):.2f}x as many",
         }
         # (5) the attention blocks (4 per encoder): projections on the fp32-accurate bf16x3 path, contractions in --attn
-        n_af, ms_af = per_step("pzn_attn_block_fwd_f32")
-        n_ab, ms_ab = per_step("pzn_attn_block_bwd_f32")
-        fl_at = (kern_flops.get("pzn_attn_block_fwd_f32", 0) + kern_flops.get("pzn_attn_block_bwd_f32", 0)) / prof_steps
-        at_ach = fl_at / ((ms_af + ms_ab) * 1e-3) / 1e12 if ms_af + ms_ab > 0 else 0.0
+        fused_names = ("pzn_attn_fused_prep_weights", "pzn_attn_fused_proj", "pzn_attn_fused_fwd", "pzn_attn_fused_bwd_q",
+                       "pzn_attn_fused_bwd_k", "pzn_attn_fused_wgrads")
+        attn_fused = "pzn_attn_fused_fwd" in kern
+        attn_names = fused_names if attn_fused else ("pzn_attn_block_fwd_f32", "pzn_attn_block_bwd_f32")
+        ms_at = sum(per_step(k)[1] for k in attn_names)
+        n_at = sum(per_step(k)[0] for k in attn_names)
+        fl_at = sum(kern_flops.get(k, 0) for k in attn_names) / prof_steps
+        at_ach = fl_at / (ms_at * 1e-3) / 1e12 if ms_at > 0 else 0.0
         roofline_attention = {
-            "bound": "mfma", "kernel": "pzn_attn_block_{fwd,bwd}_f32: layerAttention (model5_b.py:83-101), 8 + 8 launches per step; "
-                                       f"contractions q k^T / attn v and their backward in {'single bf16 MFMAs, fp32 softmax' if args.attn == 'bf16' else 'bf16x3 split precision (fp32 results)'}",
+            "bound": "mfma",
+            "kernel": ("pzn_attn_fused_{prep_weights,proj,fwd,bwd_q,bwd_k,wgrads} (csrc/attnfused.hip): layerAttention (model5_b.py:83-101) as "
+                       "chained matrix-core kernels, both encoders per launch; ALGORITHMIC flops (the backward's recomputed "
+                       "scores are not counted)") if attn_fused else
+                      ("pzn_attn_block_{fwd,bwd}_f32: layerAttention (model5_b.py:83-101), 8 + 8 launches per step; "
+                       f"contractions q k^T / attn v and their backward in {'single bf16 MFMAs, fp32 softmax' if args.attn == 'bf16' else 'bf16x3 split precision (fp32 results)'}"),
             "achieved": at_ach, "peak": MFMA_X3_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": at_ach / MFMA_X3_PEAK_TFLOPS,
-            "traffic": None, "algorithmic_flops_per_step": fl_at, "ms_per_step": ms_af + ms_ab,
-            "note": "256 tokens per cloud whatever N: 64 x (256 x 256 x 64..256) products, latency- and launch-bound rather than "
-                    "pipe-bound; with --attn bf16 the contractions issue one MFMA per product instead of six",
+            "traffic": None, "algorithmic_flops_per_step": fl_at, "ms_per_step": ms_at, "launches_per_step": n_at,
+            "note": "256 tokens per cloud whatever N: 64 x (256 x 256 x 64..256) products per encoder and block",
         }
         stages = {k: {"launches_per_step": n / prof_steps, "ms_per_step": ms / prof_steps} for k, (n, ms) in sorted(kern.items())}
         stages_api = {k: {"launches": n, "ms": ms} for k, (n, ms) in sorted(kern_api.items())}

@@ -393,6 +393,52 @@ int pzn_attn_block_bwd_f32(const float* x, const float* Wq, const float* Wk, con
                            float* dbv, float* dWo, float* dbo, int accumulate,
                            pzn_stream_t stream);
 
+/* layerAttention (model5_b.py:67-75, 83-101) as CHAINED matrix-core kernels (csrc/attnfused.hip) for the model's shape
+ * L = 256 points, E = 256 channels, dk = 64 (pzn_attn_fused_supported).  The point sits on the MFMA lane, so every
+ * product's accumulator is the next product's operand in registers: no score matrix and no q / k / v tensors in
+ * memory.  Shared operands live as bf16x3 "plane images" in MFMA-fragment order, written by their producer:
+ *   weights:  pzn_attn_fused_prep_weights -> one buffer of pzn_attn_fused_weight_bytes() per block;
+ *   q, k, v:  pzn_attn_fused_proj -> six images per problem (q, k: *_qk_image_bytes(B); v: *_v_image_bytes(B)),
+ *             each operand as a "row" image (rp) and a "transposed-read" image (t).
+ * Every entry point takes nprob = 1 or 2 independent problems as arrays of nprob pointers (the two encoders of
+ * predict5, model5_b.py:700-707, in one launch); B clouds each; all buffers 16-byte aligned.
+ *   fwd:    r = x + relu(Wo (x - softmax(q k^T / 8) v) + bo) [B*L,E];  t = x - attn v [B*L,E];  mask [B*L,8] u32 = gate
+ *           bits of the ReLU;  lse [B*L];  map[i] (may be NULL) [B,L,L]: map = scale P, or map += scale P when
+ *           map_accumulate (the mean of the four blocks' maps, model5_b.py:468-469).
+ *   bwd_q:  query side of the backward from dr [B*L,E]: dz = dr . gate, u = dr + dz Wo + dq Wq, dq [B*L,dk], delta [B*L]
+ *           and the two images of da = -dz Wo.
+ *   bwd_k:  key side: dk [B*L,dk], dv [B*L,E], dx = u + dk Wk + dv Wv [B*L,E] = the block's input gradient.
+ *   wgrads: the eight parameter gradients from dz, t, dq, dk, dv and the block input x (one problem per call). */
+int pzn_attn_fused_supported(int L, int E, int dk);
+size_t pzn_attn_fused_weight_bytes(void);
+size_t pzn_attn_fused_qk_image_bytes(int B);
+size_t pzn_attn_fused_v_image_bytes(int B);
+int pzn_attn_fused_prep_weights(const float* Wq, const float* Wk, const float* Wv, const float* Wo,
+                                void* planes, pzn_stream_t stream);
+int pzn_attn_fused_proj(int nprob, const float* const* x, const void* const* w,
+                        const float* const* bq, const float* const* bk, const float* const* bv, int B,
+                        void* const* qrp, void* const* qt, void* const* krp, void* const* kt,
+                        void* const* vrp, void* const* vt, pzn_stream_t stream);
+int pzn_attn_fused_fwd(int nprob, const float* const* x, const void* const* qrp,
+                       const void* const* krp, const void* const* vt, const void* const* w,
+                       const float* const* bo, int B, float* const* r, float* const* t,
+                       void* const* mask, float* const* map, float* const* lse, int map_accumulate,
+                       float map_scale, pzn_stream_t stream);
+int pzn_attn_fused_bwd_q(int nprob, const float* const* dr, const void* const* mask,
+                         const void* const* qrp, const void* const* krp, const void* const* kt,
+                         const void* const* vrp, const void* const* w, int B, float* const* dz,
+                         float* const* u, float* const* dq, void* const* darp, void* const* dat,
+                         float* const* delta, pzn_stream_t stream);
+int pzn_attn_fused_bwd_k(int nprob, const void* const* qrp, const void* const* qt,
+                         const void* const* krp, const void* const* vrp, const void* const* darp,
+                         const void* const* dat, const void* const* w, const float* const* lse,
+                         const float* const* delta, const float* const* u, int B, float* const* dk,
+                         float* const* dv, float* const* dx, pzn_stream_t stream);
+int pzn_attn_fused_wgrads(const float* dz, const float* t, const float* dq, const float* dk,
+                          const float* dv, const float* x, int M, int E, int dk_dim, float* dWq,
+                          float* dbq, float* dWk, float* dbk, float* dWv, float* dbv, float* dWo,
+                          float* dbo, int accumulate, pzn_stream_t stream);
+
 /* torch.max(x, dim=1) over the point axis (model5_b.py:475 global feature, :741): out[b,c] =
  * max_l x[b,l,c], idx[b,c] = its row (the lowest one on ties); backward dx[b,l,c] =
  * (l == idx[b,c]) ? dout[b,c] : 0, every element of dx written (C % 4 == 0, 16-byte aligned). */

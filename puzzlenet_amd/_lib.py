@@ -14,6 +14,7 @@ _c_f = ctypes.c_void_p      # device pointers travel as raw addresses
 _c_i = ctypes.c_int
 _c_sz = ctypes.c_size_t
 _c_fl = ctypes.c_float
+_PP = ctypes.POINTER(ctypes.c_void_p)   # array of device pointers (one per problem)
 
 # name -> (restype, argtypes); mirrors include/pzn.h one to one.
 SIGNATURES = {
@@ -53,6 +54,16 @@ SIGNATURES = {
     "pzn_gemm_get_precision": (_c_i, []),
     "pzn_attn_set_precision": (_c_i, [_c_i]),
     "pzn_attn_get_precision": (_c_i, []),
+    "pzn_attn_fused_supported": (_c_i, [_c_i, _c_i, _c_i]),
+    "pzn_attn_fused_weight_bytes": (_c_sz, []),
+    "pzn_attn_fused_qk_image_bytes": (_c_sz, [_c_i]),
+    "pzn_attn_fused_v_image_bytes": (_c_sz, [_c_i]),
+    "pzn_attn_fused_prep_weights": (_c_i, [_c_f] * 6),
+    "pzn_attn_fused_proj": (_c_i, [_c_i] + [_PP] * 5 + [_c_i] + [_PP] * 6 + [_c_f]),
+    "pzn_attn_fused_fwd": (_c_i, [_c_i] + [_PP] * 6 + [_c_i] + [_PP] * 5 + [_c_i, _c_fl, _c_f]),
+    "pzn_attn_fused_bwd_q": (_c_i, [_c_i] + [_PP] * 7 + [_c_i] + [_PP] * 6 + [_c_f]),
+    "pzn_attn_fused_bwd_k": (_c_i, [_c_i] + [_PP] * 10 + [_c_i] + [_PP] * 3 + [_c_f]),
+    "pzn_attn_fused_wgrads": (_c_i, [_c_f] * 6 + [_c_i] * 3 + [_c_f] * 8 + [_c_i, _c_f]),
     "pzn_bgemm_f32": (_c_i, [_c_i, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_fl, _c_f]),
     "pzn_sharedmlp_max_fwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 4 + [_c_f] * 4),
     "pzn_sharedmlp_max_bwd_f32": (_c_i, [_c_f] * 7 + [_c_i] * 4 + [_c_f] * 6 + [_c_i, _c_f]),

@@ -33,6 +33,7 @@ SOURCES = [
     ("emd.hip", NOSLP),
     ("chamfer.hip", NOSLP),
     ("gemm.hip", NOSLP),
+    ("attnfused.hip", NOSLP),
     ("poolbwd.hip", []),
     ("maxptsbwd.hip", NOSLP),
     ("wsgemm.hip", []),

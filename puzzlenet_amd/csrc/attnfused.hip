@@ -1,0 +1,1282 @@
+// attnfused.hip — layerAttention (model5_b.py:67-75, 83-101) as chained matrix-core kernels, gfx950 only.
+//
+// Shapes are the model's: L = 256 points per cloud, E = 256 channels, dk = 64 (model5_b.py:436-439: embed_dim 256,
+// q/k of embed_dim / 4).  Everything is computed TRANSPOSED, with the point (query or key) on the MFMA lane:
+//
+//   v_mfma_f32_32x32x16_bf16: D[i][j] += sum_k A[i][k] B[k][j]; lane (r = l & 31, h = l >> 5) holds A[r][8h..8h+7],
+//   B[8h..8h+7][r] and D[(reg & 3) + 8 (reg >> 2) + 4h][r].  A 32x32 result therefore has its COLUMN on the lane and
+//   its rows in the 16 registers, which is exactly the B operand of a following product that sums over its rows.
+//   With the shared operand (keys, values, weights) as A and the wavefront's own 32 points as the columns, every product
+//   of the block takes the previous accumulator as its B operand straight from registers:
+//
+//     S^T = K q^T   ->  P^T = softmax over keys (registers + one half-lane exchange)
+//     A^T = V^T P^T ->  t^T = x^T - A^T  ->  z^T = Wo t^T  ->  r^T = x^T + relu(z^T + bo)
+//
+//   No score matrix, no LDS transposes; a wavefront owns 32 points end to end and never talks to another one.
+//
+// Split precision: every fp32 operand is x = x1 + x2 + x3 (three bf16 "planes"); a product is the six MFMAs of
+// magnitude >= 2^-16 (fp32-GEMM accuracy, see gemm.hip).  Shared operands are split ONCE by their producer and kept in
+// memory as plane images in MFMA-fragment order; the per-wavefront operand is split in registers as it is consumed.
+//
+// Plane images (bf16, 16-byte chunks):
+//   Rp  ("row" image of M[rows][K], consumed with k = column index): [k-step][plane][row tile][lane][8], the chunk of
+//        lane (r, h) holding M[32 rt + r][16 ks + perm(h, j)], perm(h, j) = 8 (j >> 2) + 4h + (j & 3): the order in
+//        which an accumulator's registers 8s..8s+7 come out as a B fragment.  Read with ds_read_b128 (A operand through
+//        LDS) or straight from global by the lane that owns the row (B operand).
+//   T   ("transposed-read" image of M[n][F], consumed with k = ROW index): [k-step of 16 rows][plane][16][F] row-major
+//        with the 64-byte granule index XORed by a row key; read with ds_read_b64_tr_b16 (hardware transpose).
+//
+// The shared operand streams through LDS in 24 KB slabs (36 KB in the projection kernel): thread t copies 16-byte
+// pieces t, t + 256, ... global -> registers while the previous slab is being multiplied, registers -> the other
+// LDS buffer afterwards, one barrier per slab.  One wavefront per SIMD (the chained accumulators need ~400 registers).
+#include <stdio.h>
+
+#include <type_traits>
+
+#include "pzn_common.h"
+#include "pzn_internal.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16x4 __attribute__((address_space(3))) * lds4_t;
+
+constexpr int L = 256, E = 256, DK = 64;
+constexpr int SLAB = 24576;               // 3 planes x 8 KB
+constexpr int QK_IMG = 4 * 3 * 8 * 1024;  // Rp or T image of a [256][64] operand, bytes per cloud
+constexpr int V_IMG = 16 * 3 * 8 * 1024;  // Rp or T image of a [256][256] operand
+constexpr int NT = 256;                   // threads per workgroup
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ uint32_t f2bf(float x) {
+  __bf16 b = (__bf16)x;
+  return (uint32_t)__builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
+
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 values -> three dwords of two bf16 each (x = x1 + x2 + x3, every xi a round-to-nearest bf16 of the remainder):
+// 3 v_cvt_pk_bf16_f32 + 4 unpack + 4 subtract
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& a, uint32_t& bq, uint32_t& c) {
+  const floatx2 x = {x0, x1};
+  a = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
+  const floatx2 r = {x0 - __uint_as_float(a << 16), x1 - __uint_as_float(a & 0xffff0000u)};
+  bq = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+  const floatx2 t = {r[0] - __uint_as_float(bq << 16), r[1] - __uint_as_float(bq & 0xffff0000u)};
+  c = __builtin_bit_cast(uint32_t, __builtin_convertvector(t, bf16x2));
+}
+
+// eight fp32 values -> three bf16x8 fragments (x = b0 + b1 + b2 exactly up to 2^-24)
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&b)[3]) {
+  uint32_t w[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], w[0][j], w[1][j], w[2][j]);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]));
+}
+
+// The B fragment of the NEXT k-step, built a pair of values at a time behind the MFMAs of the current one
+// (BNext::pair(j), j = 0..3, from the step's fill callback), so that its ~44 vector instructions sit in the shadow of
+// the matrix pipe instead of in front of the step (measured: 660 cycles per step when issued as one block).
+struct BNext {
+  uint32_t w[3][4];
+  template <bool NEG = false>
+  __device__ __forceinline__ void pair(const floatx16& x, int s, int j) {
+    const float x0 = x[8 * s + 2 * j], x1 = x[8 * s + 2 * j + 1];
+    split_pair(NEG ? -x0 : x0, NEG ? -x1 : x1, w[0][j], w[1][j], w[2][j]);
+  }
+  __device__ __forceinline__ void get(bf16x8 (&b)[3]) const {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]));
+  }
+};
+
+// registers 8s .. 8s+7 of an accumulator tile as the B fragment of k-step s (s = 0, 1), optionally negated
+template <bool NEG = false>
+__device__ __forceinline__ void make_b(const floatx16& x, int s, bf16x8 (&b)[3]) {
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = NEG ? -x[8 * s + j] : x[8 * s + j];
+  split8(v, b);
+}
+
+// acc += A B with A, B in three planes each: the six products >= 2^-16, small terms first
+__device__ __forceinline__ floatx16 mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], floatx16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+  return c;
+}
+
+struct NoFill {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+// LDS fragment reads are inline asm with explicit waits: one wavefront per SIMD means nobody else hides the LDS latency,
+// so the fragments of the NEXT tile must be in flight while the six MFMAs of the current one issue.  Left to the
+// compiler (256 VGPRs all in use) the reads are re-issued one by one right in front of their MFMA and waited for with
+// lgkmcnt(0) three times per tile (measured: 2.6k cycles per 48-MFMA step against 1.5k of matrix-pipe time).
+// An asm read is invisible to the compiler's wait bookkeeping: RP_WAIT / TR_WAIT (s_waitcnt lgkmcnt(0) naming every
+// destination register read-write) must precede the first use (cdna_hip_programming.md, 5.7 form (ii)).
+#define RP_ISSUE(ADDR, O0, O1, O2, A0, A1, A2)                                                       \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A0) : "v"(ADDR), "n"(O0));                      \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A1) : "v"(ADDR), "n"(O1));                      \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A2) : "v"(ADDR), "n"(O2))
+#define RP_WAITN(N_, A0, A1, A2) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(A0), "+v"(A1), "+v"(A2))
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ floatx16 mma6v(bf16x8 a0, bf16x8 a1, bf16x8 a2, const bf16x8 (&b)[3], floatx16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[0], c, 0, 0, 0);
+  return c;
+}
+
+// one k-step of acc[rt] += A_rt B, A from an Rp slab in LDS: [plane][RT][lane][16 B].  lane_addr = LDS byte address of
+// the slab + 16 lane: ONE address register per ring slot, the tile and plane go into the instruction's offset field
+// (left as address arithmetic, the compiler keeps a register per (slot, tile) alive through the whole kernel: ~100
+// VGPRs, spilled).  Fragments are requested TWO tiles ahead (three register sets): one tile of MFMAs (192 cycles) does
+// not cover the LDS latency when the four wavefronts of the workgroup, in lockstep behind the step's barrier, read at
+// the same moment.  The wait before tile rt is counted: lgkmcnt(6 / 3) leaves the reads of the following tiles in
+// flight (LDS returns in order).  fill(rt) is called behind the MFMAs of tile rt: the step's DMA instructions and the
+// construction of the next B fragment go there, spread under the matrix pipe instead of standing in front of it.
+template <int RT, class Fill = NoFill>
+__device__ __forceinline__ void kstep_rp(floatx16 (&acc)[RT], uint32_t lane_addr, const bf16x8 (&b)[3],
+                                         const Fill& fill = Fill()) {
+  static_assert(RT >= 4, "pipeline depth");
+  bf16x8 f[3][3];
+  RP_ISSUE(lane_addr, 0, RT * 1024, 2 * RT * 1024, f[0][0], f[0][1], f[0][2]);
+  RP_ISSUE(lane_addr, 1024, (RT + 1) * 1024, (2 * RT + 1) * 1024, f[1][0], f[1][1], f[1][2]);
+  static_for<0, RT>([&](auto ic) {
+    constexpr int rt = decltype(ic)::value;
+    constexpr int cur = rt % 3, nxt = (rt + 2) % 3;
+    if constexpr (rt + 2 < RT) {
+      RP_ISSUE(lane_addr, (rt + 2) * 1024, (RT + rt + 2) * 1024, (2 * RT + rt + 2) * 1024, f[nxt][0], f[nxt][1], f[nxt][2]);
+      RP_WAITN(6, f[cur][0], f[cur][1], f[cur][2]);
+    } else if constexpr (rt + 1 < RT) {
+      RP_WAITN(3, f[cur][0], f[cur][1], f[cur][2]);
+    } else {
+      RP_WAITN(0, f[cur][0], f[cur][1], f[cur][2]);
+    }
+    acc[rt] = mma6v(f[cur][0], f[cur][1], f[cur][2], b, acc[rt]);
+    fill(rt);
+  });
+}
+
+// NK k-steps of ONE 32-row tile whose fragments sit 3072 bytes apart ([k-step][plane][lane][16 B]): acc += sum_k A_k B_k.
+// TILE_OFF = byte offset of the tile inside the slab (compile time); lane_addr as above.
+template <int NK, int TILE_OFF>
+__device__ __forceinline__ void chain_rp1(floatx16& acc, uint32_t lane_addr, const bf16x8 (&b)[NK][3]) {
+  static_assert(NK % 2 == 0, "two register sets alternate");
+  bf16x8 f[2][3];
+  RP_ISSUE(lane_addr, TILE_OFF, TILE_OFF + 1024, TILE_OFF + 2048, f[0][0], f[0][1], f[0][2]);
+  static_for<0, NK>([&](auto ic) {
+    constexpr int k = decltype(ic)::value;
+    constexpr int cur = k & 1, nxt = (k + 1) & 1;
+    if constexpr (k + 1 < NK) {
+      RP_ISSUE(lane_addr, TILE_OFF + (k + 1) * 3072, TILE_OFF + (k + 1) * 3072 + 1024, TILE_OFF + (k + 1) * 3072 + 2048,
+               f[nxt][0], f[nxt][1], f[nxt][2]);
+      RP_WAITN(3, f[cur][0], f[cur][1], f[cur][2]);
+    } else {
+      RP_WAITN(0, f[cur][0], f[cur][1], f[cur][2]);
+    }
+    acc = mma6v(f[cur][0], f[cur][1], f[cur][2], b[k], acc);
+  });
+}
+
+// ---- transposed-read (T) slabs -------------------------------------------------------------------------------------
+// One plane of a T slab is [16 rows][F] bf16 with the 64-byte granule index XORed by the row key (F = 256: key = row & 3;
+// F = 64: key = (row >> 1) & 1).  ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of the
+// group's 4 x 16 block and receives column (lane & 15); groups g = 0..3: k half h = g >> 1, column half g & 1; the second
+// read of a fragment is 8 rows further (same key).  The feature tile ft sits 64 ft bytes along the row, INSIDE the XOR:
+// granule (ft ^ key) for ft < 4 (F = 256: + 256 bytes for ft >= 4), so a lane needs one address per value of ft & 3
+// (F = 64: ft & 1): TrAddr, computed once per slab; everything else is an instruction offset.
+template <int F>
+struct TrAddr {
+  uint32_t a[F == 256 ? 4 : 2];
+  __device__ __forceinline__ TrAddr(uint32_t slab_addr, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int row = 4 * (g >> 1) + (i >> 2);
+    const int colb = (16 * (g & 1) + 4 * (i & 3)) * 2;
+    const int key = F == 256 ? (row & 3) : ((row >> 1) & 1);
+#pragma unroll
+    for (int t = 0; t < (F == 256 ? 4 : 2); ++t) a[t] = slab_addr + (uint32_t)(row * (2 * F) + colb + 64 * (t ^ key));
+  }
+};
+
+#define TR_ISSUE(ADDR, OFF, F_, L0, H0, L1, H1, L2, H2)                                                             \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(L0) : "v"(ADDR), "n"(OFF));                            \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H0) : "v"(ADDR), "n"((OFF) + 16 * (F_)));              \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(L1) : "v"(ADDR), "n"((OFF) + 32 * (F_)));              \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H1) : "v"(ADDR), "n"((OFF) + 48 * (F_)));              \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(L2) : "v"(ADDR), "n"((OFF) + 64 * (F_)));              \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H2) : "v"(ADDR), "n"((OFF) + 80 * (F_)))
+#define TR_WAITN(N_, L0, H0, L1, H1, L2, H2)                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(L0), "+v"(H0), "+v"(L1), "+v"(H1), "+v"(L2), "+v"(H2))
+
+// one k-step of acc[ft] += A_ft B with A read transposed from a T slab: rows of A = feature 32 ft + lane % 32.
+// KOFF = byte offset of the k-step inside the slab (compile time).  Two tiles ahead, counted waits (6 reads per tile).
+template <int FT, int F, int KOFF, class Fill = NoFill>
+__device__ __forceinline__ void kstep_tr(floatx16 (&acc)[FT], const TrAddr<F>& ta, const bf16x8 (&b)[3],
+                                         const Fill& fill = Fill()) {
+  constexpr int NA = F == 256 ? 4 : 2;
+  bf16x4 lo[3][3], hi[3][3];
+  TR_ISSUE(ta.a[0], KOFF, F, lo[0][0], hi[0][0], lo[0][1], hi[0][1], lo[0][2], hi[0][2]);
+  if constexpr (FT > 1) TR_ISSUE(ta.a[1 % NA], KOFF + 256 * (1 / NA), F, lo[1][0], hi[1][0], lo[1][1], hi[1][1], lo[1][2], hi[1][2]);
+  static_for<0, FT>([&](auto ic) {
+    constexpr int ft = decltype(ic)::value;
+    constexpr int cur = ft % 3, nxt = (ft + 2) % 3;
+    if constexpr (ft + 2 < FT) {
+      TR_ISSUE(ta.a[(ft + 2) % NA], KOFF + 256 * ((ft + 2) / NA), F, lo[nxt][0], hi[nxt][0], lo[nxt][1], hi[nxt][1], lo[nxt][2],
+               hi[nxt][2]);
+      TR_WAITN(12, lo[cur][0], hi[cur][0], lo[cur][1], hi[cur][1], lo[cur][2], hi[cur][2]);
+    } else if constexpr (ft + 1 < FT) {
+      TR_WAITN(6, lo[cur][0], hi[cur][0], lo[cur][1], hi[cur][1], lo[cur][2], hi[cur][2]);
+    } else {
+      TR_WAITN(0, lo[cur][0], hi[cur][0], lo[cur][1], hi[cur][1], lo[cur][2], hi[cur][2]);
+    }
+    const bf16x8 a0 = __builtin_shufflevector(lo[cur][0], hi[cur][0], 0, 1, 2, 3, 4, 5, 6, 7);
+    const bf16x8 a1 = __builtin_shufflevector(lo[cur][1], hi[cur][1], 0, 1, 2, 3, 4, 5, 6, 7);
+    const bf16x8 a2 = __builtin_shufflevector(lo[cur][2], hi[cur][2], 0, 1, 2, 3, 4, 5, 6, 7);
+    acc[ft] = mma6v(a0, a1, a2, b, acc[ft]);
+    fill(ft);
+  });
+}
+
+// ---- slab ring: global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, destination =
+// wave-uniform base + lane * 16), three slots, two slabs in flight.  Step c of a kernel's slab sequence is
+//     step_sync(pieces of slab c+1)      (this wave's pieces of slab c have landed; slab c+1 may still be in flight;
+//                                         barrier: everybody's pieces have landed, slot (c+2) % 3 is no longer read)
+//     ring.issue(slab c+2 -> slot (c+2) % 3)
+//     multiply slab c
+// vmcnt counts in order, so other loads / stores issued in between only make a wait more conservative.
+struct Ring {
+  unsigned char* lds;
+  int wave, lane;
+  int slot_bytes;
+  // NPW pieces per wavefront; piece j of the slab = bytes [1024 j, 1024 j + 1024) of src
+  template <int NPW>
+  __device__ __forceinline__ void issue(const unsigned char* src, int slot) const {
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int piece = i * 4 + wave;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + piece * 1024), 16, 0, 0);
+    }
+  }
+  // piece i (of NPW) of this wavefront only: lets a caller spread a slab's DMA instructions over a step
+  __device__ __forceinline__ void issue1(const unsigned char* src, int slot, int i) const {
+    const int piece = i * 4 + wave;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane * 16),
+                                     (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + piece * 1024), 16, 0, 0);
+  }
+  // rows of TWO neighbouring row tiles (2 pr, 2 pr + 1) of an Rp image with 8 row tiles, four k-steps from ks0:
+  // piece j = (tile j / 12, k-step ks0 + (j % 12) / 3, plane j % 3) -> 24 pieces
+  __device__ __forceinline__ void issue_tiles(const unsigned char* img, int ks0, int pr, int slot) const {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int piece = i * 4 + wave;
+      const int t = piece / 12, ks = ks0 + (piece % 12) / 3, p = piece % 3;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(img + (((ks * 3 + p) * 8 + 2 * pr + t) * 64 + lane) * 16),
+          (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + piece * 1024), 16, 0, 0);
+    }
+  }
+  __device__ __forceinline__ const unsigned char* slot(int s) const { return lds + s * slot_bytes; }
+  __device__ __forceinline__ uint32_t lane_addr(int s) const { return slot_addr(s) + (uint32_t)lane * 16u; }
+  __device__ __forceinline__ uint32_t slot_addr(int s) const {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds + (uint32_t)(s * slot_bytes);
+  }
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm_sync() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// younger = this wavefront's DMA instructions of the NEXT slab (the only ones that may stay in flight)
+__device__ __forceinline__ void step_sync(int younger) {
+  if (younger == 0)
+    wait_vm_sync<0>();
+  else if (younger == 6)
+    wait_vm_sync<6>();
+  else
+    wait_vm_sync<9>();
+}
+
+// XCD-aware block id: consecutive logical ids (the two halves of a cloud, neighbouring clouds) share an XCD's L2
+__device__ __forceinline__ int logical_block(int bid, int nb) {
+  if (nb & 7) return bid;
+  return (bid & 7) * (nb >> 3) + (bid >> 3);
+}
+
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+
+// ---- tile <-> memory through a per-wavefront LDS staging buffer --------------------------------------------------
+// A wavefront's result tile has the point on the lane and the features in registers, so a direct store puts every
+// lane in a different row: 32 partial cache lines per instruction (measured: ~300 cycles per store instruction, a third
+// of the forward kernel).  Instead the tile goes through LDS: written in register layout (rows padded to 132 dwords:
+// conflict-free both ways), read back row-contiguous, stored / loaded with 1 KB per instruction.  One pass moves 32 rows
+// x up to 128 fp32 features (or 256 bf16); the buffer belongs to the wavefront, so only wave-scope syncs are needed.
+constexpr int STG_LD = 132;                        // dwords per staged row
+constexpr int STG_BYTES = 32 * STG_LD * 4;         // 16,896 per wavefront
+
+// registers -> staging: tiles ft0 .. ft0 + NFT - 1 (NFT <= 4) of x at columns 32 (ft - ft0)
+template <int NFT>
+__device__ __forceinline__ void stage_put(float* stg, const floatx16* x, int ft0, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int ft = 0; ft < NFT; ++ft)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(stg + r * STG_LD + 32 * ft + 8 * g + 4 * h) =
+          make_float4(x[ft0 + ft][4 * g], x[ft0 + ft][4 * g + 1], x[ft0 + ft][4 * g + 2], x[ft0 + ft][4 * g + 3]);
+}
+template <int NFT>
+__device__ __forceinline__ void stage_get(const float* stg, floatx16* x, int ft0, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int ft = 0; ft < NFT; ++ft)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 v = *reinterpret_cast<const float4*>(stg + r * STG_LD + 32 * ft + 8 * g + 4 * h);
+      x[ft0 + ft][4 * g] = v.x, x[ft0 + ft][4 * g + 1] = v.y, x[ft0 + ft][4 * g + 2] = v.z, x[ft0 + ft][4 * g + 3] = v.w;
+    }
+}
+
+// fp32 rows [32 rows of this wavefront][ld]: FT feature tiles starting at column 0; row0 = the wavefront's first row.
+// MODE 0: store; 1: out = old + scale * tile (read-modify-write; rows are wave-private)
+template <int FT, int MODE = 0>
+__device__ __forceinline__ void store_rows(float* base, long row0, int ld, const floatx16* x, float* stg, int lane,
+                                           float scale = 1.f) {
+  constexpr int PASS = FT >= 4 ? 4 : FT;            // tiles per pass
+  constexpr int LPR = PASS * 8;                     // lanes per row (16 bytes each)
+  constexpr int RPI = 64 / LPR;                     // rows per instruction
+#pragma unroll
+  for (int ft0 = 0; ft0 < FT; ft0 += PASS) {
+    stage_put<PASS>(stg, x, ft0, lane);
+    pzn::wave_lds_sync();
+    float* g0 = base + row0 * ld + 32 * ft0 + 4 * (lane % LPR);
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+      const int rr = i * RPI + lane / LPR;
+      float4 v = *reinterpret_cast<const float4*>(stg + rr * STG_LD + 4 * (lane % LPR));
+      float4* dst = reinterpret_cast<float4*>(g0 + (long)rr * ld);
+      if (MODE == 1) {
+        const float4 o = *dst;
+        v = make_float4(o.x + scale * v.x, o.y + scale * v.y, o.z + scale * v.z, o.w + scale * v.w);
+      } else if (scale != 1.f) {
+        v = make_float4(scale * v.x, scale * v.y, scale * v.z, scale * v.w);
+      }
+      *dst = v;
+    }
+    pzn::wave_lds_sync();
+  }
+}
+template <int FT>
+__device__ __forceinline__ void load_rows(const float* base, long row0, int ld, floatx16* x, float* stg, int lane) {
+  constexpr int PASS = FT >= 4 ? 4 : FT;
+  constexpr int LPR = PASS * 8, RPI = 64 / LPR;
+#pragma unroll
+  for (int ft0 = 0; ft0 < FT; ft0 += PASS) {
+    const float* g0 = base + row0 * ld + 32 * ft0 + 4 * (lane % LPR);
+    float4 v[32 / RPI];
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) v[i] = *reinterpret_cast<const float4*>(g0 + (long)(i * RPI + lane / LPR) * ld);
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i)
+      *reinterpret_cast<float4*>(stg + (i * RPI + lane / LPR) * STG_LD + 4 * (lane % LPR)) = v[i];
+    pzn::wave_lds_sync();
+    stage_get<PASS>(stg, x, ft0, lane);
+    pzn::wave_lds_sync();
+  }
+}
+
+// Rp image of M[256 rows][16 KS features]: tile ft of the accumulators = k-steps 2 ft, 2 ft + 1; the lane's registers
+// 8s..8s+7 are exactly its own chunk.  img = this cloud's image, rt = row tile of the wavefront.
+template <int FT, bool NEG = false>
+__device__ __forceinline__ void store_rp(unsigned char* img, int rt, int lane, const floatx16* x) {
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 b[3];
+      make_b<NEG>(x[ft], s, b);
+      const int ks = 2 * ft + s;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(img + (((ks * 3 + p) * 8 + rt) * 64 + lane) * 16) = b[p];
+      __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from splitting all 16 fragments before the first store)
+    }
+}
+
+// T image of M[256 n][F]: row n = 32 rt + r -> k-step n >> 4, row n & 15, [k-step][plane][16][F] bf16 with the 64-byte
+// granule index XORed by the row key.  The tile goes through the staging buffer in fp32 (up to 128 features per pass),
+// is read back row-contiguous — a lane takes 8 consecutive features of one row —, split there and stored as one 16-byte
+// chunk per plane: 256-byte runs per row instead of 8-byte pieces from 32 rows.
+template <int FT, int F, bool NEG = false>
+__device__ __forceinline__ void store_t(unsigned char* img, int rt, int lane, const floatx16* x, float* stg) {
+  constexpr int PL = 16 * F * 2;
+  constexpr int PASS = FT >= 4 ? 4 : FT;            // tiles per pass
+  constexpr int LPR = PASS * 4, RPI = 64 / LPR;     // lanes per row (8 features each), rows per instruction
+#pragma unroll
+  for (int ft0 = 0; ft0 < FT; ft0 += PASS) {
+    stage_put<PASS>(stg, x, ft0, lane);
+    pzn::wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+      const int rr = i * RPI + lane / LPR, c8 = lane % LPR;
+      const float4 v0 = *reinterpret_cast<const float4*>(stg + rr * STG_LD + 8 * c8);
+      const float4 v1 = *reinterpret_cast<const float4*>(stg + rr * STG_LD + 8 * c8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      if (NEG) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = -v[j];
+      }
+      bf16x8 b[3];
+      split8(v, b);
+      const int n = 32 * rt + rr, nn = n & 15;
+      const int key = F == 256 ? (nn & 3) : ((nn >> 1) & 1);
+      const int colb = (32 * ft0 + 8 * c8) * 2;
+      unsigned char* dst = img + (n >> 4) * (3 * PL) + nn * (2 * F) + (colb ^ (key << 6));
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(dst + p * PL) = b[p];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    pzn::wave_lds_sync();
+  }
+}
+
+// ================================================================================================================
+// weight planes: Rp image of a logical matrix A[row][k] = src[row * rs + k * cs], rows = 32 nrt, K = 16 nks,
+// written at row tile offset rt0 of an image with RT row tiles and k-step offset ks0
+struct PackJob {
+  const float* src;
+  long rs, cs;
+  int nrt, nks, RT, rt0, ks0;
+  unsigned char* dst;
+};
+struct PackArgs {
+  PackJob job[8];
+  int njobs;
+};
+
+__global__ __launch_bounds__(256) void pack_rp_kernel(PackArgs a) {
+  const PackJob& J = a.job[blockIdx.y];
+  const int total = J.nks * J.nrt * 64;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < total; c += gridDim.x * blockDim.x) {
+    const int lane = c & 63, rt = (c >> 6) % J.nrt, ks = (c >> 6) / J.nrt;
+    const int r = lane & 31, h = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+      v[j] = J.src[(long)(32 * rt + r) * J.rs + (long)k * J.cs];
+    }
+    bf16x8 b[3];
+    split8(v, b);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      *reinterpret_cast<bf16x8*>(J.dst + ((((long)(J.ks0 + ks) * 3 + p) * J.RT + J.rt0 + rt) * 64 + lane) * 16) = b[p];
+  }
+}
+
+// byte offsets inside one layer's weight-plane buffer
+constexpr size_t W_QKV = 0;                                   // rows n (q | k | v = 384), k = c: 16 x 36864
+constexpr size_t W_O = W_QKV + 16 * 36864;                    // rows o, k = c: 16 x 24576
+constexpr size_t W_OT = W_O + 16 * SLAB;                      // rows c, k = o
+constexpr size_t W_QT = W_OT + 16 * SLAB;                     // rows c, k = d: 4 x 24576
+constexpr size_t W_KVT = W_QT + 4 * SLAB;                     // rows c, k = d (Wk) then c' (Wv): 20 x 24576
+constexpr size_t W_BYTES = W_KVT + 20 * SLAB;
+
+// ================================================================================================================
+// projection: q, k, v = x W^T + b for the wavefront's 32 points, written as plane images (Rp and T each)
+struct ProjProb {
+  const float* x;                 // [B*L, E]
+  const unsigned char* w;         // the layer's weight planes
+  const float *bq, *bk, *bv;
+  unsigned char *qrp, *qt, *krp, *kt, *vrp, *vt;
+};
+struct ProjArgs {
+  ProjProb p[2];
+  int nb;   // workgroups per problem = 2 B
+};
+
+// acc tile ft <- bias[32 ft + 8 g + 4 h + e] in register 4 g + e: the row of a transposed result is the output feature,
+// so a bias is the INITIAL accumulator (all loads are independent and issued together)
+template <int FT>
+__device__ __forceinline__ void bias_tiles(floatx16* acc, const float* bias, int h) {
+  float4 v[FT * 4];
+#pragma unroll
+  for (int i = 0; i < FT * 4; ++i) v[i] = *reinterpret_cast<const float4*>(bias + 8 * i + 4 * h);
+#pragma unroll
+  for (int i = 0; i < FT * 4; ++i) {
+    acc[i >> 2][4 * (i & 3)] = v[i].x, acc[i >> 2][4 * (i & 3) + 1] = v[i].y;
+    acc[i >> 2][4 * (i & 3) + 2] = v[i].z, acc[i >> 2][4 * (i & 3) + 3] = v[i].w;
+  }
+}
+
+#define ZERO_TILES(A, N)            \
+  _Pragma("unroll") for (int i_ = 0; i_ < (N); ++i_) _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) A[i_][j_] = 0.f
+
+__global__ __launch_bounds__(NT, 1) void attn_proj_kernel(ProjArgs a) {
+  constexpr int WSLAB = 36864;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * WSLAB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
+  const int lb = logical_block(blockIdx.x, gridDim.x);
+  const ProjProb& P = a.p[lb / a.nb];
+  const int cb = lb % a.nb, cloud = cb >> 1, rt = (cb & 1) * 4 + wave;
+  const Ring ring{lds, wave, lane, WSLAB};
+  const unsigned char* wsrc = P.w + W_QKV;
+  const long row0 = (long)cloud * L + 32 * rt;
+  float* stg = reinterpret_cast<float*>(lds + wave * STG_BYTES);   // staging aliases the ring: used before / after it
+
+  floatx16 X[8];
+  load_rows<8>(P.x, row0, E, X, stg, lane);
+  __syncthreads();
+  ring.issue<9>(wsrc, 0);
+  ring.issue<9>(wsrc + WSLAB, 1);
+  floatx16 acc[12];
+  bias_tiles<2>(acc, P.bq, h);
+  bias_tiles<2>(acc + 2, P.bk, h);
+  bias_tiles<8>(acc + 4, P.bv, h);
+  bf16x8 b[2][3];
+  make_b(X[0], 0, b[0]);
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    step_sync(ks < 15 ? 9 : 0);
+    BNext bn;
+    auto fill = [&](int t) {
+      if (t < 5) {
+        if (ks + 2 < 16) {
+          ring.issue1(wsrc + (ks + 2) * WSLAB, (ks + 2) % 3, 2 * t);
+          if (2 * t + 1 < 9) ring.issue1(wsrc + (ks + 2) * WSLAB, (ks + 2) % 3, 2 * t + 1);
+        }
+      } else if (t < 9 && ks < 15) {
+        bn.pair(X[(ks + 1) >> 1], (ks + 1) & 1, t - 5);
+      }
+    };
+    kstep_rp<12>(acc, ring.lane_addr(ks % 3), b[ks & 1], fill);
+    if (ks < 15) bn.get(b[(ks + 1) & 1]);
+  }
+  const floatx16 *q = acc, *k = acc + 2, *v = acc + 4;
+  __syncthreads();   // every wavefront is done with the last slab: the ring memory becomes the staging buffers
+  store_rp<2>(P.qrp + (size_t)cloud * QK_IMG, rt, lane, q);
+  store_t<2, 64>(P.qt + (size_t)cloud * QK_IMG, rt, lane, q, stg);
+  store_rp<2>(P.krp + (size_t)cloud * QK_IMG, rt, lane, k);
+  store_t<2, 64>(P.kt + (size_t)cloud * QK_IMG, rt, lane, k, stg);
+  store_rp<8>(P.vrp + (size_t)cloud * V_IMG, rt, lane, v);
+  store_t<8, 256>(P.vt + (size_t)cloud * V_IMG, rt, lane, v, stg);
+}
+
+// ================================================================================================================
+// softmax over the keys of S^T (8 tiles x 16 registers + the other half-lane): S <- P, returns ln sum exp + max
+__device__ __forceinline__ float softmax_regs(floatx16 (&S)[8]) {
+  float m = S[0][0];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m = fmaxf(m, S[t][i]);
+  m = fmaxf(m, xor32(m));
+  const float c = 0.125f * LOG2E;       // logits / sqrt(dk), dk = 64 (model5_b.py:70)
+  const float mc = m * c;
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float e = __builtin_amdgcn_exp2f(S[t][i] * c - mc);
+      S[t][i] = e;
+      sum += e;
+    }
+  sum += xor32(sum);
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S[t][i] *= inv;
+  return m * 0.125f + __logf(sum);
+}
+
+// the wavefront's query fragments (B operand of S^T = K q^T): 4 k-steps x 3 planes, straight from the Rp image
+__device__ __forceinline__ void load_own_frags(const unsigned char* img, int rt, int lane, bf16x8 (&f)[4][3]) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) f[ks][p] = *reinterpret_cast<const bf16x8*>(img + (((ks * 3 + p) * 8 + rt) * 64 + lane) * 16);
+}
+
+// ================================================================================================================
+// forward of one block for the wavefront's 32 points
+struct FwdProb {
+  const float* x;                          // [B*L, E] block input
+  const unsigned char *qrp, *krp, *vt;     // images of this layer's q, k, v
+  const unsigned char* w;                  // weight planes
+  const float* bo;
+  float* r;        // [B*L, E] block output
+  float* t;        // [B*L, E] x - attn v (the out projection's input: its weight gradient needs it)
+  uint32_t* mask;  // [B*L, 8] bits of (Wo t + bo > 0)
+  float* map;      // [B, L, L] mean attention map (may be NULL)
+  float* lse;      // [B*L]
+};
+#ifdef ATTN_STAMPS
+#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i)
+#endif
+struct FwdArgs {
+  FwdProb p[2];
+  long long* dbg;
+  int nb;
+  int map_accumulate;   // 0: map = scale * P, 1: map += scale * P
+  float map_scale;
+};
+
+__global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(FwdArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SLAB + 4 * STG_BYTES];   // ring | staging per wavefront
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
+  const int lb = logical_block(blockIdx.x, gridDim.x);
+  const FwdProb& P = a.p[lb / a.nb];
+  const int cb = lb % a.nb, cloud = cb >> 1, rt = (cb & 1) * 4 + wave;
+  const long row = (long)cloud * L + 32 * rt + (lane & 31);
+  const unsigned char* krp = P.krp + (size_t)cloud * QK_IMG;
+  const unsigned char* vt = P.vt + (size_t)cloud * V_IMG;
+  const unsigned char* wo = P.w + W_O;
+  const Ring ring{lds, wave, lane, SLAB};
+  const long row0 = (long)cloud * L + 32 * rt;
+  float* stg = reinterpret_cast<float*>(lds + 3 * SLAB + wave * STG_BYTES);
+  // slab sequence: K 0..3 | V^T 0..15 | Wo 0..15
+  auto src = [&](int c) { return c < 4 ? krp + c * SLAB : c < 20 ? vt + (c - 4) * SLAB : wo + (c - 20) * SLAB; };
+  constexpr int NS = 36;
+
+  STAMP(0);
+  bf16x8 qf[4][3];
+  load_own_frags(P.qrp + (size_t)cloud * QK_IMG, rt, lane, qf);
+  ring.issue<6>(src(0), 0);
+  ring.issue<6>(src(1), 1);
+  floatx16 S[8];
+  ZERO_TILES(S, 8);
+  // ---- S^T = K q^T (4 k-steps over d)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    step_sync(6);
+    auto fill = [&](int t) {
+      if (t < 3) {
+        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t);
+        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t + 1);
+      }
+    };
+    kstep_rp<8>(S, ring.lane_addr(c % 3), qf[c], fill);
+  }
+  STAMP(1);
+  const float lse = softmax_regs(S);
+  if (h == 0) P.lse[row] = lse;
+  STAMP(2);
+  if (P.map) {   // mean of the four blocks' maps (model5_b.py:468-469): this wavefront owns its 32 rows
+    if (a.map_accumulate)
+      store_rows<8, 1>(P.map, row0, L, S, stg, lane, a.map_scale);
+    else
+      store_rows<8, 0>(P.map, row0, L, S, stg, lane, a.map_scale);
+  }
+  STAMP(3);
+  // ---- A^T = V^T P^T (16 k-steps over the keys)
+  floatx16 O[8];
+  ZERO_TILES(O, 8);
+  bf16x8 b[2][3];
+  make_b(S[0], 0, b[0]);
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const int c = 4 + ks;
+    if (ks >= 4 && ks < 8) STAMP(16 + 2 * (ks - 4));
+    step_sync(6);
+    if (ks >= 4 && ks < 8) STAMP(17 + 2 * (ks - 4));
+    BNext bn;
+    auto fill = [&](int t) {
+      if (t < 3) {
+        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t);
+        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t + 1);
+      } else if (t < 7 && ks < 15) {
+        bn.pair(S[(ks + 1) >> 1], (ks + 1) & 1, t - 3);
+      }
+    };
+    kstep_tr<8, 256, 0>(O, TrAddr<256>(ring.slot_addr(c % 3), lane), b[ks & 1], fill);
+    if (ks < 15) bn.get(b[(ks + 1) & 1]);
+  }
+  STAMP(4);
+  // ---- t^T = x^T - A^T (x stays in registers for the residual at the end)
+  floatx16 X[8];
+  load_rows<8>(P.x, row0, E, X, stg, lane);
+#pragma unroll
+  for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) O[ft][i] = X[ft][i] - O[ft][i];
+  STAMP(5);
+  // ---- z^T = Wo t^T (16 k-steps over c)
+  step_sync(6);
+  store_rows<8>(P.t, row0, E, O, stg, lane);   // (behind the barrier, ahead of this step's DMA: see Ring)
+  floatx16 Z[8];
+  bias_tiles<8>(Z, P.bo, h);
+  make_b(O[0], 0, b[0]);
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const int c = 20 + ks;
+    if (ks >= 4 && ks < 8) STAMP(8 + 2 * (ks - 4));
+    if (ks > 0) step_sync(c + 1 < NS ? 6 : 0);
+    if (ks >= 4 && ks < 8) STAMP(9 + 2 * (ks - 4));
+    BNext bn;
+    auto fill = [&](int t) {
+      if (t < 3) {
+        if (c + 2 < NS) {
+          ring.issue1(src(c + 2), (c + 2) % 3, 2 * t);
+          ring.issue1(src(c + 2), (c + 2) % 3, 2 * t + 1);
+        }
+      } else if (t < 7 && ks < 15) {
+        bn.pair(O[(ks + 1) >> 1], (ks + 1) & 1, t - 3);
+      }
+    };
+    kstep_rp<8>(Z, ring.lane_addr(c % 3), b[ks & 1], fill);
+    if (ks < 15) bn.get(b[(ks + 1) & 1]);
+  }
+  STAMP(6);
+  // ---- r^T = x^T + relu(z^T + bo); gate bits for the backward
+  {
+    uint32_t bits[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float z = Z[ft][i];
+        const bool on = z > 0.f;
+        bits[ft >> 1] |= (on ? 1u : 0u) << ((ft & 1) * 16 + i);
+        Z[ft][i] = X[ft][i] + (on ? z : 0.f);
+      }
+    *reinterpret_cast<uint4*>(P.mask + (row * 2 + h) * 4) = make_uint4(bits[0], bits[1], bits[2], bits[3]);
+  }
+  store_rows<8>(P.r, row0, E, Z, stg, lane);
+  STAMP(7);
+}
+
+// ================================================================================================================
+// backward, query side: the wavefront's 32 points as QUERIES.
+//   dz = dr . gate;  dt^T = Wo^T dz^T;  da = -dt (images for the key-side pass);  dP^T = V da^T;  P^T recomputed;
+//   delta = sum_key P dP;  dS^T = P^T (dP^T - delta) / 8;  dq^T = K^T dS^T;  u = dr + dt + dq Wq (partial dx)
+struct BwdQProb {
+  const float* dr;       // [B*L, E] gradient of the block output
+  const uint32_t* mask;
+  const unsigned char *qrp, *krp, *kt, *vrp;
+  const unsigned char* w;
+  float* dz;             // [B*L, E]
+  float* u;              // [B*L, E]
+  float* dq;             // [B*L, DK]
+  unsigned char *darp, *dat;   // images of da
+  float* delta;          // [B*L]
+};
+struct BwdQArgs {
+  BwdQProb p[2];
+  int nb;
+};
+
+__global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SLAB + 4 * STG_BYTES];   // ring | staging per wavefront
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
+  const int lb = logical_block(blockIdx.x, gridDim.x);
+  const BwdQProb& P = a.p[lb / a.nb];
+  const int cb = lb % a.nb, cloud = cb >> 1, rt = (cb & 1) * 4 + wave;
+  const long row = (long)cloud * L + 32 * rt + (lane & 31);
+  const unsigned char* krp = P.krp + (size_t)cloud * QK_IMG;
+  const unsigned char* kt = P.kt + (size_t)cloud * QK_IMG;
+  const unsigned char* vrp = P.vrp + (size_t)cloud * V_IMG;
+  const unsigned char* wot = P.w + W_OT;
+  const unsigned char* wqt = P.w + W_QT;
+  const Ring ring{lds, wave, lane, SLAB};
+  const long row0 = (long)cloud * L + 32 * rt;
+  float* stg = reinterpret_cast<float*>(lds + 3 * SLAB + wave * STG_BYTES);
+  // slab sequence: Wo^T 0..15 | V 0..15 | K 0..3 | K^T (4 k-steps each) 0..3 | Wq^T 0..3
+  auto src = [&](int c) {
+    return c < 16 ? wot + c * SLAB : c < 32 ? vrp + (c - 16) * SLAB : c < 36 ? krp + (c - 32) * SLAB
+           : c < 40 ? kt + (c - 36) * SLAB : wqt + (c - 40) * SLAB;
+  };
+  constexpr int NS = 44;
+
+  floatx16 S[8];     // first dz^T, later S^T / P^T / dS^T
+  load_rows<8>(P.dr, row0, E, S, stg, lane);
+  {
+    const uint4 mb = *reinterpret_cast<const uint4*>(P.mask + (row * 2 + h) * 4);
+    const uint32_t bits[4] = {mb.x, mb.y, mb.z, mb.w};
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (!((bits[ft >> 1] >> ((ft & 1) * 16 + i)) & 1u)) S[ft][i] = 0.f;
+  }
+  store_rows<8>(P.dz, row0, E, S, stg, lane);
+  ring.issue<6>(src(0), 0);
+  ring.issue<6>(src(1), 1);
+  // ---- dt^T = Wo^T dz^T (16 k-steps over o)
+  floatx16 DT[8];
+  ZERO_TILES(DT, 8);
+  bf16x8 b[2][3];
+  make_b(S[0], 0, b[0]);
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const int c = ks;
+    step_sync(6);
+    BNext bn;
+    auto fill = [&](int t) {
+      if (t < 3) {
+        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t);
+        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t + 1);
+      } else if (t < 7 && ks < 15) {
+        bn.pair(S[(ks + 1) >> 1], (ks + 1) & 1, t - 3);
+      }
+    };
+    kstep_rp<8>(DT, ring.lane_addr(c % 3), b[ks & 1], fill);
+    if (ks < 15) bn.get(b[(ks + 1) & 1]);
+  }
+  // ---- DP^T = V dt^T = -dP^T (16 k-steps over c); da images and u0 = dr + dt go to memory at the head of its first step
+  step_sync(6);
+  {
+    store_rp<8, true>(P.darp + (size_t)cloud * V_IMG, rt, lane, DT);
+    store_t<8, 256, true>(P.dat + (size_t)cloud * V_IMG, rt, lane, DT, stg);
+    load_rows<8>(P.dr, row0, E, S, stg, lane);     // (dz^T is dead: S takes dr^T again for u0 = dr + dt)
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) S[ft][i] += DT[ft][i];
+    store_rows<8>(P.u, row0, E, S, stg, lane);
+  }
+  floatx16 DP[8];
+  ZERO_TILES(DP, 8);
+  make_b(DT[0], 0, b[0]);
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const int c = 16 + ks;
+    if (ks > 0) step_sync(6);
+    BNext bn;
+    auto fill = [&](int t) {
+      if (t < 3) {
+        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t);
+        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t + 1);
+      } else if (t < 7 && ks < 15) {
+        bn.pair(DT[(ks + 1) >> 1], (ks + 1) & 1, t - 3);
+      }
+    };
+    kstep_rp<8>(DP, ring.lane_addr(c % 3), b[ks & 1], fill);
+    if (ks < 15) bn.get(b[(ks + 1) & 1]);
+  }
+  // ---- S^T = K q^T, P^T
+  ZERO_TILES(S, 8);
+  bf16x8 qf[4][3];
+  load_own_frags(P.qrp + (size_t)cloud * QK_IMG, rt, lane, qf);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int c = 32 + ks;
+    step_sync(6);
+    auto fill = [&](int t) {
+      if (t < 3) {
+        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t);
+        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t + 1);
+      }
+    };
+    kstep_rp<8>(S, ring.lane_addr(c % 3), qf[ks], fill);
+  }
+  softmax_regs(S);
+  {  // delta = sum P dP;  dS = P (dP - delta) / 8  with dP = -DP
+    float d = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) d -= S[t][i] * DP[t][i];
+    d += xor32(d);
+    if (h == 0) P.delta[row] = d;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) S[t][i] = S[t][i] * (-DP[t][i] - d) * 0.125f;
+  }
+  // ---- dq^T = K^T dS^T (16 k-steps over the keys, 4 per slab; rows = d)
+  floatx16 DQ[2];
+  ZERO_TILES(DQ, 2);
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+    const int c = 36 + sl;
+    step_sync(6);
+    ring.issue<6>(src(c + 2), (c + 2) % 3);
+    const TrAddr<64> ta(ring.slot_addr(c % 3), lane);
+    static_for<0, 4>([&](auto iq) {
+      constexpr int q4 = decltype(iq)::value;
+      const int ks = 4 * sl + q4;
+      make_b(S[ks >> 1], ks & 1, b[0]);
+      kstep_tr<2, 64, q4 * 6144>(DQ, ta, b[0]);
+    });
+  }
+  // ---- u^T = u0^T + Wq^T dq^T (4 k-steps over d): the accumulators start from u0
+  floatx16 U[8];
+  step_sync(6);
+  store_rows<2>(P.dq, row0, DK, DQ, stg, lane);
+  load_rows<8>(P.u, row0, E, U, stg, lane);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int c = 40 + ks;
+    if (ks > 0) step_sync(c + 1 < NS ? 6 : 0);
+    auto fill = [&](int t) {
+      if (t < 3 && c + 2 < NS) {
+        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t);
+        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t + 1);
+      }
+    };
+    make_b(DQ[ks >> 1], ks & 1, b[0]);
+    kstep_rp<8>(U, ring.lane_addr(c % 3), b[0], fill);
+  }
+  store_rows<8>(P.u, row0, E, U, stg, lane);
+}
+
+// ================================================================================================================
+// backward, key side: the wavefront's 32 points as KEYS, the cloud's 256 queries walked two 32-row tiles at a time.
+//   S = q k^T (key on the lane), P = exp(S/8 - lse_q), dP = da v^T, dS = P (dP - delta_q) / 8,
+//   dv^T += da^T P, dk^T += q^T dS;  then dx = u + dk Wk + dv Wv for the wavefront's points
+struct BwdKProb {
+  const unsigned char *qrp, *qt, *krp, *vrp, *darp, *dat;
+  const unsigned char* w;
+  const float *lse, *delta;
+  const float* u;     // [B*L, E]
+  float* dk;          // [B*L, DK]
+  float* dv;          // [B*L, E]
+  float* dx;          // [B*L, E]
+};
+struct BwdKArgs {
+  BwdKProb p[2];
+  int nb;
+};
+
+__global__ __launch_bounds__(NT, 1) void attn_bwd_k_kernel(BwdKArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SLAB + 2048 + 4 * STG_BYTES];   // ring | lse[256] | delta[256] | staging
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
+  const int lb = logical_block(blockIdx.x, gridDim.x);
+  const BwdKProb& P = a.p[lb / a.nb];
+  const int cb = lb % a.nb, cloud = cb >> 1, rt = (cb & 1) * 4 + wave;
+  const long row = (long)cloud * L + 32 * rt + (lane & 31);
+  const unsigned char* qrp = P.qrp + (size_t)cloud * QK_IMG;
+  const unsigned char* qt = P.qt + (size_t)cloud * QK_IMG;
+  const unsigned char* vrp = P.vrp + (size_t)cloud * V_IMG;
+  const unsigned char* darp = P.darp + (size_t)cloud * V_IMG;
+  const unsigned char* dat = P.dat + (size_t)cloud * V_IMG;
+  const unsigned char* wkvt = P.w + W_KVT;
+  const Ring ring{lds, wave, lane, SLAB};
+  const long row0 = (long)cloud * L + 32 * rt;
+  float* stg = reinterpret_cast<float*>(lds + 3 * SLAB + 2048 + wave * STG_BYTES);
+  float* row_consts = reinterpret_cast<float*>(lds + 3 * SLAB);
+  row_consts[tid] = P.lse[(long)cloud * L + tid];
+  row_consts[256 + tid] = P.delta[(long)cloud * L + tid];
+
+  // this wavefront's key fragments (B operand of S = q k^T): 4 k-steps x 3 planes
+  bf16x8 kf[4][3];
+  load_own_frags(P.krp + (size_t)cloud * QK_IMG, rt, lane, kf);
+  // value fragments of this wavefront's keys (B operand of dP = da v^T), four k-steps at a time
+  bf16x8 vb[2][4][3];
+  auto load_vb = [&](int m, bf16x8 (&dst)[4][3]) {
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        dst[k4][p] = *reinterpret_cast<const bf16x8*>(vrp + ((((4 * m + k4) * 3 + p) * 8 + rt) * 64 + lane) * 16);
+  };
+
+  floatx16 DV[8], DKt[2];
+  ZERO_TILES(DV, 8);
+  ZERO_TILES(DKt, 2);
+
+  // Slabs of one PAIR of query tiles (2 pr, 2 pr + 1), 24 KB each, in consumption order (slab index c = 10 pr + j):
+  //   j = 0     A:  q Rp rows of the two tiles, 4 k-steps                       S  = q k^T
+  //   j = 1..4  B:  da Rp rows of the two tiles, k-steps 4 (j-1) .. 4 (j-1) + 3  dP = da v^T
+  //   j = 5..8  C:  da T k-step 4 pr + (j-5)  (16 queries x 256 c)               dv^T += da^T P
+  //   j = 9     D:  q T k-steps 4 pr .. 4 pr + 3                                 dk^T += q^T dS
+  // then the 20 k-step slabs of [Wk^T | Wv^T] (c = 40..59).
+  auto issue_slab = [&](int c) {
+    const int slot = c % 3;
+    if (c >= 40) {
+      if (c < 60) ring.issue<6>(wkvt + (c - 40) * SLAB, slot);
+      return;
+    }
+    const int pr = c / 10, j = c % 10;
+    if (j == 0)
+      ring.issue_tiles(qrp, 0, pr, slot);
+    else if (j < 5)
+      ring.issue_tiles(darp, 4 * (j - 1), pr, slot);
+    else if (j < 9)
+      ring.issue<6>(dat + (4 * pr + (j - 5)) * SLAB, slot);
+    else
+      ring.issue<6>(qt + (4 * pr) * 6144, slot);
+  };
+  issue_slab(0);
+  issue_slab(1);
+  load_vb(0, vb[0]);
+  __syncthreads();   // row constants in LDS (drains the first two slabs once)
+
+  for (int pr = 0; pr < 4; ++pr) {
+    const int c0 = 10 * pr;
+    // ---- S tiles (2 x 32 queries x this wavefront's 32 keys)
+    floatx16 S1[2], DP1[2];
+    ZERO_TILES(S1, 2);
+    ZERO_TILES(DP1, 2);
+    step_sync(6);
+    issue_slab(c0 + 2);
+    chain_rp1<4, 0>(S1[0], ring.lane_addr(c0 % 3), kf);
+    chain_rp1<4, 12288>(S1[1], ring.lane_addr(c0 % 3), kf);
+    // P = exp(S / 8 - lse_q): the query is the register's row
+    {
+      const float c = 0.125f * LOG2E;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 ls = *reinterpret_cast<const float4*>(row_consts + 64 * pr + 32 * t + 8 * g + 4 * h);
+          const float lv[4] = {ls.x, ls.y, ls.z, ls.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) S1[t][4 * g + e] = __builtin_amdgcn_exp2f(S1[t][4 * g + e] * c - lv[e] * LOG2E);
+        }
+    }
+    // ---- dP tiles = da v^T (16 k-steps over c in four slabs); B = this wavefront's value fragments
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int c = c0 + 1 + m;
+      step_sync(6);
+      if (m < 3)
+        load_vb(m + 1, vb[(m + 1) & 1]);   // (ahead of this step's DMA: older than it, landed by the next step_sync)
+      issue_slab(c + 2);
+      chain_rp1<4, 0>(DP1[0], ring.lane_addr(c % 3), vb[m & 1]);
+      chain_rp1<4, 12288>(DP1[1], ring.lane_addr(c % 3), vb[m & 1]);
+    }
+    // dS = P (dP - delta_q) / 8
+    floatx16 DS1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 de = *reinterpret_cast<const float4*>(row_consts + 256 + 64 * pr + 32 * t + 8 * g + 4 * h);
+        const float dv4[4] = {de.x, de.y, de.z, de.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) DS1[t][4 * g + e] = S1[t][4 * g + e] * (DP1[t][4 * g + e] - dv4[e]) * 0.125f;
+      }
+    // ---- dv^T += da^T P (four k-steps of 16 queries, rows = c)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int c = c0 + 5 + m;
+      step_sync(6);
+      if (m == 0 && pr < 3) load_vb(0, vb[0]);
+      issue_slab(c + 2);
+      bf16x8 b[3];
+      make_b(S1[m >> 1], m & 1, b);
+      kstep_tr<8, 256, 0>(DV, TrAddr<256>(ring.slot_addr(c % 3), lane), b);
+    }
+    // ---- dk^T += q^T dS (four k-steps, rows = d)
+    {
+      const int c = c0 + 9;
+      step_sync(6);
+      issue_slab(c + 2);
+      const TrAddr<64> ta(ring.slot_addr(c % 3), lane);
+      static_for<0, 4>([&](auto im) {
+        constexpr int m = decltype(im)::value;
+        bf16x8 b[3];
+        make_b(DS1[m >> 1], m & 1, b);
+        kstep_tr<2, 64, m * 6144>(DKt, ta, b);
+      });
+    }
+  }
+  // ---- dx^T = u^T + Wk^T dk^T + Wv^T dv^T (4 + 16 k-steps)
+  floatx16 DX[8];
+  bf16x8 bt[2][3];
+  make_b(DKt[0], 0, bt[0]);
+  step_sync(6);
+  store_rows<2>(P.dk, row0, DK, DKt, stg, lane);
+  store_rows<8>(P.dv, row0, E, DV, stg, lane);
+  load_rows<8>(P.u, row0, E, DX, stg, lane);
+#pragma unroll
+  for (int ks = 0; ks < 20; ++ks) {
+    const int c = 40 + ks;
+    if (ks > 0) step_sync(ks < 19 ? 6 : 0);
+    BNext bn;
+    auto fill = [&](int t) {
+      if (t < 3) {
+        if (c + 2 < 60) {
+          ring.issue1(wkvt + (c + 2 - 40) * SLAB, (c + 2) % 3, 2 * t);
+          ring.issue1(wkvt + (c + 2 - 40) * SLAB, (c + 2) % 3, 2 * t + 1);
+        }
+      } else if (t < 7 && ks < 19) {
+        const int kn = ks + 1;
+        if (kn < 4)
+          bn.pair(DKt[kn >> 1], kn & 1, t - 3);
+        else
+          bn.pair(DV[(kn - 4) >> 1], kn & 1, t - 3);
+      }
+    };
+    kstep_rp<8>(DX, ring.lane_addr(c % 3), bt[ks & 1], fill);
+    if (ks < 19) bn.get(bt[(ks + 1) & 1]);
+  }
+  store_rows<8>(P.dx, row0, E, DX, stg, lane);
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// ================================================================================================================
+// C ABI.  All entry points take up to two independent problems (the two encoders of predict5, model5_b.py:700-707)
+// so that one launch fills the chip: 2 B workgroups of four wavefronts per problem, one wavefront per SIMD.
+PZN_EXPORT size_t pzn_attn_fused_weight_bytes(void) { return W_BYTES; }
+PZN_EXPORT size_t pzn_attn_fused_qk_image_bytes(int B) { return B > 0 ? (size_t)B * QK_IMG : 0; }
+PZN_EXPORT size_t pzn_attn_fused_v_image_bytes(int B) { return B > 0 ? (size_t)B * V_IMG : 0; }
+
+PZN_EXPORT int pzn_attn_fused_supported(int L_, int E_, int dk) { return L_ == L && E_ == E && dk == DK; }
+
+// planes of one block's weights (Wq, Wk [dk, E]; Wv, Wo [E, E]) for all five kernels
+PZN_EXPORT int pzn_attn_fused_prep_weights(const float* Wq, const float* Wk, const float* Wv, const float* Wo, void* planes,
+                                           pzn_stream_t stream) {
+  PZN_CHECK_ARG(Wq && Wk && Wv && Wo && planes && aligned16(planes));
+  unsigned char* w = static_cast<unsigned char*>(planes);
+  PackArgs a;
+  a.njobs = 8;
+  // W_QKV: rows n = q | k | v, k = c
+  a.job[0] = PackJob{Wq, E, 1, 2, 16, 12, 0, 0, w + W_QKV};
+  a.job[1] = PackJob{Wk, E, 1, 2, 16, 12, 2, 0, w + W_QKV};
+  a.job[2] = PackJob{Wv, E, 1, 8, 16, 12, 4, 0, w + W_QKV};
+  a.job[3] = PackJob{Wo, E, 1, 8, 16, 8, 0, 0, w + W_O};        // rows o, k = c
+  a.job[4] = PackJob{Wo, 1, E, 8, 16, 8, 0, 0, w + W_OT};       // rows c, k = o:  A[c][o] = Wo[o][c]
+  a.job[5] = PackJob{Wq, 1, E, 8, 4, 8, 0, 0, w + W_QT};        // rows c, k = d:  A[c][d] = Wq[d][c]
+  a.job[6] = PackJob{Wk, 1, E, 8, 4, 8, 0, 0, w + W_KVT};       // rows c, k = d
+  a.job[7] = PackJob{Wv, 1, E, 8, 16, 8, 0, 4, w + W_KVT};      // rows c, k = c' (k-steps 4..19)
+  hipLaunchKernelGGL(pack_rp_kernel, dim3(12, 8), dim3(256), 0, pzn_hip_stream(stream), a);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+// q, k, v images of `nprob` problems: x[i][B*L, E], weight planes w[i], biases; images: qrp, qt, krp, kt (QK size), vrp, vt
+PZN_EXPORT int pzn_attn_fused_proj(int nprob, const float* const* x, const void* const* w, const float* const* bq,
+                                   const float* const* bk, const float* const* bv, int B, void* const* qrp, void* const* qt,
+                                   void* const* krp, void* const* kt, void* const* vrp, void* const* vt, pzn_stream_t stream) {
+  PZN_CHECK_ARG(nprob >= 1 && nprob <= 2 && B > 0 && x && w && bq && bk && bv && qrp && qt && krp && kt && vrp && vt);
+  ProjArgs a;
+  a.nb = 2 * B;
+  for (int i = 0; i < nprob; ++i) {
+    PZN_CHECK_ARG(x[i] && w[i] && bq[i] && bk[i] && bv[i] && qrp[i] && qt[i] && krp[i] && kt[i] && vrp[i] && vt[i]);
+    PZN_CHECK_ARG(aligned16(x[i]) && aligned16(w[i]) && aligned16(bq[i]) && aligned16(bk[i]) && aligned16(bv[i]) &&
+                  aligned16(qrp[i]) && aligned16(qt[i]) && aligned16(krp[i]) && aligned16(kt[i]) && aligned16(vrp[i]) &&
+                  aligned16(vt[i]));
+    a.p[i] = ProjProb{x[i], static_cast<const unsigned char*>(w[i]), bq[i], bk[i], bv[i],
+                      static_cast<unsigned char*>(qrp[i]), static_cast<unsigned char*>(qt[i]),
+                      static_cast<unsigned char*>(krp[i]), static_cast<unsigned char*>(kt[i]),
+                      static_cast<unsigned char*>(vrp[i]), static_cast<unsigned char*>(vt[i])};
+  }
+  hipLaunchKernelGGL(attn_proj_kernel, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+// one block forward: r = x + relu(Wo (x - softmax(q k^T / 8) v) + bo); also t = x - attn v, the gate bits, ln-sum-exp per
+// row and (map[i] != NULL) the running mean map: map = scale P (accumulate = 0) or map += scale P
+PZN_EXPORT int pzn_attn_fused_fwd(int nprob, const float* const* x, const void* const* qrp, const void* const* krp,
+                                  const void* const* vt, const void* const* w, const float* const* bo, int B,
+                                  float* const* r, float* const* t, void* const* mask, float* const* map, float* const* lse,
+                                  int map_accumulate, float map_scale, pzn_stream_t stream) {
+  PZN_CHECK_ARG(nprob >= 1 && nprob <= 2 && B > 0 && x && qrp && krp && vt && w && bo && r && t && mask && map && lse);
+  FwdArgs a;
+  a.dbg = nullptr;
+#ifdef ATTN_STAMPS
+  {
+    static long long* d = nullptr;
+    if (!d) hipMalloc(&d, 64 * sizeof(long long));
+    a.dbg = d;
+  }
+#endif
+  a.nb = 2 * B;
+  a.map_accumulate = map_accumulate;
+  a.map_scale = map_scale;
+  for (int i = 0; i < nprob; ++i) {
+    PZN_CHECK_ARG(x[i] && qrp[i] && krp[i] && vt[i] && w[i] && bo[i] && r[i] && t[i] && mask[i] && lse[i]);
+    PZN_CHECK_ARG(aligned16(x[i]) && aligned16(qrp[i]) && aligned16(krp[i]) && aligned16(vt[i]) && aligned16(w[i]) &&
+                  aligned16(bo[i]) && aligned16(r[i]) && aligned16(t[i]) && aligned16(mask[i]) && aligned16(map[i]));
+    a.p[i] = FwdProb{x[i], static_cast<const unsigned char*>(qrp[i]), static_cast<const unsigned char*>(krp[i]),
+                     static_cast<const unsigned char*>(vt[i]), static_cast<const unsigned char*>(w[i]), bo[i], r[i], t[i],
+                     static_cast<uint32_t*>(mask[i]), map[i], lse[i]};
+  }
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
+#ifdef ATTN_STAMPS
+  {
+    long long hst[24];
+    hipStreamSynchronize(pzn_hip_stream(stream));
+    hipMemcpy(hst, a.dbg, sizeof(hst), hipMemcpyDeviceToHost);
+    fprintf(stderr, "fwd stamps:");
+    for (int i = 1; i < 8; ++i) fprintf(stderr, " %lld", hst[i] - hst[i - 1]);
+    fprintf(stderr, "  total %lld | O steps (sync, compute):", hst[7] - hst[0]);
+    for (int i = 8; i < 15; ++i) fprintf(stderr, " %lld", hst[i + 1] - hst[i]);
+    fprintf(stderr, " | PV steps:");
+    for (int i = 16; i < 23; ++i) fprintf(stderr, " %lld", hst[i + 1] - hst[i]);
+    fprintf(stderr, "\n");
+  }
+#endif
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+// backward, query side (see attn_bwd_q_kernel): writes dz, u, dq, delta and the two images of da
+PZN_EXPORT int pzn_attn_fused_bwd_q(int nprob, const float* const* dr, const void* const* mask, const void* const* qrp,
+                                    const void* const* krp, const void* const* kt, const void* const* vrp,
+                                    const void* const* w, int B, float* const* dz, float* const* u, float* const* dq,
+                                    void* const* darp, void* const* dat, float* const* delta, pzn_stream_t stream) {
+  PZN_CHECK_ARG(nprob >= 1 && nprob <= 2 && B > 0 && dr && mask && qrp && krp && kt && vrp && w && dz && u && dq && darp &&
+                dat && delta);
+  BwdQArgs a;
+  a.nb = 2 * B;
+  for (int i = 0; i < nprob; ++i) {
+    PZN_CHECK_ARG(dr[i] && mask[i] && qrp[i] && krp[i] && kt[i] && vrp[i] && w[i] && dz[i] && u[i] && dq[i] && darp[i] &&
+                  dat[i] && delta[i]);
+    PZN_CHECK_ARG(aligned16(dr[i]) && aligned16(mask[i]) && aligned16(qrp[i]) && aligned16(krp[i]) && aligned16(kt[i]) &&
+                  aligned16(vrp[i]) && aligned16(w[i]) && aligned16(dz[i]) && aligned16(u[i]) && aligned16(dq[i]) &&
+                  aligned16(darp[i]) && aligned16(dat[i]));
+    a.p[i] = BwdQProb{dr[i], static_cast<const uint32_t*>(mask[i]), static_cast<const unsigned char*>(qrp[i]),
+                      static_cast<const unsigned char*>(krp[i]), static_cast<const unsigned char*>(kt[i]),
+                      static_cast<const unsigned char*>(vrp[i]), static_cast<const unsigned char*>(w[i]), dz[i], u[i], dq[i],
+                      static_cast<unsigned char*>(darp[i]), static_cast<unsigned char*>(dat[i]), delta[i]};
+  }
+  hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+// backward, key side (see attn_bwd_k_kernel): writes dk, dv and the block's input gradient dx
+PZN_EXPORT int pzn_attn_fused_bwd_k(int nprob, const void* const* qrp, const void* const* qt, const void* const* krp,
+                                    const void* const* vrp, const void* const* darp, const void* const* dat,
+                                    const void* const* w, const float* const* lse, const float* const* delta,
+                                    const float* const* u, int B, float* const* dk, float* const* dv, float* const* dx,
+                                    pzn_stream_t stream) {
+  PZN_CHECK_ARG(nprob >= 1 && nprob <= 2 && B > 0 && qrp && qt && krp && vrp && darp && dat && w && lse && delta && u && dk &&
+                dv && dx);
+  BwdKArgs a;
+  a.nb = 2 * B;
+  for (int i = 0; i < nprob; ++i) {
+    PZN_CHECK_ARG(qrp[i] && qt[i] && krp[i] && vrp[i] && darp[i] && dat[i] && w[i] && lse[i] && delta[i] && u[i] && dk[i] &&
+                  dv[i] && dx[i]);
+    PZN_CHECK_ARG(aligned16(qrp[i]) && aligned16(qt[i]) && aligned16(krp[i]) && aligned16(vrp[i]) && aligned16(darp[i]) &&
+                  aligned16(dat[i]) && aligned16(w[i]) && aligned16(lse[i]) && aligned16(delta[i]) && aligned16(u[i]) &&
+                  aligned16(dk[i]) && aligned16(dv[i]) && aligned16(dx[i]));
+    a.p[i] = BwdKProb{static_cast<const unsigned char*>(qrp[i]), static_cast<const unsigned char*>(qt[i]),
+                      static_cast<const unsigned char*>(krp[i]), static_cast<const unsigned char*>(vrp[i]),
+                      static_cast<const unsigned char*>(darp[i]), static_cast<const unsigned char*>(dat[i]),
+                      static_cast<const unsigned char*>(w[i]), lse[i], delta[i], u[i], dk[i], dv[i], dx[i]};
+  }
+  hipLaunchKernelGGL(attn_bwd_k_kernel, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
+  PZN_RETURN_LAUNCH_STATUS();
+}

@@ -1224,6 +1224,34 @@ PZN_EXPORT int pzn_attn_block_bwd_f32(const float* x, const float* Wq, const flo
   return rc;
 }
 
+// Weight gradients of one layerAttention block from what the chained kernels (attnfused.hip) leave in memory:
+//   dWo += dz^T t, dbo += sum dz;   dWq/k/v += dq/dk/dv^T x, dbq/k/v += column sums   (overwritten when !accumulate)
+PZN_EXPORT int pzn_attn_fused_wgrads(const float* dz, const float* t, const float* dq, const float* dkk, const float* dvv,
+                                     const float* x, int M, int E, int dk, float* dWq, float* dbq, float* dWk, float* dbk,
+                                     float* dWv, float* dbv, float* dWo, float* dbo, int accumulate, pzn_stream_t stream) {
+  PZN_CHECK_ARG(dz && t && dq && dkk && dvv && x && dWq && dbq && dWk && dbk && dWv && dbv && dWo && dbo && M > 0 && E > 0 &&
+                dk > 0);
+  hipStream_t st = pzn_hip_stream(stream);
+  int rc = pzn_linear_wgrad_f32(dz, nullptr, t, M, E, E, dWo, dbo, accumulate, stream);
+  if (rc != PZN_OK) return rc;
+  const float* const dys[3] = {dq, dkk, dvv};
+  const int ns[3] = {dk, dk, E};
+  float* const dWs[3] = {dWq, dWk, dWv};
+  float* const dbs[3] = {dbq, dbk, dbv};
+  if (!accumulate) {
+    for (int i = 0; i < 3; ++i) {
+      if (pzn_zero_async(dWs[i], (size_t)ns[i] * E, st) != PZN_OK) return PZN_ELAUNCH;
+      if (pzn_zero_async(dbs[i], (size_t)ns[i], st) != PZN_OK) return PZN_ELAUNCH;
+    }
+  }
+  rc = gemm_precision() != 0 ? pzn_df_wgrad3(dys, ns, dWs, dbs, x, E, M, E, st) : PZN_EUNSUPPORTED;
+  if (rc != PZN_EUNSUPPORTED) return rc;
+  rc = pzn_linear_wgrad_f32(dq, nullptr, x, M, E, dk, dWq, dbq, 1, stream);
+  if (rc == PZN_OK) rc = pzn_linear_wgrad_f32(dkk, nullptr, x, M, E, dk, dWk, dbk, 1, stream);
+  if (rc == PZN_OK) rc = pzn_linear_wgrad_f32(dvv, nullptr, x, M, E, E, dWv, dbv, 1, stream);
+  return rc;
+}
+
 // Shared MLP + max over the K = 32 neighbours (model5_b.py:452-454 / 459-461):
 //   h = relu(x W1^T + b1) [R*32, C1] (kept for the backward);  out[R,C2] = max_k relu(h W2^T + b2), argmax
 PZN_EXPORT int pzn_sharedmlp_max_fwd_f32(const float* x, const float* W1, const float* b1, const float* W2,

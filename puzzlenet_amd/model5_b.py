@@ -149,6 +149,29 @@ class PCTransformer_nonsort(nn.Module):
         x_feature = F.relu(self.bn1(dense.linear(xyz, self.mlp1.weight, self.mlp1.bias)))          # :447
         return F.relu(self.bn2(dense.linear(x_feature, self.mlp2.weight, self.mlp2.bias)))        # :448
 
+    def _block_params(self):
+        return [(a.mlpq.weight, a.mlpq.bias, a.mlpk.weight, a.mlpk.bias, a.mlpv.weight, a.mlpv.bias, a.out.weight, a.out.bias)
+                for a in (self.atten1, self.atten2, self.atten3, self.atten4)]
+
+    def stem(self, xyz, sa_plan=None, x_feature=None):
+        """:447-461: per-point MLP and the two set-abstraction levels -> (x2, f2f, x_feature)."""
+        if x_feature is None:
+            x_feature = self.local_features(xyz)
+        if self.fused_sa and not xyz.requires_grad:
+            p1, p2 = sa_plan if sa_plan is not None else (None, None)
+            x, f1f = self._set_abstraction(512, 32, xyz, x_feature, self.mlp3, self.mlp4, p1)
+            x2, f2f = self._set_abstraction(256, 32, x, f1f, self.mlp5, self.mlp6, p2)
+        else:
+            x, f1 = self.sg1(512, 0, 32, xyz, x_feature, False, True)                             # :449
+            f1f = dense.shared_mlp_max(f1, self.mlp3.weight, self.mlp3.bias, self.mlp4.weight, self.mlp4.bias)  # :452-454
+            x2, f2 = self.sg2(256, 0, 32, x, f1f, False, True)                                    # :456
+            f2f = dense.shared_mlp_max(f2, self.mlp5.weight, self.mlp5.bias, self.mlp6.weight, self.mlp6.bias)  # :459-461
+        return x2, f2f, x_feature
+
+    def chain_fused_ok(self, f2f):
+        return _ATTN_FUSED and f2f.is_cuda and ops.attention_chain_fused_supported(
+            f2f, self.atten1.mlpq.weight.shape[0], self.out.weight)
+
     def forward(self, xyz, sa_plan=None, x_feature=None):
         if x_feature is None:
             x_feature = self.local_features(xyz)
@@ -163,6 +186,10 @@ class PCTransformer_nonsort(nn.Module):
             x2, f2 = self.sg2(256, 0, 32, x, f1f, False, True)                                    # :456
             f2f = dense.shared_mlp_max(f2, self.mlp5.weight, self.mlp5.bias, self.mlp6.weight, self.mlp6.bias)  # :459-461
         blocks = (self.atten1, self.atten2, self.atten3, self.atten4)
+        if self.chain_fused_ok(f2f):
+            # :462-475 through the chained matrix-core kernels (csrc/attnfused.hip), one encoder per launch here
+            (out, attention, f_global), = ops.attention_chain_fused([f2f], [self._block_params()], [self.out.weight], [self.out.bias])
+            return f_global, x2, attention, out, x_feature
         if _ATTN_CHAIN and f2f.is_cuda and ops.attention_chain_supported(f2f, self.atten1.mlpq.weight.shape[0], self.out.weight):
             # :462-474 as one autograd node: no concatenation, no gradient-accumulation adds between the blocks
             out, attention, f_global = ops.attention_chain_out(
@@ -187,6 +214,11 @@ class PCTransformer_nonsort(nn.Module):
 
 _BN_FUSED = os.environ.get("PZN_BN_FUSED", "1") != "0"     # tuning aid
 _ATTN_CHAIN = os.environ.get("PZN_ATTN_CHAIN", "1") != "0"     # tuning aid: 0 = four autograd nodes + cat + linear
+_ATTN_FUSED = os.environ.get("PZN_ATTN_FUSED", "1") != "0"     # tuning aid: 0 = the composed block kernels (gemm.hip)
+# 1 = both encoders' chains in the same launches on one stream.  Measured slower than one chain per encoder and stream
+# (10.5 vs 10.2 ms per step): a single encoder's launch is 128 workgroups at one wavefront per SIMD, so the two streams
+# already fill the chip, and the joint launches take the stems' overlap away.
+_ATTN_DUAL = os.environ.get("PZN_ATTN_DUAL", "0") != "0"
 _EMD_SIDE = int(os.environ.get("PZN_EMD_SIDE", "2"))     # tuning aid: 0 = the N x N EMD on the main stream, 1 = forked right after the pose head, 2 = after the heads (measured best)
 
 
@@ -269,6 +301,21 @@ class TouchedRegraster(_Base):
                 for lvl in plan_f:
                     lvl[0].record_stream(cur)
             xf_m.record_stream(side)
+            if _ATTN_FUSED and _ATTN_DUAL and ops.attention_chain_fused_available():
+                # the two encoders' stems on two streams, then BOTH attention chains in the same launches on this one
+                # (a launch of one encoder is 128 four-wave workgroups at one wavefront per SIMD: half the chip)
+                with torch.cuda.stream(side):
+                    x2_m, f2f_m, xf_m2 = self.Encoder2.stem(mrpc, plan_m, xf_m)
+                x2_f, f2f_f, xf_f2 = self.Encoder.stem(fpc, plan_f, xf_f)
+                cur.wait_stream(side)
+                for t in (x2_m, f2f_m, xf_m2):
+                    t.record_stream(cur)
+                rf, rm = ops.attention_chain_fused(
+                    [f2f_f, f2f_m], [self.Encoder._block_params(), self.Encoder2._block_params()],
+                    [self.Encoder.out.weight, self.Encoder2.out.weight], [self.Encoder.out.bias, self.Encoder2.out.bias])
+                ffpcs = (rf[2], x2_f, rf[1], rf[0], xf_f2)
+                fmrpcs = (rm[2], x2_m, rm[1], rm[0], xf_m2)
+                return self._heads(ffpcs, fmrpcs, N, need, pose_hook)
             with torch.cuda.stream(side):
                 fmrpcs = self.Encoder2(mrpc, plan_m, xf_m)                          # :716
             ffpcs = self.Encoder(fpc, plan_f, xf_f)                                 # :710

@@ -929,6 +929,197 @@ def attention_chain_supported(x, dk, w_out):
     return attention_block_supported(x, dk) and w_out.shape[1] == 5 * x.shape[2] and x.shape[2] % 4 == 0
 
 
+def _ptrs(ts):
+    """Array of device pointers, one per problem, for the nprob entry points."""
+    return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+def attention_chain_fused_available():
+    """The chained kernels compute the fp32-accurate (bf16x3) path only: not with the exact-fp32 engine selected, not in
+    the opt-in bf16 attention mode."""
+    lib = _lib.load()
+    return lib.pzn_gemm_get_precision() != 0 and lib.pzn_attn_get_precision() == 0
+
+
+def attention_chain_fused_supported(x, dk, w_out):
+    """The chained-kernel path (csrc/attnfused.hip) takes the model's shape only: L = 256, E = 256, dk = 64."""
+    return (x.is_cuda and x.dim() == 3 and w_out.shape[1] == 5 * x.shape[2]
+            and bool(_lib.load().pzn_attn_fused_supported(x.shape[1], x.shape[2], dk))
+            and attention_chain_fused_available())
+
+
+class _AttnChainFused(torch.autograd.Function):
+    """model5_b.py:462-475 for nprob = 1 or 2 encoders in the same launches: the four layerAttention blocks as chained
+    matrix-core kernels (pzn_attn_fused_*: no q / k / v / score tensors in memory, one projection + one block launch
+    per layer forward, two launches + the weight gradients per layer backward), the running mean of the four maps
+    written by the block kernel, then — per encoder — the out projection over the five slices and the max over the
+    points exactly as _AttnChainOut does them.
+    inputs: nprob, then per problem x[B,L,E], 4 x (wq,bq,wk,bk,wv,bv,wo,bo), w_out, b_out
+    -> per problem (out[B,L,Nout], attention[B,L,L], f_global[B,Nout])"""
+
+    @staticmethod
+    def forward(ctx, nprob, *args):
+        per = 35
+        xs = [_f32(args[per * i], "x") for i in range(nprob)]
+        pss = [[_f32(t, "param") for t in args[per * i + 1: per * i + 35]] for i in range(nprob)]
+        B, L, E = xs[0].shape
+        dk = pss[0][0].shape[0]
+        Nout = pss[0][32].shape[0]
+        dev = xs[0].device
+        M = B * L
+        lib = _lib.load()
+        wbytes, qkb, vb = lib.pzn_attn_fused_weight_bytes(), lib.pzn_attn_fused_qk_image_bytes(B), lib.pzn_attn_fused_v_image_bytes(B)
+        mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        raw = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+        R = range(nprob)
+        with torch.cuda.device(dev):
+            st = _stream()
+            W = [[raw(wbytes) for _ in range(4)] for _ in R]
+            for p in R:
+                for i in range(4):
+                    wq, bq, wk, bk, wv, bv, wo, bo = pss[p][8 * i: 8 * i + 8]
+                    _call("pzn_attn_fused_prep_weights", _p(wq), _p(wk), _p(wv), _p(wo), _p(W[p][i]), st)
+            maps = [mk(B, L, L) for _ in R]
+            cur = [x.reshape(M, E) for x in xs]
+            saved = [[] for _ in R]
+            for i in range(4):
+                img = [[raw(qkb), raw(qkb), raw(qkb), raw(qkb), raw(vb), raw(vb)] for _ in R]   # qrp, qt, krp, kt, vrp, vt
+                _call("pzn_attn_fused_proj", nprob, _ptrs(cur), _ptrs([W[p][i] for p in R]),
+                      _ptrs([pss[p][8 * i + 1] for p in R]), _ptrs([pss[p][8 * i + 3] for p in R]),
+                      _ptrs([pss[p][8 * i + 5] for p in R]), B, *[_ptrs([img[p][j] for p in R]) for j in range(6)], st,
+                      flops=nprob * 2 * M * E * (2 * dk + E))
+                r = [mk(M, E) for _ in R]
+                t = [mk(M, E) for _ in R]
+                mask = [torch.empty((M, 8), dtype=torch.int32, device=dev) for _ in R]
+                lse = [mk(M) for _ in R]
+                _call("pzn_attn_fused_fwd", nprob, _ptrs(cur), _ptrs([img[p][0] for p in R]), _ptrs([img[p][2] for p in R]),
+                      _ptrs([img[p][5] for p in R]), _ptrs([W[p][i] for p in R]), _ptrs([pss[p][8 * i + 7] for p in R]), B,
+                      _ptrs(r), _ptrs(t), _ptrs(mask), _ptrs(maps), _ptrs(lse), int(i > 0), 0.25, st,
+                      flops=nprob * (2 * M * E * E + 2 * B * L * L * (dk + E)))
+                for p in R:
+                    saved[p].append((cur[p], t[p], mask[p], lse[p], img[p][0], img[p][1], img[p][2], img[p][3], img[p][4],
+                                     W[p][i]))
+                cur = r
+            outs, tosave = [], []
+            for p in R:
+                w_out, b_out = pss[p][32], pss[p][33]
+                y = mk(M, Nout)
+                xsl = [saved[p][1][0], saved[p][2][0], saved[p][3][0], cur[p], xs[p].reshape(M, E)]   # att1..att4, f2f (:466)
+                for i, xi in enumerate(xsl):
+                    _call("pzn_linear_slice_fwd_f32", _p(xi), w_out.data_ptr() + 4 * E * i, 5 * E, _p(b_out), M, E, Nout,
+                          int(i > 0), _p(y), st, flops=2 * M * E * Nout)
+                f_global = mk(B, Nout)
+                arg = torch.empty((B, Nout), dtype=torch.int32, device=dev)
+                _call("pzn_maxpool_points_fwd_f32", _p(y), B, L, Nout, _p(f_global), _p(arg), st)
+                outs += [y.view(B, L, Nout), maps[p], f_global]
+                tosave += [t_ for blk in saved[p] for t_ in blk] + [cur[p]] + pss[p] + [arg]
+        ctx.save_for_backward(*tosave)
+        ctx.nprob = nprob
+        ctx.dims = (B, L, E, dk, Nout)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(*maps)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gout):
+        B, L, E, dk, Nout = ctx.dims
+        nprob = ctx.nprob
+        R = range(nprob)
+        per_saved = 40 + 1 + 34 + 1
+        T = ctx.saved_tensors
+        M = B * L
+        dev = T[0].device
+        mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        raw = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+        lib = _lib.load()
+        vb = lib.pzn_attn_fused_v_image_bytes(B)
+        grads = [None] * (1 + 35 * nprob)
+        saved, ps, g, Gs, direct_blk = [], [], [], [], []
+        with torch.cuda.device(dev):
+            st = _stream()
+            for p in R:
+                t = T[per_saved * p: per_saved * (p + 1)]
+                saved.append([t[10 * i: 10 * i + 10] for i in range(4)])
+                att4 = t[40]
+                ps.append(t[41:75])
+                arg = t[75]
+                dy, dfg = gout[3 * p], gout[3 * p + 2]
+                w_out, b_out = ps[p][32], ps[p][33]
+                base = 1 + 35 * p
+                sparse = dy is None and dfg is not None and (5 * E) % 64 == 0 and L <= 600
+                if sparse:
+                    dfg = _f32(dfg, "df_global")
+                else:
+                    if dfg is not None:
+                        dmax = mk(B, L, Nout)
+                        _call("pzn_maxpool_points_bwd_f32", _p(_f32(dfg, "df_global")), _p(arg), B, L, Nout, _p(dmax), st)
+                        dy = dmax if dy is None else dy + dmax
+                    if dy is None:
+                        dy = torch.zeros((M, Nout), dtype=torch.float32, device=dev)
+                    dy = _f32(dy, "dy").reshape(M, Nout)
+                xsl = [saved[p][1][0], saved[p][2][0], saved[p][3][0], att4, saved[p][0][0]]
+                sink_w = _sink(w_out, ctx.needs_input_grad[base + 33])
+                sink_b = _sink(b_out, ctx.needs_input_grad[base + 34])
+                direct_out = sink_w is not None and sink_b is not None
+                dW_out = sink_w if direct_out else torch.zeros_like(w_out)
+                db_out = sink_b if direct_out else torch.zeros_like(b_out)
+                G = mk(M, 5 * E)
+                if sparse:
+                    segs = (ctypes.c_void_p * 5)(*[_p(xi) for xi in xsl])
+                    _call("pzn_linear_maxpts_wgrad_f32", _p(dfg), _p(arg), segs, 5, E, B, L, Nout, _p(dW_out), _p(db_out), st)
+                    mws = torch.empty((lib.pzn_linear_maxpts_workspace_bytes(B, Nout) + 3) // 4, dtype=torch.int32, device=dev)
+                    _call("pzn_linear_maxpts_dgrad_f32", _p(dfg), _p(arg), _p(w_out), B, L, 5 * E, Nout, _p(mws), _p(G), st)
+                else:
+                    for i, xi in enumerate(xsl):
+                        _call("pzn_linear_slice_wgrad_f32", _p(dy), _p(xi), M, E, Nout, dW_out.data_ptr() + 4 * E * i, 5 * E,
+                              _p(db_out) if i == 0 else None, st, flops=2 * M * E * Nout)
+                    _call("pzn_linear_dgrad_f32", _p(dy), None, _p(w_out), M, 5 * E, Nout, None, _p(G), st,
+                          flops=2 * M * 5 * E * Nout)
+                if not direct_out:
+                    grads[base + 33], grads[base + 34] = dW_out, db_out
+                Gs.append(G)
+                g.append(G[:, 3 * E: 4 * E].contiguous())
+            # scratch of the block backward, shared by the four layers
+            dz, u, dx = [mk(M, E) for _ in R], [mk(M, E) for _ in R], [mk(M, E) for _ in R]
+            dq, dkk, dvv = [mk(M, dk) for _ in R], [mk(M, dk) for _ in R], [mk(M, E) for _ in R]
+            darp, dat, delta = [raw(vb) for _ in R], [raw(vb) for _ in R], [mk(M) for _ in R]
+            for i in (3, 2, 1, 0):
+                blk = [saved[p][i] for p in R]        # (x, t, mask, lse, qrp, qt, krp, kt, vrp, W)
+                col = lambda j: _ptrs([b[j] for b in blk])
+                _call("pzn_attn_fused_bwd_q", nprob, _ptrs(g), col(2), col(4), col(6), col(7), col(8), col(9), B, _ptrs(dz),
+                      _ptrs(u), _ptrs(dq), _ptrs(darp), _ptrs(dat), _ptrs(delta), st,
+                      flops=nprob * (2 * M * E * (E + dk) + 2 * B * L * L * (2 * dk + E)))
+                _call("pzn_attn_fused_bwd_k", nprob, col(4), col(5), col(6), col(8), _ptrs(darp), _ptrs(dat), col(9), col(3),
+                      _ptrs(delta), _ptrs(u), B, _ptrs(dkk), _ptrs(dvv), _ptrs(dx), st,
+                      flops=nprob * (2 * M * E * (E + dk) + 2 * B * L * L * (2 * dk + 2 * E)))
+                for p in R:
+                    base = 1 + 35 * p
+                    prm = ps[p][8 * i: 8 * i + 8]
+                    sinks = [_sink(p_, ctx.needs_input_grad[base + 1 + 8 * i + j]) for j, p_ in enumerate(prm)]
+                    direct = all(s_ is not None for s_ in sinks)
+                    gp = sinks if direct else [torch.empty_like(p_) for p_ in prm]
+                    gq, gbq, gk, gbk, gv, gbv, go, gbo = gp
+                    _call("pzn_attn_fused_wgrads", _p(dz[p]), _p(blk[p][1]), _p(dq[p]), _p(dkk[p]), _p(dvv[p]), _p(blk[p][0]),
+                          M, E, dk, _p(gq), _p(gbq), _p(gk), _p(gbk), _p(gv), _p(gbv), _p(go), _p(gbo), int(direct), st,
+                          flops=2 * M * E * (2 * dk + 2 * E))
+                    if not direct:
+                        grads[base + 1 + 8 * i: base + 9 + 8 * i] = gp
+                    sl = i - 1 if i > 0 else 4
+                    g[p] = torch.add(Gs[p][:, sl * E: (sl + 1) * E], dx[p])
+            for p in R:
+                grads[1 + 35 * p] = g[p].view(B, L, E)
+        return tuple(grads)
+
+
+def attention_chain_fused(xs, blocks_list, w_outs, b_outs):
+    """xs: list of nprob inputs [B,L,E]; blocks_list[p]: four 8-tuples; -> list of (out, mean map, f_global) per problem"""
+    flat = []
+    for x, blocks, w, b in zip(xs, blocks_list, w_outs, b_outs):
+        flat += [x] + [p_ for blk in blocks for p_ in blk] + [w, b]
+    res = _AttnChainFused.apply(len(xs), *flat)
+    return [res[3 * i: 3 * i + 3] for i in range(len(xs))]
+
+
 class _SaMlpMax(torch.autograd.Function):
     """Set abstraction as the encoder runs it (model5_b.py:449-454 / :456-461): group the K=32 neighbours
     (pointnet_util.py:123-132), two shared-MLP layers, max over K — on padded rows {dx,dy,dz,0,f...}, with

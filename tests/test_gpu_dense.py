@@ -490,3 +490,135 @@ def test_linear_maxpts_sparse_backward(dev, B, L, seg_cols, nseg, Nout):
     ref = 0.25 + dout.reshape(B * L, Nout).t() @ torch.cat(xs, 1).double()
     assert _rel(dW, ref.float()) < 1e-5
     assert _rel(db, (-2.0 + dg.double().sum(0)).float()) < 1e-5
+
+
+# ---------------------------------------------------------------- chained attention kernels (csrc/attnfused.hip)
+
+def _attn_block_ref64(x, wq, bq, wk, bk, wv, bv, wo, bo, dr):
+    """model5_b.py:67-101 and its backward, every intermediate the chained kernels leave in memory, in float64."""
+    D = torch.float64
+    X = x.to(D)
+    q, k, v = X @ wq.to(D).T + bq.to(D), X @ wk.to(D).T + bk.to(D), X @ wv.to(D).T + bv.to(D)
+    s = q @ k.transpose(1, 2) / 8
+    P = torch.softmax(s, dim=-1)
+    t = X - P @ v
+    z = t @ wo.to(D).T + bo.to(D)
+    r = X + torch.relu(z)
+    DR = dr.to(D)
+    dz = DR * (z > 0)
+    dt = dz @ wo.to(D)
+    dP = (-dt) @ v.transpose(1, 2)
+    delta = (P * dP).sum(-1)
+    dS = P * (dP - delta[..., None]) / 8
+    dq, dk, dv = dS @ k, dS.transpose(1, 2) @ q, P.transpose(1, 2) @ (-dt)
+    u = DR + dt + dq @ wq.to(D)
+    dx = u + dk @ wk.to(D) + dv @ wv.to(D)
+    return dict(r=r, t=t, map=P, lse=torch.logsumexp(s, dim=-1), dz=dz, delta=delta, dq=dq, u=u, dk=dk, dv=dv, dx=dx, z=z)
+
+
+@pytest.mark.parametrize("B", [2, 64])
+def test_attention_fused_block_intermediates(dev, B):
+    """One layerAttention block through pzn_attn_fused_{prep_weights,proj,fwd,bwd_q,bwd_k}: the block output, x - attn v,
+    the attention map, ln-sum-exp, and every backward intermediate (dz, delta, dq, u, dk, dv, dx) against float64 at
+    1e-5 relative (measured 1e-7 .. 8e-7); B = 64 is the production launch (128 workgroups)."""
+    from puzzlenet_amd import _lib, ops
+    L, E, dk = 256, 256, 64
+    M = B * L
+    g = torch.Generator().manual_seed(3)
+    x = (0.5 * torch.randn(M, E, generator=g)).to(dev)
+    wq, wk = [(torch.randn(dk, E, generator=g) / 16).to(dev) for _ in range(2)]
+    wv, wo = [(torch.randn(E, E, generator=g) / 16).to(dev) for _ in range(2)]
+    bq, bk = [(torch.randn(dk, generator=g) / 4).to(dev) for _ in range(2)]
+    bv, bo = [(torch.randn(E, generator=g) / 4).to(dev) for _ in range(2)]
+    dr = torch.randn(M, E, generator=g).to(dev)
+    lib = _lib.load()
+    assert lib.pzn_attn_fused_supported(L, E, dk)
+    P = ops._ptrs
+    st = torch.cuda.current_stream().cuda_stream
+    raw = lambda n: torch.zeros(n, dtype=torch.uint8, device=dev)
+    mk = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+    W = raw(lib.pzn_attn_fused_weight_bytes())
+    _lib.call("pzn_attn_fused_prep_weights", wq.data_ptr(), wk.data_ptr(), wv.data_ptr(), wo.data_ptr(), W.data_ptr(), st)
+    qkb, vb = lib.pzn_attn_fused_qk_image_bytes(B), lib.pzn_attn_fused_v_image_bytes(B)
+    qrp, qt, krp, kt, vrp, vt = raw(qkb), raw(qkb), raw(qkb), raw(qkb), raw(vb), raw(vb)
+    _lib.call("pzn_attn_fused_proj", 1, P([x]), P([W]), P([bq]), P([bk]), P([bv]), B, P([qrp]), P([qt]), P([krp]), P([kt]),
+              P([vrp]), P([vt]), st)
+    r, t, lse, amap = mk(M, E), mk(M, E), mk(M), mk(B, L, L)
+    mask = torch.zeros((M, 8), dtype=torch.int32, device=dev)
+    _lib.call("pzn_attn_fused_fwd", 1, P([x]), P([qrp]), P([krp]), P([vt]), P([W]), P([bo]), B, P([r]), P([t]), P([mask]),
+              P([amap]), P([lse]), 0, 1.0, st)
+    dz, u, dq, delta = mk(M, E), mk(M, E), mk(M, dk), mk(M)
+    darp, dat = raw(vb), raw(vb)
+    _lib.call("pzn_attn_fused_bwd_q", 1, P([dr]), P([mask]), P([qrp]), P([krp]), P([kt]), P([vrp]), P([W]), B, P([dz]), P([u]),
+              P([dq]), P([darp]), P([dat]), P([delta]), st)
+    dkk, dvv, dx = mk(M, dk), mk(M, E), mk(M, E)
+    _lib.call("pzn_attn_fused_bwd_k", 1, P([qrp]), P([qt]), P([krp]), P([vrp]), P([darp]), P([dat]), P([W]), P([lse]),
+              P([delta]), P([u]), B, P([dkk]), P([dvv]), P([dx]), st)
+    ref = _attn_block_ref64(x.view(B, L, E), wq, bq, wk, bk, wv, bv, wo, bo, dr.view(B, L, E))
+    # the ReLU gate is discrete: elements whose pre-activation is within rounding of zero may be gated differently
+    gate = (ref["z"].abs() > 1e-5).reshape(M, E)
+    got = dict(r=r, t=t, map=amap, lse=lse, dz=dz, delta=delta, dq=dq, u=u, dk=dkk, dv=dvv, dx=dx)
+    flips = int(((dz != 0) != (ref["dz"].reshape(M, E) != 0))[gate].sum())
+    assert flips == 0
+    for name, val in got.items():
+        want = ref[name].reshape(val.shape)
+        tol = 1e-5 if int(((dz != 0) != (ref["dz"].reshape(M, E) != 0)).sum()) == 0 else 1e-3
+        assert _rel(val.double(), want) < tol, (name, _rel(val.double(), want))
+
+
+@pytest.mark.parametrize("nprob,use", [(1, "max"), (2, "max"), (2, "out")])
+def test_attention_chain_fused_vs_float64(dev, nprob, use):
+    """ops.attention_chain_fused (model5_b.py:462-475 for one or two encoders in the same launches) against a float64
+    composition: outputs at 1e-5, every gradient (35 tensors per encoder) at 2e-4 of its maximum (the key biases,
+    whose gradient is mathematically zero, against the 5e-2 floor), in relative L2 at 1e-4."""
+    from puzzlenet_amd import ops
+    B, L, E, dk, Nout = 4, 256, 256, 64, 1024
+    g = torch.Generator().manual_seed(11)
+    shapes = [(dk, E), (dk,), (dk, E), (dk,), (E, E), (E,), (E, E), (E,)]
+    probs = []
+    for _ in range(nprob):
+        x0 = (0.5 * torch.randn(B, L, E, generator=g)).to(dev)
+        blocks0 = [[(torch.randn(*s, generator=g) / (math.sqrt(E) if len(s) == 2 else 4)).to(dev) for s in shapes] for _ in range(4)]
+        w0 = (torch.randn(Nout, 5 * E, generator=g) / math.sqrt(5 * E)).to(dev)
+        b0 = (0.1 * torch.randn(Nout, generator=g)).to(dev)
+        wg = torch.randn(B, Nout, generator=g).to(dev) if use == "max" else (torch.randn(B, L, Nout, generator=g) / 16).to(dev)
+        probs.append((x0, blocks0, w0, b0, wg))
+
+    def leafs(dtype):
+        out = []
+        for x0, blocks0, w0, b0, wg in probs:
+            out.append((x0.to(dtype).clone().requires_grad_(True),
+                        [[p.to(dtype).clone().requires_grad_(True) for p in blk] for blk in blocks0],
+                        w0.to(dtype).clone().requires_grad_(True), b0.to(dtype).clone().requires_grad_(True), wg.to(dtype)))
+        return out
+
+    def ref64(x, blocks, w, b):
+        cur, maps, outs = x, [], []
+        for wq, bq, wk, bk, wv, bv, wo, bo in blocks:
+            q, k, v = cur @ wq.T + bq, cur @ wk.T + bk, cur @ wv.T + bv
+            a = torch.softmax(q @ k.transpose(-2, -1) / math.sqrt(q.shape[-1]), dim=-1)
+            cur = cur + torch.relu((cur - a @ v) @ wo.T + bo)
+            maps.append(a)
+            outs.append(cur)
+        y = torch.cat(outs + [x], dim=-1) @ w.T + b
+        return y, sum(maps) / 4, y.max(dim=1)[0]
+
+    res, grads = {}, {}
+    for kind, dtype in (("fused", torch.float32), ("ref", torch.float64)):
+        lf = leafs(dtype)
+        if kind == "fused":
+            assert ops.attention_chain_fused_supported(lf[0][0], dk, lf[0][2])
+            out = ops.attention_chain_fused([l[0] for l in lf], [l[1] for l in lf], [l[2] for l in lf], [l[3] for l in lf])
+        else:
+            out = [ref64(x, blocks, w, b) for x, blocks, w, b, _ in lf]
+        loss = sum((r[2 if use == "max" else 0] * l[4]).sum() for r, l in zip(out, lf))
+        loss.backward()
+        res[kind] = [(r[0].detach(), r[1].detach(), r[2].detach()) for r in out]
+        grads[kind] = [[x.grad] + [p.grad for blk in blocks for p in blk] + [w.grad, b.grad] for x, blocks, w, b, _ in lf]
+    for p in range(nprob):
+        for a_, b_ in zip(res["fused"][p], res["ref"][p]):
+            assert _rel(a_.double(), b_) < 1e-5
+        for i, (a_, b_) in enumerate(zip(grads["fused"][p], grads["ref"][p])):
+            assert float((a_.double() - b_).abs().max()) < 2e-4 * max(float(b_.abs().max()), 5e-2), i
+            if float(b_.norm()) > 1e-3:
+                assert _rel(a_.double(), b_) < 1e-4, i
