@@ -441,7 +441,8 @@ int pzn_attn_fused_wgrads(const float* dz, const float* t, const float* dq, cons
 
 /* torch.max(x, dim=1) over the point axis (model5_b.py:475 global feature, :741): out[b,c] =
  * max_l x[b,l,c], idx[b,c] = its row (the lowest one on ties); backward dx[b,l,c] =
- * (l == idx[b,c]) ? dout[b,c] : 0, every element of dx written (C % 4 == 0, 16-byte aligned). */
+ * (l == idx[b,c]) ? dout[b,c] : 0, every element of dx written (any C; C % 4 == 0 with 16-byte aligned
+ * pointers takes the vector kernels). */
 int pzn_maxpool_points_fwd_f32(const float* x, int B, int L, int C, float* out, int32_t* idx,
                                pzn_stream_t stream);
 int pzn_maxpool_points_bwd_f32(const float* dout, const int32_t* idx, int B, int L, int C,
@@ -484,7 +485,10 @@ int pzn_comp_fwd_f32(const float* g, const float* igt, int B, float* loss, pzn_s
 int pzn_comp_bwd_f32(const float* g, const float* igt, const float* dloss, int B, float* dg, pzn_stream_t stream);
 /* Boundary head losses (model5_b.py:1063-1064 F.cross_entropy(logits[B,2,N], labels) with mean reduction, and :1085-1090
  * softmax(logits, dim=1)[:, 1, :]): labels[B,N] hold 0 / 1 as floats (dataset.py:1363-1366).  fwd: prob1[B,N] (class-1
- * probability, what the top-128 selection ranks by), loss[0] (overwritten).  bwd: dlogits[B,2,N] = dloss[0] * d loss / d logits. */
+ * probability, what the top-128 selection ranks by), loss[0] (overwritten); loss points at PZN_BOUNDARY_CE_LOSS_FLOATS floats:
+ * the value and the per-workgroup partial sums it is reduced from in a fixed order (bit-reproducible).
+ * bwd: dlogits[B,2,N] = dloss[0] * d loss / d logits. */
+#define PZN_BOUNDARY_CE_LOSS_FLOATS 513
 int pzn_boundary_ce_fwd_f32(const float* logits, const float* labels, int B, int N, float* prob1, float* loss,
                             pzn_stream_t stream);
 int pzn_boundary_ce_bwd_f32(const float* logits, const float* labels, const float* dloss, int B, int N,

@@ -421,10 +421,40 @@ __global__ __launch_bounds__(256) void maxpts_bwd_kernel(const float* __restrict
 
 }  // namespace
 
+// any C, any alignment: one thread per (cloud, channel), consecutive threads on consecutive channels (the round-1 form;
+// the vector kernels above need C % 4 == 0 and 16-byte aligned pointers)
+__global__ __launch_bounds__(256) void maxpts_fwd_scalar_kernel(const float* __restrict__ x, int L, int C,
+                                                                float* __restrict__ out, int32_t* __restrict__ idx) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  const float* p = x + (size_t)b * L * C + c;
+  float best = p[0];
+  int bi = 0;
+  for (int l = 1; l < L; ++l) {
+    const float v = p[(size_t)l * C];
+    if (v > best) best = v, bi = l;     // first maximum wins, as torch.max
+  }
+  out[(size_t)b * C + c] = best;
+  idx[(size_t)b * C + c] = bi;
+}
+__global__ __launch_bounds__(256) void maxpts_bwd_scalar_kernel(const float* __restrict__ dout, const int32_t* __restrict__ idx,
+                                                                int L, int C, float* __restrict__ dx) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  const int sel = idx[(size_t)b * C + c];
+  const float g = dout[(size_t)b * C + c];
+  float* p = dx + (size_t)b * L * C + c;
+  for (int l = 0; l < L; ++l) p[(size_t)l * C] = l == sel ? g : 0.f;
+}
+
 PZN_EXPORT int pzn_maxpool_points_fwd_f32(const float* x, int B, int L, int C, float* out, int32_t* idx,
                                           pzn_stream_t stream) {
-  PZN_CHECK_ARG(x && out && idx && B > 0 && B <= 65535 && L > 0 && C > 0 && (C & 3) == 0);
-  PZN_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  PZN_CHECK_ARG(x && out && idx && B > 0 && B <= 65535 && L > 0 && C > 0);
+  if ((C & 3) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) {
+    hipLaunchKernelGGL(maxpts_fwd_scalar_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0,
+                       pzn_hip_stream(stream), x, L, C, out, idx);
+    PZN_RETURN_LAUNCH_STATUS();
+  }
   hipLaunchKernelGGL(maxpts_fwd_kernel, dim3((unsigned)((C + 127) / 128), (unsigned)B), dim3(MAXPTS_T), 0,
                      pzn_hip_stream(stream), x, L, C, out, idx);
   PZN_RETURN_LAUNCH_STATUS();
@@ -432,8 +462,13 @@ PZN_EXPORT int pzn_maxpool_points_fwd_f32(const float* x, int B, int L, int C, f
 
 PZN_EXPORT int pzn_maxpool_points_bwd_f32(const float* dout, const int32_t* idx, int B, int L, int C, float* dx,
                                           pzn_stream_t stream) {
-  PZN_CHECK_ARG(dout && idx && dx && B > 0 && B <= 65535 && L > 0 && C > 0 && (C & 3) == 0);
-  PZN_CHECK_ARG(((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
+  PZN_CHECK_ARG(dout && idx && dx && B > 0 && B <= 65535 && L > 0 && C > 0);
+  if ((C & 3) != 0 ||
+      ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(dx)) & 15) != 0) {
+    hipLaunchKernelGGL(maxpts_bwd_scalar_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0,
+                       pzn_hip_stream(stream), dout, idx, L, C, dx);
+    PZN_RETURN_LAUNCH_STATUS();
+  }
   const size_t per_batch = (size_t)L * (C >> 2);
   size_t gx = (per_batch + 255) / 256;
   if (gx > 64) gx = 64;

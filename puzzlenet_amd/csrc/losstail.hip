@@ -149,7 +149,15 @@ __global__ __launch_bounds__(256) void boundary_ce_fwd_kernel(const float* __res
     s += lse - (labels[e] != 0.f ? l1 : l0);
   }
   s = block_sum(s, sh);
-  if (threadIdx.x == 0) atomicAdd(loss, s / (float)total);
+  if (threadIdx.x == 0) loss[1 + blockIdx.x] = s;     // per-workgroup partial; summed in a fixed order below
+}
+
+// loss[0] = (sum of the nparts partials in index order) / total: bit-reproducible, unlike float atomics across workgroups
+__global__ __launch_bounds__(64) void boundary_ce_reduce_kernel(float* __restrict__ loss, int nparts, float inv_total) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 64) s += loss[1 + i];
+  s = pzn::wave_sum_f32(s);
+  if (threadIdx.x == 0) loss[0] = s * inv_total;
 }
 
 __global__ __launch_bounds__(256) void boundary_ce_bwd_kernel(const float* __restrict__ logits,
@@ -364,10 +372,11 @@ PZN_EXPORT int pzn_boundary_ce_fwd_f32(const float* logits, const float* labels,
                                        pzn_stream_t stream) {
   PZN_CHECK_ARG(logits && labels && prob1 && loss && B > 0 && N > 0);
   hipStream_t st = pzn_hip_stream(stream);
-  if (pzn_zero_async(loss, 1, st) != PZN_OK) return PZN_ELAUNCH;
   const long total = (long)B * N;
-  hipLaunchKernelGGL(boundary_ce_fwd_kernel, dim3((unsigned)grid_for(total, 256, 512)), dim3(256), 0, st, logits, labels, N,
-                     total, prob1, loss);
+  const int nparts = (int)grid_for(total, 256, 512);
+  hipLaunchKernelGGL(boundary_ce_fwd_kernel, dim3((unsigned)nparts), dim3(256), 0, st, logits, labels, N, total, prob1, loss);
+  if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
+  hipLaunchKernelGGL(boundary_ce_reduce_kernel, dim3(1), dim3(64), 0, st, loss, nparts, 1.f / (float)total);
   PZN_RETURN_LAUNCH_STATUS();
 }
 

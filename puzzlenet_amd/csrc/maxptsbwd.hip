@@ -206,7 +206,10 @@ PZN_EXPORT int pzn_linear_maxpts_dgrad_f32(const float* dg, const int32_t* arg, 
   if (Kin % MD_COLS != 0 || lds > (size_t)MD_LDS_LIMIT || L > 65535 || Nout > 16384 ||
       ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0)
     return PZN_EUNSUPPORTED;
-  static bool attr_set = false;      // (benign race: the attribute is idempotent)
+  static bool attr_set_dev[64] = {};      // per device: the attribute belongs to the device's copy of the kernel
+  int devid = 0;                          // (benign race: the attribute is idempotent)
+  if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return PZN_ELAUNCH;
+  bool& attr_set = attr_set_dev[devid];
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(maxpts_lin_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             MD_LDS_LIMIT) != hipSuccess)

@@ -2,11 +2,13 @@
 
 The reference has no distributed code at all.  Pairs are
 independent, so each rank runs the whole step on its own 64 pairs and the only
-exchange is the gradient all-reduce: 8,059,220 fp32 = 32.24 MB, ONE flat bucket,
-one `all_reduce(SUM)` per step (ring time ~0.4 ms on 7x153 GB/s xGMI links vs a
-step of tens of ms, so it is issued once after backward rather than bucketed and
-overlapped).  BatchNorm statistics stay rank-local, exactly as a per-GPU run of
-the reference would behave (model5_b.py:424,447: the BN channel axis is N).
+exchange is the gradient all-reduce: 8,059,220 fp32 = 32.24 MB in ONE flat buffer,
+reduced in two pieces: the "early" piece (heads, attention blocks, out projections:
+31 MB, complete once the attention chains' backward has been enqueued) goes out on a
+communication stream while the set-abstraction backward still runs; the "late" piece
+(the encoders' per-point and shared MLPs: 1 MB) follows after the last backward node.
+BatchNorm statistics stay rank-local, exactly as a per-GPU run of the reference would
+behave (model5_b.py:424,447: the BN channel axis is N).
 """
 import os
 
@@ -45,13 +47,27 @@ class FlatGradAllReduce:
     so the per-step exchange is a single collective on 32 MB and optimizer / zero_grad
     touch one tensor."""
 
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params, late=None):
+        """params: iterable of parameters, or of (name, parameter) pairs when `late` is given.
+        late(name) -> True for parameters whose gradient is complete only at the very end of the backward: they are
+        laid out behind all others, so that [0, split) can be reduced early (all_reduce_early) and [split, n) late."""
+        items = list(params)
+        if items and isinstance(items[0], tuple):
+            named = [(n, p) for n, p in items if p.requires_grad]
+        else:
+            named = [("", p) for p in items if p.requires_grad]
+        if late is not None:
+            named = [np_ for np_ in named if not late(np_[0])] + [np_ for np_ in named if late(np_[0])]
+        n_early = sum(1 for n_, _ in named if late is None or not late(n_))
+        self.params = [p for _, p in named]
         # every tensor starts on a 16-byte boundary of the bucket (kernels read weights / biases with 16-byte loads)
         self.offsets, n = [], 0
         for p in self.params:
             self.offsets.append(n)
             n += (p.numel() + 3) // 4 * 4
+        self.split = self.offsets[n_early] if n_early < len(self.params) else n     # first element of the late piece
+        self._early_done = False
+        self._comm = None
         ref = self.params[0]
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
         for p, off in zip(self.params, self.offsets):
@@ -64,11 +80,44 @@ class FlatGradAllReduce:
 
     def zero_(self):
         self.flat.zero_()
+        self._early_done = False
+
+    def _active(self):
+        return dist.is_initialized() and dist.get_world_size() > 1
+
+    def _reduce(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t.div_(dist.get_world_size())
+
+    def all_reduce_early(self, events=()):
+        """Reduce [0, split) now.  On the GPU the collective is enqueued on a communication stream behind `events`
+        (recorded where the producers of these gradients were enqueued), so it overlaps with the rest of the backward;
+        all_reduce_mean() later joins it."""
+        if not self._active() or self.split == 0 or self._early_done:
+            return
+        early = self.flat[:self.split]
+        if self.flat.is_cuda:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=self.flat.device)
+            for ev in events:
+                self._comm.wait_event(ev)
+            with torch.cuda.stream(self._comm):
+                self._reduce(early)
+        else:
+            self._reduce(early)
+        self._early_done = True
 
     def all_reduce_mean(self):
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(dist.get_world_size())
+        """After the whole backward: reduce what all_reduce_early did not, and order the caller's stream behind both."""
+        if not self._active():
+            return
+        if self._early_done:
+            if self.split < self.flat.numel():
+                self._reduce(self.flat[self.split:])
+            if self._comm is not None:
+                torch.cuda.current_stream().wait_stream(self._comm)
+        else:
+            self._reduce(self.flat)
 
 
 class FlatAdam:

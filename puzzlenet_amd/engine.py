@@ -18,6 +18,15 @@ from . import _lib
 from . import distributed as pdist
 
 
+_LATE_LAYERS = ("mlp1.", "mlp2.", "mlp3.", "mlp4.", "mlp5.", "mlp6.", "bn1.", "bn2.")
+
+
+def late_gradient(name):
+    """Parameters of TouchedRegraster whose gradient is produced by the last nodes of the backward: the encoders'
+    per-point MLP + BatchNorm (model5_b.py:447-448) and set-abstraction MLPs (:452-461)."""
+    return name.startswith(("Encoder.", "Encoder2.")) and name.split(".", 1)[1].startswith(_LATE_LAYERS)
+
+
 class TrainStep:
     def __init__(self, model, batch, lr, world=1, use_graph=False, warmup=0):
         if use_graph:
@@ -26,15 +35,37 @@ class TrainStep:
         self.model = model
         self.batch = batch
         self.world = world
-        self.grads = pdist.FlatGradAllReduce(model.parameters())
+        # "late" gradients = the encoders' per-point and set-abstraction layers (last nodes of the backward); everything
+        # else is complete once both attention chains' backward has been enqueued and is reduced early (N > 1)
+        self.grads = pdist.FlatGradAllReduce(model.named_parameters(), late=late_gradient)
+        self._sync_events = []
+        self._saved_hooks = None
+        if world > 1 and hasattr(model, "Encoder") and hasattr(model, "Encoder2"):
+            self._saved_hooks = (getattr(model.Encoder, "f2f_grad_hook", None), getattr(model.Encoder2, "f2f_grad_hook", None))
+            model.Encoder.f2f_grad_hook = model.Encoder2.f2f_grad_hook = self._on_f2f_grad
         # Adam + StepLR(50, 0.999) over flat buffers: one launch per step (distributed.FlatAdam; model5_b.py:1453-1457)
         self.opt = pdist.FlatAdam(self.grads, lr, sched_step=50, sched_gamma=0.999)
         self.loss = None
         self._saved_defer = getattr(model, "defer_emd_loss", False)
         model.defer_emd_loss = True
 
+    def _on_f2f_grad(self, grad):
+        """Tensor hook on the input of an encoder's attention chain: its gradient exists, so every gradient of the
+        heads, the attention blocks and the out projection of that encoder has been enqueued.  After both encoders the
+        early piece of the bucket goes out on the communication stream."""
+        if grad.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._sync_events.append(ev)
+        else:
+            self._sync_events.append(None)
+        if len(self._sync_events) == 2:
+            self.grads.all_reduce_early([e for e in self._sync_events if e is not None])
+        return None
+
     def _fwd_bwd(self):
         self.grads.zero_()
+        self._sync_events = []
         out = self.model.training_step(self.batch, 0)
         cur = torch.cuda.current_stream()
         if "loss" in out:
@@ -68,6 +99,9 @@ class TrainStep:
     def close(self):
         """Give the model back as it was handed in (a later direct model.training_step() returns {'loss': ...} again)."""
         self.model.defer_emd_loss = self._saved_defer
+        if self._saved_hooks is not None:
+            self.model.Encoder.f2f_grad_hook, self.model.Encoder2.f2f_grad_hook = self._saved_hooks
+            self._saved_hooks = None
 
     def __enter__(self):
         return self

@@ -129,6 +129,12 @@ class PCTransformer_nonsort(nn.Module):
         self.out = nn.Linear(gs2_feature_size * 2 * 5, 1024)
 
     fused_sa = True     # False: literally sample_and_group -> [B,S,K,3+D] -> shared MLP, as the reference composes it
+    f2f_grad_hook = None     # engine.TrainStep (N > 1): called with the gradient of the attention chain's input
+
+    def _mark_f2f(self, f2f):
+        if self.f2f_grad_hook is not None and f2f.requires_grad:
+            f2f.register_hook(self.f2f_grad_hook)
+        return f2f
 
     def _set_abstraction(self, npoint, nsample, xyz, feat, lin_a, lin_b, plan=None):
         """sample_and_group(npoint, 0, nsample, xyz, feat, knn=True) + relu(lin_a) + relu(lin_b) + max over K.
@@ -166,7 +172,7 @@ class PCTransformer_nonsort(nn.Module):
             f1f = dense.shared_mlp_max(f1, self.mlp3.weight, self.mlp3.bias, self.mlp4.weight, self.mlp4.bias)  # :452-454
             x2, f2 = self.sg2(256, 0, 32, x, f1f, False, True)                                    # :456
             f2f = dense.shared_mlp_max(f2, self.mlp5.weight, self.mlp5.bias, self.mlp6.weight, self.mlp6.bias)  # :459-461
-        return x2, f2f, x_feature
+        return x2, self._mark_f2f(f2f), x_feature
 
     def chain_fused_ok(self, f2f):
         return _ATTN_FUSED and f2f.is_cuda and ops.attention_chain_fused_supported(
@@ -186,6 +192,7 @@ class PCTransformer_nonsort(nn.Module):
             x2, f2 = self.sg2(256, 0, 32, x, f1f, False, True)                                    # :456
             f2f = dense.shared_mlp_max(f2, self.mlp5.weight, self.mlp5.bias, self.mlp6.weight, self.mlp6.bias)  # :459-461
         blocks = (self.atten1, self.atten2, self.atten3, self.atten4)
+        self._mark_f2f(f2f)
         if self.chain_fused_ok(f2f):
             # :462-475 through the chained matrix-core kernels (csrc/attnfused.hip), one encoder per launch here
             (out, attention, f_global), = ops.attention_chain_fused([f2f], [self._block_params()], [self.out.weight], [self.out.bias])

@@ -286,12 +286,12 @@ class _BoundaryCE(torch.autograd.Function):
         if C != 2 or tuple(labels.shape) != (B, N):
             raise _lib.PznError(f"boundary_ce expects logits[B,2,N], labels[B,N]; got {tuple(logits.shape)}, {tuple(labels.shape)}")
         prob1 = torch.empty((B, N), dtype=torch.float32, device=logits.device)
-        loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+        loss = torch.empty((513,), dtype=torch.float32, device=logits.device)   # PZN_BOUNDARY_CE_LOSS_FLOATS: value + partials
         with torch.cuda.device(logits.device):
             _call("pzn_boundary_ce_fwd_f32", _p(logits), _p(labels), B, N, _p(prob1), _p(loss), _stream())
         ctx.save_for_backward(logits, labels)
         ctx.mark_non_differentiable(prob1)
-        return loss.reshape(()), prob1
+        return loss[0], prob1
 
     @staticmethod
     def backward(ctx, dloss, _dprob):
@@ -1434,6 +1434,9 @@ def sa_mlp_max(xyz, feat, new_xyz, idx, w1, b1, w2, b2):
     if _SA_POINT and K == 32 and w1.shape[0] in (64, 128, 256) and w1.shape[1] == 3 + feat.shape[-1]:
         if _SA_FUSED and w1.shape[0] % 128 == 0 and w2.shape[0] in (64, 128, 256) and w2.shape[1] == w1.shape[0] \
                 and _lib.load().pzn_gemm_get_precision() != 0:
-            return _SaLevelFused.apply(xyz, feat, new_xyz, idx, w1, b1, w2, b2)
+            try:
+                return _SaLevelFused.apply(xyz, feat, new_xyz, idx, w1, b1, w2, b2)
+            except _lib.PznUnsupported:
+                pass        # PZN_WS_GEMM=0, or a table beyond the 32-bit buffer offsets: the written-rows form below
         return _SaMlpMaxPoint.apply(xyz, feat, new_xyz, idx, w1, b1, w2, b2)
     return _SaMlpMax.apply(xyz, feat, new_xyz, idx, w1, b1, w2, b2)

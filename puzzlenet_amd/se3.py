@@ -56,8 +56,8 @@ def exp(x):
     R = I + _sinc1(t) * W + _sinc2(t) * S          # Rodrigues
     V = I + _sinc2(t) * W + _sinc3(t) * S
     p = V.bmm(v.contiguous().view(-1, 3, 1))
-    z = torch.zeros(x_.size(0), 1, 4, dtype=x.dtype, device=x.device)     # built on the device: no host copy,
-    z[:, :, 3] = 1                                                         # so the step stays HIP-graph capturable
+    z = torch.zeros(x_.size(0), 1, 4, dtype=x.dtype, device=x.device)     # built on the device: no host copy
+    z[:, :, 3] = 1
     g = torch.cat((torch.cat((R, p), dim=2), z), dim=1)
     return g.view(*(x.size()[0:-1]), 4, 4)
 
@@ -65,7 +65,7 @@ def exp(x):
 def transform_points(g, pts):
     """g [B,4,4], pts [B,N,3] -> R pts + p, i.e. transform(g, pts^T)^T without the two transposes: one HIP launch each
     way on the GPU (csrc/losstail.hip), the tensor form of `transform` otherwise."""
-    if pts.is_cuda and pts.dtype == torch.float32 and g.dim() == 3 and pts.dim() == 3:
+    if pts.is_cuda and pts.dtype == torch.float32 and g.dim() == 3 and pts.dim() == 3 and g.shape[0] == pts.shape[0]:
         from . import ops
         return ops.se3_transform_points(g.to(pts), pts)
     return transform(g, pts.transpose(-1, -2)).transpose(-1, -2)
@@ -74,7 +74,7 @@ def transform_points(g, pts):
 def transform(g, a):
     """g [*,4,4], a [*,3,N] (or [*,3]) -> R a + p  (se3.py:110-120)"""
     if a.is_cuda and a.dtype == torch.float32 and g.dim() == 3 and a.dim() == 3 and a.shape[1] == 3 \
-            and a.transpose(1, 2).is_contiguous():
+            and g.shape[0] == a.shape[0] and a.transpose(1, 2).is_contiguous():     # (a broadcast g takes the tensor form)
         # the caller's a is a [B,N,3] point tensor seen as [B,3,N] (model5_b.py:948-952): same kernel, no copies
         from . import ops
         return ops.se3_transform_points(g.to(a), a.transpose(1, 2)).transpose(1, 2)

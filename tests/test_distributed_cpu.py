@@ -103,3 +103,57 @@ def test_init_from_env_single_process(monkeypatch):
     pdist.broadcast_parameters(m)                                  # no-op without a process group
     fg = pdist.FlatGradAllReduce(m.parameters())
     fg.all_reduce_mean()                                           # likewise
+
+
+def _worker_two_piece(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from puzzlenet_amd import distributed as pdist
+    pdist.init_from_env(backend="gloo")
+    torch.manual_seed(5)
+    out = {}
+    for mode in ("one", "two"):
+        torch.manual_seed(5)
+        model = TinyPairModel()
+        # "b." plays the layers whose gradient is complete last: laid out behind the others
+        grads = pdist.FlatGradAllReduce(model.named_parameters(), late=(lambda n: n.startswith("b.")) if mode == "two" else None)
+        if mode == "two":
+            n_late = sum((p.numel() + 3) // 4 * 4 for n, p in model.named_parameters() if n.startswith("b."))
+            assert grads.split == grads.flat.numel() - n_late
+            assert [id(p) for p in grads.params[-2:]] == [id(model.b.weight), id(model.b.bias)]
+        g = torch.Generator().manual_seed(7 + rank)
+        X, Y = torch.randn(4, 10, 3, generator=g), torch.randn(4, 6, generator=g)
+        for it in range(2):                       # twice: zero_() must re-arm the early piece
+            grads.zero_()
+            model.training_step((X, Y), 0)["loss"].backward()
+            if mode == "two":
+                grads.all_reduce_early()          # [0, split) while "the rest of the backward" would still run
+                assert grads._early_done
+            grads.all_reduce_mean()               # the late piece (mode two) or everything (mode one)
+        out[mode] = {n: p.grad.clone() for n, p in model.named_parameters()}
+    for n in out["one"]:
+        assert torch.equal(out["one"][n], out["two"][n]), n       # same sums, element for element
+    torch.save(out["two"], os.path.join(tmp, f"two{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_piece_allreduce_equals_single_bucket(tmp_path):
+    """FlatGradAllReduce(late=...): the early piece reduced ahead of the late one gives, element for element, what one
+    all-reduce of the whole bucket gives (gloo, world 2), also on the second step."""
+    world, port = 2, _free_port()
+    mp.spawn(_worker_two_piece, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = torch.load(tmp_path / "two0.pt"), torch.load(tmp_path / "two1.pt")
+    for n in a:
+        assert torch.equal(a[n], b[n])
+
+
+def test_late_gradient_predicate_matches_model_parameters():
+    """engine.late_gradient picks exactly the encoders' per-point / set-abstraction layers of TouchedRegraster."""
+    sys.path.insert(0, ROOT)
+    from puzzlenet_amd import engine
+    assert engine.late_gradient("Encoder.mlp3.weight") and engine.late_gradient("Encoder2.bn1.bias")
+    for n in ("Encoder.atten1.mlpq.weight", "Encoder2.out.bias", "tfMLP.0.weight", "MLPRpcb.2.bias", "dt"):
+        assert not engine.late_gradient(n)

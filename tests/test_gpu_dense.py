@@ -555,14 +555,14 @@ def test_attention_fused_block_intermediates(dev, B):
     _lib.call("pzn_attn_fused_bwd_k", 1, P([qrp]), P([qt]), P([krp]), P([vrp]), P([darp]), P([dat]), P([W]), P([lse]),
               P([delta]), P([u]), B, P([dkk]), P([dvv]), P([dx]), st)
     ref = _attn_block_ref64(x.view(B, L, E), wq, bq, wk, bk, wv, bv, wo, bo, dr.view(B, L, E))
-    # the ReLU gate is discrete: elements whose pre-activation is within rounding of zero may be gated differently
-    gate = (ref["z"].abs() > 1e-5).reshape(M, E)
+    # the ReLU gate is discrete: an element whose pre-activation is within rounding of zero may be gated differently,
+    # which is no kernel error; none may flip away from zero, and a flip near zero loosens the comparison
     got = dict(r=r, t=t, map=amap, lse=lse, dz=dz, delta=delta, dq=dq, u=u, dk=dkk, dv=dvv, dx=dx)
-    flips = int(((dz != 0) != (ref["dz"].reshape(M, E) != 0))[gate].sum())
-    assert flips == 0
+    flipped = (dz != 0) != (ref["dz"].reshape(M, E) != 0)
+    assert int((flipped & (ref["z"].abs() > 1e-5).reshape(M, E)).sum()) == 0
+    tol = 1e-5 if int(flipped.sum()) == 0 else 1e-3
     for name, val in got.items():
         want = ref[name].reshape(val.shape)
-        tol = 1e-5 if int(((dz != 0) != (ref["dz"].reshape(M, E) != 0)).sum()) == 0 else 1e-3
         assert _rel(val.double(), want) < tol, (name, _rel(val.double(), want))
 
 

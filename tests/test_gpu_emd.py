@@ -125,8 +125,11 @@ def test_fused_path_vs_oracle(dev, B, n, m, near):
     """near=False: independent uniform clouds (what an untrained model produces), cost to 1e-4.
     near=True: xyz2 is a jittered permutation of xyz1 (a converged registration): the optimum is a
     near-permutation whose cost is a sum of ~1e-3-sized terms, and ONE near-tie that resolves the
-    other way under different rounding (fma contraction, v_exp_f32) moves the cost by ~3e-4
-    (measured: 2.8e-4 on one of two 1024-point pairs, with exact expf too).  Held to 1e-3."""
+    other way under different rounding moves the cost by up to ~3e-4.  That is a property of the
+    ALGORITHM, not of the kernels: the same C restatement run in float32 and in float64 differs by as
+    much on such pairs.  So the kernel's cost must lie within 1e-4 of the float32 restatement OR
+    within twice the float32 <-> float64 spread of the restatement itself (per pair), and never
+    further than 1e-3 from either."""
     from puzzlenet_amd import ops
     rng = np.random.default_rng(n * 5 + m)
     x1 = rng.random((B, n, 3), dtype=np.float32)
@@ -138,7 +141,16 @@ def test_fused_path_vs_oracle(dev, B, n, m, near):
     t1, t2 = _t(x1, dev).requires_grad_(True), _t(x2, dev).requires_grad_(True)
     cost = ops.emd_fused(t1, t2)
     ocost, omatch = orc.earth_mover_distance(x1, x2)
-    assert _rel(cost.detach().cpu().numpy(), ocost) < (1e-3 if near else RTOL)
+    got = cost.detach().cpu().numpy().astype(np.float64)
+    if not near:
+        assert _rel(got, ocost) < RTOL
+    else:
+        o64, _ = orc.earth_mover_distance(x1.astype(np.float64), x2.astype(np.float64))
+        err32 = np.abs(got - ocost) / np.abs(o64)
+        err64 = np.abs(got - o64) / np.abs(o64)
+        spread = np.abs(ocost.astype(np.float64) - o64) / np.abs(o64)      # the restatement against itself
+        ok = (err32 < RTOL) | (err64 < RTOL) | (np.minimum(err32, err64) <= 2 * spread)
+        assert ok.all() and max(err32.max(), err64.max()) < 1e-3, (err32, err64, spread)
     gc = rng.standard_normal(B).astype(np.float32)
     (cost * _t(gc, dev)).sum().backward()
     o1, o2 = orc.emd_matchcost_grad(gc, x1, x2, omatch)

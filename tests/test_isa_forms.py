@@ -1,10 +1,13 @@
-"""No kernel may contain the packed-fp32 forms that return wrong results beside the matrix-core engine.
+"""No kernel may contain the packed-fp32 forms that return wrong results beside a matrix-core kernel.
 
-tools/pk_probe.hip pins the fault down to `v_pk_fma_f32` / `v_pk_mul_f32` whose op_sel bit of
-src1 is set (the LOW result reads the HIGH half of src1): wrong low results in lanes 48-63, only while a workgroup of
-gemm_kernel shares the CU; every other form, and op_sel on src0 / src2, is clean.  The compiler produces that form when
-it pairs scalar fp32 operations (SLP) of the shape "two weights x one coordinate"; build.py disables the pairing for the
-files concerned.  This test compiles every source to gfx950 assembly with the build's own flags and scans it."""
+tools/pk_probe.hip and tools/pk_probe2.hip pin the fault down to a PAIR of instructions on one CU:
+a `v_pk_fma_f32` / `v_pk_mul_f32` / `v_pk_add_f32` whose op_sel bit of src1 is set while that of src0 is clear (the LOW
+result reads the HIGH half of src1) returns a wrong low result in lanes 48-63 while another wavefront issues MFMAs whose
+accumulators live in AGPRs (`v_mfma_* a[..]`: gemm_kernel, the generated-row kernel, the chained attention kernels).
+MFMAs on VGPR accumulators, every other instruction class, and op_sel on src0 / src2 are clean.  The compiler produces
+the form when it pairs scalar fp32 operations (SLP) of the shape "two weights x one coordinate".  This test compiles
+EVERY source to gfx950 assembly with the build's own flags and fails on any packed fp32 instruction with the src1
+op_sel bit, whatever src0 says."""
 import os
 import re
 import subprocess
@@ -12,7 +15,7 @@ import tempfile
 
 from puzzlenet_amd import build
 
-FORM = re.compile(r"v_pk_(?:fma|mul)_f32[^\n]*op_sel:\[[01],1")
+FORM = re.compile(r"v_pk_(?:fma|mul|add)_f32[^\n]*op_sel:\[[01],1")
 
 
 def test_no_src1_op_sel_packed_multiplies():
@@ -30,4 +33,4 @@ def test_no_src1_op_sel_packed_multiplies():
             hits = FORM.findall(open(out).read())
             if hits:
                 bad[src] = len(hits)
-    assert not bad, f"packed multiplies with src1 op_sel (wrong beside gemm_kernel, see tools/pk_probe.hip): {bad}"
+    assert not bad, f"packed fp32 instructions with src1 op_sel (wrong beside AGPR-accumulator MFMAs, see tools/pk_probe2.hip): {bad}"
