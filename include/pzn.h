@@ -405,8 +405,9 @@ int pzn_attn_block_bwd_f32(const float* x, const float* Wq, const float* Wk, con
  *   fwd:    r = x + relu(Wo (x - softmax(q k^T / 8) v) + bo) [B*L,E];  t = x - attn v [B*L,E];  mask [B*L,8] u32 = gate
  *           bits of the ReLU;  lse [B*L];  map[i] (may be NULL) [B,L,L]: map = scale P, or map += scale P when
  *           map_accumulate (the mean of the four blocks' maps, model5_b.py:468-469).
- *   bwd_q:  query side of the backward from dr [B*L,E]: dz = dr . gate, u = dr + dz Wo + dq Wq, dq [B*L,dk], delta [B*L]
- *           and the two images of da = -dz Wo.
+ *   bwd_q:  query side of the backward from dr (+ dr2 when non-NULL: rows of ld_dr / ld_dr2 floats, so a column slice of
+ *           a wider gradient needs no copy and the sum of two gradients no add): dz = dr . gate, u = dr + dz Wo + dq Wq,
+ *           dq [B*L,dk], delta [B*L] and the two images of da = -dz Wo.
  *   bwd_k:  key side: dk [B*L,dk], dv [B*L,E], dx = u + dk Wk + dv Wv [B*L,E] = the block's input gradient.
  *   wgrads: the eight parameter gradients from dz, t, dq, dk, dv and the block input x (one problem per call). */
 int pzn_attn_fused_supported(int L, int E, int dk);
@@ -424,7 +425,8 @@ int pzn_attn_fused_fwd(int nprob, const float* const* x, const void* const* qrp,
                        const float* const* bo, int B, float* const* r, float* const* t,
                        void* const* mask, float* const* map, float* const* lse, int map_accumulate,
                        float map_scale, pzn_stream_t stream);
-int pzn_attn_fused_bwd_q(int nprob, const float* const* dr, const void* const* mask,
+int pzn_attn_fused_bwd_q(int nprob, const float* const* dr, int ld_dr, const float* const* dr2,
+                         int ld_dr2, const void* const* mask,
                          const void* const* qrp, const void* const* krp, const void* const* kt,
                          const void* const* vrp, const void* const* w, int B, float* const* dz,
                          float* const* u, float* const* dq, void* const* darp, void* const* dat,

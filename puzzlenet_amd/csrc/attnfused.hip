@@ -778,7 +778,9 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(FwdArgs a) {
 //   dz = dr . gate;  dt^T = Wo^T dz^T;  da = -dt (images for the key-side pass);  dP^T = V da^T;  P^T recomputed;
 //   delta = sum_key P dP;  dS^T = P^T (dP^T - delta) / 8;  dq^T = K^T dS^T;  u = dr + dt + dq Wq (partial dx)
 struct BwdQProb {
-  const float* dr;       // [B*L, E] gradient of the block output
+  const float* dr;       // gradient of the block output: rows of ld_dr floats (a column slice of a wider matrix is fine)
+  const float* dr2;      // optional second addend of that gradient (NULL: none), rows of ld_dr2 floats
+  int ld_dr, ld_dr2;
   const uint32_t* mask;
   const unsigned char *qrp, *krp, *kt, *vrp;
   const unsigned char* w;
@@ -816,7 +818,13 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
   constexpr int NS = 44;
 
   floatx16 S[8];     // first dz^T, later S^T / P^T / dS^T
-  load_rows<8>(P.dr, row0, E, S, stg, lane);
+  load_rows<8>(P.dr, row0, P.ld_dr, S, stg, lane);
+  if (P.dr2) {
+    floatx16 T2[8];
+    load_rows<8>(P.dr2, row0, P.ld_dr2, T2, stg, lane);
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft) S[ft] += T2[ft];
+  }
   {
     const uint4 mb = *reinterpret_cast<const uint4*>(P.mask + (row * 2 + h) * 4);
     const uint32_t bits[4] = {mb.x, mb.y, mb.z, mb.w};
@@ -855,7 +863,13 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
   {
     store_rp<8, true>(P.darp + (size_t)cloud * V_IMG, rt, lane, DT);
     store_t<8, 256, true>(P.dat + (size_t)cloud * V_IMG, rt, lane, DT, stg);
-    load_rows<8>(P.dr, row0, E, S, stg, lane);     // (dz^T is dead: S takes dr^T again for u0 = dr + dt)
+    load_rows<8>(P.dr, row0, P.ld_dr, S, stg, lane);     // (dz^T is dead: S takes dr^T again for u0 = dr + dt)
+    if (P.dr2) {
+      floatx16 T2[8];
+      load_rows<8>(P.dr2, row0, P.ld_dr2, T2, stg, lane);
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) S[ft] += T2[ft];
+    }
 #pragma unroll
     for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
@@ -1233,7 +1247,8 @@ PZN_EXPORT int pzn_attn_fused_fwd(int nprob, const float* const* x, const void* 
 }
 
 // backward, query side (see attn_bwd_q_kernel): writes dz, u, dq, delta and the two images of da
-PZN_EXPORT int pzn_attn_fused_bwd_q(int nprob, const float* const* dr, const void* const* mask, const void* const* qrp,
+PZN_EXPORT int pzn_attn_fused_bwd_q(int nprob, const float* const* dr, int ld_dr, const float* const* dr2, int ld_dr2,
+                                    const void* const* mask, const void* const* qrp,
                                     const void* const* krp, const void* const* kt, const void* const* vrp,
                                     const void* const* w, int B, float* const* dz, float* const* u, float* const* dq,
                                     void* const* darp, void* const* dat, float* const* delta, pzn_stream_t stream) {
@@ -1247,7 +1262,9 @@ PZN_EXPORT int pzn_attn_fused_bwd_q(int nprob, const float* const* dr, const voi
     PZN_CHECK_ARG(aligned16(dr[i]) && aligned16(mask[i]) && aligned16(qrp[i]) && aligned16(krp[i]) && aligned16(kt[i]) &&
                   aligned16(vrp[i]) && aligned16(w[i]) && aligned16(dz[i]) && aligned16(u[i]) && aligned16(dq[i]) &&
                   aligned16(darp[i]) && aligned16(dat[i]));
-    a.p[i] = BwdQProb{dr[i], static_cast<const uint32_t*>(mask[i]), static_cast<const unsigned char*>(qrp[i]),
+    PZN_CHECK_ARG(ld_dr >= E && (ld_dr & 3) == 0 && (!dr2 || !dr2[i] || (aligned16(dr2[i]) && ld_dr2 >= E && (ld_dr2 & 3) == 0)));
+    a.p[i] = BwdQProb{dr[i], dr2 ? dr2[i] : nullptr, ld_dr, ld_dr2, static_cast<const uint32_t*>(mask[i]),
+                      static_cast<const unsigned char*>(qrp[i]),
                       static_cast<const unsigned char*>(krp[i]), static_cast<const unsigned char*>(kt[i]),
                       static_cast<const unsigned char*>(vrp[i]), static_cast<const unsigned char*>(w[i]), dz[i], u[i], dq[i],
                       static_cast<unsigned char*>(darp[i]), static_cast<unsigned char*>(dat[i]), delta[i]};

@@ -17,8 +17,11 @@ Randomness stays OUTSIDE: the caller passes the draws (plane normal / offset, FP
 draw with the reference's functions (tests/golden/make_golden_data.py -> data.npz).  The double-cut variants are the
 same machinery on REGIONS of two planes (`make_pairs_regions`; `plan_double_cut_like_reference` replays the
 reference's branch decisions and draws); `building_pairs` is the item contract of `BuildingDataset` (two given pieces).
-The mesh-based cuts (sphere, cylinder, cone: dataset.py:716-758) go through open3d ray casting and are out of scope
-(no open3d here).
+The solid cuts (sphere, cylinder, cone: dataset.py:716-758) are `solid_cut_mask` + `make_pairs_solid`: the reference
+asks open3d for the signed distance to a tessellated mesh and keeps `distance < 0`; here the same solids are evaluated
+analytically (inside-tests of the exact sphere / cylinder / cone under the reference's rotation and translation draws).
+open3d is not in this image, so no fixture can be produced: PARITY UNPINNED for these three masks — a point closer to
+the surface than the 50-segment tessellation's sagitta (<= 0.2 % of the radius) may fall on the other side.
 """
 import numpy as np
 import torch
@@ -57,6 +60,68 @@ def plane_cut_mask(raw, normal, z):
     # numpy's dot of a row with the 3-vector sums in index order; so does the line above after the product
     dis = dis + z.to(torch.float64).reshape(-1, 1)
     return dis >= 0
+
+
+def rotation_from_axis_angle(w):
+    """open3d.geometry.get_rotation_matrix_from_axis_angle(w): Rodrigues rotation by |w| about w / |w| (the reference
+    feeds np.random.rand(3,1), dataset.py:735, :751).  w [B,3] float64 -> R [B,3,3] float64."""
+    w = w.to(torch.float64)
+    th = w.norm(dim=1, keepdim=True).clamp_min(1e-300)
+    k = w / th
+    K = torch.zeros(w.shape[0], 3, 3, dtype=torch.float64, device=w.device)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0] = -k[:, 2], k[:, 1], k[:, 2]
+    K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -k[:, 0], -k[:, 1], k[:, 0]
+    th = th.unsqueeze(-1)
+    eye = torch.eye(3, dtype=torch.float64, device=w.device).expand_as(K)
+    return eye + torch.sin(th) * K + (1 - torch.cos(th)) * (K @ K)
+
+
+def solid_cut_mask(raw, kind, rot=None, shift=None):
+    """up-mask (signed distance < 0 = INSIDE the solid) of the reference's mesh cuts, evaluated on the exact solids:
+      "sphere"   (dataset.py:716-730): radius 0.5, centre = shift (np.random.rand(3,1)/3)
+      "cylinder" (:732-747): radius 0.6, height 1 about z, rotated by the axis-angle vector rot (np.random.rand(3,1))
+                 about the origin, then translated by shift (np.random.rand(3,1)/3)
+      "cone"     (:749-763): base radius 1 at z = -1, apex at z = +1 (create_cone(1, 2) translated by (0,0,-1)), rotated
+                 by rot about the origin
+    raw [B,M,3] fp32, rot / shift [B,3] float64 (the draws) -> bool [B,M].  float64 like the plane cut."""
+    p = raw.to(torch.float64)
+    if kind == "sphere":
+        d = p - shift.to(torch.float64).unsqueeze(1)
+        return (d * d).sum(-1) < 0.25
+    R = rotation_from_axis_angle(rot)                     # mesh point = R x (+ shift): x = R^T (p - shift)
+    if kind == "cylinder":
+        q = torch.einsum("bji,bmj->bmi", R, p - shift.to(torch.float64).unsqueeze(1))
+        return (q[..., 0] ** 2 + q[..., 1] ** 2 < 0.36) & (q[..., 2].abs() < 0.5)
+    if kind == "cone":
+        q = torch.einsum("bji,bmj->bmi", R, p)
+        h = q[..., 2] + 1.0                               # height above the base plane, apex at h = 2
+        rad = (q[..., 0] ** 2 + q[..., 1] ** 2).sqrt()
+        return (h > 0) & (h < 2) & (rad < 1.0 - h / 2)
+    raise _lib.PznError(f"solid_cut_mask: unknown solid {kind!r}")
+
+
+def make_pairs_mask(raw, mask, start_up, start_down, twist, n=1024, k=128, cap=None):
+    """The pair construction of make_pairs from a given up-mask [B,M] (whatever cut produced it)."""
+    if not raw.is_cuda:
+        raise _lib.PznError("datapipe.make_pairs_mask runs on the GPU (puzzlenet_amd has no CPU fallback)")
+    raw = raw.to(torch.float32).contiguous()
+    B, M, _ = raw.shape
+    cap = M if cap is None else int(cap)
+    up_piece, n_up = _compact(raw, mask, cap)
+    down_piece, n_down = _compact(raw, ~mask, cap)
+    ok = (n_up >= n) & (n_down >= n) & (n_up <= cap) & (n_down <= cap)
+    both = fps_to_n(torch.cat([up_piece, down_piece], 0), torch.cat([n_up, n_down], 0),
+                    torch.cat([start_up.reshape(-1), start_down.reshape(-1)], 0), n)
+    up, down = both[:B].contiguous(), both[B:].contiguous()
+    downb, upb, down_mask, up_mask = boundary(down, up, k)
+    moved, igt = move(up, twist)
+    return (down, moved, igt, up, downb, upb, down_mask, up_mask), ok
+
+
+def make_pairs_solid(raw, kind, rot, shift, start_up, start_down, twist, n=1024, k=128, cap=None):
+    """CADDataset with slice = sphere_split / cylinder_split / cone_split (dataset.py:1463-1546 keys *_sphere, *_cyl,
+    *_cone; BASELINE configs[0] "bed_sphere"): the solid's inside is `up`.  Parity unpinned (see the module header)."""
+    return make_pairs_mask(raw, solid_cut_mask(raw, kind, rot, shift), start_up, start_down, twist, n, k, cap)
 
 
 def _compact(raw, mask, cap):

@@ -1078,15 +1078,19 @@ class _AttnChainFused(torch.autograd.Function):
                 if not direct_out:
                     grads[base + 33], grads[base + 34] = dW_out, db_out
                 Gs.append(G)
-                g.append(G[:, 3 * E: 4 * E].contiguous())
+                g.append(G[:, 3 * E: 4 * E])          # gradient of att4: its slice of the projection only (read in place)
             # scratch of the block backward, shared by the four layers
             dz, u, dx = [mk(M, E) for _ in R], [mk(M, E) for _ in R], [mk(M, E) for _ in R]
             dq, dkk, dvv = [mk(M, dk) for _ in R], [mk(M, dk) for _ in R], [mk(M, E) for _ in R]
             darp, dat, delta = [raw(vb) for _ in R], [raw(vb) for _ in R], [mk(M) for _ in R]
+            g2 = None
             for i in (3, 2, 1, 0):
                 blk = [saved[p][i] for p in R]        # (x, t, mask, lse, qrp, qt, krp, kt, vrp, W)
                 col = lambda j: _ptrs([b[j] for b in blk])
-                _call("pzn_attn_fused_bwd_q", nprob, _ptrs(g), col(2), col(4), col(6), col(7), col(8), col(9), B, _ptrs(dz),
+                # the block's output gradient = its slice of the projection's input gradient (+ what the next block passed
+                # back): both read in place by the kernel, no copy and no tensor add
+                _call("pzn_attn_fused_bwd_q", nprob, _ptrs(g), 5 * E, _ptrs(g2) if g2 is not None else None, E,
+                      col(2), col(4), col(6), col(7), col(8), col(9), B, _ptrs(dz),
                       _ptrs(u), _ptrs(dq), _ptrs(darp), _ptrs(dat), _ptrs(delta), st,
                       flops=nprob * (2 * M * E * (E + dk) + 2 * B * L * L * (2 * dk + E)))
                 _call("pzn_attn_fused_bwd_k", nprob, col(4), col(5), col(6), col(8), _ptrs(darp), _ptrs(dat), col(9), col(3),
@@ -1104,10 +1108,11 @@ class _AttnChainFused(torch.autograd.Function):
                           flops=2 * M * E * (2 * dk + 2 * E))
                     if not direct:
                         grads[base + 1 + 8 * i: base + 9 + 8 * i] = gp
-                    sl = i - 1 if i > 0 else 4
-                    g[p] = torch.add(Gs[p][:, sl * E: (sl + 1) * E], dx[p])
+                sl = i - 1 if i > 0 else 4            # att_i sits in slice i-1 of the concatenation, f2f in slice 4
+                g = [Gs[p][:, sl * E: (sl + 1) * E] for p in R]
+                g2, dx = dx, [mk(M, E) for _ in R] if i > 0 else dx      # (dx of this block is the next one's second addend)
             for p in R:
-                grads[1 + 35 * p] = g[p].view(B, L, E)
+                grads[1 + 35 * p] = torch.add(g[p], g2[p]).view(B, L, E)
         return tuple(grads)
 
 

@@ -108,3 +108,41 @@ def test_double_cut_planner_follows_the_reference(golden_data2):
         kinds.add(str(G[k + "kind"]))
     assert {"single", "single_after_rejection", "half_vs_rest", "half_vs_rest_lower", "half_vs_other", "half_vs_other_lower",
             "halves", "halves_lower"} <= kinds
+
+
+def test_solid_cut_masks_against_closed_forms():
+    """datapipe.solid_cut_mask (the reference's sphere / cylinder / cone cuts, dataset.py:716-763, on the exact solids;
+    parity unpinned: open3d is not in the image) against independent numpy closed forms, and the rotation against the
+    axis-angle properties open3d documents (R w = w, R R^T = I, rotation angle |w|)."""
+    import numpy as np
+    import torch
+    from puzzlenet_amd import datapipe as dp
+    rng = np.random.default_rng(5)
+    B, M = 3, 4000
+    pts = rng.random((B, M, 3)).astype(np.float32)
+    rot, shift = rng.random((B, 3)), rng.random((B, 3)) / 3
+    R = dp.rotation_from_axis_angle(torch.from_numpy(rot)).numpy()
+    for b in range(B):
+        w = rot[b]
+        np.testing.assert_allclose(R[b] @ w, w, atol=1e-12)
+        np.testing.assert_allclose(R[b] @ R[b].T, np.eye(3), atol=1e-12)
+        np.testing.assert_allclose(np.trace(R[b]), 1 + 2 * np.cos(np.linalg.norm(w)), atol=1e-12)
+    t = torch.from_numpy(pts)
+    m = dp.solid_cut_mask(t, "sphere", None, torch.from_numpy(shift)).numpy()
+    want = ((pts.astype(np.float64) - shift[:, None]) ** 2).sum(-1) < 0.25
+    assert np.array_equal(m, want) and 0 < m.mean() < 1
+    m = dp.solid_cut_mask(t, "cylinder", torch.from_numpy(rot), torch.from_numpy(shift)).numpy()
+    for b in range(B):
+        q = (pts[b].astype(np.float64) - shift[b]) @ R[b]          # rows: R^T (p - shift)
+        want = (q[:, 0] ** 2 + q[:, 1] ** 2 < 0.36) & (np.abs(q[:, 2]) < 0.5)
+        assert np.array_equal(m[b], want)
+    m = dp.solid_cut_mask(t, "cone", torch.from_numpy(rot), None).numpy()
+    for b in range(B):
+        q = pts[b].astype(np.float64) @ R[b]
+        h = q[:, 2] + 1
+        want = (h > 0) & (h < 2) & (np.hypot(q[:, 0], q[:, 1]) < 1 - h / 2)
+        assert np.array_equal(m[b], want)
+    # apex and base of the cone as open3d builds it (create_cone(radius=1, height=2) then translate (0,0,-1)), unrotated
+    zero = torch.zeros(1, 3, dtype=torch.float64)
+    probe = torch.tensor([[[0.0, 0.0, 0.9], [0.0, 0.0, 1.1], [0.9, 0.0, -0.95], [1.05, 0.0, -0.95], [0.0, 0.0, -1.05]]])
+    assert dp.solid_cut_mask(probe, "cone", zero + 1e-12, None).tolist() == [[True, False, True, False, False]]

@@ -121,3 +121,42 @@ def test_building_pairs_match_reference(golden_data2):
     out = datapipe.building_pairs(torch.from_numpy(G["b_fpcs"]).to(dev), torch.from_numpy(G["b_rpcs"]).to(dev), twist)
     for i in range(3):
         _check_item(out, G, f"b{i}_", i)
+
+
+@pytest.mark.parametrize("kind", ["sphere", "cylinder", "cone"])
+def test_make_pairs_solid_cuts(kind):
+    """datapipe.make_pairs_solid (dataset.py:716-763 + the pair construction of CADDataset): the solid's inside becomes
+    `up`.  Parity with open3d's tessellated meshes is unpinned (not in the image), so the contract is checked
+    structurally: every sampled point is a point of the raw cloud on the right side of the exact solid, the FPS start
+    point is first, 128 boundary points per piece, and the motion is the SE(3) exponential of the twist."""
+    from puzzlenet_amd import datapipe, se3
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng({"sphere": 1, "cylinder": 2, "cone": 3}[kind])
+    B, M, n = 3, 12000, 1024
+    raw_np = (rng.random((B, M, 3)) * (1.6 if kind == "cone" else 1.0) - (0.8 if kind == "cone" else 0.0)).astype(np.float32)
+    raw = torch.from_numpy(raw_np).to(dev)
+    rot = torch.from_numpy(rng.random((B, 3))).to(dev)
+    shift = torch.from_numpy(rng.random((B, 3)) / 3).to(dev)
+    mask = datapipe.solid_cut_mask(raw, kind, rot, shift)
+    n_up = mask.sum(1)
+    assert bool(((n_up >= n) & (M - n_up >= n)).all()), n_up.tolist()
+    s_up = torch.tensor([int(rng.integers(0, int(c))) for c in n_up.tolist()], device=dev)
+    s_down = torch.tensor([int(rng.integers(0, M - int(c))) for c in n_up.tolist()], device=dev)
+    tw = torch.from_numpy(rng.standard_normal((B, 6)).astype(np.float32))
+    tw = (tw / tw.norm(dim=1, keepdim=True) * 0.8).to(dev)
+    (down, moved, igt, up, downb, upb, down_mask, up_mask), ok = datapipe.make_pairs_solid(
+        raw, kind, rot, shift, s_up, s_down, tw, n=n)
+    assert bool(ok.all()) and up.shape == (B, n, 3) and down.shape == (B, n, 3)
+    for b in range(B):
+        rows = {tuple(r) for r in raw_np[b]}
+        inside = {tuple(r) for r in raw_np[b][mask[b].cpu().numpy()]}
+        u, d = up[b].cpu().numpy(), down[b].cpu().numpy()
+        assert all(tuple(r) in inside for r in u)
+        assert all(tuple(r) in rows and tuple(r) not in inside for r in d)
+        assert tuple(u[0]) == tuple(raw_np[b][mask[b].cpu().numpy()][int(s_up[b])])      # FPS starts at the drawn point
+        assert len({tuple(r) for r in u}) == n and len({tuple(r) for r in d}) == n
+        assert int(up_mask[b].sum()) == 128 and int(down_mask[b].sum()) == 128
+    g = se3.exp(tw)
+    np.testing.assert_allclose(igt.cpu().numpy(), g.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    want = torch.einsum("bij,bnj->bni", g[:, :3, :3], up) + g[:, :3, 3].unsqueeze(1)
+    np.testing.assert_allclose(moved.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-6)

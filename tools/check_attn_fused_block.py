@@ -46,7 +46,7 @@ def main():
               P([amap]), P([lse]), 0, 1.0, st)
     dz, u, dq, delta = mk(M, E), mk(M, E), mk(M, dk), mk(M)
     darp, dat = raw(vb), raw(vb)
-    _lib.call("pzn_attn_fused_bwd_q", 1, P([dr]), P([mask]), P([qrp]), P([krp]), P([kt]), P([vrp]), P([W]), B, P([dz]), P([u]),
+    _lib.call("pzn_attn_fused_bwd_q", 1, P([dr]), E, None, E, P([mask]), P([qrp]), P([krp]), P([kt]), P([vrp]), P([W]), B, P([dz]), P([u]),
               P([dq]), P([darp]), P([dat]), P([delta]), st)
     dkk, dvv, dx = mk(M, dk), mk(M, E), mk(M, E)
     _lib.call("pzn_attn_fused_bwd_k", 1, P([qrp]), P([qt]), P([krp]), P([vrp]), P([darp]), P([dat]), P([W]), P([lse]),
