@@ -34,6 +34,7 @@ SOURCES = [
     ("chamfer.hip", NOSLP),
     ("gemm.hip", NOSLP),
     ("attnfused.hip", NOSLP),
+    ("salevel.hip", NOSLP),
     ("poolbwd.hip", []),
     ("maxptsbwd.hip", NOSLP),
     ("wsgemm.hip", []),

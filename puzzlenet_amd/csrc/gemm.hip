@@ -1314,6 +1314,24 @@ PZN_EXPORT int pzn_sa_level_fwd_f32(const float* Pp, const float* Q, const int64
   return pzn_ws_gemm_gather_maxpool(Pp, Q, idx, W2, b2, B * S, N, S, C1, C2, out, argmax, pzn_hip_stream(stream));
 }
 
+// The same level with a caller-owned workspace (pzn_sa_level_fwd_workspace_bytes; 0 = this shape has no streamed
+// form): the streamed-weights kernel of salevel.hip generates every row ONCE per group (the weight-stationary kernel
+// regenerates it once per 64-column slice of W2) and streams the split weight planes through LDS instead.
+PZN_EXPORT size_t pzn_sa_level_fwd_workspace_bytes(int C1, int C2) { return pzn_sa_level_stream_workspace_bytes(C1, C2); }
+
+PZN_EXPORT int pzn_sa_level_fwd_ws_f32(const float* Pp, const float* Q, const int64_t* idx, const float* W2,
+                                       const float* b2, int B, int N, int S, int C1, int C2, float* out,
+                                       int32_t* argmax, void* workspace, pzn_stream_t stream) {
+  PZN_CHECK_ARG(Pp && Q && idx && W2 && out && argmax && B > 0 && N > 0 && S > 0 && C1 > 0 && C2 > 0);
+  PZN_CHECK_ARG((long)B * S * 32 < 2147483647L);
+  if (gemm_precision() == 0) return PZN_EUNSUPPORTED;
+  if (workspace && b2) {
+    int rc = pzn_sa_level_stream(Pp, Q, idx, W2, b2, B * S, N, S, C1, C2, out, argmax, workspace, pzn_hip_stream(stream));
+    if (rc != PZN_EUNSUPPORTED) return rc;
+  }
+  return pzn_ws_gemm_gather_maxpool(Pp, Q, idx, W2, b2, B * S, N, S, C1, C2, out, argmax, pzn_hip_stream(stream));
+}
+
 // Backward of the pooled layer behind pzn_sa_level_fwd_f32: dh[B*S*32, C1] (the ReLU-masked gradient of the generated
 // rows: written, the per-point sum pzn_sa_point_l1_bwd_f32 reads it), dW2, db2 (overwritten, or added to when
 // accumulate), and what flows through Q: dW1[:, 0:3] -= dq^T new_xyz, db1 += column sums of dq (dq[g] = sum_k dh[g,k]);

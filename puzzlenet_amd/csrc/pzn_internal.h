@@ -45,6 +45,10 @@ int pzn_ws_gemm_ex(const float* A, int lda, const float* W, int ldw, int w_kmajo
                    const int64_t* scat, int scat_in, int scat_out, const float* residual, float* C2, int accumulate,
                    hipStream_t st);
 
+// salevel.hip: the generated-row max-pool level with W2 streamed through LDS; PZN_EUNSUPPORTED for other shapes
+size_t pzn_sa_level_stream_workspace_bytes(int C1, int C2);
+int pzn_sa_level_stream(const float* Pp, const float* Q, const int64_t* idx, const float* W2, const float* b2, int G, int N,
+                        int S, int C1, int C2, float* out, int32_t* argmax, void* workspace, hipStream_t st);
 // max-pool variant on a generated activation stream (first set-abstraction layer per point): see wsgemm.hip
 int pzn_ws_gemm_gather_maxpool(const float* Pp, const float* Q, const int64_t* idx, const float* W2, const float* b2, int G,
                                int N, int S, int C1, int C2, float* out, int32_t* argmax, hipStream_t st);

@@ -1,0 +1,303 @@
+// pzn_mfma.h — building blocks of the chained matrix-core kernels (attnfused.hip, salevel.hip), gfx950 only:
+// bf16x3 split precision, fragment reads from LDS as inline asm with counted waits (two tiles ahead), the LDS-DMA slab
+// ring (three slots, two slabs in flight, one barrier per slab), compile-time loops.  Included inside an anonymous
+// namespace by each translation unit (which includes <type_traits> and pzn_common.h first).
+#pragma once
+
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16x4 __attribute__((address_space(3))) * lds4_t;
+
+constexpr int SLAB = 24576;               // 3 planes x 8 KB
+constexpr int NT = 256;                   // threads per workgroup
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ uint32_t f2bf(float x) {
+  __bf16 b = (__bf16)x;
+  return (uint32_t)__builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
+
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 values -> three dwords of two bf16 each (x = x1 + x2 + x3, every xi a round-to-nearest bf16 of the remainder):
+// 3 v_cvt_pk_bf16_f32 + 4 unpack + 4 subtract
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& a, uint32_t& bq, uint32_t& c) {
+  const floatx2 x = {x0, x1};
+  a = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
+  const floatx2 r = {x0 - __uint_as_float(a << 16), x1 - __uint_as_float(a & 0xffff0000u)};
+  bq = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+  const floatx2 t = {r[0] - __uint_as_float(bq << 16), r[1] - __uint_as_float(bq & 0xffff0000u)};
+  c = __builtin_bit_cast(uint32_t, __builtin_convertvector(t, bf16x2));
+}
+
+// eight fp32 values -> three bf16x8 fragments (x = b0 + b1 + b2 exactly up to 2^-24)
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&b)[3]) {
+  uint32_t w[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], w[0][j], w[1][j], w[2][j]);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]));
+}
+
+// The B fragment of the NEXT k-step, built a pair of values at a time behind the MFMAs of the current one
+// (BNext::pair(j), j = 0..3, from the step's fill callback), so that its ~44 vector instructions sit in the shadow of
+// the matrix pipe instead of in front of the step (measured: 660 cycles per step when issued as one block).
+struct BNext {
+  uint32_t w[3][4];
+  template <bool NEG = false>
+  __device__ __forceinline__ void pair(const floatx16& x, int s, int j) {
+    const float x0 = x[8 * s + 2 * j], x1 = x[8 * s + 2 * j + 1];
+    split_pair(NEG ? -x0 : x0, NEG ? -x1 : x1, w[0][j], w[1][j], w[2][j]);
+  }
+  __device__ __forceinline__ void get(bf16x8 (&b)[3]) const {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(bf16x8, make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]));
+  }
+};
+
+// registers 8s .. 8s+7 of an accumulator tile as the B fragment of k-step s (s = 0, 1), optionally negated
+template <bool NEG = false>
+__device__ __forceinline__ void make_b(const floatx16& x, int s, bf16x8 (&b)[3]) {
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = NEG ? -x[8 * s + j] : x[8 * s + j];
+  split8(v, b);
+}
+
+// acc += A B with A, B in three planes each: the six products >= 2^-16, small terms first
+__device__ __forceinline__ floatx16 mma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], floatx16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+  return c;
+}
+
+struct NoFill {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+// LDS fragment reads are inline asm with explicit waits: one wavefront per SIMD means nobody else hides the LDS latency,
+// so the fragments of the NEXT tile must be in flight while the six MFMAs of the current one issue.  Left to the
+// compiler (256 VGPRs all in use) the reads are re-issued one by one right in front of their MFMA and waited for with
+// lgkmcnt(0) three times per tile (measured: 2.6k cycles per 48-MFMA step against 1.5k of matrix-pipe time).
+// An asm read is invisible to the compiler's wait bookkeeping: RP_WAIT / TR_WAIT (s_waitcnt lgkmcnt(0) naming every
+// destination register read-write) must precede the first use (cdna_hip_programming.md, 5.7 form (ii)).
+#define RP_ISSUE(ADDR, O0, O1, O2, A0, A1, A2)                                                       \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A0) : "v"(ADDR), "n"(O0));                      \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A1) : "v"(ADDR), "n"(O1));                      \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A2) : "v"(ADDR), "n"(O2))
+#define RP_WAITN(N_, A0, A1, A2) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(A0), "+v"(A1), "+v"(A2))
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ floatx16 mma6v(bf16x8 a0, bf16x8 a1, bf16x8 a2, const bf16x8 (&b)[3], floatx16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[0], c, 0, 0, 0);
+  return c;
+}
+
+// one k-step of acc[rt] += A_rt B, A from an Rp slab in LDS: [plane][RT][lane][16 B].  lane_addr = LDS byte address of
+// the slab + 16 lane: ONE address register per ring slot, the tile and plane go into the instruction's offset field
+// (left as address arithmetic, the compiler keeps a register per (slot, tile) alive through the whole kernel: ~100
+// VGPRs, spilled).  Fragments are requested TWO tiles ahead (three register sets): one tile of MFMAs (192 cycles) does
+// not cover the LDS latency when the four wavefronts of the workgroup, in lockstep behind the step's barrier, read at
+// the same moment.  The wait before tile rt is counted: lgkmcnt(6 / 3) leaves the reads of the following tiles in
+// flight (LDS returns in order).  fill(rt) is called behind the MFMAs of tile rt: the step's DMA instructions and the
+// construction of the next B fragment go there, spread under the matrix pipe instead of standing in front of it.
+// LDS_IS_B: the register operand is the MFMA's A (rows of the result = ITS rows), the LDS fragments are B.
+template <int RT, class Fill = NoFill, bool LDS_IS_B = false>
+__device__ __forceinline__ void kstep_rp(floatx16 (&acc)[RT], uint32_t lane_addr, const bf16x8 (&b)[3],
+                                         const Fill& fill = Fill()) {
+  static_assert(RT >= 4, "pipeline depth");
+  bf16x8 f[3][3];
+  RP_ISSUE(lane_addr, 0, RT * 1024, 2 * RT * 1024, f[0][0], f[0][1], f[0][2]);
+  RP_ISSUE(lane_addr, 1024, (RT + 1) * 1024, (2 * RT + 1) * 1024, f[1][0], f[1][1], f[1][2]);
+  static_for<0, RT>([&](auto ic) {
+    constexpr int rt = decltype(ic)::value;
+    constexpr int cur = rt % 3, nxt = (rt + 2) % 3;
+    if constexpr (rt + 2 < RT) {
+      RP_ISSUE(lane_addr, (rt + 2) * 1024, (RT + rt + 2) * 1024, (2 * RT + rt + 2) * 1024, f[nxt][0], f[nxt][1], f[nxt][2]);
+      RP_WAITN(6, f[cur][0], f[cur][1], f[cur][2]);
+    } else if constexpr (rt + 1 < RT) {
+      RP_WAITN(3, f[cur][0], f[cur][1], f[cur][2]);
+    } else {
+      RP_WAITN(0, f[cur][0], f[cur][1], f[cur][2]);
+    }
+    if constexpr (LDS_IS_B)
+      acc[rt] = mma6v(b[0], b[1], b[2], f[cur], acc[rt]);
+    else
+      acc[rt] = mma6v(f[cur][0], f[cur][1], f[cur][2], b, acc[rt]);
+    fill(rt);
+  });
+}
+
+// NK k-steps of ONE 32-row tile whose fragments sit 3072 bytes apart ([k-step][plane][lane][16 B]): acc += sum_k A_k B_k.
+// TILE_OFF = byte offset of the tile inside the slab (compile time); lane_addr as above.
+template <int NK, int TILE_OFF>
+__device__ __forceinline__ void chain_rp1(floatx16& acc, uint32_t lane_addr, const bf16x8 (&b)[NK][3]) {
+  static_assert(NK % 2 == 0, "two register sets alternate");
+  bf16x8 f[2][3];
+  RP_ISSUE(lane_addr, TILE_OFF, TILE_OFF + 1024, TILE_OFF + 2048, f[0][0], f[0][1], f[0][2]);
+  static_for<0, NK>([&](auto ic) {
+    constexpr int k = decltype(ic)::value;
+    constexpr int cur = k & 1, nxt = (k + 1) & 1;
+    if constexpr (k + 1 < NK) {
+      RP_ISSUE(lane_addr, TILE_OFF + (k + 1) * 3072, TILE_OFF + (k + 1) * 3072 + 1024, TILE_OFF + (k + 1) * 3072 + 2048,
+               f[nxt][0], f[nxt][1], f[nxt][2]);
+      RP_WAITN(3, f[cur][0], f[cur][1], f[cur][2]);
+    } else {
+      RP_WAITN(0, f[cur][0], f[cur][1], f[cur][2]);
+    }
+    acc = mma6v(f[cur][0], f[cur][1], f[cur][2], b[k], acc);
+  });
+}
+
+// ---- transposed-read (T) slabs -------------------------------------------------------------------------------------
+// One plane of a T slab is [16 rows][F] bf16 with the 64-byte granule index XORed by the row key (F = 256: key = row & 3;
+// F = 64: key = (row >> 1) & 1).  ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of the
+// group's 4 x 16 block and receives column (lane & 15); groups g = 0..3: k half h = g >> 1, column half g & 1; the second
+// read of a fragment is 8 rows further (same key).  The feature tile ft sits 64 ft bytes along the row, INSIDE the XOR:
+// granule (ft ^ key) for ft < 4 (F = 256: + 256 bytes for ft >= 4), so a lane needs one address per value of ft & 3
+// (F = 64: ft & 1): TrAddr, computed once per slab; everything else is an instruction offset.
+template <int F>
+struct TrAddr {
+  uint32_t a[F == 256 ? 4 : 2];
+  __device__ __forceinline__ TrAddr(uint32_t slab_addr, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int row = 4 * (g >> 1) + (i >> 2);
+    const int colb = (16 * (g & 1) + 4 * (i & 3)) * 2;
+    const int key = F == 256 ? (row & 3) : ((row >> 1) & 1);
+#pragma unroll
+    for (int t = 0; t < (F == 256 ? 4 : 2); ++t) a[t] = slab_addr + (uint32_t)(row * (2 * F) + colb + 64 * (t ^ key));
+  }
+};
+
+#define TR_ISSUE(ADDR, OFF, F_, L0, H0, L1, H1, L2, H2)                                                             \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(L0) : "v"(ADDR), "n"(OFF));                            \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H0) : "v"(ADDR), "n"((OFF) + 16 * (F_)));              \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(L1) : "v"(ADDR), "n"((OFF) + 32 * (F_)));              \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H1) : "v"(ADDR), "n"((OFF) + 48 * (F_)));              \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(L2) : "v"(ADDR), "n"((OFF) + 64 * (F_)));              \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H2) : "v"(ADDR), "n"((OFF) + 80 * (F_)))
+#define TR_WAITN(N_, L0, H0, L1, H1, L2, H2)                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(L0), "+v"(H0), "+v"(L1), "+v"(H1), "+v"(L2), "+v"(H2))
+
+// one k-step of acc[ft] += A_ft B with A read transposed from a T slab: rows of A = feature 32 ft + lane % 32.
+// KOFF = byte offset of the k-step inside the slab (compile time).  Two tiles ahead, counted waits (6 reads per tile).
+template <int FT, int F, int KOFF, class Fill = NoFill>
+__device__ __forceinline__ void kstep_tr(floatx16 (&acc)[FT], const TrAddr<F>& ta, const bf16x8 (&b)[3],
+                                         const Fill& fill = Fill()) {
+  constexpr int NA = F == 256 ? 4 : 2;
+  bf16x4 lo[3][3], hi[3][3];
+  TR_ISSUE(ta.a[0], KOFF, F, lo[0][0], hi[0][0], lo[0][1], hi[0][1], lo[0][2], hi[0][2]);
+  if constexpr (FT > 1) TR_ISSUE(ta.a[1 % NA], KOFF + 256 * (1 / NA), F, lo[1][0], hi[1][0], lo[1][1], hi[1][1], lo[1][2], hi[1][2]);
+  static_for<0, FT>([&](auto ic) {
+    constexpr int ft = decltype(ic)::value;
+    constexpr int cur = ft % 3, nxt = (ft + 2) % 3;
+    if constexpr (ft + 2 < FT) {
+      TR_ISSUE(ta.a[(ft + 2) % NA], KOFF + 256 * ((ft + 2) / NA), F, lo[nxt][0], hi[nxt][0], lo[nxt][1], hi[nxt][1], lo[nxt][2],
+               hi[nxt][2]);
+      TR_WAITN(12, lo[cur][0], hi[cur][0], lo[cur][1], hi[cur][1], lo[cur][2], hi[cur][2]);
+    } else if constexpr (ft + 1 < FT) {
+      TR_WAITN(6, lo[cur][0], hi[cur][0], lo[cur][1], hi[cur][1], lo[cur][2], hi[cur][2]);
+    } else {
+      TR_WAITN(0, lo[cur][0], hi[cur][0], lo[cur][1], hi[cur][1], lo[cur][2], hi[cur][2]);
+    }
+    const bf16x8 a0 = __builtin_shufflevector(lo[cur][0], hi[cur][0], 0, 1, 2, 3, 4, 5, 6, 7);
+    const bf16x8 a1 = __builtin_shufflevector(lo[cur][1], hi[cur][1], 0, 1, 2, 3, 4, 5, 6, 7);
+    const bf16x8 a2 = __builtin_shufflevector(lo[cur][2], hi[cur][2], 0, 1, 2, 3, 4, 5, 6, 7);
+    acc[ft] = mma6v(a0, a1, a2, b, acc[ft]);
+    fill(ft);
+  });
+}
+
+// ---- slab ring: global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, destination =
+// wave-uniform base + lane * 16), three slots, two slabs in flight.  Step c of a kernel's slab sequence is
+//     step_sync(pieces of slab c+1)      (this wave's pieces of slab c have landed; slab c+1 may still be in flight;
+//                                         barrier: everybody's pieces have landed, slot (c+2) % 3 is no longer read)
+//     ring.issue(slab c+2 -> slot (c+2) % 3)
+//     multiply slab c
+// vmcnt counts in order, so other loads / stores issued in between only make a wait more conservative.
+struct Ring {
+  unsigned char* lds;
+  int wave, lane;
+  int slot_bytes;
+  int nw = 4;            // wavefronts of the workgroup that share the issue of a slab's pieces
+  // NPW pieces per wavefront; piece j of the slab = bytes [1024 j, 1024 j + 1024) of src
+  template <int NPW>
+  __device__ __forceinline__ void issue(const unsigned char* src, int slot) const {
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int piece = i * nw + wave;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + piece * 1024), 16, 0, 0);
+    }
+  }
+  // piece i (of NPW) of this wavefront only: lets a caller spread a slab's DMA instructions over a step
+  __device__ __forceinline__ void issue1(const unsigned char* src, int slot, int i) const {
+    const int piece = i * nw + wave;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane * 16),
+                                     (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + piece * 1024), 16, 0, 0);
+  }
+  // rows of TWO neighbouring row tiles (2 pr, 2 pr + 1) of an Rp image with 8 row tiles, four k-steps from ks0:
+  // piece j = (tile j / 12, k-step ks0 + (j % 12) / 3, plane j % 3) -> 24 pieces
+  __device__ __forceinline__ void issue_tiles(const unsigned char* img, int ks0, int pr, int slot) const {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int piece = i * nw + wave;
+      const int t = piece / 12, ks = ks0 + (piece % 12) / 3, p = piece % 3;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(img + (((ks * 3 + p) * 8 + 2 * pr + t) * 64 + lane) * 16),
+          (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + piece * 1024), 16, 0, 0);
+    }
+  }
+  __device__ __forceinline__ const unsigned char* slot(int s) const { return lds + s * slot_bytes; }
+  __device__ __forceinline__ uint32_t lane_addr(int s) const { return slot_addr(s) + (uint32_t)lane * 16u; }
+  __device__ __forceinline__ uint32_t slot_addr(int s) const {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds + (uint32_t)(s * slot_bytes);
+  }
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm_sync() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// younger = this wavefront's DMA instructions of the NEXT slab (the only ones that may stay in flight)
+__device__ __forceinline__ void step_sync(int younger) {
+  if (younger == 0)
+    wait_vm_sync<0>();
+  else if (younger == 3)
+    wait_vm_sync<3>();
+  else if (younger == 6)
+    wait_vm_sync<6>();
+  else
+    wait_vm_sync<9>();
+}
+
+// XCD-aware block id: consecutive logical ids (the two halves of a cloud, neighbouring clouds) share an XCD's L2
+__device__ __forceinline__ int logical_block(int bid, int nb) {
+  if (nb & 7) return bid;
+  return (bid & 7) * (nb >> 3) + (bid >> 3);
+}
+
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+

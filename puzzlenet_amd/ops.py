@@ -1378,8 +1378,10 @@ class _SaLevelFused(torch.autograd.Function):
                 idx = torch.empty((B, S, 32), dtype=torch.int64, device=dev)
                 _call("pzn_knn_f32", _p(xyz), _p(new_xyz), B, N, S, 32, _p(idx), _stream())
             _call("pzn_sa_prep_f32", _p(xyz), _p(new_xyz), _p(w1), _p(b1), B, N, S, D, C1, _p(P), _p(Q), _stream())
-            _call("pzn_sa_level_fwd_f32", _p(P), _p(Q), _p(idx), _p(w2), _p(b2), B, N, S, C1, C2, _p(out), _p(arg), _stream(),
-                  flops=2 * R * 32 * C1 * C2)
+            ws_bytes = _lib.load().pzn_sa_level_fwd_workspace_bytes(C1, C2)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
+            _call("pzn_sa_level_fwd_ws_f32", _p(P), _p(Q), _p(idx), _p(w2), _p(b2), B, N, S, C1, C2, _p(out), _p(arg),
+                  _p(ws), _stream(), flops=2 * R * 32 * C1 * C2)
         ctx.save_for_backward(xyz, feat, new_xyz, idx, w1, w_f, w2, out, arg, P, Q)
         ctx.dims = (B, N, S, D, R, C1, C2)
         ctx.param_refs = (w1, b1, w2, b2)
