@@ -333,7 +333,7 @@ int pzn_sa_prep_f32(const float* xyz, const float* new_xyz, const float* W1, con
 int pzn_sa_level_fwd_f32(const float* Pp, const float* Q, const int64_t* idx, const float* W2, const float* b2,
                          int B, int N, int S, int C1, int C2, float* out, int32_t* argmax, pzn_stream_t stream);
 /* same, with a caller-owned 16-byte aligned workspace of pzn_sa_level_fwd_workspace_bytes(C1, C2) bytes (0 = no streamed
- * form for this shape; workspace may then be NULL): C1, C2 in {128, 256} run the streamed-weights kernel, which
+ * form for this shape; workspace may then be NULL): C1 = C2 in {128, 256} run the streamed-weights kernel, which
  * generates each grouped row once and streams the split planes of W2 through LDS; identical results (same products,
  * same tie rule of the arg-max). */
 size_t pzn_sa_level_fwd_workspace_bytes(int C1, int C2);

@@ -122,20 +122,25 @@ __device__ __forceinline__ floatx16 mma6v(bf16x8 a0, bf16x8 a1, bf16x8 a2, const
 // flight (LDS returns in order).  fill(rt) is called behind the MFMAs of tile rt: the step's DMA instructions and the
 // construction of the next B fragment go there, spread under the matrix pipe instead of standing in front of it.
 // LDS_IS_B: the register operand is the MFMA's A (rows of the result = ITS rows), the LDS fragments are B.
-template <int RT, class Fill = NoFill, bool LDS_IS_B = false>
+// AHEAD = 1: one tile ahead, two register sets (12 registers fewer; enough where a second wavefront shares the SIMD).
+template <int RT, class Fill = NoFill, bool LDS_IS_B = false, int AHEAD = 2>
 __device__ __forceinline__ void kstep_rp(floatx16 (&acc)[RT], uint32_t lane_addr, const bf16x8 (&b)[3],
                                          const Fill& fill = Fill()) {
-  static_assert(RT >= 4, "pipeline depth");
-  bf16x8 f[3][3];
+  static_assert(RT >= 4 && (AHEAD == 1 || AHEAD == 2), "pipeline depth");
+  constexpr int NS = AHEAD + 1;
+  bf16x8 f[NS][3];
   RP_ISSUE(lane_addr, 0, RT * 1024, 2 * RT * 1024, f[0][0], f[0][1], f[0][2]);
-  RP_ISSUE(lane_addr, 1024, (RT + 1) * 1024, (2 * RT + 1) * 1024, f[1][0], f[1][1], f[1][2]);
+  if constexpr (AHEAD == 2) RP_ISSUE(lane_addr, 1024, (RT + 1) * 1024, (2 * RT + 1) * 1024, f[1][0], f[1][1], f[1][2]);
   static_for<0, RT>([&](auto ic) {
     constexpr int rt = decltype(ic)::value;
-    constexpr int cur = rt % 3, nxt = (rt + 2) % 3;
-    if constexpr (rt + 2 < RT) {
-      RP_ISSUE(lane_addr, (rt + 2) * 1024, (RT + rt + 2) * 1024, (2 * RT + rt + 2) * 1024, f[nxt][0], f[nxt][1], f[nxt][2]);
-      RP_WAITN(6, f[cur][0], f[cur][1], f[cur][2]);
-    } else if constexpr (rt + 1 < RT) {
+    constexpr int cur = rt % NS, nxt = (rt + AHEAD) % NS;
+    if constexpr (rt + AHEAD < RT) {
+      RP_ISSUE(lane_addr, (rt + AHEAD) * 1024, (RT + rt + AHEAD) * 1024, (2 * RT + rt + AHEAD) * 1024, f[nxt][0], f[nxt][1], f[nxt][2]);
+      if constexpr (AHEAD == 2)
+        RP_WAITN(6, f[cur][0], f[cur][1], f[cur][2]);
+      else
+        RP_WAITN(3, f[cur][0], f[cur][1], f[cur][2]);
+    } else if constexpr (rt + 1 < RT && AHEAD == 2) {
       RP_WAITN(3, f[cur][0], f[cur][1], f[cur][2]);
     } else {
       RP_WAITN(0, f[cur][0], f[cur][1], f[cur][2]);

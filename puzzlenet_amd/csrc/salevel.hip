@@ -187,7 +187,51 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_level_stream_kernel(SaArg
 #pragma unroll
   for (int j = 0; j < 4; ++j) pair_of(std::integral_constant<int, 0>{}, j);
   bn.get(af);
-  int c = 0;
+  floatx16 acc[CT];                       // starts from the bias (the column sits on the lane: one value per tile)
+  auto acc_init = [&](int ct) __attribute__((always_inline)) {
+    const float bv = sbias[32 * ct + r];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[ct][e] = bv;
+  };
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) acc_init(ct);
+  // ReLU + max / arg-max over the 32 rows of group g, one column tile: element e of lane l = row (e&3) + 8 (e>>2) + 4 h,
+  // column l & 31.  The max runs first, ReLU after (model5_b.py:453-454 has ReLU first: the same value, and the same
+  // arg-max as long as the maximum is positive; if it is not, every ReLU'd row is 0 and the lowest slot wins: the fix-up
+  // below), 3 instead of 5 vector instructions per element.
+  auto epilogue_tile = [&](int ct, int g, bool live) __attribute__((always_inline)) {
+    // (a chain of 15 compare-select pairs; as a tree - depth 4 - the same tile took 1230 instead of 870 cycles: measured)
+    float best = acc[ct][0];
+    int be = 0;                             // register of the maximum (its row below: no table of 16 row numbers in registers)
+#pragma unroll
+    for (int e = 1; e < 16; ++e) {
+      const float v = acc[ct][e];
+      const bool gt = v > best;
+      best = gt ? v : best;
+      be = gt ? e : be;
+    }
+    int bi = (be & 3) + 8 * (be >> 2) + 4 * h;
+    // the other half's candidate: v_permlane32_swap (vector ALU; __shfl_xor is an LDS instruction, waited for with
+    // lgkmcnt(0): every fragment read in flight with it)
+    const auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+    const auto si = __builtin_amdgcn_permlane32_swap((uint32_t)bi, (uint32_t)bi, false, false);
+    const float ob = __uint_as_float(h ? sb[0] : sb[1]);
+    const int oi = (int)(h ? si[0] : si[1]);
+    const bool take = ob > best || (ob == best && oi < bi);
+    best = take ? ob : best;
+    bi = take ? oi : bi;
+    if (!(best > 0.f)) best = 0.f, bi = 0;
+    if (live) {   // one store per lane: lower half the value, upper half the index
+      float* dst = h ? reinterpret_cast<float*>(a.argmax) : a.out;
+      dst[(size_t)g * (CT * 32) + 32 * ct + r] = h ? __int_as_float(bi) : best;
+    }
+  };
+  // The epilogue of a round runs inside the FIRST k-step of the next one: tile 0 in front of it, tile rt+1 (and the reset
+  // of its accumulator to the bias) behind the MFMAs of tile rt.  As a block between two rounds its ~50 vector
+  // instructions per tile stand in front of the matrix pipe of every wavefront at once (~4000 of a round's 65000 cycles
+  // with eight column tiles, of 20000 with four).
+  int c = 0, g_prev = 0;
+  bool live_prev = false;
   for (int rd = 0; rd < rounds; ++rd) {
     const int g = g_cur;
     const bool live = rd * per_round + (int)blockIdx.x * SA_WAVES + wave < a.G;
@@ -201,27 +245,24 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_level_stream_kernel(SaArg
     // (the last step of a round leaves the issue of its slab to here, behind the epilogue's stores, the index load and the
     // copy of Q: the DMA pieces of the NEXT slab are then the youngest memory operations at every step's wait)
     if (rd > 0) issue_slab(c + 1, std::integral_constant<int, 1 % NSL>{});
-    floatx16 acc[CT];                     // starts from the bias (the column sits on the lane: one value per tile)
-#pragma unroll
-    for (int i = 0; i < CT; ++i) {
-      const float bv = sbias[32 * i + r];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][e] = bv;
-    }
     static_for<0, NSL>([&](auto slc) {
       constexpr int sl = decltype(slc)::value;
-      if (rd == 1 && sl >= 2 && sl < 6) STAMP(4 * (sl - 2));
+      constexpr int S0 = NSL == 4 ? 0 : 2;        // (SA_STAMPS: the four steps whose phases are stamped)
+      (void)S0;
+      if (rd == 1 && sl >= S0 && sl < S0 + 4) STAMP(4 * (sl - S0));
       if (c + 1 < total)
         wait_vm_sync<3>();                // may stay in flight: the next slab's 3 DMA pieces
       else
         wait_vm_sync<0>();
-      if (rd == 1 && sl >= 2 && sl < 6) STAMP(4 * (sl - 2) + 1);
+      if (rd == 1 && sl >= S0 && sl < S0 + 4) STAMP(4 * (sl - S0) + 1);
       static_for<0, KPS>([&](auto kc) {   // the sets split during this step are complete behind that wait
         constexpr int st = (sl * KPS + 1 + decltype(kc)::value) % NSET;
         SA_GREADY(st);
       });
+      if constexpr (sl == 0)
+        if (rd > 0) epilogue_tile(0, g_prev, live_prev), acc_init(0);
       const uint32_t la = ring.lane_addr(c % 3);
-      if (rd == 1 && sl >= 2 && sl < 6) STAMP(4 * (sl - 2) + 2);
+      if (rd == 1 && sl >= S0 && sl < S0 + 4) STAMP(4 * (sl - S0) + 2);
       static_for<0, KPS>([&](auto kc) {
         constexpr int kk = decltype(kc)::value, ksn = sl * KPS + kk + 1, st = ksn % NSET;
         if constexpr (ksn < KS)
@@ -239,6 +280,8 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_level_stream_kernel(SaArg
           // memory instruction m of the step behind tile 1 + 2m (one k-step per slab) / 1 + m (two): the KPS row loads of
           // the k-steps split during the NEXT step, then the three DMA pieces of slab c + 2
           const int m = KPS == 1 ? ((t & 1) ? (t - 1) / 2 : -1) : t - 1;
+          if constexpr (sl == 0 && kk == 0)
+            if (rd > 0 && rt + 1 < CT) epilogue_tile(rt + 1, g_prev, live_prev), acc_init(rt + 1);
           static_for<0, KPS>([&](auto ic) {
             constexpr int i = decltype(ic)::value, ksl = (sl + 1) * KPS + 1 + i, sn = ksl % NSET;
             if (m == i) {
@@ -248,54 +291,34 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_level_stream_kernel(SaArg
                 SA_GLOAD2(prow_n, ksl - KS, sn);
             }
           });
-          if constexpr (sl + 1 < NSL)
+          if constexpr (sl == 0 && KPS == 1) {   // (behind the epilogue's stores: the pieces stay the youngest memory operations)
+            if (t == CT - 1) issue_slab(c + 2, std::integral_constant<int, (sl + 2) % NSL>{});
+          } else if constexpr (sl + 1 < NSL) {
             if (m >= KPS && m < KPS + 3) issue_piece(c + 2, std::integral_constant<int, (sl + 2) % NSL>{}, m - KPS);
+          }
         };
         kstep_rp<CT, decltype(fill), true>(acc, la + kk * KBLK, af, fill);
         bn.get(af);
       });
-      if (rd == 1 && sl >= 2 && sl < 6) STAMP(4 * (sl - 2) + 3);
+      if (rd == 1 && sl >= S0 && sl < S0 + 4) STAMP(4 * (sl - S0) + 3);
       ++c;
     });
-    // bias + ReLU + max / arg-max over the group's 32 rows: element e of lane l = row (e&3) + 8 (e>>2) + 4 h, column l & 31
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      const int col = 32 * ct + r;
-      // max over the 32 rows first, ReLU after (model5_b.py:453-454 has ReLU first: the same value, and the same arg-max
-      // as long as the maximum is positive; if it is not, every ReLU'd row is 0 and the lowest slot wins: the fix-up
-      // below), 3 instead of 5 vector instructions per element
-      float best = acc[ct][0];
-      int bi = 4 * h;
-#pragma unroll
-      for (int e = 1; e < 16; ++e) {
-        const int rl = (e & 3) + 8 * (e >> 2) + 4 * h;
-        const float v = acc[ct][e];
-        const bool gt = v > best;
-        best = gt ? v : best;
-        bi = gt ? rl : bi;
-      }
-      const float ob = __shfl_xor(best, 32, 64);
-      const int oi = __shfl_xor(bi, 32, 64);
-      const bool take = ob > best || (ob == best && oi < bi);
-      best = take ? ob : best;
-      bi = take ? oi : bi;
-      if (!(best > 0.f)) best = 0.f, bi = 0;
-      if (live) {   // one store per lane: lower half the value, upper half the index
-        float* dst = h ? reinterpret_cast<float*>(a.argmax) : a.out;
-        dst[(size_t)g * (CT * 32) + col] = h ? __int_as_float(bi) : best;
-      }
-    }
     if (rd == 1) STAMP(16);
     asm volatile("" : "+v"(j_next2));
     g_cur = g_next, g_next = g_next2, j_next = j_next2;
     prow = prow_n, qaddr = qaddr_n;
+    g_prev = g, live_prev = live;
   }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) epilogue_tile(ct, g_prev, live_prev);     // the last round's
 }
 
 }  // namespace
 
 size_t pzn_sa_level_stream_workspace_bytes(int C1, int C2) {
-  return ((C1 == 128 || C1 == 256) && (C2 == 128 || C2 == 256)) ? (size_t)C1 * C2 * 6 : 0;
+  // (the two production shapes, model5_b.py:449-461; the mixed shapes compile, but with in-flight row registers spilled:
+  // tests/test_isa_forms.py checks the instantiated ones)
+  return (C1 == C2 && (C1 == 128 || C1 == 256)) ? (size_t)C1 * C2 * 6 : 0;
 }
 
 // -> PZN_EUNSUPPORTED for shapes it does not take (the weight-stationary kernel then)
@@ -318,14 +341,10 @@ int pzn_sa_level_stream(const float* Pp, const float* Q, const int64_t* idx, con
 #endif
   int gx = (G + SA_WAVES - 1) / SA_WAVES;
   if (gx > 256) gx = 256;
-  if (C1 == 256 && C2 == 256)
+  if (C1 == 256)
     hipLaunchKernelGGL((sa_level_stream_kernel<256, 8>), dim3(gx), dim3(SA_WAVES * 64), 0, st, a);
-  else if (C1 == 128 && C2 == 128)
-    hipLaunchKernelGGL((sa_level_stream_kernel<128, 4>), dim3(gx), dim3(SA_WAVES * 64), 0, st, a);
-  else if (C1 == 128 && C2 == 256)
-    hipLaunchKernelGGL((sa_level_stream_kernel<128, 8>), dim3(gx), dim3(SA_WAVES * 64), 0, st, a);
   else
-    hipLaunchKernelGGL((sa_level_stream_kernel<256, 4>), dim3(gx), dim3(SA_WAVES * 64), 0, st, a);
+    hipLaunchKernelGGL((sa_level_stream_kernel<128, 4>), dim3(gx), dim3(SA_WAVES * 64), 0, st, a);
 #ifdef SA_STAMPS
   {
     long long hst[17];

@@ -34,3 +34,120 @@ def test_no_src1_op_sel_packed_multiplies():
             if hits:
                 bad[src] = len(hits)
     assert not bad, f"packed fp32 instructions with src1 op_sel (wrong beside AGPR-accumulator MFMAs, see tools/pk_probe2.hip): {bad}"
+
+
+ASM_LOAD = re.compile(r"^global_load_dword(?:x[24])?\s+(v\[\d+:\d+\]|v\d+)")
+VREG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
+
+
+def _vregs(text):
+    out = set()
+    for m in VREG.finditer(text):
+        if m.group(1):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def test_no_use_of_in_flight_asm_load_registers():
+    """salevel.hip issues its row loads as inline asm and covers them with the step's own `s_waitcnt vmcnt` (also asm):
+    the compiler does not know the destination registers are written LATER.  Under register pressure it has spilled such
+    a register right behind the load (the mixed-shape instantiations, not built: DESIGN.md section 4) - stale data, no
+    diagnostic.  This test walks every instantiated streamed kernel in text order and fails when any instruction between
+    an asm load and the next asm vmcnt wait touches one of the load's destination registers."""
+    hipcc = build.hipcc()
+    flags = [f for f in build.COMMON if f not in ("-fPIC", "-fvisibility=hidden")]
+    extra = dict(build.SOURCES)["salevel.hip"]
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "salevel.s")
+        cmd = [hipcc] + flags + extra + ["-S", "--cuda-device-only", "-o", out, os.path.join(build.CSRC, "salevel.hip")]
+        assert subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode == 0
+        text = open(out).read()
+    kernels = re.split(r"\n(?=_ZN\S*sa_level_stream_kernel\S*:)", text)[1:]
+    assert kernels, "no streamed kernel in the assembly"
+    for k in kernels:
+        name = k.split(":")[0]
+        body = k[:k.index("s_endpgm")]
+        in_asm, in_flight, bad, loads = False, set(), [], 0
+        for line in body.split("\n"):
+            t = line.strip()
+            if "ASMSTART" in t:
+                in_asm = True
+                continue
+            if "ASMEND" in t:
+                in_asm = False
+                continue
+            if not t or t[0] in ";.":
+                continue
+            m = ASM_LOAD.match(t) if in_asm else None
+            if m:
+                in_flight |= _vregs(m.group(1))
+                loads += 1
+                continue
+            if t.startswith("s_waitcnt vmcnt") and (in_asm or t.startswith("s_waitcnt vmcnt(0)")):
+                in_flight.clear()
+                continue
+            hit = _vregs(t) & in_flight
+            if hit:
+                bad.append((t, sorted(hit)))
+        assert loads > 0, name
+        assert not bad, f"{name}: in-flight asm-load registers touched before their wait: {bad[:4]}"
+
+
+ASM_DS = re.compile(r"^ds_read\w*\s+(v\[\d+:\d+\]|v\d+)")
+LGKM = re.compile(r"^s_waitcnt\s+(?:vmcnt\(\d+\)\s+)?lgkmcnt\((\d+)\)")
+
+
+def _lds_in_flight_violations(source):
+    """Same walk for the asm LDS reads (pzn_mfma.h: RP_ISSUE / TR_ISSUE with counted lgkmcnt waits; LDS returns in order,
+    so `lgkmcnt(N)` leaves the N youngest reads in flight)."""
+    hipcc = build.hipcc()
+    flags = [f for f in build.COMMON if f not in ("-fPIC", "-fvisibility=hidden")]
+    extra = dict(build.SOURCES)[source]
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, source + ".s")
+        cmd = [hipcc] + flags + extra + ["-S", "--cuda-device-only", "-o", out, os.path.join(build.CSRC, source)]
+        assert subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode == 0
+        text = open(out).read()
+    bad, reads = {}, 0
+    for k in re.split(r"\n(?=_Z\S+:\s)", text)[1:]:
+        name = k.split(":")[0]
+        if "s_endpgm" not in k:
+            continue
+        in_asm, queue = False, []                       # queue: destination register sets of asm reads, oldest first
+        for line in k[:k.index("s_endpgm")].split("\n"):
+            t = line.strip()
+            if "ASMSTART" in t:
+                in_asm = True
+                continue
+            if "ASMEND" in t:
+                in_asm = False
+                continue
+            if not t or t[0] in ";.":
+                continue
+            m = ASM_DS.match(t) if in_asm else None
+            if m:
+                queue.append(_vregs(m.group(1)))
+                reads += 1
+                continue
+            w = LGKM.match(t)
+            if w:
+                n = int(w.group(1))
+                queue = queue[len(queue) - n:] if n else []
+                continue
+            if t.startswith("s_waitcnt") and "lgkmcnt" not in t:
+                continue
+            flying = set().union(*queue) if queue else set()
+            hit = _vregs(t) & flying
+            if hit and not t.startswith("ds_read"):      # (a compiler-issued LDS read of its own does not touch them)
+                bad.setdefault(name, []).append((t, sorted(hit)))
+    return reads, bad
+
+
+def test_no_use_of_in_flight_asm_lds_read_registers():
+    for source in ("attnfused.hip", "salevel.hip"):
+        reads, bad = _lds_in_flight_violations(source)
+        assert reads > 0, source
+        assert not bad, f"{source}: registers of asm LDS reads touched before their counted wait: " \
+                        f"{ {k: v[:3] for k, v in bad.items()} }"
