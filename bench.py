@@ -185,15 +185,15 @@ def pmc_traffic(key, B, N):
     """HBM bytes per step of a kernel / stage from the committed PMC passes (tools/pmc_summary.py, collected with
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` in separate runs of this same command): only when they were taken
     on THIS build and on this workload; otherwise null.  -> (bytes or None, provenance string)."""
-    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
     if not os.path.exists(path):
         return None, "no PMC summary committed for this round"
     doc = json.load(open(path))
     if doc.get("build_id") != build_id():
-        return None, f"profiles/r2_pmc_traffic.json was collected on build {doc.get('build_id')}, this is {build_id()}"
+        return None, f"profiles/r3_pmc_traffic.json was collected on build {doc.get('build_id')}, this is {build_id()}"
     if (doc.get("batch"), doc.get("points")) != (B, N):
-        return None, "profiles/r2_pmc_traffic.json was collected on another workload"
-    return doc.get(key), f"profiles/r2_pmc_traffic.json (build {doc.get('build_id')}, separate --pmc passes of bench.py)"
+        return None, "profiles/r3_pmc_traffic.json was collected on another workload"
+    return doc.get(key), f"profiles/r3_pmc_traffic.json (build {doc.get('build_id')}, separate --pmc passes of bench.py)"
 
 
 def main():

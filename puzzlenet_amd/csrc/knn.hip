@@ -1003,7 +1003,7 @@ PZN_EXPORT int pzn_knn_f32(const float* xyz, const float* new_xyz, int B, int N,
 
 // pointnet_util.py:117-132 with knn=True, K = 32, in ONE launch and in the reference's layout: idx[B,S,32] (stable
 // (distance, index) order, as pzn_knn_f32) and out[B,S,32,3+D] = cat(xyz[idx] - new_xyz, feat[idx]); grouped_xyz
-// [B,S,32,3] (returnfps) when non-NULL.  64 <= N <= 4096, D > 0, D % 4 == 0, feat / out 16-byte aligned; other
+// [B,S,32,3] (returnfps) when non-NULL.  64 <= N <= 8192, D > 0, D % 4 == 0, feat / out 16-byte aligned; other
 // shapes return PZN_EUNSUPPORTED (compose pzn_knn_f32 + pzn_group_fwd_f32 then).
 PZN_EXPORT int pzn_knn_group_f32(const float* xyz, const float* feat, const float* new_xyz, int B, int N, int S, int D,
                                  int64_t* idx, float* out, float* grouped_xyz, pzn_stream_t stream) {

@@ -36,6 +36,10 @@ def rig():
     wg = (torch.randn(1024, 1280, generator=g) / 30).to(dev)
     yg = torch.empty(4096, 1024, device=dev)
     side = torch.cuda.Stream()
+    bg = torch.zeros(1024, device=dev)
+
+    def chain():      # the four blocks of an encoder as chained kernels (csrc/attnfused.hip: AGPR accumulators) + out projection
+        return ops.attention_chain_fused([xa], [[tuple(aw)] * 4], [wg], [bg])[0]
     victims = {
         "knn": lambda: ops.knn(xyz, new_xyz, 32),
         "knn_group": lambda: ops.knn_group(xyz, feat, new_xyz)[0],
@@ -44,6 +48,7 @@ def rig():
         "sa_level": lambda: ops.sa_mlp_max(xyz, feat, new_xyz, None, w1, b1, w2, b2),
         "chamfer": lambda: torch.cat([t.reshape(-1).float() for t in ops.chamfer(a_pts, b_pts)]),
         "attention_block": lambda: ops.attention_block(xa, *aw)[0],
+        "attention_chain_fused": lambda: torch.cat([t.reshape(-1) for t in chain()]),
         "linear_weight_stationary": lambda: dense.linear(xl, wl, bl, relu=True),
         "linear_general_engine": lambda: dense.linear(xg, wg, None),
         "max_over_points": lambda: ops.max_over_points(xa),
@@ -60,10 +65,15 @@ def rig():
         with torch.cuda.stream(side):
             ops.attention_block(xa, *aw)
 
-    return dev, side, victims, {"general_engine": agg_general, "sa_level": agg_level, "attention_block": agg_attention}
+    def agg_chain():
+        with torch.cuda.stream(side):
+            chain()
+
+    return dev, side, victims, {"general_engine": agg_general, "sa_level": agg_level, "attention_block": agg_attention,
+                                "attention_fused": agg_chain}
 
 
-@pytest.mark.parametrize("aggressor", ["general_engine", "sa_level", "attention_block"])
+@pytest.mark.parametrize("aggressor", ["general_engine", "sa_level", "attention_block", "attention_fused"])
 def test_results_do_not_depend_on_the_other_stream(rig, aggressor):
     dev, side, victims, aggressors = rig
     ag = aggressors[aggressor]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 --pmc counter_collection.csv dumps into the per-kernel HBM traffic summary bench.py attaches to its
-roofline objects (profiles/r2_pmc_traffic.json).
+roofline objects (profiles/r3_pmc_traffic.json).
 
     python tools/pmc_summary.py <fetch_dir> <write_dir> <out.json> [--batch 64 --points 2048]
 
@@ -62,9 +62,11 @@ def main():
     kg = sel(r"^knn_select_kernel<\d+, \d+, true")
     stage = round(2 * sum(v["hbm_bytes_per_launch"] for v in kg.values())) if len(kg) == 2 else None
     # the named matrix-core kernel (max-pool variant with the generated operand): 2 clouds x (level 1 + level 2)
-    mp = sel(r"^ws_gemm_kernel<\d+, true, false, \d+, true, (true|false), true>")
+    # (round 3: the streamed-weights kernel of salevel.hip + its weight split; the weight-stationary GATH variant when
+    # PZN_SA_STREAM=0)
+    mp = sel(r"^sa_level_stream_kernel<") or sel(r"^ws_gemm_kernel<\d+, true, false, \d+, true, (true|false), true>")
     maxpool = round(2 * sum(v["hbm_bytes_per_launch"] for v in mp.values())) if len(mp) == 2 else None
-    fam = sel(r"^(ws_gemm_kernel|df_wgrad_kernel|gemm_kernel)")
+    fam = sel(r"^(ws_gemm_kernel|df_wgrad_kernel|gemm_kernel|sa_level_stream_kernel|attn_(proj|fwd|bwd_q|bwd_k)_kernel)")
     mfma = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam.values()) / a.steps_in_trace) or None
     sa = sel(r"^(sa_point_l1_bwd_kernel|sa_point_l1_fwd_kernel|sa_prep_kernel)")
     sa_b = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sa.values()) / a.steps_in_trace) or None
