@@ -449,6 +449,17 @@ int pzn_attn_fused_wgrads(const float* dz, const float* t, const float* dq, cons
                           float* dbq, float* dWk, float* dbk, float* dWv, float* dbv, float* dWo,
                           float* dbo, int accumulate, pzn_stream_t stream);
 
+/* The encoder's out projection and the max over the points in ONE launch (model5_b.py:466-475):
+ *   out[b,l,:] = cat(x[0] .. x[nslice-1])[b,l,:] W^T + bias   (W[Nout, nslice*E]; the concatenation is never built),
+ *   fmax[b,:] = max_l out[b,l,:],  arg[b,:] = its point (the lowest one on ties, as torch.max).
+ * out may be NULL: predict5 uses only the maximum (model5_b.py:723).  Shape taken: L = 256, E = 256, nslice = 5,
+ * Nout = 1024 (pzn_outproj_maxpts_workspace_bytes > 0; the workspace, 16-byte aligned, holds the split planes of W);
+ * everything else, and the exact-fp32 engine, returns PZN_EUNSUPPORTED (compose pzn_linear_slice_fwd_f32 +
+ * pzn_maxpool_points_fwd_f32 then).  arg feeds pzn_linear_maxpts_dgrad/wgrad_f32. */
+size_t pzn_outproj_maxpts_workspace_bytes(int L, int E, int nslice, int Nout);
+int pzn_outproj_maxpts_fwd_f32(const float* const* x, int nslice, const float* W, const float* bias, int B, int L, int E,
+                               int Nout, float* out, float* fmax, int32_t* arg, void* workspace, pzn_stream_t stream);
+
 /* torch.max(x, dim=1) over the point axis (model5_b.py:475 global feature, :741): out[b,c] =
  * max_l x[b,l,c], idx[b,c] = its row (the lowest one on ties); backward dx[b,l,c] =
  * (l == idx[b,c]) ? dout[b,c] : 0, every element of dx written (any C; C % 4 == 0 with 16-byte aligned

@@ -35,6 +35,7 @@ SOURCES = [
     ("gemm.hip", NOSLP),
     ("attnfused.hip", NOSLP),
     ("salevel.hip", NOSLP),
+    ("outproj.hip", NOSLP),
     ("poolbwd.hip", []),
     ("maxptsbwd.hip", NOSLP),
     ("wsgemm.hip", []),

@@ -309,6 +309,10 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_level_stream_kernel(SaArg
     prow = prow_n, qaddr = qaddr_n;
     g_prev = g, live_prev = live;
   }
+  // (the row loads and the index load issued during the last steps - for a round that does not exist - are still in flight,
+  // and the compiler believes their registers dead: drained before the epilogue's addresses and values reuse them.
+  // outproj.hip has the measured failure.)
+  asm volatile("s_waitcnt vmcnt(0) ; pzn_drain" ::: "memory");
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) epilogue_tile(ct, g_prev, live_prev);     // the last round's
 }

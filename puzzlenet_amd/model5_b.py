@@ -129,6 +129,7 @@ class PCTransformer_nonsort(nn.Module):
         self.out = nn.Linear(gs2_feature_size * 2 * 5, 1024)
 
     fused_sa = True     # False: literally sample_and_group -> [B,S,K,3+D] -> shared MLP, as the reference composes it
+    need_out = True     # False: slot 3 of the 5-tuple (the [B,256,1024] projection) is None; predict5 sets it around its calls
     f2f_grad_hook = None     # engine.TrainStep (N > 1): called with the gradient of the attention chain's input
 
     def _mark_f2f(self, f2f):
@@ -195,7 +196,9 @@ class PCTransformer_nonsort(nn.Module):
         self._mark_f2f(f2f)
         if self.chain_fused_ok(f2f):
             # :462-475 through the chained matrix-core kernels (csrc/attnfused.hip), one encoder per launch here
-            (out, attention, f_global), = ops.attention_chain_fused([f2f], [self._block_params()], [self.out.weight], [self.out.bias])
+            # need_out = False (set by predict5, which uses only the maximum: :723): `out` is None, never written
+            (out, attention, f_global), = ops.attention_chain_fused([f2f], [self._block_params()], [self.out.weight], [self.out.bias],
+                                                                   need_out=self.need_out)
             return f_global, x2, attention, out, x_feature
         if _ATTN_CHAIN and f2f.is_cuda and ops.attention_chain_supported(f2f, self.atten1.mlpq.weight.shape[0], self.out.weight):
             # :462-474 as one autograd node: no concatenation, no gradient-accumulation adds between the blocks
@@ -285,6 +288,15 @@ class TouchedRegraster(_Base):
             mrpc = mrpc.unsqueeze(0)
         N = fpc.shape[1]
 
+        # the encoders' [B,256,1024] projection itself (5-tuple slot 3) is not used by predict5, only its max over the
+        # points (:723): not materialised here (the encoder called on its own still returns it)
+        self.Encoder.need_out = self.Encoder2.need_out = False
+        try:
+            return self._predict5_encoders(fpc, mrpc, N, need, pose_hook)
+        finally:
+            self.Encoder.need_out = self.Encoder2.need_out = True
+
+    def _predict5_encoders(self, fpc, mrpc, N, need, pose_hook):
         if self.two_streams and fpc.is_cuda:
             # FPS is a latency-bound chain on 128 workgroups: it runs on the side stream while this one computes the
             # per-point features of both clouds, which do not depend on it; then Encoder stays here, Encoder2 goes
@@ -319,7 +331,8 @@ class TouchedRegraster(_Base):
                     t.record_stream(cur)
                 rf, rm = ops.attention_chain_fused(
                     [f2f_f, f2f_m], [self.Encoder._block_params(), self.Encoder2._block_params()],
-                    [self.Encoder.out.weight, self.Encoder2.out.weight], [self.Encoder.out.bias, self.Encoder2.out.bias])
+                    [self.Encoder.out.weight, self.Encoder2.out.weight], [self.Encoder.out.bias, self.Encoder2.out.bias],
+                    need_out=False)
                 ffpcs = (rf[2], x2_f, rf[1], rf[0], xf_f2)
                 fmrpcs = (rm[2], x2_m, rm[1], rm[0], xf_m2)
                 return self._heads(ffpcs, fmrpcs, N, need, pose_hook)

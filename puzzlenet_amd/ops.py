@@ -954,11 +954,11 @@ class _AttnChainFused(torch.autograd.Function):
     per layer forward, two launches + the weight gradients per layer backward), the running mean of the four maps
     written by the block kernel, then — per encoder — the out projection over the five slices and the max over the
     points exactly as _AttnChainOut does them.
-    inputs: nprob, then per problem x[B,L,E], 4 x (wq,bq,wk,bk,wv,bv,wo,bo), w_out, b_out
+    inputs: nprob, need_out (False: `out` is not materialised, an empty placeholder stands in the tuple), then per problem x[B,L,E], 4 x (wq,bq,wk,bk,wv,bv,wo,bo), w_out, b_out
     -> per problem (out[B,L,Nout], attention[B,L,L], f_global[B,Nout])"""
 
     @staticmethod
-    def forward(ctx, nprob, *args):
+    def forward(ctx, nprob, need_out, *args):
         per = 35
         xs = [_f32(args[per * i], "x") for i in range(nprob)]
         pss = [[_f32(t, "param") for t in args[per * i + 1: per * i + 35]] for i in range(nprob)]
@@ -1000,24 +1000,41 @@ class _AttnChainFused(torch.autograd.Function):
                     saved[p].append((cur[p], t[p], mask[p], lse[p], img[p][0], img[p][1], img[p][2], img[p][3], img[p][4],
                                      W[p][i]))
                 cur = r
-            outs, tosave = [], []
+            outs, tosave, empties = [], [], []
             for p in R:
                 w_out, b_out = pss[p][32], pss[p][33]
-                y = mk(M, Nout)
                 xsl = [saved[p][1][0], saved[p][2][0], saved[p][3][0], cur[p], xs[p].reshape(M, E)]   # att1..att4, f2f (:466)
-                for i, xi in enumerate(xsl):
-                    _call("pzn_linear_slice_fwd_f32", _p(xi), w_out.data_ptr() + 4 * E * i, 5 * E, _p(b_out), M, E, Nout,
-                          int(i > 0), _p(y), st, flops=2 * M * E * Nout)
                 f_global = mk(B, Nout)
                 arg = torch.empty((B, Nout), dtype=torch.int32, device=dev)
-                _call("pzn_maxpool_points_fwd_f32", _p(y), B, L, Nout, _p(f_global), _p(arg), st)
-                outs += [y.view(B, L, Nout), maps[p], f_global]
+                y = mk(M, Nout) if need_out else None
+                ws_bytes = lib.pzn_outproj_maxpts_workspace_bytes(L, E, 5, Nout)
+                fused = False
+                if ws_bytes:
+                    # :466-475 in one launch (csrc/outproj.hip); `out` only when the caller wants it
+                    try:
+                        _call("pzn_outproj_maxpts_fwd_f32", _ptrs(xsl), 5, _p(w_out), _p(b_out), B, L, E, Nout, _p(y), _p(f_global),
+                              _p(arg), _p(raw(ws_bytes)), st, flops=2 * M * 5 * E * Nout)
+                        fused = True
+                    except _lib.PznUnsupported:
+                        pass
+                if not fused:
+                    y = mk(M, Nout) if y is None else y
+                    for i, xi in enumerate(xsl):
+                        _call("pzn_linear_slice_fwd_f32", _p(xi), w_out.data_ptr() + 4 * E * i, 5 * E, _p(b_out), M, E, Nout,
+                              int(i > 0), _p(y), st, flops=2 * M * E * Nout)
+                    _call("pzn_maxpool_points_fwd_f32", _p(y), B, L, Nout, _p(f_global), _p(arg), st)
+                if y is None:         # (a placeholder keeps the output tuple's shape; it carries no data and no gradient)
+                    y = f_global.new_empty((0,))
+                    outs += [y, maps[p], f_global]
+                    empties.append(y)
+                else:
+                    outs += [y.view(B, L, Nout), maps[p], f_global]
                 tosave += [t_ for blk in saved[p] for t_ in blk] + [cur[p]] + pss[p] + [arg]
         ctx.save_for_backward(*tosave)
         ctx.nprob = nprob
         ctx.dims = (B, L, E, dk, Nout)
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(*maps)
+        ctx.mark_non_differentiable(*maps, *empties)
         return tuple(outs)
 
     @staticmethod
@@ -1033,7 +1050,7 @@ class _AttnChainFused(torch.autograd.Function):
         raw = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
         lib = _lib.load()
         vb = lib.pzn_attn_fused_v_image_bytes(B)
-        grads = [None] * (1 + 35 * nprob)
+        grads = [None] * (2 + 35 * nprob)
         saved, ps, g, Gs, direct_blk = [], [], [], [], []
         with torch.cuda.device(dev):
             st = _stream()
@@ -1045,7 +1062,7 @@ class _AttnChainFused(torch.autograd.Function):
                 arg = t[75]
                 dy, dfg = gout[3 * p], gout[3 * p + 2]
                 w_out, b_out = ps[p][32], ps[p][33]
-                base = 1 + 35 * p
+                base = 2 + 35 * p
                 sparse = dy is None and dfg is not None and (5 * E) % 64 == 0 and L <= 600
                 if sparse:
                     dfg = _f32(dfg, "df_global")
@@ -1097,7 +1114,7 @@ class _AttnChainFused(torch.autograd.Function):
                       _ptrs(delta), _ptrs(u), B, _ptrs(dkk), _ptrs(dvv), _ptrs(dx), st,
                       flops=nprob * (2 * M * E * (E + dk) + 2 * B * L * L * (2 * dk + 2 * E)))
                 for p in R:
-                    base = 1 + 35 * p
+                    base = 2 + 35 * p
                     prm = ps[p][8 * i: 8 * i + 8]
                     sinks = [_sink(p_, ctx.needs_input_grad[base + 1 + 8 * i + j]) for j, p_ in enumerate(prm)]
                     direct = all(s_ is not None for s_ in sinks)
@@ -1112,17 +1129,19 @@ class _AttnChainFused(torch.autograd.Function):
                 g = [Gs[p][:, sl * E: (sl + 1) * E] for p in R]
                 g2, dx = dx, [mk(M, E) for _ in R] if i > 0 else dx      # (dx of this block is the next one's second addend)
             for p in R:
-                grads[1 + 35 * p] = torch.add(g[p], g2[p]).view(B, L, E)
+                grads[2 + 35 * p] = torch.add(g[p], g2[p]).view(B, L, E)
         return tuple(grads)
 
 
-def attention_chain_fused(xs, blocks_list, w_outs, b_outs):
-    """xs: list of nprob inputs [B,L,E]; blocks_list[p]: four 8-tuples; -> list of (out, mean map, f_global) per problem"""
+def attention_chain_fused(xs, blocks_list, w_outs, b_outs, need_out=True):
+    """xs: list of nprob inputs [B,L,E]; blocks_list[p]: four 8-tuples; -> list of (out, mean map, f_global) per problem.
+    need_out=False: only f_global = max over the points of the out projection is wanted (predict5, model5_b.py:723);
+    `out` is then None and its 67 MB per encoder at B = 64 are never written."""
     flat = []
     for x, blocks, w, b in zip(xs, blocks_list, w_outs, b_outs):
         flat += [x] + [p_ for blk in blocks for p_ in blk] + [w, b]
-    res = _AttnChainFused.apply(len(xs), *flat)
-    return [res[3 * i: 3 * i + 3] for i in range(len(xs))]
+    res = _AttnChainFused.apply(len(xs), bool(need_out), *flat)
+    return [(res[3 * i] if res[3 * i].numel() else None, res[3 * i + 1], res[3 * i + 2]) for i in range(len(xs))]
 
 
 class _SaMlpMax(torch.autograd.Function):

@@ -5,6 +5,8 @@ caught a real fault: the packed-fp32 form of the set-abstraction prep kernel (v_
 sums with one term missing in lanes 48-63 while the general matrix-core engine ran beside it (csrc/sapoint.hip).  Every
 deterministic forward kernel family is run alone (reference, checked to be bit-reproducible) and then 40 times while an
 aggressor kernel is kept busy on a second stream; outputs must be bit-identical."""
+import os
+
 import pytest
 import torch
 
@@ -73,6 +75,13 @@ def rig():
                                 "attention_fused": agg_chain}
 
 
+def _trace(line):
+    path = os.environ.get("PZN_TEST_TRACE")
+    if path:
+        with open(path, "a") as f:
+            f.write(line + "\n")
+
+
 @pytest.mark.parametrize("aggressor", ["general_engine", "sa_level", "attention_block", "attention_fused"])
 def test_results_do_not_depend_on_the_other_stream(rig, aggressor):
     dev, side, victims, aggressors = rig
@@ -80,6 +89,7 @@ def test_results_do_not_depend_on_the_other_stream(rig, aggressor):
     report = {}
     with torch.no_grad():
         for name, fn in victims.items():
+            _trace(f"[{aggressor}] {name}")      # (PZN_TEST_TRACE=<file>: which pair was running if the GPU faults)
             ref, again = fn(), fn()
             torch.cuda.synchronize()
             assert torch.equal(ref, again), f"{name} is not reproducible even alone"

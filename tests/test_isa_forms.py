@@ -51,20 +51,25 @@ def _vregs(text):
 
 
 def test_no_use_of_in_flight_asm_load_registers():
-    """salevel.hip issues its row loads as inline asm and covers them with the step's own `s_waitcnt vmcnt` (also asm):
+    """salevel.hip and outproj.hip issue their row loads as inline asm and covers them with the step's own `s_waitcnt vmcnt` (also asm):
     the compiler does not know the destination registers are written LATER.  Under register pressure it has spilled such
     a register right behind the load (the mixed-shape instantiations, not built: DESIGN.md section 4) - stale data, no
     diagnostic.  This test walks every instantiated streamed kernel in text order and fails when any instruction between
     an asm load and the next asm vmcnt wait touches one of the load's destination registers."""
+    for source, kernel in (("salevel.hip", "sa_level_stream_kernel"), ("outproj.hip", "outproj_maxpts_kernel")):
+        _check_asm_loads(source, kernel)
+
+
+def _check_asm_loads(source, kernel):
     hipcc = build.hipcc()
     flags = [f for f in build.COMMON if f not in ("-fPIC", "-fvisibility=hidden")]
-    extra = dict(build.SOURCES)["salevel.hip"]
+    extra = dict(build.SOURCES)[source]
     with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "salevel.s")
-        cmd = [hipcc] + flags + extra + ["-S", "--cuda-device-only", "-o", out, os.path.join(build.CSRC, "salevel.hip")]
+        out = os.path.join(tmp, source + ".s")
+        cmd = [hipcc] + flags + extra + ["-S", "--cuda-device-only", "-o", out, os.path.join(build.CSRC, source)]
         assert subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode == 0
         text = open(out).read()
-    kernels = re.split(r"\n(?=_ZN\S*sa_level_stream_kernel\S*:)", text)[1:]
+    kernels = re.split(r"\n(?=_ZN\S*" + kernel + r"\S*:)", text)[1:]
     assert kernels, "no streamed kernel in the assembly"
     for k in kernels:
         name = k.split(":")[0]
@@ -93,6 +98,9 @@ def test_no_use_of_in_flight_asm_load_registers():
                 bad.append((t, sorted(hit)))
         assert loads > 0, name
         assert not bad, f"{name}: in-flight asm-load registers touched before their wait: {bad[:4]}"
+        # the loads of the LAST step are never consumed: they must be drained before the final epilogue reuses their
+        # registers (the text-order walk above cannot see that: the compiler places the epilogue in front of the loop)
+        assert "pzn_drain" in body, f"{name}: no vmcnt(0) drain between the last asm loads and the epilogue"
 
 
 ASM_DS = re.compile(r"^ds_read\w*\s+(v\[\d+:\d+\]|v\d+)")
@@ -146,7 +154,7 @@ def _lds_in_flight_violations(source):
 
 
 def test_no_use_of_in_flight_asm_lds_read_registers():
-    for source in ("attnfused.hip", "salevel.hip"):
+    for source in ("attnfused.hip", "salevel.hip", "outproj.hip"):
         reads, bad = _lds_in_flight_violations(source)
         assert reads > 0, source
         assert not bad, f"{source}: registers of asm LDS reads touched before their counted wait: " \
