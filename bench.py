@@ -309,7 +309,7 @@ def main():
         # (1b) every dense matrix-core entry point together (no sparse vector-ALU passes in the sum)
         dense_names = ("pzn_linear_fwd_f32", "pzn_linear_dgrad_f32", "pzn_linear_wgrad_f32", "pzn_linear_maxpool_fwd_f32",
                        "pzn_sharedmlp_max_fwd_f32", "pzn_attn_fwd_f32", "pzn_attn_bwd_f32", "pzn_attn_block_fwd_f32",
-                       "pzn_attn_block_bwd_f32", "pzn_sa_level_fwd_f32", "pzn_sa_level_fwd_ws_f32", "pzn_attn_fused_proj", "pzn_attn_fused_fwd",
+                       "pzn_attn_block_bwd_f32", "pzn_sa_level_fwd_f32", "pzn_sa_level_fwd_ws_f32", "pzn_outproj_maxpts_fwd_f32", "pzn_attn_fused_proj", "pzn_attn_fused_fwd",
                        "pzn_attn_fused_bwd_q", "pzn_attn_fused_bwd_k", "pzn_attn_fused_wgrads", "pzn_linear_slice_fwd_f32")
         d_ms = sum(kern.get(k, (0, 0.0))[1] for k in dense_names) / prof_steps
         d_fl = sum(kern_flops.get(k, 0) for k in dense_names) / prof_steps
