@@ -98,6 +98,8 @@ SIGNATURES = {
     "pzn_sa_level_fwd_ws_f32": (_c_i, [_c_f] * 5 + [_c_i] * 5 + [_c_f] * 4),
     "pzn_sa_level_fwd_workspace_bytes": (_c_sz, [_c_i, _c_i]),
     "pzn_outproj_maxpts_workspace_bytes": (_c_sz, [_c_i] * 4),
+    "pzn_cloud_bias_relu_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f]),
+    "pzn_cloud_gated_colsum_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_outproj_maxpts_fwd_f32": (_c_i, [_PP, _c_i, _c_f, _c_f] + [_c_i] * 4 + [_c_f] * 5),
     "pzn_sa_level_bwd_f32": (_c_i, [_c_f] * 8 + [_c_i] * 6 + [_c_f] * 5 + [_c_i, _c_f]),
     "pzn_sa_point_l1_fwd_f32": (_c_i, [_c_f] * 6 + [_c_i] * 5 + [_c_f, _c_f]),

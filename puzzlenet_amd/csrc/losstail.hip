@@ -284,6 +284,45 @@ __global__ __launch_bounds__(256) void avg4_kernel(const float4* __restrict__ a,
   }
 }
 
+// ------------------------------------------------------------------------------------ per-cloud bias + ReLU
+// The first layer of the boundary heads (model5_b.py:745-752) is Linear(cat([g.repeat(1,N,1), x], -1)): its product splits
+// into x W[:,Cg:]^T per point and (g W[:,:Cg]^T + b) per CLOUD.  y[b,n,:] = relu(y[b,n,:] + cb[b,:]) in place, and for
+// the backward the per-cloud column sums of the gated gradient: dcb[b,c] = sum_n (y[b,n,c] > 0 ? dy[b,n,c] : 0).
+__global__ __launch_bounds__(256) void cloud_bias_relu_kernel(float4* __restrict__ y, const float4* __restrict__ cb, long n4,
+                                                              int c4, long per_cloud4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 b = cb[(i / per_cloud4) * c4 + (i % c4)];
+    float4 v = y[i];
+    v.x = fmaxf(v.x + b.x, 0.f), v.y = fmaxf(v.y + b.y, 0.f), v.z = fmaxf(v.z + b.z, 0.f), v.w = fmaxf(v.w + b.w, 0.f);
+    y[i] = v;
+  }
+}
+
+// grid (chunks, B); block 256 = 16 column quads x 16 row lanes (C = 64) ... generally c4 column quads x 256 / c4 row lanes;
+// partial sums meet in LDS, one atomic add per column and workgroup (dcb zeroed by the host wrapper)
+__global__ __launch_bounds__(256) void cloud_gated_colsum_kernel(const float4* __restrict__ dy, const float4* __restrict__ y,
+                                                                 int N, int c4, float* __restrict__ dcb) {
+  __shared__ float4 part[256];
+  const int b = blockIdx.y, q = threadIdx.x % c4, rl = threadIdx.x / c4, nrl = 256 / c4;
+  const long base = (long)b * N * c4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rl < nrl)
+    for (int n = blockIdx.x * nrl + rl; n < N; n += gridDim.x * nrl) {
+      const float4 g = dy[base + (long)n * c4 + q], v = y[base + (long)n * c4 + q];
+      s.x += v.x > 0.f ? g.x : 0.f, s.y += v.y > 0.f ? g.y : 0.f, s.z += v.z > 0.f ? g.z : 0.f, s.w += v.w > 0.f ? g.w : 0.f;
+    }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0) {
+    for (int j = 1; j < nrl; ++j) {
+      const float4 o = part[j * c4 + q];
+      s.x += o.x, s.y += o.y, s.z += o.z, s.w += o.w;
+    }
+    float* d = dcb + ((long)b * c4 + q) * 4;
+    atomicAdd(d, s.x), atomicAdd(d + 1, s.y), atomicAdd(d + 2, s.z), atomicAdd(d + 3, s.w);
+  }
+}
+
 // ------------------------------------------------------------------------------------ column mean + argmax
 // a [B, R, C] -> mean[b, c] = (sum_r a[b, r, c]) / R;  arg[b] = first index of the largest mean.  Two launches so that
 // the 16.8 MB of a [64,256,256] map are read by 8 workgroups per cloud instead of one (108 -> ~15 us): partial column
@@ -406,6 +445,32 @@ PZN_EXPORT int pzn_avg4_f32(const float* a, const float* b, const float* c, cons
   hipLaunchKernelGGL(avg4_kernel, dim3((unsigned)grid_for((long)(n >> 2), 256, 4096)), dim3(256), 0, pzn_hip_stream(stream),
                      reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b), reinterpret_cast<const float4*>(c),
                      reinterpret_cast<const float4*>(d), (long)(n >> 2), reinterpret_cast<float4*>(out));
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+PZN_EXPORT int pzn_cloud_bias_relu_f32(float* y, const float* cb, int B, int N, int C, pzn_stream_t stream) {
+  PZN_CHECK_ARG(y && cb && B > 0 && N > 0 && C > 0);
+  if ((C & 3) || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(cb)) & 15)) return PZN_EUNSUPPORTED;
+  const long n4 = (long)B * N * (C / 4);
+  hipLaunchKernelGGL(cloud_bias_relu_kernel, dim3((unsigned)grid_for(n4, 256, 4096)), dim3(256), 0, pzn_hip_stream(stream),
+                     reinterpret_cast<float4*>(y), reinterpret_cast<const float4*>(cb), n4, C / 4, (long)N * (C / 4));
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+PZN_EXPORT int pzn_cloud_gated_colsum_f32(const float* dy, const float* y, int B, int N, int C, float* dcb,
+                                          pzn_stream_t stream) {
+  PZN_CHECK_ARG(dy && y && dcb && B > 0 && B <= 65535 && N > 0 && C > 0);
+  if ((C & 3) || C > 1024 || 256 % (C / 4) != 0 ||
+      ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dcb)) & 15))
+    return PZN_EUNSUPPORTED;
+  hipStream_t st = pzn_hip_stream(stream);
+  if (pzn_zero_async(dcb, (size_t)B * C, st) != PZN_OK) return PZN_ELAUNCH;
+  const int nrl = 256 / (C / 4);
+  int chunks = (N + nrl * 8 - 1) / (nrl * 8);      // >= 8 rows per row lane
+  if (chunks > 16) chunks = 16;
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(cloud_gated_colsum_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, st,
+                     reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(y), N, C / 4, dcb);
   PZN_RETURN_LAUNCH_STATUS();
 }
 

@@ -253,6 +253,18 @@ def _run_seq(seq, x):
     return x
 
 
+def _run_seq_cat_global(seq, x, g):
+    """_run_seq on cat([g.repeat(1, N, 1), x], -1) with the first Linear + ReLU split into a per-point and a per-cloud part."""
+    mods = list(seq)
+    if not (len(mods) >= 2 and isinstance(mods[1], nn.ReLU)):
+        return _run_seq(seq, torch.cat([g.expand(-1, x.shape[1], -1), x], dim=-1))
+    y = ops.cat_global_linear_relu(x, g, mods[0].weight, mods[0].bias)
+    return _run_seq(mods[2:], y)
+
+
+_HEAD_SPLIT = os.environ.get("PZN_HEAD_SPLIT", "1") != "0"     # tuning aid: 0 = repeat + cat + Linear as the reference composes it
+
+
 class TouchedRegraster(_Base):
     """model5_b.py:519-1519 (live path only)."""
 
@@ -363,12 +375,18 @@ class TouchedRegraster(_Base):
         non_sg_fmrpc = _run_seq(self.MLPLocalPreRpc, non_sg_fmrpc)                  # :739
         # :741 — the reference takes the max of non_sg_fmrpc for BOTH globals (its bug, kept)
         g_max = ops.max_over_points(non_sg_fmrpc).unsqueeze(1)      # one reduction serves both (identical) globals
-        non_sg_ffpc_global = g_max.expand(-1, N, -1)      # (:745-746 repeat(1, N, 1): the concat below reads the broadcast view)
-        non_sg_fmrpc_global = non_sg_ffpc_global
-        ffpc_feature4seg = torch.cat([non_sg_fmrpc_global, non_sg_ffpc], dim=-1)    # :748
-        fmrpc_feature4seg = torch.cat([non_sg_ffpc_global, non_sg_fmrpc], dim=-1)   # :749
-        de_fpcb = _run_seq(self.MLPFpcb, ffpc_feature4seg).permute(0, 2, 1)         # :751-752
-        de_mrpcb = _run_seq(self.MLPRpcb, fmrpc_feature4seg).permute(0, 2, 1)       # :753-754
+        if _HEAD_SPLIT and non_sg_ffpc.is_cuda:
+            # :745-752 without the repeat and the concatenation: the first layer of a head = a per-point product on the
+            # local features + a per-cloud bias from the global one (ops._CatGlobalLinearRelu)
+            de_fpcb = _run_seq_cat_global(self.MLPFpcb, non_sg_ffpc, g_max).permute(0, 2, 1)      # :748, :751-752
+            de_mrpcb = _run_seq_cat_global(self.MLPRpcb, non_sg_fmrpc, g_max).permute(0, 2, 1)    # :749, :753-754
+        else:
+            non_sg_ffpc_global = g_max.expand(-1, N, -1)      # (:745-746 repeat(1, N, 1): the concat below reads the broadcast view)
+            non_sg_fmrpc_global = non_sg_ffpc_global
+            ffpc_feature4seg = torch.cat([non_sg_fmrpc_global, non_sg_ffpc], dim=-1)    # :748
+            fmrpc_feature4seg = torch.cat([non_sg_ffpc_global, non_sg_fmrpc], dim=-1)   # :749
+            de_fpcb = _run_seq(self.MLPFpcb, ffpc_feature4seg).permute(0, 2, 1)         # :751-752
+            de_mrpcb = _run_seq(self.MLPRpcb, fmrpc_feature4seg).permute(0, 2, 1)       # :753-754
         if not need:
             return out, out, de_fpcb, de_mrpcb
         return out, [0], ffpcs[1], ffpcs[2], fmrpcs[1], fmrpcs[2], de_fpcb, de_mrpcb

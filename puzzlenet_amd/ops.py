@@ -651,6 +651,70 @@ def linear(x, weight, bias=None, relu=False):
     return _Linear.apply(x, weight, bias, relu)
 
 
+class _CatGlobalLinearRelu(torch.autograd.Function):
+    """relu(Linear(cat([g.repeat(1, N, 1), x], -1))) without the concatenation (model5_b.py:745-752, first layer of the
+    boundary heads): the product splits into x W[:, Cg:]^T per point and g W[:, :Cg]^T + b per CLOUD; the per-cloud part
+    is a [B, Cout] bias added (with the ReLU) by pzn_cloud_bias_relu_f32.  Backward: the gated gradient goes through the
+    point part's two products (the kernels take the ReLU mask), its per-cloud column sums (pzn_cloud_gated_colsum_f32)
+    through the global part's.  x[B,N,C], g[B,Cg] (or [B,1,Cg]), weight[Cout, Cg + C], bias[Cout]."""
+
+    @staticmethod
+    def forward(ctx, x, g, weight, bias):
+        x, g, weight, bias = _f32(x, "x"), _f32(g, "g"), _f32(weight, "weight"), _f32(bias, "bias")
+        B, N, C = x.shape
+        g2 = g.reshape(B, -1)
+        Cg = g2.shape[1]
+        Co = weight.shape[0]
+        if weight.shape[1] != Cg + C:
+            raise _lib.PznError(f"cat_global_linear_relu: weight{tuple(weight.shape)} vs {Cg} + {C} input columns")
+        dev = x.device
+        w_g, w_x = weight[:, :Cg].contiguous(), weight[:, Cg:].contiguous()
+        x2 = x.reshape(B * N, C)
+        y = torch.empty((B * N, Co), dtype=torch.float32, device=dev)
+        cb = torch.empty((B, Co), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _stream()
+            _call("pzn_linear_fwd_f32", _p(g2), _p(w_g), _p(bias), B, Cg, Co, 0, _p(cb), st, flops=2 * B * Cg * Co)
+            _call("pzn_linear_fwd_f32", _p(x2), _p(w_x), None, B * N, C, Co, 0, _p(y), st, flops=2 * B * N * C * Co)
+            _call("pzn_cloud_bias_relu_f32", _p(y), _p(cb), B, N, Co, st)
+        ctx.save_for_backward(x2, g2, w_g, w_x, y)
+        ctx.dims = (B, N, C, Cg, Co)
+        ctx.g_shape = g.shape
+        return y.view(B, N, Co)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g2, w_g, w_x, y = ctx.saved_tensors
+        B, N, C, Cg, Co = ctx.dims
+        dev = y.device
+        dy = _f32(dy, "dy").reshape(B * N, Co)
+        mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        dx = dg = dW = db = None
+        with torch.cuda.device(dev):
+            st = _stream()
+            dcb = mk(B, Co)
+            _call("pzn_cloud_gated_colsum_f32", _p(dy), _p(y), B, N, Co, _p(dcb), st)
+            if ctx.needs_input_grad[0]:
+                dx = mk(B * N, C)
+                _call("pzn_linear_dgrad_f32", _p(dy), _p(y), _p(w_x), B * N, C, Co, None, _p(dx), st, flops=2 * B * N * C * Co)
+                dx = dx.view(B, N, C)
+            if ctx.needs_input_grad[1]:
+                dg = mk(B, Cg)
+                _call("pzn_linear_dgrad_f32", _p(dcb), None, _p(w_g), B, Cg, Co, None, _p(dg), st, flops=2 * B * Cg * Co)
+                dg = dg.view(ctx.g_shape)
+            if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+                dWx, dWg, db = mk(Co, C), mk(Co, Cg), mk(Co)
+                _call("pzn_linear_wgrad_f32", _p(dy), _p(y), _p(x2), B * N, C, Co, _p(dWx), _p(db), 0, st,
+                      flops=2 * B * N * C * Co)                                   # db = column sums of the gated gradient
+                _call("pzn_linear_wgrad_f32", _p(dcb), None, _p(g2), B, Cg, Co, _p(dWg), None, 0, st, flops=2 * B * Cg * Co)
+                dW = torch.cat([dWg, dWx], dim=1)
+        return dx, dg, dW, db
+
+
+def cat_global_linear_relu(x, g, weight, bias):
+    return _CatGlobalLinearRelu.apply(x, g, weight, bias)
+
+
 class _SharedMlpMax(torch.autograd.Function):
     """relu(x W1^T + b1) -> relu(. W2^T + b2) -> max over the K=32 axis (model5_b.py:452-454, 459-461)."""
 

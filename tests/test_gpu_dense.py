@@ -623,3 +623,29 @@ def test_attention_chain_fused_vs_float64(dev, nprob, use):
             assert float((a_.double() - b_).abs().max()) < 2e-4 * max(float(b_.abs().max()), 0.25), i
             if float(b_.norm()) > 1e-3:
                 assert _rel(a_.double(), b_) < 1e-4, i
+
+
+@pytest.mark.parametrize("B,N", [(3, 100), (8, 2048)])
+def test_cat_global_linear_relu_vs_torch(dev, B, N):
+    """First layer of the boundary heads (model5_b.py:745-752) without the repeat + concatenation: relu(Linear(cat([g.repeat,
+    x], -1))) as a per-point product + a per-cloud bias, forward and every gradient against the float64 composition."""
+    from puzzlenet_amd import ops
+    C, Cg, Co = 64, 64, 64
+    g_ = torch.Generator().manual_seed(11)
+    x = torch.randn(B, N, C, generator=g_)
+    gl = torch.randn(B, 1, Cg, generator=g_)
+    w = torch.randn(Co, Cg + C, generator=g_) / (Cg + C) ** 0.5
+    b = 0.1 * torch.randn(Co, generator=g_)
+    go = torch.randn(B, N, Co, generator=g_)
+    ts = [t.to(dev).requires_grad_(True) for t in (x, gl, w, b)]
+    y = ops.cat_global_linear_relu(*ts)
+    (y * go.to(dev)).sum().backward()
+    td = [t.double().requires_grad_(True) for t in (x, gl, w, b)]
+    ref = torch.relu(torch.nn.functional.linear(torch.cat([td[1].expand(-1, N, -1), td[0]], dim=-1), td[2], td[3]))
+    (ref * go.double()).sum().backward()
+
+    def rel(a, r):
+        return float((a.detach().cpu().double() - r).norm() / (r.norm() + 1e-30))
+    assert rel(y, ref.detach()) < 1e-5
+    for name, t, r in zip(("dx", "dg", "dW", "db"), ts, td):
+        assert rel(t.grad, r.grad) < 1e-4, name
