@@ -81,6 +81,10 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_level_stream_kernel(SaArg
   Ring ring{lds, wave, lane, SLAB};
   ring.nw = SA_WAVES;
   const int per_round = gridDim.x * SA_WAVES;
+  // XCD-aware: workgroups bid, bid + 8, ... share an XCD; consecutive LOGICAL ids (= consecutive groups = whole clouds) go
+  // to the same XCD, so a cloud's per-point table is gathered through ONE L2 instead of all eight (PMC: the kernel's
+  // fetch traffic was 4x the tables it reads)
+  const int lb = logical_block((int)blockIdx.x, (int)gridDim.x);
   const int rounds = (a.G + per_round - 1) / per_round;
   // the slab sequence is the same every round: slab c of the kernel = slab c % NSL of the weights, ring slot c % 3.
   // The slab number is a compile-time constant at every call site (a run-time c % NSL made the compiler precompute all
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_level_stream_kernel(SaArg
   // loads per k-step, issued one step ahead of the step that splits them).  No dependent index -> address -> row round
   // trip stands at the head of a round.
   auto group_of = [&](int rd) {
-    const int g = rd * per_round + blockIdx.x * SA_WAVES + wave;
+    const int g = rd * per_round + lb * SA_WAVES + wave;
     return g < a.G ? g : a.G - 1;                                   // (idle wavefronts of the last round redo the last group)
   };
   auto prow_of = [&](int g, int j) { return a.Pp + ((size_t)(g / a.S) * a.N + j) * C1 + 8 * h; };   // lane's row, its k half
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 2) void sa_level_stream_kernel(SaArg
   bool live_prev = false;
   for (int rd = 0; rd < rounds; ++rd) {
     const int g = g_cur;
-    const bool live = rd * per_round + (int)blockIdx.x * SA_WAVES + wave < a.G;
+    const bool live = rd * per_round + lb * SA_WAVES + wave < a.G;
     prow_n = prow_of(g_next, j_next);
     const int g_next2 = group_of(rd + 2 < rounds ? rd + 2 : rounds - 1);
     // (asm for the same reason as the row loads: the step waits of this round cover it; a compiler-managed load is
