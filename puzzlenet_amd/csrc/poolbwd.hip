@@ -144,20 +144,28 @@ __global__ __launch_bounds__(NWV * 64) void pool_wgrad_kernel(PoolBwdArgs p) {
       acc[c] += gs * hr;                                                            \
     }                                                                               \
   } while (0)
-  const int gs_ = gridDim.x;
-  if (regen) {
-    PB_IDX((int)blockIdx.x, ja0, ja1);
-    PB_IDX((int)blockIdx.x + gs_, jb0, jb1);
+  // XCD-aware walk (round 3): workgroups x, x + 8, ... share an XCD; XCD x takes the contiguous eighth [x Gx, (x+1) Gx) of
+  // the groups - whole clouds - so that a cloud's per-point table is gathered through ONE L2 (PMC: the strided walk fetched
+  // 290-400 MB per launch for tables of 34-67 MB)
+  int g_first = blockIdx.x, gs_ = gridDim.x, g_end = p.G;
+  if ((gridDim.x & 7) == 0) {
+    const int xcd = blockIdx.x & 7, gx8 = (p.G + 7) >> 3;
+    g_first = xcd * gx8 + (int)(blockIdx.x >> 3), gs_ = gridDim.x >> 3;
+    g_end = (xcd + 1) * gx8 < p.G ? (xcd + 1) * gx8 : p.G;
   }
-  PB_ISSUE((int)blockIdx.x, pa0, pa1, qa, ava, gva, ja0, ja1);
-  PB_ISSUE((int)blockIdx.x + gs_, pb0, pb1, qb, avb, gvb, jb0, jb1);
   if (regen) {
-    PB_IDX((int)blockIdx.x + 2 * gs_, ja0, ja1);
-    PB_IDX((int)blockIdx.x + 3 * gs_, jb0, jb1);
+    PB_IDX(g_first, ja0, ja1);
+    PB_IDX(g_first + gs_, jb0, jb1);
   }
-  for (int g = blockIdx.x; g < p.G; g += 2 * gs_) {
+  PB_ISSUE(g_first, pa0, pa1, qa, ava, gva, ja0, ja1);
+  PB_ISSUE(g_first + gs_, pb0, pb1, qb, avb, gvb, jb0, jb1);
+  if (regen) {
+    PB_IDX(g_first + 2 * gs_, ja0, ja1);
+    PB_IDX(g_first + 3 * gs_, jb0, jb1);
+  }
+  for (int g = g_first; g < g_end; g += 2 * gs_) {
     PB_GROUP(0, pa0, pa1, qa, ava, gva, ja0, ja1, g + 2 * gs_);
-    if (g + gs_ >= p.G) break;
+    if (g + gs_ >= g_end) break;
     PB_GROUP(1, pb0, pb1, qb, avb, gvb, jb0, jb1, g + 3 * gs_);
   }
 #undef PB_GROUP
@@ -193,7 +201,13 @@ __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
   }
   __syncthreads();  // the only barrier: from here on every wavefront walks its own groups
 
-  const int gw = blockIdx.x * (PD_T / 64) + wave, nw = gridDim.x * (PD_T / 64);
+  // XCD-aware walk (see pool_wgrad_kernel): the wavefronts of XCD x stride through the x-th contiguous eighth of the groups
+  int gw = blockIdx.x * (PD_T / 64) + wave, nw = gridDim.x * (PD_T / 64), g_end = p.G;
+  if ((gridDim.x & 7) == 0) {
+    const int xcd = blockIdx.x & 7, gx8 = (p.G + 7) >> 3;
+    gw = xcd * gx8 + (int)(blockIdx.x >> 3) * (PD_T / 64) + wave, nw = (int)(gridDim.x >> 3) * (PD_T / 64);
+    g_end = (xcd + 1) * gx8 < p.G ? (xcd + 1) * gx8 : p.G;
+  }
   const bool qform = p.gQ != nullptr;      // h = relu(P'[idx] + Q[g]) (pzn_sa_prep_f32); else the round-1 expression
   float gwx0 = 0.f, gwy0 = 0.f, gwz0 = 0.f, gbb0 = 0.f, gwx1 = 0.f, gwy1 = 0.f, gwz1 = 0.f, gbb1 = 0.f;
   if (p.gP && !qform) {  // first-layer xyz weights and bias of this lane's two columns
@@ -217,14 +231,14 @@ __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
       gv_n[q] = go > 0.f ? gd : 0.f;                                \
     }                                                               \
   } while (0)
-  if (gw < p.G) PD_PREFETCH(gw);
+  if (gw < g_end) PD_PREFETCH(gw);
 
-  for (int g = gw; g < p.G; g += nw) {
+  for (int g = gw; g < g_end; g += nw) {
     int av[NQ];
     float gv[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) av[q] = av_n[q], gv[q] = gv_n[q];
-    if (g + nw < p.G) PD_PREFETCH(g + nw);
+    if (g + nw < g_end) PD_PREFETCH(g + nw);
     const size_t row0 = ((size_t)g * 32) * p.C1 + col0 + 2 * lane;
     // regenerated gate: lane l (mod 32) fetches row l's point (and centre offset) once per group
     int gprow = 0;

@@ -649,3 +649,84 @@ def test_cat_global_linear_relu_vs_torch(dev, B, N):
     assert rel(y, ref.detach()) < 1e-5
     for name, t, r in zip(("dx", "dg", "dW", "db"), ts, td):
         assert rel(t.grad, r.grad) < 1e-4, name
+
+
+@pytest.mark.parametrize("B,need_out", [(2, True), (5, False), (16, True)])
+def test_outproj_maxpts_vs_float64(dev, B, need_out):
+    """csrc/outproj.hip through the C ABI: cat(x_0..x_4) W^T + b and the max over the 256 points (model5_b.py:466-475) against
+    float64; B = 5 takes the plain block order (4 B workgroups not a multiple of 8), out = NULL writes only the maximum;
+    two identical points in every cloud pin the tie rule (the lower point wins, as torch.max)."""
+    from puzzlenet_amd import _lib, ops
+    L, E, Nout = 256, 256, 1024
+    M = B * L
+    g = torch.Generator().manual_seed(21 + B)
+    xs = [torch.randn(B, L, E, generator=g) for _ in range(5)]
+    for x in xs:
+        x[:, 200] = x[:, 37]                     # points 37 and 200 of every cloud coincide in all five slices
+    w = torch.randn(Nout, 5 * E, generator=g) / (5 * E) ** 0.5
+    b = 0.1 * torch.randn(Nout, generator=g)
+    xd = [x.reshape(M, E).contiguous().to(dev) for x in xs]
+    wd, bd = w.to(dev), b.to(dev)
+    lib = _lib.load()
+    ws = torch.empty(lib.pzn_outproj_maxpts_workspace_bytes(L, E, 5, Nout), dtype=torch.uint8, device=dev)
+    assert ws.numel() > 0
+    out = torch.full((M, Nout), float("nan"), device=dev) if need_out else None
+    fmax = torch.empty(B, Nout, device=dev)
+    arg = torch.empty(B, Nout, dtype=torch.int32, device=dev)
+    _lib.call("pzn_outproj_maxpts_fwd_f32", ops._ptrs(xd), 5, wd.data_ptr(), bd.data_ptr(), B, L, E, Nout,
+              out.data_ptr() if need_out else None, fmax.data_ptr(), arg.data_ptr(), ws.data_ptr(),
+              torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = torch.cat([x.double() for x in xs], dim=-1) @ w.double().T + b.double()          # [B, L, Nout]
+    rmax, rarg = ref.max(dim=1)
+    if need_out:
+        assert _rel(out.cpu().view(B, L, Nout), ref) < 2e-6
+    assert float((fmax.cpu().double() - rmax).abs().max()) < 1e-5 * float(rmax.abs().max())
+    a = arg.cpu().long()
+    assert int(a.min()) >= 0 and int(a.max()) < L
+    # the kernel's arg-max row reaches the maximum to rounding, and never names point 200 (its twin 37 is lower)
+    picked = ref.gather(1, a.unsqueeze(1)).squeeze(1)
+    assert float((picked - rmax).abs().max()) < 1e-5 * float(rmax.abs().max())
+    assert int((a == 200).sum()) == 0
+    assert float((a == rarg).float().mean()) > 0.999
+
+
+@pytest.mark.parametrize("B,N,S,C", [(3, 300, 100, 128), (5, 512, 500, 256), (1, 64, 8, 256)])
+def test_sa_level_streamed_vs_float64(dev, B, N, S, C):
+    """csrc/salevel.hip through pzn_sa_level_fwd_ws_f32 on ragged group counts (G = 300: one round with idle wavefronts;
+    2500: two rounds, the second partly empty; 8: the minimum): max and arg-max over the 32 generated rows against float64
+    and against the weight-stationary kernel."""
+    from puzzlenet_amd import _lib
+    g = torch.Generator().manual_seed(C + S)
+    P = torch.randn(B * N, C, generator=g).to(dev)
+    Q = (0.3 * torch.randn(B * S, C, generator=g)).to(dev)
+    idx = torch.randint(0, N, (B, S, 32), generator=g).to(dev)
+    w2 = (torch.randn(C, C, generator=g) / C ** 0.5).to(dev)
+    b2 = (0.1 * torch.randn(C, generator=g)).to(dev)
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    R = B * S
+    ws = torch.empty(lib.pzn_sa_level_fwd_workspace_bytes(C, C), dtype=torch.uint8, device=dev)
+    assert ws.numel() == C * C * 6
+    res = []
+    for use_ws in (True, False):
+        out = torch.full((R, C), float("nan"), device=dev)
+        arg = torch.full((R, C), -1, dtype=torch.int32, device=dev)
+        if use_ws:
+            _lib.call("pzn_sa_level_fwd_ws_f32", P.data_ptr(), Q.data_ptr(), idx.data_ptr(), w2.data_ptr(), b2.data_ptr(), B, N, S,
+                      C, C, out.data_ptr(), arg.data_ptr(), ws.data_ptr(), st)
+        else:
+            _lib.call("pzn_sa_level_fwd_f32", P.data_ptr(), Q.data_ptr(), idx.data_ptr(), w2.data_ptr(), b2.data_ptr(), B, N, S, C,
+                      C, out.data_ptr(), arg.data_ptr(), st)
+        res.append((out, arg))
+    torch.cuda.synchronize()
+    (o1, a1), (o0, a0) = res
+    rows = torch.relu(P.double().view(B, N, C)[torch.arange(B, device=dev)[:, None, None], idx] + Q.double().view(B, S, 1, C))
+    ref = torch.relu(rows @ w2.double().T + b2.double())                 # [B, S, 32, C]
+    rmax = ref.max(dim=2).values.view(R, C)
+    assert bool(torch.isfinite(o1).all()) and int(a1.min()) >= 0 and int(a1.max()) < 32
+    assert float((o1.double() - rmax).abs().max()) < 2e-6 * max(1.0, float(rmax.abs().max()))
+    assert float((o1 - o0).abs().max()) < 1e-5
+    assert float((a1 != a0).float().mean()) < 1e-4
+    picked = ref.view(R, 32, C).gather(1, a1.long().unsqueeze(1)).squeeze(1)
+    assert float((picked - rmax).abs().max()) < 1e-5
