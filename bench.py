@@ -367,14 +367,16 @@ def main():
         gf1, gb1 = gather_bytes(N, 512, 128)
         gf2, gb2 = gather_bytes(512, 256, 256)
         n_gf, ms_gf = per_step("pzn_sa_point_l1_fwd_f32")
-        n_gb, ms_gb = per_step("pzn_sa_point_l1_bwd_f32")
+        n_gb, ms_gb = per_step("pzn_sa_point_l1_bwd_rm_f32" if "pzn_sa_point_l1_bwd_rm_f32" in kern else "pzn_sa_point_l1_bwd_f32")
         g_bytes = 2 * B * ((gf1 + gf2 if n_gf else 0) + (gb1 + gb2 if n_gb else 0))
         g_ms = ms_gf + ms_gb
         g_ach = g_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
         g_traffic, g_src = pmc_traffic("sa_gather_stage_bytes_per_step", B, N)
         roofline_sa_gather = {
-            "bound": "hbm", "kernel": "sa_point_l1_bwd_kernel (pzn_sa_point_l1_bwd_f32: the per-point sums of dh over inverse neighbour "
-                                      "lists)" + (" + sa_point_l1_fwd_kernel (rows written: PZN_SA_FUSED=0)" if n_gf else
+            "bound": "hbm", "kernel": "sa_point_l1_bwd_kernel (pzn_sa_point_l1_bwd[_rm]_f32: the per-point sums of dh over inverse neighbour "
+                                      "lists; with the row mask (_rm, default) rows that won no channel - exactly zero, about half of level 1 and "
+                                      "a third of level 2 - are not read, so `achieved`, which prices the DENSE dh, exceeds what the HBM "
+                                      "delivered: `traffic` has the counted bytes)" + (" + sa_point_l1_fwd_kernel (rows written: PZN_SA_FUSED=0)" if n_gf else
                                                   "; the forward writes no rows any more (generated inside the matrix-core kernel)"),
             "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g_ach / HBM_PEAK_GBS,
             "traffic": g_traffic, "traffic_source": g_src,
@@ -411,7 +413,7 @@ def main():
         #      one non-zero per (group, channel) = one row axpy of length C1 in each pass.  Two ceilings: the bytes it must
         #      move (dh[R*32, C1] written once, gate rows P'[idx] re-read from L2 not counted) and the vector lanes it must
         #      issue (hits x C1 multiply-adds per pass, one lane-slot each, against the chip's vector issue rate).
-        n_pb, ms_pb = per_step("pzn_sa_level_bwd_f32")
+        n_pb, ms_pb = per_step("pzn_sa_level_bwd_rm_f32" if "pzn_sa_level_bwd_rm_f32" in kern else "pzn_sa_level_bwd_f32")
         lvl = ((B * 512, 128, 128), (B * 256, 256, 256))              # (groups R, C1, C2) of the two levels
         pb_bytes = 2 * sum(4.0 * R_ * 32 * C1_ + 4.0 * R_ * C2_ * 2 + 4.0 * C1_ * C2_ for R_, C1_, C2_ in lvl)
         pb_fma = 2 * sum(2.0 * R_ * C2_ * C1_ for R_, C1_, C2_ in lvl)         # input-gradient + weight-gradient pass

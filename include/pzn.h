@@ -311,6 +311,9 @@ int pzn_knn_inverse_lists(const int64_t* idx, int B, int N, int S, int K, int32_
 int pzn_sa_point_l1_bwd_f32(const float* dh, const float* xyz, const float* new_xyz,
                             const int32_t* rows, const int32_t* pts, int B, int N, int S, int D,
                             int C1, float* dP, float* dW1, float* db1, pzn_stream_t stream);
+int pzn_sa_point_l1_bwd_rm_f32(const float* dh, const float* xyz, const float* new_xyz, const int32_t* rows,
+                               const int32_t* pts, int B, int N, int S, int D, int C1, float* dP, float* dW1, float* db1,
+                               const uint32_t* rowmask, pzn_stream_t stream);
 /* Second (pooled) layer backward alone (model5_b.py:453-454 / :460-461): dh[R*32,C1] = ReLU-masked (by h)
  * gradient of the first layer's output, dW2[C2,C1], db2[C2] (overwritten, or added to when accumulate). */
 int pzn_pooled_layer_bwd_f32(const float* dout, const int32_t* argmax, const float* out,
@@ -344,6 +347,13 @@ int pzn_sa_level_bwd_f32(const float* dout, const int32_t* argmax, const float* 
                          const float* Pp, const float* Q, const int64_t* idx, const float* new_xyz, int B, int N,
                          int S, int D, int C1, int C2, float* dh, float* dW2, float* db2, float* dW1, float* db1,
                          int accumulate, pzn_stream_t stream);
+/* The same with a row mask: about half the rows of a level-1 group (a third at level 2) win no channel and their dh row is
+ * exactly zero.  rowmask[B*S] (written): bit k of word g = row (g, k) is non-zero; row PAIRS (2i, 2i+1) without a bit are
+ * not written at all, and pzn_sa_point_l1_bwd_rm_f32 reads only rows whose bit is set. */
+int pzn_sa_level_bwd_rm_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
+                            const float* Pp, const float* Q, const int64_t* idx, const float* new_xyz, int B, int N,
+                            int S, int D, int C1, int C2, float* dh, float* dW2, float* db2, float* dW1, float* db1,
+                            int accumulate, uint32_t* rowmask, pzn_stream_t stream);
 
 /* relu(BatchNorm1d(num_points)(x)) of the per-point feature MLP (model5_b.py:424, :447-448): x[B,N,C], the BN
  * "channel" axis is the POINT index, statistics over the B*C values of a point.  training != 0: batch statistics

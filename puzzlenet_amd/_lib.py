@@ -102,9 +102,11 @@ SIGNATURES = {
     "pzn_cloud_gated_colsum_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_outproj_maxpts_fwd_f32": (_c_i, [_PP, _c_i, _c_f, _c_f] + [_c_i] * 4 + [_c_f] * 5),
     "pzn_sa_level_bwd_f32": (_c_i, [_c_f] * 8 + [_c_i] * 6 + [_c_f] * 5 + [_c_i, _c_f]),
+    "pzn_sa_level_bwd_rm_f32": (_c_i, [_c_f] * 8 + [_c_i] * 6 + [_c_f] * 5 + [_c_i, _c_f, _c_f]),
     "pzn_sa_point_l1_fwd_f32": (_c_i, [_c_f] * 6 + [_c_i] * 5 + [_c_f, _c_f]),
     "pzn_knn_inverse_lists": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f]),
     "pzn_sa_point_l1_bwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 5 + [_c_f] * 4),
+    "pzn_sa_point_l1_bwd_rm_f32": (_c_i, [_c_f] * 5 + [_c_i] * 5 + [_c_f] * 5),
     "pzn_sa_pooled_layer_bwd_f32": (_c_i, [_c_f] * 11 + [_c_i] * 6 + [_c_f] * 3 + [_c_i, _c_f]),
     "pzn_pooled_layer_bwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 3 + [_c_f] * 3 + [_c_i, _c_f]),
     "pzn_sa_mlp_max_bwd_scatter_f32": (_c_i, [_c_f] * 8 + [_c_i] * 6 + [_c_f] * 7 + [_c_i, _c_f]),

@@ -1336,10 +1336,34 @@ PZN_EXPORT int pzn_sa_level_fwd_ws_f32(const float* Pp, const float* Q, const in
 // rows: written, the per-point sum pzn_sa_point_l1_bwd_f32 reads it), dW2, db2 (overwritten, or added to when
 // accumulate), and what flows through Q: dW1[:, 0:3] -= dq^T new_xyz, db1 += column sums of dq (dq[g] = sum_k dh[g,k]);
 // dW1[C1, 3+D] and db1[C1] are ADDED to.  Both sparse passes regenerate the rows from Pp / Q / idx: h does not exist.
+static int sa_level_bwd(const float* dout, const int32_t* argmax, const float* out, const float* W2, const float* Pp,
+                        const float* Q, const int64_t* idx, const float* new_xyz, int B, int N, int S, int D, int C1, int C2,
+                        float* dh, float* dW2, float* db2, float* dW1, float* db1, int accumulate, uint32_t* rowmask,
+                        pzn_stream_t stream);
+
 PZN_EXPORT int pzn_sa_level_bwd_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
                                     const float* Pp, const float* Q, const int64_t* idx, const float* new_xyz, int B,
                                     int N, int S, int D, int C1, int C2, float* dh, float* dW2, float* db2, float* dW1,
                                     float* db1, int accumulate, pzn_stream_t stream) {
+  return sa_level_bwd(dout, argmax, out, W2, Pp, Q, idx, new_xyz, B, N, S, D, C1, C2, dh, dW2, db2, dW1, db1, accumulate,
+                      nullptr, stream);
+}
+
+// The same with a row mask (rowmask[B*S] words, written): bit k of word g = row (g, k) of dh is non-zero.  Rows whose pair
+// (2i, 2i+1) holds no non-zero row are NOT written; the reader (pzn_sa_point_l1_bwd_rm_f32) skips rows without their bit.
+PZN_EXPORT int pzn_sa_level_bwd_rm_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
+                                       const float* Pp, const float* Q, const int64_t* idx, const float* new_xyz, int B,
+                                       int N, int S, int D, int C1, int C2, float* dh, float* dW2, float* db2, float* dW1,
+                                       float* db1, int accumulate, uint32_t* rowmask, pzn_stream_t stream) {
+  PZN_CHECK_ARG(rowmask != nullptr);
+  return sa_level_bwd(dout, argmax, out, W2, Pp, Q, idx, new_xyz, B, N, S, D, C1, C2, dh, dW2, db2, dW1, db1, accumulate,
+                      rowmask, stream);
+}
+
+static int sa_level_bwd(const float* dout, const int32_t* argmax, const float* out, const float* W2, const float* Pp,
+                        const float* Q, const int64_t* idx, const float* new_xyz, int B, int N, int S, int D, int C1, int C2,
+                        float* dh, float* dW2, float* db2, float* dW1, float* db1, int accumulate, uint32_t* rowmask,
+                        pzn_stream_t stream) {
   PZN_CHECK_ARG(dout && argmax && out && W2 && Pp && Q && idx && new_xyz && dh && dW2 && db2 && dW1);
   PZN_CHECK_ARG(B > 0 && N > 0 && S > 0 && D >= 0 && C1 > 0 && C2 > 0 && (long)B * N < 2147483647L);
   if (!pzn_pool_bwd_supported(C1, C2, W2, nullptr, dh)) return PZN_EUNSUPPORTED;
@@ -1349,6 +1373,7 @@ PZN_EXPORT int pzn_sa_level_bwd_f32(const float* dout, const int32_t* argmax, co
     if (pzn_zero_async(db2, (size_t)C2, st) != PZN_OK) return PZN_ELAUNCH;
   }
   PznGateSource gs{Pp, idx, nullptr, new_xyz, nullptr, nullptr, 3 + D, N, S, Q, dW1, db1};
+  gs.rowmask = rowmask;
   return pzn_pool_bwd_sparse(dout, argmax, out, W2, nullptr, dh, dW2, db2, B * S, C1, C2, st, &gs);
 }
 

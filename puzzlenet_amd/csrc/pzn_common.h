@@ -92,6 +92,16 @@ __device__ __forceinline__ uint32_t wave_max_u32_dpp(uint32_t v) {
   o = xor_lane<32>(v), v = o > v ? o : v;
   return v;
 }
+// 64-lane OR of a dword
+__device__ __forceinline__ uint32_t wave_or_u32_dpp(uint32_t v) {
+  v |= xor_lane<1>(v);
+  v |= xor_lane<2>(v);
+  v |= xor_lane<4>(v);
+  v |= xor_lane<8>(v);
+  v |= xor_lane<16>(v);
+  v |= xor_lane<32>(v);
+  return v;
+}
 __device__ __forceinline__ uint32_t wave_min_u32_dpp(uint32_t v) {
   uint32_t o;
   o = xor_lane<1>(v), v = o < v ? o : v;

@@ -25,6 +25,8 @@ struct PznGateSource {
   const float* Q;
   float* dW1x;   // [C1, ldw] (columns 0..2 are added to)
   float* db1;    // [C1]
+  uint32_t* rowmask = nullptr;   // [G] or NULL: bit k of word g = row (g, k) of dh is non-zero; rows whose PAIR (2i, 2i+1) has no
+                                 // bit set are then NOT written (the reader skips rows without their bit)
 };
 int pzn_pool_bwd_sparse(const float* dout, const int32_t* argmax, const float* out, const float* W, const float* h,
                         float* dh, float* dW, float* db, int G, int C1, int C2, hipStream_t st, const PznGateSource* gs = nullptr);

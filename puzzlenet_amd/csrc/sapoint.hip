@@ -238,7 +238,8 @@ __global__ __launch_bounds__(SP_T) void sa_point_l1_bwd_kernel(const float* __re
                                                                const int32_t* __restrict__ pts, int N, int S,
                                                                long entries, float* __restrict__ dP,
                                                                float* __restrict__ dW1, int ldw,
-                                                               float* __restrict__ db1) {
+                                                               float* __restrict__ db1,
+                                                               const uint32_t* __restrict__ rowmask) {
   constexpr int C1 = 64 * V;
   __shared__ float red[SP_T / 64][4][C1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -251,11 +252,13 @@ __global__ __launch_bounds__(SP_T) void sa_point_l1_bwd_kernel(const float* __re
   for (long bt = gw; bt < nbatch; bt += nw) {
     const long e = bt * 64 + lane;
     int grow = 0, gp = -1;  // global row of dh, global point
+    int nz = 1;             // rowmask: rows without their bit are exactly zero and were not written (poolbwd.hip): not read
     float dx = 0.f, dy = 0.f, dz = 0.f;
     if (e < entries) {
       const long b = e / SK;
       const int rid = rows[e], pj = pts[e];
       grow = (int)(b * SK + rid);
+      if (rowmask) nz = (int)((rowmask[grow >> 5] >> (grow & 31)) & 1u);
       gp = (int)(b * N + pj);
       const float* q = xyz + (size_t)gp * 3;
       if (new_xyz) {
@@ -302,13 +305,25 @@ __global__ __launch_bounds__(SP_T) void sa_point_l1_bwd_kernel(const float* __re
     for (; r + G <= nr; r += G) {  // G dh rows in flight
       float g[G][V];
 #pragma unroll
-      for (int u = 0; u < G; ++u) load_vec_nt<V>(dhl + (size_t)__builtin_amdgcn_readlane(grow, r + u) * C1, g[u]);
+      for (int u = 0; u < G; ++u) {
+        if (__builtin_amdgcn_readlane(nz, r + u)) {      // wave-uniform
+          load_vec_nt<V>(dhl + (size_t)__builtin_amdgcn_readlane(grow, r + u) * C1, g[u]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < V; ++i) g[u][i] = 0.f;
+        }
+      }
 #pragma unroll
       for (int u = 0; u < G; ++u) take(g[u], r + u);
     }
     for (; r < nr; ++r) {
       float g0[V];
-      load_vec_nt<V>(dhl + (size_t)__builtin_amdgcn_readlane(grow, r) * C1, g0);
+      if (__builtin_amdgcn_readlane(nz, r)) {
+        load_vec_nt<V>(dhl + (size_t)__builtin_amdgcn_readlane(grow, r) * C1, g0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) g0[i] = 0.f;
+      }
       take(g0, r);
     }
     flush(cur);
@@ -469,9 +484,26 @@ PZN_EXPORT int pzn_knn_inverse_lists(const int64_t* idx, int B, int N, int S, in
   PZN_RETURN_LAUNCH_STATUS();
 }
 
+static int sa_point_l1_bwd(const float* dh, const float* xyz, const float* new_xyz, const int32_t* rows,
+                           const int32_t* pts, int B, int N, int S, int D, int C1, float* dP, float* dW1,
+                           float* db1, const uint32_t* rowmask, pzn_stream_t stream);
+
 PZN_EXPORT int pzn_sa_point_l1_bwd_f32(const float* dh, const float* xyz, const float* new_xyz, const int32_t* rows,
                                        const int32_t* pts, int B, int N, int S, int D, int C1, float* dP, float* dW1,
                                        float* db1, pzn_stream_t stream) {
+  return sa_point_l1_bwd(dh, xyz, new_xyz, rows, pts, B, N, S, D, C1, dP, dW1, db1, nullptr, stream);
+}
+
+// the same with the row mask of pzn_sa_level_bwd_rm_f32: rows of dh without their bit are not read
+PZN_EXPORT int pzn_sa_point_l1_bwd_rm_f32(const float* dh, const float* xyz, const float* new_xyz, const int32_t* rows,
+                                          const int32_t* pts, int B, int N, int S, int D, int C1, float* dP, float* dW1,
+                                          float* db1, const uint32_t* rowmask, pzn_stream_t stream) {
+  return sa_point_l1_bwd(dh, xyz, new_xyz, rows, pts, B, N, S, D, C1, dP, dW1, db1, rowmask, stream);
+}
+
+static int sa_point_l1_bwd(const float* dh, const float* xyz, const float* new_xyz, const int32_t* rows,
+                           const int32_t* pts, int B, int N, int S, int D, int C1, float* dP, float* dW1,
+                           float* db1, const uint32_t* rowmask, pzn_stream_t stream) {
   PZN_CHECK_ARG(dh && xyz && rows && pts && dP && dW1 && B > 0 && N > 0 && S > 0 && D >= 0);      // (new_xyz may be NULL)
   PZN_CHECK_ARG((long)B * N < 2147483647L && (long)B * S * 32 < 2147483647L);
   if (C1 != 64 && C1 != 128 && C1 != 256) return PZN_EUNSUPPORTED;
@@ -491,7 +523,7 @@ PZN_EXPORT int pzn_sa_point_l1_bwd_f32(const float* dh, const float* xyz, const 
   const int ldw = 3 + D;
 #define PZN_SP_BWD(VV, GG)                                                                                              \
   hipLaunchKernelGGL((sa_point_l1_bwd_kernel<VV, GG>), grid, block, 0, st, dh, xyz, new_xyz, rows, pts, N, S, entries, dP, \
-                     dW1, ldw, db1)
+                     dW1, ldw, db1, rowmask)
   if (C1 == 64) {
     if (g8 == 16) PZN_SP_BWD(1, 16); else if (g8 == 8) PZN_SP_BWD(1, 8); else PZN_SP_BWD(1, 4);
   } else if (C1 == 128) {

@@ -1496,12 +1496,24 @@ class _SaLevelFused(torch.autograd.Function):
         dP = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
         dfeat = None
         with torch.cuda.device(dev):
-            _call("pzn_sa_level_bwd_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(P), _p(Q), _p(idx), _p(new_xyz), B, N, S, D,
-                  C1, C2, _p(dh), _p(dW2), _p(db2), _p(dW1), _p(db1), int(direct), _stream(), flops=2 * R * (2 * C1 * C2))
+            if _SA_ROWMASK:
+                # rows of dh that won no channel are exactly zero (half of them at level 1): neither written nor read
+                rmask = torch.empty((R,), dtype=torch.int32, device=dev)
+                _call("pzn_sa_level_bwd_rm_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(P), _p(Q), _p(idx), _p(new_xyz), B, N, S,
+                      D, C1, C2, _p(dh), _p(dW2), _p(db2), _p(dW1), _p(db1), int(direct), _p(rmask), _stream(),
+                      flops=2 * R * (2 * C1 * C2))
+            else:
+                rmask = None
+                _call("pzn_sa_level_bwd_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(P), _p(Q), _p(idx), _p(new_xyz), B, N, S, D,
+                      C1, C2, _p(dh), _p(dW2), _p(db2), _p(dW1), _p(db1), int(direct), _stream(), flops=2 * R * (2 * C1 * C2))
             _call("pzn_knn_inverse_lists", _p(idx), B, N, S, 32, _p(off), _p(rows), _p(pts), _stream())
             # dP = per-point sums of dh; dW1[:,0:3] += dh^T xyz[idx] (centres = NULL: their part went through Q above)
-            _call("pzn_sa_point_l1_bwd_f32", _p(dh), _p(xyz), None, _p(rows), _p(pts), B, N, S, D, C1, _p(dP),
-                  _p(dW1), None, _stream())
+            if rmask is not None:
+                _call("pzn_sa_point_l1_bwd_rm_f32", _p(dh), _p(xyz), None, _p(rows), _p(pts), B, N, S, D, C1, _p(dP),
+                      _p(dW1), None, _p(rmask), _stream())
+            else:
+                _call("pzn_sa_point_l1_bwd_f32", _p(dh), _p(xyz), None, _p(rows), _p(pts), B, N, S, D, C1, _p(dP),
+                      _p(dW1), None, _stream())
             if need_feat:
                 dfeat = torch.empty((B, N, D), dtype=torch.float32, device=dev)
                 _call("pzn_linear_dgrad_f32", _p(dP), None, _p(w_f), B * N, D, C1, None, _p(dfeat), _stream(),
@@ -1514,6 +1526,7 @@ class _SaLevelFused(torch.autograd.Function):
         return None, dfeat, None, None, dW1, db1, dW2, db2
 
 
+_SA_ROWMASK = os.environ.get("PZN_SA_ROWMASK", "1") != "0"     # tuning aid: 0 = every row of dh written and read
 _SA_REGEN = os.environ.get("PZN_SA_REGEN", "1") != "0"     # tuning aid: 0 = the pooled backward reads its gate from h
 _SA_POINT = os.environ.get("PZN_SA_POINT", "1") != "0"     # tuning aid: 0 = the grouped-row path (_SaMlpMax)
 _SA_FUSED = os.environ.get("PZN_SA_FUSED", "1") != "0"     # tuning aid: 0 = per-point first layer WITH its rows in memory (_SaMlpMaxPoint)
