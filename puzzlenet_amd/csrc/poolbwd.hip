@@ -231,9 +231,9 @@ __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
   do {                                                              \
     _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                \
       size_t o = (size_t)(gg) * C2 + q * 64 + lane;                 \
-      av_n[q] = p.argmax[o];                                        \
       float go = p.out[o], gd = p.dout[o];                          \
       gv_n[q] = go > 0.f ? gd : 0.f;                                \
+      av_n[q] = gv_n[q] != 0.f ? p.argmax[o] : -1; /* (a dead channel - ReLU off, ~45 % of them - is no hit of any row) */ \
     }                                                               \
   } while (0)
   if (gw < g_end) PD_PREFETCH(gw);
