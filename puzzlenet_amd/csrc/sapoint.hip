@@ -301,30 +301,23 @@ __global__ __launch_bounds__(SP_T) void sa_point_l1_bwd_kernel(const float* __re
       }
     };
     const float* dhl = dh + lane * V;
-    int r = 0;
-    for (; r + G <= nr; r += G) {  // G dh rows in flight
-      float g[G][V];
+    // the rows that are read: with a row mask only those whose bit is set (the others are exactly zero: a point all of
+    // whose rows are skipped keeps the zero dP was filled with), G of them in flight per trip
+    uint64_t todo = __ballot(e < entries && nz != 0);
+    while (todo) {      // wave-uniform
+      int ru[G];
 #pragma unroll
       for (int u = 0; u < G; ++u) {
-        if (__builtin_amdgcn_readlane(nz, r + u)) {      // wave-uniform
-          load_vec_nt<V>(dhl + (size_t)__builtin_amdgcn_readlane(grow, r + u) * C1, g[u]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < V; ++i) g[u][i] = 0.f;
-        }
+        ru[u] = todo ? __builtin_ctzll(todo) : -1;
+        todo &= todo - 1;
       }
+      float g[G][V];
 #pragma unroll
-      for (int u = 0; u < G; ++u) take(g[u], r + u);
-    }
-    for (; r < nr; ++r) {
-      float g0[V];
-      if (__builtin_amdgcn_readlane(nz, r)) {
-        load_vec_nt<V>(dhl + (size_t)__builtin_amdgcn_readlane(grow, r) * C1, g0);
-      } else {
+      for (int u = 0; u < G; ++u)
+        if (ru[u] >= 0) load_vec_nt<V>(dhl + (size_t)__builtin_amdgcn_readlane(grow, ru[u]) * C1, g[u]);
 #pragma unroll
-        for (int i = 0; i < V; ++i) g0[i] = 0.f;
-      }
-      take(g0, r);
+      for (int u = 0; u < G; ++u)
+        if (ru[u] >= 0) take(g[u], ru[u]);
     }
     flush(cur);
   }
