@@ -145,7 +145,10 @@ __global__ __launch_bounds__(NWV * 64) void pool_wgrad_kernel(PoolBwdArgs p) {
     _Pragma("unroll") for (int c = 0; c < CPW; ++c) {                               \
       const int a = __builtin_amdgcn_readlane(av, c);                               \
       const float gs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gv), c)); \
-      v2f hr = *reinterpret_cast<const v2f*>(&hbuf[buf][a][2 * lane]);             \
+      v2f hr = v2f{0.f, 0.f};                                                       \
+      /* wave-uniform: a dead channel (ReLU off, ~45 % of them) reads nothing; with 16 channels per wavefront the branches */ \
+      /* cost more registers than the 128 a 1024-thread workgroup has (the accumulators went to scratch: 30x slower) */      \
+      if (CPW > 8 || gs != 0.f) hr = *reinterpret_cast<const v2f*>(&hbuf[buf][a][2 * lane]); \
       acc[c] += gs * hr;                                                            \
     }                                                                               \
   } while (0)
