@@ -256,6 +256,7 @@ def _run_seq_cat_global(seq, x, g):
 # 1 = stem / tail of the two encoders enqueued alternately.  Measured 1.5 % slower (10.23 vs 10.08 ms per step, same box): the
 # host runs ahead of the GPU in steady state, so the enqueue order buys nothing and the finer interleaving overlaps worse.
 _ENC_INTERLEAVE = os.environ.get("PZN_ENC_INTERLEAVE", "0") != "0"
+_HEAD_STREAMS = os.environ.get("PZN_HEAD_STREAMS", "1") != "0"     # tuning aid: 0 = both boundary heads on the main stream
 _HEAD_SPLIT = os.environ.get("PZN_HEAD_SPLIT", "1") != "0"     # tuning aid: 0 = repeat + cat + Linear as the reference composes it
 
 
@@ -353,6 +354,8 @@ class TouchedRegraster(_Base):
                 with torch.cuda.stream(side):
                     fmrpcs = self.Encoder2(mrpc, plan_m, xf_m)                      # :716
                 ffpcs = self.Encoder(fpc, plan_f, xf_f)                             # :710
+            if _HEAD_STREAMS and _HEAD_SPLIT:
+                return self._heads(ffpcs, fmrpcs, N, need, pose_hook, side=side)
             cur.wait_stream(side)
             for t in fmrpcs:
                 if isinstance(t, torch.Tensor):
@@ -363,10 +366,37 @@ class TouchedRegraster(_Base):
         fmrpcs = self.Encoder2(mrpc, plan_m)                                        # :716
         return self._heads(ffpcs, fmrpcs, N, need, pose_hook)
 
-    def _heads(self, ffpcs, fmrpcs, N, need, pose_hook=None):
-        """:723-759: pose head on the two global features, boundary heads on the per-point features."""
+    def _heads(self, ffpcs, fmrpcs, N, need, pose_hook=None, side=None):
+        """:723-759: pose head on the two global features, boundary heads on the per-point features.
+        side: the stream Encoder2 ran on (fmrpcs not yet joined).  The boundary head of the second cloud then stays on
+        that stream - its inputs were produced there - beside the pose head and the first cloud's boundary head on this
+        one: two chains of 131 072-row layers (25 us launches at a third of the HBM rate each) instead of one, forward and,
+        since autograd replays a node on its forward stream, backward."""
         ffpc, non_sg_ffpc = ffpcs[0], ffpcs[4]
         fmrpc, non_sg_fmrpc = fmrpcs[0], fmrpcs[4]
+        if side is not None:
+            cur = torch.cuda.current_stream()
+            with torch.cuda.stream(side):
+                non_sg_fmrpc = _run_seq(self.MLPLocalPreRpc, non_sg_fmrpc)              # :739
+                g_max = ops.max_over_points(non_sg_fmrpc).unsqueeze(1)                  # :741 (serves both globals)
+                ready = torch.cuda.Event()
+                ready.record(side)
+                de_mrpcb = _run_seq_cat_global(self.MLPRpcb, non_sg_fmrpc, g_max).permute(0, 2, 1)    # :749, :753-754
+            cur.wait_event(ready)                                                       # Encoder2's outputs and g_max
+            for t in list(fmrpcs) + [g_max]:
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(cur)
+            f = torch.cat([ffpc, fmrpc], dim=-1)                                        # :723
+            out = _run_seq(self.tfMLP, f)                                               # :725
+            if pose_hook is not None:
+                pose_hook(out)
+            non_sg_ffpc = _run_seq(self.MLPLocalPreFpc, non_sg_ffpc)                    # :738
+            de_fpcb = _run_seq_cat_global(self.MLPFpcb, non_sg_ffpc, g_max).permute(0, 2, 1)          # :748, :751-752
+            cur.wait_stream(side)
+            de_mrpcb.record_stream(cur)
+            if not need:
+                return out, out, de_fpcb, de_mrpcb
+            return out, [0], ffpcs[1], ffpcs[2], fmrpcs[1], fmrpcs[2], de_fpcb, de_mrpcb
 
         f = torch.cat([ffpc, fmrpc], dim=-1)                                        # :723
         out = _run_seq(self.tfMLP, f)                                               # :725
