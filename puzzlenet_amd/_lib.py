@@ -155,6 +155,14 @@ def check(status, what):
         raise (PznUnsupported if status == -3 else PznError)(f"{what} failed: {msg} (status {status})")
 
 
+_FN = {}
+
+
 def call(name, *args):
     """Invoke an int-status entry point and raise on error."""
-    check(getattr(load(), name)(*args), name)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
+    status = fn(*args)
+    if status != 0:
+        check(status, name)

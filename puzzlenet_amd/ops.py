@@ -13,8 +13,35 @@ import torch
 from . import _lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """Raw handle of torch's current stream on the current device.  (torch.cuda.current_stream() builds a Stream object:
+    9 us a call, 77 calls per training step; the raw getter is what torch's own C++ extensions use.)"""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+class _NoCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_CTX = _NoCtx()
+
+
+def _on(dev):
+    """`with _on(dev):` = torch.cuda.device(dev), skipped when dev is already the current device (one process per GPU:
+    always; the context manager cost 10 us per use, 70 uses per step)."""
+    if _cur_device is not None and dev.index is not None and dev.index == _cur_device():
+        return _NO_CTX
+    return torch.cuda.device(dev)
 
 
 class KernelTimer:
@@ -94,7 +121,7 @@ def square_distance(src, dst):
         raise _lib.PznError("square_distance: expected src[B,S,3], dst[B,N,3]")
     N = dst.shape[1]
     out = torch.empty((B, S, N), dtype=torch.float32, device=src.device)
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         _call("pzn_square_distance_f32", _p(src), _p(dst), B, S, N, _p(out), _stream())
     return out
 
@@ -106,7 +133,7 @@ def farthest_point_sample(xyz, npoint, start_idx):
         raise _lib.PznError("farthest_point_sample: expected xyz[B,N,3]")
     start_idx = _i64(start_idx, "start_idx")
     out = torch.empty((B, npoint), dtype=torch.int64, device=xyz.device)
-    with torch.cuda.device(xyz.device):
+    with _on(xyz.device):
         _call("pzn_fps_f32", _p(xyz), B, N, int(npoint), _p(start_idx), _p(out), _stream())
     return out
 
@@ -116,7 +143,7 @@ def knn(xyz, new_xyz, K):
     B, N, _ = xyz.shape
     S = new_xyz.shape[1]
     out = torch.empty((B, S, K), dtype=torch.int64, device=xyz.device)
-    with torch.cuda.device(xyz.device):
+    with _on(xyz.device):
         _call("pzn_knn_f32", _p(xyz), _p(new_xyz), B, N, S, int(K), _p(out), _stream())
     return out
 
@@ -128,7 +155,7 @@ def ball_query(radius, nsample, xyz, new_xyz):
     out = torch.empty((B, S, nsample), dtype=torch.int64, device=xyz.device)
     # `sqrdists > radius ** 2` is an fp32 comparison in the reference (pointnet_util.py:91)
     r2 = float(torch.tensor(float(radius) ** 2, dtype=torch.float32))
-    with torch.cuda.device(xyz.device):
+    with _on(xyz.device):
         _call("pzn_ball_query_f32", r2, int(nsample), _p(xyz), _p(new_xyz), B, N, S, _p(out), _stream())
     return out
 
@@ -144,7 +171,7 @@ class _Gather(torch.autograd.Function):
         flat = idx.reshape(B, -1)
         M = flat.shape[1]
         out = torch.empty((B, M, C), dtype=torch.float32, device=points.device)
-        with torch.cuda.device(points.device):
+        with _on(points.device):
             _call("pzn_gather_fwd_f32", _p(points), _p(flat), B, N, M, C, _p(out), _stream())
         ctx.save_for_backward(flat)
         ctx.dims = (B, N, M, C)
@@ -156,7 +183,7 @@ class _Gather(torch.autograd.Function):
         B, N, M, C = ctx.dims
         grad_out = _f32(grad_out, "grad_out")
         g = torch.zeros((B, N, C), dtype=torch.float32, device=grad_out.device)
-        with torch.cuda.device(grad_out.device):
+        with _on(grad_out.device):
             _call("pzn_gather_bwd_f32", _p(grad_out), _p(flat), B, N, M, C, _p(g), _stream())
         return g, None
 
@@ -175,7 +202,7 @@ class _MaxOverPoints(torch.autograd.Function):
         B, L, C = x.shape
         out = torch.empty((B, C), dtype=torch.float32, device=x.device)
         idx = torch.empty((B, C), dtype=torch.int32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _call("pzn_maxpool_points_fwd_f32", _p(x), B, L, C, _p(out), _p(idx), _stream())
         ctx.save_for_backward(idx)
         ctx.dims = (B, L, C)
@@ -187,7 +214,7 @@ class _MaxOverPoints(torch.autograd.Function):
         B, L, C = ctx.dims
         dout = _f32(dout, "dout")
         dx = torch.empty((B, L, C), dtype=torch.float32, device=dout.device)
-        with torch.cuda.device(dout.device):
+        with _on(dout.device):
             _call("pzn_maxpool_points_bwd_f32", _p(dout), _p(idx), B, L, C, _p(dx), _stream())
         return dx
 
@@ -200,7 +227,7 @@ class _Se3Exp(torch.autograd.Function):
         x = _f32(x, "twist")
         B = x.shape[0]
         g = torch.empty((B, 4, 4), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _call("pzn_se3_exp_fwd_f32", _p(x), B, _p(g), _stream())
         ctx.save_for_backward(x)
         return g
@@ -210,7 +237,7 @@ class _Se3Exp(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         dg = _f32(dg, "dg")
         dx = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _call("pzn_se3_exp_bwd_f32", _p(x), _p(dg), x.shape[0], _p(dx), _stream())
         return dx
 
@@ -223,7 +250,7 @@ class _Se3Transform(torch.autograd.Function):
         g, p = _f32(g, "g"), _f32(p, "points")
         B, N, _ = p.shape
         out = torch.empty_like(p)
-        with torch.cuda.device(p.device):
+        with _on(p.device):
             _call("pzn_se3_transform_fwd_f32", _p(g), _p(p), B, N, _p(out), _stream())
         ctx.save_for_backward(g, p)
         return out
@@ -237,7 +264,7 @@ class _Se3Transform(torch.autograd.Function):
         dp = torch.empty_like(p) if ctx.needs_input_grad[1] else None
         if dg is None and dp is None:
             return None, None
-        with torch.cuda.device(p.device):
+        with _on(p.device):
             _call("pzn_se3_transform_bwd_f32", _p(g), _p(p), _p(dout), B, N, _p(dp), _p(dg), _stream())
         return dg, dp
 
@@ -256,7 +283,7 @@ class _CompLoss(torch.autograd.Function):
     def forward(ctx, g, igt):
         g, igt = _f32(g, "g"), _f32(igt, "igt")
         loss = torch.empty((1,), dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
+        with _on(g.device):
             _call("pzn_comp_fwd_f32", _p(g), _p(igt), g.shape[0], _p(loss), _stream())
         ctx.save_for_backward(g, igt)
         return loss.reshape(())
@@ -266,7 +293,7 @@ class _CompLoss(torch.autograd.Function):
         g, igt = ctx.saved_tensors
         dl = _f32(dloss, "dloss").reshape(1)
         dg = torch.empty_like(g)
-        with torch.cuda.device(g.device):
+        with _on(g.device):
             _call("pzn_comp_bwd_f32", _p(g), _p(igt), _p(dl), g.shape[0], _p(dg), _stream())
         return dg, None
 
@@ -287,7 +314,7 @@ class _BoundaryCE(torch.autograd.Function):
             raise _lib.PznError(f"boundary_ce expects logits[B,2,N], labels[B,N]; got {tuple(logits.shape)}, {tuple(labels.shape)}")
         prob1 = torch.empty((B, N), dtype=torch.float32, device=logits.device)
         loss = torch.empty((513,), dtype=torch.float32, device=logits.device)   # PZN_BOUNDARY_CE_LOSS_FLOATS: value + partials
-        with torch.cuda.device(logits.device):
+        with _on(logits.device):
             _call("pzn_boundary_ce_fwd_f32", _p(logits), _p(labels), B, N, _p(prob1), _p(loss), _stream())
         ctx.save_for_backward(logits, labels)
         ctx.mark_non_differentiable(prob1)
@@ -299,7 +326,7 @@ class _BoundaryCE(torch.autograd.Function):
         B, _, N = logits.shape
         dl = _f32(dloss, "dloss").reshape(1)
         dlogits = torch.empty_like(logits)
-        with torch.cuda.device(logits.device):
+        with _on(logits.device):
             _call("pzn_boundary_ce_bwd_f32", _p(logits), _p(labels), _p(dl), B, N, _p(dlogits), _stream())
         return dlogits, None
 
@@ -314,7 +341,7 @@ def topk_rows(x, k):
     x = _f32(x.detach(), "x")
     R, N = x.shape
     idx = torch.empty((R, int(k)), dtype=torch.int64, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _call("pzn_topk_rows_f32", _p(x), R, N, int(k), _p(idx), _stream())
     return idx
 
@@ -326,7 +353,7 @@ class _Avg4(torch.autograd.Function):
     def forward(ctx, a, b, c, d):
         a, b, c, d = (_f32(t, "map") for t in (a, b, c, d))
         out = torch.empty_like(a)
-        with torch.cuda.device(a.device):
+        with _on(a.device):
             _call("pzn_avg4_f32", _p(a), _p(b), _p(c), _p(d), a.numel(), _p(out), _stream())
         return out
 
@@ -347,7 +374,7 @@ def colmean_argmax(a):
     mean = torch.empty((B, C), dtype=torch.float32, device=a.device)
     arg = torch.empty((B,), dtype=torch.int64, device=a.device)
     ws = torch.empty((_lib.load().pzn_colmean_workspace_bytes(B, C) + 3) // 4, dtype=torch.float32, device=a.device)
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         _call("pzn_colmean_argmax_f32", _p(a), B, R, C, _p(mean), _p(arg), _p(ws), _stream())
     return mean, arg
 
@@ -384,7 +411,7 @@ class _Group(torch.autograd.Function):
         feat_c = None if feat is None else _f32(feat, "points")
         out = torch.empty((B, S, K, 3 + D), dtype=torch.float32, device=xyz.device)
         gx = torch.empty((B, S, K, 3), dtype=torch.float32, device=xyz.device) if want_grouped_xyz else None
-        with torch.cuda.device(xyz.device):
+        with _on(xyz.device):
             if fuse_knn:
                 _call("pzn_knn_group_f32", _p(xyz), _p(feat_c), _p(new_xyz), B, N, S, D, _p(idx), _p(out), _p(gx), _stream())
             else:
@@ -411,7 +438,7 @@ class _Group(torch.autograd.Function):
         gxyz = torch.zeros((B, N, 3), dtype=torch.float32, device=dev) if need_xyz else None
         gfeat = torch.zeros((B, N, D), dtype=torch.float32, device=dev) if need_feat else None
         gnew = torch.empty((B, S, 3), dtype=torch.float32, device=dev) if need_new else None
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call("pzn_group_bwd_f32", _p(grad_out), _p(idx), B, N, S, K, D, _p(gxyz), _p(gfeat), _p(gnew),
                       _stream())
         return gxyz, gfeat, gnew, None, None
@@ -453,7 +480,7 @@ def emd_approxmatch(xyz1, xyz2):
     B, n, m = _emd_shapes(xyz1, xyz2)
     match = torch.empty((B, m, n), dtype=torch.float32, device=xyz1.device)
     ws = _emd_ws(B, n, m, xyz1.device)
-    with torch.cuda.device(xyz1.device):
+    with _on(xyz1.device):
         _call("pzn_emd_approxmatch_f32", _p(xyz1), _p(xyz2), B, n, m, _p(match), _p(ws), _stream())
     return match
 
@@ -463,7 +490,7 @@ def emd_matchcost(xyz1, xyz2, match):
     xyz1, xyz2, match = _f32(xyz1, "xyz1"), _f32(xyz2, "xyz2"), _f32(match, "match")
     B, n, m = _emd_shapes(xyz1, xyz2)
     cost = torch.empty((B,), dtype=torch.float32, device=xyz1.device)
-    with torch.cuda.device(xyz1.device):
+    with _on(xyz1.device):
         _call("pzn_emd_matchcost_f32", _p(xyz1), _p(xyz2), _p(match), B, n, m, _p(cost), _stream())
     return cost
 
@@ -475,7 +502,7 @@ def emd_matchcost_grad(grad_cost, xyz1, xyz2, match):
     B, n, m = _emd_shapes(xyz1, xyz2)
     g1 = torch.empty((B, n, 3), dtype=torch.float32, device=xyz1.device)
     g2 = torch.empty((B, m, 3), dtype=torch.float32, device=xyz1.device)
-    with torch.cuda.device(xyz1.device):
+    with _on(xyz1.device):
         _call("pzn_emd_matchcost_grad_f32", _p(grad_cost), _p(xyz1), _p(xyz2), _p(match), B, n, m,
                   _p(g1), _p(g2), _stream())
     return [g1, g2]
@@ -496,7 +523,7 @@ class _EmdFused(torch.autograd.Function):
         g1 = torch.empty((B, n, 3), dtype=torch.float32, device=dev)
         g2 = torch.empty((B, m, 3), dtype=torch.float32, device=dev)
         ws = _emd_ws(B, n, m, dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call("pzn_emd_fused_f32", _p(xyz1), _p(xyz2), B, n, m, _p(cost), _p(g1), _p(g2), _p(ws), _stream())
         if EMD_WALK_STATS is not None:       # measurement only (bench.py): lengths of the active lists the passes walked
             off = _lib.load().pzn_emd_walk_counter_offset(B, n, m)
@@ -533,7 +560,7 @@ class _Chamfer(torch.autograd.Function):
         aoa = torch.empty((B, m), dtype=torch.int32, device=dev)
         aob = torch.empty((B, n), dtype=torch.int32, device=dev)
         ws = torch.empty((_lib.load().pzn_chamfer_workspace_bytes(B, n, m) + 3) // 4, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call("pzn_chamfer_fwd_f32", _p(a), _p(b), B, n, m, _p(moa), _p(aoa), _p(mob), _p(aob), _p(ws), _stream())
         ctx.save_for_backward(a, b, aoa, aob)
         ctx.mark_non_differentiable(aoa, aob)
@@ -547,7 +574,7 @@ class _Chamfer(torch.autograd.Function):
         g_mob = None if g_mob is None else _f32(g_mob, "g_over_b")
         ga = torch.zeros_like(a)
         gb = torch.zeros_like(b)
-        with torch.cuda.device(a.device):
+        with _on(a.device):
             _call("pzn_chamfer_bwd_f32", _p(a), _p(b), B, n, m, _p(g_moa), _p(aoa), _p(g_mob), _p(aob),
                   _p(ga), _p(gb), _stream())
         return ga, gb
@@ -610,7 +637,7 @@ class _Linear(torch.autograd.Function):
         x2 = x.reshape(-1, Kin)
         M = x2.shape[0]
         y = torch.empty((M, Nout), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _call("pzn_linear_fwd_f32", _p(x2), _p(weight), _p(bias_c), M, Kin, Nout, int(bool(relu)), _p(y), _stream(),
                   flops=2 * M * Kin * Nout)
         ctx.save_for_backward(x2, weight, y if relu else None)
@@ -627,7 +654,7 @@ class _Linear(torch.autograd.Function):
         dy = _f32(dy, "dy").reshape(M, Nout)
         dev = dy.device
         dx = dW = db = None
-        with torch.cuda.device(dev):
+        with _on(dev):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty((M, Kin), dtype=torch.float32, device=dev)
                 _call("pzn_linear_dgrad_f32", _p(dy), _p(y), _p(weight), M, Kin, Nout, None, _p(dx), _stream(),
@@ -672,7 +699,7 @@ class _CatGlobalLinearRelu(torch.autograd.Function):
         x2 = x.reshape(B * N, C)
         y = torch.empty((B * N, Co), dtype=torch.float32, device=dev)
         cb = torch.empty((B, Co), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             st = _stream()
             _call("pzn_linear_fwd_f32", _p(g2), _p(w_g), _p(bias), B, Cg, Co, 0, _p(cb), st, flops=2 * B * Cg * Co)
             _call("pzn_linear_fwd_f32", _p(x2), _p(w_x), None, B * N, C, Co, 0, _p(y), st, flops=2 * B * N * C * Co)
@@ -690,7 +717,7 @@ class _CatGlobalLinearRelu(torch.autograd.Function):
         dy = _f32(dy, "dy").reshape(B * N, Co)
         mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
         dx = dg = dW = db = None
-        with torch.cuda.device(dev):
+        with _on(dev):
             st = _stream()
             dcb = mk(B, Co)
             _call("pzn_cloud_gated_colsum_f32", _p(dy), _p(y), B, N, Co, _p(dcb), st)
@@ -731,7 +758,7 @@ class _SharedMlpMax(torch.autograd.Function):
         h = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
         out = torch.empty((R, C2), dtype=torch.float32, device=dev)
         arg = torch.empty((R, C2), dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call("pzn_sharedmlp_max_fwd_f32", _p(x), _p(w1), _p(b1), _p(w2), _p(b2), R, C0, C1, C2,
                   _p(h), _p(out), _p(arg), _stream())
         ctx.save_for_backward(x, w1, w2, h, out, arg)
@@ -750,7 +777,7 @@ class _SharedMlpMax(torch.autograd.Function):
         db1 = torch.empty((C1,), dtype=torch.float32, device=dev)
         dW2 = torch.empty_like(w2)
         db2 = torch.empty((C2,), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call("pzn_sharedmlp_max_bwd_f32", _p(x), _p(w1), _p(w2), _p(h), _p(out), _p(arg), _p(dout),
                   R, C0, C1, C2, _p(dh), _p(dx), _p(dW1), _p(db1), _p(dW2), _p(db2), 0, _stream())
         return (None if dx is None else dx.reshape(Bq, S, 32, C0)), dW1, db1, dW2, db2
@@ -771,7 +798,7 @@ class _Attention(torch.autograd.Function):
         dev = q.device
         attn = torch.empty((B, L, L), dtype=torch.float32, device=dev)
         out = torch.empty((B, L, dv), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call("pzn_attn_fwd_f32", _p(q), _p(k), _p(v), B, L, dk, dv, _p(attn), _p(out), _stream(),
                   flops=2 * B * L * L * (dk + dv))
         ctx.save_for_backward(q, k, v, attn)
@@ -788,7 +815,7 @@ class _Attention(torch.autograd.Function):
         d_attn = None if d_attn is None else _f32(d_attn, "d_attn")
         dq, dk_, dv_ = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         ws = torch.empty((B, L, L), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call("pzn_attn_bwd_f32", _p(q), _p(k), _p(v), _p(attn), _p(d_out), _p(d_attn), B, L, dk, dv,
                   _p(dq), _p(dk_), _p(dv_), _p(ws), _stream(), flops=2 * B * L * L * (2 * dk + 2 * dv))
         return dq, dk_, dv_
@@ -814,7 +841,7 @@ class _AttentionBlock(torch.autograd.Function):
         mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
         q, k, v = mk(M, dk), mk(M, dk), mk(M, E)
         attn, r, yo, out = mk(B, L, L), mk(M, E), mk(M, E), mk(M, E)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call("pzn_attn_block_fwd_f32", _p(x), _p(wq), _p(bq), _p(wk), _p(bk), _p(wv), _p(bv), _p(wo), _p(bo),
                   B, L, E, dk, _p(q), _p(k), _p(v), _p(attn), _p(r), _p(yo), _p(out), _stream(),
                   flops=2 * M * E * (2 * dk + 2 * E) + 2 * B * L * L * (dk + E))
@@ -842,7 +869,7 @@ class _AttentionBlock(torch.autograd.Function):
         nbytes = _lib.load().pzn_attn_block_bwd_workspace_bytes(B, L, E, dk)
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
         gq, gbq, gk, gbk, gv, gbv, go, gbo = grads
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call("pzn_attn_block_bwd_f32", _p(x), _p(wq), _p(wk), _p(wv), _p(wo), _p(q), _p(k), _p(v), _p(attn), _p(r),
                   _p(yo), _p(dout), _p(dattn), B, L, E, dk, _p(ws), _p(dx), _p(gq), _p(gbq), _p(gk), _p(gbk), _p(gv),
                   _p(gbv), _p(go), _p(gbo), int(direct), _stream(),
@@ -886,7 +913,7 @@ class _AttnChainOut(torch.autograd.Function):
         M = B * L
         mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
         saved, cur = [], x.reshape(M, E)
-        with torch.cuda.device(dev):
+        with _on(dev):
             for (wq, bq, wk, bk, wv, bv, wo, bo) in blocks:
                 q, k, v = mk(M, dk), mk(M, dk), mk(M, E)
                 attn, r, yo, out = mk(B, L, L), mk(M, E), mk(M, E), mk(M, E)
@@ -933,7 +960,7 @@ class _AttnChainOut(torch.autograd.Function):
         else:
             if dfg is not None:      # `out` itself carries a gradient too: dense products on the summed gradient
                 dmax = mk(B, L, Nout)
-                with torch.cuda.device(dev):
+                with _on(dev):
                     _call("pzn_maxpool_points_bwd_f32", _p(_f32(dfg, "df_global")), _p(arg), B, L, Nout, _p(dmax), _stream())
                 dy = dmax if dy is None else dy + dmax
             if dy is None:
@@ -947,7 +974,7 @@ class _AttnChainOut(torch.autograd.Function):
         grads = [None] * 34
         nbytes = _lib.load().pzn_attn_block_bwd_workspace_bytes(B, L, E, dk)
         ws = mk((nbytes + 3) // 4)
-        with torch.cuda.device(dev):
+        with _on(dev):
             G = mk(M, 5 * E)
             if sparse:
                 segs = (ctypes.c_void_p * 5)(*[_p(xi) for xi in xs])
@@ -1036,7 +1063,7 @@ class _AttnChainFused(torch.autograd.Function):
         mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
         raw = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
         R = range(nprob)
-        with torch.cuda.device(dev):
+        with _on(dev):
             st = _stream()
             W = [[raw(wbytes) for _ in range(4)] for _ in R]
             for p in R:
@@ -1116,7 +1143,7 @@ class _AttnChainFused(torch.autograd.Function):
         vb = lib.pzn_attn_fused_v_image_bytes(B)
         grads = [None] * (2 + 35 * nprob)
         saved, ps, g, Gs, direct_blk = [], [], [], [], []
-        with torch.cuda.device(dev):
+        with _on(dev):
             st = _stream()
             for p in R:
                 t = T[per_saved * p: per_saved * (p + 1)]
@@ -1237,7 +1264,7 @@ class _SaMlpMax(torch.autograd.Function):
         h = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
         out = torch.empty((R, C2), dtype=torch.float32, device=dev)
         arg = torch.empty((R, C2), dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             if fuse_knn:     # neighbour search + group in one launch (idx is an output)
                 _call("pzn_knn_group_pad_f32", _p(xyz), _p(feat), _p(new_xyz), B, N, S, D, _p(idx), _p(xg), _stream())
             else:
@@ -1273,7 +1300,7 @@ class _SaMlpMax(torch.autograd.Function):
         # layer 2 is the sparse pass (one non-zero per group and channel: R*C2 row-axpys each way), layer 1 the
         # dense matrix-core products
         fl = 2 * R * (2 * C1 * C2) + 2 * R * 32 * ((3 + D) * C1 + (D * C1 if need_feat else 0))
-        with torch.cuda.device(dev):
+        with _on(dev):
             if need_feat:   # feature gradient scatter-added from the GEMM epilogue: the [R*32, D] rows are never written
                 dfeat = torch.zeros((B, N, D), dtype=torch.float32, device=dev)
                 rows_ws = torch.empty((R * 32, D), dtype=torch.float32, device=dev)   # fallback scratch (allocator only)
@@ -1300,7 +1327,7 @@ class _BnPointsRelu(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty((N,), dtype=torch.float32, device=dev)
         invstd = torch.empty((N,), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call("pzn_bn_points_relu_fwd_f32", _p(x), _p(weight), _p(bias), _p(running_mean), _p(running_var),
                   int(bool(training)), float(momentum), float(eps), B, N, C, _p(y), _p(mean), _p(invstd), _stream())
         ctx.save_for_backward(x, weight, bias, mean, invstd)
@@ -1323,7 +1350,7 @@ class _BnPointsRelu(torch.autograd.Function):
         else:
             dw = torch.zeros((N,), dtype=torch.float32, device=dev) if need_w else None
             db = torch.zeros((N,), dtype=torch.float32, device=dev) if need_b else None
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call("pzn_bn_points_relu_bwd_f32", _p(x), _p(dy), _p(weight), _p(bias), _p(mean), _p(invstd),
                   int(ctx.training), B, N, C, _p(dx), _p(dw), _p(db), _stream())
         if direct:
@@ -1367,7 +1394,7 @@ class _SaMlpMaxPoint(torch.autograd.Function):
         h = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
         out = torch.empty((R, C2), dtype=torch.float32, device=dev)
         arg = torch.empty((R, C2), dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call("pzn_linear_fwd_f32", _p(feat), _p(w_f), None, B * N, D, C1, 0, _p(P), _stream(),
                   flops=2 * B * N * D * C1)
             if idx is None:
@@ -1407,7 +1434,7 @@ class _SaMlpMaxPoint(torch.autograd.Function):
         pts = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
         dP = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
         dfeat = None
-        with torch.cuda.device(dev):
+        with _on(dev):
             if _SA_REGEN:    # the ReLU gate of h regenerated from P / idx (L2) instead of read from h (HBM)
                 _call("pzn_sa_pooled_layer_bwd_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(h), _p(P), _p(idx), _p(xyz),
                       _p(new_xyz), _p(w1), _p(b1), B, N, S, D, C1, C2, _p(dh), _p(dW2), _p(db2), int(direct), _stream(),
@@ -1454,7 +1481,7 @@ class _SaLevelFused(torch.autograd.Function):
         Q = torch.empty((R, C1), dtype=torch.float32, device=dev)
         out = torch.empty((R, C2), dtype=torch.float32, device=dev)
         arg = torch.empty((R, C2), dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _call("pzn_linear_fwd_f32", _p(feat), _p(w_f), None, B * N, D, C1, 0, _p(P), _stream(),
                   flops=2 * B * N * D * C1)
             if idx is None:
@@ -1495,7 +1522,7 @@ class _SaLevelFused(torch.autograd.Function):
         pts = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
         dP = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
         dfeat = None
-        with torch.cuda.device(dev):
+        with _on(dev):
             if _SA_ROWMASK:
                 # rows of dh that won no channel are exactly zero (half of them at level 1): neither written nor read
                 rmask = torch.empty((R,), dtype=torch.int32, device=dev)
