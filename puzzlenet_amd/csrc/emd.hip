@@ -35,6 +35,8 @@
 // next level's active list (emd_compact_kernel), then C fused with the next level's A, walking the active list
 // (emd_pass_ca_kernel).  A point with remainR_l == 0 stays at 0 (:114-117) and contributes exactly +0 to the sums
 // of A and C, so leaving it out changes nothing but the summation order.
+#include <stdlib.h>
+
 #include "pzn_common.h"
 
 namespace {
@@ -898,9 +900,10 @@ int run_levels(const float* xyz1, const float* xyz2, int B, int n, int m, float*
   };
   // x window of a level: exp2(c d^2) with c d^2 <= -150 is exactly +0 in fp32 (below the smallest denormal), and
   // d^2 >= (x distance)^2: points farther than sqrt(150 / -c) along x are not walked (level 0: no window)
+  static const float win_bits = [] { const char* e = getenv("PZN_EMD_WIN_BITS"); return e ? (float)atof(e) : 150.f; }();  // tuning aid
   auto winf = [&](int j) {
     const float c = cof(j);
-    return c < 0.f ? sqrtf(150.f / -c) : INFINITY;
+    return c < 0.f ? sqrtf(win_bits / -c) : INFINITY;
   };
   if (LISTED) {  // A(7); then per level B, and C fused with the next level's A; the last level ends with a plain C
     hipLaunchKernelGGL(emd_pass_a_kernel, gk, dim3(EMD_T), 0, st, n, m, cof(7), w, winf(7));
