@@ -27,6 +27,13 @@ xg = torch.randn(4096, 1280, generator=g).to(dev)
 wg = (torch.randn(1024, 1280, generator=g) / 30).to(dev)
 yg = torch.empty(4096, 1024, device=dev)
 side = torch.cuda.Stream()
+bg = torch.zeros(1024, device=dev)
+
+
+def chain():      # the four attention blocks as chained kernels + the fused out projection / max over points (round 3)
+    return ops.attention_chain_fused([xa], [[tuple(aw)] * 4], [wg], [bg])[0]
+
+
 victims = {
     "knn": lambda: ops.knn(xyz, new_xyz, 32),
     "knn_group": lambda: ops.knn_group(xyz, feat, new_xyz)[0],
@@ -38,6 +45,7 @@ victims = {
     "linear_weight_stationary": lambda: dense.linear(xl, wl, bl, relu=True),
     "linear_general_engine": lambda: dense.linear(xg, wg, None),
     "max_over_points": lambda: ops.max_over_points(xa),
+    "attention_chain_fused": lambda: torch.cat([t.reshape(-1) for t in chain()]),
 }
 
 def agg_general():
@@ -73,7 +81,11 @@ def agg_sa_backward():
         y = ops.sa_mlp_max(xyz, fr, new_xyz, None, w1, b1, w2, b2)
         y.sum().backward()
         fr.grad = None
-aggs.update(emd=agg_emd, knn_group=agg_knn_group, fps=agg_fps, chamfer=agg_chamfer, sa_backward=agg_sa_backward)
+def agg_chain():
+    with torch.cuda.stream(side):
+        chain()
+aggs.update(emd=agg_emd, knn_group=agg_knn_group, fps=agg_fps, chamfer=agg_chamfer, sa_backward=agg_sa_backward,
+            attention_fused=agg_chain)
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 print("victim \\ aggressor".ljust(28) + "".join(a[:14].rjust(15) for a in aggs))
 for name, fn in victims.items():
