@@ -63,6 +63,7 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     dev = torch.device("cuda:0")
     run(2, 64, 20, 128, 128, dev)          # ragged: 40 groups, the last round half empty
+    run(3, 64, 21, 128, 128, dev)          # 63 groups: an odd count (the last pair's second group is its first)
     run(B, 2048, 512, 128, 128, dev)
     run(B, 512, 256, 256, 256, dev)
     run(B, 4096, 512, 128, 128, dev)
