@@ -219,3 +219,20 @@ def test_dropin_signature(dev):
     assert earth_mover_distance(a[0].t(), b[0].t(), transpose=False).shape == (1,)   # 2-D inputs are unsqueezed
     with pytest.raises(AssertionError):
         earth_mover_distance(a.cpu(), b.cpu())
+
+
+def test_double_clouds_keep_their_dtype(dev):
+    """emd_kernel.cu:187,273,391 instantiate the kernels for float and double; here double clouds are computed in fp32 and
+    the cost and both gradients come back as double, equal to the fp32 call's."""
+    from puzzlenet_amd.PyTorchEMD.emd import earth_mover_distance
+    g = torch.Generator().manual_seed(4)
+    a = torch.rand(3, 96, 3, generator=g, dtype=torch.float64).to(dev).requires_grad_(True)
+    b = torch.rand(3, 80, 3, generator=g, dtype=torch.float64).to(dev).requires_grad_(True)
+    cost = earth_mover_distance(a, b, transpose=False)
+    assert cost.dtype == torch.float64 and cost.shape == (3,)
+    cost.sum().backward()
+    assert a.grad.dtype == torch.float64 and b.grad.dtype == torch.float64
+    a32, b32 = a.detach().float().requires_grad_(True), b.detach().float().requires_grad_(True)
+    c32 = earth_mover_distance(a32, b32, transpose=False)
+    c32.sum().backward()
+    assert torch.equal(cost.float(), c32) and torch.equal(a.grad.float(), a32.grad) and torch.equal(b.grad.float(), b32.grad)
