@@ -269,10 +269,20 @@ def main():
         torch.cuda.synchronize()
         ops.KernelTimer.start()
         ops.EMD_WALK_STATS = []
+        ops.SA_ROWMASK_STATS = []
         for _ in range(prof_steps):
             eager.step()
         kern = ops.KernelTimer.stop()
         emd_walk, ops.EMD_WALK_STATS = ops.EMD_WALK_STATS, None
+        rowmasks, ops.SA_ROWMASK_STATS = ops.SA_ROWMASK_STATS, None
+        # rows of dh that exist (mask bit set) per step, in bytes: what the masked list sum has to read
+        def _bits(t):
+            v = t.to(torch.int64) & 0xffffffff
+            c = torch.zeros_like(v)
+            for sh in range(32):
+                c += (v >> sh) & 1
+            return int(c.sum())
+        dh_rows_bytes = sum(_bits(m) * c1 * 4 for m, c1 in rowmasks) / prof_steps if rowmasks else None
         kern_flops = dict(ops.KernelTimer.flops)
         eager.close()
         kern_api, stage_kg, cold_kg = time_knn_group_api(batch, dev, 20)
@@ -368,19 +378,24 @@ def main():
         gf2, gb2 = gather_bytes(512, 256, 256)
         n_gf, ms_gf = per_step("pzn_sa_point_l1_fwd_f32")
         n_gb, ms_gb = per_step("pzn_sa_point_l1_bwd_rm_f32" if "pzn_sa_point_l1_bwd_rm_f32" in kern else "pzn_sa_point_l1_bwd_f32")
-        g_bytes = 2 * B * ((gf1 + gf2 if n_gf else 0) + (gb1 + gb2 if n_gb else 0))
+        g_bytes_dense = 2 * B * ((gf1 + gf2 if n_gf else 0) + (gb1 + gb2 if n_gb else 0))
+        g_bytes = g_bytes_dense
+        if dh_rows_bytes is not None and n_gb and not n_gf:
+            # with the row mask the list sum reads only the rows that exist: the dense dh term is replaced by what the masks
+            # of this very pass count (device popcount), everything else (dP, lists, coordinates) stays
+            g_bytes = g_bytes_dense - 2 * B * 4 * 32 * (512 * 128 + 256 * 256) + dh_rows_bytes
         g_ms = ms_gf + ms_gb
         g_ach = g_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
         g_traffic, g_src = pmc_traffic("sa_gather_stage_bytes_per_step", B, N)
         roofline_sa_gather = {
             "bound": "hbm", "kernel": "sa_point_l1_bwd_kernel (pzn_sa_point_l1_bwd[_rm]_f32: the per-point sums of dh over inverse neighbour "
                                       "lists; with the row mask (_rm, default) rows that won no channel - exactly zero, about half of level 1 and "
-                                      "a third of level 2 - are not read, so `achieved`, which prices the DENSE dh, exceeds what the HBM "
-                                      "delivered: `traffic` has the counted bytes)" + (" + sa_point_l1_fwd_kernel (rows written: PZN_SA_FUSED=0)" if n_gf else
+                                      "a third of level 2 - are not read: `algorithmic_bytes_per_step` counts the rows that exist (popcount of "
+                                      "the masks of the instrumented pass), `dense_bytes_per_step` is the figure without the mask)" + (" + sa_point_l1_fwd_kernel (rows written: PZN_SA_FUSED=0)" if n_gf else
                                                   "; the forward writes no rows any more (generated inside the matrix-core kernel)"),
             "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g_ach / HBM_PEAK_GBS,
             "traffic": g_traffic, "traffic_source": g_src,
-            "algorithmic_bytes_per_step": g_bytes,
+            "algorithmic_bytes_per_step": g_bytes, "dense_bytes_per_step": g_bytes_dense,
             "avg_launch_ms": {"sa_point_l1_fwd_kernel": ms_gf / max(1.0, n_gf), "sa_point_l1_bwd_kernel": ms_gb / max(1.0, n_gb)},
         }
         # (4) EMD: vector-ALU / transcendental bound.  The reference's schedule is 10 levels x 3 passes x n*m pair
@@ -415,15 +430,21 @@ def main():
         #      issue (hits x C1 multiply-adds per pass, one lane-slot each, against the chip's vector issue rate).
         n_pb, ms_pb = per_step("pzn_sa_level_bwd_rm_f32" if "pzn_sa_level_bwd_rm_f32" in kern else "pzn_sa_level_bwd_f32")
         lvl = ((B * 512, 128, 128), (B * 256, 256, 256))              # (groups R, C1, C2) of the two levels
-        pb_bytes = 2 * sum(4.0 * R_ * 32 * C1_ + 4.0 * R_ * C2_ * 2 + 4.0 * C1_ * C2_ for R_, C1_, C2_ in lvl)
+        pb_bytes_dense = 2 * sum(4.0 * R_ * 32 * C1_ + 4.0 * R_ * C2_ * 2 + 4.0 * C1_ * C2_ for R_, C1_, C2_ in lvl)
+        pb_bytes = pb_bytes_dense
+        if dh_rows_bytes is not None and "pzn_sa_level_bwd_rm_f32" in kern:
+            # with the row mask only the rows that exist are written (rows are stored in pairs: this counts the rows with a bit)
+            pb_bytes = pb_bytes_dense - 2 * sum(4.0 * R_ * 32 * C1_ for R_, C1_, C2_ in lvl) + dh_rows_bytes
         pb_fma = 2 * sum(2.0 * R_ * C2_ * C1_ for R_, C1_, C2_ in lvl)         # input-gradient + weight-gradient pass
         t_hbm, t_valu = pb_bytes / (HBM_PEAK_GBS * 1e9), pb_fma / VALU_LANE_SLOTS_PER_S
         roofline_pool_bwd = {
-            "bound": "hbm", "kernel": "pool_dgrad_kernel + pool_wgrad_kernel (csrc/poolbwd.hip) behind pzn_sa_level_bwd_f32, "
-                                      "4 launches per step (2 levels x 2 clouds)",
+            "bound": "hbm", "kernel": "pool_dgrad_kernel + pool_wgrad_kernel (csrc/poolbwd.hip) behind pzn_sa_level_bwd[_rm]_f32, "
+                                      "4 launches per step (2 levels x 2 clouds); with the row mask (_rm) the dh term of the bytes counts "
+                                      "the rows that exist (device popcount of the masks), `dense_bytes_per_step` is the figure without it",
             "achieved": pb_bytes / (ms_pb * 1e-3) / 1e9 if ms_pb > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (pb_bytes / (ms_pb * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_pb > 0 else 0.0, "traffic": None,
-            "algorithmic_bytes_per_step": pb_bytes, "ms_per_step": ms_pb, "launches_per_step": n_pb,
+            "algorithmic_bytes_per_step": pb_bytes, "dense_bytes_per_step": pb_bytes_dense, "ms_per_step": ms_pb,
+            "launches_per_step": n_pb,
             "vector_issue": {"lane_multiply_adds_per_step": pb_fma, "peak_lane_slots_per_s": VALU_LANE_SLOTS_PER_S,
                              "frac": (pb_fma / (ms_pb * 1e-3) / VALU_LANE_SLOTS_PER_S) if ms_pb > 0 else 0.0},
             "floor_ms_per_step": {"hbm": t_hbm * 1e3, "vector_issue": t_valu * 1e3},

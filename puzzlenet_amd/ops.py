@@ -1526,6 +1526,8 @@ class _SaLevelFused(torch.autograd.Function):
             if _SA_ROWMASK:
                 # rows of dh that won no channel are exactly zero (half of them at level 1): neither written nor read
                 rmask = torch.empty((R,), dtype=torch.int32, device=dev)
+                if SA_ROWMASK_STATS is not None:      # measurement only (bench.py): the masks, to count the rows that exist
+                    SA_ROWMASK_STATS.append((rmask, C1))
                 _call("pzn_sa_level_bwd_rm_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(P), _p(Q), _p(idx), _p(new_xyz), B, N, S,
                       D, C1, C2, _p(dh), _p(dW2), _p(db2), _p(dW1), _p(db1), int(direct), _p(rmask), _stream(),
                       flops=2 * R * (2 * C1 * C2))
@@ -1553,6 +1555,7 @@ class _SaLevelFused(torch.autograd.Function):
         return None, dfeat, None, None, dW1, db1, dW2, db2
 
 
+SA_ROWMASK_STATS = None      # bench.py sets this to a list: every masked level backward appends (row mask [B*S] int32, C1)
 _SA_ROWMASK = os.environ.get("PZN_SA_ROWMASK", "1") != "0"     # tuning aid: 0 = every row of dh written and read
 _SA_REGEN = os.environ.get("PZN_SA_REGEN", "1") != "0"     # tuning aid: 0 = the pooled backward reads its gate from h
 _SA_POINT = os.environ.get("PZN_SA_POINT", "1") != "0"     # tuning aid: 0 = the grouped-row path (_SaMlpMax)
