@@ -38,7 +38,16 @@ def init_from_env(backend=None):
         kw = {}
         if backend == "nccl" and on_gpu:
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        except (TypeError, ValueError, RuntimeError):
+            # (the eager, device-bound communicator has never met this build's multi-GPU hardware: fall back to the lazy one,
+            # which binds to the current device - already selected above - at the first collective)
+            if not kw:
+                raise
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
