@@ -656,7 +656,10 @@ def test_outproj_maxpts_vs_float64(dev, B, need_out):
     """csrc/outproj.hip through the C ABI: cat(x_0..x_4) W^T + b and the max over the 256 points (model5_b.py:466-475) against
     float64; B = 5 takes the plain block order (4 B workgroups not a multiple of 8), out = NULL writes only the maximum;
     two identical points in every cloud pin the tie rule (the lower point wins, as torch.max)."""
+    import os
     from puzzlenet_amd import _lib, ops
+    if os.environ.get("PZN_OUTPROJ_FUSED", "1") == "0":
+        pytest.skip("the tuning switch PZN_OUTPROJ_FUSED=0 turns this kernel off (it then reports PZN_E_UNSUPPORTED)")
     L, E, Nout = 256, 256, 1024
     M = B * L
     g = torch.Generator().manual_seed(21 + B)
