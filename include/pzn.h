@@ -466,6 +466,19 @@ int pzn_attn_fused_wgrads(const float* dz, const float* t, const float* dq, cons
 int pzn_cloud_bias_relu_f32(float* y, const float* cb, int B, int N, int C, pzn_stream_t stream);
 int pzn_cloud_gated_colsum_f32(const float* dy, const float* y, int B, int N, int C, float* dcb, pzn_stream_t stream);
 
+/* The per-point MLP chains of the boundary heads as ONE launch each way (csrc/pointmlp.hip; replaces the three
+ * nn.Linear (+ ReLU) launches of nn.Sequential at model5_b.py:571-592 as called at :738-739, :751-754):
+ *   y = (relu(relu(x W1^T + b1) W2^T + b2)) W3^T + b3  on M rows of 64 floats, h1 / h2 = the hidden activations.
+ * Chains: 64 -> 64 -> 64 -> 64 (C2 = C3 = 64) and 64 -> 64 -> 32 -> 2 (C2 = 32, C3 = 2); W1[64, ldw1] may be a column
+ * slice of a wider matrix (ldw1 >= 64); b1 is [64], or with b1_per_cloud != 0 one row of 64 per cloud of rows_per_cloud
+ * rows (the folded global half of a head's first layer, see pzn_cloud_bias_relu_f32).  M % 32 == 0, 16-byte aligned
+ * operands; PZN_EUNSUPPORTED for other chains (compose pzn_linear_* then). */
+int pzn_point_mlp3_supported(int C0, int C1, int C2, int C3);
+int pzn_point_mlp3_fwd_f32(const float* x, long long M, int rows_per_cloud, const float* W1, int ldw1,
+                           const float* b1, int b1_per_cloud, const float* W2, const float* b2,
+                           const float* W3, const float* b3, int C2, int C3, float* h1, float* h2,
+                           float* y, pzn_stream_t stream);
+
 /* The encoder's out projection and the max over the points in ONE launch (model5_b.py:466-475):
  *   out[b,l,:] = cat(x[0] .. x[nslice-1])[b,l,:] W^T + bias   (W[Nout, nslice*E]; the concatenation is never built),
  *   fmax[b,:] = max_l out[b,l,:],  arg[b,:] = its point (the lowest one on ties, as torch.max).

@@ -14,6 +14,7 @@ _c_f = ctypes.c_void_p      # device pointers travel as raw addresses
 _c_i = ctypes.c_int
 _c_sz = ctypes.c_size_t
 _c_fl = ctypes.c_float
+_c_ll = ctypes.c_longlong
 _PP = ctypes.POINTER(ctypes.c_void_p)   # array of device pointers (one per problem)
 
 # name -> (restype, argtypes); mirrors include/pzn.h one to one.
@@ -99,6 +100,8 @@ SIGNATURES = {
     "pzn_sa_level_fwd_workspace_bytes": (_c_sz, [_c_i, _c_i]),
     "pzn_outproj_maxpts_workspace_bytes": (_c_sz, [_c_i] * 4),
     "pzn_cloud_bias_relu_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f]),
+    "pzn_point_mlp3_supported": (_c_i, [_c_i] * 4),
+    "pzn_point_mlp3_fwd_f32": (_c_i, [_c_f, _c_ll, _c_i, _c_f, _c_i, _c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f]),
     "pzn_cloud_gated_colsum_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_outproj_maxpts_fwd_f32": (_c_i, [_PP, _c_i, _c_f, _c_f] + [_c_i] * 4 + [_c_f] * 5),
     "pzn_sa_level_bwd_f32": (_c_i, [_c_f] * 8 + [_c_i] * 6 + [_c_f] * 5 + [_c_i, _c_f]),

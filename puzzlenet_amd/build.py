@@ -36,6 +36,7 @@ SOURCES = [
     ("attnfused.hip", NOSLP),
     ("salevel.hip", NOSLP),
     ("outproj.hip", NOSLP),
+    ("pointmlp.hip", NOSLP),
     ("poolbwd.hip", []),
     ("maxptsbwd.hip", NOSLP),
     ("wsgemm.hip", []),

@@ -220,6 +220,7 @@ _ATTN_FUSED = os.environ.get("PZN_ATTN_FUSED", "1") != "0"     # tuning aid: 0 =
 # (10.5 vs 10.2 ms per step): a single encoder's launch is 128 workgroups at one wavefront per SIMD, so the two streams
 # already fill the chip, and the joint launches take the stems' overlap away.
 _ATTN_DUAL = os.environ.get("PZN_ATTN_DUAL", "0") != "0"
+_EMD_OWN_STREAM = os.environ.get("PZN_EMD_OWN_STREAM", "0") != "0"   # tuning aid: the N x N EMD on a third stream
 _EMD_SIDE = int(os.environ.get("PZN_EMD_SIDE", "2"))     # tuning aid: 0 = the N x N EMD on the main stream, 1 = forked right after the pose head, 2 = after the heads (measured best)
 
 
@@ -281,6 +282,7 @@ class TouchedRegraster(_Base):
         self.MLPFpcb = _seq(128, 64, 32, 2)
         self.two_streams = True        # Encoder2 on a side stream (GPU only); False = everything on the current stream
         self._side_stream = None
+        self._emd_stream = None
         self.defer_emd_loss = False    # see training_step: the EMD term as a separate backward root (engine.TrainStep)
 
     # ------------------------------------------------------------------ forward
@@ -485,6 +487,10 @@ class TouchedRegraster(_Base):
             if _EMD_SIDE and self.two_streams and o.is_cuda and self._side_stream is not None:
                 cur = torch.cuda.current_stream()
                 side = self._side_stream
+                if _EMD_OWN_STREAM:      # not behind / in front of the second cloud's boundary head and its backward
+                    if self._emd_stream is None:
+                        self._emd_stream = torch.cuda.Stream()
+                    side = self._emd_stream
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     pose['emd'] = earth_mover_distance(pose['de_mrpc'], rpc, transpose=False)
