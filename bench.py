@@ -320,7 +320,8 @@ def main():
         dense_names = ("pzn_linear_fwd_f32", "pzn_linear_dgrad_f32", "pzn_linear_wgrad_f32", "pzn_linear_maxpool_fwd_f32",
                        "pzn_sharedmlp_max_fwd_f32", "pzn_attn_fwd_f32", "pzn_attn_bwd_f32", "pzn_attn_block_fwd_f32",
                        "pzn_attn_block_bwd_f32", "pzn_sa_level_fwd_f32", "pzn_sa_level_fwd_ws_f32", "pzn_outproj_maxpts_fwd_f32", "pzn_attn_fused_proj", "pzn_attn_fused_fwd",
-                       "pzn_attn_fused_bwd_q", "pzn_attn_fused_bwd_k", "pzn_attn_fused_wgrads", "pzn_linear_slice_fwd_f32")
+                       "pzn_attn_fused_bwd_q", "pzn_attn_fused_bwd_k", "pzn_attn_fused_wgrads", "pzn_linear_slice_fwd_f32",
+                       "pzn_point_mlp3_fwd_f32", "pzn_point_mlp3_bwd_f32")
         d_ms = sum(kern.get(k, (0, 0.0))[1] for k in dense_names) / prof_steps
         d_fl = sum(kern_flops.get(k, 0) for k in dense_names) / prof_steps
         d_n = sum(kern.get(k, (0, 0.0))[0] for k in dense_names) / prof_steps
@@ -328,8 +329,8 @@ def main():
         fam_traffic, fam_src = pmc_traffic("mfma_family_bytes_per_step", B, N)
         roofline_mfma_family = {
             "bound": "mfma",
-            "kernel": "all dense matrix-core launches of the step (ws_gemm_kernel, df_wgrad_kernel, gemm_kernel behind "
-                      "pzn_linear_* / pzn_attn_block_*): algorithmic 2*M*N*K over summed launch time; the sparse vector-ALU "
+            "kernel": "all dense matrix-core launches of the step (ws_gemm_kernel, df_wgrad_kernel, gemm_kernel, point_mlp3_* behind "
+                      "pzn_linear_* / pzn_attn_* / pzn_point_mlp3_*): algorithmic 2*M*N*K over summed launch time; the sparse vector-ALU "
                       "passes of the pooled backward (pool_dgrad / pool_wgrad) are NOT in this sum",
             "achieved": fam_ach, "peak": MFMA_X3_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fam_ach / MFMA_X3_PEAK_TFLOPS,
             "traffic": fam_traffic, "traffic_source": fam_src,

@@ -478,6 +478,15 @@ int pzn_point_mlp3_fwd_f32(const float* x, long long M, int rows_per_cloud, cons
                            const float* b1, int b1_per_cloud, const float* W2, const float* b2,
                            const float* W3, const float* b3, int C2, int C3, float* h1, float* h2,
                            float* y, pzn_stream_t stream);
+/* Backward of the chain in one pass + a fixed-order sum of its partial results (timing-independent output):
+ * dx[M, 64], dW1[64, ldw1] (columns 0..63 written), dW2[C2, 64], dW3[C3, C2], db2[C2], db3[C3] and db1 — [64], or with
+ * b1_per_cloud != 0 one row of 64 per cloud (the gradient of the per-cloud bias) —, all OVERWRITTEN; x, h1, h2 as the
+ * forward left them; workspace of pzn_point_mlp3_bwd_workspace_bytes() bytes (0 = unsupported shape). */
+size_t pzn_point_mlp3_bwd_workspace_bytes(long long M, int rows_per_cloud, int b1_per_cloud, int C2, int C3);
+int pzn_point_mlp3_bwd_f32(const float* dy, const float* x, const float* h1, const float* h2, long long M,
+                           int rows_per_cloud, const float* W1, int ldw1, int b1_per_cloud, const float* W2,
+                           const float* W3, int C2, int C3, float* dx, float* dW1, float* db1, float* dW2,
+                           float* db2, float* dW3, float* db3, void* workspace, pzn_stream_t stream);
 
 /* The encoder's out projection and the max over the points in ONE launch (model5_b.py:466-475):
  *   out[b,l,:] = cat(x[0] .. x[nslice-1])[b,l,:] W^T + bias   (W[Nout, nslice*E]; the concatenation is never built),

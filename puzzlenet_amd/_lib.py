@@ -101,6 +101,8 @@ SIGNATURES = {
     "pzn_outproj_maxpts_workspace_bytes": (_c_sz, [_c_i] * 4),
     "pzn_cloud_bias_relu_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f]),
     "pzn_point_mlp3_supported": (_c_i, [_c_i] * 4),
+    "pzn_point_mlp3_bwd_workspace_bytes": (_c_sz, [_c_ll, _c_i, _c_i, _c_i, _c_i]),
+    "pzn_point_mlp3_bwd_f32": (_c_i, [_c_f] * 4 + [_c_ll, _c_i, _c_f, _c_i, _c_i, _c_f, _c_f, _c_i, _c_i] + [_c_f] * 9),
     "pzn_point_mlp3_fwd_f32": (_c_i, [_c_f, _c_ll, _c_i, _c_f, _c_i, _c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f]),
     "pzn_cloud_gated_colsum_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_outproj_maxpts_fwd_f32": (_c_i, [_PP, _c_i, _c_f, _c_f] + [_c_i] * 4 + [_c_f] * 5),

@@ -233,9 +233,26 @@ def _seq(*dims):
     return nn.Sequential(*layers)
 
 
+def _chain3(mods, x, cin):
+    """(Linear, ReLU, Linear, ReLU, Linear) on [B, N, 64] rows that csrc/pointmlp.hip runs as one launch each way
+    (the boundary heads' chains: 64 -> 64 -> 64 -> 64 and (64 |) 64 -> 64 -> 32 -> 2); None otherwise."""
+    if not (len(mods) == 5 and isinstance(mods[1], nn.ReLU) and isinstance(mods[3], nn.ReLU)
+            and all(isinstance(mods[i], nn.Linear) and mods[i].bias is not None for i in (0, 2, 4))
+            and x.is_cuda and x.dim() == 3 and x.dtype == torch.float32 and x.shape[1] % 32 == 0):
+        return None
+    l1, l2, l3 = mods[0], mods[2], mods[4]
+    if l1.in_features != cin or l2.in_features != l1.out_features or l3.in_features != l2.out_features:
+        return None
+    return (l1, l2, l3) if ops.point_mlp3_available(x.shape[2], l1.out_features, l2.out_features, l3.out_features) else None
+
+
 def _run_seq(seq, x):
     """nn.Sequential(Linear, ReLU, Linear, ...) through the fused linear(+ReLU) kernel."""
     mods = list(seq)
+    ch = _chain3(mods, x, x.shape[-1])
+    if ch is not None:
+        l1, l2, l3 = ch
+        return ops.point_mlp3(x, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias)
     i = 0
     while i < len(mods):
         lin = mods[i]
@@ -250,6 +267,10 @@ def _run_seq_cat_global(seq, x, g):
     mods = list(seq)
     if not (len(mods) >= 2 and isinstance(mods[1], nn.ReLU)):
         return _run_seq(seq, torch.cat([g.expand(-1, x.shape[1], -1), x], dim=-1))
+    ch = _chain3(mods, x, g.shape[-1] + x.shape[-1])
+    if ch is not None:
+        l1, l2, l3 = ch
+        return ops.point_mlp3(x, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, g=g)
     y = ops.cat_global_linear_relu(x, g, mods[0].weight, mods[0].bias)
     return _run_seq(mods[2:], y)
 

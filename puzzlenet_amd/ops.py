@@ -742,6 +742,85 @@ def cat_global_linear_relu(x, g, weight, bias):
     return _CatGlobalLinearRelu.apply(x, g, weight, bias)
 
 
+class _PointMlp3(torch.autograd.Function):
+    """Three Linear layers with ReLU after the first two on [B, N, 64] rows, one launch each way (csrc/pointmlp.hip):
+    nn.Sequential(Linear, ReLU, Linear, ReLU, Linear) of the boundary heads (model5_b.py:571-592, 738-739, 751-754).
+    g is None: 64 -> 64 -> C2 -> C3 as it stands.  g[B, Cg] (or [B, 1, Cg]): the first layer acts on
+    cat([g.repeat(1, N, 1), x], -1) (model5_b.py:745-749) — its global half becomes a per-cloud bias g W1[:, :Cg]^T + b1,
+    whose gradient (the per-cloud column sums of the first gated gradient) the backward pass returns with the rest."""
+
+    @staticmethod
+    def forward(ctx, x, g, w1, b1, w2, b2, w3, b3):
+        x = _f32(x, "x")
+        w1, b1, w2, b2, w3, b3 = (_f32(t, n) for t, n in ((w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2"), (w3, "w3"), (b3, "b3")))
+        B, N, C = x.shape
+        M, C2, C3 = B * N, w2.shape[0], w3.shape[0]
+        dev = x.device
+        mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        x2 = x.reshape(M, C)
+        h1, h2, y = mk(M, 64), mk(M, C2), mk(M, C3)
+        Cg = 0
+        g2 = w_g = None
+        with _on(dev):
+            st = _stream()
+            if g is not None:
+                g2 = _f32(g, "g").reshape(B, -1)
+                Cg = g2.shape[1]
+                if w1.shape[1] != Cg + C:
+                    raise _lib.PznError(f"point_mlp3: w1{tuple(w1.shape)} vs {Cg} + {C} input columns")
+                w_g = w1[:, :Cg].contiguous()
+                bias1 = mk(B, 64)
+                _call("pzn_linear_fwd_f32", _p(g2), _p(w_g), _p(b1), B, Cg, 64, 0, _p(bias1), st, flops=2 * B * Cg * 64)
+            else:
+                bias1 = b1
+            _call("pzn_point_mlp3_fwd_f32", _p(x2), M, N, _p(w1) + 4 * Cg, w1.shape[1], _p(bias1), 1 if g is not None else 0,
+                  _p(w2), _p(b2), _p(w3), _p(b3), C2, C3, _p(h1), _p(h2), _p(y), st,
+                  flops=2 * M * (64 * 64 + 64 * C2 + C2 * C3))
+        ctx.save_for_backward(x2, g2, w_g, w1, w2, w3, h1, h2)
+        ctx.dims = (B, N, C2, C3, Cg)
+        ctx.g_shape = None if g is None else g.shape
+        return y.view(B, N, C3)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g2, w_g, w1, w2, w3, h1, h2 = ctx.saved_tensors
+        B, N, C2, C3, Cg = ctx.dims
+        M = B * N
+        dev = x2.device
+        dy = _f32(dy, "dy").reshape(M, C3)
+        mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        per_cloud = 1 if g2 is not None else 0
+        nws = _lib.load().pzn_point_mlp3_bwd_workspace_bytes(M, N, per_cloud, C2, C3)
+        ws = torch.empty((max(16, nws),), dtype=torch.uint8, device=dev)
+        dx, dW1, dW2, dW3, db2, db3 = mk(M, 64), mk(64, Cg + 64), mk(C2, 64), mk(C3, C2), mk(C2), mk(C3)
+        db1 = mk(B, 64) if per_cloud else mk(64)
+        dg = None
+        with _on(dev):
+            st = _stream()
+            _call("pzn_point_mlp3_bwd_f32", _p(dy), _p(x2), _p(h1), _p(h2), M, N, _p(w1) + 4 * Cg, Cg + 64, per_cloud, _p(w2),
+                  _p(w3), C2, C3, _p(dx), _p(dW1) + 4 * Cg, _p(db1), _p(dW2), _p(db2), _p(dW3), _p(db3), _p(ws), st,
+                  flops=4 * M * (64 * 64 + 64 * C2 + C2 * C3))
+            if per_cloud:       # the global half of the first layer: [B, Cg] products on the per-cloud bias gradient
+                dcb, db1 = db1, mk(64)
+                dWg = mk(64, Cg)
+                _call("pzn_linear_wgrad_f32", _p(dcb), None, _p(g2), B, Cg, 64, _p(dWg), _p(db1), 0, st, flops=2 * B * Cg * 64)
+                dW1[:, :Cg] = dWg
+                if ctx.needs_input_grad[1]:
+                    dg = mk(B, Cg)
+                    _call("pzn_linear_dgrad_f32", _p(dcb), None, _p(w_g), B, Cg, 64, None, _p(dg), st, flops=2 * B * Cg * 64)
+                    dg = dg.view(ctx.g_shape)
+        return dx.view(B, N, 64), dg, dW1, db1, dW2, db2, dW3, db3
+
+
+def point_mlp3_available(C0, C1, C2, C3):
+    return bool(_lib.load().pzn_point_mlp3_supported(int(C0), int(C1), int(C2), int(C3)))
+
+
+def point_mlp3(x, w1, b1, w2, b2, w3, b3, g=None):
+    """(relu(relu([g |] x) W1^T + b1) W2^T + b2) W3^T + b3 on [B, N, 64] rows; see _PointMlp3."""
+    return _PointMlp3.apply(x, g, w1, b1, w2, b2, w3, b3)
+
+
 class _SharedMlpMax(torch.autograd.Function):
     """relu(x W1^T + b1) -> relu(. W2^T + b2) -> max over the K=32 axis (model5_b.py:452-454, 459-461)."""
 

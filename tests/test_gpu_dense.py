@@ -733,3 +733,70 @@ def test_sa_level_streamed_vs_float64(dev, B, N, S, C):
     assert float((a1 != a0).float().mean()) < 1e-4
     picked = ref.view(R, 32, C).gather(1, a1.long().unsqueeze(1)).squeeze(1)
     assert float((picked - rmax).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("B,N,C2,C3,per_cloud", [(2, 64, 64, 64, False), (3, 96, 32, 2, True), (3, 160, 64, 64, False),
+                                                  (4, 2048, 32, 2, True), (5, 2048, 64, 64, False), (1, 32, 32, 2, True)])
+def test_point_mlp3_vs_float64(dev, B, N, C2, C3, per_cloud):
+    """csrc/pointmlp.hip through ops.point_mlp3: the boundary heads' three-layer chains (model5_b.py:571-592, 738-754) in one
+    launch each way against float64 autograd — output and every gradient, with the global half of the first layer
+    (per_cloud: cat([g.repeat(1, N, 1), x], -1), :745-749) folded into a per-cloud bias.  Sizes cover one tile per
+    wavefront, several tiles per wavefront (the walk with the next operands in flight) and a lone tile."""
+    from puzzlenet_amd import ops
+    if not ops.point_mlp3_available(64, 64, C2, C3):
+        pytest.skip("PZN_POINT_MLP=0 turns the fused chains off")
+    g = torch.Generator().manual_seed(7 + C2 + B)
+    x = torch.randn(B, N, 64, generator=g)
+    gl = torch.randn(B, 1, 64, generator=g) if per_cloud else None
+    W1 = torch.randn(64, 128 if per_cloud else 64, generator=g) / 8
+    b1 = 0.1 * torch.randn(64, generator=g)
+    W2, b2 = torch.randn(C2, 64, generator=g) / 8, 0.1 * torch.randn(C2, generator=g)
+    W3, b3 = torch.randn(C3, C2, generator=g) / C2 ** 0.5, 0.1 * torch.randn(C3, generator=g)
+    go = torch.randn(B, N, C3, generator=g)
+    leaves = [x, W1, b1, W2, b2, W3, b3] + ([gl] if per_cloud else [])
+    ref = [t.double().requires_grad_(True) for t in leaves]
+    xin = torch.cat([ref[7].expand(-1, N, -1), ref[0]], -1) if per_cloud else ref[0]
+    yr = F.linear(F.relu(F.linear(F.relu(F.linear(xin, ref[1], ref[2])), ref[3], ref[4])), ref[5], ref[6])
+    (yr * go.double()).sum().backward()
+    d = [t.to(dev).requires_grad_(True) for t in leaves]
+    y = ops.point_mlp3(d[0], d[1], d[2], d[3], d[4], d[5], d[6], g=d[7] if per_cloud else None)
+    assert y.shape == (B, N, C3)
+    assert _rel(y, yr) < 1e-5
+    (y * go.to(dev)).sum().backward()
+    for name, a, r in zip(("x", "W1", "b1", "W2", "b2", "W3", "b3", "g"), d, ref):
+        assert _rel(a.grad, r.grad) < 2e-5, name
+    # the same result on a second call (fixed summation order of the partial sums)
+    first = [t.grad.clone() for t in d]
+    for t in d:
+        t.grad = None
+    (ops.point_mlp3(d[0], d[1], d[2], d[3], d[4], d[5], d[6], g=d[7] if per_cloud else None) * go.to(dev)).sum().backward()
+    for a, f in zip(d, first):
+        assert torch.equal(a.grad, f)
+
+
+def test_point_mlp3_matches_layer_by_layer(dev):
+    """The fused chain against the three ops.linear launches it replaces on the heads' full shape (64 x 2048 rows):
+    same arithmetic (bf16x3 products, fp32 sums), different summation order only."""
+    from puzzlenet_amd import ops
+    if not ops.point_mlp3_available(64, 64, 64, 64):
+        pytest.skip("PZN_POINT_MLP=0 turns the fused chains off")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(64, 2048, 64, generator=g).to(dev)
+    ws = [(torch.randn(64, 64, generator=g) / 8).to(dev) for _ in range(3)]
+    bs = [(0.1 * torch.randn(64, generator=g)).to(dev) for _ in range(3)]
+    go = torch.randn(64, 2048, 64, generator=g).to(dev)
+    outs = []
+    for fused in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in [x] + ws + bs]
+        xx, w, b = leaves[0], leaves[1:4], leaves[4:7]
+        if fused:
+            y = ops.point_mlp3(xx, w[0], b[0], w[1], b[1], w[2], b[2])
+        else:
+            y = ops.linear(ops.linear(ops.linear(xx, w[0], b[0], True), w[1], b[1], True), w[2], b[2], False)
+        (y * go).sum().backward()
+        outs.append([y.detach()] + [t.grad for t in leaves])
+    for name, a, r in zip(("y", "dx", "dW1", "dW2", "dW3", "db1", "db2", "db3"), outs[0], outs[1]):
+        # a ReLU gate within rounding of zero may fall differently in the two summation orders: a handful of hidden units,
+        # each of which changes one row (64 elements) of dx
+        bad = ((a - r).abs() > 1e-4 * r.abs().max()).sum().item()
+        assert bad <= (64 if name == "dx" else 1) * max(2, a.numel() // 500000), (name, bad)

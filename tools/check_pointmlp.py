@@ -71,5 +71,49 @@ def run(B, N, C2, C3, per_cloud):
     print()
 
 
+def run_bwd(B, N, C2, C3, per_cloud):
+    """ops.point_mlp3 forward + backward against float64 autograd, and its time against the layer-by-layer path."""
+    g = torch.Generator().manual_seed(7 + C2 + B)
+    x = torch.randn(B, N, 64, generator=g)
+    gl = torch.randn(B, 1, 64, generator=g) if per_cloud else None
+    W1 = torch.randn(64, 128 if per_cloud else 64, generator=g) / 8
+    b1 = 0.1 * torch.randn(64, generator=g)
+    W2, b2 = torch.randn(C2, 64, generator=g) / 8, 0.1 * torch.randn(C2, generator=g)
+    W3, b3 = torch.randn(C3, C2, generator=g) / C2 ** 0.5, 0.1 * torch.randn(C3, generator=g)
+    go = torch.randn(B, N, C3, generator=g)
+    leaves = [x, W1, b1, W2, b2, W3, b3] + ([gl] if per_cloud else [])
+    ref = [t.double().requires_grad_(True) for t in leaves]
+    xin = torch.cat([ref[7].expand(-1, N, -1), ref[0]], -1) if per_cloud else ref[0]
+    h2r = F.relu(F.linear(F.relu(F.linear(xin, ref[1], ref[2])), ref[3], ref[4]))
+    yr = F.linear(h2r, ref[5], ref[6])
+    gate_h2 = h2r.detach() > 0
+    (yr * go.double()).sum().backward()
+    d = [t.to(dev).requires_grad_(True) for t in leaves]
+    y = ops.point_mlp3(d[0], d[1], d[2], d[3], d[4], d[5], d[6], g=d[7] if per_cloud else None)
+    (y * go.to(dev)).sum().backward()
+    names = ["x", "W1", "b1", "W2", "b2", "W3", "b3", "g"]
+    errs = " ".join(f"{n} {rel(a.grad, r.grad):.1e}" for n, a, r in zip(names, d, ref))
+    print(f"bwd B={B} N={N} ->{C2}->{C3} per_cloud={per_cloud}: y {rel(y, yr):.1e} | grads {errs}", end="")
+    if B * N >= 65536:
+        god = go.to(dev)
+
+        def fused():
+            for t in d:
+                t.grad = None
+            (ops.point_mlp3(d[0], d[1], d[2], d[3], d[4], d[5], d[6], g=d[7] if per_cloud else None) * god).sum().backward()
+
+        def composed():
+            for t in d:
+                t.grad = None
+            a = ops.cat_global_linear_relu(d[0], d[7], d[1], d[2]) if per_cloud else ops.linear(d[0], d[1], d[2], True)
+            a = ops.linear(a, d[3], d[4], True)
+            (ops.linear(a, d[5], d[6], False) * god).sum().backward()
+        print(f" | fwd+bwd fused {timeit(fused):.0f} us, layer by layer {timeit(composed):.0f} us", end="")
+    print()
+
+
 for cfg in [(2, 64, 64, 64, False), (3, 96, 32, 2, True), (5, 2048, 64, 64, False), (64, 2048, 64, 64, False), (64, 2048, 32, 2, True)]:
     run(*cfg)
+for cfg in [(2, 64, 64, 64, False), (3, 96, 32, 2, True), (4, 2048, 32, 2, True), (3, 160, 64, 64, False), (64, 2048, 64, 64, False),
+            (64, 2048, 32, 2, True)]:
+    run_bwd(*cfg)
