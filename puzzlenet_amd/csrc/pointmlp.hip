@@ -256,24 +256,41 @@ __device__ __forceinline__ void pm_dma_tile(const float* __restrict__ g, float* 
 }
 __device__ __forceinline__ void pm_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// The lane's share of those addresses, computed once per kernel (left in the loop, the swizzle arithmetic was a fifth of the
+// backward pass's instructions); everything else is an immediate offset.  All in dwords.
+template <int F>
+struct PmOff {
+  int fo[8];   // fragment of a sum over points: point 8 h + j, feature r          (+ 16 s F + 32 ot)
+  int go[4];   // D layout <-> tile: row r, chunk 2 g + h                           (+ 32 ft)
+  int co[8];   // column sums, lane = feature: point j                              (+ 8 a F)
+  __device__ __forceinline__ PmOff(int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      fo[j] = (8 * h + j) * F + 4 * ((r >> 2) ^ j) + (r & 3);
+      co[j] = j * F + 4 * (((lane >> 2) & (F / 4 - 1)) ^ j) + (lane & 3);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) go[g] = r * F + 4 * ((2 * g + h) ^ (r & 7));
+  }
+};
+
 template <int NFT, int F>
-__device__ __forceinline__ void pm_put_sw(float* stg, const floatx16* x, int lane) {
-  const int r = lane & 31, h = lane >> 5;
+__device__ __forceinline__ void pm_put_sw(float* stg, const floatx16* x, const PmOff<F>& o) {
 #pragma unroll
   for (int ft = 0; ft < NFT; ++ft)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      *reinterpret_cast<pm_f4*>(stg + pm_sw<F>(r, 32 * ft + 8 * g + 4 * h)) =
+      *reinterpret_cast<pm_f4*>(stg + o.go[g] + 32 * ft) =
           pm_f4{x[ft][4 * g], x[ft][4 * g + 1], x[ft][4 * g + 2], x[ft][4 * g + 3]};
 }
 template <int NFT, int F>
-__device__ __forceinline__ void pm_get_sw(const float* stg, floatx16* x, int lane) {
-  const int r = lane & 31, h = lane >> 5;
+__device__ __forceinline__ void pm_get_sw(const float* stg, floatx16* x, const PmOff<F>& o) {
 #pragma unroll
   for (int ft = 0; ft < NFT; ++ft)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const pm_f4 v = *reinterpret_cast<const pm_f4*>(stg + pm_sw<F>(r, 32 * ft + 8 * g + 4 * h));
+      const pm_f4 v = *reinterpret_cast<const pm_f4*>(stg + o.go[g] + 32 * ft);
       x[ft][4 * g] = v[0], x[ft][4 * g + 1] = v[1], x[ft][4 * g + 2] = v[2], x[ft][4 * g + 3] = v[3];
     }
 }
@@ -292,23 +309,25 @@ __device__ __forceinline__ void pm_sw_to_rows(const float* stg, float* g, int la
   for (int i = 0; i < F / 8; ++i) g4[i * 64 + lane] = v[i];
 }
 // fragment of a product that sums over the POINTS (k-step s = points 16 s .. 16 s + 15): lane (r, h) takes feature
-// f0 + r of points 16 s + 8 h + j, j = 0..7, from a row-major tile; three planes
+// 32 ot + r of points 16 s + 8 h + j, j = 0..7, from a row-major tile; three planes
 template <int F>
-__device__ __forceinline__ void pm_point_frag(const float* stg, int f, int s, int h, bf16x8 (&b)[3]) {
+__device__ __forceinline__ void pm_point_frag(const float* stg, int ot, int s, const PmOff<F>& o, bf16x8 (&b)[3]) {
   float v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = stg[pm_sw<F>(16 * s + 8 * h + j, f)];
+  for (int j = 0; j < 8; ++j) v[j] = stg[o.fo[j] + 16 * s * F + 32 * ot];
   split8(v, b);
 }
-// column sums of a tile: lane = feature (< F)
+// column sums of a tile: lane = feature (< F); four chains
 template <int F>
-__device__ __forceinline__ float pm_colsum(const float* stg, int lane) {
-  float s = 0.f;
+__device__ __forceinline__ float pm_colsum(const float* stg, int lane, const PmOff<F>& o) {
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
   if (F == 64 || lane < F) {
 #pragma unroll
-    for (int p = 0; p < 32; ++p) s += stg[pm_sw<F>(p, lane)];
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j & 3] += stg[o.co[j] + 8 * a * F];
   }
-  return s;
+  return (s[0] + s[1]) + (s[2] + s[3]);
 }
 
 struct PmBwdArgs {
@@ -363,6 +382,9 @@ __global__ __launch_bounds__(256, 1) void point_mlp3_bwd_kernel(PmBwdArgs a) {
 #pragma unroll
     for (int j = 0; j < T2; ++j) ZERO16(dW3[i][j]);
   float db1 = 0.f, db2 = 0.f, db3 = 0.f;      // lane = feature
+  const PmOff<64> o1(lane);                    // tiles of 64 features (x, h1, G1, dx)
+  const PmOff<C2> o2(lane);                    // h2, G2
+  const PmOff<(C3 >= 32 ? C3 : 32)> o3(lane);  // dy (the two-column form is read directly)
 
   if (t0 < t1) {
     if constexpr (C3 >= 32) pm_dma_tile<C3>(a.dy + (long)t0 * 32 * C3, P, lane);
@@ -379,8 +401,8 @@ __global__ __launch_bounds__(256, 1) void point_mlp3_bwd_kernel(PmBwdArgs a) {
     floatx16 G3[T3], H2[T2];
     if constexpr (C3 >= 32) {
       pm_dma_wait();
-      pm_get_sw<T3, C3>(P, G3, lane);
-      db3 += pm_colsum<C3>(P, lane);
+      pm_get_sw<T3, C3>(P, G3, o3);
+      db3 += pm_colsum<C3>(P, lane, o3);
     } else {      // two columns: registers 0, 1 of the lanes with h = 0; the tile [32 points][2] for the point fragments
       ZERO16(G3[0]);
       const float2 d = h == 0 ? *reinterpret_cast<const float2*>(a.dy + (row0 + r) * 2) : make_float2(0.f, 0.f);
@@ -395,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void point_mlp3_bwd_kernel(PmBwdArgs a) {
         db3 += s;
       }
     }
-    pm_get_sw<T2, C2>(Q, H2, lane);
+    pm_get_sw<T2, C2>(Q, H2, o2);
     // dW3[o][i] += sum_p G3[p][o] h2[p][i]
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -403,7 +425,7 @@ __global__ __launch_bounds__(256, 1) void point_mlp3_bwd_kernel(PmBwdArgs a) {
 #pragma unroll
       for (int ot = 0; ot < T3; ++ot) {
         if constexpr (C3 >= 32) {
-          pm_point_frag<C3>(P, 32 * ot + r, s, h, fa[ot]);
+          pm_point_frag<C3>(P, ot, s, o3, fa[ot]);
         } else {
           float v[8];
 #pragma unroll
@@ -412,7 +434,7 @@ __global__ __launch_bounds__(256, 1) void point_mlp3_bwd_kernel(PmBwdArgs a) {
         }
       }
 #pragma unroll
-      for (int it = 0; it < T2; ++it) pm_point_frag<C2>(Q, 32 * it + r, s, h, fb[it]);
+      for (int it = 0; it < T2; ++it) pm_point_frag<C2>(Q, it, s, o2, fb[it]);
 #pragma unroll
       for (int ot = 0; ot < T3; ++ot)
 #pragma unroll
@@ -429,20 +451,20 @@ __global__ __launch_bounds__(256, 1) void point_mlp3_bwd_kernel(PmBwdArgs a) {
     for (int i = 0; i < T2; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) G2[i][e] = H2[i][e] > 0.f ? G2[i][e] : 0.f;
-    pm_put_sw<T2, C2>(P, G2, lane);
+    pm_put_sw<T2, C2>(P, G2, o2);
     pm_dma_wait();
     pzn::wave_lds_sync();
     // ---- layer 2
     floatx16 H1[2];
-    pm_get_sw<2, 64>(Q, H1, lane);
-    db2 += pm_colsum<C2>(P, lane);
+    pm_get_sw<2, 64>(Q, H1, o1);
+    db2 += pm_colsum<C2>(P, lane, o2);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 fa[T2][3], fb[2][3];
 #pragma unroll
-      for (int ot = 0; ot < T2; ++ot) pm_point_frag<C2>(P, 32 * ot + r, s, h, fa[ot]);
+      for (int ot = 0; ot < T2; ++ot) pm_point_frag<C2>(P, ot, s, o2, fa[ot]);
 #pragma unroll
-      for (int it = 0; it < 2; ++it) pm_point_frag<64>(Q, 32 * it + r, s, h, fb[it]);
+      for (int it = 0; it < 2; ++it) pm_point_frag<64>(Q, it, s, o1, fb[it]);
 #pragma unroll
       for (int ot = 0; ot < T2; ++ot)
 #pragma unroll
@@ -458,18 +480,18 @@ __global__ __launch_bounds__(256, 1) void point_mlp3_bwd_kernel(PmBwdArgs a) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) G1[i][e] = H1[i][e] > 0.f ? G1[i][e] : 0.f;
-    pm_put_sw<2, 64>(P, G1, lane);
+    pm_put_sw<2, 64>(P, G1, o1);
     pm_dma_wait();
     pzn::wave_lds_sync();
     // ---- layer 1
-    db1 += pm_colsum<64>(P, lane);
+    db1 += pm_colsum<64>(P, lane, o1);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 fa[2][3], fb[2][3];
 #pragma unroll
-      for (int ot = 0; ot < 2; ++ot) pm_point_frag<64>(P, 32 * ot + r, s, h, fa[ot]);
+      for (int ot = 0; ot < 2; ++ot) pm_point_frag<64>(P, ot, s, o1, fa[ot]);
 #pragma unroll
-      for (int it = 0; it < 2; ++it) pm_point_frag<64>(Q, 32 * it + r, s, h, fb[it]);
+      for (int it = 0; it < 2; ++it) pm_point_frag<64>(Q, it, s, o1, fb[it]);
 #pragma unroll
       for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -481,7 +503,7 @@ __global__ __launch_bounds__(256, 1) void point_mlp3_bwd_kernel(PmBwdArgs a) {
     ZERO16(DX[0]);
     ZERO16(DX[1]);
     pm_layer<2, 4>(DX, G1, img1, lane);
-    pm_put_sw<2, 64>(P, DX, lane);
+    pm_put_sw<2, 64>(P, DX, o1);
     pzn::wave_lds_sync();
     pm_sw_to_rows<64>(P, a.dx + row0 * 64, lane);
     pzn::wave_lds_sync();

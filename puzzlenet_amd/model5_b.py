@@ -220,7 +220,7 @@ _ATTN_FUSED = os.environ.get("PZN_ATTN_FUSED", "1") != "0"     # tuning aid: 0 =
 # (10.5 vs 10.2 ms per step): a single encoder's launch is 128 workgroups at one wavefront per SIMD, so the two streams
 # already fill the chip, and the joint launches take the stems' overlap away.
 _ATTN_DUAL = os.environ.get("PZN_ATTN_DUAL", "0") != "0"
-_EMD_OWN_STREAM = os.environ.get("PZN_EMD_OWN_STREAM", "0") != "0"   # tuning aid: the N x N EMD on a third stream
+_EMD_OWN_STREAM = int(os.environ.get("PZN_EMD_OWN_STREAM", "0"))   # tuning aid: 1 = the N x N EMD on a third stream, 2 = a high-priority one
 _EMD_SIDE = int(os.environ.get("PZN_EMD_SIDE", "2"))     # tuning aid: 0 = the N x N EMD on the main stream, 1 = forked right after the pose head, 2 = after the heads (measured best)
 
 
@@ -510,7 +510,7 @@ class TouchedRegraster(_Base):
                 side = self._side_stream
                 if _EMD_OWN_STREAM:      # not behind / in front of the second cloud's boundary head and its backward
                     if self._emd_stream is None:
-                        self._emd_stream = torch.cuda.Stream()
+                        self._emd_stream = torch.cuda.Stream(priority=-1 if _EMD_OWN_STREAM == 2 else 0)
                     side = self._emd_stream
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
