@@ -42,7 +42,21 @@ def rig():
 
     def chain():      # the four blocks of an encoder as chained kernels (csrc/attnfused.hip: AGPR accumulators) + out projection
         return ops.attention_chain_fused([xa], [[tuple(aw)] * 4], [wg], [bg])[0]
+    # a boundary-head chain forward + backward (csrc/pointmlp.hip: LDS-DMA staging tiles, AGPR accumulators, partial sums)
+    pm_w = [(torch.randn(o, i, generator=g) / 8).to(dev) for o, i in ((64, 128), (64, 64), (32, 64), (2, 32))][1:]
+    pm_w1 = (torch.randn(64, 128, generator=g) / 8).to(dev)
+    pm_b = [torch.randn(o, generator=g).to(dev) for o in (64, 32, 2)]
+    pm_x, pm_g = torch.randn(16, 2048, 64, generator=g).to(dev), torch.randn(16, 1, 64, generator=g).to(dev)
+    pm_go = torch.randn(16, 2048, 2, generator=g).to(dev)
+
+    def point_mlp():
+        with torch.enable_grad():
+            leaves = [t.detach().requires_grad_(True) for t in (pm_x, pm_g, pm_w1, pm_b[0], pm_w[1], pm_b[1], pm_w[2], pm_b[2])]
+            y = ops.point_mlp3(leaves[0], leaves[2], leaves[3], leaves[4], leaves[5], leaves[6], leaves[7], g=leaves[1])
+            grads = torch.autograd.grad(y, leaves, pm_go)
+        return torch.cat([y.detach().reshape(-1)] + [t.reshape(-1) for t in grads])
     victims = {
+        "point_mlp3": point_mlp,
         "knn": lambda: ops.knn(xyz, new_xyz, 32),
         "knn_group": lambda: ops.knn_group(xyz, feat, new_xyz)[0],
         "fps": lambda: ops.farthest_point_sample(xyz, 256, torch.zeros(B, dtype=torch.long, device=dev)),
@@ -71,8 +85,12 @@ def rig():
         with torch.cuda.stream(side):
             chain()
 
+    def agg_point_mlp():
+        with torch.cuda.stream(side):
+            point_mlp()
+
     return dev, side, victims, {"general_engine": agg_general, "sa_level": agg_level, "attention_block": agg_attention,
-                                "attention_fused": agg_chain}
+                                "attention_fused": agg_chain, "point_mlp3": agg_point_mlp}
 
 
 def _trace(line):
@@ -82,7 +100,7 @@ def _trace(line):
             f.write(line + "\n")
 
 
-@pytest.mark.parametrize("aggressor", ["general_engine", "sa_level", "attention_block", "attention_fused"])
+@pytest.mark.parametrize("aggressor", ["general_engine", "sa_level", "attention_block", "attention_fused", "point_mlp3"])
 def test_results_do_not_depend_on_the_other_stream(rig, aggressor):
     dev, side, victims, aggressors = rig
     ag = aggressors[aggressor]
