@@ -12,6 +12,8 @@ its counters with `hipMemsetAsync`; captured as memset NODES those ran out of st
 (tools/hip_graph_memset_repro.py shows the same defect in isolation), so the select read stale counters and produced
 garbage indices.  DESIGN.md §7 keeps the record.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -28,7 +30,7 @@ def late_gradient(name):
 
 
 class TrainStep:
-    def __init__(self, model, batch, lr, world=1, use_graph=False, warmup=0):
+    def __init__(self, model, batch, lr, world=1, use_graph=False, warmup=0, prefetch=None):
         if use_graph:
             raise _lib.PznError("the HIP-graph step was removed (slower than eager and unsafe with torch.topk's memset "
                                 "nodes on this runtime): see puzzlenet_amd/engine.py")
@@ -46,6 +48,8 @@ class TrainStep:
         # Adam + StepLR(50, 0.999) over flat buffers: one launch per step (distributed.FlatAdam; model5_b.py:1453-1457)
         self.opt = pdist.FlatAdam(self.grads, lr, sched_step=50, sched_gamma=0.999)
         self.loss = None
+        self.prefetch = os.environ.get("PZN_PLAN_PREFETCH", "1") != "0" if prefetch is None else bool(prefetch)
+        self._plans_ahead = None
         self._saved_defer = getattr(model, "defer_emd_loss", False)
         model.defer_emd_loss = True
 
@@ -89,16 +93,33 @@ class TrainStep:
             cur.wait_stream(side)
         return loss
 
-    def step(self):
+    def step(self, next_batch=None):
+        """One training step on self.batch.  next_batch: the batch of the FOLLOWING step when it differs (a data loader);
+        this runner then moves on to it.  With `prefetch` the coordinate-only part of the following step (FPS, centroid
+        gathers, neighbour searches: model.prefetch_plans) is enqueued first, on a background stream, and runs beside
+        this step's kernels instead of standing at the head of the next step; this step uses the plan the previous one
+        left.  Work per step is unchanged (one sampling pass per step), only its place in the queue."""
+        model = self.model
+        if self.prefetch and hasattr(model, "prefetch_plans"):
+            if self._plans_ahead is None:      # first step: its own plan first (the start indices keep their order of draw)
+                self._plans_ahead = model.prefetch_plans(self.batch[0], self.batch[1])
+            model.use_plans(self._plans_ahead)
+            nb = self.batch if next_batch is None else next_batch
+            self._plans_ahead = model.prefetch_plans(nb[0], nb[1])
         self.loss = self._fwd_bwd()
         if self.world > 1:          # (an extra single-rank runner inside a multi-rank job must not join collectives)
             self.grads.all_reduce_mean()
         self.opt.step()
+        if next_batch is not None:
+            self.batch = next_batch
         return self.loss
 
     def close(self):
         """Give the model back as it was handed in (a later direct model.training_step() returns {'loss': ...} again)."""
         self.model.defer_emd_loss = self._saved_defer
+        self._plans_ahead = None
+        if hasattr(self.model, "use_plans"):
+            self.model.use_plans(None)
         if self._saved_hooks is not None:
             self.model.Encoder.f2f_grad_hook, self.model.Encoder2.f2f_grad_hook = self._saved_hooks
             self._saved_hooks = None

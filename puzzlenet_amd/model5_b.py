@@ -304,6 +304,8 @@ class TouchedRegraster(_Base):
         self.two_streams = True        # Encoder2 on a side stream (GPU only); False = everything on the current stream
         self._side_stream = None
         self._emd_stream = None
+        self._plan_stream = None
+        self._plan_cache = None        # (fpc, mrpc, plans, event) from prefetch_plans, handed over by use_plans
         self.defer_emd_loss = False    # see training_step: the EMD term as a separate backward root (engine.TrainStep)
 
     # ------------------------------------------------------------------ forward
@@ -340,12 +342,19 @@ class TouchedRegraster(_Base):
                     _quiet(False)
             side = self._side_stream
             side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                plan_f, plan_m = self._sa_plans(fpc, mrpc)
-            xf_f = self.Encoder.local_features(fpc)
-            xf_m = self.Encoder2.local_features(mrpc)
-            cur.wait_stream(side)          # plans -> this stream
-            side.wait_stream(cur)          # xf_m -> side stream
+            taken = self._take_plans(fpc, mrpc, (cur, side))
+            if taken is not None:          # sampling + searches were done ahead (prefetch_plans): both encoders start at once
+                plan_f, plan_m = taken
+                with torch.cuda.stream(side):
+                    xf_m = self.Encoder2.local_features(mrpc)
+                xf_f = self.Encoder.local_features(fpc)
+            else:
+                with torch.cuda.stream(side):
+                    plan_f, plan_m = self._sa_plans(fpc, mrpc)
+                xf_f = self.Encoder.local_features(fpc)
+                xf_m = self.Encoder2.local_features(mrpc)
+                cur.wait_stream(side)          # plans -> this stream
+                side.wait_stream(cur)          # xf_m -> side stream
             if plan_f is not None:
                 for lvl in plan_f:
                     lvl[0].record_stream(cur)
@@ -449,7 +458,45 @@ class TouchedRegraster(_Base):
     def forward(self, batch, bat=None):
         return self.predict5(batch, bat)
 
-    def _sa_plans(self, fpc, mrpc):
+    def prefetch_plans(self, fpc, mrpc):
+        """The coordinate-only part of a LATER predict5(fpc, mrpc) call — the FPS chain, the centroid gathers and the two
+        neighbour searches of both clouds, none of which depends on a weight — enqueued now on a background stream, so
+        that it runs beside whatever the other streams are doing (engine.TrainStep calls it at the start of a step for
+        the next step's batch: FPS is 0.5 ms of latency-bound launches on 128 workgroups that otherwise stand at the head
+        of every step).  The start indices are drawn here, in the reference's order.  Returns the plan for use_plans();
+        predict5 picks it up when it is called with the same two tensors and computes it in place otherwise."""
+        if len(fpc.shape) == 2 or not (self.two_streams and fpc.is_cuda):
+            return None
+        if self._plan_stream is None:
+            self._plan_stream = torch.cuda.Stream()
+        ps = self._plan_stream
+        ps.wait_stream(torch.cuda.current_stream())       # the clouds exist
+        with torch.cuda.stream(ps):
+            plans = self._sa_plans(fpc, mrpc, with_knn=True)
+            ready = torch.cuda.Event()
+            ready.record(ps)
+        return (fpc, mrpc, plans, ready) if plans[0] is not None else None
+
+    def use_plans(self, prefetched):
+        """Hand a prefetch_plans() result to the next predict5 call (None: nothing prefetched)."""
+        self._plan_cache = prefetched
+
+    def _take_plans(self, fpc, mrpc, streams):
+        """The prefetched plan of exactly these tensors (once), made visible to `streams`; None if there is none."""
+        cached, self._plan_cache = self._plan_cache, None
+        if cached is None or cached[0] is not fpc or cached[1] is not mrpc:
+            return None
+        plans, ready = cached[2], cached[3]
+        for st in streams:
+            st.wait_event(ready)
+            for plan in plans:
+                for new_xyz, idx in plan:
+                    new_xyz.record_stream(st)
+                    if idx is not None:
+                        idx.record_stream(st)
+        return plans
+
+    def _sa_plans(self, fpc, mrpc, with_knn=False):
         """FPS -> gather of BOTH set-abstraction levels for BOTH clouds, hoisted in front of the
         encoders: the sampling chain depends on coordinates only, so the two encoders' 64-workgroup,
         latency-bound FPS launches become one 128-workgroup launch per level (same wall time each).  The four start-index draws are made first, in the
@@ -472,6 +519,9 @@ class TouchedRegraster(_Base):
         x1 = ops.index_points(xyz, f1)
         f2 = ops.farthest_point_sample(x1, 256, torch.cat([d2, d4]))
         x2 = ops.index_points(x1, f2)
+        if with_knn:      # (prefetch_plans) the searches too: coordinates only
+            i1, i2 = ops.knn(xyz, x1, 32), ops.knn(x1, x2, 32)
+            return ((x1[:B], i1[:B]), (x2[:B], i2[:B])), ((x1[B:], i1[B:]), (x2[B:], i2[B:]))
         # the neighbour search itself runs inside each encoder, fused with the group write (idx = None)
         return ((x1[:B], None), (x2[:B], None)), ((x1[B:], None), (x2[B:], None))
 

@@ -350,3 +350,46 @@ def test_se3_exp_kernel_vs_tensor_ops(dev):
     np.testing.assert_allclose(gd.detach().cpu().numpy(), gr.detach().numpy(), rtol=2e-6, atol=2e-7)
     (gd * wgt.to(dev)).sum().backward()
     np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=2e-6)
+
+
+def test_train_step_with_prefetched_sampling_plans(golden_loss, dev):
+    """engine.TrainStep enqueues the coordinate-only part of the NEXT step (FPS, centroid gathers, neighbour searches:
+    TouchedRegraster.prefetch_plans) on a background stream at the start of a step.  Same start-index draws in the same
+    order, same kernels, another place in the queue: the losses of three optimiser steps must be those of the runner
+    without it (to the run-to-run rounding of the atomically summed layers), and a runner fed a different batch for the
+    following step must pick that batch's plan up."""
+    from puzzlenet_amd import engine
+    from puzzlenet_amd import model5_b as mb
+    from puzzlenet_amd import ops
+    G = golden_loss
+    batch = [_t(G[f"ts_batch{i}"], dev) for i in range(8)]
+    batch2 = [t.clone() for t in batch]
+    batch2[0], batch2[1] = batch[1].clone(), batch[0].clone()       # another pair of clouds for the second step
+
+    def run(prefetch):
+        m = mb.TouchedRegraster(mr.Cfg(loss_mode=1, use_emd2=True, use_cd2=True, use_emd3=True))
+        mr.fill_params(m)
+        m.to(dev)
+        ops.clear_grad_sinks()
+        torch.manual_seed(11)
+        losses, took = [], []
+        orig = m._take_plans
+
+        def spy(fpc, mrpc, streams):
+            r = orig(fpc, mrpc, streams)
+            took.append(r is not None)
+            return r
+        m._take_plans = spy
+        with engine.TrainStep(m, batch, 1e-3, world=1, prefetch=prefetch) as r:
+            losses.append(float(r.step(next_batch=batch2)))
+            losses.append(float(r.step(next_batch=batch)))
+            losses.append(float(r.step()))
+        torch.cuda.synchronize()
+        assert m._plan_cache is None
+        return losses, took
+
+    l0, t0 = run(False)
+    l1, t1 = run(True)
+    assert t0 == [False] * 3 and t1 == [True] * 3
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 1e-4 * abs(a), (l0, l1)
