@@ -296,8 +296,10 @@ def main():
         #     max-pool variant (pzn_sa_level_fwd_f32: second shared-MLP layer + ReLU + max over the 32 neighbours on the
         #     generated rows of the first, model5_b.py:452-454 / :459-461; 4 launches per step).  It issues v_mfma_f32_32x32x16_bf16 six times per
         #     fp32 product, so it is priced against the bf16 pipe / 6, with the fp32-input MFMA rate beside it.
-        mp_entry = next((n for n in ("pzn_sa_level_fwd_ws_f32", "pzn_sa_level_fwd_f32") if n in kern), "pzn_linear_maxpool_fwd_f32")
-        streamed = mp_entry == "pzn_sa_level_fwd_ws_f32" and os.environ.get("PZN_SA_STREAM", "1") != "0"
+        mp_entry = next((n for n in ("pzn_sa_level_fwd_packed_f32", "pzn_sa_level_fwd_ws_f32", "pzn_sa_level_fwd_f32") if n in kern),
+                        "pzn_linear_maxpool_fwd_f32")
+        packed = mp_entry == "pzn_sa_level_fwd_packed_f32"     # the kernel alone: the split of W2 is its own entry point (timed beside)
+        streamed = packed or (mp_entry == "pzn_sa_level_fwd_ws_f32" and os.environ.get("PZN_SA_STREAM", "1") != "0")
         n_mp, ms_mp = per_step(mp_entry)
         fl_mp = kern_flops.get(mp_entry, 0) / prof_steps
         mp_ach = fl_mp / (ms_mp * 1e-3) / 1e12 if ms_mp > 0 else 0.0
@@ -306,7 +308,9 @@ def main():
             "bound": "mfma",
             "kernel": ("sa_level_stream_kernel<C1, CT> (csrc/salevel.hip: bf16x3 MFMA kernel, the rows relu(P'[idx] + Q) of the first "
                        "layer generated once per group in registers, W2 streamed through a three-slot LDS ring by LDS-DMA, "
-                       "max / arg-max epilogue in registers; + sa_pack_w_kernel, the split of W2 into planes) behind " if streamed else
+                       "max / arg-max epilogue in registers" + ("; the split of W2 into planes, sa_pack_w_kernel, is the entry point "
+                       "pzn_sa_level_prep_weights_f32: `weight_split_ms_per_step`) behind " if packed else
+                       "; + sa_pack_w_kernel, the split of W2 into planes) behind ") if streamed else
                        "ws_gemm_kernel<NT, MAXPOOL=true, ..., GATH> (csrc/wsgemm.hip: weight-stationary bf16x3 kernel, max-pool epilogue; "
                        "GATH: the first layer's rows relu(P'[idx] + Q) are generated in its operand loader) behind ") + mp_entry,
             "achieved": mp_ach, "peak": MFMA_X3_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mp_ach / MFMA_X3_PEAK_TFLOPS,
@@ -316,10 +320,12 @@ def main():
             "algorithmic_flops_per_step": fl_mp, "ms_per_step": ms_mp, "launches_per_step": n_mp,
             "avg_launch_ms": ms_mp / max(1.0, n_mp),
         }
+        if packed:
+            roofline["weight_split_ms_per_step"] = per_step("pzn_sa_level_prep_weights_f32")[1]
         # (1b) every dense matrix-core entry point together (no sparse vector-ALU passes in the sum)
         dense_names = ("pzn_linear_fwd_f32", "pzn_linear_dgrad_f32", "pzn_linear_wgrad_f32", "pzn_linear_maxpool_fwd_f32",
                        "pzn_sharedmlp_max_fwd_f32", "pzn_attn_fwd_f32", "pzn_attn_bwd_f32", "pzn_attn_block_fwd_f32",
-                       "pzn_attn_block_bwd_f32", "pzn_sa_level_fwd_f32", "pzn_sa_level_fwd_ws_f32", "pzn_outproj_maxpts_fwd_f32", "pzn_attn_fused_proj", "pzn_attn_fused_fwd",
+                       "pzn_attn_block_bwd_f32", "pzn_sa_level_fwd_f32", "pzn_sa_level_fwd_ws_f32", "pzn_sa_level_fwd_packed_f32", "pzn_sa_level_prep_weights_f32", "pzn_outproj_maxpts_fwd_f32", "pzn_attn_fused_proj", "pzn_attn_fused_fwd",
                        "pzn_attn_fused_bwd_q", "pzn_attn_fused_bwd_k", "pzn_attn_fused_wgrads", "pzn_linear_slice_fwd_f32",
                        "pzn_point_mlp3_fwd_f32", "pzn_point_mlp3_bwd_f32")
         d_ms = sum(kern.get(k, (0, 0.0))[1] for k in dense_names) / prof_steps

@@ -343,6 +343,14 @@ size_t pzn_sa_level_fwd_workspace_bytes(int C1, int C2);
 int pzn_sa_level_fwd_ws_f32(const float* Pp, const float* Q, const int64_t* idx, const float* W2, const float* b2,
                             int B, int N, int S, int C1, int C2, float* out, int32_t* argmax, void* workspace,
                             pzn_stream_t stream);
+/* The same in two launches that a caller times (or schedules) separately, as pzn_attn_fused_prep_weights is for the
+ * attention blocks: the split of W2 into the streamed kernel's plane image (workspace of
+ * pzn_sa_level_fwd_workspace_bytes() bytes), and the level on a workspace that holds it.  PZN_EUNSUPPORTED where the
+ * shape has no streamed form (pzn_sa_level_fwd_ws_f32 serves every shape). */
+int pzn_sa_level_prep_weights_f32(const float* W2, int C1, int C2, void* workspace, pzn_stream_t stream);
+int pzn_sa_level_fwd_packed_f32(const float* Pp, const float* Q, const int64_t* idx, const float* b2, int B, int N,
+                                int S, int C1, int C2, float* out, int32_t* argmax, const void* workspace,
+                                pzn_stream_t stream);
 int pzn_sa_level_bwd_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
                          const float* Pp, const float* Q, const int64_t* idx, const float* new_xyz, int B, int N,
                          int S, int D, int C1, int C2, float* dh, float* dW2, float* db2, float* dW1, float* db1,

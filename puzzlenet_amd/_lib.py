@@ -98,6 +98,8 @@ SIGNATURES = {
     "pzn_sa_level_fwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 5 + [_c_f] * 3),
     "pzn_sa_level_fwd_ws_f32": (_c_i, [_c_f] * 5 + [_c_i] * 5 + [_c_f] * 4),
     "pzn_sa_level_fwd_workspace_bytes": (_c_sz, [_c_i, _c_i]),
+    "pzn_sa_level_prep_weights_f32": (_c_i, [_c_f, _c_i, _c_i, _c_f, _c_f]),
+    "pzn_sa_level_fwd_packed_f32": (_c_i, [_c_f] * 4 + [_c_i] * 5 + [_c_f] * 4),
     "pzn_outproj_maxpts_workspace_bytes": (_c_sz, [_c_i] * 4),
     "pzn_cloud_bias_relu_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f]),
     "pzn_point_mlp3_supported": (_c_i, [_c_i] * 4),

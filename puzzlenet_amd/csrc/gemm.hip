@@ -1332,6 +1332,25 @@ PZN_EXPORT int pzn_sa_level_fwd_ws_f32(const float* Pp, const float* Q, const in
   return pzn_ws_gemm_gather_maxpool(Pp, Q, idx, W2, b2, B * S, N, S, C1, C2, out, argmax, pzn_hip_stream(stream));
 }
 
+// The two halves of pzn_sa_level_fwd_ws_f32 as separate entry points (as pzn_attn_fused_prep_weights is for the attention
+// blocks): the split of W2 into the streamed kernel's plane image, and the level on a workspace that already holds it.
+// PZN_EUNSUPPORTED where the shape has no streamed form (use pzn_sa_level_fwd_ws_f32 then).
+PZN_EXPORT int pzn_sa_level_prep_weights_f32(const float* W2, int C1, int C2, void* workspace, pzn_stream_t stream) {
+  PZN_CHECK_ARG(W2 && C1 > 0 && C2 > 0);
+  if (gemm_precision() == 0) return PZN_EUNSUPPORTED;
+  return pzn_sa_level_stream_pack(W2, C1, C2, workspace, pzn_hip_stream(stream));
+}
+
+PZN_EXPORT int pzn_sa_level_fwd_packed_f32(const float* Pp, const float* Q, const int64_t* idx, const float* b2, int B, int N,
+                                           int S, int C1, int C2, float* out, int32_t* argmax, const void* workspace,
+                                           pzn_stream_t stream) {
+  PZN_CHECK_ARG(Pp && Q && idx && b2 && out && argmax && workspace && B > 0 && N > 0 && S > 0 && C1 > 0 && C2 > 0);
+  PZN_CHECK_ARG((long)B * S * 32 < 2147483647L);
+  if (gemm_precision() == 0) return PZN_EUNSUPPORTED;
+  return pzn_sa_level_stream(Pp, Q, idx, nullptr, b2, B * S, N, S, C1, C2, out, argmax, const_cast<void*>(workspace),
+                             pzn_hip_stream(stream), 1);
+}
+
 // Backward of the pooled layer behind pzn_sa_level_fwd_f32: dh[B*S*32, C1] (the ReLU-masked gradient of the generated
 // rows: written, the per-point sum pzn_sa_point_l1_bwd_f32 reads it), dW2, db2 (overwritten, or added to when
 // accumulate), and what flows through Q: dW1[:, 0:3] -= dq^T new_xyz, db1 += column sums of dq (dq[g] = sum_k dh[g,k]);

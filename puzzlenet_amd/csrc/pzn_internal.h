@@ -50,7 +50,8 @@ int pzn_ws_gemm_ex(const float* A, int lda, const float* W, int ldw, int w_kmajo
 // salevel.hip: the generated-row max-pool level with W2 streamed through LDS; PZN_EUNSUPPORTED for other shapes
 size_t pzn_sa_level_stream_workspace_bytes(int C1, int C2);
 int pzn_sa_level_stream(const float* Pp, const float* Q, const int64_t* idx, const float* W2, const float* b2, int G, int N,
-                        int S, int C1, int C2, float* out, int32_t* argmax, void* workspace, hipStream_t st);
+                        int S, int C1, int C2, float* out, int32_t* argmax, void* workspace, hipStream_t st, int prepacked = 0);
+int pzn_sa_level_stream_pack(const float* W2, int C1, int C2, void* workspace, hipStream_t st);
 // max-pool variant on a generated activation stream (first set-abstraction layer per point): see wsgemm.hip
 int pzn_ws_gemm_gather_maxpool(const float* Pp, const float* Q, const int64_t* idx, const float* W2, const float* b2, int G,
                                int N, int S, int C1, int C2, float* out, int32_t* argmax, hipStream_t st);

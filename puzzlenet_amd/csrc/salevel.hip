@@ -330,15 +330,30 @@ size_t pzn_sa_level_stream_workspace_bytes(int C1, int C2) {
 }
 
 // -> PZN_EUNSUPPORTED for shapes it does not take (the weight-stationary kernel then)
-int pzn_sa_level_stream(const float* Pp, const float* Q, const int64_t* idx, const float* W2, const float* b2, int G, int N,
-                        int S, int C1, int C2, float* out, int32_t* argmax, void* workspace, hipStream_t st) {
+static bool sa_stream_on() {
   static const bool on = [] { const char* e = getenv("PZN_SA_STREAM"); return !(e && e[0] == '0'); }();   // tuning aid
-  if (!on || !workspace || pzn_sa_level_stream_workspace_bytes(C1, C2) == 0 || G < SA_WAVES) return PZN_EUNSUPPORTED;
+  return on;
+}
+
+// the split of W2 into its plane image alone (the workspace a later pzn_sa_level_stream(..., prepacked = 1) reads)
+int pzn_sa_level_stream_pack(const float* W2, int C1, int C2, void* workspace, hipStream_t st) {
+  if (!sa_stream_on() || !workspace || pzn_sa_level_stream_workspace_bytes(C1, C2) == 0 ||
+      (reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
+    return PZN_EUNSUPPORTED;
+  hipLaunchKernelGGL(sa_pack_w_kernel, dim3(64), dim3(256), 0, st, W2, C1, C2, static_cast<unsigned char*>(workspace));
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+int pzn_sa_level_stream(const float* Pp, const float* Q, const int64_t* idx, const float* W2, const float* b2, int G, int N,
+                        int S, int C1, int C2, float* out, int32_t* argmax, void* workspace, hipStream_t st, int prepacked) {
+  if (!sa_stream_on() || !workspace || pzn_sa_level_stream_workspace_bytes(C1, C2) == 0 || G < SA_WAVES) return PZN_EUNSUPPORTED;
   if (((reinterpret_cast<uintptr_t>(Pp) | reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(workspace)) & 15) != 0)
     return PZN_EUNSUPPORTED;
   unsigned char* w = static_cast<unsigned char*>(workspace);
-  hipLaunchKernelGGL(sa_pack_w_kernel, dim3(64), dim3(256), 0, st, W2, C1, C2, w);
-  if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
+  if (!prepacked) {
+    hipLaunchKernelGGL(sa_pack_w_kernel, dim3(64), dim3(256), 0, st, W2, C1, C2, w);
+    if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
+  }
   SaArgs a{Pp, Q, idx, w, b2, out, argmax, G, N, S, nullptr};
 #ifdef SA_STAMPS
   {

@@ -1569,8 +1569,18 @@ class _SaLevelFused(torch.autograd.Function):
             _call("pzn_sa_prep_f32", _p(xyz), _p(new_xyz), _p(w1), _p(b1), B, N, S, D, C1, _p(P), _p(Q), _stream())
             ws_bytes = _lib.load().pzn_sa_level_fwd_workspace_bytes(C1, C2)
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
-            _call("pzn_sa_level_fwd_ws_f32", _p(P), _p(Q), _p(idx), _p(w2), _p(b2), B, N, S, C1, C2, _p(out), _p(arg),
-                  _p(ws), _stream(), flops=2 * R * 32 * C1 * C2)
+            done = False
+            if ws is not None and _SA_PACKED:      # streamed-weights kernel: the weight split and the level as two entry points
+                try:
+                    _call("pzn_sa_level_prep_weights_f32", _p(w2), C1, C2, _p(ws), _stream())
+                    _call("pzn_sa_level_fwd_packed_f32", _p(P), _p(Q), _p(idx), _p(b2), B, N, S, C1, C2, _p(out), _p(arg),
+                          _p(ws), _stream(), flops=2 * R * 32 * C1 * C2)
+                    done = True
+                except _lib.PznUnsupported:
+                    pass
+            if not done:
+                _call("pzn_sa_level_fwd_ws_f32", _p(P), _p(Q), _p(idx), _p(w2), _p(b2), B, N, S, C1, C2, _p(out), _p(arg),
+                      _p(ws), _stream(), flops=2 * R * 32 * C1 * C2)
         ctx.save_for_backward(xyz, feat, new_xyz, idx, w1, w_f, w2, out, arg, P, Q)
         ctx.dims = (B, N, S, D, R, C1, C2)
         ctx.param_refs = (w1, b1, w2, b2)
@@ -1635,6 +1645,7 @@ class _SaLevelFused(torch.autograd.Function):
 
 
 SA_ROWMASK_STATS = None      # bench.py sets this to a list: every masked level backward appends (row mask [B*S] int32, C1)
+_SA_PACKED = os.environ.get("PZN_SA_PACKED", "1") != "0"     # tuning aid: 0 = weight split inside pzn_sa_level_fwd_ws_f32
 _SA_ROWMASK = os.environ.get("PZN_SA_ROWMASK", "1") != "0"     # tuning aid: 0 = every row of dh written and read
 _SA_REGEN = os.environ.get("PZN_SA_REGEN", "1") != "0"     # tuning aid: 0 = the pooled backward reads its gate from h
 _SA_POINT = os.environ.get("PZN_SA_POINT", "1") != "0"     # tuning aid: 0 = the grouped-row path (_SaMlpMax)

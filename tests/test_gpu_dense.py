@@ -733,6 +733,17 @@ def test_sa_level_streamed_vs_float64(dev, B, N, S, C):
     assert float((a1 != a0).float().mean()) < 1e-4
     picked = ref.view(R, 32, C).gather(1, a1.long().unsqueeze(1)).squeeze(1)
     assert float((picked - rmax).abs().max()) < 1e-5
+    # the two halves as their own entry points (weight split, then the level on the prepared workspace): the same bits
+    import os
+    if os.environ.get("PZN_SA_STREAM", "1") != "0" and R >= 8:
+        ws2 = torch.empty_like(ws)
+        o2 = torch.full((R, C), float("nan"), device=dev)
+        a2 = torch.full((R, C), -1, dtype=torch.int32, device=dev)
+        _lib.call("pzn_sa_level_prep_weights_f32", w2.data_ptr(), C, C, ws2.data_ptr(), st)
+        _lib.call("pzn_sa_level_fwd_packed_f32", P.data_ptr(), Q.data_ptr(), idx.data_ptr(), b2.data_ptr(), B, N, S, C, C,
+                  o2.data_ptr(), a2.data_ptr(), ws2.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert torch.equal(o2, o1) and torch.equal(a2, a1)
 
 
 @pytest.mark.parametrize("B,N,C2,C3,per_cloud", [(2, 64, 64, 64, False), (3, 96, 32, 2, True), (3, 160, 64, 64, False),
