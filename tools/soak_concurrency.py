@@ -1,5 +1,5 @@
 """Extended cross-stream soak (the matrix behind tests/test_gpu_concurrency.py): every deterministic forward kernel family
-run REPS times beside each of eight aggressor kernels on a second stream; prints the number of elements that differ from
+run REPS times beside each of ten aggressor kernels on a second stream; prints the number of elements that differ from
 the result obtained alone (all zeros on the current build):  python tools/soak_concurrency.py [REPS]"""
 import os, sys
 sys.path.insert(0, os.getcwd())
@@ -34,7 +34,24 @@ def chain():      # the four attention blocks as chained kernels + the fused out
     return ops.attention_chain_fused([xa], [[tuple(aw)] * 4], [wg], [bg])[0]
 
 
+# a boundary-head chain forward + backward (csrc/pointmlp.hip), every output and gradient
+pm_w1 = (torch.randn(64, 128, generator=g) / 8).to(dev)
+pm_w = [(torch.randn(o, i, generator=g) / 8).to(dev) for o, i in ((32, 64), (2, 32))]
+pm_b = [torch.randn(o, generator=g).to(dev) for o in (64, 32, 2)]
+pm_x, pm_g = torch.randn(16, 2048, 64, generator=g).to(dev), torch.randn(16, 1, 64, generator=g).to(dev)
+pm_go = torch.randn(16, 2048, 2, generator=g).to(dev)
+
+
+def point_mlp():
+    with torch.enable_grad():
+        leaves = [t.detach().requires_grad_(True) for t in (pm_x, pm_g, pm_w1, pm_b[0], pm_w[0], pm_b[1], pm_w[1], pm_b[2])]
+        y = ops.point_mlp3(leaves[0], leaves[2], leaves[3], leaves[4], leaves[5], leaves[6], leaves[7], g=leaves[1])
+        grads = torch.autograd.grad(y, leaves, pm_go)
+    return torch.cat([y.detach().reshape(-1)] + [t.reshape(-1) for t in grads])
+
+
 victims = {
+    "point_mlp3": point_mlp,
     "knn": lambda: ops.knn(xyz, new_xyz, 32),
     "knn_group": lambda: ops.knn_group(xyz, feat, new_xyz)[0],
     "fps": lambda: ops.farthest_point_sample(xyz, 256, torch.zeros(B, dtype=torch.long, device=dev)),
@@ -84,8 +101,11 @@ def agg_sa_backward():
 def agg_chain():
     with torch.cuda.stream(side):
         chain()
+def agg_point_mlp():
+    with torch.cuda.stream(side):
+        point_mlp()
 aggs.update(emd=agg_emd, knn_group=agg_knn_group, fps=agg_fps, chamfer=agg_chamfer, sa_backward=agg_sa_backward,
-            attention_fused=agg_chain)
+            attention_fused=agg_chain, point_mlp3=agg_point_mlp)
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 print("victim \\ aggressor".ljust(28) + "".join(a[:14].rjust(15) for a in aggs))
 for name, fn in victims.items():
