@@ -747,7 +747,10 @@ def test_sa_level_streamed_vs_float64(dev, B, N, S, C):
 
 
 @pytest.mark.parametrize("B,N,C2,C3,per_cloud", [(2, 64, 64, 64, False), (3, 96, 32, 2, True), (3, 160, 64, 64, False),
-                                                  (4, 2048, 32, 2, True), (5, 2048, 64, 64, False), (1, 32, 32, 2, True)])
+                                                  (4, 2048, 32, 2, True), (5, 2048, 64, 64, False), (1, 32, 32, 2, True),
+                                                  # three tiles per wavefront with a ragged last one / four (a divisor of the
+                                                  # cloud's 64 tiles) / a cloud of 4096 points
+                                                  (33, 2048, 64, 64, False), (33, 2048, 32, 2, True), (9, 4096, 32, 2, True)])
 def test_point_mlp3_vs_float64(dev, B, N, C2, C3, per_cloud):
     """csrc/pointmlp.hip through ops.point_mlp3: the boundary heads' three-layer chains (model5_b.py:571-592, 738-754) in one
     launch each way against float64 autograd — output and every gradient, with the global half of the first layer
