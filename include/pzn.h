@@ -424,17 +424,18 @@ int pzn_attn_block_bwd_f32(const float* x, const float* Wq, const float* Wk, con
  * product's accumulator is the next product's operand in registers: no score matrix and no q / k / v tensors in
  * memory.  Shared operands live as bf16x3 "plane images" in MFMA-fragment order, written by their producer:
  *   weights:  pzn_attn_fused_prep_weights -> one buffer of pzn_attn_fused_weight_bytes() per block;
- *   q, k, v:  pzn_attn_fused_proj -> six images per problem (q, k: *_qk_image_bytes(B); v: *_v_image_bytes(B)),
- *             each operand as a "row" image (rp) and a "transposed-read" image (t).
+ *   q, k, v:  pzn_attn_fused_proj -> three images per problem (q, k: *_qk_image_bytes(B); v: *_v_image_bytes(B)); one
+ *             image serves the products that sum over its columns (plain slabs) and those that sum over its rows
+ *             (the same bytes fetched in a transposed-read cut by the LDS-DMA: no second copy since round 4).
  * Every entry point takes nprob = 1 or 2 independent problems as arrays of nprob pointers (the two encoders of
  * predict5, model5_b.py:700-707, in one launch); B clouds each; all buffers 16-byte aligned.
  *   fwd:    r = x + relu(Wo (x - softmax(q k^T / 8) v) + bo) [B*L,E];  t = x - attn v [B*L,E];  mask [B*L,8] u32 = gate
  *           bits of the ReLU;  lse [B*L];  map[i] (may be NULL) [B,L,L]: map = scale P, or map += scale P when
  *           map_accumulate (the mean of the four blocks' maps, model5_b.py:468-469).
  *   bwd_q:  query side of the backward from dr (+ dr2 when non-NULL: rows of ld_dr / ld_dr2 floats, so a column slice of
- *           a wider gradient needs no copy and the sum of two gradients no add): dz = dr . gate, u = dr + dz Wo + dq Wq,
- *           dq [B*L,dk], delta [B*L] and the two images of da = -dz Wo.
- *   bwd_k:  key side: dk [B*L,dk], dv [B*L,E], dx = u + dk Wk + dv Wv [B*L,E] = the block's input gradient.
+ *           a wider gradient needs no copy and the sum of two gradients no add): dz = dr . gate, u = dr + dz Wo,
+ *           dq [B*L,dk], delta [B*L] and the image of da = -dz Wo.
+ *   bwd_k:  key side: dk [B*L,dk], dv [B*L,E], dx = u + dq Wq + dk Wk + dv Wv [B*L,E] = the block's input gradient.
  *   wgrads: the eight parameter gradients from dz, t, dq, dk, dv and the block input x (one problem per call). */
 int pzn_attn_fused_supported(int L, int E, int dk);
 size_t pzn_attn_fused_weight_bytes(void);
@@ -444,24 +445,23 @@ int pzn_attn_fused_prep_weights(const float* Wq, const float* Wk, const float* W
                                 void* planes, pzn_stream_t stream);
 int pzn_attn_fused_proj(int nprob, const float* const* x, const void* const* w,
                         const float* const* bq, const float* const* bk, const float* const* bv, int B,
-                        void* const* qrp, void* const* qt, void* const* krp, void* const* kt,
-                        void* const* vrp, void* const* vt, pzn_stream_t stream);
+                        void* const* qrp, void* const* krp, void* const* vrp, pzn_stream_t stream);
 int pzn_attn_fused_fwd(int nprob, const float* const* x, const void* const* qrp,
-                       const void* const* krp, const void* const* vt, const void* const* w,
+                       const void* const* krp, const void* const* vrp, const void* const* w,
                        const float* const* bo, int B, float* const* r, float* const* t,
                        void* const* mask, float* const* map, float* const* lse, int map_accumulate,
                        float map_scale, pzn_stream_t stream);
 int pzn_attn_fused_bwd_q(int nprob, const float* const* dr, int ld_dr, const float* const* dr2,
                          int ld_dr2, const void* const* mask,
-                         const void* const* qrp, const void* const* krp, const void* const* kt,
-                         const void* const* vrp, const void* const* w, int B, float* const* dz,
-                         float* const* u, float* const* dq, void* const* darp, void* const* dat,
-                         float* const* delta, pzn_stream_t stream);
-int pzn_attn_fused_bwd_k(int nprob, const void* const* qrp, const void* const* qt,
-                         const void* const* krp, const void* const* vrp, const void* const* darp,
-                         const void* const* dat, const void* const* w, const float* const* lse,
-                         const float* const* delta, const float* const* u, int B, float* const* dk,
-                         float* const* dv, float* const* dx, pzn_stream_t stream);
+                         const void* const* qrp, const void* const* krp, const void* const* vrp,
+                         const void* const* w, int B, float* const* dz, float* const* u,
+                         float* const* dq, void* const* darp, float* const* delta,
+                         pzn_stream_t stream);
+int pzn_attn_fused_bwd_k(int nprob, const void* const* qrp, const void* const* krp,
+                         const void* const* vrp, const void* const* darp, const void* const* w,
+                         const float* const* lse, const float* const* delta, const float* const* u,
+                         const float* const* dq, int B, float* const* dk, float* const* dv,
+                         float* const* dx, pzn_stream_t stream);
 int pzn_attn_fused_wgrads(const float* dz, const float* t, const float* dq, const float* dk,
                           const float* dv, const float* x, int M, int E, int dk_dim, float* dWq,
                           float* dbq, float* dWk, float* dbk, float* dWv, float* dbv, float* dWo,

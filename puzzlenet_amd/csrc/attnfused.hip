@@ -18,17 +18,17 @@
 // magnitude >= 2^-16 (fp32-GEMM accuracy, see gemm.hip).  Shared operands are split ONCE by their producer and kept in
 // memory as plane images in MFMA-fragment order; the per-wavefront operand is split in registers as it is consumed.
 //
-// Plane images (bf16, 16-byte chunks):
-//   Rp  ("row" image of M[rows][K], consumed with k = column index): [k-step][plane][row tile][lane][8], the chunk of
-//        lane (r, h) holding M[32 rt + r][16 ks + perm(h, j)], perm(h, j) = 8 (j >> 2) + 4h + (j & 3): the order in
-//        which an accumulator's registers 8s..8s+7 come out as a B fragment.  Read with ds_read_b128 (A operand through
-//        LDS) or straight from global by the lane that owns the row (B operand).
-//   T   ("transposed-read" image of M[n][F], consumed with k = ROW index): [k-step of 16 rows][plane][16][F] row-major
-//        with the 64-byte granule index XORed by a row key; read with ds_read_b64_tr_b16 (hardware transpose).
+// Plane images (bf16, 16-byte chunks), ONE per operand (round 4: the separate transposed-read images are gone):
+//   Rp  image of M[rows][K]: [k-step][plane][row tile][lane][8], the chunk of lane (r, h) holding
+//        M[32 rt + r][16 ks + perm(h, j)], perm(h, j) = 8 (j >> 2) + 4h + (j & 3): the order in which an accumulator's
+//        registers 8s..8s+7 come out as a B fragment.  Consumed three ways:
+//        - k = column index, operand through LDS: plain slabs of one k-step, ds_read_b128;
+//        - k = column index, the wavefront's own rows: straight from global by the lane that owns the row (B operand);
+//        - k = ROW index (the operand is M^T): the same bytes fetched in the T-use cut of pzn_mfma.h (the LDS-DMA's
+//          per-lane source address does the re-arrangement) and read with ds_read_b64_tr_b16 (hardware transpose).
 //
-// The shared operand streams through LDS in 24 KB slabs (36 KB in the projection kernel): thread t copies 16-byte
-// pieces t, t + 256, ... global -> registers while the previous slab is being multiplied, registers -> the other
-// LDS buffer afterwards, one barrier per slab.  One wavefront per SIMD (the chained accumulators need ~400 registers).
+// The shared operand streams through LDS in 24 KB slabs (36 KB in the projection kernel) by LDS-DMA, three slots,
+// one barrier per slab.  One wavefront per SIMD (the chained accumulators need ~400 registers).
 #include <stdio.h>
 
 #include <type_traits>
@@ -40,9 +40,22 @@ namespace {
 
 #include "pzn_mfma.h"
 
+#ifdef ATTN_STAMPS
+// diagnostic build only (tools/attn_stamps.py): cycle stamps of wavefront 0 of two workgroups per kernel
+__device__ long long g_stamps[4][2][64];
+#define STAMPK(K, i)                                                                                   \
+  do {                                                                                                 \
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 77))                                      \
+      g_stamps[K][blockIdx.x ? 1 : 0][i] = (long long)__builtin_amdgcn_s_memtime();                     \
+  } while (0)
+#else
+#define STAMPK(K, i) do { } while (0)
+#endif
+#define STAMP(i) STAMPK(1, i)
+
 constexpr int L = 256, E = 256, DK = 64;
-constexpr int QK_IMG = 4 * 3 * 8 * 1024;  // Rp or T image of a [256][64] operand, bytes per cloud
-constexpr int V_IMG = 16 * 3 * 8 * 1024;  // Rp or T image of a [256][256] operand
+constexpr int QK_IMG = 4 * 3 * 8 * 1024;  // Rp image of a [256][64] operand, bytes per cloud
+constexpr int V_IMG = 16 * 3 * 8 * 1024;  // Rp image of a [256][256] operand
 
 // ---- tile <-> memory through a per-wavefront LDS staging buffer --------------------------------------------------
 // A wavefront's result tile has the point on the lane and the features in registers, so a direct store puts every
@@ -53,18 +66,31 @@ constexpr int V_IMG = 16 * 3 * 8 * 1024;  // Rp or T image of a [256][256] opera
 constexpr int STG_LD = 132;                        // dwords per staged row
 constexpr int STG_BYTES = 32 * STG_LD * 4;         // 16,896 per wavefront
 
-// registers -> staging: tiles ft0 .. ft0 + NFT - 1 (NFT <= 4) of x at columns 32 (ft - ft0)
-template <int NFT>
-__device__ __forceinline__ void stage_put(float* stg, const floatx16* x, int ft0, int lane) {
+// registers -> staging: tiles ft0 .. ft0 + NFT - 1 (NFT <= 4) of x at columns 32 (ft - ft0); gate != NULL: element i of
+// tile ft is replaced by zero unless bit (ft & 1) * 16 + i of gate[ft >> 1] is set (ReLU mask of the forward pass)
+struct NoGate {};
+struct Gate4 {
+  uint32_t w[4];
+};
+template <int NFT, class G = NoGate>
+__device__ __forceinline__ void stage_put(float* stg, const floatx16* x, int ft0, int lane, const G& gate = G()) {
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int ft = 0; ft < NFT; ++ft)
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      *reinterpret_cast<float4*>(stg + r * STG_LD + 32 * ft + 8 * g + 4 * h) =
-          make_float4(x[ft0 + ft][4 * g], x[ft0 + ft][4 * g + 1], x[ft0 + ft][4 * g + 2], x[ft0 + ft][4 * g + 3]);
+    for (int g = 0; g < 4; ++g) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = x[ft0 + ft][4 * g + e];
+        if constexpr (std::is_same<G, Gate4>::value) {
+          if (!((gate.w[(ft0 + ft) >> 1] >> (((ft0 + ft) & 1) * 16 + 4 * g + e)) & 1u)) v[e] = 0.f;
+        }
+      }
+      *reinterpret_cast<float4*>(stg + r * STG_LD + 32 * ft + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+    }
 }
-template <int NFT>
+template <int NFT, bool ADD = false>
 __device__ __forceinline__ void stage_get(const float* stg, floatx16* x, int ft0, int lane) {
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -72,21 +98,25 @@ __device__ __forceinline__ void stage_get(const float* stg, floatx16* x, int ft0
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const float4 v = *reinterpret_cast<const float4*>(stg + r * STG_LD + 32 * ft + 8 * g + 4 * h);
-      x[ft0 + ft][4 * g] = v.x, x[ft0 + ft][4 * g + 1] = v.y, x[ft0 + ft][4 * g + 2] = v.z, x[ft0 + ft][4 * g + 3] = v.w;
+      if (ADD) {
+        x[ft0 + ft][4 * g] += v.x, x[ft0 + ft][4 * g + 1] += v.y, x[ft0 + ft][4 * g + 2] += v.z, x[ft0 + ft][4 * g + 3] += v.w;
+      } else {
+        x[ft0 + ft][4 * g] = v.x, x[ft0 + ft][4 * g + 1] = v.y, x[ft0 + ft][4 * g + 2] = v.z, x[ft0 + ft][4 * g + 3] = v.w;
+      }
     }
 }
 
 // fp32 rows [32 rows of this wavefront][ld]: FT feature tiles starting at column 0; row0 = the wavefront's first row.
 // MODE 0: store; 1: out = old + scale * tile (read-modify-write; rows are wave-private)
-template <int FT, int MODE = 0>
+template <int FT, int MODE = 0, class G = NoGate>
 __device__ __forceinline__ void store_rows(float* base, long row0, int ld, const floatx16* x, float* stg, int lane,
-                                           float scale = 1.f) {
+                                           float scale = 1.f, const G& gate = G()) {
   constexpr int PASS = FT >= 4 ? 4 : FT;            // tiles per pass
   constexpr int LPR = PASS * 8;                     // lanes per row (16 bytes each)
   constexpr int RPI = 64 / LPR;                     // rows per instruction
 #pragma unroll
   for (int ft0 = 0; ft0 < FT; ft0 += PASS) {
-    stage_put<PASS>(stg, x, ft0, lane);
+    stage_put<PASS, G>(stg, x, ft0, lane, gate);
     pzn::wave_lds_sync();
     float* g0 = base + row0 * ld + 32 * ft0 + 4 * (lane % LPR);
 #pragma unroll
@@ -105,7 +135,8 @@ __device__ __forceinline__ void store_rows(float* base, long row0, int ld, const
     pzn::wave_lds_sync();
   }
 }
-template <int FT>
+// ADD: x += the rows (a second addend of the same tile)
+template <int FT, bool ADD = false>
 __device__ __forceinline__ void load_rows(const float* base, long row0, int ld, floatx16* x, float* stg, int lane) {
   constexpr int PASS = FT >= 4 ? 4 : FT;
   constexpr int LPR = PASS * 8, RPI = 64 / LPR;
@@ -119,7 +150,7 @@ __device__ __forceinline__ void load_rows(const float* base, long row0, int ld, 
     for (int i = 0; i < 32 / RPI; ++i)
       *reinterpret_cast<float4*>(stg + (i * RPI + lane / LPR) * STG_LD + 4 * (lane % LPR)) = v[i];
     pzn::wave_lds_sync();
-    stage_get<PASS>(stg, x, ft0, lane);
+    stage_get<PASS, ADD>(stg, x, ft0, lane);
     pzn::wave_lds_sync();
   }
 }
@@ -139,43 +170,6 @@ __device__ __forceinline__ void store_rp(unsigned char* img, int rt, int lane, c
       for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(img + (((ks * 3 + p) * 8 + rt) * 64 + lane) * 16) = b[p];
       __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from splitting all 16 fragments before the first store)
     }
-}
-
-// T image of M[256 n][F]: row n = 32 rt + r -> k-step n >> 4, row n & 15, [k-step][plane][16][F] bf16 with the 64-byte
-// granule index XORed by the row key.  The tile goes through the staging buffer in fp32 (up to 128 features per pass),
-// is read back row-contiguous — a lane takes 8 consecutive features of one row —, split there and stored as one 16-byte
-// chunk per plane: 256-byte runs per row instead of 8-byte pieces from 32 rows.
-template <int FT, int F, bool NEG = false>
-__device__ __forceinline__ void store_t(unsigned char* img, int rt, int lane, const floatx16* x, float* stg) {
-  constexpr int PL = 16 * F * 2;
-  constexpr int PASS = FT >= 4 ? 4 : FT;            // tiles per pass
-  constexpr int LPR = PASS * 4, RPI = 64 / LPR;     // lanes per row (8 features each), rows per instruction
-#pragma unroll
-  for (int ft0 = 0; ft0 < FT; ft0 += PASS) {
-    stage_put<PASS>(stg, x, ft0, lane);
-    pzn::wave_lds_sync();
-#pragma unroll
-    for (int i = 0; i < 32 / RPI; ++i) {
-      const int rr = i * RPI + lane / LPR, c8 = lane % LPR;
-      const float4 v0 = *reinterpret_cast<const float4*>(stg + rr * STG_LD + 8 * c8);
-      const float4 v1 = *reinterpret_cast<const float4*>(stg + rr * STG_LD + 8 * c8 + 4);
-      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      if (NEG) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = -v[j];
-      }
-      bf16x8 b[3];
-      split8(v, b);
-      const int n = 32 * rt + rr, nn = n & 15;
-      const int key = F == 256 ? (nn & 3) : ((nn >> 1) & 1);
-      const int colb = (32 * ft0 + 8 * c8) * 2;
-      unsigned char* dst = img + (n >> 4) * (3 * PL) + nn * (2 * F) + (colb ^ (key << 6));
-#pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(dst + p * PL) = b[p];
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    pzn::wave_lds_sync();
-  }
 }
 
 // ================================================================================================================
@@ -226,7 +220,7 @@ struct ProjProb {
   const float* x;                 // [B*L, E]
   const unsigned char* w;         // the layer's weight planes
   const float *bq, *bk, *bv;
-  unsigned char *qrp, *qt, *krp, *kt, *vrp, *vt;
+  unsigned char *qrp, *krp, *vrp;
 };
 struct ProjArgs {
   ProjProb p[2];
@@ -262,9 +256,11 @@ __global__ __launch_bounds__(NT, 1) void attn_proj_kernel(ProjArgs a) {
   const long row0 = (long)cloud * L + 32 * rt;
   float* stg = reinterpret_cast<float*>(lds + wave * STG_BYTES);   // staging aliases the ring: used before / after it
 
+  STAMPK(0, 0);
   floatx16 X[8];
   load_rows<8>(P.x, row0, E, X, stg, lane);
   __syncthreads();
+  STAMPK(0, 1);
   ring.issue<9>(wsrc, 0);
   ring.issue<9>(wsrc + WSLAB, 1);
   floatx16 acc[12];
@@ -291,13 +287,12 @@ __global__ __launch_bounds__(NT, 1) void attn_proj_kernel(ProjArgs a) {
     if (ks < 15) bn.get(b[(ks + 1) & 1]);
   }
   const floatx16 *q = acc, *k = acc + 2, *v = acc + 4;
-  __syncthreads();   // every wavefront is done with the last slab: the ring memory becomes the staging buffers
+  STAMPK(0, 2);
   store_rp<2>(P.qrp + (size_t)cloud * QK_IMG, rt, lane, q);
-  store_t<2, 64>(P.qt + (size_t)cloud * QK_IMG, rt, lane, q, stg);
   store_rp<2>(P.krp + (size_t)cloud * QK_IMG, rt, lane, k);
-  store_t<2, 64>(P.kt + (size_t)cloud * QK_IMG, rt, lane, k, stg);
+  STAMPK(0, 3);
   store_rp<8>(P.vrp + (size_t)cloud * V_IMG, rt, lane, v);
-  store_t<8, 256>(P.vt + (size_t)cloud * V_IMG, rt, lane, v, stg);
+  STAMPK(0, 4);
 }
 
 // ================================================================================================================
@@ -341,7 +336,7 @@ __device__ __forceinline__ void load_own_frags(const unsigned char* img, int rt,
 // forward of one block for the wavefront's 32 points
 struct FwdProb {
   const float* x;                          // [B*L, E] block input
-  const unsigned char *qrp, *krp, *vt;     // images of this layer's q, k, v
+  const unsigned char *qrp, *krp, *vrp;    // images of this layer's q, k, v
   const unsigned char* w;                  // weight planes
   const float* bo;
   float* r;        // [B*L, E] block output
@@ -350,14 +345,8 @@ struct FwdProb {
   float* map;      // [B, L, L] mean attention map (may be NULL)
   float* lse;      // [B*L]
 };
-#ifdef ATTN_STAMPS
-#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define STAMP(i)
-#endif
 struct FwdArgs {
   FwdProb p[2];
-  long long* dbg;
   int nb;
   int map_accumulate;   // 0: map = scale * P, 1: map += scale * P
   float map_scale;
@@ -371,20 +360,30 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(FwdArgs a) {
   const int cb = lb % a.nb, cloud = cb >> 1, rt = (cb & 1) * 4 + wave;
   const long row = (long)cloud * L + 32 * rt + (lane & 31);
   const unsigned char* krp = P.krp + (size_t)cloud * QK_IMG;
-  const unsigned char* vt = P.vt + (size_t)cloud * V_IMG;
+  const unsigned char* vrp = P.vrp + (size_t)cloud * V_IMG;
   const unsigned char* wo = P.w + W_O;
   const Ring ring{lds, wave, lane, SLAB};
   const long row0 = (long)cloud * L + 32 * rt;
   float* stg = reinterpret_cast<float*>(lds + 3 * SLAB + wave * STG_BYTES);
-  // slab sequence: K 0..3 | V^T 0..15 | Wo 0..15
-  auto src = [&](int c) { return c < 4 ? krp + c * SLAB : c < 20 ? vt + (c - 4) * SLAB : wo + (c - 20) * SLAB; };
+  const uint32_t tsrc = tr_src_lane_off(lane);
+  // slab sequence: K 0..3 | V^T (T use of the v image, k-step = 16 keys) 0..15 | Wo 0..15
   constexpr int NS = 36;
+  auto issue1 = [&](int c, int i) {   // piece i of this wavefront of slab c -> slot c % 3
+    if (c < 4)
+      ring.issue1(krp + c * SLAB, c % 3, i);
+    else if (c < 20)
+      ring.issue1_t<256>(vrp, tsrc, c - 4, c % 3, i);
+    else if (c < NS)
+      ring.issue1(wo + (c - 20) * SLAB, c % 3, i);
+  };
 
   STAMP(0);
   bf16x8 qf[4][3];
   load_own_frags(P.qrp + (size_t)cloud * QK_IMG, rt, lane, qf);
-  ring.issue<6>(src(0), 0);
-  ring.issue<6>(src(1), 1);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) issue1(0, i);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) issue1(1, i);
   floatx16 S[8];
   ZERO_TILES(S, 8);
   // ---- S^T = K q^T (4 k-steps over d)
@@ -393,8 +392,8 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(FwdArgs a) {
     step_sync(6);
     auto fill = [&](int t) {
       if (t < 3) {
-        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t);
-        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t + 1);
+        issue1(c + 2, 2 * t);
+        issue1(c + 2, 2 * t + 1);
       }
     };
     kstep_rp<8>(S, ring.lane_addr(c % 3), qf[c], fill);
@@ -424,13 +423,13 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(FwdArgs a) {
     BNext bn;
     auto fill = [&](int t) {
       if (t < 3) {
-        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t);
-        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t + 1);
+        issue1(c + 2, 2 * t);
+        issue1(c + 2, 2 * t + 1);
       } else if (t < 7 && ks < 15) {
         bn.pair(S[(ks + 1) >> 1], (ks + 1) & 1, t - 3);
       }
     };
-    kstep_tr<8, 256, 0>(O, TrAddr<256>(ring.slot_addr(c % 3), lane), b[ks & 1], fill);
+    kstep_tr<8, 256, 0>(O, tr_lane_addr(ring.slot_addr(c % 3), lane), b[ks & 1], fill);
     if (ks < 15) bn.get(b[(ks + 1) & 1]);
   }
   STAMP(4);
@@ -457,10 +456,8 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(FwdArgs a) {
     BNext bn;
     auto fill = [&](int t) {
       if (t < 3) {
-        if (c + 2 < NS) {
-          ring.issue1(src(c + 2), (c + 2) % 3, 2 * t);
-          ring.issue1(src(c + 2), (c + 2) % 3, 2 * t + 1);
-        }
+        issue1(c + 2, 2 * t);
+        issue1(c + 2, 2 * t + 1);
       } else if (t < 7 && ks < 15) {
         bn.pair(O[(ks + 1) >> 1], (ks + 1) & 1, t - 3);
       }
@@ -489,19 +486,22 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(FwdArgs a) {
 
 // ================================================================================================================
 // backward, query side: the wavefront's 32 points as QUERIES.
-//   dz = dr . gate;  dt^T = Wo^T dz^T;  da = -dt (images for the key-side pass);  dP^T = V da^T;  P^T recomputed;
-//   delta = sum_key P dP;  dS^T = P^T (dP^T - delta) / 8;  dq^T = K^T dS^T;  u = dr + dt + dq Wq (partial dx)
+//   dz = dr . gate;  dt^T = Wo^T dz^T;  da = -dt (image for the key-side pass);  dP^T = V da^T;  P^T recomputed;
+//   delta = sum_key P dP;  dS^T = P^T (dP^T - delta) / 8;  dq^T = K^T dS^T;  u = dr + dt (partial dx: the key-side pass
+//   adds dq Wq with its own terms).
+// Round 4: dr is read once (the gate is applied where dz is consumed: in the split of the B fragments and in the store
+// of dz, so dr is still there for u = dr + dt), u is written once, and never more than two accumulator sets are live.
 struct BwdQProb {
   const float* dr;       // gradient of the block output: rows of ld_dr floats (a column slice of a wider matrix is fine)
   const float* dr2;      // optional second addend of that gradient (NULL: none), rows of ld_dr2 floats
   int ld_dr, ld_dr2;
   const uint32_t* mask;
-  const unsigned char *qrp, *krp, *kt, *vrp;
+  const unsigned char *qrp, *krp, *vrp;
   const unsigned char* w;
   float* dz;             // [B*L, E]
   float* u;              // [B*L, E]
   float* dq;             // [B*L, DK]
-  unsigned char *darp, *dat;   // images of da
+  unsigned char* darp;   // image of da
   float* delta;          // [B*L]
 };
 struct BwdQArgs {
@@ -511,85 +511,97 @@ struct BwdQArgs {
 
 __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SLAB + 4 * STG_BYTES];   // ring | staging per wavefront
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lb = logical_block(blockIdx.x, gridDim.x);
   const BwdQProb& P = a.p[lb / a.nb];
   const int cb = lb % a.nb, cloud = cb >> 1, rt = (cb & 1) * 4 + wave;
-  const long row = (long)cloud * L + 32 * rt + (lane & 31);
   const unsigned char* krp = P.krp + (size_t)cloud * QK_IMG;
-  const unsigned char* kt = P.kt + (size_t)cloud * QK_IMG;
   const unsigned char* vrp = P.vrp + (size_t)cloud * V_IMG;
   const unsigned char* wot = P.w + W_OT;
-  const unsigned char* wqt = P.w + W_QT;
-  const Ring ring{lds, wave, lane, SLAB};
   const long row0 = (long)cloud * L + 32 * rt;
   float* stg = reinterpret_cast<float*>(lds + 3 * SLAB + wave * STG_BYTES);
-  // slab sequence: Wo^T 0..15 | V 0..15 | K 0..3 | K^T (4 k-steps each) 0..3 | Wq^T 0..3
-  auto src = [&](int c) {
-    return c < 16 ? wot + c * SLAB : c < 32 ? vrp + (c - 16) * SLAB : c < 36 ? krp + (c - 32) * SLAB
-           : c < 40 ? kt + (c - 36) * SLAB : wqt + (c - 40) * SLAB;
-  };
-  constexpr int NS = 44;
-
-  floatx16 S[8];     // first dz^T, later S^T / P^T / dS^T
-  load_rows<8>(P.dr, row0, P.ld_dr, S, stg, lane);
-  if (P.dr2) {
-    floatx16 T2[8];
-    load_rows<8>(P.dr2, row0, P.ld_dr2, T2, stg, lane);
-#pragma unroll
-    for (int ft = 0; ft < 8; ++ft) S[ft] += T2[ft];
-  }
+  constexpr int NS = 40;
+  STAMPK(2, 0);
+  // ---- prologue: dr (+ dr2) -> registers, gate bits, dz -> memory.  What derives from the lane id here does not outlive
+  // the prologue: the loops below take the lane id from the hardware again (fresh_lane) instead of keeping it, and its
+  // derived addresses, alive through the register-hungry transposes (the allocator spilled them otherwise).
+  floatx16 S[8];     // dr^T, then u^T = dr^T + dt^T, later the scores
+  Gate4 gate;
   {
-    const uint4 mb = *reinterpret_cast<const uint4*>(P.mask + (row * 2 + h) * 4);
-    const uint32_t bits[4] = {mb.x, mb.y, mb.z, mb.w};
+    const int lane0 = tid & 63;
+    const Ring ring0{lds, wave, lane0, SLAB};
 #pragma unroll
-    for (int ft = 0; ft < 8; ++ft)
+    for (int i = 0; i < 6; ++i) ring0.issue1(wot, 0, i);
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
-        if (!((bits[ft >> 1] >> ((ft & 1) * 16 + i)) & 1u)) S[ft][i] = 0.f;
+    for (int i = 0; i < 6; ++i) ring0.issue1(wot + SLAB, 1, i);
+    load_rows<8>(P.dr, row0, P.ld_dr, S, stg, lane0);
+    if (P.dr2) load_rows<8, true>(P.dr2, row0, P.ld_dr2, S, stg, lane0);
+    const long row = row0 + (lane0 & 31);
+    const uint4 mb = *reinterpret_cast<const uint4*>(P.mask + (row * 2 + (lane0 >> 5)) * 4);
+    gate.w[0] = mb.x, gate.w[1] = mb.y, gate.w[2] = mb.z, gate.w[3] = mb.w;
+    STAMPK(2, 1);
+    store_rows<8, 0, Gate4>(P.dz, row0, E, S, stg, lane0, 1.f, gate);
+    STAMPK(2, 2);
   }
-  store_rows<8>(P.dz, row0, E, S, stg, lane);
-  ring.issue<6>(src(0), 0);
-  ring.issue<6>(src(1), 1);
-  // ---- dt^T = Wo^T dz^T (16 k-steps over o)
+  __builtin_amdgcn_sched_barrier(0);
+  const int lane = fresh_lane();
+  const Ring ring{lds, wave, lane, SLAB};
+  const uint32_t tsrc = tr_src_lane_off(lane);
+  // slab sequence: Wo^T 0..15 | V 0..15 | K 0..3 | K^T (T use of the k image, 4 k-steps of 16 keys each) 0..3
+  auto issue1 = [&](int c, int i) {
+    if (c < 16)
+      ring.issue1(wot + c * SLAB, c % 3, i);
+    else if (c < 32)
+      ring.issue1(vrp + (c - 16) * SLAB, c % 3, i);
+    else if (c < 36)
+      ring.issue1(krp + (c - 32) * SLAB, c % 3, i);
+    else if (c < NS)
+      ring.issue1_t<64>(krp, tsrc, 4 * (c - 36), c % 3, i);
+  };
+  auto fill_dma = [&](int c, int t) {
+    if (t < 3) {
+      issue1(c + 2, 2 * t);
+      issue1(c + 2, 2 * t + 1);
+    }
+  };
+
+  // ---- dt^T = Wo^T dz^T (16 k-steps over o); the gate is applied as the fragments are split
   floatx16 DT[8];
   ZERO_TILES(DT, 8);
   bf16x8 b[2][3];
-  make_b(S[0], 0, b[0]);
+  {
+    BNext b0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b0.pair_gated(S[0], 0, j, gate.w[0], 0);
+    b0.get(b[0]);
+  }
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     const int c = ks;
-    step_sync(6);
+    step_sync(ks == 0 ? 0 : 6);   // (first step: the stores of dz stand between the two slabs and this wait)
     BNext bn;
     auto fill = [&](int t) {
-      if (t < 3) {
-        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t);
-        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t + 1);
-      } else if (t < 7 && ks < 15) {
-        bn.pair(S[(ks + 1) >> 1], (ks + 1) & 1, t - 3);
+      fill_dma(c, t);
+      if (t >= 3 && t < 7 && ks < 15) {
+        const int kn = ks + 1, ft = kn >> 1;
+        bn.pair_gated(S[ft], kn & 1, t - 3, gate.w[ft >> 1], (ft & 1) * 16);
       }
     };
     kstep_rp<8>(DT, ring.lane_addr(c % 3), b[ks & 1], fill);
     if (ks < 15) bn.get(b[(ks + 1) & 1]);
   }
-  // ---- DP^T = V dt^T = -dP^T (16 k-steps over c); da images and u0 = dr + dt go to memory at the head of its first step
+  // ---- DP^T = V dt^T = -dP^T (16 k-steps over c); the da image and u go to memory at the head of its first step
+  STAMPK(2, 3);
   step_sync(6);
-  {
-    store_rp<8, true>(P.darp + (size_t)cloud * V_IMG, rt, lane, DT);
-    store_t<8, 256, true>(P.dat + (size_t)cloud * V_IMG, rt, lane, DT, stg);
-    load_rows<8>(P.dr, row0, P.ld_dr, S, stg, lane);     // (dz^T is dead: S takes dr^T again for u0 = dr + dt)
-    if (P.dr2) {
-      floatx16 T2[8];
-      load_rows<8>(P.dr2, row0, P.ld_dr2, T2, stg, lane);
+  STAMPK(2, 4);
 #pragma unroll
-      for (int ft = 0; ft < 8; ++ft) S[ft] += T2[ft];
-    }
-#pragma unroll
-    for (int ft = 0; ft < 8; ++ft)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) S[ft][i] += DT[ft][i];
-    store_rows<8>(P.u, row0, E, S, stg, lane);
-  }
+  for (int ft = 0; ft < 8; ++ft) S[ft] += DT[ft];       // u = dr + dt
+  store_rows<8>(P.u, row0, E, S, stg, lane);
+  __builtin_amdgcn_sched_barrier(0);   // (one accumulator set leaves before the next piece of work needs registers)
+  STAMPK(2, 5);
+  store_rp<8, true>(P.darp + (size_t)cloud * V_IMG, rt, lane, DT);
+  __builtin_amdgcn_sched_barrier(0);
+  STAMPK(2, 6);
   floatx16 DP[8];
   ZERO_TILES(DP, 8);
   make_b(DT[0], 0, b[0]);
@@ -599,92 +611,91 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
     if (ks > 0) step_sync(6);
     BNext bn;
     auto fill = [&](int t) {
-      if (t < 3) {
-        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t);
-        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t + 1);
-      } else if (t < 7 && ks < 15) {
-        bn.pair(DT[(ks + 1) >> 1], (ks + 1) & 1, t - 3);
-      }
+      fill_dma(c, t);
+      if (t >= 3 && t < 7 && ks < 15) bn.pair(DT[(ks + 1) >> 1], (ks + 1) & 1, t - 3);
     };
     kstep_rp<8>(DP, ring.lane_addr(c % 3), b[ks & 1], fill);
     if (ks < 15) bn.get(b[(ks + 1) & 1]);
   }
-  // ---- S^T = K q^T, P^T
-  ZERO_TILES(S, 8);
-  bf16x8 qf[4][3];
-  load_own_frags(P.qrp + (size_t)cloud * QK_IMG, rt, lane, qf);
+  // ---- S^T = K q^T, P^T (u is in memory: its registers hold the scores now)
+  __builtin_amdgcn_sched_barrier(0);
+  STAMPK(2, 9);
+  // (what the tail derives from the lane id is derived again here instead of occupying registers through the loops above)
+  const int lane2 = fresh_lane();
+  const int h2 = lane2 >> 5;
+  const long row2 = (long)cloud * L + 32 * rt + (lane2 & 31);
+  floatx16(&S2)[8] = S;
+  ZERO_TILES(S2, 8);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     const int c = 32 + ks;
-    step_sync(6);
-    auto fill = [&](int t) {
-      if (t < 3) {
-        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t);
-        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t + 1);
-      }
-    };
-    kstep_rp<8>(S, ring.lane_addr(c % 3), qf[ks], fill);
+    bf16x8 qf[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      qf[p] = *reinterpret_cast<const bf16x8*>(P.qrp + (size_t)cloud * QK_IMG + (((ks * 3 + p) * 8 + rt) * 64 + lane2) * 16);
+    step_sync(9);    // (the three fragment loads above are younger than the slab waited for)
+    auto fill = [&](int t) { fill_dma(c, t); };
+    kstep_rp<8>(S2, ring.lane_addr(c % 3), qf, fill);
   }
-  softmax_regs(S);
+  STAMPK(2, 10);
+  softmax_regs(S2);
   {  // delta = sum P dP;  dS = P (dP - delta) / 8  with dP = -DP
     float d = 0.f;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) d -= S[t][i] * DP[t][i];
+      for (int i = 0; i < 16; ++i) d -= S2[t][i] * DP[t][i];
     d += xor32(d);
-    if (h == 0) P.delta[row] = d;
+    if (h2 == 0) P.delta[row2] = d;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) S[t][i] = S[t][i] * (-DP[t][i] - d) * 0.125f;
+      for (int i = 0; i < 16; ++i) S2[t][i] = S2[t][i] * (-DP[t][i] - d) * 0.125f;
   }
   // ---- dq^T = K^T dS^T (16 k-steps over the keys, 4 per slab; rows = d)
+  __builtin_amdgcn_sched_barrier(0);
+  STAMPK(2, 11);
   floatx16 DQ[2];
   ZERO_TILES(DQ, 2);
+  make_b(S2[0], 0, b[0]);
 #pragma unroll
   for (int sl = 0; sl < 4; ++sl) {
     const int c = 36 + sl;
-    step_sync(6);
-    ring.issue<6>(src(c + 2), (c + 2) % 3);
-    const TrAddr<64> ta(ring.slot_addr(c % 3), lane);
+    step_sync(sl == 0 ? 7 : sl == 3 ? 0 : 6);   // (sl == 0: the store of delta is younger than the slab as well)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue1(c + 2, i);
+    const uint32_t ta = tr_lane_addr(ring.slot_addr(c % 3), lane2);
     static_for<0, 4>([&](auto iq) {
       constexpr int q4 = decltype(iq)::value;
       const int ks = 4 * sl + q4;
-      make_b(S[ks >> 1], ks & 1, b[0]);
-      kstep_tr<2, 64, q4 * 6144>(DQ, ta, b[0]);
+      BNext bn;
+      auto fill = [&](int t) {
+        if (ks < 15) {
+          bn.pair(S2[(ks + 1) >> 1], (ks + 1) & 1, 2 * t);
+          bn.pair(S2[(ks + 1) >> 1], (ks + 1) & 1, 2 * t + 1);
+        }
+      };
+      kstep_tr<2, 64, q4 * 6144>(DQ, ta, b[ks & 1], fill);
+      if (ks < 15) bn.get(b[(ks + 1) & 1]);
     });
   }
-  // ---- u^T = u0^T + Wq^T dq^T (4 k-steps over d): the accumulators start from u0
-  floatx16 U[8];
-  step_sync(6);
-  store_rows<2>(P.dq, row0, DK, DQ, stg, lane);
-  load_rows<8>(P.u, row0, E, U, stg, lane);
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const int c = 40 + ks;
-    if (ks > 0) step_sync(c + 1 < NS ? 6 : 0);
-    auto fill = [&](int t) {
-      if (t < 3 && c + 2 < NS) {
-        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t);
-        ring.issue1(src(c + 2), (c + 2) % 3, 2 * t + 1);
-      }
-    };
-    make_b(DQ[ks >> 1], ks & 1, b[0]);
-    kstep_rp<8>(U, ring.lane_addr(c % 3), b[0], fill);
-  }
-  store_rows<8>(P.u, row0, E, U, stg, lane);
+  STAMPK(2, 12);
+  store_rows<2>(P.dq, row0, DK, DQ, stg, lane2);
+  STAMPK(2, 13);
 }
 
 // ================================================================================================================
-// backward, key side: the wavefront's 32 points as KEYS, the cloud's 256 queries walked two 32-row tiles at a time.
-//   S = q k^T (key on the lane), P = exp(S/8 - lse_q), dP = da v^T, dS = P (dP - delta_q) / 8,
-//   dv^T += da^T P, dk^T += q^T dS;  then dx = u + dk Wk + dv Wv for the wavefront's points
+// backward, key side: the wavefront's 32 points as KEYS against all 256 queries of the cloud (round 4: whole-cloud
+// accumulators as in the forward kernel instead of query-tile pairs: every slab feeds 48 MFMAs per wavefront).
+//   S = q k^T (key on the lane, query in the registers), P = exp(S/8 - lse_q), dP = da v^T, dS = P (dP - delta_q) / 8,
+//   dk^T = q^T dS, dv^T = da^T P (in this order: dS dies before the dv accumulators are born);
+//   then dx = u + dq Wq + dk Wk + dv Wv for the wavefront's points (u = dr + dt and dq from the query-side pass)
 struct BwdKProb {
-  const unsigned char *qrp, *qt, *krp, *vrp, *darp, *dat;
+  const unsigned char *qrp, *krp, *vrp, *darp;
   const unsigned char* w;
   const float *lse, *delta;
   const float* u;     // [B*L, E]
+  const float* dq;    // [B*L, DK]
   float* dk;          // [B*L, DK]
   float* dv;          // [B*L, E]
   float* dx;          // [B*L, E]
@@ -700,165 +711,187 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_k_kernel(BwdKArgs a) {
   const int lb = logical_block(blockIdx.x, gridDim.x);
   const BwdKProb& P = a.p[lb / a.nb];
   const int cb = lb % a.nb, cloud = cb >> 1, rt = (cb & 1) * 4 + wave;
-  const long row = (long)cloud * L + 32 * rt + (lane & 31);
   const unsigned char* qrp = P.qrp + (size_t)cloud * QK_IMG;
-  const unsigned char* qt = P.qt + (size_t)cloud * QK_IMG;
+  const unsigned char* krp = P.krp + (size_t)cloud * QK_IMG;
   const unsigned char* vrp = P.vrp + (size_t)cloud * V_IMG;
   const unsigned char* darp = P.darp + (size_t)cloud * V_IMG;
-  const unsigned char* dat = P.dat + (size_t)cloud * V_IMG;
-  const unsigned char* wkvt = P.w + W_KVT;
+  const unsigned char* wqkvt = P.w + W_QT;    // [Wq^T | Wk^T | Wv^T]: 4 + 4 + 16 k-step slabs, contiguous
   const Ring ring{lds, wave, lane, SLAB};
   const long row0 = (long)cloud * L + 32 * rt;
   float* stg = reinterpret_cast<float*>(lds + 3 * SLAB + 2048 + wave * STG_BYTES);
   float* row_consts = reinterpret_cast<float*>(lds + 3 * SLAB);
+  const uint32_t tsrc = tr_src_lane_off(lane);
+  STAMPK(3, 0);
   row_consts[tid] = P.lse[(long)cloud * L + tid];
   row_consts[256 + tid] = P.delta[(long)cloud * L + tid];
-
-  // this wavefront's key fragments (B operand of S = q k^T): 4 k-steps x 3 planes
-  bf16x8 kf[4][3];
-  load_own_frags(P.krp + (size_t)cloud * QK_IMG, rt, lane, kf);
-  // value fragments of this wavefront's keys (B operand of dP = da v^T), four k-steps at a time
-  bf16x8 vb[2][4][3];
-  auto load_vb = [&](int m, bf16x8 (&dst)[4][3]) {
-#pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4)
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        dst[k4][p] = *reinterpret_cast<const bf16x8*>(vrp + ((((4 * m + k4) * 3 + p) * 8 + rt) * 64 + lane) * 16);
+  // slab sequence: q 0..3 (k = d) | da 0..15 (k = c) | q^T (T use, 4 k-steps of 16 queries each) 0..3 |
+  //                da^T (T use, k-step = 16 queries) 0..15 | [Wq^T | Wk^T | Wv^T] 0..23
+  constexpr int NS = 64;
+  auto issue1 = [&](int c, int i) {
+    if (c < 4)
+      ring.issue1(qrp + c * SLAB, c % 3, i);
+    else if (c < 20)
+      ring.issue1(darp + (c - 4) * SLAB, c % 3, i);
+    else if (c < 24)
+      ring.issue1_t<64>(qrp, tsrc, 4 * (c - 20), c % 3, i);
+    else if (c < 40)
+      ring.issue1_t<256>(darp, tsrc, c - 24, c % 3, i);
+    else if (c < NS)
+      ring.issue1(wqkvt + (c - 40) * SLAB, c % 3, i);
   };
-
-  floatx16 DV[8], DKt[2];
-  ZERO_TILES(DV, 8);
-  ZERO_TILES(DKt, 2);
-
-  // Slabs of one PAIR of query tiles (2 pr, 2 pr + 1), 24 KB each, in consumption order (slab index c = 10 pr + j):
-  //   j = 0     A:  q Rp rows of the two tiles, 4 k-steps                       S  = q k^T
-  //   j = 1..4  B:  da Rp rows of the two tiles, k-steps 4 (j-1) .. 4 (j-1) + 3  dP = da v^T
-  //   j = 5..8  C:  da T k-step 4 pr + (j-5)  (16 queries x 256 c)               dv^T += da^T P
-  //   j = 9     D:  q T k-steps 4 pr .. 4 pr + 3                                 dk^T += q^T dS
-  // then the 20 k-step slabs of [Wk^T | Wv^T] (c = 40..59).
-  auto issue_slab = [&](int c) {
-    const int slot = c % 3;
-    if (c >= 40) {
-      if (c < 60) ring.issue<6>(wkvt + (c - 40) * SLAB, slot);
-      return;
+  auto fill_dma = [&](int c, int t) {
+    if (t < 3) {
+      issue1(c + 2, 2 * t);
+      issue1(c + 2, 2 * t + 1);
     }
-    const int pr = c / 10, j = c % 10;
-    if (j == 0)
-      ring.issue_tiles(qrp, 0, pr, slot);
-    else if (j < 5)
-      ring.issue_tiles(darp, 4 * (j - 1), pr, slot);
-    else if (j < 9)
-      ring.issue<6>(dat + (4 * pr + (j - 5)) * SLAB, slot);
-    else
-      ring.issue<6>(qt + (4 * pr) * 6144, slot);
   };
-  issue_slab(0);
-  issue_slab(1);
-  load_vb(0, vb[0]);
+  // the wavefront's own rows of an Rp image as the B operand of k-step ks: three chunks straight from global
+  auto own_frag = [&](const unsigned char* img, int ks, bf16x8 (&f)[3]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const bf16x8*>(img + (((ks * 3 + p) * 8 + rt) * 64 + lane) * 16);
+  };
+#pragma unroll
+  for (int i = 0; i < 6; ++i) issue1(0, i);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) issue1(1, i);
+  bf16x8 of[2][3];
+  own_frag(krp, 0, of[0]);
   __syncthreads();   // row constants in LDS (drains the first two slabs once)
+  STAMPK(3, 1);
 
-  for (int pr = 0; pr < 4; ++pr) {
-    const int c0 = 10 * pr;
-    // ---- S tiles (2 x 32 queries x this wavefront's 32 keys)
-    floatx16 S1[2], DP1[2];
-    ZERO_TILES(S1, 2);
-    ZERO_TILES(DP1, 2);
-    step_sync(6);
-    issue_slab(c0 + 2);
-    chain_rp1<4, 0>(S1[0], ring.lane_addr(c0 % 3), kf);
-    chain_rp1<4, 12288>(S1[1], ring.lane_addr(c0 % 3), kf);
-    // P = exp(S / 8 - lse_q): the query is the register's row
-    {
-      const float c = 0.125f * LOG2E;
+  // ---- S = q k^T (4 k-steps over d): rows = the cloud's 256 queries, B = this wavefront's key fragments
+  floatx16 S[8];
+  ZERO_TILES(S, 8);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+  for (int ks = 0; ks < 4; ++ks) {
+    const int c = ks;
+    if (ks > 0) step_sync(9);   // (the fragment loads of the next step are younger than the slab waited for)
+    if (ks < 3)
+      own_frag(krp, ks + 1, of[(ks + 1) & 1]);
+    else
+      own_frag(vrp, 0, of[(ks + 1) & 1]);
+    auto fill = [&](int t) { fill_dma(c, t); };
+    kstep_rp<8>(S, ring.lane_addr(c % 3), of[ks & 1], fill);
+  }
+  STAMPK(3, 2);
+  // P = exp(S / 8 - lse_q): the query is the register's row
+  {
+    const float c = 0.125f * LOG2E;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 ls = *reinterpret_cast<const float4*>(row_consts + 64 * pr + 32 * t + 8 * g + 4 * h);
-          const float lv[4] = {ls.x, ls.y, ls.z, ls.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) S1[t][4 * g + e] = __builtin_amdgcn_exp2f(S1[t][4 * g + e] * c - lv[e] * LOG2E);
-        }
-    }
-    // ---- dP tiles = da v^T (16 k-steps over c in four slabs); B = this wavefront's value fragments
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int c = c0 + 1 + m;
-      step_sync(6);
-      if (m < 3)
-        load_vb(m + 1, vb[(m + 1) & 1]);   // (ahead of this step's DMA: older than it, landed by the next step_sync)
-      issue_slab(c + 2);
-      chain_rp1<4, 0>(DP1[0], ring.lane_addr(c % 3), vb[m & 1]);
-      chain_rp1<4, 12288>(DP1[1], ring.lane_addr(c % 3), vb[m & 1]);
-    }
-    // dS = P (dP - delta_q) / 8
-    floatx16 DS1[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 8; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 de = *reinterpret_cast<const float4*>(row_consts + 256 + 64 * pr + 32 * t + 8 * g + 4 * h);
-        const float dv4[4] = {de.x, de.y, de.z, de.w};
+        const float4 ls = *reinterpret_cast<const float4*>(row_consts + 32 * t + 8 * g + 4 * h);
+        const float lv[4] = {ls.x, ls.y, ls.z, ls.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) DS1[t][4 * g + e] = S1[t][4 * g + e] * (DP1[t][4 * g + e] - dv4[e]) * 0.125f;
+        for (int e = 0; e < 4; ++e) S[t][4 * g + e] = __builtin_amdgcn_exp2f(S[t][4 * g + e] * c - lv[e] * LOG2E);
       }
-    // ---- dv^T += da^T P (four k-steps of 16 queries, rows = c)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int c = c0 + 5 + m;
-      step_sync(6);
-      if (m == 0 && pr < 3) load_vb(0, vb[0]);
-      issue_slab(c + 2);
-      bf16x8 b[3];
-      make_b(S1[m >> 1], m & 1, b);
-      kstep_tr<8, 256, 0>(DV, TrAddr<256>(ring.slot_addr(c % 3), lane), b);
-    }
-    // ---- dk^T += q^T dS (four k-steps, rows = d)
-    {
-      const int c = c0 + 9;
-      step_sync(6);
-      issue_slab(c + 2);
-      const TrAddr<64> ta(ring.slot_addr(c % 3), lane);
-      static_for<0, 4>([&](auto im) {
-        constexpr int m = decltype(im)::value;
-        bf16x8 b[3];
-        make_b(DS1[m >> 1], m & 1, b);
-        kstep_tr<2, 64, m * 6144>(DKt, ta, b);
-      });
-    }
   }
-  // ---- dx^T = u^T + Wk^T dk^T + Wv^T dv^T (4 + 16 k-steps)
-  floatx16 DX[8];
-  bf16x8 bt[2][3];
-  make_b(DKt[0], 0, bt[0]);
+  __builtin_amdgcn_sched_barrier(0);
+  STAMPK(3, 3);
+  // ---- dP = da v^T (16 k-steps over c); B = this wavefront's value fragments, one step ahead
+  floatx16 DP[8];
+  ZERO_TILES(DP, 8);
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const int c = 4 + ks;
+    step_sync(9);
+    if (ks < 15) own_frag(vrp, ks + 1, of[(ks + 1) & 1]);
+    auto fill = [&](int t) { fill_dma(c, t); };
+    kstep_rp<8>(DP, ring.lane_addr(c % 3), of[ks & 1], fill);
+  }
+  STAMPK(3, 4);
+  // dS = P (dP - delta_q) / 8
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 de = *reinterpret_cast<const float4*>(row_consts + 256 + 32 * t + 8 * g + 4 * h);
+      const float dv4[4] = {de.x, de.y, de.z, de.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) DP[t][4 * g + e] = S[t][4 * g + e] * (DP[t][4 * g + e] - dv4[e]) * 0.125f;
+    }
+  // ---- dk^T = q^T dS (16 k-steps of 16 queries, four per slab; rows = d)
+  __builtin_amdgcn_sched_barrier(0);
+  floatx16 DKt[2];
+  ZERO_TILES(DKt, 2);
+  bf16x8 b[2][3];
+  make_b(DP[0], 0, b[0]);
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+    const int c = 20 + sl;
+    step_sync(6);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue1(c + 2, i);
+    const uint32_t ta = tr_lane_addr(ring.slot_addr(c % 3), lane);
+    static_for<0, 4>([&](auto iq) {
+      constexpr int q4 = decltype(iq)::value;
+      const int ks = 4 * sl + q4;
+      BNext bn;
+      auto fill = [&](int t) {
+        if (ks < 15) {
+          bn.pair(DP[(ks + 1) >> 1], (ks + 1) & 1, 2 * t);
+          bn.pair(DP[(ks + 1) >> 1], (ks + 1) & 1, 2 * t + 1);
+        }
+      };
+      kstep_tr<2, 64, q4 * 6144>(DKt, ta, b[ks & 1], fill);
+      if (ks < 15) bn.get(b[(ks + 1) & 1]);
+    });
+  }
+  STAMPK(3, 5);
+  // ---- dv^T = da^T P (16 k-steps of 16 queries, rows = c); dS is dead: its registers are the accumulators
+  __builtin_amdgcn_sched_barrier(0);
+  floatx16(&DV)[8] = DP;
+  ZERO_TILES(DV, 8);
+  make_b(S[0], 0, b[0]);
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const int c = 24 + ks;
+    step_sync(6);
+    BNext bn;
+    auto fill = [&](int t) {
+      fill_dma(c, t);
+      if (t >= 3 && t < 7 && ks < 15) bn.pair(S[(ks + 1) >> 1], (ks + 1) & 1, t - 3);
+    };
+    kstep_tr<8, 256, 0>(DV, tr_lane_addr(ring.slot_addr(c % 3), lane), b[ks & 1], fill);
+    if (ks < 15) bn.get(b[(ks + 1) & 1]);
+  }
+  // ---- dx^T = u^T + Wq^T dq^T + Wk^T dk^T + Wv^T dv^T (4 + 4 + 16 k-steps); P is dead: its registers take u
+  STAMPK(3, 6);
+  __builtin_amdgcn_sched_barrier(0);
+  floatx16(&DX)[8] = S;
+  floatx16 DQ[2];
   step_sync(6);
   store_rows<2>(P.dk, row0, DK, DKt, stg, lane);
   store_rows<8>(P.dv, row0, E, DV, stg, lane);
+  load_rows<2>(P.dq, row0, DK, DQ, stg, lane);
   load_rows<8>(P.u, row0, E, DX, stg, lane);
+  bf16x8 bt[2][3];
+  make_b(DQ[0], 0, bt[0]);
+  STAMPK(3, 7);
 #pragma unroll
-  for (int ks = 0; ks < 20; ++ks) {
+  for (int ks = 0; ks < 24; ++ks) {
     const int c = 40 + ks;
-    if (ks > 0) step_sync(ks < 19 ? 6 : 0);
+    if (ks > 0) step_sync(ks < 23 ? 6 : 0);
     BNext bn;
     auto fill = [&](int t) {
-      if (t < 3) {
-        if (c + 2 < 60) {
-          ring.issue1(wkvt + (c + 2 - 40) * SLAB, (c + 2) % 3, 2 * t);
-          ring.issue1(wkvt + (c + 2 - 40) * SLAB, (c + 2) % 3, 2 * t + 1);
-        }
-      } else if (t < 7 && ks < 19) {
+      if (c + 2 < NS) fill_dma(c, t);
+      if (t >= 3 && t < 7 && ks < 23) {
         const int kn = ks + 1;
         if (kn < 4)
-          bn.pair(DKt[kn >> 1], kn & 1, t - 3);
+          bn.pair(DQ[kn >> 1], kn & 1, t - 3);
+        else if (kn < 8)
+          bn.pair(DKt[(kn - 4) >> 1], kn & 1, t - 3);
         else
-          bn.pair(DV[(kn - 4) >> 1], kn & 1, t - 3);
+          bn.pair(DV[(kn - 8) >> 1], kn & 1, t - 3);
       }
     };
     kstep_rp<8>(DX, ring.lane_addr(c % 3), bt[ks & 1], fill);
-    if (ks < 19) bn.get(bt[(ks + 1) & 1]);
+    if (ks < 23) bn.get(bt[(ks + 1) & 1]);
   }
+  STAMPK(3, 8);
   store_rows<8>(P.dx, row0, E, DX, stg, lane);
+  STAMPK(3, 9);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -868,6 +901,16 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 // ================================================================================================================
 // C ABI.  All entry points take up to two independent problems (the two encoders of predict5, model5_b.py:700-707)
 // so that one launch fills the chip: 2 B workgroups of four wavefronts per problem, one wavefront per SIMD.
+#ifdef ATTN_STAMPS
+extern "C" __attribute__((visibility("default"))) int pzn_attn_fused_read_stamps(long long* host, int clear) {
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess) return -1;
+  if (clear) {
+    static long long z[4][2][64];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 PZN_EXPORT size_t pzn_attn_fused_weight_bytes(void) { return W_BYTES; }
 PZN_EXPORT size_t pzn_attn_fused_qk_image_bytes(int B) { return B > 0 ? (size_t)B * QK_IMG : 0; }
 PZN_EXPORT size_t pzn_attn_fused_v_image_bytes(int B) { return B > 0 ? (size_t)B * V_IMG : 0; }
@@ -894,22 +937,20 @@ PZN_EXPORT int pzn_attn_fused_prep_weights(const float* Wq, const float* Wk, con
   PZN_RETURN_LAUNCH_STATUS();
 }
 
-// q, k, v images of `nprob` problems: x[i][B*L, E], weight planes w[i], biases; images: qrp, qt, krp, kt (QK size), vrp, vt
+// q, k, v images of `nprob` problems: x[i][B*L, E], weight planes w[i], biases; images: qrp, krp (QK size), vrp (V size)
 PZN_EXPORT int pzn_attn_fused_proj(int nprob, const float* const* x, const void* const* w, const float* const* bq,
-                                   const float* const* bk, const float* const* bv, int B, void* const* qrp, void* const* qt,
-                                   void* const* krp, void* const* kt, void* const* vrp, void* const* vt, pzn_stream_t stream) {
-  PZN_CHECK_ARG(nprob >= 1 && nprob <= 2 && B > 0 && x && w && bq && bk && bv && qrp && qt && krp && kt && vrp && vt);
+                                   const float* const* bk, const float* const* bv, int B, void* const* qrp,
+                                   void* const* krp, void* const* vrp, pzn_stream_t stream) {
+  PZN_CHECK_ARG(nprob >= 1 && nprob <= 2 && B > 0 && x && w && bq && bk && bv && qrp && krp && vrp);
   ProjArgs a;
   a.nb = 2 * B;
   for (int i = 0; i < nprob; ++i) {
-    PZN_CHECK_ARG(x[i] && w[i] && bq[i] && bk[i] && bv[i] && qrp[i] && qt[i] && krp[i] && kt[i] && vrp[i] && vt[i]);
+    PZN_CHECK_ARG(x[i] && w[i] && bq[i] && bk[i] && bv[i] && qrp[i] && krp[i] && vrp[i]);
     PZN_CHECK_ARG(aligned16(x[i]) && aligned16(w[i]) && aligned16(bq[i]) && aligned16(bk[i]) && aligned16(bv[i]) &&
-                  aligned16(qrp[i]) && aligned16(qt[i]) && aligned16(krp[i]) && aligned16(kt[i]) && aligned16(vrp[i]) &&
-                  aligned16(vt[i]));
+                  aligned16(qrp[i]) && aligned16(krp[i]) && aligned16(vrp[i]));
     a.p[i] = ProjProb{x[i], static_cast<const unsigned char*>(w[i]), bq[i], bk[i], bv[i],
-                      static_cast<unsigned char*>(qrp[i]), static_cast<unsigned char*>(qt[i]),
-                      static_cast<unsigned char*>(krp[i]), static_cast<unsigned char*>(kt[i]),
-                      static_cast<unsigned char*>(vrp[i]), static_cast<unsigned char*>(vt[i])};
+                      static_cast<unsigned char*>(qrp[i]), static_cast<unsigned char*>(krp[i]),
+                      static_cast<unsigned char*>(vrp[i])};
   }
   hipLaunchKernelGGL(attn_proj_kernel, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
   PZN_RETURN_LAUNCH_STATUS();
@@ -918,95 +959,64 @@ PZN_EXPORT int pzn_attn_fused_proj(int nprob, const float* const* x, const void*
 // one block forward: r = x + relu(Wo (x - softmax(q k^T / 8) v) + bo); also t = x - attn v, the gate bits, ln-sum-exp per
 // row and (map[i] != NULL) the running mean map: map = scale P (accumulate = 0) or map += scale P
 PZN_EXPORT int pzn_attn_fused_fwd(int nprob, const float* const* x, const void* const* qrp, const void* const* krp,
-                                  const void* const* vt, const void* const* w, const float* const* bo, int B,
+                                  const void* const* vrp, const void* const* w, const float* const* bo, int B,
                                   float* const* r, float* const* t, void* const* mask, float* const* map, float* const* lse,
                                   int map_accumulate, float map_scale, pzn_stream_t stream) {
-  PZN_CHECK_ARG(nprob >= 1 && nprob <= 2 && B > 0 && x && qrp && krp && vt && w && bo && r && t && mask && map && lse);
+  PZN_CHECK_ARG(nprob >= 1 && nprob <= 2 && B > 0 && x && qrp && krp && vrp && w && bo && r && t && mask && map && lse);
   FwdArgs a;
-  a.dbg = nullptr;
-#ifdef ATTN_STAMPS
-  {
-    static long long* d = nullptr;
-    if (!d) hipMalloc(&d, 64 * sizeof(long long));
-    a.dbg = d;
-  }
-#endif
   a.nb = 2 * B;
   a.map_accumulate = map_accumulate;
   a.map_scale = map_scale;
   for (int i = 0; i < nprob; ++i) {
-    PZN_CHECK_ARG(x[i] && qrp[i] && krp[i] && vt[i] && w[i] && bo[i] && r[i] && t[i] && mask[i] && lse[i]);
-    PZN_CHECK_ARG(aligned16(x[i]) && aligned16(qrp[i]) && aligned16(krp[i]) && aligned16(vt[i]) && aligned16(w[i]) &&
+    PZN_CHECK_ARG(x[i] && qrp[i] && krp[i] && vrp[i] && w[i] && bo[i] && r[i] && t[i] && mask[i] && lse[i]);
+    PZN_CHECK_ARG(aligned16(x[i]) && aligned16(qrp[i]) && aligned16(krp[i]) && aligned16(vrp[i]) && aligned16(w[i]) &&
                   aligned16(bo[i]) && aligned16(r[i]) && aligned16(t[i]) && aligned16(mask[i]) && aligned16(map[i]));
     a.p[i] = FwdProb{x[i], static_cast<const unsigned char*>(qrp[i]), static_cast<const unsigned char*>(krp[i]),
-                     static_cast<const unsigned char*>(vt[i]), static_cast<const unsigned char*>(w[i]), bo[i], r[i], t[i],
+                     static_cast<const unsigned char*>(vrp[i]), static_cast<const unsigned char*>(w[i]), bo[i], r[i], t[i],
                      static_cast<uint32_t*>(mask[i]), map[i], lse[i]};
   }
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
-#ifdef ATTN_STAMPS
-  {
-    long long hst[24];
-    hipStreamSynchronize(pzn_hip_stream(stream));
-    hipMemcpy(hst, a.dbg, sizeof(hst), hipMemcpyDeviceToHost);
-    fprintf(stderr, "fwd stamps:");
-    for (int i = 1; i < 8; ++i) fprintf(stderr, " %lld", hst[i] - hst[i - 1]);
-    fprintf(stderr, "  total %lld | O steps (sync, compute):", hst[7] - hst[0]);
-    for (int i = 8; i < 15; ++i) fprintf(stderr, " %lld", hst[i + 1] - hst[i]);
-    fprintf(stderr, " | PV steps:");
-    for (int i = 16; i < 23; ++i) fprintf(stderr, " %lld", hst[i + 1] - hst[i]);
-    fprintf(stderr, "\n");
-  }
-#endif
   PZN_RETURN_LAUNCH_STATUS();
 }
 
-// backward, query side (see attn_bwd_q_kernel): writes dz, u, dq, delta and the two images of da
+// backward, query side (see attn_bwd_q_kernel): writes dz, u = dr + dt, dq, delta and the image of da
 PZN_EXPORT int pzn_attn_fused_bwd_q(int nprob, const float* const* dr, int ld_dr, const float* const* dr2, int ld_dr2,
-                                    const void* const* mask, const void* const* qrp,
-                                    const void* const* krp, const void* const* kt, const void* const* vrp,
-                                    const void* const* w, int B, float* const* dz, float* const* u, float* const* dq,
-                                    void* const* darp, void* const* dat, float* const* delta, pzn_stream_t stream) {
-  PZN_CHECK_ARG(nprob >= 1 && nprob <= 2 && B > 0 && dr && mask && qrp && krp && kt && vrp && w && dz && u && dq && darp &&
-                dat && delta);
+                                    const void* const* mask, const void* const* qrp, const void* const* krp,
+                                    const void* const* vrp, const void* const* w, int B, float* const* dz, float* const* u,
+                                    float* const* dq, void* const* darp, float* const* delta, pzn_stream_t stream) {
+  PZN_CHECK_ARG(nprob >= 1 && nprob <= 2 && B > 0 && dr && mask && qrp && krp && vrp && w && dz && u && dq && darp && delta);
   BwdQArgs a;
   a.nb = 2 * B;
   for (int i = 0; i < nprob; ++i) {
-    PZN_CHECK_ARG(dr[i] && mask[i] && qrp[i] && krp[i] && kt[i] && vrp[i] && w[i] && dz[i] && u[i] && dq[i] && darp[i] &&
-                  dat[i] && delta[i]);
-    PZN_CHECK_ARG(aligned16(dr[i]) && aligned16(mask[i]) && aligned16(qrp[i]) && aligned16(krp[i]) && aligned16(kt[i]) &&
-                  aligned16(vrp[i]) && aligned16(w[i]) && aligned16(dz[i]) && aligned16(u[i]) && aligned16(dq[i]) &&
-                  aligned16(darp[i]) && aligned16(dat[i]));
+    PZN_CHECK_ARG(dr[i] && mask[i] && qrp[i] && krp[i] && vrp[i] && w[i] && dz[i] && u[i] && dq[i] && darp[i] && delta[i]);
+    PZN_CHECK_ARG(aligned16(dr[i]) && aligned16(mask[i]) && aligned16(qrp[i]) && aligned16(krp[i]) && aligned16(vrp[i]) &&
+                  aligned16(w[i]) && aligned16(dz[i]) && aligned16(u[i]) && aligned16(dq[i]) && aligned16(darp[i]));
     PZN_CHECK_ARG(ld_dr >= E && (ld_dr & 3) == 0 && (!dr2 || !dr2[i] || (aligned16(dr2[i]) && ld_dr2 >= E && (ld_dr2 & 3) == 0)));
     a.p[i] = BwdQProb{dr[i], dr2 ? dr2[i] : nullptr, ld_dr, ld_dr2, static_cast<const uint32_t*>(mask[i]),
-                      static_cast<const unsigned char*>(qrp[i]),
-                      static_cast<const unsigned char*>(krp[i]), static_cast<const unsigned char*>(kt[i]),
+                      static_cast<const unsigned char*>(qrp[i]), static_cast<const unsigned char*>(krp[i]),
                       static_cast<const unsigned char*>(vrp[i]), static_cast<const unsigned char*>(w[i]), dz[i], u[i], dq[i],
-                      static_cast<unsigned char*>(darp[i]), static_cast<unsigned char*>(dat[i]), delta[i]};
+                      static_cast<unsigned char*>(darp[i]), delta[i]};
   }
   hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
-// backward, key side (see attn_bwd_k_kernel): writes dk, dv and the block's input gradient dx
-PZN_EXPORT int pzn_attn_fused_bwd_k(int nprob, const void* const* qrp, const void* const* qt, const void* const* krp,
-                                    const void* const* vrp, const void* const* darp, const void* const* dat,
-                                    const void* const* w, const float* const* lse, const float* const* delta,
-                                    const float* const* u, int B, float* const* dk, float* const* dv, float* const* dx,
-                                    pzn_stream_t stream) {
-  PZN_CHECK_ARG(nprob >= 1 && nprob <= 2 && B > 0 && qrp && qt && krp && vrp && darp && dat && w && lse && delta && u && dk &&
-                dv && dx);
+// backward, key side (see attn_bwd_k_kernel): writes dk, dv and the block's input gradient dx = u + dq Wq + dk Wk + dv Wv
+PZN_EXPORT int pzn_attn_fused_bwd_k(int nprob, const void* const* qrp, const void* const* krp, const void* const* vrp,
+                                    const void* const* darp, const void* const* w, const float* const* lse,
+                                    const float* const* delta, const float* const* u, const float* const* dq, int B,
+                                    float* const* dk, float* const* dv, float* const* dx, pzn_stream_t stream) {
+  PZN_CHECK_ARG(nprob >= 1 && nprob <= 2 && B > 0 && qrp && krp && vrp && darp && w && lse && delta && u && dq && dk && dv && dx);
   BwdKArgs a;
   a.nb = 2 * B;
   for (int i = 0; i < nprob; ++i) {
-    PZN_CHECK_ARG(qrp[i] && qt[i] && krp[i] && vrp[i] && darp[i] && dat[i] && w[i] && lse[i] && delta[i] && u[i] && dk[i] &&
-                  dv[i] && dx[i]);
-    PZN_CHECK_ARG(aligned16(qrp[i]) && aligned16(qt[i]) && aligned16(krp[i]) && aligned16(vrp[i]) && aligned16(darp[i]) &&
-                  aligned16(dat[i]) && aligned16(w[i]) && aligned16(lse[i]) && aligned16(delta[i]) && aligned16(u[i]) &&
-                  aligned16(dk[i]) && aligned16(dv[i]) && aligned16(dx[i]));
-    a.p[i] = BwdKProb{static_cast<const unsigned char*>(qrp[i]), static_cast<const unsigned char*>(qt[i]),
-                      static_cast<const unsigned char*>(krp[i]), static_cast<const unsigned char*>(vrp[i]),
-                      static_cast<const unsigned char*>(darp[i]), static_cast<const unsigned char*>(dat[i]),
-                      static_cast<const unsigned char*>(w[i]), lse[i], delta[i], u[i], dk[i], dv[i], dx[i]};
+    PZN_CHECK_ARG(qrp[i] && krp[i] && vrp[i] && darp[i] && w[i] && lse[i] && delta[i] && u[i] && dq[i] && dk[i] && dv[i] && dx[i]);
+    PZN_CHECK_ARG(aligned16(qrp[i]) && aligned16(krp[i]) && aligned16(vrp[i]) && aligned16(darp[i]) && aligned16(w[i]) &&
+                  aligned16(lse[i]) && aligned16(delta[i]) && aligned16(u[i]) && aligned16(dq[i]) && aligned16(dk[i]) &&
+                  aligned16(dv[i]) && aligned16(dx[i]));
+    a.p[i] = BwdKProb{static_cast<const unsigned char*>(qrp[i]), static_cast<const unsigned char*>(krp[i]),
+                      static_cast<const unsigned char*>(vrp[i]), static_cast<const unsigned char*>(darp[i]),
+                      static_cast<const unsigned char*>(w[i]), lse[i], delta[i], u[i], dq[i], dk[i], dv[i], dx[i]};
   }
   hipLaunchKernelGGL(attn_bwd_k_kernel, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
   PZN_RETURN_LAUNCH_STATUS();

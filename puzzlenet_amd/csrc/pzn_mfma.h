@@ -1,4 +1,4 @@
-// pzn_mfma.h — building blocks of the chained matrix-core kernels (attnfused.hip, salevel.hip), gfx950 only:
+// pzn_mfma.h — building blocks of the chained matrix-core kernels (attnfused.hip, salevel.hip, outproj.hip), gfx950 only:
 // bf16x3 split precision, fragment reads from LDS as inline asm with counted waits (two tiles ahead), the LDS-DMA slab
 // ring (three slots, two slabs in flight, one barrier per slab), compile-time loops.  Included inside an anonymous
 // namespace by each translation unit (which includes <type_traits> and pzn_common.h first).
@@ -50,8 +50,18 @@ struct BNext {
   uint32_t w[3][4];
   template <bool NEG = false>
   __device__ __forceinline__ void pair(const floatx16& x, int s, int j) {
+#ifdef PZN_EXP_NOSPLIT   // timing experiment only: what the split of the next B fragment costs the step
+    w[0][j] = w[1][j] = w[2][j] = __float_as_uint(x[8 * s + 2 * j]);
+    return;
+#endif
     const float x0 = x[8 * s + 2 * j], x1 = x[8 * s + 2 * j + 1];
     split_pair(NEG ? -x0 : x0, NEG ? -x1 : x1, w[0][j], w[1][j], w[2][j]);
+  }
+  // the same with the values gated by bits (16 s' + 8 s + 2 j) and the next one of `word` (a ReLU mask)
+  __device__ __forceinline__ void pair_gated(const floatx16& x, int s, int j, uint32_t word, int bit0) {
+    const int i = 8 * s + 2 * j;
+    const float x0 = (word >> (bit0 + i)) & 1u ? x[i] : 0.f, x1 = (word >> (bit0 + i + 1)) & 1u ? x[i + 1] : 0.f;
+    split_pair(x0, x1, w[0][j], w[1][j], w[2][j]);
   }
   __device__ __forceinline__ void get(bf16x8 (&b)[3]) const {
 #pragma unroll
@@ -153,72 +163,60 @@ __device__ __forceinline__ void kstep_rp(floatx16 (&acc)[RT], uint32_t lane_addr
   });
 }
 
-// NK k-steps of ONE 32-row tile whose fragments sit 3072 bytes apart ([k-step][plane][lane][16 B]): acc += sum_k A_k B_k.
-// TILE_OFF = byte offset of the tile inside the slab (compile time); lane_addr as above.
-template <int NK, int TILE_OFF>
-__device__ __forceinline__ void chain_rp1(floatx16& acc, uint32_t lane_addr, const bf16x8 (&b)[NK][3]) {
-  static_assert(NK % 2 == 0, "two register sets alternate");
-  bf16x8 f[2][3];
-  RP_ISSUE(lane_addr, TILE_OFF, TILE_OFF + 1024, TILE_OFF + 2048, f[0][0], f[0][1], f[0][2]);
-  static_for<0, NK>([&](auto ic) {
-    constexpr int k = decltype(ic)::value;
-    constexpr int cur = k & 1, nxt = (k + 1) & 1;
-    if constexpr (k + 1 < NK) {
-      RP_ISSUE(lane_addr, TILE_OFF + (k + 1) * 3072, TILE_OFF + (k + 1) * 3072 + 1024, TILE_OFF + (k + 1) * 3072 + 2048,
-               f[nxt][0], f[nxt][1], f[nxt][2]);
-      RP_WAITN(3, f[cur][0], f[cur][1], f[cur][2]);
-    } else {
-      RP_WAITN(0, f[cur][0], f[cur][1], f[cur][2]);
-    }
-    acc = mma6v(f[cur][0], f[cur][1], f[cur][2], b[k], acc);
-  });
+// ---- transposed reads of an Rp image ("T use") --------------------------------------------------------------------
+// One Rp image of M[n][F] serves both kinds of product.  With k = feature it is streamed in plain slabs
+// ([plane][row tile][lane][16 B], ds_read_b128).  With k = ROW n (the operand is M^T[f][n]) the same bytes are fetched
+// in a different cut and read with ds_read_b64_tr_b16 (hardware transpose of 4 x 16 blocks of 16-bit elements: in a
+// 16-lane group lane 4q+p supplies the 8-byte unit (row q, columns 4p..4p+3) and receives column (lane & 15), rows
+// 0..3).  The 8-byte halves of an Rp chunk are exactly such units: the chunk of lane (r, h) of k-step ks_f holds row r,
+// features 16 ks_f + 4h + {0..3} and 16 ks_f + 8 + 4h + {0..3}.
+//
+// T-use slab of k-step kk (16 rows n = 16 kk .. 16 kk + 15, all F features): [plane][ks_f = 0 .. F/16-1] blocks of 512
+// bytes = the 32 chunks (r16 = n & 15, h) of that (plane, ks_f), at position
+//     pos(r16, h; ks_f) = (r16 & 3) + 4 h + 8 (((r16 >> 2) ^ ks_f) & 1) + 16 (r16 >> 3)
+// (the ks_f parity in bit 3 separates the two feature halves of a 32-lane service group: conflict-free).  The fragment
+// of feature tile ft, plane p for the lane (g = lane >> 4, i = lane & 15; q = i >> 2, pp = i & 3, hp = g >> 1, gb = g & 1):
+//     lo (rows 4 hp + q) at  TrAddr + p PLS + 1024 ft,   hi (rows 8 + 4 hp + q) 256 bytes further,
+//     TrAddr = slab + 512 gb + 16 (q + 4 (pp & 1) + 8 (gb ^ hp)) + 8 (pp >> 1),   PLS = 32 F bytes per plane.
+// The k order of the fragment (k = 8 hp + j <-> row perm(hp, j) = 8 (j >> 2) + 4 hp + (j & 3)) is the order in which an
+// accumulator's registers come out as a B operand, as for the Rp chunks themselves.
+__device__ __forceinline__ uint32_t tr_lane_addr(uint32_t slab_addr, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, hp = g >> 1, gb = g & 1;
+  return slab_addr + (uint32_t)(512 * gb + 16 * (q + 4 * (pp & 1) + 8 * (gb ^ hp)) + 8 * (pp >> 1));
+}
+// per-lane part of the SOURCE address of a T-use DMA piece (1 KB = the blocks ks_f even | odd of one plane): lane L
+// writes position L & 31 of block L >> 5, i.e. fetches the chunk (r16, h) that belongs there
+__device__ __forceinline__ uint32_t tr_src_lane_off(int lane) {
+  const int blk = lane >> 5, pos = lane & 31;
+  const int q = pos & 3, hs = (pos >> 2) & 1, x = (pos >> 3) & 1, hi = pos >> 4;
+  const int r16 = q + 4 * (x ^ blk) + 8 * hi;
+  return (uint32_t)(blk * (3 * 8 * 1024) + (hs * 32 + r16) * 16);
 }
 
-// ---- transposed-read (T) slabs -------------------------------------------------------------------------------------
-// One plane of a T slab is [16 rows][F] bf16 with the 64-byte granule index XORed by the row key (F = 256: key = row & 3;
-// F = 64: key = (row >> 1) & 1).  ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of the
-// group's 4 x 16 block and receives column (lane & 15); groups g = 0..3: k half h = g >> 1, column half g & 1; the second
-// read of a fragment is 8 rows further (same key).  The feature tile ft sits 64 ft bytes along the row, INSIDE the XOR:
-// granule (ft ^ key) for ft < 4 (F = 256: + 256 bytes for ft >= 4), so a lane needs one address per value of ft & 3
-// (F = 64: ft & 1): TrAddr, computed once per slab; everything else is an instruction offset.
-template <int F>
-struct TrAddr {
-  uint32_t a[F == 256 ? 4 : 2];
-  __device__ __forceinline__ TrAddr(uint32_t slab_addr, int lane) {
-    const int g = lane >> 4, i = lane & 15;
-    const int row = 4 * (g >> 1) + (i >> 2);
-    const int colb = (16 * (g & 1) + 4 * (i & 3)) * 2;
-    const int key = F == 256 ? (row & 3) : ((row >> 1) & 1);
-#pragma unroll
-    for (int t = 0; t < (F == 256 ? 4 : 2); ++t) a[t] = slab_addr + (uint32_t)(row * (2 * F) + colb + 64 * (t ^ key));
-  }
-};
-
-#define TR_ISSUE(ADDR, OFF, F_, L0, H0, L1, H1, L2, H2)                                                             \
+#define TR_ISSUE(ADDR, OFF, PLS_, L0, H0, L1, H1, L2, H2)                                                           \
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(L0) : "v"(ADDR), "n"(OFF));                            \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H0) : "v"(ADDR), "n"((OFF) + 16 * (F_)));              \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(L1) : "v"(ADDR), "n"((OFF) + 32 * (F_)));              \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H1) : "v"(ADDR), "n"((OFF) + 48 * (F_)));              \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(L2) : "v"(ADDR), "n"((OFF) + 64 * (F_)));              \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H2) : "v"(ADDR), "n"((OFF) + 80 * (F_)))
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H0) : "v"(ADDR), "n"((OFF) + 256));                    \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(L1) : "v"(ADDR), "n"((OFF) + (PLS_)));                 \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H1) : "v"(ADDR), "n"((OFF) + (PLS_) + 256));           \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(L2) : "v"(ADDR), "n"((OFF) + 2 * (PLS_)));             \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H2) : "v"(ADDR), "n"((OFF) + 2 * (PLS_) + 256))
 #define TR_WAITN(N_, L0, H0, L1, H1, L2, H2)                                                                        \
   asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(L0), "+v"(H0), "+v"(L1), "+v"(H1), "+v"(L2), "+v"(H2))
 
-// one k-step of acc[ft] += A_ft B with A read transposed from a T slab: rows of A = feature 32 ft + lane % 32.
-// KOFF = byte offset of the k-step inside the slab (compile time).  Two tiles ahead, counted waits (6 reads per tile).
+// one k-step of acc[ft] += A_ft B with A read transposed from a T-use slab: rows of A = feature 32 ft + lane % 32.
+// ta = tr_lane_addr of the slab, KOFF = byte offset of the k-step inside it (compile time).  Two tiles ahead, counted
+// waits (6 reads per tile).
 template <int FT, int F, int KOFF, class Fill = NoFill>
-__device__ __forceinline__ void kstep_tr(floatx16 (&acc)[FT], const TrAddr<F>& ta, const bf16x8 (&b)[3],
-                                         const Fill& fill = Fill()) {
-  constexpr int NA = F == 256 ? 4 : 2;
+__device__ __forceinline__ void kstep_tr(floatx16 (&acc)[FT], uint32_t ta, const bf16x8 (&b)[3], const Fill& fill = Fill()) {
+  constexpr int PLS = 32 * F;
   bf16x4 lo[3][3], hi[3][3];
-  TR_ISSUE(ta.a[0], KOFF, F, lo[0][0], hi[0][0], lo[0][1], hi[0][1], lo[0][2], hi[0][2]);
-  if constexpr (FT > 1) TR_ISSUE(ta.a[1 % NA], KOFF + 256 * (1 / NA), F, lo[1][0], hi[1][0], lo[1][1], hi[1][1], lo[1][2], hi[1][2]);
+  TR_ISSUE(ta, KOFF, PLS, lo[0][0], hi[0][0], lo[0][1], hi[0][1], lo[0][2], hi[0][2]);
+  if constexpr (FT > 1) TR_ISSUE(ta, KOFF + 1024, PLS, lo[1][0], hi[1][0], lo[1][1], hi[1][1], lo[1][2], hi[1][2]);
   static_for<0, FT>([&](auto ic) {
     constexpr int ft = decltype(ic)::value;
     constexpr int cur = ft % 3, nxt = (ft + 2) % 3;
     if constexpr (ft + 2 < FT) {
-      TR_ISSUE(ta.a[(ft + 2) % NA], KOFF + 256 * ((ft + 2) / NA), F, lo[nxt][0], hi[nxt][0], lo[nxt][1], hi[nxt][1], lo[nxt][2],
-               hi[nxt][2]);
+      TR_ISSUE(ta, KOFF + 1024 * (ft + 2), PLS, lo[nxt][0], hi[nxt][0], lo[nxt][1], hi[nxt][1], lo[nxt][2], hi[nxt][2]);
       TR_WAITN(12, lo[cur][0], hi[cur][0], lo[cur][1], hi[cur][1], lo[cur][2], hi[cur][2]);
     } else if constexpr (ft + 1 < FT) {
       TR_WAITN(6, lo[cur][0], hi[cur][0], lo[cur][1], hi[cur][1], lo[cur][2], hi[cur][2]);
@@ -257,21 +255,38 @@ struct Ring {
   }
   // piece i (of NPW) of this wavefront only: lets a caller spread a slab's DMA instructions over a step
   __device__ __forceinline__ void issue1(const unsigned char* src, int slot, int i) const {
+#ifdef PZN_EXP_NODMA   // timing experiment only (results are wrong): what the DMA instructions cost the step
+    if (slot >= 0) return;
+#endif
     const int piece = i * nw + wave;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane * 16),
                                      (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + piece * 1024), 16, 0, 0);
   }
-  // rows of TWO neighbouring row tiles (2 pr, 2 pr + 1) of an Rp image with 8 row tiles, four k-steps from ks0:
-  // piece j = (tile j / 12, k-step ks0 + (j % 12) / 3, plane j % 3) -> 24 pieces
-  __device__ __forceinline__ void issue_tiles(const unsigned char* img, int ks0, int pr, int slot) const {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int piece = i * nw + wave;
-      const int t = piece / 12, ks = ks0 + (piece % 12) / 3, p = piece % 3;
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(img + (((ks * 3 + p) * 8 + 2 * pr + t) * 64 + lane) * 16),
-          (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + piece * 1024), 16, 0, 0);
+  // piece i (of 6) of this wavefront of a T-use slab (see tr_lane_addr) of an Rp image with 8 row tiles.
+  // F = 256: the slab is k-step kk0 (16 rows), 24 pieces j = (plane j >> 3, ks_f pair j & 7).
+  // F = 64: the slab holds the four k-steps kk0 .. kk0 + 3, 6 pieces each: j % 6 = (plane >> 1, ks_f pair & 1).
+  // tsrc = tr_src_lane_off(lane).  The LDS side is piece-linear like every other slab.
+  template <int F>
+  __device__ __forceinline__ void issue1_t(const unsigned char* img, uint32_t tsrc, int kk0, int slot, int i) const {
+#ifdef PZN_EXP_NODMA
+    if (slot >= 0) return;
+#endif
+    const int j = i * nw + wave;
+    int kk, plane, ksf0;
+    if (F == 256) {
+      kk = kk0, plane = j >> 3, ksf0 = 2 * (j & 7);
+    } else {
+      const int m = j % 6;
+      kk = kk0 + j / 6, plane = m >> 1, ksf0 = 2 * (m & 1);
     }
+    const unsigned char* src = img + ((ksf0 * 3 + plane) * 8 + (kk >> 1)) * 1024 + (kk & 1) * 256 + tsrc;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + j * 1024), 16, 0, 0);
+  }
+  template <int F>
+  __device__ __forceinline__ void issue_t(const unsigned char* img, uint32_t tsrc, int kk0, int slot) const {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue1_t<F>(img, tsrc, kk0, slot, i);
   }
   __device__ __forceinline__ const unsigned char* slot(int s) const { return lds + s * slot_bytes; }
   __device__ __forceinline__ uint32_t lane_addr(int s) const { return slot_addr(s) + (uint32_t)lane * 16u; }
@@ -286,16 +301,19 @@ __device__ __forceinline__ void wait_vm_sync() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
-// younger = this wavefront's DMA instructions of the NEXT slab (the only ones that may stay in flight)
+// younger = this wavefront's vector-memory instructions that may stay in flight: the DMA pieces of the NEXT slab plus
+// whatever else it issued after the last piece of the slab waited for (vmcnt counts in order).  The argument folds to a
+// constant in the unrolled loops.
 __device__ __forceinline__ void step_sync(int younger) {
-  if (younger == 0)
-    wait_vm_sync<0>();
-  else if (younger == 3)
-    wait_vm_sync<3>();
-  else if (younger == 6)
-    wait_vm_sync<6>();
-  else
-    wait_vm_sync<9>();
+  switch (younger) {
+    case 0: wait_vm_sync<0>(); break;
+    case 3: wait_vm_sync<3>(); break;
+    case 6: wait_vm_sync<6>(); break;
+    case 7: wait_vm_sync<7>(); break;
+    case 9: wait_vm_sync<9>(); break;
+    case 12: wait_vm_sync<12>(); break;
+    default: wait_vm_sync<0>(); break;   // (unknown count: drain)
+  }
 }
 
 // XCD-aware block id: consecutive logical ids (the two halves of a cloud, neighbouring clouds) share an XCD's L2
@@ -303,6 +321,9 @@ __device__ __forceinline__ int logical_block(int bid, int nb) {
   if (nb & 7) return bid;
   return (bid & 7) * (nb >> 3) + (bid >> 3);
 }
+
+// the lane id from the hardware (two instructions) instead of a register kept alive since the kernel's first line
+__device__ __forceinline__ int fresh_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 

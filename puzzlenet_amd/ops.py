@@ -1153,22 +1153,21 @@ class _AttnChainFused(torch.autograd.Function):
             cur = [x.reshape(M, E) for x in xs]
             saved = [[] for _ in R]
             for i in range(4):
-                img = [[raw(qkb), raw(qkb), raw(qkb), raw(qkb), raw(vb), raw(vb)] for _ in R]   # qrp, qt, krp, kt, vrp, vt
+                img = [[raw(qkb), raw(qkb), raw(vb)] for _ in R]   # Rp images of q, k, v
                 _call("pzn_attn_fused_proj", nprob, _ptrs(cur), _ptrs([W[p][i] for p in R]),
                       _ptrs([pss[p][8 * i + 1] for p in R]), _ptrs([pss[p][8 * i + 3] for p in R]),
-                      _ptrs([pss[p][8 * i + 5] for p in R]), B, *[_ptrs([img[p][j] for p in R]) for j in range(6)], st,
+                      _ptrs([pss[p][8 * i + 5] for p in R]), B, *[_ptrs([img[p][j] for p in R]) for j in range(3)], st,
                       flops=nprob * 2 * M * E * (2 * dk + E))
                 r = [mk(M, E) for _ in R]
                 t = [mk(M, E) for _ in R]
                 mask = [torch.empty((M, 8), dtype=torch.int32, device=dev) for _ in R]
                 lse = [mk(M) for _ in R]
-                _call("pzn_attn_fused_fwd", nprob, _ptrs(cur), _ptrs([img[p][0] for p in R]), _ptrs([img[p][2] for p in R]),
-                      _ptrs([img[p][5] for p in R]), _ptrs([W[p][i] for p in R]), _ptrs([pss[p][8 * i + 7] for p in R]), B,
+                _call("pzn_attn_fused_fwd", nprob, _ptrs(cur), _ptrs([img[p][0] for p in R]), _ptrs([img[p][1] for p in R]),
+                      _ptrs([img[p][2] for p in R]), _ptrs([W[p][i] for p in R]), _ptrs([pss[p][8 * i + 7] for p in R]), B,
                       _ptrs(r), _ptrs(t), _ptrs(mask), _ptrs(maps), _ptrs(lse), int(i > 0), 0.25, st,
                       flops=nprob * (2 * M * E * E + 2 * B * L * L * (dk + E)))
                 for p in R:
-                    saved[p].append((cur[p], t[p], mask[p], lse[p], img[p][0], img[p][1], img[p][2], img[p][3], img[p][4],
-                                     W[p][i]))
+                    saved[p].append((cur[p], t[p], mask[p], lse[p], img[p][0], img[p][1], img[p][2], W[p][i]))
                 cur = r
             outs, tosave, empties = [], [], []
             for p in R:
@@ -1212,7 +1211,7 @@ class _AttnChainFused(torch.autograd.Function):
         B, L, E, dk, Nout = ctx.dims
         nprob = ctx.nprob
         R = range(nprob)
-        per_saved = 40 + 1 + 34 + 1
+        per_saved = 32 + 1 + 34 + 1
         T = ctx.saved_tensors
         M = B * L
         dev = T[0].device
@@ -1226,10 +1225,10 @@ class _AttnChainFused(torch.autograd.Function):
             st = _stream()
             for p in R:
                 t = T[per_saved * p: per_saved * (p + 1)]
-                saved.append([t[10 * i: 10 * i + 10] for i in range(4)])
-                att4 = t[40]
-                ps.append(t[41:75])
-                arg = t[75]
+                saved.append([t[8 * i: 8 * i + 8] for i in range(4)])
+                att4 = t[32]
+                ps.append(t[33:67])
+                arg = t[67]
                 dy, dfg = gout[3 * p], gout[3 * p + 2]
                 w_out, b_out = ps[p][32], ps[p][33]
                 base = 2 + 35 * p
@@ -1269,19 +1268,19 @@ class _AttnChainFused(torch.autograd.Function):
             # scratch of the block backward, shared by the four layers
             dz, u, dx = [mk(M, E) for _ in R], [mk(M, E) for _ in R], [mk(M, E) for _ in R]
             dq, dkk, dvv = [mk(M, dk) for _ in R], [mk(M, dk) for _ in R], [mk(M, E) for _ in R]
-            darp, dat, delta = [raw(vb) for _ in R], [raw(vb) for _ in R], [mk(M) for _ in R]
+            darp, delta = [raw(vb) for _ in R], [mk(M) for _ in R]
             g2 = None
             for i in (3, 2, 1, 0):
-                blk = [saved[p][i] for p in R]        # (x, t, mask, lse, qrp, qt, krp, kt, vrp, W)
+                blk = [saved[p][i] for p in R]        # (x, t, mask, lse, qrp, krp, vrp, W)
                 col = lambda j: _ptrs([b[j] for b in blk])
                 # the block's output gradient = its slice of the projection's input gradient (+ what the next block passed
                 # back): both read in place by the kernel, no copy and no tensor add
                 _call("pzn_attn_fused_bwd_q", nprob, _ptrs(g), 5 * E, _ptrs(g2) if g2 is not None else None, E,
-                      col(2), col(4), col(6), col(7), col(8), col(9), B, _ptrs(dz),
-                      _ptrs(u), _ptrs(dq), _ptrs(darp), _ptrs(dat), _ptrs(delta), st,
+                      col(2), col(4), col(5), col(6), col(7), B, _ptrs(dz),
+                      _ptrs(u), _ptrs(dq), _ptrs(darp), _ptrs(delta), st,
                       flops=nprob * (2 * M * E * (E + dk) + 2 * B * L * L * (2 * dk + E)))
-                _call("pzn_attn_fused_bwd_k", nprob, col(4), col(5), col(6), col(8), _ptrs(darp), _ptrs(dat), col(9), col(3),
-                      _ptrs(delta), _ptrs(u), B, _ptrs(dkk), _ptrs(dvv), _ptrs(dx), st,
+                _call("pzn_attn_fused_bwd_k", nprob, col(4), col(5), col(6), _ptrs(darp), col(7), col(3),
+                      _ptrs(delta), _ptrs(u), _ptrs(dq), B, _ptrs(dkk), _ptrs(dvv), _ptrs(dx), st,
                       flops=nprob * (2 * M * E * (E + dk) + 2 * B * L * L * (2 * dk + 2 * E)))
                 for p in R:
                     base = 2 + 35 * p

@@ -511,8 +511,8 @@ def _attn_block_ref64(x, wq, bq, wk, bk, wv, bv, wo, bo, dr):
     delta = (P * dP).sum(-1)
     dS = P * (dP - delta[..., None]) / 8
     dq, dk, dv = dS @ k, dS.transpose(1, 2) @ q, P.transpose(1, 2) @ (-dt)
-    u = DR + dt + dq @ wq.to(D)
-    dx = u + dk @ wk.to(D) + dv @ wv.to(D)
+    u = DR + dt                                   # (what the query-side pass leaves for the key-side pass)
+    dx = u + dq @ wq.to(D) + dk @ wk.to(D) + dv @ wv.to(D)
     return dict(r=r, t=t, map=P, lse=torch.logsumexp(s, dim=-1), dz=dz, delta=delta, dq=dq, u=u, dk=dk, dv=dv, dx=dx, z=z)
 
 
@@ -540,20 +540,19 @@ def test_attention_fused_block_intermediates(dev, B):
     W = raw(lib.pzn_attn_fused_weight_bytes())
     _lib.call("pzn_attn_fused_prep_weights", wq.data_ptr(), wk.data_ptr(), wv.data_ptr(), wo.data_ptr(), W.data_ptr(), st)
     qkb, vb = lib.pzn_attn_fused_qk_image_bytes(B), lib.pzn_attn_fused_v_image_bytes(B)
-    qrp, qt, krp, kt, vrp, vt = raw(qkb), raw(qkb), raw(qkb), raw(qkb), raw(vb), raw(vb)
-    _lib.call("pzn_attn_fused_proj", 1, P([x]), P([W]), P([bq]), P([bk]), P([bv]), B, P([qrp]), P([qt]), P([krp]), P([kt]),
-              P([vrp]), P([vt]), st)
+    qrp, krp, vrp = raw(qkb), raw(qkb), raw(vb)
+    _lib.call("pzn_attn_fused_proj", 1, P([x]), P([W]), P([bq]), P([bk]), P([bv]), B, P([qrp]), P([krp]), P([vrp]), st)
     r, t, lse, amap = mk(M, E), mk(M, E), mk(M), mk(B, L, L)
     mask = torch.zeros((M, 8), dtype=torch.int32, device=dev)
-    _lib.call("pzn_attn_fused_fwd", 1, P([x]), P([qrp]), P([krp]), P([vt]), P([W]), P([bo]), B, P([r]), P([t]), P([mask]),
+    _lib.call("pzn_attn_fused_fwd", 1, P([x]), P([qrp]), P([krp]), P([vrp]), P([W]), P([bo]), B, P([r]), P([t]), P([mask]),
               P([amap]), P([lse]), 0, 1.0, st)
     dz, u, dq, delta = mk(M, E), mk(M, E), mk(M, dk), mk(M)
-    darp, dat = raw(vb), raw(vb)
-    _lib.call("pzn_attn_fused_bwd_q", 1, P([dr]), E, None, E, P([mask]), P([qrp]), P([krp]), P([kt]), P([vrp]), P([W]), B, P([dz]), P([u]),
-              P([dq]), P([darp]), P([dat]), P([delta]), st)
+    darp = raw(vb)
+    _lib.call("pzn_attn_fused_bwd_q", 1, P([dr]), E, None, E, P([mask]), P([qrp]), P([krp]), P([vrp]), P([W]), B, P([dz]), P([u]),
+              P([dq]), P([darp]), P([delta]), st)
     dkk, dvv, dx = mk(M, dk), mk(M, E), mk(M, E)
-    _lib.call("pzn_attn_fused_bwd_k", 1, P([qrp]), P([qt]), P([krp]), P([vrp]), P([darp]), P([dat]), P([W]), P([lse]),
-              P([delta]), P([u]), B, P([dkk]), P([dvv]), P([dx]), st)
+    _lib.call("pzn_attn_fused_bwd_k", 1, P([qrp]), P([krp]), P([vrp]), P([darp]), P([W]), P([lse]),
+              P([delta]), P([u]), P([dq]), B, P([dkk]), P([dvv]), P([dx]), st)
     ref = _attn_block_ref64(x.view(B, L, E), wq, bq, wk, bk, wv, bv, wo, bo, dr.view(B, L, E))
     # the ReLU gate is discrete: an element whose pre-activation is within rounding of zero may be gated differently,
     # which is no kernel error; none may flip away from zero, and a flip near zero loosens the comparison

@@ -159,3 +159,40 @@ def test_no_use_of_in_flight_asm_lds_read_registers():
         assert reads > 0, source
         assert not bad, f"{source}: registers of asm LDS reads touched before their counted wait: " \
                         f"{ {k: v[:3] for k, v in bad.items()} }"
+
+
+SPILL_FREE = {   # source -> kernels (substring of the mangled name) that must not spill a single register
+    "attnfused.hip": ("attn_proj_kernel", "attn_fwd_kernel", "attn_bwd_q_kernel", "attn_bwd_k_kernel"),
+    "salevel.hip": ("sa_level_stream_kernel",),
+    "outproj.hip": ("outproj_maxpts_kernel",),
+    "pointmlp.hip": ("point_mlp3_fwd_kernel", "point_mlp3_bwd_kernel"),
+}
+
+
+def test_matrix_core_kernels_do_not_spill():
+    """The chained matrix-core kernels run one wavefront per SIMD on (nearly) the whole register file; a spilled
+    register is a scratch access in the vmcnt stream their counted waits are written against, and a latency nobody
+    hides.  Round 3's attention backward spilled 294 / 107 registers (996 / 368 bytes of scratch per lane): this test
+    reads `.vgpr_spill_count` and `.private_segment_fixed_size` from the code object metadata of every such kernel."""
+    hipcc = build.hipcc()
+    flags = [f for f in build.COMMON if f not in ("-fPIC", "-fvisibility=hidden")]
+    for source, kernels in SPILL_FREE.items():
+        extra = dict(build.SOURCES)[source]
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, source + ".s")
+            cmd = [hipcc] + flags + extra + ["-S", "--cuda-device-only", "-o", out, os.path.join(build.CSRC, source)]
+            assert subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode == 0
+            text = open(out).read()
+        meta = text[text.index("amdhsa.kernels:"):]
+        seen = set()
+        for entry in re.split(r"\n  - ", meta)[1:]:
+            m = re.search(r"\.name:\s+(\S+)", entry)
+            which = [k for k in kernels if m and k in m.group(1)]
+            if not which:
+                continue
+            name = m.group(1)
+            seen.add(which[0])
+            spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", entry).group(1))
+            scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", entry).group(1))
+            assert spills == 0 and scratch == 0, f"{name}: {spills} spilled registers, {scratch} bytes of scratch per lane"
+        assert seen == set(kernels), (source, seen)

@@ -37,20 +37,19 @@ def main():
     W = raw(lib.pzn_attn_fused_weight_bytes())
     _lib.call("pzn_attn_fused_prep_weights", wq.data_ptr(), wk.data_ptr(), wv.data_ptr(), wo.data_ptr(), W.data_ptr(), st)
     qkb, vb = lib.pzn_attn_fused_qk_image_bytes(B), lib.pzn_attn_fused_v_image_bytes(B)
-    qrp, qt, krp, kt, vrp, vt = raw(qkb), raw(qkb), raw(qkb), raw(qkb), raw(vb), raw(vb)
-    _lib.call("pzn_attn_fused_proj", 1, P([x]), P([W]), P([bq]), P([bk]), P([bv]), B, P([qrp]), P([qt]), P([krp]), P([kt]),
-              P([vrp]), P([vt]), st)
+    qrp, krp, vrp = raw(qkb), raw(qkb), raw(vb)
+    _lib.call("pzn_attn_fused_proj", 1, P([x]), P([W]), P([bq]), P([bk]), P([bv]), B, P([qrp]), P([krp]), P([vrp]), st)
     r, t, lse, amap = mk(M, E), mk(M, E), mk(M), mk(B, L, L)
     mask = torch.zeros((M, 8), dtype=torch.int32, device=dev)
-    _lib.call("pzn_attn_fused_fwd", 1, P([x]), P([qrp]), P([krp]), P([vt]), P([W]), P([bo]), B, P([r]), P([t]), P([mask]),
+    _lib.call("pzn_attn_fused_fwd", 1, P([x]), P([qrp]), P([krp]), P([vrp]), P([W]), P([bo]), B, P([r]), P([t]), P([mask]),
               P([amap]), P([lse]), 0, 1.0, st)
     dz, u, dq, delta = mk(M, E), mk(M, E), mk(M, dk), mk(M)
-    darp, dat = raw(vb), raw(vb)
-    _lib.call("pzn_attn_fused_bwd_q", 1, P([dr]), E, None, E, P([mask]), P([qrp]), P([krp]), P([kt]), P([vrp]), P([W]), B, P([dz]), P([u]),
-              P([dq]), P([darp]), P([dat]), P([delta]), st)
+    darp = raw(vb)
+    _lib.call("pzn_attn_fused_bwd_q", 1, P([dr]), E, None, E, P([mask]), P([qrp]), P([krp]), P([vrp]), P([W]), B, P([dz]), P([u]),
+              P([dq]), P([darp]), P([delta]), st)
     dkk, dvv, dx = mk(M, dk), mk(M, E), mk(M, E)
-    _lib.call("pzn_attn_fused_bwd_k", 1, P([qrp]), P([qt]), P([krp]), P([vrp]), P([darp]), P([dat]), P([W]), P([lse]),
-              P([delta]), P([u]), B, P([dkk]), P([dvv]), P([dx]), st)
+    _lib.call("pzn_attn_fused_bwd_k", 1, P([qrp]), P([krp]), P([vrp]), P([darp]), P([W]), P([lse]),
+              P([delta]), P([u]), P([dq]), B, P([dkk]), P([dvv]), P([dx]), st)
     torch.cuda.synchronize()
 
     D = torch.float64
@@ -74,8 +73,8 @@ def main():
     DQ = DS @ k
     DKr = DS.transpose(1, 2) @ q
     DVr = Pm.transpose(1, 2) @ DA
-    U = DR + DT + DQ @ wq.to(D)
-    DX = U + DKr @ wk.to(D) + DVr @ wv.to(D)
+    U = DR + DT
+    DX = U + DQ @ wq.to(D) + DKr @ wk.to(D) + DVr @ wv.to(D)
     LSE = torch.logsumexp(s, dim=-1)
     for name, got, want in (("r", r, rr), ("t", t, tt), ("map", amap, Pm), ("lse", lse, LSE), ("dz", dz, DZ), ("delta", delta, dl),
                             ("dq", dq, DQ), ("u", u, U), ("dk", dkk, DKr), ("dv", dvv, DVr), ("dx", dx, DX)):
