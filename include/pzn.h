@@ -433,9 +433,11 @@ int pzn_attn_block_bwd_f32(const float* x, const float* Wq, const float* Wk, con
  *           bits of the ReLU;  lse [B*L];  map[i] (may be NULL) [B,L,L]: map = scale P, or map += scale P when
  *           map_accumulate (the mean of the four blocks' maps, model5_b.py:468-469).
  *   bwd_q:  query side of the backward from dr (+ dr2 when non-NULL: rows of ld_dr / ld_dr2 floats, so a column slice of
- *           a wider gradient needs no copy and the sum of two gradients no add): dz = dr . gate, u = dr + dz Wo,
- *           dq [B*L,dk], delta [B*L] and the image of da = -dz Wo.
- *   bwd_k:  key side: dk [B*L,dk], dv [B*L,E], dx = u + dq Wq + dk Wk + dv Wv [B*L,E] = the block's input gradient.
+ *           a wider gradient needs no copy and the sum of two gradients no add): dz = dr . gate, dq [B*L,dk], delta [B*L],
+ *           the image of da = -dz Wo, and for bwd_k only: u = dr + dz Wo [B*L,E] and dq_tiles [B*L,dk] in the kernels'
+ *           own register-tile order (same sizes as the row tensors; not meant to be read by anything else).
+ *   bwd_k:  key side (u, dq = the two tile tensors of bwd_q): dk [B*L,dk], dv [B*L,E],
+ *           dx = u + dq Wq + dk Wk + dv Wv [B*L,E] = the block's input gradient.
  *   wgrads: the eight parameter gradients from dz, t, dq, dk, dv and the block input x (one problem per call). */
 int pzn_attn_fused_supported(int L, int E, int dk);
 size_t pzn_attn_fused_weight_bytes(void);
@@ -443,6 +445,10 @@ size_t pzn_attn_fused_qk_image_bytes(int B);
 size_t pzn_attn_fused_v_image_bytes(int B);
 int pzn_attn_fused_prep_weights(const float* Wq, const float* Wk, const float* Wv, const float* Wo,
                                 void* planes, pzn_stream_t stream);
+/* the same for n <= 4 blocks in one launch (an encoder's four layers): arrays of n pointers */
+int pzn_attn_fused_prep_weights_n(int n, const float* const* Wq, const float* const* Wk,
+                                  const float* const* Wv, const float* const* Wo,
+                                  void* const* planes, pzn_stream_t stream);
 int pzn_attn_fused_proj(int nprob, const float* const* x, const void* const* w,
                         const float* const* bq, const float* const* bk, const float* const* bv, int B,
                         void* const* qrp, void* const* krp, void* const* vrp, pzn_stream_t stream);
@@ -455,8 +461,8 @@ int pzn_attn_fused_bwd_q(int nprob, const float* const* dr, int ld_dr, const flo
                          int ld_dr2, const void* const* mask,
                          const void* const* qrp, const void* const* krp, const void* const* vrp,
                          const void* const* w, int B, float* const* dz, float* const* u,
-                         float* const* dq, void* const* darp, float* const* delta,
-                         pzn_stream_t stream);
+                         float* const* dq, float* const* dq_tiles, void* const* darp,
+                         float* const* delta, pzn_stream_t stream);
 int pzn_attn_fused_bwd_k(int nprob, const void* const* qrp, const void* const* krp,
                          const void* const* vrp, const void* const* darp, const void* const* w,
                          const float* const* lse, const float* const* delta, const float* const* u,

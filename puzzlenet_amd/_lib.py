@@ -60,9 +60,10 @@ SIGNATURES = {
     "pzn_attn_fused_qk_image_bytes": (_c_sz, [_c_i]),
     "pzn_attn_fused_v_image_bytes": (_c_sz, [_c_i]),
     "pzn_attn_fused_prep_weights": (_c_i, [_c_f] * 6),
+    "pzn_attn_fused_prep_weights_n": (_c_i, [_c_i] + [_PP] * 5 + [_c_f]),
     "pzn_attn_fused_proj": (_c_i, [_c_i] + [_PP] * 5 + [_c_i] + [_PP] * 3 + [_c_f]),
     "pzn_attn_fused_fwd": (_c_i, [_c_i] + [_PP] * 6 + [_c_i] + [_PP] * 5 + [_c_i, _c_fl, _c_f]),
-    "pzn_attn_fused_bwd_q": (_c_i, [_c_i, _PP, _c_i, _PP, _c_i] + [_PP] * 5 + [_c_i] + [_PP] * 5 + [_c_f]),
+    "pzn_attn_fused_bwd_q": (_c_i, [_c_i, _PP, _c_i, _PP, _c_i] + [_PP] * 5 + [_c_i] + [_PP] * 6 + [_c_f]),
     "pzn_attn_fused_bwd_k": (_c_i, [_c_i] + [_PP] * 9 + [_c_i] + [_PP] * 3 + [_c_f]),
     "pzn_attn_fused_wgrads": (_c_i, [_c_f] * 6 + [_c_i] * 3 + [_c_f] * 8 + [_c_i, _c_f]),
     "pzn_bgemm_f32": (_c_i, [_c_i, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_fl, _c_f]),

@@ -155,6 +155,30 @@ __device__ __forceinline__ void load_rows(const float* base, long row0, int ld, 
   }
 }
 
+// fp32 tensors that only travel between these kernels (u, dq: query-side -> key-side backward) skip the staging: the
+// "tile image" of M[rows][32 FT] keeps a tile in register order, [row tile][feature tile][register group g][lane][4],
+// so a lane's four registers 4g..4g+3 are one 16-byte piece and every instruction moves 1 KB contiguously.
+template <int FT>
+__device__ __forceinline__ void store_tiles(float* img, long tile0, int lane, const floatx16* x) {
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(img + (((tile0 * FT + ft) * 4 + g) * 64 + lane) * 4) =
+          make_float4(x[ft][4 * g], x[ft][4 * g + 1], x[ft][4 * g + 2], x[ft][4 * g + 3]);
+}
+template <int FT>
+__device__ __forceinline__ void load_tiles(const float* img, long tile0, int lane, floatx16* x) {
+  float4 v[FT * 4];
+#pragma unroll
+  for (int i = 0; i < FT * 4; ++i) v[i] = *reinterpret_cast<const float4*>(img + ((tile0 * FT * 4 + i) * 64 + lane) * 4);
+#pragma unroll
+  for (int i = 0; i < FT * 4; ++i) {
+    x[i >> 2][4 * (i & 3)] = v[i].x, x[i >> 2][4 * (i & 3) + 1] = v[i].y;
+    x[i >> 2][4 * (i & 3) + 2] = v[i].z, x[i >> 2][4 * (i & 3) + 3] = v[i].w;
+  }
+}
+
 // Rp image of M[256 rows][16 KS features]: tile ft of the accumulators = k-steps 2 ft, 2 ft + 1; the lane's registers
 // 8s..8s+7 are exactly its own chunk.  img = this cloud's image, rt = row tile of the wavefront.
 template <int FT, bool NEG = false>
@@ -182,7 +206,7 @@ struct PackJob {
   unsigned char* dst;
 };
 struct PackArgs {
-  PackJob job[8];
+  PackJob job[32];
   int njobs;
 };
 
@@ -499,8 +523,9 @@ struct BwdQProb {
   const unsigned char *qrp, *krp, *vrp;
   const unsigned char* w;
   float* dz;             // [B*L, E]
-  float* u;              // [B*L, E]
-  float* dq;             // [B*L, DK]
+  float* u;              // [B*L, E] as a tile image (store_tiles): read by the key-side pass only
+  float* dq;             // [B*L, DK] rows (weight gradients)
+  float* dqt;            // [B*L, DK] as a tile image (key-side pass)
   unsigned char* darp;   // image of da
   float* delta;          // [B*L]
 };
@@ -546,7 +571,6 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
   __builtin_amdgcn_sched_barrier(0);
   const int lane = fresh_lane();
   const Ring ring{lds, wave, lane, SLAB};
-  const uint32_t tsrc = tr_src_lane_off(lane);
   // slab sequence: Wo^T 0..15 | V 0..15 | K 0..3 | K^T (T use of the k image, 4 k-steps of 16 keys each) 0..3
   auto issue1 = [&](int c, int i) {
     if (c < 16)
@@ -555,8 +579,8 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
       ring.issue1(vrp + (c - 16) * SLAB, c % 3, i);
     else if (c < 36)
       ring.issue1(krp + (c - 32) * SLAB, c % 3, i);
-    else if (c < NS)
-      ring.issue1_t<64>(krp, tsrc, 4 * (c - 36), c % 3, i);
+    else if (c < NS)   // (the lane's source offset is derived on the spot: 4 of 40 slabs, and one register less across the loops)
+      ring.issue1_t<64>(krp, tr_src_lane_off(fresh_lane()), 4 * (c - 36), c % 3, i);
   };
   auto fill_dma = [&](int c, int t) {
     if (t < 3) {
@@ -569,6 +593,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
   floatx16 DT[8];
   ZERO_TILES(DT, 8);
   bf16x8 b[2][3];
+  Stash stash;
   {
     BNext b0;
 #pragma unroll
@@ -587,7 +612,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
         bn.pair_gated(S[ft], kn & 1, t - 3, gate.w[ft >> 1], (ft & 1) * 16);
       }
     };
-    kstep_rp<8>(DT, ring.lane_addr(c % 3), b[ks & 1], fill);
+    kstep_rp_d<8>(DT, ring.lane_addr(c % 3), b[ks & 1], b[(ks + 1) & 1], stash, ks == 0, ks == 15, fill);
     if (ks < 15) bn.get(b[(ks + 1) & 1]);
   }
   // ---- DP^T = V dt^T = -dP^T (16 k-steps over c); the da image and u go to memory at the head of its first step
@@ -596,7 +621,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
   STAMPK(2, 4);
 #pragma unroll
   for (int ft = 0; ft < 8; ++ft) S[ft] += DT[ft];       // u = dr + dt
-  store_rows<8>(P.u, row0, E, S, stg, lane);
+  store_tiles<8>(P.u, (long)cloud * 8 + rt, lane, S);
   __builtin_amdgcn_sched_barrier(0);   // (one accumulator set leaves before the next piece of work needs registers)
   STAMPK(2, 5);
   store_rp<8, true>(P.darp + (size_t)cloud * V_IMG, rt, lane, DT);
@@ -614,28 +639,26 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
       fill_dma(c, t);
       if (t >= 3 && t < 7 && ks < 15) bn.pair(DT[(ks + 1) >> 1], (ks + 1) & 1, t - 3);
     };
-    kstep_rp<8>(DP, ring.lane_addr(c % 3), b[ks & 1], fill);
+    kstep_rp_d<8>(DP, ring.lane_addr(c % 3), b[ks & 1], b[(ks + 1) & 1], stash, ks == 0, ks == 15, fill);
     if (ks < 15) bn.get(b[(ks + 1) & 1]);
   }
   // ---- S^T = K q^T, P^T (u is in memory: its registers hold the scores now)
   __builtin_amdgcn_sched_barrier(0);
   STAMPK(2, 9);
-  // (what the tail derives from the lane id is derived again here instead of occupying registers through the loops above)
-  const int lane2 = fresh_lane();
-  const int h2 = lane2 >> 5;
-  const long row2 = (long)cloud * L + 32 * rt + (lane2 & 31);
+  // (what the tail derives from the lane id is derived where it is used, from a fresh read of the lane id, instead of
+  //  occupying registers through the loops)
   floatx16(&S2)[8] = S;
   ZERO_TILES(S2, 8);
+  bf16x8 qf[2][3];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     const int c = 32 + ks;
-    bf16x8 qf[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
-      qf[p] = *reinterpret_cast<const bf16x8*>(P.qrp + (size_t)cloud * QK_IMG + (((ks * 3 + p) * 8 + rt) * 64 + lane2) * 16);
+      qf[ks & 1][p] = *reinterpret_cast<const bf16x8*>(P.qrp + (size_t)cloud * QK_IMG + (((ks * 3 + p) * 8 + rt) * 64 + fresh_lane()) * 16);
     step_sync(9);    // (the three fragment loads above are younger than the slab waited for)
     auto fill = [&](int t) { fill_dma(c, t); };
-    kstep_rp<8>(S2, ring.lane_addr(c % 3), qf, fill);
+    kstep_rp_d<8>(S2, ring.lane_addr(c % 3), qf[ks & 1], qf[(ks + 1) & 1], stash, ks == 0, ks == 3, fill);
   }
   STAMPK(2, 10);
   softmax_regs(S2);
@@ -646,7 +669,8 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) d -= S2[t][i] * DP[t][i];
     d += xor32(d);
-    if (h2 == 0) P.delta[row2] = d;
+    const int l2 = fresh_lane();
+    if (l2 < 32) P.delta[row0 + l2] = d;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -664,7 +688,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
     step_sync(sl == 0 ? 7 : sl == 3 ? 0 : 6);   // (sl == 0: the store of delta is younger than the slab as well)
 #pragma unroll
     for (int i = 0; i < 6; ++i) issue1(c + 2, i);
-    const uint32_t ta = tr_lane_addr(ring.slot_addr(c % 3), lane2);
+    const uint32_t ta = tr_lane_addr(ring.slot_addr(c % 3), fresh_lane());
     static_for<0, 4>([&](auto iq) {
       constexpr int q4 = decltype(iq)::value;
       const int ks = 4 * sl + q4;
@@ -680,7 +704,11 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
     });
   }
   STAMPK(2, 12);
-  store_rows<2>(P.dq, row0, DK, DQ, stg, lane2);
+  {
+    const int l2 = fresh_lane();
+    store_tiles<2>(P.dqt, (long)cloud * 8 + rt, l2, DQ);
+    store_rows<2>(P.dq, row0, DK, DQ, stg, l2);
+  }
   STAMPK(2, 13);
 }
 
@@ -694,8 +722,8 @@ struct BwdKProb {
   const unsigned char *qrp, *krp, *vrp, *darp;
   const unsigned char* w;
   const float *lse, *delta;
-  const float* u;     // [B*L, E]
-  const float* dq;    // [B*L, DK]
+  const float* u;     // [B*L, E] tile image
+  const float* dq;    // [B*L, DK] tile image
   float* dk;          // [B*L, DK]
   float* dv;          // [B*L, E]
   float* dx;          // [B*L, E]
@@ -754,7 +782,9 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_k_kernel(BwdKArgs a) {
   for (int i = 0; i < 6; ++i) issue1(0, i);
 #pragma unroll
   for (int i = 0; i < 6; ++i) issue1(1, i);
-  bf16x8 of[2][3];
+  bf16x8 of[3][3];   // own fragments of global step g (S loop: g = ks, dP loop: g = 4 + ks) in of[g % 3]: this step's, the
+                     // previous one's (the deferred tile still multiplies by it) and the next one's (in flight)
+  Stash stash;
   own_frag(krp, 0, of[0]);
   __syncthreads();   // row constants in LDS (drains the first two slabs once)
   STAMPK(3, 1);
@@ -767,11 +797,11 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_k_kernel(BwdKArgs a) {
     const int c = ks;
     if (ks > 0) step_sync(9);   // (the fragment loads of the next step are younger than the slab waited for)
     if (ks < 3)
-      own_frag(krp, ks + 1, of[(ks + 1) & 1]);
+      own_frag(krp, ks + 1, of[(ks + 1) % 3]);
     else
-      own_frag(vrp, 0, of[(ks + 1) & 1]);
+      own_frag(vrp, 0, of[(ks + 1) % 3]);
     auto fill = [&](int t) { fill_dma(c, t); };
-    kstep_rp<8>(S, ring.lane_addr(c % 3), of[ks & 1], fill);
+    kstep_rp_d<8>(S, ring.lane_addr(c % 3), of[ks % 3], of[(ks + 2) % 3], stash, ks == 0, ks == 3, fill);
   }
   STAMPK(3, 2);
   // P = exp(S / 8 - lse_q): the query is the register's row
@@ -796,9 +826,9 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_k_kernel(BwdKArgs a) {
   for (int ks = 0; ks < 16; ++ks) {
     const int c = 4 + ks;
     step_sync(9);
-    if (ks < 15) own_frag(vrp, ks + 1, of[(ks + 1) & 1]);
+    if (ks < 15) own_frag(vrp, ks + 1, of[(c + 1) % 3]);
     auto fill = [&](int t) { fill_dma(c, t); };
-    kstep_rp<8>(DP, ring.lane_addr(c % 3), of[ks & 1], fill);
+    kstep_rp_d<8>(DP, ring.lane_addr(c % 3), of[c % 3], of[(c + 2) % 3], stash, ks == 0, ks == 15, fill);
   }
   STAMPK(3, 4);
   // dS = P (dP - delta_q) / 8
@@ -862,10 +892,10 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_k_kernel(BwdKArgs a) {
   floatx16(&DX)[8] = S;
   floatx16 DQ[2];
   step_sync(6);
+  load_tiles<2>(P.dq, (long)cloud * 8 + rt, lane, DQ);    // (in flight while dk and dv leave through the staging buffer)
+  load_tiles<8>(P.u, (long)cloud * 8 + rt, lane, DX);
   store_rows<2>(P.dk, row0, DK, DKt, stg, lane);
   store_rows<8>(P.dv, row0, E, DV, stg, lane);
-  load_rows<2>(P.dq, row0, DK, DQ, stg, lane);
-  load_rows<8>(P.u, row0, E, DX, stg, lane);
   bf16x8 bt[2][3];
   make_b(DQ[0], 0, bt[0]);
   STAMPK(3, 7);
@@ -917,24 +947,35 @@ PZN_EXPORT size_t pzn_attn_fused_v_image_bytes(int B) { return B > 0 ? (size_t)B
 
 PZN_EXPORT int pzn_attn_fused_supported(int L_, int E_, int dk) { return L_ == L && E_ == E && dk == DK; }
 
-// planes of one block's weights (Wq, Wk [dk, E]; Wv, Wo [E, E]) for all five kernels
+// planes of the weights of n <= 4 blocks (Wq, Wk [dk, E]; Wv, Wo [E, E]) for all kernels, one launch
+static void pack_jobs(PackArgs& a, int at, const float* Wq, const float* Wk, const float* Wv, const float* Wo, unsigned char* w) {
+  // W_QKV: rows n = q | k | v, k = c
+  a.job[at + 0] = PackJob{Wq, E, 1, 2, 16, 12, 0, 0, w + W_QKV};
+  a.job[at + 1] = PackJob{Wk, E, 1, 2, 16, 12, 2, 0, w + W_QKV};
+  a.job[at + 2] = PackJob{Wv, E, 1, 8, 16, 12, 4, 0, w + W_QKV};
+  a.job[at + 3] = PackJob{Wo, E, 1, 8, 16, 8, 0, 0, w + W_O};        // rows o, k = c
+  a.job[at + 4] = PackJob{Wo, 1, E, 8, 16, 8, 0, 0, w + W_OT};       // rows c, k = o:  A[c][o] = Wo[o][c]
+  a.job[at + 5] = PackJob{Wq, 1, E, 8, 4, 8, 0, 0, w + W_QT};        // rows c, k = d:  A[c][d] = Wq[d][c]
+  a.job[at + 6] = PackJob{Wk, 1, E, 8, 4, 8, 0, 0, w + W_KVT};       // rows c, k = d
+  a.job[at + 7] = PackJob{Wv, 1, E, 8, 16, 8, 0, 4, w + W_KVT};      // rows c, k = c' (k-steps 4..19)
+}
+
+PZN_EXPORT int pzn_attn_fused_prep_weights_n(int n, const float* const* Wq, const float* const* Wk, const float* const* Wv,
+                                             const float* const* Wo, void* const* planes, pzn_stream_t stream) {
+  PZN_CHECK_ARG(n >= 1 && n <= 4 && Wq && Wk && Wv && Wo && planes);
+  PackArgs a;
+  a.njobs = 8 * n;
+  for (int i = 0; i < n; ++i) {
+    PZN_CHECK_ARG(Wq[i] && Wk[i] && Wv[i] && Wo[i] && planes[i] && aligned16(planes[i]));
+    pack_jobs(a, 8 * i, Wq[i], Wk[i], Wv[i], Wo[i], static_cast<unsigned char*>(planes[i]));
+  }
+  hipLaunchKernelGGL(pack_rp_kernel, dim3(12, a.njobs), dim3(256), 0, pzn_hip_stream(stream), a);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
 PZN_EXPORT int pzn_attn_fused_prep_weights(const float* Wq, const float* Wk, const float* Wv, const float* Wo, void* planes,
                                            pzn_stream_t stream) {
-  PZN_CHECK_ARG(Wq && Wk && Wv && Wo && planes && aligned16(planes));
-  unsigned char* w = static_cast<unsigned char*>(planes);
-  PackArgs a;
-  a.njobs = 8;
-  // W_QKV: rows n = q | k | v, k = c
-  a.job[0] = PackJob{Wq, E, 1, 2, 16, 12, 0, 0, w + W_QKV};
-  a.job[1] = PackJob{Wk, E, 1, 2, 16, 12, 2, 0, w + W_QKV};
-  a.job[2] = PackJob{Wv, E, 1, 8, 16, 12, 4, 0, w + W_QKV};
-  a.job[3] = PackJob{Wo, E, 1, 8, 16, 8, 0, 0, w + W_O};        // rows o, k = c
-  a.job[4] = PackJob{Wo, 1, E, 8, 16, 8, 0, 0, w + W_OT};       // rows c, k = o:  A[c][o] = Wo[o][c]
-  a.job[5] = PackJob{Wq, 1, E, 8, 4, 8, 0, 0, w + W_QT};        // rows c, k = d:  A[c][d] = Wq[d][c]
-  a.job[6] = PackJob{Wk, 1, E, 8, 4, 8, 0, 0, w + W_KVT};       // rows c, k = d
-  a.job[7] = PackJob{Wv, 1, E, 8, 16, 8, 0, 4, w + W_KVT};      // rows c, k = c' (k-steps 4..19)
-  hipLaunchKernelGGL(pack_rp_kernel, dim3(12, 8), dim3(256), 0, pzn_hip_stream(stream), a);
-  PZN_RETURN_LAUNCH_STATUS();
+  return pzn_attn_fused_prep_weights_n(1, &Wq, &Wk, &Wv, &Wo, &planes, stream);
 }
 
 // q, k, v images of `nprob` problems: x[i][B*L, E], weight planes w[i], biases; images: qrp, krp (QK size), vrp (V size)
@@ -979,23 +1020,26 @@ PZN_EXPORT int pzn_attn_fused_fwd(int nprob, const float* const* x, const void* 
   PZN_RETURN_LAUNCH_STATUS();
 }
 
-// backward, query side (see attn_bwd_q_kernel): writes dz, u = dr + dt, dq, delta and the image of da
+// backward, query side (see attn_bwd_q_kernel): writes dz, dq (rows), delta, the image of da, and for the key-side pass
+// u = dr + dt and dq again as tile images (same sizes as the row tensors, layout private to the two kernels)
 PZN_EXPORT int pzn_attn_fused_bwd_q(int nprob, const float* const* dr, int ld_dr, const float* const* dr2, int ld_dr2,
                                     const void* const* mask, const void* const* qrp, const void* const* krp,
                                     const void* const* vrp, const void* const* w, int B, float* const* dz, float* const* u,
-                                    float* const* dq, void* const* darp, float* const* delta, pzn_stream_t stream) {
-  PZN_CHECK_ARG(nprob >= 1 && nprob <= 2 && B > 0 && dr && mask && qrp && krp && vrp && w && dz && u && dq && darp && delta);
+                                    float* const* dq, float* const* dqt, void* const* darp, float* const* delta,
+                                    pzn_stream_t stream) {
+  PZN_CHECK_ARG(nprob >= 1 && nprob <= 2 && B > 0 && dr && mask && qrp && krp && vrp && w && dz && u && dq && dqt && darp && delta);
   BwdQArgs a;
   a.nb = 2 * B;
   for (int i = 0; i < nprob; ++i) {
-    PZN_CHECK_ARG(dr[i] && mask[i] && qrp[i] && krp[i] && vrp[i] && w[i] && dz[i] && u[i] && dq[i] && darp[i] && delta[i]);
+    PZN_CHECK_ARG(dr[i] && mask[i] && qrp[i] && krp[i] && vrp[i] && w[i] && dz[i] && u[i] && dq[i] && dqt[i] && darp[i] && delta[i]);
     PZN_CHECK_ARG(aligned16(dr[i]) && aligned16(mask[i]) && aligned16(qrp[i]) && aligned16(krp[i]) && aligned16(vrp[i]) &&
-                  aligned16(w[i]) && aligned16(dz[i]) && aligned16(u[i]) && aligned16(dq[i]) && aligned16(darp[i]));
+                  aligned16(w[i]) && aligned16(dz[i]) && aligned16(u[i]) && aligned16(dq[i]) && aligned16(dqt[i]) &&
+                  aligned16(darp[i]));
     PZN_CHECK_ARG(ld_dr >= E && (ld_dr & 3) == 0 && (!dr2 || !dr2[i] || (aligned16(dr2[i]) && ld_dr2 >= E && (ld_dr2 & 3) == 0)));
     a.p[i] = BwdQProb{dr[i], dr2 ? dr2[i] : nullptr, ld_dr, ld_dr2, static_cast<const uint32_t*>(mask[i]),
                       static_cast<const unsigned char*>(qrp[i]), static_cast<const unsigned char*>(krp[i]),
                       static_cast<const unsigned char*>(vrp[i]), static_cast<const unsigned char*>(w[i]), dz[i], u[i], dq[i],
-                      static_cast<unsigned char*>(darp[i]), delta[i]};
+                      dqt[i], static_cast<unsigned char*>(darp[i]), delta[i]};
   }
   hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
   PZN_RETURN_LAUNCH_STATUS();

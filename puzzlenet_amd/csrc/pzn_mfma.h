@@ -99,11 +99,16 @@ struct NoFill {
 // lgkmcnt(0) three times per tile (measured: 2.6k cycles per 48-MFMA step against 1.5k of matrix-pipe time).
 // An asm read is invisible to the compiler's wait bookkeeping: RP_WAIT / TR_WAIT (s_waitcnt lgkmcnt(0) naming every
 // destination register read-write) must precede the first use (cdna_hip_programming.md, 5.7 form (ii)).
+#ifdef PZN_EXP_NOLDS   // timing experiment only (results are wrong): the step without its LDS fragment reads
+#define RP_ISSUE(ADDR, O0, O1, O2, A0, A1, A2) asm volatile("" : "=v"(A0), "=v"(A1), "=v"(A2) : "v"(ADDR))
+#define RP_WAITN(N_, A0, A1, A2) asm volatile("" : "+v"(A0), "+v"(A1), "+v"(A2))
+#else
 #define RP_ISSUE(ADDR, O0, O1, O2, A0, A1, A2)                                                       \
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A0) : "v"(ADDR), "n"(O0));                      \
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A1) : "v"(ADDR), "n"(O1));                      \
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A2) : "v"(ADDR), "n"(O2))
 #define RP_WAITN(N_, A0, A1, A2) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(A0), "+v"(A1), "+v"(A2))
+#endif
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -163,6 +168,44 @@ __device__ __forceinline__ void kstep_rp(floatx16 (&acc)[RT], uint32_t lane_addr
   });
 }
 
+// ---- the same step with its LAST tile deferred across the next barrier ---------------------------------------------
+// Behind a step's barrier the first fragment reads of the new slab have nobody to hide behind (one wavefront per SIMD:
+// measured ~260 cycles per 48-MFMA step).  The deferred forms keep the last tile's fragments in registers (Stash) when a
+// step ends and issue its six MFMAs at the head of the NEXT step, right behind that step's first reads: bprev is the B
+// operand of the step the stash belongs to (still intact: the B fragments are double-buffered), first / last fold to
+// constants in the unrolled loops (first: nothing stashed yet; last: the tile is multiplied at once).  Every
+// accumulator still receives its products in the same order: results are bit-identical to the plain forms.
+struct Stash {
+  bf16x8 a[3];
+};
+
+template <int RT, class Fill = NoFill>
+__device__ __forceinline__ void kstep_rp_d(floatx16 (&acc)[RT], uint32_t lane_addr, const bf16x8 (&b)[3], const bf16x8 (&bprev)[3],
+                                           Stash& st, bool first, bool last, const Fill& fill = Fill()) {
+  static_assert(RT >= 4, "pipeline depth");
+  bf16x8 f[3][3];
+  RP_ISSUE(lane_addr, 0, RT * 1024, 2 * RT * 1024, f[0][0], f[0][1], f[0][2]);
+  RP_ISSUE(lane_addr, 1024, (RT + 1) * 1024, (2 * RT + 1) * 1024, f[1][0], f[1][1], f[1][2]);
+  __builtin_amdgcn_sched_barrier(0);
+  if (!first) acc[RT - 1] = mma6v(st.a[0], st.a[1], st.a[2], bprev, acc[RT - 1]);
+  static_for<0, RT - 1>([&](auto ic) {
+    constexpr int rt = decltype(ic)::value;
+    constexpr int cur = rt % 3, nxt = (rt + 2) % 3;
+    if constexpr (rt + 2 < RT) {
+      RP_ISSUE(lane_addr, (rt + 2) * 1024, (RT + rt + 2) * 1024, (2 * RT + rt + 2) * 1024, f[nxt][0], f[nxt][1], f[nxt][2]);
+      RP_WAITN(6, f[cur][0], f[cur][1], f[cur][2]);
+    } else {
+      RP_WAITN(3, f[cur][0], f[cur][1], f[cur][2]);
+    }
+    acc[rt] = mma6v(f[cur][0], f[cur][1], f[cur][2], b, acc[rt]);
+    fill(rt);
+  });
+  constexpr int lst = (RT - 1) % 3;
+  RP_WAITN(0, f[lst][0], f[lst][1], f[lst][2]);
+  st.a[0] = f[lst][0], st.a[1] = f[lst][1], st.a[2] = f[lst][2];
+  if (last) acc[RT - 1] = mma6v(st.a[0], st.a[1], st.a[2], b, acc[RT - 1]);
+}
+
 // ---- transposed reads of an Rp image ("T use") --------------------------------------------------------------------
 // One Rp image of M[n][F] serves both kinds of product.  With k = feature it is streamed in plain slabs
 // ([plane][row tile][lane][16 B], ds_read_b128).  With k = ROW n (the operand is M^T[f][n]) the same bytes are fetched
@@ -193,6 +236,11 @@ __device__ __forceinline__ uint32_t tr_src_lane_off(int lane) {
   return (uint32_t)(blk * (3 * 8 * 1024) + (hs * 32 + r16) * 16);
 }
 
+#ifdef PZN_EXP_NOLDS
+#define TR_ISSUE(ADDR, OFF, PLS_, L0, H0, L1, H1, L2, H2) \
+  asm volatile("" : "=v"(L0), "=v"(H0), "=v"(L1), "=v"(H1), "=v"(L2), "=v"(H2) : "v"(ADDR))
+#define TR_WAITN(N_, L0, H0, L1, H1, L2, H2) asm volatile("" : "+v"(L0), "+v"(H0), "+v"(L1), "+v"(H1), "+v"(L2), "+v"(H2))
+#else
 #define TR_ISSUE(ADDR, OFF, PLS_, L0, H0, L1, H1, L2, H2)                                                           \
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(L0) : "v"(ADDR), "n"(OFF));                            \
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H0) : "v"(ADDR), "n"((OFF) + 256));                    \
@@ -202,6 +250,7 @@ __device__ __forceinline__ uint32_t tr_src_lane_off(int lane) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H2) : "v"(ADDR), "n"((OFF) + 2 * (PLS_) + 256))
 #define TR_WAITN(N_, L0, H0, L1, H1, L2, H2)                                                                        \
   asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(L0), "+v"(H0), "+v"(L1), "+v"(H1), "+v"(L2), "+v"(H2))
+#endif
 
 // one k-step of acc[ft] += A_ft B with A read transposed from a T-use slab: rows of A = feature 32 ft + lane % 32.
 // ta = tr_lane_addr of the slab, KOFF = byte offset of the k-step inside it (compile time).  Two tiles ahead, counted
@@ -229,6 +278,40 @@ __device__ __forceinline__ void kstep_tr(floatx16 (&acc)[FT], uint32_t ta, const
     acc[ft] = mma6v(a0, a1, a2, b, acc[ft]);
     fill(ft);
   });
+}
+
+// kstep_tr with its last tile deferred across the next barrier (see kstep_rp_d)
+template <int FT, int F, int KOFF, class Fill = NoFill>
+__device__ __forceinline__ void kstep_tr_d(floatx16 (&acc)[FT], uint32_t ta, const bf16x8 (&b)[3], const bf16x8 (&bprev)[3],
+                                           Stash& st, bool first, bool last, const Fill& fill = Fill()) {
+  static_assert(FT >= 4, "pipeline depth");
+  constexpr int PLS = 32 * F;
+  bf16x4 lo[3][3], hi[3][3];
+  TR_ISSUE(ta, KOFF, PLS, lo[0][0], hi[0][0], lo[0][1], hi[0][1], lo[0][2], hi[0][2]);
+  TR_ISSUE(ta, KOFF + 1024, PLS, lo[1][0], hi[1][0], lo[1][1], hi[1][1], lo[1][2], hi[1][2]);
+  __builtin_amdgcn_sched_barrier(0);
+  if (!first) acc[FT - 1] = mma6v(st.a[0], st.a[1], st.a[2], bprev, acc[FT - 1]);
+  static_for<0, FT - 1>([&](auto ic) {
+    constexpr int ft = decltype(ic)::value;
+    constexpr int cur = ft % 3, nxt = (ft + 2) % 3;
+    if constexpr (ft + 2 < FT) {
+      TR_ISSUE(ta, KOFF + 1024 * (ft + 2), PLS, lo[nxt][0], hi[nxt][0], lo[nxt][1], hi[nxt][1], lo[nxt][2], hi[nxt][2]);
+      TR_WAITN(12, lo[cur][0], hi[cur][0], lo[cur][1], hi[cur][1], lo[cur][2], hi[cur][2]);
+    } else {
+      TR_WAITN(6, lo[cur][0], hi[cur][0], lo[cur][1], hi[cur][1], lo[cur][2], hi[cur][2]);
+    }
+    const bf16x8 a0 = __builtin_shufflevector(lo[cur][0], hi[cur][0], 0, 1, 2, 3, 4, 5, 6, 7);
+    const bf16x8 a1 = __builtin_shufflevector(lo[cur][1], hi[cur][1], 0, 1, 2, 3, 4, 5, 6, 7);
+    const bf16x8 a2 = __builtin_shufflevector(lo[cur][2], hi[cur][2], 0, 1, 2, 3, 4, 5, 6, 7);
+    acc[ft] = mma6v(a0, a1, a2, b, acc[ft]);
+    fill(ft);
+  });
+  constexpr int lst = (FT - 1) % 3;
+  TR_WAITN(0, lo[lst][0], hi[lst][0], lo[lst][1], hi[lst][1], lo[lst][2], hi[lst][2]);
+  st.a[0] = __builtin_shufflevector(lo[lst][0], hi[lst][0], 0, 1, 2, 3, 4, 5, 6, 7);
+  st.a[1] = __builtin_shufflevector(lo[lst][1], hi[lst][1], 0, 1, 2, 3, 4, 5, 6, 7);
+  st.a[2] = __builtin_shufflevector(lo[lst][2], hi[lst][2], 0, 1, 2, 3, 4, 5, 6, 7);
+  if (last) acc[FT - 1] = mma6v(st.a[0], st.a[1], st.a[2], b, acc[FT - 1]);
 }
 
 // ---- slab ring: global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, destination =
@@ -305,6 +388,9 @@ __device__ __forceinline__ void wait_vm_sync() {
 // whatever else it issued after the last piece of the slab waited for (vmcnt counts in order).  The argument folds to a
 // constant in the unrolled loops.
 __device__ __forceinline__ void step_sync(int younger) {
+#ifdef PZN_EXP_NOBARRIER   // timing experiment only: the step without its wait and barrier
+  return;
+#endif
   switch (younger) {
     case 0: wait_vm_sync<0>(); break;
     case 3: wait_vm_sync<3>(); break;
@@ -323,7 +409,12 @@ __device__ __forceinline__ int logical_block(int bid, int nb) {
 }
 
 // the lane id from the hardware (two instructions) instead of a register kept alive since the kernel's first line
-__device__ __forceinline__ int fresh_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// (asm volatile: two calls are two computations; the builtin form is folded with every earlier one and the value kept)
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 

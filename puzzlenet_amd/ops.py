@@ -1145,10 +1145,9 @@ class _AttnChainFused(torch.autograd.Function):
         with _on(dev):
             st = _stream()
             W = [[raw(wbytes) for _ in range(4)] for _ in R]
-            for p in R:
-                for i in range(4):
-                    wq, bq, wk, bk, wv, bv, wo, bo = pss[p][8 * i: 8 * i + 8]
-                    _call("pzn_attn_fused_prep_weights", _p(wq), _p(wk), _p(wv), _p(wo), _p(W[p][i]), st)
+            for p in R:      # the four layers' weight planes in one launch per encoder
+                _call("pzn_attn_fused_prep_weights_n", 4, *[_ptrs([pss[p][8 * i + j] for i in range(4)]) for j in (0, 2, 4, 6)],
+                      _ptrs(W[p]), st)
             maps = [mk(B, L, L) for _ in R]
             cur = [x.reshape(M, E) for x in xs]
             saved = [[] for _ in R]
@@ -1268,6 +1267,7 @@ class _AttnChainFused(torch.autograd.Function):
             # scratch of the block backward, shared by the four layers
             dz, u, dx = [mk(M, E) for _ in R], [mk(M, E) for _ in R], [mk(M, E) for _ in R]
             dq, dkk, dvv = [mk(M, dk) for _ in R], [mk(M, dk) for _ in R], [mk(M, E) for _ in R]
+            dqt = [mk(M, dk) for _ in R]          # dq once more in the kernels' tile order (query side -> key side)
             darp, delta = [raw(vb) for _ in R], [mk(M) for _ in R]
             g2 = None
             for i in (3, 2, 1, 0):
@@ -1277,10 +1277,10 @@ class _AttnChainFused(torch.autograd.Function):
                 # back): both read in place by the kernel, no copy and no tensor add
                 _call("pzn_attn_fused_bwd_q", nprob, _ptrs(g), 5 * E, _ptrs(g2) if g2 is not None else None, E,
                       col(2), col(4), col(5), col(6), col(7), B, _ptrs(dz),
-                      _ptrs(u), _ptrs(dq), _ptrs(darp), _ptrs(delta), st,
+                      _ptrs(u), _ptrs(dq), _ptrs(dqt), _ptrs(darp), _ptrs(delta), st,
                       flops=nprob * (2 * M * E * (E + dk) + 2 * B * L * L * (2 * dk + E)))
                 _call("pzn_attn_fused_bwd_k", nprob, col(4), col(5), col(6), _ptrs(darp), col(7), col(3),
-                      _ptrs(delta), _ptrs(u), _ptrs(dq), B, _ptrs(dkk), _ptrs(dvv), _ptrs(dx), st,
+                      _ptrs(delta), _ptrs(u), _ptrs(dqt), B, _ptrs(dkk), _ptrs(dvv), _ptrs(dx), st,
                       flops=nprob * (2 * M * E * (E + dk) + 2 * B * L * L * (2 * dk + 2 * E)))
                 for p in R:
                     base = 2 + 35 * p

@@ -547,16 +547,20 @@ def test_attention_fused_block_intermediates(dev, B):
     _lib.call("pzn_attn_fused_fwd", 1, P([x]), P([qrp]), P([krp]), P([vrp]), P([W]), P([bo]), B, P([r]), P([t]), P([mask]),
               P([amap]), P([lse]), 0, 1.0, st)
     dz, u, dq, delta = mk(M, E), mk(M, E), mk(M, dk), mk(M)
+    dqt = mk(M, dk)
     darp = raw(vb)
     _lib.call("pzn_attn_fused_bwd_q", 1, P([dr]), E, None, E, P([mask]), P([qrp]), P([krp]), P([vrp]), P([W]), B, P([dz]), P([u]),
-              P([dq]), P([darp]), P([delta]), st)
+              P([dq]), P([dqt]), P([darp]), P([delta]), st)
     dkk, dvv, dx = mk(M, dk), mk(M, E), mk(M, E)
     _lib.call("pzn_attn_fused_bwd_k", 1, P([qrp]), P([krp]), P([vrp]), P([darp]), P([W]), P([lse]),
-              P([delta]), P([u]), P([dq]), B, P([dkk]), P([dvv]), P([dx]), st)
+              P([delta]), P([u]), P([dqt]), B, P([dkk]), P([dvv]), P([dx]), st)
     ref = _attn_block_ref64(x.view(B, L, E), wq, bq, wk, bk, wv, bv, wo, bo, dr.view(B, L, E))
     # the ReLU gate is discrete: an element whose pre-activation is within rounding of zero may be gated differently,
     # which is no kernel error; none may flip away from zero, and a flip near zero loosens the comparison
-    got = dict(r=r, t=t, map=amap, lse=lse, dz=dz, delta=delta, dq=dq, u=u, dk=dkk, dv=dvv, dx=dx)
+    def untile(x, F):     # tile image [row tile][feature tile][g][h][r][e] -> rows: feature = 32 ft + 8 g + 4 h + e
+        return x.view(M // 32, F // 32, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(M, F)
+    assert torch.equal(untile(dqt, dk), dq)                    # the same values in the two layouts
+    got = dict(r=r, t=t, map=amap, lse=lse, dz=dz, delta=delta, dq=dq, u=untile(u, E), dk=dkk, dv=dvv, dx=dx)
     flipped = (dz != 0) != (ref["dz"].reshape(M, E) != 0)
     assert int((flipped & (ref["z"].abs() > 1e-5).reshape(M, E)).sum()) == 0
     tol = 1e-5 if int(flipped.sum()) == 0 else 1e-3

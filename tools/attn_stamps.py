@@ -76,6 +76,7 @@ def run(Bs):
         r, t, lse, amap = mk(M, E), mk(M, E), mk(M), mk(B, L, L)
         mask = torch.zeros((M, 8), dtype=torch.int32, device=dev)
         dz, u, dq, delta = mk(M, E), mk(M, E), mk(M, dk), mk(M)
+        dqt = mk(M, dk)
         darp = raw(vb)
         dkk, dvv, dx = mk(M, dk), mk(M, E), mk(M, E)
         calls = {
@@ -83,9 +84,9 @@ def run(Bs):
             1: lambda: _lib.call("pzn_attn_fused_fwd", 1, P([x]), P([qrp]), P([krp]), P([vrp]), P([W]), P([bo]), B, P([r]), P([t]),
                                  P([mask]), P([amap]), P([lse]), 1, 0.25, st),
             2: lambda: _lib.call("pzn_attn_fused_bwd_q", 1, P([dr]), E, P([dr2]), E, P([mask]), P([qrp]), P([krp]),
-                                 P([vrp]), P([W]), B, P([dz]), P([u]), P([dq]), P([darp]), P([delta]), st),
+                                 P([vrp]), P([W]), B, P([dz]), P([u]), P([dq]), P([dqt]), P([darp]), P([delta]), st),
             3: lambda: _lib.call("pzn_attn_fused_bwd_k", 1, P([qrp]), P([krp]), P([vrp]), P([darp]), P([W]),
-                                 P([lse]), P([delta]), P([u]), P([dq]), B, P([dkk]), P([dvv]), P([dx]), st),
+                                 P([lse]), P([delta]), P([u]), P([dqt]), B, P([dkk]), P([dvv]), P([dx]), st),
         }
         big = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
         times = {}

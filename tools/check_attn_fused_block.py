@@ -44,12 +44,13 @@ def main():
     _lib.call("pzn_attn_fused_fwd", 1, P([x]), P([qrp]), P([krp]), P([vrp]), P([W]), P([bo]), B, P([r]), P([t]), P([mask]),
               P([amap]), P([lse]), 0, 1.0, st)
     dz, u, dq, delta = mk(M, E), mk(M, E), mk(M, dk), mk(M)
+    dqt = mk(M, dk)
     darp = raw(vb)
     _lib.call("pzn_attn_fused_bwd_q", 1, P([dr]), E, None, E, P([mask]), P([qrp]), P([krp]), P([vrp]), P([W]), B, P([dz]), P([u]),
-              P([dq]), P([darp]), P([delta]), st)
+              P([dq]), P([dqt]), P([darp]), P([delta]), st)
     dkk, dvv, dx = mk(M, dk), mk(M, E), mk(M, E)
     _lib.call("pzn_attn_fused_bwd_k", 1, P([qrp]), P([krp]), P([vrp]), P([darp]), P([W]), P([lse]),
-              P([delta]), P([u]), P([dq]), B, P([dkk]), P([dvv]), P([dx]), st)
+              P([delta]), P([u]), P([dqt]), B, P([dkk]), P([dvv]), P([dx]), st)
     torch.cuda.synchronize()
 
     D = torch.float64
@@ -77,7 +78,8 @@ def main():
     DX = U + DQ @ wq.to(D) + DKr @ wk.to(D) + DVr @ wv.to(D)
     LSE = torch.logsumexp(s, dim=-1)
     for name, got, want in (("r", r, rr), ("t", t, tt), ("map", amap, Pm), ("lse", lse, LSE), ("dz", dz, DZ), ("delta", delta, dl),
-                            ("dq", dq, DQ), ("u", u, U), ("dk", dkk, DKr), ("dv", dvv, DVr), ("dx", dx, DX)):
+                            ("dq", dq, DQ),
+                            ("u", u.view(M // 32, E // 32, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(M, E), U), ("dk", dkk, DKr), ("dv", dvv, DVr), ("dx", dx, DX)):
         print(f"{name:6s} rel {rel(got.view(-1), want.reshape(-1)):.3e}")
 
 
