@@ -38,15 +38,17 @@ def init_from_env(backend=None):
         kw = {}
         if backend == "nccl" and on_gpu:
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        if os.environ.get("PZN_DIST_LAZY_INIT") == "1":
+            kw = {}              # every rank takes the same path: the switch is an environment variable, not an exception
         try:
             dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
-        except (TypeError, ValueError, RuntimeError):
-            # (the eager, device-bound communicator has never met this build's multi-GPU hardware: fall back to the lazy one,
-            # which binds to the current device - already selected above - at the first collective)
+        except TypeError:
+            # this torch build does not know the `device_id` keyword: the lazy communicator binds to the current device
+            # (selected above) at the first collective.  Only a TypeError - raised before any rendezvous, on every rank
+            # alike - is retried: a RuntimeError from a half-built group on ONE rank must not lead that rank into a second
+            # rendezvous on the same port while its peers are past the first (set PZN_DIST_LAZY_INIT=1 on all ranks instead).
             if not kw:
                 raise
-            if dist.is_initialized():
-                dist.destroy_process_group()
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 

@@ -29,6 +29,40 @@ def late_gradient(name):
     return name.startswith(("Encoder.", "Encoder2.")) and name.split(".", 1)[1].startswith(_LATE_LAYERS)
 
 
+class _EarlyGate:
+    """When may the early piece of the gradient bucket go out?  When the backward of EVERYTHING that writes into it has
+    been enqueued.  The model marks tensors during the forward pass (`mark`): the input of each encoder's attention
+    chain (behind it: the chain, the out projection and, through the global feature, the pose head) and an alias of
+    each boundary head's per-point input (behind it: MLPLocalPre* and MLP*b, which hang off the per-point features and
+    are NOT ancestors of the chain inputs).  Each marker's tensor hook fires when that tensor's gradient exists, i.e.
+    after the backward nodes behind it have run (autograd's data dependency, not its queue order); the hook records an
+    event on the stream it runs on.  When every marker armed in this step's forward has fired, `on_open(events)` is
+    called once."""
+
+    def __init__(self, on_open):
+        self.on_open = on_open
+        self.reset()
+
+    def reset(self):
+        self.armed, self.fired, self.events, self.opened = 0, 0, [], False
+
+    def mark(self, t):
+        self.armed += 1
+        t.register_hook(self._fire)
+        return t
+
+    def _fire(self, grad):
+        self.fired += 1
+        if grad.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.events.append(ev)
+        if self.fired == self.armed and not self.opened:
+            self.opened = True
+            self.on_open(self.events)
+        return None
+
+
 class TrainStep:
     def __init__(self, model, batch, lr, world=1, use_graph=False, warmup=0, prefetch=None):
         if use_graph:
@@ -38,13 +72,16 @@ class TrainStep:
         self.batch = batch
         self.world = world
         # "late" gradients = the encoders' per-point and set-abstraction layers (last nodes of the backward); everything
-        # else is complete once both attention chains' backward has been enqueued and is reduced early (N > 1)
+        # else is complete once both attention chains' AND both boundary heads' backward has been enqueued (_EarlyGate)
+        # and is reduced early (N > 1)
         self.grads = pdist.FlatGradAllReduce(model.named_parameters(), late=late_gradient)
-        self._sync_events = []
-        self._saved_hooks = None
+        self._gate = _EarlyGate(self.grads.all_reduce_early)
+        self._saved_markers = None
         if world > 1 and hasattr(model, "Encoder") and hasattr(model, "Encoder2"):
-            self._saved_hooks = (getattr(model.Encoder, "f2f_grad_hook", None), getattr(model.Encoder2, "f2f_grad_hook", None))
-            model.Encoder.f2f_grad_hook = model.Encoder2.f2f_grad_hook = self._on_f2f_grad
+            holders = (model, model.Encoder, model.Encoder2)
+            self._saved_markers = [(h, getattr(h, "grad_marker", None)) for h in holders]
+            for h in holders:
+                h.grad_marker = self._gate.mark
         # Adam + StepLR(50, 0.999) over flat buffers: one launch per step (distributed.FlatAdam; model5_b.py:1453-1457)
         self.opt = pdist.FlatAdam(self.grads, lr, sched_step=50, sched_gamma=0.999)
         self.loss = None
@@ -53,23 +90,9 @@ class TrainStep:
         self._saved_defer = getattr(model, "defer_emd_loss", False)
         model.defer_emd_loss = True
 
-    def _on_f2f_grad(self, grad):
-        """Tensor hook on the input of an encoder's attention chain: its gradient exists, so every gradient of the
-        heads, the attention blocks and the out projection of that encoder has been enqueued.  After both encoders the
-        early piece of the bucket goes out on the communication stream."""
-        if grad.is_cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self._sync_events.append(ev)
-        else:
-            self._sync_events.append(None)
-        if len(self._sync_events) == 2:
-            self.grads.all_reduce_early([e for e in self._sync_events if e is not None])
-        return None
-
     def _fwd_bwd(self):
         self.grads.zero_()
-        self._sync_events = []
+        self._gate.reset()
         out = self.model.training_step(self.batch, 0)
         cur = torch.cuda.current_stream()
         if "loss" in out:
@@ -120,9 +143,10 @@ class TrainStep:
         self._plans_ahead = None
         if hasattr(self.model, "use_plans"):
             self.model.use_plans(None)
-        if self._saved_hooks is not None:
-            self.model.Encoder.f2f_grad_hook, self.model.Encoder2.f2f_grad_hook = self._saved_hooks
-            self._saved_hooks = None
+        if self._saved_markers is not None:
+            for h, m in self._saved_markers:
+                h.grad_marker = m
+            self._saved_markers = None
 
     def __enter__(self):
         return self

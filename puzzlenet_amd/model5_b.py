@@ -130,11 +130,13 @@ class PCTransformer_nonsort(nn.Module):
 
     fused_sa = True     # False: literally sample_and_group -> [B,S,K,3+D] -> shared MLP, as the reference composes it
     need_out = True     # False: slot 3 of the 5-tuple (the [B,256,1024] projection) is None; predict5 sets it around its calls
-    f2f_grad_hook = None     # engine.TrainStep (N > 1): called with the gradient of the attention chain's input
+    grad_marker = None       # engine.TrainStep (N > 1): marker(tensor) registers "the backward has come this far" on it
 
     def _mark_f2f(self, f2f):
-        if self.f2f_grad_hook is not None and f2f.requires_grad:
-            f2f.register_hook(self.f2f_grad_hook)
+        """The input of the attention chain: when its gradient exists, the chain's and the out projection's backward of
+        this encoder has been enqueued (data dependency)."""
+        if self.grad_marker is not None and f2f.requires_grad:
+            self.grad_marker(f2f)
         return f2f
 
     def _set_abstraction(self, npoint, nsample, xyz, feat, lin_a, lin_b, plan=None):
@@ -305,7 +307,8 @@ class TouchedRegraster(_Base):
         self._side_stream = None
         self._emd_stream = None
         self._plan_stream = None
-        self._plan_cache = None        # (fpc, mrpc, plans, event) from prefetch_plans, handed over by use_plans
+        self._plan_cache = None        # (fpc, mrpc, plans, event, versions) from prefetch_plans, handed over by use_plans
+        self.grad_marker = None        # engine.TrainStep (N > 1), see _heads
         self.defer_emd_loss = False    # see training_step: the EMD term as a separate backward root (engine.TrainStep)
 
     # ------------------------------------------------------------------ forward
@@ -406,6 +409,14 @@ class TouchedRegraster(_Base):
         since autograd replays a node on its forward stream, backward."""
         ffpc, non_sg_ffpc = ffpcs[0], ffpcs[4]
         fmrpc, non_sg_fmrpc = fmrpcs[0], fmrpcs[4]
+        if self.grad_marker is not None:
+            # The boundary branch hangs off the encoders' per-point features, NOT off the attention chains: its backward
+            # is no ancestor of the chains' input gradient.  An alias of each input carries its own marker: that alias's
+            # gradient exists exactly when MLPLocalPre* / MLP*b of that cloud have been through their backward.
+            if non_sg_ffpc.requires_grad:
+                non_sg_ffpc = self.grad_marker(non_sg_ffpc.view_as(non_sg_ffpc))
+            if non_sg_fmrpc.requires_grad:
+                non_sg_fmrpc = self.grad_marker(non_sg_fmrpc.view_as(non_sg_fmrpc))
         if side is not None:
             cur = torch.cuda.current_stream()
             with torch.cuda.stream(side):
@@ -475,7 +486,10 @@ class TouchedRegraster(_Base):
             plans = self._sa_plans(fpc, mrpc, with_knn=True)
             ready = torch.cuda.Event()
             ready.record(ps)
-        return (fpc, mrpc, plans, ready) if plans[0] is not None else None
+        # the plan belongs to these tensors AS THEY ARE NOW: an in-place refresh of a persistent batch buffer
+        # (batch[0].copy_(...)) bumps the version counter and the plan is not taken (predict5 then computes its own)
+        stamp = (fpc._version, mrpc._version, fpc.data_ptr(), mrpc.data_ptr())
+        return (fpc, mrpc, plans, ready, stamp) if plans[0] is not None else None
 
     def use_plans(self, prefetched):
         """Hand a prefetch_plans() result to the next predict5 call (None: nothing prefetched)."""
@@ -486,6 +500,8 @@ class TouchedRegraster(_Base):
         cached, self._plan_cache = self._plan_cache, None
         if cached is None or cached[0] is not fpc or cached[1] is not mrpc:
             return None
+        if cached[4] != (fpc._version, mrpc._version, fpc.data_ptr(), mrpc.data_ptr()):
+            return None                # same tensor objects, other contents: the prefetched samples are stale
         plans, ready = cached[2], cached[3]
         for st in streams:
             st.wait_event(ready)
