@@ -11,10 +11,13 @@ Workload = BASELINE.json configs[1]: N=2048 points, 64 pairs per GPU, fp32.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (the max-pool variant of the
-weight-stationary matrix-core kernel, priced against the bf16 pipe it issues on), `roofline_knn_group` (the stage the
-north star names: the drop-in sample_and_group's search + group launch, HBM-bound, SURVEY 8(d) bytes), further
-per-stage rooflines, and `cpu_baseline` (the torch-CPU + C restatement in oracle/, kind "port", on the host cores).
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` = the DOMINANT kernel of the step
+(the single-kernel entry point with the largest launch-time sum in the instrumented pass: one of the chained attention
+kernels, the streamed set-abstraction level or the out projection; flops, launches and average launch time printed, the
+committed rocprofv3 average beside the live one), `roofline_sa_level` (the streamed generated-row max-pool kernel, the
+`roofline` of rounds 2-3), `roofline_knn_group` (the stage the north star names: the drop-in sample_and_group's search +
+group launch, HBM-bound, SURVEY 8(d) bytes), further per-stage rooflines, and `cpu_baseline` (the torch-CPU + C
+restatement in oracle/, kind "port", on the host cores).
 """
 import argparse
 import json
@@ -181,19 +184,40 @@ def build_id():
     return h.hexdigest()[:16]
 
 
+ROUND = "r4"
+
+
 def pmc_traffic(key, B, N):
     """HBM bytes per step of a kernel / stage from the committed PMC passes (tools/pmc_summary.py, collected with
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` in separate runs of this same command): only when they were taken
     on THIS build and on this workload; otherwise null.  -> (bytes or None, provenance string)."""
-    path = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
+    name = f"{ROUND}_pmc_traffic.json"
+    path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None, "no PMC summary committed for this round"
     doc = json.load(open(path))
     if doc.get("build_id") != build_id():
-        return None, f"profiles/r3_pmc_traffic.json was collected on build {doc.get('build_id')}, this is {build_id()}"
+        return None, f"profiles/{name} was collected on build {doc.get('build_id')}, this is {build_id()}"
     if (doc.get("batch"), doc.get("points")) != (B, N):
-        return None, "profiles/r3_pmc_traffic.json was collected on another workload"
-    return doc.get(key), f"profiles/r3_pmc_traffic.json (build {doc.get('build_id')}, separate --pmc passes of bench.py)"
+        return None, f"profiles/{name} was collected on another workload"
+    return doc.get(key), f"profiles/{name} (build {doc.get('build_id')}, separate --pmc passes of bench.py)"
+
+
+def profile_kernel_rows(kernel):
+    """Rows of the committed `rocprofv3 --kernel-trace --stats` summary (profiles/<round>_kernel_stats.csv) whose kernel
+    name contains `kernel`, as (name, calls, average ns, share of GPU time), with the file's rank of the first of them
+    (1 = top row); None when no summary of this round is committed."""
+    import csv
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_kernel_stats.csv")
+    if not os.path.exists(path):
+        return None
+    rows = []
+    with open(path, newline="") as f:
+        for rank_, r in enumerate(csv.DictReader(f), 1):
+            if kernel in r["Name"]:
+                rows.append({"rank": rank_, "name": r["Name"][:96], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
+                             "percent_of_gpu_time": float(r["Percentage"])})
+    return rows or None
 
 
 def main():
@@ -273,6 +297,7 @@ def main():
         for _ in range(prof_steps):
             eager.step()
         kern = ops.KernelTimer.stop()
+        kern_variants = dict(ops.KernelTimer.variants)
         emd_walk, ops.EMD_WALK_STATS = ops.EMD_WALK_STATS, None
         rowmasks, ops.SA_ROWMASK_STATS = ops.SA_ROWMASK_STATS, None
         # rows of dh that exist (mask bit set) per step, in bytes: what the masked list sum has to read
@@ -292,10 +317,10 @@ def main():
             n, ms = (table or kern).get(name, (0, 0.0))
             return n / prof_steps, ms / prof_steps
 
-        # (1) `roofline`: ONE named kernel, the largest single matrix-core launch of the step: ws_gemm_kernel in its
-        #     max-pool variant (pzn_sa_level_fwd_f32: second shared-MLP layer + ReLU + max over the 32 neighbours on the
-        #     generated rows of the first, model5_b.py:452-454 / :459-461; 4 launches per step).  It issues v_mfma_f32_32x32x16_bf16 six times per
-        #     fp32 product, so it is priced against the bf16 pipe / 6, with the fp32-input MFMA rate beside it.
+        # (1) `roofline_sa_level`: the generated-row max-pool level (pzn_sa_level_fwd_*: second shared-MLP layer + ReLU + max
+        #     over the 32 neighbours on the generated rows of the first, model5_b.py:452-454 / :459-461; 4 launches per
+        #     step).  It issues v_mfma_f32_32x32x16_bf16 six times per fp32 product, so it is priced against the bf16
+        #     pipe / 6, with the fp32-input MFMA rate beside it.  (`roofline` of rounds 2-3; see (6) for this round's.)
         mp_entry = next((n for n in ("pzn_sa_level_fwd_packed_f32", "pzn_sa_level_fwd_ws_f32", "pzn_sa_level_fwd_f32") if n in kern),
                         "pzn_linear_maxpool_fwd_f32")
         packed = mp_entry == "pzn_sa_level_fwd_packed_f32"     # the kernel alone: the split of W2 is its own entry point (timed beside)
@@ -304,7 +329,7 @@ def main():
         fl_mp = kern_flops.get(mp_entry, 0) / prof_steps
         mp_ach = fl_mp / (ms_mp * 1e-3) / 1e12 if ms_mp > 0 else 0.0
         mp_traffic, mp_src = pmc_traffic("ws_gemm_maxpool_bytes_per_step", B, N)
-        roofline = {
+        roofline_sa_level = {
             "bound": "mfma",
             "kernel": ("sa_level_stream_kernel<C1, CT> (csrc/salevel.hip: bf16x3 MFMA kernel, the rows relu(P'[idx] + Q) of the first "
                        "layer generated once per group in registers, W2 streamed through a three-slot LDS ring by LDS-DMA, "
@@ -321,7 +346,7 @@ def main():
             "avg_launch_ms": ms_mp / max(1.0, n_mp),
         }
         if packed:
-            roofline["weight_split_ms_per_step"] = per_step("pzn_sa_level_prep_weights_f32")[1]
+            roofline_sa_level["weight_split_ms_per_step"] = per_step("pzn_sa_level_prep_weights_f32")[1]
         # (1b) every dense matrix-core entry point together (no sparse vector-ALU passes in the sum)
         dense_names = ("pzn_linear_fwd_f32", "pzn_linear_dgrad_f32", "pzn_linear_wgrad_f32", "pzn_linear_maxpool_fwd_f32",
                        "pzn_sharedmlp_max_fwd_f32", "pzn_attn_fwd_f32", "pzn_attn_bwd_f32", "pzn_attn_block_fwd_f32",
@@ -456,25 +481,96 @@ def main():
                              "frac": (pb_fma / (ms_pb * 1e-3) / VALU_LANE_SLOTS_PER_S) if ms_pb > 0 else 0.0},
             "floor_ms_per_step": {"hbm": t_hbm * 1e3, "vector_issue": t_valu * 1e3},
         }
-        fused_names = ("pzn_attn_fused_prep_weights", "pzn_attn_fused_proj", "pzn_attn_fused_fwd", "pzn_attn_fused_bwd_q",
-                       "pzn_attn_fused_bwd_k", "pzn_attn_fused_wgrads")
+        fused_names = ("pzn_attn_fused_prep_weights", "pzn_attn_fused_prep_weights_n", "pzn_attn_fused_proj", "pzn_attn_fused_fwd",
+                       "pzn_attn_fused_bwd_q", "pzn_attn_fused_bwd_k", "pzn_attn_fused_wgrads")
         attn_fused = "pzn_attn_fused_fwd" in kern
         attn_names = fused_names if attn_fused else ("pzn_attn_block_fwd_f32", "pzn_attn_block_bwd_f32")
         ms_at = sum(per_step(k)[1] for k in attn_names)
         n_at = sum(per_step(k)[0] for k in attn_names)
         fl_at = sum(kern_flops.get(k, 0) for k in attn_names) / prof_steps
         at_ach = fl_at / (ms_at * 1e-3) / 1e12 if ms_at > 0 else 0.0
+        # what the attention kernels' products issue per fp32 product: six bf16 MFMAs (default), ONE in --attn bf16
+        # (the chained kernels' single-plane instantiation: every product of the block, priced against the bf16 pipe itself;
+        # the weight gradients stay bf16x3 and are a small share)
+        attn_peak = MFMA_BF16_PEAK_TFLOPS if (args.attn == "bf16" and attn_fused) else MFMA_X3_PEAK_TFLOPS
         roofline_attention = {
             "bound": "mfma",
-            "kernel": ("pzn_attn_fused_{prep_weights,proj,fwd,bwd_q,bwd_k,wgrads} (csrc/attnfused.hip): layerAttention (model5_b.py:83-101) as "
-                       "chained matrix-core kernels, both encoders per launch; ALGORITHMIC flops (the backward's recomputed "
-                       "scores are not counted)") if attn_fused else
+            "kernel": ("pzn_attn_fused_{prep_weights_n,proj,fwd,bwd_q,bwd_k,wgrads} (csrc/attnfused.hip): layerAttention (model5_b.py:83-101) as "
+                       "chained matrix-core kernels, ONE encoder per launch (128 workgroups at B = 64; the two encoders run on two "
+                       "streams in the timed loop and one after the other in this instrumented pass); ALGORITHMIC flops (the "
+                       "backward's recomputed scores are not counted)") if attn_fused else
                       ("pzn_attn_block_{fwd,bwd}_f32: layerAttention (model5_b.py:83-101), 8 + 8 launches per step; "
                        f"contractions q k^T / attn v and their backward in {'single bf16 MFMAs, fp32 softmax' if args.attn == 'bf16' else 'bf16x3 split precision (fp32 results)'}"),
-            "achieved": at_ach, "peak": MFMA_X3_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": at_ach / MFMA_X3_PEAK_TFLOPS,
+            "achieved": at_ach, "peak": attn_peak, "unit": "TFLOP/s", "frac": at_ach / attn_peak,
             "traffic": None, "algorithmic_flops_per_step": fl_at, "ms_per_step": ms_at, "launches_per_step": n_at,
             "note": "256 tokens per cloud whatever N: 64 x (256 x 256 x 64..256) products per encoder and block",
         }
+        # (6) `roofline`: the DOMINANT kernel.  Candidates = the entry points that launch exactly ONE kernel each (so that the
+        #     event pair around the call times that kernel and nothing else) and whose algorithmic flops the wrapper records;
+        #     the winner is the one with the largest launch-time sum per step in this instrumented pass.  (Entry points that
+        #     are sequences of kernels - EMD: ~20 passes per N x N call, the sparse pooled backward: two passes - are priced as
+        #     stages of their own, roofline_emd / roofline_pool_bwd; their largest single kernels are listed in
+        #     `largest_multi_kernel_entries` with the committed profile's figures so that the ranking can be checked.)
+        single = {
+            "pzn_attn_fused_fwd": ("attn_fwd_kernel", "csrc/attnfused.hip: scores, softmax, PV, x - a, out projection, x + relu(.) for 32 points per wavefront (model5_b.py:67-75, 83-101)"),
+            "pzn_attn_fused_bwd_q": ("attn_bwd_q_kernel", "csrc/attnfused.hip: query side of the block's backward (dz, dt, da image, dP, recomputed P, delta, dS, dq)"),
+            "pzn_attn_fused_bwd_k": ("attn_bwd_k_kernel", "csrc/attnfused.hip: key side of the block's backward (S, P, dP, dS, dk, dv, dx = u + dq Wq + dk Wk + dv Wv)"),
+            "pzn_attn_fused_proj": ("attn_proj_kernel", "csrc/attnfused.hip: q, k, v projection into bf16-plane images"),
+            mp_entry: ("sa_level_stream_kernel", "csrc/salevel.hip: generated-row max-pool level (two instantiations: <128,4>, <256,8>)"),
+            "pzn_outproj_maxpts_fwd_f32": ("outproj_maxpts_kernel", "csrc/outproj.hip: out projection of the five slices + max over the points"),
+        }
+        cand = {e: per_step(e) for e in single if e in kern and kern_flops.get(e, 0) > 0}
+        cand_fl = {e: kern_flops.get(e, 0) / prof_steps for e in cand}
+        # an entry point with several kernel instantiations (the level kernel: <128, 4> and <256, 8>) competes per instantiation,
+        # as in the rows of a rocprofv3 kernel summary
+        split_entries = {e for (e, _v) in kern_variants if e in cand}
+        for (e, var), (n_, ms_, fl_) in kern_variants.items():
+            if e in split_entries:
+                key = e + var
+                single[key] = (single[e][0] + var, single[e][1])
+                cand[key] = (n_ / prof_steps, ms_ / prof_steps)
+                cand_fl[key] = fl_ / prof_steps
+        for e in split_entries:
+            cand.pop(e)
+        dom = max(cand, key=lambda e: cand[e][1])
+        dn, dms = cand[dom]
+        dfl = cand_fl[dom]
+        dom_peak = attn_peak if dom.startswith("pzn_attn_fused") else MFMA_X3_PEAK_TFLOPS
+        dach = dfl / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
+        prof_rows = profile_kernel_rows(single[dom][0])
+        # HBM bytes per launch of that kernel from this build's committed PMC passes (per-kernel table of tools/pmc_summary.py)
+        pk, pk_src = pmc_traffic("per_kernel", B, N)
+        dom_traffic = None
+        if pk:
+            hit = [v for k_, v in pk.items() if k_.startswith(single[dom][0])]
+            if hit:
+                dom_traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit)
+        roofline = {
+            "bound": "mfma",
+            "kernel": f"{single[dom][0]} behind {dom.split('<')[0]} ({single[dom][1]})",
+            "achieved": dach, "peak": dom_peak, "unit": "TFLOP/s", "frac": dach / dom_peak,
+            "traffic": dom_traffic, "traffic_source": pk_src + " (bytes per launch, like algorithmic_flops_per_launch)",
+            "peak_note": ("dense bf16 MFMA rate (2500 TFLOP/s) / 6 issued bf16 MFMAs per fp32 product" if dom_peak == MFMA_X3_PEAK_TFLOPS
+                          else "dense bf16 MFMA rate (one bf16 MFMA per product in --attn bf16)"),
+            "algorithmic_flops_per_step": dfl, "algorithmic_flops_per_launch": dfl / max(1.0, dn),
+            "ms_per_step": dms, "launches_per_step": dn, "avg_launch_us": 1e3 * dms / max(1.0, dn),
+            "how_chosen": "largest launch-time sum per step among the single-kernel entry points of the instrumented (one-stream) pass",
+            "candidates_ms_per_step": {single[e][0]: cand[e][1] for e in sorted(cand, key=lambda e: -cand[e][1])},
+        }
+        if prof_rows:
+            pavg = sum(r["avg_us"] * r["calls"] for r in prof_rows) / sum(r["calls"] for r in prof_rows)
+            roofline["profile"] = {
+                "file": f"profiles/{ROUND}_kernel_stats.csv", "rows": prof_rows, "profile_avg_launch_us": pavg,
+                "frac_from_profile_avg": dfl / max(1.0, dn) / (pavg * 1e-6) / 1e12 / dom_peak,
+                "note": "rocprofv3 --kernel-trace --stats of this command: averages over the timed loop, where the two encoders' "
+                        "kernels share the chip (two streams), and the one-stream instrumented pass"}
+        multi = {}
+        for k_ in ("emd_pass_ca_kernel", "emd_pass_b_list_kernel", "pool_wgrad_kernel", "pool_dgrad_kernel", "df_wgrad_kernel"):
+            rows_ = profile_kernel_rows(k_)
+            if rows_:
+                multi[k_] = rows_
+        if multi:
+            roofline["largest_multi_kernel_entries"] = multi
         stages = {k: {"launches_per_step": n / prof_steps, "ms_per_step": ms / prof_steps} for k, (n, ms) in sorted(kern.items())}
         stages_api = {k: {"launches": n, "ms": ms} for k, (n, ms) in sorted(kern_api.items())}
         out = {
@@ -489,6 +585,7 @@ def main():
                        "matrix_core_path": "bf16x3 split precision (fp32 results; six bf16 MFMAs per product)",
                        "attention": args.attn, "build_id": build_id()},
             "roofline": roofline,
+            "roofline_sa_level": roofline_sa_level,
             "roofline_mfma_family": roofline_mfma_family,
             "roofline_knn_group": roofline_knn_group,
             "roofline_sa_gather": roofline_sa_gather,

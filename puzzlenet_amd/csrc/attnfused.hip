@@ -181,17 +181,17 @@ __device__ __forceinline__ void load_tiles(const float* img, long tile0, int lan
 
 // Rp image of M[256 rows][16 KS features]: tile ft of the accumulators = k-steps 2 ft, 2 ft + 1; the lane's registers
 // 8s..8s+7 are exactly its own chunk.  img = this cloud's image, rt = row tile of the wavefront.
-template <int FT, bool NEG = false>
+template <int FT, int NPL, bool NEG = false>
 __device__ __forceinline__ void store_rp(unsigned char* img, int rt, int lane, const floatx16* x) {
 #pragma unroll
   for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 b[3];
-      make_b<NEG>(x[ft], s, b);
+      make_bn<NPL, NEG>(x[ft], s, b);
       const int ks = 2 * ft + s;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(img + (((ks * 3 + p) * 8 + rt) * 64 + lane) * 16) = b[p];
+      for (int p = 0; p < NPL; ++p) *reinterpret_cast<bf16x8*>(img + (((ks * 3 + p) * 8 + rt) * 64 + lane) * 16) = b[p];
       __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from splitting all 16 fragments before the first store)
     }
 }
@@ -268,6 +268,7 @@ __device__ __forceinline__ void bias_tiles(floatx16* acc, const float* bias, int
 #define ZERO_TILES(A, N)            \
   _Pragma("unroll") for (int i_ = 0; i_ < (N); ++i_) _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) A[i_][j_] = 0.f
 
+template <int NPL>
 __global__ __launch_bounds__(NT, 1) void attn_proj_kernel(ProjArgs a) {
   constexpr int WSLAB = 36864;
   __shared__ __attribute__((aligned(16))) unsigned char lds[3 * WSLAB];
@@ -285,37 +286,39 @@ __global__ __launch_bounds__(NT, 1) void attn_proj_kernel(ProjArgs a) {
   load_rows<8>(P.x, row0, E, X, stg, lane);
   __syncthreads();
   STAMPK(0, 1);
-  ring.issue<9>(wsrc, 0);
-  ring.issue<9>(wsrc + WSLAB, 1);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) ring.issue1<NPL, 12>(wsrc, 0, i);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) ring.issue1<NPL, 12>(wsrc + WSLAB, 1, i);
   floatx16 acc[12];
   bias_tiles<2>(acc, P.bq, h);
   bias_tiles<2>(acc + 2, P.bk, h);
   bias_tiles<8>(acc + 4, P.bv, h);
   bf16x8 b[2][3];
-  make_b(X[0], 0, b[0]);
+  make_bn<NPL>(X[0], 0, b[0]);
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
-    step_sync(ks < 15 ? 9 : 0);
-    BNext bn;
+    step_sync(ks < 15 ? (NPL == 3 ? 9 : 3) : 0);
+    BNextN<NPL> bn;
     auto fill = [&](int t) {
       if (t < 5) {
         if (ks + 2 < 16) {
-          ring.issue1(wsrc + (ks + 2) * WSLAB, (ks + 2) % 3, 2 * t);
-          if (2 * t + 1 < 9) ring.issue1(wsrc + (ks + 2) * WSLAB, (ks + 2) % 3, 2 * t + 1);
+          ring.issue1<NPL, 12>(wsrc + (ks + 2) * WSLAB, (ks + 2) % 3, 2 * t);
+          if (2 * t + 1 < 9) ring.issue1<NPL, 12>(wsrc + (ks + 2) * WSLAB, (ks + 2) % 3, 2 * t + 1);
         }
       } else if (t < 9 && ks < 15) {
         bn.pair(X[(ks + 1) >> 1], (ks + 1) & 1, t - 5);
       }
     };
-    kstep_rp<12>(acc, ring.lane_addr(ks % 3), b[ks & 1], fill);
+    kstep_rp_n<12, NPL>(acc, ring.lane_addr(ks % 3), b[ks & 1], fill);
     if (ks < 15) bn.get(b[(ks + 1) & 1]);
   }
   const floatx16 *q = acc, *k = acc + 2, *v = acc + 4;
   STAMPK(0, 2);
-  store_rp<2>(P.qrp + (size_t)cloud * QK_IMG, rt, lane, q);
-  store_rp<2>(P.krp + (size_t)cloud * QK_IMG, rt, lane, k);
+  store_rp<2, NPL>(P.qrp + (size_t)cloud * QK_IMG, rt, lane, q);
+  store_rp<2, NPL>(P.krp + (size_t)cloud * QK_IMG, rt, lane, k);
   STAMPK(0, 3);
-  store_rp<8>(P.vrp + (size_t)cloud * V_IMG, rt, lane, v);
+  store_rp<8, NPL>(P.vrp + (size_t)cloud * V_IMG, rt, lane, v);
   STAMPK(0, 4);
 }
 
@@ -349,11 +352,12 @@ __device__ __forceinline__ float softmax_regs(floatx16 (&S)[8]) {
 }
 
 // the wavefront's query fragments (B operand of S^T = K q^T): 4 k-steps x 3 planes, straight from the Rp image
+template <int NPL>
 __device__ __forceinline__ void load_own_frags(const unsigned char* img, int rt, int lane, bf16x8 (&f)[4][3]) {
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) f[ks][p] = *reinterpret_cast<const bf16x8*>(img + (((ks * 3 + p) * 8 + rt) * 64 + lane) * 16);
+    for (int p = 0; p < NPL; ++p) f[ks][p] = *reinterpret_cast<const bf16x8*>(img + (((ks * 3 + p) * 8 + rt) * 64 + lane) * 16);
 }
 
 // ================================================================================================================
@@ -376,7 +380,9 @@ struct FwdArgs {
   float map_scale;
 };
 
+template <int NPL>
 __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(FwdArgs a) {
+  constexpr int DPW = NPL == 3 ? 6 : 2;   // DMA pieces per wavefront and slab (NPL = 1: plane 0 only)
   __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SLAB + 4 * STG_BYTES];   // ring | staging per wavefront
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
   const int lb = logical_block(blockIdx.x, gridDim.x);
@@ -394,16 +400,16 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(FwdArgs a) {
   constexpr int NS = 36;
   auto issue1 = [&](int c, int i) {   // piece i of this wavefront of slab c -> slot c % 3
     if (c < 4)
-      ring.issue1(krp + c * SLAB, c % 3, i);
+      ring.issue1<NPL>(krp + c * SLAB, c % 3, i);
     else if (c < 20)
-      ring.issue1_t<256>(vrp, tsrc, c - 4, c % 3, i);
+      ring.issue1_t<256, NPL>(vrp, tsrc, c - 4, c % 3, i);
     else if (c < NS)
-      ring.issue1(wo + (c - 20) * SLAB, c % 3, i);
+      ring.issue1<NPL>(wo + (c - 20) * SLAB, c % 3, i);
   };
 
   STAMP(0);
   bf16x8 qf[4][3];
-  load_own_frags(P.qrp + (size_t)cloud * QK_IMG, rt, lane, qf);
+  load_own_frags<NPL>(P.qrp + (size_t)cloud * QK_IMG, rt, lane, qf);
 #pragma unroll
   for (int i = 0; i < 6; ++i) issue1(0, i);
 #pragma unroll
@@ -413,14 +419,14 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(FwdArgs a) {
   // ---- S^T = K q^T (4 k-steps over d)
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    step_sync(6);
+    step_sync(DPW);
     auto fill = [&](int t) {
       if (t < 3) {
         issue1(c + 2, 2 * t);
         issue1(c + 2, 2 * t + 1);
       }
     };
-    kstep_rp<8>(S, ring.lane_addr(c % 3), qf[c], fill);
+    kstep_rp_n<8, NPL>(S, ring.lane_addr(c % 3), qf[c], fill);
   }
   STAMP(1);
   const float lse = softmax_regs(S);
@@ -437,14 +443,14 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(FwdArgs a) {
   floatx16 O[8];
   ZERO_TILES(O, 8);
   bf16x8 b[2][3];
-  make_b(S[0], 0, b[0]);
+  make_bn<NPL>(S[0], 0, b[0]);
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     const int c = 4 + ks;
     if (ks >= 4 && ks < 8) STAMP(16 + 2 * (ks - 4));
-    step_sync(6);
+    step_sync(DPW);
     if (ks >= 4 && ks < 8) STAMP(17 + 2 * (ks - 4));
-    BNext bn;
+    BNextN<NPL> bn;
     auto fill = [&](int t) {
       if (t < 3) {
         issue1(c + 2, 2 * t);
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(FwdArgs a) {
         bn.pair(S[(ks + 1) >> 1], (ks + 1) & 1, t - 3);
       }
     };
-    kstep_tr<8, 256, 0>(O, tr_lane_addr(ring.slot_addr(c % 3), lane), b[ks & 1], fill);
+    kstep_tr<8, 256, 0, NPL>(O, tr_lane_addr(ring.slot_addr(c % 3), lane), b[ks & 1], fill);
     if (ks < 15) bn.get(b[(ks + 1) & 1]);
   }
   STAMP(4);
@@ -466,18 +472,18 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(FwdArgs a) {
     for (int i = 0; i < 16; ++i) O[ft][i] = X[ft][i] - O[ft][i];
   STAMP(5);
   // ---- z^T = Wo t^T (16 k-steps over c)
-  step_sync(6);
+  step_sync(DPW);
   store_rows<8>(P.t, row0, E, O, stg, lane);   // (behind the barrier, ahead of this step's DMA: see Ring)
   floatx16 Z[8];
   bias_tiles<8>(Z, P.bo, h);
-  make_b(O[0], 0, b[0]);
+  make_bn<NPL>(O[0], 0, b[0]);
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     const int c = 20 + ks;
     if (ks >= 4 && ks < 8) STAMP(8 + 2 * (ks - 4));
-    if (ks > 0) step_sync(c + 1 < NS ? 6 : 0);
+    if (ks > 0) step_sync(c + 1 < NS ? DPW : 0);
     if (ks >= 4 && ks < 8) STAMP(9 + 2 * (ks - 4));
-    BNext bn;
+    BNextN<NPL> bn;
     auto fill = [&](int t) {
       if (t < 3) {
         issue1(c + 2, 2 * t);
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(NT, 1) void attn_fwd_kernel(FwdArgs a) {
         bn.pair(O[(ks + 1) >> 1], (ks + 1) & 1, t - 3);
       }
     };
-    kstep_rp<8>(Z, ring.lane_addr(c % 3), b[ks & 1], fill);
+    kstep_rp_n<8, NPL>(Z, ring.lane_addr(c % 3), b[ks & 1], fill);
     if (ks < 15) bn.get(b[(ks + 1) & 1]);
   }
   STAMP(6);
@@ -534,7 +540,9 @@ struct BwdQArgs {
   int nb;
 };
 
+template <int NPL>
 __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
+  constexpr int DPW = NPL == 3 ? 6 : 2;   // DMA pieces per wavefront and slab (NPL = 1: plane 0 only)
   __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SLAB + 4 * STG_BYTES];   // ring | staging per wavefront
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lb = logical_block(blockIdx.x, gridDim.x);
@@ -556,9 +564,9 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
     const int lane0 = tid & 63;
     const Ring ring0{lds, wave, lane0, SLAB};
 #pragma unroll
-    for (int i = 0; i < 6; ++i) ring0.issue1(wot, 0, i);
+    for (int i = 0; i < 6; ++i) ring0.issue1<NPL>(wot, 0, i);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) ring0.issue1(wot + SLAB, 1, i);
+    for (int i = 0; i < 6; ++i) ring0.issue1<NPL>(wot + SLAB, 1, i);
     load_rows<8>(P.dr, row0, P.ld_dr, S, stg, lane0);
     if (P.dr2) load_rows<8, true>(P.dr2, row0, P.ld_dr2, S, stg, lane0);
     const long row = row0 + (lane0 & 31);
@@ -574,13 +582,13 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
   // slab sequence: Wo^T 0..15 | V 0..15 | K 0..3 | K^T (T use of the k image, 4 k-steps of 16 keys each) 0..3
   auto issue1 = [&](int c, int i) {
     if (c < 16)
-      ring.issue1(wot + c * SLAB, c % 3, i);
+      ring.issue1<NPL>(wot + c * SLAB, c % 3, i);
     else if (c < 32)
-      ring.issue1(vrp + (c - 16) * SLAB, c % 3, i);
+      ring.issue1<NPL>(vrp + (c - 16) * SLAB, c % 3, i);
     else if (c < 36)
-      ring.issue1(krp + (c - 32) * SLAB, c % 3, i);
+      ring.issue1<NPL>(krp + (c - 32) * SLAB, c % 3, i);
     else if (c < NS)   // (the lane's source offset is derived on the spot: 4 of 40 slabs, and one register less across the loops)
-      ring.issue1_t<64>(krp, tr_src_lane_off(fresh_lane()), 4 * (c - 36), c % 3, i);
+      ring.issue1_t<64, NPL>(krp, tr_src_lane_off(fresh_lane()), 4 * (c - 36), c % 3, i);
   };
   auto fill_dma = [&](int c, int t) {
     if (t < 3) {
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
   bf16x8 b[2][3];
   Stash stash;
   {
-    BNext b0;
+    BNextN<NPL> b0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) b0.pair_gated(S[0], 0, j, gate.w[0], 0);
     b0.get(b[0]);
@@ -603,8 +611,8 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     const int c = ks;
-    step_sync(ks == 0 ? 0 : 6);   // (first step: the stores of dz stand between the two slabs and this wait)
-    BNext bn;
+    step_sync(ks == 0 ? 0 : DPW);   // (first step: the stores of dz stand between the two slabs and this wait)
+    BNextN<NPL> bn;
     auto fill = [&](int t) {
       fill_dma(c, t);
       if (t >= 3 && t < 7 && ks < 15) {
@@ -612,34 +620,34 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
         bn.pair_gated(S[ft], kn & 1, t - 3, gate.w[ft >> 1], (ft & 1) * 16);
       }
     };
-    kstep_rp_d<8>(DT, ring.lane_addr(c % 3), b[ks & 1], b[(ks + 1) & 1], stash, ks == 0, ks == 15, fill);
+    kstep_rp_d<8, NPL>(DT, ring.lane_addr(c % 3), b[ks & 1], b[(ks + 1) & 1], stash, ks == 0, ks == 15, fill);
     if (ks < 15) bn.get(b[(ks + 1) & 1]);
   }
   // ---- DP^T = V dt^T = -dP^T (16 k-steps over c); the da image and u go to memory at the head of its first step
   STAMPK(2, 3);
-  step_sync(6);
+  step_sync(DPW);
   STAMPK(2, 4);
 #pragma unroll
   for (int ft = 0; ft < 8; ++ft) S[ft] += DT[ft];       // u = dr + dt
   store_tiles<8>(P.u, (long)cloud * 8 + rt, lane, S);
   __builtin_amdgcn_sched_barrier(0);   // (one accumulator set leaves before the next piece of work needs registers)
   STAMPK(2, 5);
-  store_rp<8, true>(P.darp + (size_t)cloud * V_IMG, rt, lane, DT);
+  store_rp<8, NPL, true>(P.darp + (size_t)cloud * V_IMG, rt, lane, DT);
   __builtin_amdgcn_sched_barrier(0);
   STAMPK(2, 6);
   floatx16 DP[8];
   ZERO_TILES(DP, 8);
-  make_b(DT[0], 0, b[0]);
+  make_bn<NPL>(DT[0], 0, b[0]);
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     const int c = 16 + ks;
-    if (ks > 0) step_sync(6);
-    BNext bn;
+    if (ks > 0) step_sync(DPW);
+    BNextN<NPL> bn;
     auto fill = [&](int t) {
       fill_dma(c, t);
       if (t >= 3 && t < 7 && ks < 15) bn.pair(DT[(ks + 1) >> 1], (ks + 1) & 1, t - 3);
     };
-    kstep_rp_d<8>(DP, ring.lane_addr(c % 3), b[ks & 1], b[(ks + 1) & 1], stash, ks == 0, ks == 15, fill);
+    kstep_rp_d<8, NPL>(DP, ring.lane_addr(c % 3), b[ks & 1], b[(ks + 1) & 1], stash, ks == 0, ks == 15, fill);
     if (ks < 15) bn.get(b[(ks + 1) & 1]);
   }
   // ---- S^T = K q^T, P^T (u is in memory: its registers hold the scores now)
@@ -654,11 +662,11 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
   for (int ks = 0; ks < 4; ++ks) {
     const int c = 32 + ks;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NPL; ++p)
       qf[ks & 1][p] = *reinterpret_cast<const bf16x8*>(P.qrp + (size_t)cloud * QK_IMG + (((ks * 3 + p) * 8 + rt) * 64 + fresh_lane()) * 16);
-    step_sync(9);    // (the three fragment loads above are younger than the slab waited for)
+    step_sync(DPW + NPL);    // (the three fragment loads above are younger than the slab waited for)
     auto fill = [&](int t) { fill_dma(c, t); };
-    kstep_rp_d<8>(S2, ring.lane_addr(c % 3), qf[ks & 1], qf[(ks + 1) & 1], stash, ks == 0, ks == 3, fill);
+    kstep_rp_d<8, NPL>(S2, ring.lane_addr(c % 3), qf[ks & 1], qf[(ks + 1) & 1], stash, ks == 0, ks == 3, fill);
   }
   STAMPK(2, 10);
   softmax_regs(S2);
@@ -681,25 +689,25 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_q_kernel(BwdQArgs a) {
   STAMPK(2, 11);
   floatx16 DQ[2];
   ZERO_TILES(DQ, 2);
-  make_b(S2[0], 0, b[0]);
+  make_bn<NPL>(S2[0], 0, b[0]);
 #pragma unroll
   for (int sl = 0; sl < 4; ++sl) {
     const int c = 36 + sl;
-    step_sync(sl == 0 ? 7 : sl == 3 ? 0 : 6);   // (sl == 0: the store of delta is younger than the slab as well)
+    step_sync(sl == 0 ? DPW + 1 : sl == 3 ? 0 : DPW);   // (sl == 0: the store of delta is younger than the slab as well)
 #pragma unroll
     for (int i = 0; i < 6; ++i) issue1(c + 2, i);
     const uint32_t ta = tr_lane_addr(ring.slot_addr(c % 3), fresh_lane());
     static_for<0, 4>([&](auto iq) {
       constexpr int q4 = decltype(iq)::value;
       const int ks = 4 * sl + q4;
-      BNext bn;
+      BNextN<NPL> bn;
       auto fill = [&](int t) {
         if (ks < 15) {
           bn.pair(S2[(ks + 1) >> 1], (ks + 1) & 1, 2 * t);
           bn.pair(S2[(ks + 1) >> 1], (ks + 1) & 1, 2 * t + 1);
         }
       };
-      kstep_tr<2, 64, q4 * 6144>(DQ, ta, b[ks & 1], fill);
+      kstep_tr<2, 64, q4 * 6144, NPL>(DQ, ta, b[ks & 1], fill);
       if (ks < 15) bn.get(b[(ks + 1) & 1]);
     });
   }
@@ -733,7 +741,9 @@ struct BwdKArgs {
   int nb;
 };
 
+template <int NPL>
 __global__ __launch_bounds__(NT, 1) void attn_bwd_k_kernel(BwdKArgs a) {
+  constexpr int DPW = NPL == 3 ? 6 : 2;   // DMA pieces per wavefront and slab (NPL = 1: plane 0 only)
   __shared__ __attribute__((aligned(16))) unsigned char lds[3 * SLAB + 2048 + 4 * STG_BYTES];   // ring | lse[256] | delta[256] | staging
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
   const int lb = logical_block(blockIdx.x, gridDim.x);
@@ -757,15 +767,15 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_k_kernel(BwdKArgs a) {
   constexpr int NS = 64;
   auto issue1 = [&](int c, int i) {
     if (c < 4)
-      ring.issue1(qrp + c * SLAB, c % 3, i);
+      ring.issue1<NPL>(qrp + c * SLAB, c % 3, i);
     else if (c < 20)
-      ring.issue1(darp + (c - 4) * SLAB, c % 3, i);
+      ring.issue1<NPL>(darp + (c - 4) * SLAB, c % 3, i);
     else if (c < 24)
-      ring.issue1_t<64>(qrp, tsrc, 4 * (c - 20), c % 3, i);
+      ring.issue1_t<64, NPL>(qrp, tsrc, 4 * (c - 20), c % 3, i);
     else if (c < 40)
-      ring.issue1_t<256>(darp, tsrc, c - 24, c % 3, i);
+      ring.issue1_t<256, NPL>(darp, tsrc, c - 24, c % 3, i);
     else if (c < NS)
-      ring.issue1(wqkvt + (c - 40) * SLAB, c % 3, i);
+      ring.issue1<NPL>(wqkvt + (c - 40) * SLAB, c % 3, i);
   };
   auto fill_dma = [&](int c, int t) {
     if (t < 3) {
@@ -776,7 +786,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_k_kernel(BwdKArgs a) {
   // the wavefront's own rows of an Rp image as the B operand of k-step ks: three chunks straight from global
   auto own_frag = [&](const unsigned char* img, int ks, bf16x8 (&f)[3]) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const bf16x8*>(img + (((ks * 3 + p) * 8 + rt) * 64 + lane) * 16);
+    for (int p = 0; p < NPL; ++p) f[p] = *reinterpret_cast<const bf16x8*>(img + (((ks * 3 + p) * 8 + rt) * 64 + lane) * 16);
   };
 #pragma unroll
   for (int i = 0; i < 6; ++i) issue1(0, i);
@@ -795,13 +805,13 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_k_kernel(BwdKArgs a) {
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     const int c = ks;
-    if (ks > 0) step_sync(9);   // (the fragment loads of the next step are younger than the slab waited for)
+    if (ks > 0) step_sync(DPW + NPL);   // (the fragment loads of the next step are younger than the slab waited for)
     if (ks < 3)
       own_frag(krp, ks + 1, of[(ks + 1) % 3]);
     else
       own_frag(vrp, 0, of[(ks + 1) % 3]);
     auto fill = [&](int t) { fill_dma(c, t); };
-    kstep_rp_d<8>(S, ring.lane_addr(c % 3), of[ks % 3], of[(ks + 2) % 3], stash, ks == 0, ks == 3, fill);
+    kstep_rp_d<8, NPL>(S, ring.lane_addr(c % 3), of[ks % 3], of[(ks + 2) % 3], stash, ks == 0, ks == 3, fill);
   }
   STAMPK(3, 2);
   // P = exp(S / 8 - lse_q): the query is the register's row
@@ -825,10 +835,10 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_k_kernel(BwdKArgs a) {
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     const int c = 4 + ks;
-    step_sync(9);
+    step_sync(DPW + NPL);
     if (ks < 15) own_frag(vrp, ks + 1, of[(c + 1) % 3]);
     auto fill = [&](int t) { fill_dma(c, t); };
-    kstep_rp_d<8>(DP, ring.lane_addr(c % 3), of[c % 3], of[(c + 2) % 3], stash, ks == 0, ks == 15, fill);
+    kstep_rp_d<8, NPL>(DP, ring.lane_addr(c % 3), of[c % 3], of[(c + 2) % 3], stash, ks == 0, ks == 15, fill);
   }
   STAMPK(3, 4);
   // dS = P (dP - delta_q) / 8
@@ -846,25 +856,25 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_k_kernel(BwdKArgs a) {
   floatx16 DKt[2];
   ZERO_TILES(DKt, 2);
   bf16x8 b[2][3];
-  make_b(DP[0], 0, b[0]);
+  make_bn<NPL>(DP[0], 0, b[0]);
 #pragma unroll
   for (int sl = 0; sl < 4; ++sl) {
     const int c = 20 + sl;
-    step_sync(6);
+    step_sync(DPW);
 #pragma unroll
     for (int i = 0; i < 6; ++i) issue1(c + 2, i);
     const uint32_t ta = tr_lane_addr(ring.slot_addr(c % 3), lane);
     static_for<0, 4>([&](auto iq) {
       constexpr int q4 = decltype(iq)::value;
       const int ks = 4 * sl + q4;
-      BNext bn;
+      BNextN<NPL> bn;
       auto fill = [&](int t) {
         if (ks < 15) {
           bn.pair(DP[(ks + 1) >> 1], (ks + 1) & 1, 2 * t);
           bn.pair(DP[(ks + 1) >> 1], (ks + 1) & 1, 2 * t + 1);
         }
       };
-      kstep_tr<2, 64, q4 * 6144>(DKt, ta, b[ks & 1], fill);
+      kstep_tr<2, 64, q4 * 6144, NPL>(DKt, ta, b[ks & 1], fill);
       if (ks < 15) bn.get(b[(ks + 1) & 1]);
     });
   }
@@ -873,17 +883,17 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_k_kernel(BwdKArgs a) {
   __builtin_amdgcn_sched_barrier(0);
   floatx16(&DV)[8] = DP;
   ZERO_TILES(DV, 8);
-  make_b(S[0], 0, b[0]);
+  make_bn<NPL>(S[0], 0, b[0]);
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     const int c = 24 + ks;
-    step_sync(6);
-    BNext bn;
+    step_sync(DPW);
+    BNextN<NPL> bn;
     auto fill = [&](int t) {
       fill_dma(c, t);
       if (t >= 3 && t < 7 && ks < 15) bn.pair(S[(ks + 1) >> 1], (ks + 1) & 1, t - 3);
     };
-    kstep_tr<8, 256, 0>(DV, tr_lane_addr(ring.slot_addr(c % 3), lane), b[ks & 1], fill);
+    kstep_tr<8, 256, 0, NPL>(DV, tr_lane_addr(ring.slot_addr(c % 3), lane), b[ks & 1], fill);
     if (ks < 15) bn.get(b[(ks + 1) & 1]);
   }
   // ---- dx^T = u^T + Wq^T dq^T + Wk^T dk^T + Wv^T dv^T (4 + 4 + 16 k-steps); P is dead: its registers take u
@@ -891,19 +901,19 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_k_kernel(BwdKArgs a) {
   __builtin_amdgcn_sched_barrier(0);
   floatx16(&DX)[8] = S;
   floatx16 DQ[2];
-  step_sync(6);
+  step_sync(DPW);
   load_tiles<2>(P.dq, (long)cloud * 8 + rt, lane, DQ);    // (in flight while dk and dv leave through the staging buffer)
   load_tiles<8>(P.u, (long)cloud * 8 + rt, lane, DX);
   store_rows<2>(P.dk, row0, DK, DKt, stg, lane);
   store_rows<8>(P.dv, row0, E, DV, stg, lane);
   bf16x8 bt[2][3];
-  make_b(DQ[0], 0, bt[0]);
+  make_bn<NPL>(DQ[0], 0, bt[0]);
   STAMPK(3, 7);
 #pragma unroll
   for (int ks = 0; ks < 24; ++ks) {
     const int c = 40 + ks;
-    if (ks > 0) step_sync(ks < 23 ? 6 : 0);
-    BNext bn;
+    if (ks > 0) step_sync(ks < 23 ? DPW : 0);
+    BNextN<NPL> bn;
     auto fill = [&](int t) {
       if (c + 2 < NS) fill_dma(c, t);
       if (t >= 3 && t < 7 && ks < 23) {
@@ -916,7 +926,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_k_kernel(BwdKArgs a) {
           bn.pair(DV[(kn - 8) >> 1], kn & 1, t - 3);
       }
     };
-    kstep_rp<8>(DX, ring.lane_addr(c % 3), bt[ks & 1], fill);
+    kstep_rp_n<8, NPL>(DX, ring.lane_addr(c % 3), bt[ks & 1], fill);
     if (ks < 23) bn.get(bt[(ks + 1) & 1]);
   }
   STAMPK(3, 8);
@@ -993,7 +1003,10 @@ PZN_EXPORT int pzn_attn_fused_proj(int nprob, const float* const* x, const void*
                       static_cast<unsigned char*>(qrp[i]), static_cast<unsigned char*>(krp[i]),
                       static_cast<unsigned char*>(vrp[i])};
   }
-  hipLaunchKernelGGL(attn_proj_kernel, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
+  if (pzn_attn_precision_mode() == 1)
+    hipLaunchKernelGGL(attn_proj_kernel<1>, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
+  else
+    hipLaunchKernelGGL(attn_proj_kernel<3>, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
@@ -1016,7 +1029,10 @@ PZN_EXPORT int pzn_attn_fused_fwd(int nprob, const float* const* x, const void* 
                      static_cast<const unsigned char*>(vrp[i]), static_cast<const unsigned char*>(w[i]), bo[i], r[i], t[i],
                      static_cast<uint32_t*>(mask[i]), map[i], lse[i]};
   }
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
+  if (pzn_attn_precision_mode() == 1)
+    hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<3>, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
@@ -1041,7 +1057,10 @@ PZN_EXPORT int pzn_attn_fused_bwd_q(int nprob, const float* const* dr, int ld_dr
                       static_cast<const unsigned char*>(vrp[i]), static_cast<const unsigned char*>(w[i]), dz[i], u[i], dq[i],
                       dqt[i], static_cast<unsigned char*>(darp[i]), delta[i]};
   }
-  hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
+  if (pzn_attn_precision_mode() == 1)
+    hipLaunchKernelGGL(attn_bwd_q_kernel<1>, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
+  else
+    hipLaunchKernelGGL(attn_bwd_q_kernel<3>, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
@@ -1062,6 +1081,9 @@ PZN_EXPORT int pzn_attn_fused_bwd_k(int nprob, const void* const* qrp, const voi
                       static_cast<const unsigned char*>(vrp[i]), static_cast<const unsigned char*>(darp[i]),
                       static_cast<const unsigned char*>(w[i]), lse[i], delta[i], u[i], dq[i], dk[i], dv[i], dx[i]};
   }
-  hipLaunchKernelGGL(attn_bwd_k_kernel, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
+  if (pzn_attn_precision_mode() == 1)
+    hipLaunchKernelGGL(attn_bwd_k_kernel<1>, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
+  else
+    hipLaunchKernelGGL(attn_bwd_k_kernel<3>, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
   PZN_RETURN_LAUNCH_STATUS();
 }

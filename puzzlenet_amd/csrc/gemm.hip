@@ -937,6 +937,7 @@ PZN_EXPORT int pzn_attn_set_precision(int mode) {
   return PZN_OK;
 }
 PZN_EXPORT int pzn_attn_get_precision(void) { return attn_precision(); }
+int pzn_attn_precision_mode() { return attn_precision(); }
 
 PZN_EXPORT int pzn_bgemm_f32(int mode, const float* A, const float* B, float* C, int batch, int M, int N, int K,
                              float alpha, pzn_stream_t stream) {

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// gemm.hip: 0 = attention products on the split-precision path (fp32 results), 1 = single bf16 MFMAs (pzn_attn_set_precision)
+int pzn_attn_precision_mode();
+
 // poolbwd.hip: sparse backward of linear + ReLU + max over 32 neighbours.
 //   dh != NULL: dh[G*32, C1] = scatter(dout) W, ReLU-masked by h when h != NULL (overwritten)
 //   dW != NULL: dW[C2, C1] += scatter(dout)^T h,  db[C2] += column sums (db may be NULL)

@@ -50,10 +50,6 @@ struct BNext {
   uint32_t w[3][4];
   template <bool NEG = false>
   __device__ __forceinline__ void pair(const floatx16& x, int s, int j) {
-#ifdef PZN_EXP_NOSPLIT   // timing experiment only: what the split of the next B fragment costs the step
-    w[0][j] = w[1][j] = w[2][j] = __float_as_uint(x[8 * s + 2 * j]);
-    return;
-#endif
     const float x0 = x[8 * s + 2 * j], x1 = x[8 * s + 2 * j + 1];
     split_pair(NEG ? -x0 : x0, NEG ? -x1 : x1, w[0][j], w[1][j], w[2][j]);
   }
@@ -99,16 +95,11 @@ struct NoFill {
 // lgkmcnt(0) three times per tile (measured: 2.6k cycles per 48-MFMA step against 1.5k of matrix-pipe time).
 // An asm read is invisible to the compiler's wait bookkeeping: RP_WAIT / TR_WAIT (s_waitcnt lgkmcnt(0) naming every
 // destination register read-write) must precede the first use (cdna_hip_programming.md, 5.7 form (ii)).
-#ifdef PZN_EXP_NOLDS   // timing experiment only (results are wrong): the step without its LDS fragment reads
-#define RP_ISSUE(ADDR, O0, O1, O2, A0, A1, A2) asm volatile("" : "=v"(A0), "=v"(A1), "=v"(A2) : "v"(ADDR))
-#define RP_WAITN(N_, A0, A1, A2) asm volatile("" : "+v"(A0), "+v"(A1), "+v"(A2))
-#else
 #define RP_ISSUE(ADDR, O0, O1, O2, A0, A1, A2)                                                       \
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A0) : "v"(ADDR), "n"(O0));                      \
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A1) : "v"(ADDR), "n"(O1));                      \
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A2) : "v"(ADDR), "n"(O2))
 #define RP_WAITN(N_, A0, A1, A2) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(A0), "+v"(A1), "+v"(A2))
-#endif
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -168,42 +159,133 @@ __device__ __forceinline__ void kstep_rp(floatx16 (&acc)[RT], uint32_t lane_addr
   });
 }
 
+// =====================================================================================================================
+// The attention kernels' forms of the above, with the number of planes as a template parameter:
+//   NPL = 3: split precision (x = x1 + x2 + x3, six MFMAs per product, fp32-GEMM accuracy) - the default path;
+//   NPL = 1: every operand rounded to ONE bf16 plane, one MFMA per product, fp32 accumulation (the opt-in bf16 attention
+//            mode, pzn_attn_set_precision(1) / BASELINE configs[4]).  Images and slabs keep their layout; only plane 0 is
+//            written, fetched and read.
+template <int NPL>
+__device__ __forceinline__ floatx16 mma_n(bf16x8 a0, bf16x8 a1, bf16x8 a2, const bf16x8 (&b)[3], floatx16 c) {
+  if constexpr (NPL == 3) {
+    return mma6v(a0, a1, a2, b, c);
+  } else {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[0], c, 0, 0, 0);
+  }
+}
+
+// B fragment of the next k-step, a pair of values at a time (see BNext)
+template <int NPL>
+struct BNextN {
+  uint32_t w[3][4];
+  __device__ __forceinline__ void put(float x0, float x1, int j) {
+    if constexpr (NPL == 3) {
+      split_pair(x0, x1, w[0][j], w[1][j], w[2][j]);
+    } else {
+      const floatx2 x = {x0, x1};
+      w[0][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
+    }
+  }
+  template <bool NEG = false>
+  __device__ __forceinline__ void pair(const floatx16& x, int s, int j) {
+    const float x0 = x[8 * s + 2 * j], x1 = x[8 * s + 2 * j + 1];
+    put(NEG ? -x0 : x0, NEG ? -x1 : x1, j);
+  }
+  // the same with the values gated by bits (bit0 + 8 s + 2 j) and the next one of `word` (a ReLU mask)
+  __device__ __forceinline__ void pair_gated(const floatx16& x, int s, int j, uint32_t word, int bit0) {
+    const int i = 8 * s + 2 * j;
+    put((word >> (bit0 + i)) & 1u ? x[i] : 0.f, (word >> (bit0 + i + 1)) & 1u ? x[i + 1] : 0.f, j);
+  }
+  __device__ __forceinline__ void get(bf16x8 (&b)[3]) const {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) b[p] = __builtin_bit_cast(bf16x8, make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]));
+  }
+};
+template <int NPL, bool NEG = false>
+__device__ __forceinline__ void make_bn(const floatx16& x, int s, bf16x8 (&b)[3]) {
+  BNextN<NPL> t;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) t.template pair<NEG>(x, s, j);
+  t.get(b);
+}
+
+// asm fragment reads (see RP_ISSUE): NPL reads per tile, counted waits in units of reads
+template <int NPL, int O0, int O1, int O2>
+__device__ __forceinline__ void rp_issue(uint32_t addr, bf16x8 (&a)[3]) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[0]) : "v"(addr), "n"(O0));
+  if constexpr (NPL == 3) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[1]) : "v"(addr), "n"(O1));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[2]) : "v"(addr), "n"(O2));
+  }
+}
+template <int NPL, int N>
+__device__ __forceinline__ void rp_wait(bf16x8 (&a)[3]) {
+  if constexpr (NPL == 3)
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "n"(N));
+  else
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[0]) : "n"(N));
+}
+
+// kstep_rp (two tiles ahead) with NPL planes
+template <int RT, int NPL, class Fill = NoFill>
+__device__ __forceinline__ void kstep_rp_n(floatx16 (&acc)[RT], uint32_t lane_addr, const bf16x8 (&b)[3], const Fill& fill = Fill()) {
+  static_assert(RT >= 4, "pipeline depth");
+  bf16x8 f[3][3];
+  rp_issue<NPL, 0, RT * 1024, 2 * RT * 1024>(lane_addr, f[0]);
+  rp_issue<NPL, 1024, (RT + 1) * 1024, (2 * RT + 1) * 1024>(lane_addr, f[1]);
+  static_for<0, RT>([&](auto ic) {
+    constexpr int rt = decltype(ic)::value;
+    constexpr int cur = rt % 3, nxt = (rt + 2) % 3;
+    if constexpr (rt + 2 < RT) {
+      rp_issue<NPL, (rt + 2) * 1024, (RT + rt + 2) * 1024, (2 * RT + rt + 2) * 1024>(lane_addr, f[nxt]);
+      rp_wait<NPL, 2 * NPL>(f[cur]);
+    } else if constexpr (rt + 1 < RT) {
+      rp_wait<NPL, NPL>(f[cur]);
+    } else {
+      rp_wait<NPL, 0>(f[cur]);
+    }
+    acc[rt] = mma_n<NPL>(f[cur][0], f[cur][1], f[cur][2], b, acc[rt]);
+    fill(rt);
+  });
+}
+
 // ---- the same step with its LAST tile deferred across the next barrier ---------------------------------------------
-// Behind a step's barrier the first fragment reads of the new slab have nobody to hide behind (one wavefront per SIMD:
-// measured ~260 cycles per 48-MFMA step).  The deferred forms keep the last tile's fragments in registers (Stash) when a
-// step ends and issue its six MFMAs at the head of the NEXT step, right behind that step's first reads: bprev is the B
-// operand of the step the stash belongs to (still intact: the B fragments are double-buffered), first / last fold to
-// constants in the unrolled loops (first: nothing stashed yet; last: the tile is multiplied at once).  Every
-// accumulator still receives its products in the same order: results are bit-identical to the plain forms.
+// Behind a step's barrier the first fragment reads of the new slab have nobody to hide behind (one wavefront per SIMD).
+// The deferred forms keep the last tile's fragments in registers (Stash) when a step ends and issue its MFMAs at the
+// head of the NEXT step, right behind that step's first reads: bprev is the B operand of the step the stash belongs to
+// (still intact: the B fragments are double-buffered), first / last fold to constants in the unrolled loops (first:
+// nothing stashed yet; last: the tile is multiplied at once).  Every accumulator still receives its products in the same
+// order: results are bit-identical to the plain forms.
 struct Stash {
   bf16x8 a[3];
 };
 
-template <int RT, class Fill = NoFill>
+template <int RT, int NPL, class Fill = NoFill>
 __device__ __forceinline__ void kstep_rp_d(floatx16 (&acc)[RT], uint32_t lane_addr, const bf16x8 (&b)[3], const bf16x8 (&bprev)[3],
                                            Stash& st, bool first, bool last, const Fill& fill = Fill()) {
   static_assert(RT >= 4, "pipeline depth");
   bf16x8 f[3][3];
-  RP_ISSUE(lane_addr, 0, RT * 1024, 2 * RT * 1024, f[0][0], f[0][1], f[0][2]);
-  RP_ISSUE(lane_addr, 1024, (RT + 1) * 1024, (2 * RT + 1) * 1024, f[1][0], f[1][1], f[1][2]);
+  rp_issue<NPL, 0, RT * 1024, 2 * RT * 1024>(lane_addr, f[0]);
+  rp_issue<NPL, 1024, (RT + 1) * 1024, (2 * RT + 1) * 1024>(lane_addr, f[1]);
   __builtin_amdgcn_sched_barrier(0);
-  if (!first) acc[RT - 1] = mma6v(st.a[0], st.a[1], st.a[2], bprev, acc[RT - 1]);
+  if (!first) acc[RT - 1] = mma_n<NPL>(st.a[0], st.a[1], st.a[2], bprev, acc[RT - 1]);
   static_for<0, RT - 1>([&](auto ic) {
     constexpr int rt = decltype(ic)::value;
     constexpr int cur = rt % 3, nxt = (rt + 2) % 3;
     if constexpr (rt + 2 < RT) {
-      RP_ISSUE(lane_addr, (rt + 2) * 1024, (RT + rt + 2) * 1024, (2 * RT + rt + 2) * 1024, f[nxt][0], f[nxt][1], f[nxt][2]);
-      RP_WAITN(6, f[cur][0], f[cur][1], f[cur][2]);
+      rp_issue<NPL, (rt + 2) * 1024, (RT + rt + 2) * 1024, (2 * RT + rt + 2) * 1024>(lane_addr, f[nxt]);
+      rp_wait<NPL, 2 * NPL>(f[cur]);
     } else {
-      RP_WAITN(3, f[cur][0], f[cur][1], f[cur][2]);
+      rp_wait<NPL, NPL>(f[cur]);
     }
-    acc[rt] = mma6v(f[cur][0], f[cur][1], f[cur][2], b, acc[rt]);
+    acc[rt] = mma_n<NPL>(f[cur][0], f[cur][1], f[cur][2], b, acc[rt]);
     fill(rt);
   });
   constexpr int lst = (RT - 1) % 3;
-  RP_WAITN(0, f[lst][0], f[lst][1], f[lst][2]);
-  st.a[0] = f[lst][0], st.a[1] = f[lst][1], st.a[2] = f[lst][2];
-  if (last) acc[RT - 1] = mma6v(st.a[0], st.a[1], st.a[2], b, acc[RT - 1]);
+  rp_wait<NPL, 0>(f[lst]);
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) st.a[p] = f[lst][p];
+  if (last) acc[RT - 1] = mma_n<NPL>(st.a[0], st.a[1], st.a[2], b, acc[RT - 1]);
 }
 
 // ---- transposed reads of an Rp image ("T use") --------------------------------------------------------------------
@@ -236,82 +318,88 @@ __device__ __forceinline__ uint32_t tr_src_lane_off(int lane) {
   return (uint32_t)(blk * (3 * 8 * 1024) + (hs * 32 + r16) * 16);
 }
 
-#ifdef PZN_EXP_NOLDS
-#define TR_ISSUE(ADDR, OFF, PLS_, L0, H0, L1, H1, L2, H2) \
-  asm volatile("" : "=v"(L0), "=v"(H0), "=v"(L1), "=v"(H1), "=v"(L2), "=v"(H2) : "v"(ADDR))
-#define TR_WAITN(N_, L0, H0, L1, H1, L2, H2) asm volatile("" : "+v"(L0), "+v"(H0), "+v"(L1), "+v"(H1), "+v"(L2), "+v"(H2))
-#else
-#define TR_ISSUE(ADDR, OFF, PLS_, L0, H0, L1, H1, L2, H2)                                                           \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(L0) : "v"(ADDR), "n"(OFF));                            \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H0) : "v"(ADDR), "n"((OFF) + 256));                    \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(L1) : "v"(ADDR), "n"((OFF) + (PLS_)));                 \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H1) : "v"(ADDR), "n"((OFF) + (PLS_) + 256));           \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(L2) : "v"(ADDR), "n"((OFF) + 2 * (PLS_)));             \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(H2) : "v"(ADDR), "n"((OFF) + 2 * (PLS_) + 256))
-#define TR_WAITN(N_, L0, H0, L1, H1, L2, H2)                                                                        \
-  asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(L0), "+v"(H0), "+v"(L1), "+v"(H1), "+v"(L2), "+v"(H2))
-#endif
+// the fragment of one tile: lo / hi halves of NPL planes (2 NPL reads), counted waits in units of reads
+struct TrFrag {
+  bf16x4 lo[3], hi[3];
+};
+template <int NPL, int OFF, int PLS>
+__device__ __forceinline__ void tr_issue(uint32_t addr, TrFrag& t) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.lo[0]) : "v"(addr), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.hi[0]) : "v"(addr), "n"(OFF + 256));
+  if constexpr (NPL == 3) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.lo[1]) : "v"(addr), "n"(OFF + PLS));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.hi[1]) : "v"(addr), "n"(OFF + PLS + 256));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.lo[2]) : "v"(addr), "n"(OFF + 2 * PLS));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.hi[2]) : "v"(addr), "n"(OFF + 2 * PLS + 256));
+  }
+}
+template <int NPL, int N>
+__device__ __forceinline__ void tr_wait(TrFrag& t) {
+  if constexpr (NPL == 3)
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(t.lo[0]), "+v"(t.hi[0]), "+v"(t.lo[1]), "+v"(t.hi[1]), "+v"(t.lo[2]), "+v"(t.hi[2]) : "n"(N));
+  else
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(t.lo[0]), "+v"(t.hi[0]) : "n"(N));
+}
+template <int NPL>
+__device__ __forceinline__ void tr_join(const TrFrag& t, bf16x8 (&a)[3]) {
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) a[p] = __builtin_shufflevector(t.lo[p], t.hi[p], 0, 1, 2, 3, 4, 5, 6, 7);
+}
 
 // one k-step of acc[ft] += A_ft B with A read transposed from a T-use slab: rows of A = feature 32 ft + lane % 32.
-// ta = tr_lane_addr of the slab, KOFF = byte offset of the k-step inside it (compile time).  Two tiles ahead, counted
-// waits (6 reads per tile).
-template <int FT, int F, int KOFF, class Fill = NoFill>
+// ta = tr_lane_addr of the slab, KOFF = byte offset of the k-step inside it (compile time).  Two tiles ahead, counted waits.
+template <int FT, int F, int KOFF, int NPL, class Fill = NoFill>
 __device__ __forceinline__ void kstep_tr(floatx16 (&acc)[FT], uint32_t ta, const bf16x8 (&b)[3], const Fill& fill = Fill()) {
   constexpr int PLS = 32 * F;
-  bf16x4 lo[3][3], hi[3][3];
-  TR_ISSUE(ta, KOFF, PLS, lo[0][0], hi[0][0], lo[0][1], hi[0][1], lo[0][2], hi[0][2]);
-  if constexpr (FT > 1) TR_ISSUE(ta, KOFF + 1024, PLS, lo[1][0], hi[1][0], lo[1][1], hi[1][1], lo[1][2], hi[1][2]);
+  TrFrag t[3];
+  tr_issue<NPL, KOFF, PLS>(ta, t[0]);
+  if constexpr (FT > 1) tr_issue<NPL, KOFF + 1024, PLS>(ta, t[1]);
   static_for<0, FT>([&](auto ic) {
     constexpr int ft = decltype(ic)::value;
     constexpr int cur = ft % 3, nxt = (ft + 2) % 3;
     if constexpr (ft + 2 < FT) {
-      TR_ISSUE(ta, KOFF + 1024 * (ft + 2), PLS, lo[nxt][0], hi[nxt][0], lo[nxt][1], hi[nxt][1], lo[nxt][2], hi[nxt][2]);
-      TR_WAITN(12, lo[cur][0], hi[cur][0], lo[cur][1], hi[cur][1], lo[cur][2], hi[cur][2]);
+      tr_issue<NPL, KOFF + 1024 * (ft + 2), PLS>(ta, t[nxt]);
+      tr_wait<NPL, 4 * NPL>(t[cur]);
     } else if constexpr (ft + 1 < FT) {
-      TR_WAITN(6, lo[cur][0], hi[cur][0], lo[cur][1], hi[cur][1], lo[cur][2], hi[cur][2]);
+      tr_wait<NPL, 2 * NPL>(t[cur]);
     } else {
-      TR_WAITN(0, lo[cur][0], hi[cur][0], lo[cur][1], hi[cur][1], lo[cur][2], hi[cur][2]);
+      tr_wait<NPL, 0>(t[cur]);
     }
-    const bf16x8 a0 = __builtin_shufflevector(lo[cur][0], hi[cur][0], 0, 1, 2, 3, 4, 5, 6, 7);
-    const bf16x8 a1 = __builtin_shufflevector(lo[cur][1], hi[cur][1], 0, 1, 2, 3, 4, 5, 6, 7);
-    const bf16x8 a2 = __builtin_shufflevector(lo[cur][2], hi[cur][2], 0, 1, 2, 3, 4, 5, 6, 7);
-    acc[ft] = mma6v(a0, a1, a2, b, acc[ft]);
+    bf16x8 a[3];
+    tr_join<NPL>(t[cur], a);
+    acc[ft] = mma_n<NPL>(a[0], a[1], a[2], b, acc[ft]);
     fill(ft);
   });
 }
 
 // kstep_tr with its last tile deferred across the next barrier (see kstep_rp_d)
-template <int FT, int F, int KOFF, class Fill = NoFill>
+template <int FT, int F, int KOFF, int NPL, class Fill = NoFill>
 __device__ __forceinline__ void kstep_tr_d(floatx16 (&acc)[FT], uint32_t ta, const bf16x8 (&b)[3], const bf16x8 (&bprev)[3],
                                            Stash& st, bool first, bool last, const Fill& fill = Fill()) {
   static_assert(FT >= 4, "pipeline depth");
   constexpr int PLS = 32 * F;
-  bf16x4 lo[3][3], hi[3][3];
-  TR_ISSUE(ta, KOFF, PLS, lo[0][0], hi[0][0], lo[0][1], hi[0][1], lo[0][2], hi[0][2]);
-  TR_ISSUE(ta, KOFF + 1024, PLS, lo[1][0], hi[1][0], lo[1][1], hi[1][1], lo[1][2], hi[1][2]);
+  TrFrag t[3];
+  tr_issue<NPL, KOFF, PLS>(ta, t[0]);
+  tr_issue<NPL, KOFF + 1024, PLS>(ta, t[1]);
   __builtin_amdgcn_sched_barrier(0);
-  if (!first) acc[FT - 1] = mma6v(st.a[0], st.a[1], st.a[2], bprev, acc[FT - 1]);
+  if (!first) acc[FT - 1] = mma_n<NPL>(st.a[0], st.a[1], st.a[2], bprev, acc[FT - 1]);
   static_for<0, FT - 1>([&](auto ic) {
     constexpr int ft = decltype(ic)::value;
     constexpr int cur = ft % 3, nxt = (ft + 2) % 3;
     if constexpr (ft + 2 < FT) {
-      TR_ISSUE(ta, KOFF + 1024 * (ft + 2), PLS, lo[nxt][0], hi[nxt][0], lo[nxt][1], hi[nxt][1], lo[nxt][2], hi[nxt][2]);
-      TR_WAITN(12, lo[cur][0], hi[cur][0], lo[cur][1], hi[cur][1], lo[cur][2], hi[cur][2]);
+      tr_issue<NPL, KOFF + 1024 * (ft + 2), PLS>(ta, t[nxt]);
+      tr_wait<NPL, 4 * NPL>(t[cur]);
     } else {
-      TR_WAITN(6, lo[cur][0], hi[cur][0], lo[cur][1], hi[cur][1], lo[cur][2], hi[cur][2]);
+      tr_wait<NPL, 2 * NPL>(t[cur]);
     }
-    const bf16x8 a0 = __builtin_shufflevector(lo[cur][0], hi[cur][0], 0, 1, 2, 3, 4, 5, 6, 7);
-    const bf16x8 a1 = __builtin_shufflevector(lo[cur][1], hi[cur][1], 0, 1, 2, 3, 4, 5, 6, 7);
-    const bf16x8 a2 = __builtin_shufflevector(lo[cur][2], hi[cur][2], 0, 1, 2, 3, 4, 5, 6, 7);
-    acc[ft] = mma6v(a0, a1, a2, b, acc[ft]);
+    bf16x8 a[3];
+    tr_join<NPL>(t[cur], a);
+    acc[ft] = mma_n<NPL>(a[0], a[1], a[2], b, acc[ft]);
     fill(ft);
   });
-  constexpr int lst = (FT - 1) % 3;
-  TR_WAITN(0, lo[lst][0], hi[lst][0], lo[lst][1], hi[lst][1], lo[lst][2], hi[lst][2]);
-  st.a[0] = __builtin_shufflevector(lo[lst][0], hi[lst][0], 0, 1, 2, 3, 4, 5, 6, 7);
-  st.a[1] = __builtin_shufflevector(lo[lst][1], hi[lst][1], 0, 1, 2, 3, 4, 5, 6, 7);
-  st.a[2] = __builtin_shufflevector(lo[lst][2], hi[lst][2], 0, 1, 2, 3, 4, 5, 6, 7);
-  if (last) acc[FT - 1] = mma6v(st.a[0], st.a[1], st.a[2], b, acc[FT - 1]);
+  tr_wait<NPL, 0>(t[(FT - 1) % 3]);
+  tr_join<NPL>(t[(FT - 1) % 3], st.a);
+  if (last) acc[FT - 1] = mma_n<NPL>(st.a[0], st.a[1], st.a[2], b, acc[FT - 1]);
 }
 
 // ---- slab ring: global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, destination =
@@ -336,11 +424,11 @@ struct Ring {
                                        (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + piece * 1024), 16, 0, 0);
     }
   }
-  // piece i (of NPW) of this wavefront only: lets a caller spread a slab's DMA instructions over a step
+  // piece i (of NPW) of this wavefront only: lets a caller spread a slab's DMA instructions over a step.
+  // NPL = 1: only the pieces of plane 0 (the first PPP pieces of a plain slab) are fetched.
+  template <int NPL = 3, int PPP = 8>
   __device__ __forceinline__ void issue1(const unsigned char* src, int slot, int i) const {
-#ifdef PZN_EXP_NODMA   // timing experiment only (results are wrong): what the DMA instructions cost the step
-    if (slot >= 0) return;
-#endif
+    if (NPL == 1 && i >= PPP / 4) return;      // (i is a constant in the unrolled callers: no run-time test; nw = 4)
     const int piece = i * nw + wave;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane * 16),
                                      (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + piece * 1024), 16, 0, 0);
@@ -349,27 +437,26 @@ struct Ring {
   // F = 256: the slab is k-step kk0 (16 rows), 24 pieces j = (plane j >> 3, ks_f pair j & 7).
   // F = 64: the slab holds the four k-steps kk0 .. kk0 + 3, 6 pieces each: j % 6 = (plane >> 1, ks_f pair & 1).
   // tsrc = tr_src_lane_off(lane).  The LDS side is piece-linear like every other slab.
-  template <int F>
+  template <int F, int NPL = 3>
   __device__ __forceinline__ void issue1_t(const unsigned char* img, uint32_t tsrc, int kk0, int slot, int i) const {
-#ifdef PZN_EXP_NODMA
-    if (slot >= 0) return;
-#endif
-    const int j = i * nw + wave;
-    int kk, plane, ksf0;
-    if (F == 256) {
-      kk = kk0, plane = j >> 3, ksf0 = 2 * (j & 7);
+    int j = i * nw + wave, kk, plane, ksf0, dst;
+    if (NPL == 1) {      // plane 0 only: 8 pieces per slab, two per wavefront (nw = 4)
+      if (i >= 2) return;
+      plane = 0;
+      if (F == 256) {
+        kk = kk0, ksf0 = 2 * j, dst = j * 1024;
+      } else {
+        kk = kk0 + (j >> 1), ksf0 = 2 * (j & 1), dst = (j >> 1) * 6144 + (j & 1) * 1024;
+      }
+    } else if (F == 256) {
+      kk = kk0, plane = j >> 3, ksf0 = 2 * (j & 7), dst = j * 1024;
     } else {
       const int m = j % 6;
-      kk = kk0 + j / 6, plane = m >> 1, ksf0 = 2 * (m & 1);
+      kk = kk0 + j / 6, plane = m >> 1, ksf0 = 2 * (m & 1), dst = j * 1024;
     }
     const unsigned char* src = img + ((ksf0 * 3 + plane) * 8 + (kk >> 1)) * 1024 + (kk & 1) * 256 + tsrc;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + j * 1024), 16, 0, 0);
-  }
-  template <int F>
-  __device__ __forceinline__ void issue_t(const unsigned char* img, uint32_t tsrc, int kk0, int slot) const {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) issue1_t<F>(img, tsrc, kk0, slot, i);
+                                     (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + dst), 16, 0, 0);
   }
   __device__ __forceinline__ const unsigned char* slot(int s) const { return lds + s * slot_bytes; }
   __device__ __forceinline__ uint32_t lane_addr(int s) const { return slot_addr(s) + (uint32_t)lane * 16u; }
@@ -388,17 +475,18 @@ __device__ __forceinline__ void wait_vm_sync() {
 // whatever else it issued after the last piece of the slab waited for (vmcnt counts in order).  The argument folds to a
 // constant in the unrolled loops.
 __device__ __forceinline__ void step_sync(int younger) {
-#ifdef PZN_EXP_NOBARRIER   // timing experiment only: the step without its wait and barrier
-  return;
-#endif
   switch (younger) {
-    case 0: wait_vm_sync<0>(); break;
+    case 1: wait_vm_sync<1>(); break;
+    case 2: wait_vm_sync<2>(); break;
     case 3: wait_vm_sync<3>(); break;
+    case 4: wait_vm_sync<4>(); break;
+    case 5: wait_vm_sync<5>(); break;
     case 6: wait_vm_sync<6>(); break;
     case 7: wait_vm_sync<7>(); break;
+    case 8: wait_vm_sync<8>(); break;
     case 9: wait_vm_sync<9>(); break;
     case 12: wait_vm_sync<12>(); break;
-    default: wait_vm_sync<0>(); break;   // (unknown count: drain)
+    default: wait_vm_sync<0>(); break;   // (0 or an unknown count: drain)
   }
 }
 

@@ -52,6 +52,7 @@ class KernelTimer:
     records = {}
     flops = {}
     shapes = None   # set to {} before start() to also collect {(entry point, int args): [ms, ...]} (tools/)
+    variants = {}   # {(entry point, variant tag): (launches, ms, flops)} for calls that pass variant= (one kernel instantiation each)
 
     @classmethod
     def start(cls):
@@ -64,6 +65,13 @@ class KernelTimer:
         cls.enabled = False
         torch.cuda.synchronize()
         out = {k: (len(v), sum(a.elapsed_time(b) for a, b, _ in v)) for k, v in cls.records.items()}
+        cls.variants = {}
+        for k, v in cls.records.items():
+            for a, b, f in v:
+                if isinstance(f, tuple) and isinstance(f[-1], str):
+                    n_, ms_, fl_ = cls.variants.get((k, f[-1]), (0, 0.0, 0))
+                    cls.variants[(k, f[-1])] = (n_ + 1, ms_ + a.elapsed_time(b), fl_ + f[0])
+            v[:] = [(a, b, f[0] if (isinstance(f, tuple) and isinstance(f[-1], str)) else f) for a, b, f in v]
         if cls.shapes is not None:
             for k, v in cls.records.items():
                 for a, b, f in v:
@@ -76,13 +84,16 @@ class KernelTimer:
         return out
 
 
-def _call(name, *args, flops=0):
-    """Invoke a C-ABI entry point; `flops` = algorithmic 2*M*N*K of the dense entry points (bench accounting)."""
+def _call(name, *args, flops=0, variant=None):
+    """Invoke a C-ABI entry point; `flops` = algorithmic 2*M*N*K of the dense entry points (bench accounting); `variant` =
+    the template arguments of the kernel this call launches, where one entry point has several instantiations."""
     if KernelTimer.enabled:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         _lib.call(name, *args)
         b.record()
+        if variant is not None and KernelTimer.shapes is None:
+            flops = (flops, variant)
         if KernelTimer.shapes is not None:
             flops = (flops, tuple(x for x in args if isinstance(x, int) and 0 <= x < (1 << 31)))
         KernelTimer.records.setdefault(name, []).append((a, b, flops))
@@ -1105,10 +1116,10 @@ def _ptrs(ts):
 
 
 def attention_chain_fused_available():
-    """The chained kernels compute the fp32-accurate (bf16x3) path only: not with the exact-fp32 engine selected, not in
-    the opt-in bf16 attention mode."""
-    lib = _lib.load()
-    return lib.pzn_gemm_get_precision() != 0 and lib.pzn_attn_get_precision() == 0
+    """The chained kernels run on the bf16 matrix pipe: three planes per operand (fp32 results, default) or, in the opt-in
+    bf16 attention mode (pzn_attn_set_precision(1)), one plane (single bf16 MFMAs, fp32 accumulation and softmax) - not with
+    the exact-fp32 engine selected."""
+    return _lib.load().pzn_gemm_get_precision() != 0
 
 
 def attention_chain_fused_supported(x, dk, w_out):
@@ -1573,7 +1584,7 @@ class _SaLevelFused(torch.autograd.Function):
                 try:
                     _call("pzn_sa_level_prep_weights_f32", _p(w2), C1, C2, _p(ws), _stream())
                     _call("pzn_sa_level_fwd_packed_f32", _p(P), _p(Q), _p(idx), _p(b2), B, N, S, C1, C2, _p(out), _p(arg),
-                          _p(ws), _stream(), flops=2 * R * 32 * C1 * C2)
+                          _p(ws), _stream(), flops=2 * R * 32 * C1 * C2, variant=f"<{C1}, {C2 // 32}>")
                     done = True
                 except _lib.PznUnsupported:
                     pass

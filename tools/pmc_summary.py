@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 --pmc counter_collection.csv dumps into the per-kernel HBM traffic summary bench.py attaches to its
-roofline objects (profiles/r3_pmc_traffic.json).
+roofline objects (profiles/<round>_pmc_traffic.json).
 
     python tools/pmc_summary.py <fetch_dir> <write_dir> <out.json> [--batch 64 --points 2048]
 
