@@ -18,10 +18,11 @@ draw with the reference's functions (tests/golden/make_golden_data.py -> data.np
 same machinery on REGIONS of two planes (`make_pairs_regions`; `plan_double_cut_like_reference` replays the
 reference's branch decisions and draws); `building_pairs` is the item contract of `BuildingDataset` (two given pieces).
 The solid cuts (sphere, cylinder, cone: dataset.py:716-758) are `solid_cut_mask` + `make_pairs_solid`: the reference
-asks open3d for the signed distance to a tessellated mesh and keeps `distance < 0`; here the same solids are evaluated
-analytically (inside-tests of the exact sphere / cylinder / cone under the reference's rotation and translation draws).
-open3d is not in this image, so no fixture can be produced: PARITY UNPINNED for these three masks — a point closer to
-the surface than the 50-segment tessellation's sagitta (<= 0.2 % of the radius) may fall on the other side.
+asks open3d (0.15.2, README.md:25) for the signed distance to a tessellated mesh and keeps `distance < 0`.  open3d is not
+in this image, so its published mesh construction is restated (oracle/solids.py: vertex formulas of create_sphere /
+create_cylinder / create_cone at resolution 50) and `solid_cut_mask` evaluates membership of exactly those convex
+polyhedra in closed form; tests/test_datapipe_cpu.py holds it to the oracle's brute-force face-plane test point for
+point.  Parity is pinned to that restatement, not to the library itself (no fixture can be produced here).
 """
 import numpy as np
 import torch
@@ -76,27 +77,94 @@ def rotation_from_axis_angle(w):
     return eye + torch.sin(th) * K + (1 - torch.cos(th)) * (K @ K)
 
 
-def solid_cut_mask(raw, kind, rot=None, shift=None):
-    """up-mask (signed distance < 0 = INSIDE the solid) of the reference's mesh cuts, evaluated on the exact solids:
-      "sphere"   (dataset.py:716-730): radius 0.5, centre = shift (np.random.rand(3,1)/3)
-      "cylinder" (:732-747): radius 0.6, height 1 about z, rotated by the axis-angle vector rot (np.random.rand(3,1))
-                 about the origin, then translated by shift (np.random.rand(3,1)/3)
-      "cone"     (:749-763): base radius 1 at z = -1, apex at z = +1 (create_cone(1, 2) translated by (0,0,-1)), rotated
-                 by rot about the origin
-    raw [B,M,3] fp32, rot / shift [B,3] float64 (the draws) -> bool [B,M].  float64 like the plane cut."""
+_MESH_RES = 50        # resolution of the reference's three meshes (dataset.py:717, :733, :750)
+
+
+def _sphere_poly_inside(q, radius, res):
+    """Strictly inside the polyhedron of open3d's create_sphere(radius, res) centred at the origin (oracle/solids.py has
+    the vertex formulas): rings at polar angles alpha_i = i pi / res, 2 res meridians.  The polyhedron is convex and
+    contains the origin, so q is inside iff it is on the inner side of the face its ray from the origin pierces; that
+    face lies in q's own meridian sector (meridian edges project to meridians) and in its own latitude band or a
+    neighbouring one (ring chords project to great-circle arcs that bulge across the latitude circle by less than a
+    band): three plane tests.  q [...,3] float64."""
+    step = torch.pi / res
+    rho = q.norm(dim=-1).clamp_min(1e-300)
+    alpha = torch.acos((q[..., 2] / rho).clamp(-1.0, 1.0))
+    theta = torch.atan2(q[..., 1], q[..., 0])
+    theta = torch.where(theta < 0, theta + 2 * torch.pi, theta)
+    j = torch.clamp((theta / step).floor(), 0, 2 * res - 1)
+    i0 = torch.clamp((alpha / step).floor(), 0, res - 1)
+    t0, t1 = j * step, (j + 1) * step
+
+    def ring(i, t):          # vertex of ring i (0 = north pole, res = south pole) on meridian t
+        a = i * step
+        return torch.stack([radius * torch.sin(a) * torch.cos(t), radius * torch.sin(a) * torch.sin(t), radius * torch.cos(a)], -1)
+
+    inside = torch.ones(q.shape[:-1], dtype=torch.bool, device=q.device)
+    for di in (-1, 0, 1):
+        i = torch.clamp(i0 + di, 0, res - 1)
+        # three non-collinear corners of the face (band i, sector j): a triangle at the poles, a planar trapezoid elsewhere
+        a_ = ring(i, t0)
+        b_ = torch.where((i == 0).unsqueeze(-1), ring(i + 1, t0), ring(i, t1))
+        c_ = ring(i + 1, t1)
+        n = torch.cross(b_ - a_, c_ - a_, dim=-1)
+        n = n * torch.sign((n * a_).sum(-1, keepdim=True) + (n * c_).sum(-1, keepdim=True))      # outward (origin inside)
+        n = n / n.norm(dim=-1, keepdim=True)
+        inside &= (n * q).sum(-1) < (n * c_).sum(-1)
+    return inside
+
+
+def _ngon_inside(x, y, radius, res):
+    """Strictly inside the regular res-gon with vertices radius (cos(2 pi j / res), sin(2 pi j / res))."""
+    step = 2 * torch.pi / res
+    theta = torch.atan2(y, x)
+    theta = torch.where(theta < 0, theta + 2 * torch.pi, theta)
+    j = torch.clamp((theta / step).floor(), 0, res - 1)
+    phi = (j + 0.5) * step                                   # outward normal of the edge (V_j, V_j+1)
+    return x * torch.cos(phi) + y * torch.sin(phi) < radius * torch.cos(torch.tensor(step / 2, dtype=x.dtype, device=x.device))
+
+
+def solid_cut_mask(raw, kind, rot=None, shift=None, exact_solid=False):
+    """up-mask (signed distance < 0 = strictly INSIDE the closed mesh) of the reference's mesh cuts:
+      "sphere"   (dataset.py:716-730): create_sphere(0.5, 50), centre = shift (np.random.rand(3,1)/3)
+      "cylinder" (:732-747): create_cylinder(0.6, 1, 50) about z, rotated by the axis-angle vector rot
+                 (np.random.rand(3,1)) about the origin, then translated by shift (np.random.rand(3,1)/3)
+      "cone"     (:749-763): create_cone(1, 2, 50) translated by (0,0,-1) (base at z = -1, apex at z = +1), rotated by
+                 rot about the origin
+    evaluated on the POLYHEDRA open3d 0.15.2 builds (resolution 50: a 4902-vertex UV sphere, a 50-gon prism, a 50-gon
+    pyramid; vertex formulas restated in oracle/solids.py) in closed form: the meshes are convex, so membership is a
+    handful of plane tests per point.  exact_solid=True: the smooth solids instead (round 3's form; differs in a band of
+    <= 0.1 % of the radius under the surface).  raw [B,M,3] fp32, rot / shift [B,3] float64 (the draws) -> bool [B,M];
+    float64 like the plane cut."""
     p = raw.to(torch.float64)
+    res = _MESH_RES
     if kind == "sphere":
         d = p - shift.to(torch.float64).unsqueeze(1)
-        return (d * d).sum(-1) < 0.25
+        if exact_solid:
+            return (d * d).sum(-1) < 0.25
+        return _sphere_poly_inside(d, 0.5, res)
     R = rotation_from_axis_angle(rot)                     # mesh point = R x (+ shift): x = R^T (p - shift)
     if kind == "cylinder":
         q = torch.einsum("bji,bmj->bmi", R, p - shift.to(torch.float64).unsqueeze(1))
-        return (q[..., 0] ** 2 + q[..., 1] ** 2 < 0.36) & (q[..., 2].abs() < 0.5)
+        if exact_solid:
+            return (q[..., 0] ** 2 + q[..., 1] ** 2 < 0.36) & (q[..., 2].abs() < 0.5)
+        return _ngon_inside(q[..., 0], q[..., 1], 0.6, res) & (q[..., 2].abs() < 0.5)
     if kind == "cone":
         q = torch.einsum("bji,bmj->bmi", R, p)
         h = q[..., 2] + 1.0                               # height above the base plane, apex at h = 2
-        rad = (q[..., 0] ** 2 + q[..., 1] ** 2).sqrt()
-        return (h > 0) & (h < 2) & (rad < 1.0 - h / 2)
+        if exact_solid:
+            rad = (q[..., 0] ** 2 + q[..., 1] ** 2).sqrt()
+            return (h > 0) & (h < 2) & (rad < 1.0 - h / 2)
+        # side face of sector j: the plane through the apex (0,0,2) and the base edge (V_j, V_j+1); its outward normal is
+        # (cos(phi) 2, sin(phi) 2, cos(step / 2)) up to scale, phi = (j + 1/2) step: 2 (x cos phi + y sin phi) + c h < 2 c
+        step = 2 * torch.pi / res
+        theta = torch.atan2(q[..., 1], q[..., 0])
+        theta = torch.where(theta < 0, theta + 2 * torch.pi, theta)
+        j = torch.clamp((theta / step).floor(), 0, res - 1)
+        phi = (j + 0.5) * step
+        c = torch.cos(torch.tensor(step / 2, dtype=torch.float64, device=q.device))
+        side = 2.0 * (q[..., 0] * torch.cos(phi) + q[..., 1] * torch.sin(phi)) + c * h < 2.0 * c
+        return (h > 0) & side
     raise _lib.PznError(f"solid_cut_mask: unknown solid {kind!r}")
 
 
@@ -120,7 +188,7 @@ def make_pairs_mask(raw, mask, start_up, start_down, twist, n=1024, k=128, cap=N
 
 def make_pairs_solid(raw, kind, rot, shift, start_up, start_down, twist, n=1024, k=128, cap=None):
     """CADDataset with slice = sphere_split / cylinder_split / cone_split (dataset.py:1463-1546 keys *_sphere, *_cyl,
-    *_cone; BASELINE configs[0] "bed_sphere"): the solid's inside is `up`.  Parity unpinned (see the module header)."""
+    *_cone; BASELINE configs[0] "bed_sphere"): the mesh's inside is `up` (parity: see the module header)."""
     return make_pairs_mask(raw, solid_cut_mask(raw, kind, rot, shift), start_up, start_down, twist, n, k, cap)
 
 

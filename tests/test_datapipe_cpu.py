@@ -110,38 +110,49 @@ def test_double_cut_planner_follows_the_reference(golden_data2):
             "halves", "halves_lower"} <= kinds
 
 
-def test_solid_cut_masks_against_closed_forms():
-    """datapipe.solid_cut_mask (the reference's sphere / cylinder / cone cuts, dataset.py:716-763, on the exact solids;
-    parity unpinned: open3d is not in the image) against independent numpy closed forms, and the rotation against the
-    axis-angle properties open3d documents (R w = w, R R^T = I, rotation angle |w|)."""
+def test_solid_cut_masks_against_the_restated_meshes():
+    """datapipe.solid_cut_mask (the reference's sphere / cylinder / cone cuts, dataset.py:716-763) against the oracle's
+    restatement of what the reference computes: open3d 0.15.2's create_sphere / create_cylinder / create_cone meshes at
+    resolution 50 (vertex formulas in oracle/solids.py), moved by the reference's draws, membership = strictly inside
+    every face plane (brute force over all 9800 / 500 / 100 triangles).  The product evaluates the same polyhedra in
+    closed form (three plane tests for the sphere, one or two for the others): the two must agree POINT FOR POINT,
+    including points within 1e-5 of a face or an edge.  (open3d itself is not in the image: pinned to the restatement.)
+    Also: the rotation against the axis-angle properties open3d documents, and the smooth solids (exact_solid=True)
+    differ from the meshes only inside the tessellation's band."""
     import numpy as np
     import torch
+    from oracle import solids
     from puzzlenet_amd import datapipe as dp
     rng = np.random.default_rng(5)
-    B, M = 3, 4000
-    pts = rng.random((B, M, 3)).astype(np.float32)
-    rot, shift = rng.random((B, 3)), rng.random((B, 3)) / 3
-    R = dp.rotation_from_axis_angle(torch.from_numpy(rot)).numpy()
-    for b in range(B):
-        w = rot[b]
-        np.testing.assert_allclose(R[b] @ w, w, atol=1e-12)
-        np.testing.assert_allclose(R[b] @ R[b].T, np.eye(3), atol=1e-12)
-        np.testing.assert_allclose(np.trace(R[b]), 1 + 2 * np.cos(np.linalg.norm(w)), atol=1e-12)
-    t = torch.from_numpy(pts)
-    m = dp.solid_cut_mask(t, "sphere", None, torch.from_numpy(shift)).numpy()
-    want = ((pts.astype(np.float64) - shift[:, None]) ** 2).sum(-1) < 0.25
-    assert np.array_equal(m, want) and 0 < m.mean() < 1
-    m = dp.solid_cut_mask(t, "cylinder", torch.from_numpy(rot), torch.from_numpy(shift)).numpy()
-    for b in range(B):
-        q = (pts[b].astype(np.float64) - shift[b]) @ R[b]          # rows: R^T (p - shift)
-        want = (q[:, 0] ** 2 + q[:, 1] ** 2 < 0.36) & (np.abs(q[:, 2]) < 0.5)
-        assert np.array_equal(m[b], want)
-    m = dp.solid_cut_mask(t, "cone", torch.from_numpy(rot), None).numpy()
-    for b in range(B):
-        q = pts[b].astype(np.float64) @ R[b]
-        h = q[:, 2] + 1
-        want = (h > 0) & (h < 2) & (np.hypot(q[:, 0], q[:, 1]) < 1 - h / 2)
-        assert np.array_equal(m[b], want)
+    for kind in ("sphere", "cylinder", "cone"):
+        V0, T0 = {"sphere": solids.create_sphere(0.5, 50), "cylinder": solids.create_cylinder(0.6, 1.0, 50),
+                  "cone": solids.create_cone(1.0, 2.0, 50)}[kind]
+        assert len(V0) == {"sphere": 4902, "cylinder": 252, "cone": 52}[kind]          # open3d's vertex counts
+        assert len(T0) == {"sphere": 9800, "cylinder": 500, "cone": 100}[kind]
+        for trial in range(3):
+            rot, shift = rng.random(3), rng.random(3) / 3
+            R = dp.rotation_from_axis_angle(torch.from_numpy(rot)[None])[0].numpy()
+            np.testing.assert_allclose(R, solids.rotation_from_axis_angle(rot), atol=1e-14)
+            np.testing.assert_allclose(R @ rot, rot, atol=1e-12)
+            np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-12)
+            np.testing.assert_allclose(np.trace(R), 1 + 2 * np.cos(np.linalg.norm(rot)), atol=1e-12)
+            V, T = solids.solid_mesh(kind, rot, shift)
+            cen = V.mean(0)
+            bulk = rng.random((20000, 3)) * 2.4 - 1.2
+            fc, ec = V[T].mean(1), 0.5 * (V[T[:, 0]] + V[T[:, 1]])
+            near_f = cen + (fc - cen) * rng.choice([0.999, 0.9999, 0.99999, 1.00001, 1.0001, 1.001], size=(len(fc), 1))
+            near_e = cen + (ec - cen) * rng.choice([0.9999, 0.99999, 1.00001, 1.0001], size=(len(ec), 1))
+            P = np.concatenate([bulk, near_f, near_e]).astype(np.float32)
+            want = solids.solid_cut_mask(P.astype(np.float64), kind, rot, shift)
+            t = torch.from_numpy(P)[None]
+            got = dp.solid_cut_mask(t, kind, torch.from_numpy(rot)[None], torch.from_numpy(shift)[None])[0].numpy()
+            assert np.array_equal(got, want), (kind, trial, int((got != want).sum()))
+            assert 0 < got[:20000].mean() < 1
+            # the smooth solid of the same name: same answer except inside the tessellation's band under the surface
+            smooth = dp.solid_cut_mask(t, kind, torch.from_numpy(rot)[None], torch.from_numpy(shift)[None], exact_solid=True)[0].numpy()
+            diff = smooth != got
+            assert not (got & ~smooth).any()                       # the mesh is inscribed: never inside it but outside the solid
+            assert diff[:20000].mean() < 5e-3
     # apex and base of the cone as open3d builds it (create_cone(radius=1, height=2) then translate (0,0,-1)), unrotated
     zero = torch.zeros(1, 3, dtype=torch.float64)
     probe = torch.tensor([[[0.0, 0.0, 0.9], [0.0, 0.0, 1.1], [0.9, 0.0, -0.95], [1.05, 0.0, -0.95], [0.0, 0.0, -1.05]]])

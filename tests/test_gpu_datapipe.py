@@ -125,10 +125,11 @@ def test_building_pairs_match_reference(golden_data2):
 
 @pytest.mark.parametrize("kind", ["sphere", "cylinder", "cone"])
 def test_make_pairs_solid_cuts(kind):
-    """datapipe.make_pairs_solid (dataset.py:716-763 + the pair construction of CADDataset): the solid's inside becomes
-    `up`.  Parity with open3d's tessellated meshes is unpinned (not in the image), so the contract is checked
-    structurally: every sampled point is a point of the raw cloud on the right side of the exact solid, the FPS start
-    point is first, 128 boundary points per piece, and the motion is the SE(3) exponential of the twist."""
+    """datapipe.make_pairs_solid (dataset.py:716-763 + the pair construction of CADDataset): the mesh's inside becomes
+    `up`.  The mask on the GPU is the oracle's (oracle/solids.py: open3d 0.15.2's resolution-50 meshes restated, brute-force
+    face-plane membership) point for point; then the contract of the pair construction: every sampled point is a point
+    of the raw cloud on the right side, the FPS start point is first, 128 boundary points per piece, and the motion is
+    the SE(3) exponential of the twist."""
     from puzzlenet_amd import datapipe, se3
     dev = torch.device("cuda:0")
     rng = np.random.default_rng({"sphere": 1, "cylinder": 2, "cone": 3}[kind])
@@ -138,6 +139,10 @@ def test_make_pairs_solid_cuts(kind):
     rot = torch.from_numpy(rng.random((B, 3))).to(dev)
     shift = torch.from_numpy(rng.random((B, 3)) / 3).to(dev)
     mask = datapipe.solid_cut_mask(raw, kind, rot, shift)
+    from oracle import solids
+    for b in range(B):
+        want = solids.solid_cut_mask(raw_np[b].astype(np.float64), kind, rot[b].cpu().numpy(), shift[b].cpu().numpy())
+        assert np.array_equal(mask[b].cpu().numpy(), want), (kind, b)
     n_up = mask.sum(1)
     assert bool(((n_up >= n) & (M - n_up >= n)).all()), n_up.tolist()
     s_up = torch.tensor([int(rng.integers(0, int(c))) for c in n_up.tolist()], device=dev)
