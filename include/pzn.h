@@ -476,7 +476,7 @@ int pzn_attn_fused_wgrads(const float* dz, const float* t, const float* dq, cons
 /* First layer of the boundary heads without the concatenation (model5_b.py:745-752: Linear(cat([g.repeat(1,N,1), x], -1))
  * = x W[:,Cg:]^T per point + (g W[:,:Cg]^T + b) per cloud):
  *   pzn_cloud_bias_relu_f32:     y[b,n,:] = relu(y[b,n,:] + cb[b,:])  in place       (C % 4 == 0, 16-byte aligned)
- *   pzn_cloud_gated_colsum_f32:  dcb[b,c] = sum_n (y[b,n,c] > 0 ? dy[b,n,c] : 0)    (overwritten; atomics inside) */
+ *   pzn_cloud_gated_colsum_f32:  dcb[b,c] = sum_n (y[b,n,c] > 0 ? dy[b,n,c] : 0)    (overwritten; fixed summation order) */
 int pzn_cloud_bias_relu_f32(float* y, const float* cb, int B, int N, int C, pzn_stream_t stream);
 int pzn_cloud_gated_colsum_f32(const float* dy, const float* y, int B, int N, int C, float* dcb, pzn_stream_t stream);
 

@@ -298,16 +298,17 @@ __global__ __launch_bounds__(256) void cloud_bias_relu_kernel(float4* __restrict
   }
 }
 
-// grid (chunks, B); block 256 = 16 column quads x 16 row lanes (C = 64) ... generally c4 column quads x 256 / c4 row lanes;
-// partial sums meet in LDS, one atomic add per column and workgroup (dcb zeroed by the host wrapper)
-__global__ __launch_bounds__(256) void cloud_gated_colsum_kernel(const float4* __restrict__ dy, const float4* __restrict__ y,
-                                                                 int N, int c4, float* __restrict__ dcb) {
-  __shared__ float4 part[256];
-  const int b = blockIdx.y, q = threadIdx.x % c4, rl = threadIdx.x / c4, nrl = 256 / c4;
+// grid (B); block 1024 = c4 column quads x 1024 / c4 row lanes: ONE workgroup per cloud walks all N rows, the row lanes'
+// partial sums meet in LDS in a fixed order and the result is stored (no atomics: bit-reproducible run to run, like
+// boundary_ce_reduce_kernel and point_mlp3_reduce_kernel; this is the boundary heads' layer-by-layer path, PZN_POINT_MLP=0)
+__global__ __launch_bounds__(1024) void cloud_gated_colsum_kernel(const float4* __restrict__ dy, const float4* __restrict__ y,
+                                                                  int N, int c4, float* __restrict__ dcb) {
+  __shared__ float4 part[1024];
+  const int b = blockIdx.x, q = threadIdx.x % c4, rl = threadIdx.x / c4, nrl = 1024 / c4;
   const long base = (long)b * N * c4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (rl < nrl)
-    for (int n = blockIdx.x * nrl + rl; n < N; n += gridDim.x * nrl) {
+    for (int n = rl; n < N; n += nrl) {
       const float4 g = dy[base + (long)n * c4 + q], v = y[base + (long)n * c4 + q];
       s.x += v.x > 0.f ? g.x : 0.f, s.y += v.y > 0.f ? g.y : 0.f, s.z += v.z > 0.f ? g.z : 0.f, s.w += v.w > 0.f ? g.w : 0.f;
     }
@@ -318,8 +319,7 @@ __global__ __launch_bounds__(256) void cloud_gated_colsum_kernel(const float4* _
       const float4 o = part[j * c4 + q];
       s.x += o.x, s.y += o.y, s.z += o.z, s.w += o.w;
     }
-    float* d = dcb + ((long)b * c4 + q) * 4;
-    atomicAdd(d, s.x), atomicAdd(d + 1, s.y), atomicAdd(d + 2, s.z), atomicAdd(d + 3, s.w);
+    *reinterpret_cast<float4*>(dcb + ((long)b * c4 + q) * 4) = s;
   }
 }
 
@@ -460,16 +460,11 @@ PZN_EXPORT int pzn_cloud_bias_relu_f32(float* y, const float* cb, int B, int N, 
 PZN_EXPORT int pzn_cloud_gated_colsum_f32(const float* dy, const float* y, int B, int N, int C, float* dcb,
                                           pzn_stream_t stream) {
   PZN_CHECK_ARG(dy && y && dcb && B > 0 && B <= 65535 && N > 0 && C > 0);
-  if ((C & 3) || C > 1024 || 256 % (C / 4) != 0 ||
+  if ((C & 3) || C > 1024 || 1024 % (C / 4) != 0 ||
       ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dcb)) & 15))
     return PZN_EUNSUPPORTED;
   hipStream_t st = pzn_hip_stream(stream);
-  if (pzn_zero_async(dcb, (size_t)B * C, st) != PZN_OK) return PZN_ELAUNCH;
-  const int nrl = 256 / (C / 4);
-  int chunks = (N + nrl * 8 - 1) / (nrl * 8);      // >= 8 rows per row lane
-  if (chunks > 16) chunks = 16;
-  if (chunks < 1) chunks = 1;
-  hipLaunchKernelGGL(cloud_gated_colsum_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, st,
+  hipLaunchKernelGGL(cloud_gated_colsum_kernel, dim3((unsigned)B), dim3(1024), 0, st,
                      reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(y), N, C / 4, dcb);
   PZN_RETURN_LAUNCH_STATUS();
 }

@@ -8,7 +8,7 @@ What is different from the reference file
   * every hard-wired 1024 (BatchNorm1d(num_points), repeat(1,1024,1),
     zeros(B,1024)) follows ``num_points`` (``config.num_points``, default 1024);
   * the point ops, EMD, chamfer, shared-MLP and attention run as hand-written
-    gfx950 kernels behind the C ABI (puzzlenet_amd.ops / .dense);
+    gfx950 kernels behind the C ABI (puzzlenet_amd.ops);
   * TensorBoard meshes / matplotlib figures of the reference's training_step
     (model5_b.py:975-982, 1130-1134) are host-side logging and are not produced;
   * dead code of the reference (Encoder, decoders other than BiDecoderNoneCross,
@@ -26,7 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib, dense, metrics, ops, se3
+from . import _lib, metrics, ops, se3
 from . import pointnet_util as pu
 from .PyTorchEMD.emd import earth_mover_distance
 
@@ -50,7 +50,7 @@ def scaled_dot_production(q, k, v, mask=None):
     """model5_b.py:67-75 -> (values, attention)."""
     if mask is not None:
         raise NotImplementedError("mask is never passed on the live path (model5_b.py:96)")
-    return dense.attention(q, k, v)
+    return ops.attention(q, k, v)
 
 
 class layerAttention(nn.Module):
@@ -73,12 +73,12 @@ class layerAttention(nn.Module):
                                            self.mlpv.weight, self.mlpv.bias, self.out.weight, self.out.bias)
             except _lib.PznUnsupported:      # a shape / alignment the fused block does not take: compose it below
                 pass
-        q = dense.linear(xyz, self.mlpq.weight, self.mlpq.bias)
-        k = dense.linear(xyz, self.mlpk.weight, self.mlpk.bias)
-        v = dense.linear(xyz, self.mlpv.weight, self.mlpv.bias)
+        q = ops.linear(xyz, self.mlpq.weight, self.mlpq.bias)
+        k = ops.linear(xyz, self.mlpk.weight, self.mlpk.bias)
+        v = ops.linear(xyz, self.mlpv.weight, self.mlpv.bias)
         r, attention = scaled_dot_production(q, k, v)
         r = xyz - r
-        r = xyz + dense.linear(r, self.out.weight, self.out.bias, relu=True)
+        r = xyz + ops.linear(r, self.out.weight, self.out.bias, relu=True)
         return r, attention
 
 
@@ -97,9 +97,9 @@ class BiDecoderNoneCross(nn.Module):
         f_global = f_global.unsqueeze(1) if len(f_global.shape) == 2 else f_global
         f = f_global.repeat(1, 256, 1)
         f = torch.cat([f_local, f], dim=1).permute(0, 2, 1)
-        f = dense.linear(f, self.mlp1.weight, self.mlp1.bias, relu=True)
-        f = dense.linear(f, self.mlp2.weight, self.mlp2.bias, relu=True)
-        f = dense.linear(f, self.mlp3.weight, self.mlp3.bias)
+        f = ops.linear(f, self.mlp1.weight, self.mlp1.bias, relu=True)
+        f = ops.linear(f, self.mlp2.weight, self.mlp2.bias, relu=True)
+        f = ops.linear(f, self.mlp3.weight, self.mlp3.bias)
         return f.permute(0, 2, 1)
 
 
@@ -148,15 +148,15 @@ class PCTransformer_nonsort(nn.Module):
             idx = None                                                    # :118-119 fused into the group launch
         else:
             new_xyz, idx = plan
-        return new_xyz, dense.sa_mlp_max(xyz, feat, new_xyz, idx, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias)
+        return new_xyz, ops.sa_mlp_max(xyz, feat, new_xyz, idx, lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias)
 
     def local_features(self, xyz):
         """:447-448, the per-point MLP in front of the set abstraction (does not need the sampling plan)."""
         if xyz.is_cuda and _BN_FUSED:      # BatchNorm + ReLU as one launch each way (csrc/bnpoints.hip)
-            x_feature = ops.bn_points_relu(dense.linear(xyz, self.mlp1.weight, self.mlp1.bias), self.bn1)   # :447
-            return ops.bn_points_relu(dense.linear(x_feature, self.mlp2.weight, self.mlp2.bias), self.bn2)  # :448
-        x_feature = F.relu(self.bn1(dense.linear(xyz, self.mlp1.weight, self.mlp1.bias)))          # :447
-        return F.relu(self.bn2(dense.linear(x_feature, self.mlp2.weight, self.mlp2.bias)))        # :448
+            x_feature = ops.bn_points_relu(ops.linear(xyz, self.mlp1.weight, self.mlp1.bias), self.bn1)   # :447
+            return ops.bn_points_relu(ops.linear(x_feature, self.mlp2.weight, self.mlp2.bias), self.bn2)  # :448
+        x_feature = F.relu(self.bn1(ops.linear(xyz, self.mlp1.weight, self.mlp1.bias)))          # :447
+        return F.relu(self.bn2(ops.linear(x_feature, self.mlp2.weight, self.mlp2.bias)))        # :448
 
     def _block_params(self):
         return [(a.mlpq.weight, a.mlpq.bias, a.mlpk.weight, a.mlpk.bias, a.mlpv.weight, a.mlpv.bias, a.out.weight, a.out.bias)
@@ -172,9 +172,9 @@ class PCTransformer_nonsort(nn.Module):
             x2, f2f = self._set_abstraction(256, 32, x, f1f, self.mlp5, self.mlp6, p2)
         else:
             x, f1 = self.sg1(512, 0, 32, xyz, x_feature, False, True)                             # :449
-            f1f = dense.shared_mlp_max(f1, self.mlp3.weight, self.mlp3.bias, self.mlp4.weight, self.mlp4.bias)  # :452-454
+            f1f = ops.shared_mlp_max(f1, self.mlp3.weight, self.mlp3.bias, self.mlp4.weight, self.mlp4.bias)  # :452-454
             x2, f2 = self.sg2(256, 0, 32, x, f1f, False, True)                                    # :456
-            f2f = dense.shared_mlp_max(f2, self.mlp5.weight, self.mlp5.bias, self.mlp6.weight, self.mlp6.bias)  # :459-461
+            f2f = ops.shared_mlp_max(f2, self.mlp5.weight, self.mlp5.bias, self.mlp6.weight, self.mlp6.bias)  # :459-461
         return x2, self._mark_f2f(f2f), x_feature
 
     def chain_fused_ok(self, f2f):
@@ -210,7 +210,7 @@ class PCTransformer_nonsort(nn.Module):
                 attention = attention1 + attention2 + attention3 + attention4
                 attention = attention / 4
             att = torch.cat([att1, att2, att3, att4, f2f], dim=-1)       # (:466, :470 as one copy instead of two)
-            out = dense.linear(att, self.out.weight, self.out.bias)                                   # :474
+            out = ops.linear(att, self.out.weight, self.out.bias)                                   # :474
         f_global = ops.max_over_points(out)                                                       # :475
         return f_global, x2, attention, out, x_feature
 
@@ -259,7 +259,7 @@ def _run_seq(seq, x):
     while i < len(mods):
         lin = mods[i]
         relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-        x = dense.linear(x, lin.weight, lin.bias, relu=relu)
+        x = ops.linear(x, lin.weight, lin.bias, relu=relu)
         i += 2 if relu else 1
     return x
 
@@ -544,7 +544,7 @@ class TouchedRegraster(_Base):
     # ------------------------------------------------------------------ losses
     def chamfer_loss(self, a, b):
         """model5_b.py:1495-1505 -> (min over a per b-point [B,m], min over b per a-point [B,n])."""
-        return dense.chamfer(a, b)
+        return ops.chamfer(a, b)
 
     def comp(self, g, igt):
         """model5_b.py:1512-1519: |g igt - I|^2 mean * 16."""

@@ -1371,7 +1371,7 @@ class _SaMlpMax(torch.autograd.Function):
         B, N, S, K, D, R, C1, C2 = ctx.dims
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
             raise _lib.PznError("sa_mlp_max: gradients w.r.t. point coordinates are not provided on the fused "
-                                "encoder path; use pointnet_util.sample_and_group + dense.shared_mlp_max")
+                                "encoder path; use pointnet_util.sample_and_group + ops.shared_mlp_max")
         dout = _f32(dout, "dout").reshape(R, C2)
         dev = dout.device
         need_feat = ctx.needs_input_grad[1]
@@ -1504,7 +1504,7 @@ class _SaMlpMaxPoint(torch.autograd.Function):
         B, N, S, D, R, C1, C2 = ctx.dims
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
             raise _lib.PznError("sa_mlp_max: gradients w.r.t. point coordinates are not provided on the fused "
-                                "encoder path; use pointnet_util.sample_and_group + dense.shared_mlp_max")
+                                "encoder path; use pointnet_util.sample_and_group + ops.shared_mlp_max")
         dout = _f32(dout, "dout").reshape(R, C2)
         dev = dout.device
         need_feat = ctx.needs_input_grad[1]
@@ -1602,7 +1602,7 @@ class _SaLevelFused(torch.autograd.Function):
         B, N, S, D, R, C1, C2 = ctx.dims
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
             raise _lib.PznError("sa_mlp_max: gradients w.r.t. point coordinates are not provided on the fused "
-                                "encoder path; use pointnet_util.sample_and_group + dense.shared_mlp_max")
+                                "encoder path; use pointnet_util.sample_and_group + ops.shared_mlp_max")
         dout = _f32(dout, "dout").reshape(R, C2)
         dev = dout.device
         need_feat = ctx.needs_input_grad[1]

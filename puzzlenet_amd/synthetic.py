@@ -10,7 +10,7 @@ datasets.  Built on the GPU with the product's own ops.
 """
 import torch
 
-from . import dense, ops, se3
+from . import ops, se3
 
 
 def make_batch(B, N, device, seed=1234, n_boundary=128):
@@ -21,7 +21,7 @@ def make_batch(B, N, device, seed=1234, n_boundary=128):
     x = (0.8 * x / x.norm(dim=1, keepdim=True)).to(device)
     igt = se3.exp(x)
     mrpc = se3.transform(igt, rpc.permute(0, 2, 1)).permute(0, 2, 1).contiguous()
-    cd1, cd2 = dense.chamfer(fpc, rpc)                 # cd1: per rpc point, cd2: per fpc point
+    cd1, cd2 = ops.chamfer(fpc, rpc)                 # cd1: per rpc point, cd2: per fpc point
     r_top = torch.topk(-cd1, n_boundary, dim=1)[1]
     f_top = torch.topk(-cd2, n_boundary, dim=1)[1]
     rpcb = ops.index_points(rpc, r_top)

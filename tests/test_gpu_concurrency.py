@@ -16,7 +16,7 @@ REPS = 40
 
 @pytest.fixture(scope="module")
 def rig():
-    from puzzlenet_amd import dense, ops
+    from puzzlenet_amd import ops
     from puzzlenet_amd.ops import _call, _p
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(3)
@@ -55,8 +55,15 @@ def rig():
             y = ops.point_mlp3(leaves[0], leaves[2], leaves[3], leaves[4], leaves[5], leaves[6], leaves[7], g=leaves[1])
             grads = torch.autograd.grad(y, leaves, pm_go)
         return torch.cat([y.detach().reshape(-1)] + [t.reshape(-1) for t in grads])
+    def cat_global():      # the boundary heads' first layer on the layer-by-layer path (csrc/losstail.hip: per-cloud bias, gated
+        with torch.enable_grad():      # column sums in a fixed order), forward + backward
+            leaves = [t.detach().requires_grad_(True) for t in (pm_x, pm_g)]      # (input gradients: the weight gradients of
+            y = ops.cat_global_linear_relu(leaves[0], leaves[1], pm_w1, pm_b[0])   #  this path end in float atomics)
+            grads = torch.autograd.grad(y, leaves, torch.ones_like(y))
+        return torch.cat([y.detach().reshape(-1)] + [t.reshape(-1) for t in grads])
     victims = {
         "point_mlp3": point_mlp,
+        "cat_global_linear_relu": cat_global,
         "knn": lambda: ops.knn(xyz, new_xyz, 32),
         "knn_group": lambda: ops.knn_group(xyz, feat, new_xyz)[0],
         "fps": lambda: ops.farthest_point_sample(xyz, 256, torch.zeros(B, dtype=torch.long, device=dev)),
@@ -65,8 +72,8 @@ def rig():
         "chamfer": lambda: torch.cat([t.reshape(-1).float() for t in ops.chamfer(a_pts, b_pts)]),
         "attention_block": lambda: ops.attention_block(xa, *aw)[0],
         "attention_chain_fused": lambda: torch.cat([t.reshape(-1) for t in chain()]),
-        "linear_weight_stationary": lambda: dense.linear(xl, wl, bl, relu=True),
-        "linear_general_engine": lambda: dense.linear(xg, wg, None),
+        "linear_weight_stationary": lambda: ops.linear(xl, wl, bl, relu=True),
+        "linear_general_engine": lambda: ops.linear(xg, wg, None),
         "max_over_points": lambda: ops.max_over_points(xa),
     }
 

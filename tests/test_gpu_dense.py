@@ -233,7 +233,7 @@ def test_attention_block_fused_vs_composed(dev, sinks):
     in GEMM epilogues) against the block composed from linear + attention + tensor ops, outputs and every
     gradient, also with the attention map receiving a gradient and with the parameter gradients going straight
     into registered sinks (accumulate epilogues)."""
-    from puzzlenet_amd import dense, ops
+    from puzzlenet_amd import ops
     B, L, E, dk = 20, 256, 256, 64            # 5120 rows: inside the weight-stationary kernel's domain
     g = torch.Generator().manual_seed(3)
     x0 = (0.5 * torch.randn(B, L, E, generator=g)).to(dev)
@@ -254,9 +254,9 @@ def test_attention_block_fused_vs_composed(dev, sinks):
             r, a = ops.attention_block(x, *ps)
         else:
             wq, bq, wk, bk, wv, bv, wo, bo = ps
-            q, k, v = dense.linear(x, wq, bq), dense.linear(x, wk, bk), dense.linear(x, wv, bv)
+            q, k, v = ops.linear(x, wq, bq), ops.linear(x, wk, bk), ops.linear(x, wv, bv)
             t, a = ops.attention(q, k, v)
-            r = x + dense.linear(x - t, wo, bo, relu=True)
+            r = x + ops.linear(x - t, wo, bo, relu=True)
         ((r * wr).sum() + (a * wa).sum()).backward()
         ops.clear_grad_sinks()
         return r.detach(), a.detach(), x.grad, [p.grad for p in ps]
@@ -365,7 +365,7 @@ def test_attention_chain_node_vs_composed(dev, sinks, use):
     outputs and every gradient (35 tensors), also with the parameter gradients going into registered sinks.
     use = "max": only f_global = max over the points carries a gradient, as in predict5 — the out projection's backward
     then runs as sparse row operations (csrc/maxptsbwd.hip); "out" / "both": the dense products."""
-    from puzzlenet_amd import dense, ops
+    from puzzlenet_amd import ops
     B, L, E, dk, Nout = 20, 256, 256, 64, 1024
     g = torch.Generator().manual_seed(7)
     x0 = (0.5 * torch.randn(B, L, E, generator=g)).to(dev)
@@ -396,7 +396,7 @@ def test_attention_chain_node_vs_composed(dev, sinks, use):
                 maps.append(m)
                 outs.append(cur)
             a = ops.avg4(*maps)
-            y = dense.linear(torch.cat(outs + [x], dim=-1), w, b)
+            y = ops.linear(torch.cat(outs + [x], dim=-1), w, b)
             fg = ops.max_over_points(y)
         loss = 0
         if use in ("max", "both"):

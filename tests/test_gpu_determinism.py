@@ -79,7 +79,7 @@ def test_predict5_forward_repeatable(golden_model, dev, two_streams):
 def test_encoder_stages_repeatable(golden_model, dev):
     """the encoder's stages one by one on the same inputs: set abstraction (search + P'/Q + generated-row max-pool kernel),
     attention chain node"""
-    from puzzlenet_amd import dense, model5_b as mb, ops
+    from puzzlenet_amd import model5_b as mb, ops
     G = golden_model
     m = mb.TouchedRegraster(mr.Cfg())
     mr.fill_params(m)
@@ -95,14 +95,14 @@ def test_encoder_stages_repeatable(golden_model, dev):
         first = None
         for r in range(REPS):
             xf_r = enc.local_features(xyz)
-            a = dense.sa_mlp_max(xyz, xf, x1, None, enc.mlp3.weight, enc.mlp3.bias, enc.mlp4.weight, enc.mlp4.bias)
-            b = dense.sa_mlp_max(x1, a, x2, None, enc.mlp5.weight, enc.mlp5.bias, enc.mlp6.weight, enc.mlp6.bias)
+            a = ops.sa_mlp_max(xyz, xf, x1, None, enc.mlp3.weight, enc.mlp3.bias, enc.mlp4.weight, enc.mlp4.bias)
+            b = ops.sa_mlp_max(x1, a, x2, None, enc.mlp5.weight, enc.mlp5.bias, enc.mlp6.weight, enc.mlp6.bias)
             cur = {"local_features": xf_r, "sa1": a, "sa2": b}
             x = b
             for i, blk in enumerate((enc.atten1, enc.atten2, enc.atten3, enc.atten4)):
                 x, amap = blk(x)
                 cur[f"att{i + 1}"], cur[f"map{i + 1}"] = x, amap
-            cur["out"] = dense.linear(torch.cat([cur["att1"], cur["att2"], cur["att3"], cur["att4"], b], dim=-1),
+            cur["out"] = ops.linear(torch.cat([cur["att1"], cur["att2"], cur["att3"], cur["att4"], b], dim=-1),
                                       enc.out.weight, enc.out.bias)
             cur["max"] = ops.max_over_points(cur["out"])
             torch.cuda.synchronize()

@@ -68,8 +68,13 @@ def main():
     maxpool = round(2 * sum(v["hbm_bytes_per_launch"] for v in mp.values())) if len(mp) == 2 else None
     fam = sel(r"^(ws_gemm_kernel|df_wgrad_kernel|gemm_kernel|sa_level_stream_kernel|outproj_maxpts_kernel|point_mlp3_(fwd|bwd)_kernel|attn_(proj|fwd|bwd_q|bwd_k)_kernel)")
     mfma = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam.values()) / a.steps_in_trace) or None
-    sa = sel(r"^(sa_point_l1_bwd_kernel|sa_point_l1_fwd_kernel|sa_prep_kernel)")
+    # the list sum of the model path (what roofline_sa_gather prices: its algorithmic bytes are the backward's only, the forward
+    # writes no rows since round 2); the forward prep kernel (P', Q) is listed beside it, not inside it (it was until round 3:
+    # 0.48 GB per step of the figure then reported belonged to sa_prep_kernel)
+    sa = sel(r"^(sa_point_l1_bwd_kernel|sa_point_l1_fwd_kernel)")
     sa_b = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sa.values()) / a.steps_in_trace) or None
+    prep = sel(r"^sa_prep_kernel")
+    prep_b = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in prep.values()) / a.steps_in_trace) or None
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, python3 bench.py --steps 2 --warmup 1 "
                      "--no-cpu-baseline",
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE half-count, MI355X_MICROARCH.md)",
@@ -81,6 +86,7 @@ def main():
            "ws_gemm_maxpool_bytes_per_step": maxpool, "ws_gemm_maxpool_kernels": mp,
            "mfma_family_bytes_per_step": mfma,
            "sa_gather_stage_bytes_per_step": sa_b,
+           "sa_prep_bytes_per_step": prep_b,
            "per_kernel": per}
     json.dump(doc, open(a.out, "w"), indent=1)
     print(json.dumps({k: doc[k] for k in ("build_id", "knn_group_stage_bytes_per_step", "knn_group_stage_algorithmic_bytes_per_step",

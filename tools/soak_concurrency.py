@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
 
-from puzzlenet_amd import dense, ops
+from puzzlenet_amd import ops
 from puzzlenet_amd.ops import _call, _p
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(3)
@@ -59,8 +59,8 @@ victims = {
     "sa_level": lambda: ops.sa_mlp_max(xyz, feat, new_xyz, None, w1, b1, w2, b2),
     "chamfer": lambda: torch.cat([t.reshape(-1).float() for t in ops.chamfer(a_pts, b_pts)]),
     "attention_block": lambda: ops.attention_block(xa, *aw)[0],
-    "linear_weight_stationary": lambda: dense.linear(xl, wl, bl, relu=True),
-    "linear_general_engine": lambda: dense.linear(xg, wg, None),
+    "linear_weight_stationary": lambda: ops.linear(xl, wl, bl, relu=True),
+    "linear_general_engine": lambda: ops.linear(xg, wg, None),
     "max_over_points": lambda: ops.max_over_points(xa),
     "attention_chain_fused": lambda: torch.cat([t.reshape(-1) for t in chain()]),
 }
