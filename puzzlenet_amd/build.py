@@ -34,6 +34,7 @@ SOURCES = [
     ("chamfer.hip", NOSLP),
     ("gemm.hip", NOSLP),
     ("attnfused.hip", NOSLP),
+    ("attn16.hip", NOSLP),
     ("salevel.hip", NOSLP),
     ("outproj.hip", NOSLP),
     ("pointmlp.hip", NOSLP),

@@ -68,7 +68,6 @@ constexpr int STG_BYTES = 32 * STG_LD * 4;         // 16,896 per wavefront
 
 // registers -> staging: tiles ft0 .. ft0 + NFT - 1 (NFT <= 4) of x at columns 32 (ft - ft0); gate != NULL: element i of
 // tile ft is replaced by zero unless bit (ft & 1) * 16 + i of gate[ft >> 1] is set (ReLU mask of the forward pass)
-struct NoGate {};
 struct Gate4 {
   uint32_t w[4];
 };
@@ -952,6 +951,18 @@ extern "C" __attribute__((visibility("default"))) int pzn_attn_fused_read_stamps
 }
 #endif
 PZN_EXPORT size_t pzn_attn_fused_weight_bytes(void) { return W_BYTES; }
+
+// tile shape of the chained kernels: 32 (four wavefronts per workgroup, v_mfma_f32_32x32x16_bf16) or 16 (eight wavefronts,
+// v_mfma_f32_16x16x32_bf16: attn16.hip).  PZN_ATTN_ROWS selects; read once.  The images, the gate words and the tile
+// images differ between the two, so the mode is a property of the process, not of a call.
+int pzn_attn_rows_mode() {
+  static const int mode = [] {
+    const char* e = getenv("PZN_ATTN_ROWS");
+    return e && atoi(e) == 32 ? 32 : 16;
+  }();
+  return mode;
+}
+PZN_EXPORT int pzn_attn_fused_rows(void) { return pzn_attn_rows_mode(); }
 PZN_EXPORT size_t pzn_attn_fused_qk_image_bytes(int B) { return B > 0 ? (size_t)B * QK_IMG : 0; }
 PZN_EXPORT size_t pzn_attn_fused_v_image_bytes(int B) { return B > 0 ? (size_t)B * V_IMG : 0; }
 
@@ -979,6 +990,7 @@ PZN_EXPORT int pzn_attn_fused_prep_weights_n(int n, const float* const* Wq, cons
     PZN_CHECK_ARG(Wq[i] && Wk[i] && Wv[i] && Wo[i] && planes[i] && aligned16(planes[i]));
     pack_jobs(a, 8 * i, Wq[i], Wk[i], Wv[i], Wo[i], static_cast<unsigned char*>(planes[i]));
   }
+  if (pzn_attn_rows_mode() == 16) return pzn_attn16_prep_weights(n, Wq, Wk, Wv, Wo, planes, pzn_hip_stream(stream));
   hipLaunchKernelGGL(pack_rp_kernel, dim3(12, a.njobs), dim3(256), 0, pzn_hip_stream(stream), a);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -1003,6 +1015,7 @@ PZN_EXPORT int pzn_attn_fused_proj(int nprob, const float* const* x, const void*
                       static_cast<unsigned char*>(qrp[i]), static_cast<unsigned char*>(krp[i]),
                       static_cast<unsigned char*>(vrp[i])};
   }
+  if (pzn_attn_rows_mode() == 16) return pzn_attn16_proj(nprob, x, w, bq, bk, bv, B, qrp, krp, vrp, pzn_hip_stream(stream));
   if (pzn_attn_precision_mode() == 1)
     hipLaunchKernelGGL(attn_proj_kernel<1>, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
   else
@@ -1029,6 +1042,8 @@ PZN_EXPORT int pzn_attn_fused_fwd(int nprob, const float* const* x, const void* 
                      static_cast<const unsigned char*>(vrp[i]), static_cast<const unsigned char*>(w[i]), bo[i], r[i], t[i],
                      static_cast<uint32_t*>(mask[i]), map[i], lse[i]};
   }
+  if (pzn_attn_rows_mode() == 16)
+    return pzn_attn16_fwd(nprob, x, qrp, krp, vrp, w, bo, B, r, t, mask, map, lse, map_accumulate, map_scale, pzn_hip_stream(stream));
   if (pzn_attn_precision_mode() == 1)
     hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
   else
@@ -1057,6 +1072,8 @@ PZN_EXPORT int pzn_attn_fused_bwd_q(int nprob, const float* const* dr, int ld_dr
                       static_cast<const unsigned char*>(vrp[i]), static_cast<const unsigned char*>(w[i]), dz[i], u[i], dq[i],
                       dqt[i], static_cast<unsigned char*>(darp[i]), delta[i]};
   }
+  if (pzn_attn_rows_mode() == 16)
+    return pzn_attn16_bwd_q(nprob, dr, ld_dr, dr2, ld_dr2, mask, qrp, krp, vrp, w, B, dz, u, dq, dqt, darp, delta, pzn_hip_stream(stream));
   if (pzn_attn_precision_mode() == 1)
     hipLaunchKernelGGL(attn_bwd_q_kernel<1>, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
   else
@@ -1081,6 +1098,8 @@ PZN_EXPORT int pzn_attn_fused_bwd_k(int nprob, const void* const* qrp, const voi
                       static_cast<const unsigned char*>(vrp[i]), static_cast<const unsigned char*>(darp[i]),
                       static_cast<const unsigned char*>(w[i]), lse[i], delta[i], u[i], dq[i], dk[i], dv[i], dx[i]};
   }
+  if (pzn_attn_rows_mode() == 16)
+    return pzn_attn16_bwd_k(nprob, qrp, krp, vrp, darp, w, lse, delta, u, dq, B, dk, dv, dx, pzn_hip_stream(stream));
   if (pzn_attn_precision_mode() == 1)
     hipLaunchKernelGGL(attn_bwd_k_kernel<1>, dim3(a.nb * nprob), dim3(NT), 0, pzn_hip_stream(stream), a);
   else

@@ -85,6 +85,7 @@ __device__ __forceinline__ floatx16 mma6(const bf16x8 (&a)[3], const bf16x8 (&b)
   return c;
 }
 
+struct NoGate {};
 struct NoFill {
   __device__ __forceinline__ void operator()(int) const {}
 };

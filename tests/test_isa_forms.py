@@ -165,6 +165,8 @@ SPILL_FREE = {   # source -> kernels (substring of the mangled name) that must n
     # (ILi3E: the three-plane instantiations, i.e. the default fp32-result path; the single-plane instantiations of the
     #  opt-in bf16 attention mode are held to a bound below, not to zero)
     "attnfused.hip": ("attn_proj_kernelILi3E", "attn_fwd_kernelILi3E", "attn_bwd_q_kernelILi3E", "attn_bwd_k_kernelILi3E"),
+    "attn16.hip": ("attn16_proj_kernelILi3E", "attn16_fwd_kernelILi3E", "attn16_bwd_q_kernelILi3E", "attn16_bwd_k_kernelILi3E",
+                   "attn16_proj_kernelILi1E", "attn16_fwd_kernelILi1E", "attn16_bwd_q_kernelILi1E", "attn16_bwd_k_kernelILi1E"),
     "salevel.hip": ("sa_level_stream_kernel",),
     "outproj.hip": ("outproj_maxpts_kernel",),
     "pointmlp.hip": ("point_mlp3_fwd_kernel", "point_mlp3_bwd_kernel"),

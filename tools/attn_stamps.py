@@ -23,10 +23,13 @@ def build(extra=(), suffix=""):
     from puzzlenet_amd import build as pb
     pb.build()
     os.makedirs(os.path.join(PKG, "_obj_stamps"), exist_ok=True)
-    o = os.path.join(PKG, "_obj_stamps", f"attnfused{suffix}.o")
-    flags = dict(pb.SOURCES)["attnfused.hip"]
-    subprocess.check_call([pb.hipcc()] + pb.COMMON + flags + ["-DATTN_STAMPS", *extra, "-c", os.path.join(pb.CSRC, "attnfused.hip"), "-o", o])
-    objs = [os.path.join(pb.OBJ, s.replace(".hip", ".o")) for s, _ in pb.SOURCES if s != "attnfused.hip"] + [o]
+    stamped = ("attnfused.hip", "attn16.hip")
+    objs = [os.path.join(pb.OBJ, s.replace(".hip", ".o")) for s, _ in pb.SOURCES if s not in stamped]
+    for src in stamped:
+        o = os.path.join(PKG, "_obj_stamps", src.replace(".hip", f"{suffix}.o"))
+        flags = dict(pb.SOURCES)[src]
+        subprocess.check_call([pb.hipcc()] + pb.COMMON + flags + ["-DATTN_STAMPS", *extra, "-c", os.path.join(pb.CSRC, src), "-o", o])
+        objs.append(o)
     lib = STAMP_LIB.replace(".so", f"{suffix}.so")
     subprocess.check_call([pb.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     print(lib)
@@ -50,7 +53,8 @@ def run(Bs):
     from puzzlenet_amd import _lib, ops
     _lib.LIB_PATH = os.environ.get("PZN_STAMP_LIB", STAMP_LIB)
     lib = _lib.load()
-    rd = lib.pzn_attn_fused_read_stamps
+    rd = lib.pzn_attn16_read_stamps if lib.pzn_attn_fused_rows() == 16 else lib.pzn_attn_fused_read_stamps
+    print("rows per wavefront tile:", lib.pzn_attn_fused_rows())
     rd.restype = ctypes.c_int
     rd.argtypes = [ctypes.c_void_p, ctypes.c_int]
     dev = torch.device("cuda:0")

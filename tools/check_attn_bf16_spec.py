@@ -63,7 +63,7 @@ def main():
     dkk, dvv, dx = mk(M, dk), mk(M, E), mk(M, E)
     _lib.call("pzn_attn_fused_bwd_k", 1, P([qrp]), P([krp]), P([vrp]), P([darp]), P([W]), P([lse]),
               P([delta]), P([u]), P([dqt]), B, P([dkk]), P([dvv]), P([dx]), st)
-    untile = lambda x_, F_: x_.view(M // 32, F_ // 32, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(M, F_)
+    untile = ops.attention_tile_image_rows
     got = dict(r=r, t=t, map=amap, lse=lse, dz=dz, delta=delta, dq=dq, u=untile(u, E), dk=dkk, dv=dvv, dx=dx)
     args = (x.view(B, L, E), wq, bq, wk, bk, wv, bv, wo, bo, dr.view(B, L, E))
     spec, exact = T._attn_block_bf16_spec(*args), T._attn_block_ref64(*args)

@@ -79,8 +79,9 @@ def main():
     LSE = torch.logsumexp(s, dim=-1)
     for name, got, want in (("r", r, rr), ("t", t, tt), ("map", amap, Pm), ("lse", lse, LSE), ("dz", dz, DZ), ("delta", delta, dl),
                             ("dq", dq, DQ),
-                            ("u", u.view(M // 32, E // 32, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(M, E), U), ("dk", dkk, DKr), ("dv", dvv, DVr), ("dx", dx, DX)):
-        print(f"{name:6s} rel {rel(got.view(-1), want.reshape(-1)):.3e}")
+                            ("u", ops.attention_tile_image_rows(u, E), U), ("dk", dkk, DKr), ("dv", dvv, DVr), ("dx", dx, DX)):
+        print(f"{name:6s} rel {rel(got.reshape(-1), want.reshape(-1)):.3e}")
+    print("dq tile image == dq rows:", bool(torch.equal(ops.attention_tile_image_rows(dqt, dk), dq)), " rows mode", lib.pzn_attn_fused_rows())
 
 
 if __name__ == "__main__":
