@@ -524,7 +524,7 @@ def main():
         #     stages of their own, roofline_emd / roofline_pool_bwd; their largest single kernels are listed in
         #     `largest_multi_kernel_entries` with the committed profile's figures so that the ranking can be checked.)
         single = {
-            "pzn_attn_fused_fwd": ("attn_fwd_kernel", "csrc/attnfused.hip: scores, softmax, PV, x - a, out projection, x + relu(.) for 32 points per wavefront (model5_b.py:67-75, 83-101)"),
+            "pzn_attn_fused_fwd": ("attn_fwd_kernel", "csrc/attnfused.hip: scores, softmax, PV, x - a, out projection, x + relu(.) for 16 points per wavefront (model5_b.py:67-75, 83-101)"),
             "pzn_attn_fused_bwd_q": ("attn_bwd_q_kernel", "csrc/attnfused.hip: query side of the block's backward (dz, dt, da image, dP, recomputed P, delta, dS, dq)"),
             "pzn_attn_fused_bwd_k": ("attn_bwd_k_kernel", "csrc/attnfused.hip: key side of the block's backward (S, P, dP, dS, dk, dv, dx = u + dq Wq + dk Wk + dv Wv)"),
             "pzn_attn_fused_proj": ("attn_proj_kernel", "csrc/attnfused.hip: q, k, v projection into bf16-plane images"),

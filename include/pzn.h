@@ -441,9 +441,6 @@ int pzn_attn_block_bwd_f32(const float* x, const float* Wq, const float* Wk, con
  *   wgrads: the eight parameter gradients from dz, t, dq, dk, dv and the block input x (one problem per call). */
 int pzn_attn_fused_supported(int L, int E, int dk);
 size_t pzn_attn_fused_weight_bytes(void);
-/* rows per wavefront tile of the chained kernels in this process: 32 or 16 (environment PZN_ATTN_ROWS, read once).  Only the
- * layout of the buffers PRIVATE to the kernels depends on it (images, gate words, the u / dq tile images). */
-int pzn_attn_fused_rows(void);
 size_t pzn_attn_fused_qk_image_bytes(int B);
 size_t pzn_attn_fused_v_image_bytes(int B);
 int pzn_attn_fused_prep_weights(const float* Wq, const float* Wk, const float* Wv, const float* Wo,

@@ -57,7 +57,6 @@ SIGNATURES = {
     "pzn_attn_get_precision": (_c_i, []),
     "pzn_attn_fused_supported": (_c_i, [_c_i, _c_i, _c_i]),
     "pzn_attn_fused_weight_bytes": (_c_sz, []),
-    "pzn_attn_fused_rows": (_c_i, []),
     "pzn_attn_fused_qk_image_bytes": (_c_sz, [_c_i]),
     "pzn_attn_fused_v_image_bytes": (_c_sz, [_c_i]),
     "pzn_attn_fused_prep_weights": (_c_i, [_c_f] * 6),

@@ -34,7 +34,6 @@ SOURCES = [
     ("chamfer.hip", NOSLP),
     ("gemm.hip", NOSLP),
     ("attnfused.hip", NOSLP),
-    ("attn16.hip", NOSLP),
     ("salevel.hip", NOSLP),
     ("outproj.hip", NOSLP),
     ("pointmlp.hip", NOSLP),

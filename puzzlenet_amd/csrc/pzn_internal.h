@@ -5,21 +5,6 @@
 
 // gemm.hip: 0 = attention products on the split-precision path (fp32 results), 1 = single bf16 MFMAs (pzn_attn_set_precision)
 int pzn_attn_precision_mode();
-int pzn_attn_rows_mode();   // 32 | 16 (attn16.hip)
-int pzn_attn16_prep_weights(int n, const float* const* Wq, const float* const* Wk, const float* const* Wv, const float* const* Wo,
-                            void* const* planes, hipStream_t st);
-int pzn_attn16_proj(int nprob, const float* const* x, const void* const* w, const float* const* bq, const float* const* bk,
-                    const float* const* bv, int B, void* const* qrp, void* const* krp, void* const* vrp, hipStream_t st);
-int pzn_attn16_fwd(int nprob, const float* const* x, const void* const* qrp, const void* const* krp, const void* const* vrp,
-                   const void* const* w, const float* const* bo, int B, float* const* r, float* const* t, void* const* mask,
-                   float* const* map, float* const* lse, int map_accumulate, float map_scale, hipStream_t st);
-int pzn_attn16_bwd_q(int nprob, const float* const* dr, int ld_dr, const float* const* dr2, int ld_dr2, const void* const* mask,
-                     const void* const* qrp, const void* const* krp, const void* const* vrp, const void* const* w, int B,
-                     float* const* dz, float* const* u, float* const* dq, float* const* dqt, void* const* darp,
-                     float* const* delta, hipStream_t st);
-int pzn_attn16_bwd_k(int nprob, const void* const* qrp, const void* const* krp, const void* const* vrp, const void* const* darp,
-                     const void* const* w, const float* const* lse, const float* const* delta, const float* const* u,
-                     const float* const* dq, int B, float* const* dk, float* const* dv, float* const* dx, hipStream_t st);
 
 // poolbwd.hip: sparse backward of linear + ReLU + max over 32 neighbours.
 //   dh != NULL: dh[G*32, C1] = scatter(dout) W, ReLU-masked by h when h != NULL (overwritten)

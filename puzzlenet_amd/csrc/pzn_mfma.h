@@ -1,4 +1,4 @@
-// pzn_mfma.h — building blocks of the chained matrix-core kernels (attnfused.hip, salevel.hip, outproj.hip), gfx950 only:
+// pzn_mfma.h — building blocks of the chained matrix-core kernels (attnfused.hip via pzn_mfma16.h, salevel.hip, outproj.hip), gfx950 only:
 // bf16x3 split precision, fragment reads from LDS as inline asm with counted waits (two tiles ahead), the LDS-DMA slab
 // ring (three slots, two slabs in flight, one barrier per slab), compile-time loops.  Included inside an anonymous
 // namespace by each translation unit (which includes <type_traits> and pzn_common.h first).
@@ -161,54 +161,11 @@ __device__ __forceinline__ void kstep_rp(floatx16 (&acc)[RT], uint32_t lane_addr
 }
 
 // =====================================================================================================================
-// The attention kernels' forms of the above, with the number of planes as a template parameter:
+// Forms with the number of planes as a template parameter (the attention kernels, pzn_mfma16.h):
 //   NPL = 3: split precision (x = x1 + x2 + x3, six MFMAs per product, fp32-GEMM accuracy) - the default path;
 //   NPL = 1: every operand rounded to ONE bf16 plane, one MFMA per product, fp32 accumulation (the opt-in bf16 attention
 //            mode, pzn_attn_set_precision(1) / BASELINE configs[4]).  Images and slabs keep their layout; only plane 0 is
 //            written, fetched and read.
-template <int NPL>
-__device__ __forceinline__ floatx16 mma_n(bf16x8 a0, bf16x8 a1, bf16x8 a2, const bf16x8 (&b)[3], floatx16 c) {
-  if constexpr (NPL == 3) {
-    return mma6v(a0, a1, a2, b, c);
-  } else {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[0], c, 0, 0, 0);
-  }
-}
-
-// B fragment of the next k-step, a pair of values at a time (see BNext)
-template <int NPL>
-struct BNextN {
-  uint32_t w[3][4];
-  __device__ __forceinline__ void put(float x0, float x1, int j) {
-    if constexpr (NPL == 3) {
-      split_pair(x0, x1, w[0][j], w[1][j], w[2][j]);
-    } else {
-      const floatx2 x = {x0, x1};
-      w[0][j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
-    }
-  }
-  template <bool NEG = false>
-  __device__ __forceinline__ void pair(const floatx16& x, int s, int j) {
-    const float x0 = x[8 * s + 2 * j], x1 = x[8 * s + 2 * j + 1];
-    put(NEG ? -x0 : x0, NEG ? -x1 : x1, j);
-  }
-  // the same with the values gated by bits (bit0 + 8 s + 2 j) and the next one of `word` (a ReLU mask)
-  __device__ __forceinline__ void pair_gated(const floatx16& x, int s, int j, uint32_t word, int bit0) {
-    const int i = 8 * s + 2 * j;
-    put((word >> (bit0 + i)) & 1u ? x[i] : 0.f, (word >> (bit0 + i + 1)) & 1u ? x[i + 1] : 0.f, j);
-  }
-  __device__ __forceinline__ void get(bf16x8 (&b)[3]) const {
-#pragma unroll
-    for (int p = 0; p < NPL; ++p) b[p] = __builtin_bit_cast(bf16x8, make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]));
-  }
-};
-template <int NPL, bool NEG = false>
-__device__ __forceinline__ void make_bn(const floatx16& x, int s, bf16x8 (&b)[3]) {
-  BNextN<NPL> t;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) t.template pair<NEG>(x, s, j);
-  t.get(b);
-}
 
 // asm fragment reads (see RP_ISSUE): NPL reads per tile, counted waits in units of reads
 template <int NPL, int O0, int O1, int O2>
@@ -227,113 +184,16 @@ __device__ __forceinline__ void rp_wait(bf16x8 (&a)[3]) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[0]) : "n"(N));
 }
 
-// kstep_rp (two tiles ahead) with NPL planes
-template <int RT, int NPL, class Fill = NoFill>
-__device__ __forceinline__ void kstep_rp_n(floatx16 (&acc)[RT], uint32_t lane_addr, const bf16x8 (&b)[3], const Fill& fill = Fill()) {
-  static_assert(RT >= 4, "pipeline depth");
-  bf16x8 f[3][3];
-  rp_issue<NPL, 0, RT * 1024, 2 * RT * 1024>(lane_addr, f[0]);
-  rp_issue<NPL, 1024, (RT + 1) * 1024, (2 * RT + 1) * 1024>(lane_addr, f[1]);
-  static_for<0, RT>([&](auto ic) {
-    constexpr int rt = decltype(ic)::value;
-    constexpr int cur = rt % 3, nxt = (rt + 2) % 3;
-    if constexpr (rt + 2 < RT) {
-      rp_issue<NPL, (rt + 2) * 1024, (RT + rt + 2) * 1024, (2 * RT + rt + 2) * 1024>(lane_addr, f[nxt]);
-      rp_wait<NPL, 2 * NPL>(f[cur]);
-    } else if constexpr (rt + 1 < RT) {
-      rp_wait<NPL, NPL>(f[cur]);
-    } else {
-      rp_wait<NPL, 0>(f[cur]);
-    }
-    acc[rt] = mma_n<NPL>(f[cur][0], f[cur][1], f[cur][2], b, acc[rt]);
-    fill(rt);
-  });
-}
-
-// ---- the same step with its LAST tile deferred across the next barrier ---------------------------------------------
-// Behind a step's barrier the first fragment reads of the new slab have nobody to hide behind (one wavefront per SIMD).
-// The deferred forms keep the last tile's fragments in registers (Stash) when a step ends and issue its MFMAs at the
-// head of the NEXT step, right behind that step's first reads: bprev is the B operand of the step the stash belongs to
-// (still intact: the B fragments are double-buffered), first / last fold to constants in the unrolled loops (first:
-// nothing stashed yet; last: the tile is multiplied at once).  Every accumulator still receives its products in the same
-// order: results are bit-identical to the plain forms.
-struct Stash {
-  bf16x8 a[3];
-};
-
-template <int RT, int NPL, class Fill = NoFill>
-__device__ __forceinline__ void kstep_rp_d(floatx16 (&acc)[RT], uint32_t lane_addr, const bf16x8 (&b)[3], const bf16x8 (&bprev)[3],
-                                           Stash& st, bool first, bool last, const Fill& fill = Fill()) {
-  static_assert(RT >= 4, "pipeline depth");
-  bf16x8 f[3][3];
-  rp_issue<NPL, 0, RT * 1024, 2 * RT * 1024>(lane_addr, f[0]);
-  rp_issue<NPL, 1024, (RT + 1) * 1024, (2 * RT + 1) * 1024>(lane_addr, f[1]);
-  __builtin_amdgcn_sched_barrier(0);
-  if (!first) acc[RT - 1] = mma_n<NPL>(st.a[0], st.a[1], st.a[2], bprev, acc[RT - 1]);
-  static_for<0, RT - 1>([&](auto ic) {
-    constexpr int rt = decltype(ic)::value;
-    constexpr int cur = rt % 3, nxt = (rt + 2) % 3;
-    if constexpr (rt + 2 < RT) {
-      rp_issue<NPL, (rt + 2) * 1024, (RT + rt + 2) * 1024, (2 * RT + rt + 2) * 1024>(lane_addr, f[nxt]);
-      rp_wait<NPL, 2 * NPL>(f[cur]);
-    } else {
-      rp_wait<NPL, NPL>(f[cur]);
-    }
-    acc[rt] = mma_n<NPL>(f[cur][0], f[cur][1], f[cur][2], b, acc[rt]);
-    fill(rt);
-  });
-  constexpr int lst = (RT - 1) % 3;
-  rp_wait<NPL, 0>(f[lst]);
-#pragma unroll
-  for (int p = 0; p < NPL; ++p) st.a[p] = f[lst][p];
-  if (last) acc[RT - 1] = mma_n<NPL>(st.a[0], st.a[1], st.a[2], b, acc[RT - 1]);
-}
-
-// ---- transposed reads of an Rp image ("T use") --------------------------------------------------------------------
-// One Rp image of M[n][F] serves both kinds of product.  With k = feature it is streamed in plain slabs
-// ([plane][row tile][lane][16 B], ds_read_b128).  With k = ROW n (the operand is M^T[f][n]) the same bytes are fetched
-// in a different cut and read with ds_read_b64_tr_b16 (hardware transpose of 4 x 16 blocks of 16-bit elements: in a
-// 16-lane group lane 4q+p supplies the 8-byte unit (row q, columns 4p..4p+3) and receives column (lane & 15), rows
-// 0..3).  The 8-byte halves of an Rp chunk are exactly such units: the chunk of lane (r, h) of k-step ks_f holds row r,
-// features 16 ks_f + 4h + {0..3} and 16 ks_f + 8 + 4h + {0..3}.
-//
-// T-use slab of k-step kk (16 rows n = 16 kk .. 16 kk + 15, all F features): [plane][ks_f = 0 .. F/16-1] blocks of 512
-// bytes = the 32 chunks (r16 = n & 15, h) of that (plane, ks_f), at position
-//     pos(r16, h; ks_f) = (r16 & 3) + 4 h + 8 (((r16 >> 2) ^ ks_f) & 1) + 16 (r16 >> 3)
-// (the ks_f parity in bit 3 separates the two feature halves of a 32-lane service group: conflict-free).  The fragment
-// of feature tile ft, plane p for the lane (g = lane >> 4, i = lane & 15; q = i >> 2, pp = i & 3, hp = g >> 1, gb = g & 1):
-//     lo (rows 4 hp + q) at  TrAddr + p PLS + 1024 ft,   hi (rows 8 + 4 hp + q) 256 bytes further,
-//     TrAddr = slab + 512 gb + 16 (q + 4 (pp & 1) + 8 (gb ^ hp)) + 8 (pp >> 1),   PLS = 32 F bytes per plane.
-// The k order of the fragment (k = 8 hp + j <-> row perm(hp, j) = 8 (j >> 2) + 4 hp + (j & 3)) is the order in which an
-// accumulator's registers come out as a B operand, as for the Rp chunks themselves.
-__device__ __forceinline__ uint32_t tr_lane_addr(uint32_t slab_addr, int lane) {
-  const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, hp = g >> 1, gb = g & 1;
-  return slab_addr + (uint32_t)(512 * gb + 16 * (q + 4 * (pp & 1) + 8 * (gb ^ hp)) + 8 * (pp >> 1));
-}
-// per-lane part of the SOURCE address of a T-use DMA piece (1 KB = the blocks ks_f even | odd of one plane): lane L
-// writes position L & 31 of block L >> 5, i.e. fetches the chunk (r16, h) that belongs there
-__device__ __forceinline__ uint32_t tr_src_lane_off(int lane) {
-  const int blk = lane >> 5, pos = lane & 31;
-  const int q = pos & 3, hs = (pos >> 2) & 1, x = (pos >> 3) & 1, hi = pos >> 4;
-  const int r16 = q + 4 * (x ^ blk) + 8 * hi;
-  return (uint32_t)(blk * (3 * 8 * 1024) + (hs * 32 + r16) * 16);
-}
-
+// ---- transposed reads of a plane image ("T use") -------------------------------------------------------------------
+// One image of M[n][F] serves both kinds of product.  With k = feature it is streamed in plain slabs (ds_read_b128).
+// With k = ROW n (the operand is M^T[f][n]) the same bytes are fetched in a different cut - the LDS-DMA's per-lane
+// source address does the re-arrangement - and read with ds_read_b64_tr_b16 (hardware transpose of 4 x 16 blocks of
+// 16-bit elements: in a 16-lane group lane 4q+p supplies the 8-byte unit (row q, columns 4p..4p+3) and receives column
+// (lane & 15), rows 0..3).  The 8-byte halves of an image chunk are exactly such units (pzn_mfma16.h has the cut).
 // the fragment of one tile: lo / hi halves of NPL planes (2 NPL reads), counted waits in units of reads
 struct TrFrag {
   bf16x4 lo[3], hi[3];
 };
-template <int NPL, int OFF, int PLS>
-__device__ __forceinline__ void tr_issue(uint32_t addr, TrFrag& t) {
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.lo[0]) : "v"(addr), "n"(OFF));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.hi[0]) : "v"(addr), "n"(OFF + 256));
-  if constexpr (NPL == 3) {
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.lo[1]) : "v"(addr), "n"(OFF + PLS));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.hi[1]) : "v"(addr), "n"(OFF + PLS + 256));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.lo[2]) : "v"(addr), "n"(OFF + 2 * PLS));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.hi[2]) : "v"(addr), "n"(OFF + 2 * PLS + 256));
-  }
-}
 template <int NPL, int N>
 __device__ __forceinline__ void tr_wait(TrFrag& t) {
   if constexpr (NPL == 3)
@@ -345,62 +205,6 @@ template <int NPL>
 __device__ __forceinline__ void tr_join(const TrFrag& t, bf16x8 (&a)[3]) {
 #pragma unroll
   for (int p = 0; p < NPL; ++p) a[p] = __builtin_shufflevector(t.lo[p], t.hi[p], 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-// one k-step of acc[ft] += A_ft B with A read transposed from a T-use slab: rows of A = feature 32 ft + lane % 32.
-// ta = tr_lane_addr of the slab, KOFF = byte offset of the k-step inside it (compile time).  Two tiles ahead, counted waits.
-template <int FT, int F, int KOFF, int NPL, class Fill = NoFill>
-__device__ __forceinline__ void kstep_tr(floatx16 (&acc)[FT], uint32_t ta, const bf16x8 (&b)[3], const Fill& fill = Fill()) {
-  constexpr int PLS = 32 * F;
-  TrFrag t[3];
-  tr_issue<NPL, KOFF, PLS>(ta, t[0]);
-  if constexpr (FT > 1) tr_issue<NPL, KOFF + 1024, PLS>(ta, t[1]);
-  static_for<0, FT>([&](auto ic) {
-    constexpr int ft = decltype(ic)::value;
-    constexpr int cur = ft % 3, nxt = (ft + 2) % 3;
-    if constexpr (ft + 2 < FT) {
-      tr_issue<NPL, KOFF + 1024 * (ft + 2), PLS>(ta, t[nxt]);
-      tr_wait<NPL, 4 * NPL>(t[cur]);
-    } else if constexpr (ft + 1 < FT) {
-      tr_wait<NPL, 2 * NPL>(t[cur]);
-    } else {
-      tr_wait<NPL, 0>(t[cur]);
-    }
-    bf16x8 a[3];
-    tr_join<NPL>(t[cur], a);
-    acc[ft] = mma_n<NPL>(a[0], a[1], a[2], b, acc[ft]);
-    fill(ft);
-  });
-}
-
-// kstep_tr with its last tile deferred across the next barrier (see kstep_rp_d)
-template <int FT, int F, int KOFF, int NPL, class Fill = NoFill>
-__device__ __forceinline__ void kstep_tr_d(floatx16 (&acc)[FT], uint32_t ta, const bf16x8 (&b)[3], const bf16x8 (&bprev)[3],
-                                           Stash& st, bool first, bool last, const Fill& fill = Fill()) {
-  static_assert(FT >= 4, "pipeline depth");
-  constexpr int PLS = 32 * F;
-  TrFrag t[3];
-  tr_issue<NPL, KOFF, PLS>(ta, t[0]);
-  tr_issue<NPL, KOFF + 1024, PLS>(ta, t[1]);
-  __builtin_amdgcn_sched_barrier(0);
-  if (!first) acc[FT - 1] = mma_n<NPL>(st.a[0], st.a[1], st.a[2], bprev, acc[FT - 1]);
-  static_for<0, FT - 1>([&](auto ic) {
-    constexpr int ft = decltype(ic)::value;
-    constexpr int cur = ft % 3, nxt = (ft + 2) % 3;
-    if constexpr (ft + 2 < FT) {
-      tr_issue<NPL, KOFF + 1024 * (ft + 2), PLS>(ta, t[nxt]);
-      tr_wait<NPL, 4 * NPL>(t[cur]);
-    } else {
-      tr_wait<NPL, 2 * NPL>(t[cur]);
-    }
-    bf16x8 a[3];
-    tr_join<NPL>(t[cur], a);
-    acc[ft] = mma_n<NPL>(a[0], a[1], a[2], b, acc[ft]);
-    fill(ft);
-  });
-  tr_wait<NPL, 0>(t[(FT - 1) % 3]);
-  tr_join<NPL>(t[(FT - 1) % 3], st.a);
-  if (last) acc[FT - 1] = mma_n<NPL>(st.a[0], st.a[1], st.a[2], b, acc[FT - 1]);
 }
 
 // ---- slab ring: global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, destination =
@@ -424,40 +228,6 @@ struct Ring {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane * 16),
                                        (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + piece * 1024), 16, 0, 0);
     }
-  }
-  // piece i (of NPW) of this wavefront only: lets a caller spread a slab's DMA instructions over a step.
-  // NPL = 1: only the pieces of plane 0 (the first PPP pieces of a plain slab) are fetched.
-  template <int NPL = 3, int PPP = 8>
-  __device__ __forceinline__ void issue1(const unsigned char* src, int slot, int i) const {
-    if (NPL == 1 && i >= PPP / 4) return;      // (i is a constant in the unrolled callers: no run-time test; nw = 4)
-    const int piece = i * nw + wave;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane * 16),
-                                     (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + piece * 1024), 16, 0, 0);
-  }
-  // piece i (of 6) of this wavefront of a T-use slab (see tr_lane_addr) of an Rp image with 8 row tiles.
-  // F = 256: the slab is k-step kk0 (16 rows), 24 pieces j = (plane j >> 3, ks_f pair j & 7).
-  // F = 64: the slab holds the four k-steps kk0 .. kk0 + 3, 6 pieces each: j % 6 = (plane >> 1, ks_f pair & 1).
-  // tsrc = tr_src_lane_off(lane).  The LDS side is piece-linear like every other slab.
-  template <int F, int NPL = 3>
-  __device__ __forceinline__ void issue1_t(const unsigned char* img, uint32_t tsrc, int kk0, int slot, int i) const {
-    int j = i * nw + wave, kk, plane, ksf0, dst;
-    if (NPL == 1) {      // plane 0 only: 8 pieces per slab, two per wavefront (nw = 4)
-      if (i >= 2) return;
-      plane = 0;
-      if (F == 256) {
-        kk = kk0, ksf0 = 2 * j, dst = j * 1024;
-      } else {
-        kk = kk0 + (j >> 1), ksf0 = 2 * (j & 1), dst = (j >> 1) * 6144 + (j & 1) * 1024;
-      }
-    } else if (F == 256) {
-      kk = kk0, plane = j >> 3, ksf0 = 2 * (j & 7), dst = j * 1024;
-    } else {
-      const int m = j % 6;
-      kk = kk0 + j / 6, plane = m >> 1, ksf0 = 2 * (m & 1), dst = j * 1024;
-    }
-    const unsigned char* src = img + ((ksf0 * 3 + plane) * 8 + (kk >> 1)) * 1024 + (kk & 1) * 256 + tsrc;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(lds + slot * slot_bytes + dst), 16, 0, 0);
   }
   __device__ __forceinline__ const unsigned char* slot(int s) const { return lds + s * slot_bytes; }
   __device__ __forceinline__ uint32_t lane_addr(int s) const { return slot_addr(s) + (uint32_t)lane * 16u; }
@@ -496,14 +266,3 @@ __device__ __forceinline__ int logical_block(int bid, int nb) {
   if (nb & 7) return bid;
   return (bid & 7) * (nb >> 3) + (bid >> 3);
 }
-
-// the lane id from the hardware (two instructions) instead of a register kept alive since the kernel's first line
-// (asm volatile: two calls are two computations; the builtin form is folded with every earlier one and the value kept)
-__device__ __forceinline__ int fresh_lane() {
-  int l;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-  return l;
-}
-
-__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
-

@@ -219,7 +219,7 @@ _BN_FUSED = os.environ.get("PZN_BN_FUSED", "1") != "0"     # tuning aid
 _ATTN_CHAIN = os.environ.get("PZN_ATTN_CHAIN", "1") != "0"     # tuning aid: 0 = four autograd nodes + cat + linear
 _ATTN_FUSED = os.environ.get("PZN_ATTN_FUSED", "1") != "0"     # tuning aid: 0 = the composed block kernels (gemm.hip)
 # 1 = both encoders' chains in the same launches on one stream.  Measured slower than one chain per encoder and stream
-# (10.5 vs 10.2 ms per step): a single encoder's launch is 128 workgroups at one wavefront per SIMD, so the two streams
+# (10.5 vs 10.2 ms per step in round 3, 8.2 vs 7.9 in round 4): a single encoder's launch is 128 workgroups, one per CU, so the two streams
 # already fill the chip, and the joint launches take the stems' overlap away.
 _ATTN_DUAL = os.environ.get("PZN_ATTN_DUAL", "0") != "0"
 _EMD_OWN_STREAM = int(os.environ.get("PZN_EMD_OWN_STREAM", "0"))   # tuning aid: 1 = the N x N EMD on a third stream, 2 = a high-priority one
@@ -364,7 +364,7 @@ class TouchedRegraster(_Base):
             xf_m.record_stream(side)
             if _ATTN_FUSED and _ATTN_DUAL and ops.attention_chain_fused_available():
                 # the two encoders' stems on two streams, then BOTH attention chains in the same launches on this one
-                # (a launch of one encoder is 128 four-wave workgroups at one wavefront per SIMD: half the chip)
+                # (a launch of one encoder is 128 workgroups of eight wavefronts, one per CU: half the chip)
                 with torch.cuda.stream(side):
                     x2_m, f2f_m, xf_m2 = self.Encoder2.stem(mrpc, plan_m, xf_m)
                 x2_f, f2f_f, xf_f2 = self.Encoder.stem(fpc, plan_f, xf_f)

@@ -1123,13 +1123,10 @@ def attention_chain_fused_available():
 
 
 def attention_tile_image_rows(img, F):
-    """A register-order tile image the chained kernels pass to each other (u, dq), as rows [M, F] - for checks only.
-    32-row tiles: [row tile][feature tile][g][h][r][e], feature = 32 ft + 8 g + 4 h + e; 16-row tiles (csrc/attn16.hip):
-    [row tile][feature tile][g][c][r], feature = 16 ft + 4 g + r."""
+    """A register-order tile image the chained kernels pass to each other (u, dq), as rows [M, F] - for checks only:
+    [16-row tile][feature tile][g][c][r], feature = 16 ft + 4 g + r (csrc/pzn_mfma16.h, store_tiles16)."""
     M = img.numel() // F
-    if _lib.load().pzn_attn_fused_rows() == 16:
-        return img.view(M // 16, F // 16, 4, 16, 4).permute(0, 3, 1, 2, 4).reshape(M, F)
-    return img.view(M // 32, F // 32, 4, 2, 32, 4).permute(0, 4, 1, 2, 3, 5).reshape(M, F)
+    return img.view(M // 16, F // 16, 4, 16, 4).permute(0, 3, 1, 2, 4).reshape(M, F)
 
 
 def attention_chain_fused_supported(x, dk, w_out):

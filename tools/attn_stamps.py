@@ -23,7 +23,7 @@ def build(extra=(), suffix=""):
     from puzzlenet_amd import build as pb
     pb.build()
     os.makedirs(os.path.join(PKG, "_obj_stamps"), exist_ok=True)
-    stamped = ("attnfused.hip", "attn16.hip")
+    stamped = ("attnfused.hip",)
     objs = [os.path.join(pb.OBJ, s.replace(".hip", ".o")) for s, _ in pb.SOURCES if s not in stamped]
     for src in stamped:
         o = os.path.join(PKG, "_obj_stamps", src.replace(".hip", f"{suffix}.o"))
@@ -53,8 +53,7 @@ def run(Bs):
     from puzzlenet_amd import _lib, ops
     _lib.LIB_PATH = os.environ.get("PZN_STAMP_LIB", STAMP_LIB)
     lib = _lib.load()
-    rd = lib.pzn_attn16_read_stamps if lib.pzn_attn_fused_rows() == 16 else lib.pzn_attn_fused_read_stamps
-    print("rows per wavefront tile:", lib.pzn_attn_fused_rows())
+    rd = lib.pzn_attn_fused_read_stamps
     rd.restype = ctypes.c_int
     rd.argtypes = [ctypes.c_void_p, ctypes.c_int]
     dev = torch.device("cuda:0")

@@ -81,7 +81,7 @@ def main():
                             ("dq", dq, DQ),
                             ("u", ops.attention_tile_image_rows(u, E), U), ("dk", dkk, DKr), ("dv", dvv, DVr), ("dx", dx, DX)):
         print(f"{name:6s} rel {rel(got.reshape(-1), want.reshape(-1)):.3e}")
-    print("dq tile image == dq rows:", bool(torch.equal(ops.attention_tile_image_rows(dqt, dk), dq)), " rows mode", lib.pzn_attn_fused_rows())
+    print("dq tile image == dq rows:", bool(torch.equal(ops.attention_tile_image_rows(dqt, dk), dq)))
 
 
 if __name__ == "__main__":
