@@ -33,3 +33,24 @@ gaps.sort(reverse=True)
 print("idle total %.2f ms/step in %d gaps/step; largest gaps (us, kernel after the gap):" % (sum(g for g, _ in gaps) / 1e6 / (steps + 1), len(gaps) // (steps + 1)))
 for g, n in gaps[:12]:
     print("  %7.1f  %s" % (g / 1e3, n[:90]))
+# how much of the wall time has exactly one kernel in flight, and which kernels those are (the serial sections)
+ev = []
+for i, (s, e, n, _) in enumerate(sel):
+    ev.append((s, 1, i))
+    ev.append((e, -1, i))
+ev.sort()
+live, last, hist, alone = set(), None, {}, {}
+for t, d, i in ev:
+    if last is not None and t > last and live:
+        k = min(len(live), 4)
+        hist[k] = hist.get(k, 0) + (t - last)
+        if len(live) == 1:
+            nm = sel[next(iter(live))][2]
+            nm = nm.replace("(anonymous namespace)::", "").replace("void ", "")[:70]
+            alone[nm] = alone.get(nm, 0) + (t - last)
+    (live.add if d > 0 else live.discard)(i)
+    last = t
+print("time with k kernels in flight (ms/step): " + "  ".join("%s%d: %.2f" % ("" if k < 4 else ">=", k, v / 1e6 / (steps + 1)) for k, v in sorted(hist.items())))
+print("alone on the chip (ms/step):")
+for nm, v in sorted(alone.items(), key=lambda kv: -kv[1])[:25]:
+    print("  %6.3f  %s" % (v / 1e6 / (steps + 1), nm))
