@@ -64,7 +64,7 @@ class _EarlyGate:
 
 
 class TrainStep:
-    def __init__(self, model, batch, lr, world=1, use_graph=False, warmup=0, prefetch=None):
+    def __init__(self, model, batch, lr, world=1, use_graph=False, warmup=0, prefetch=None, fps_generator=None):
         if use_graph:
             raise _lib.PznError("the HIP-graph step was removed (slower than eager and unsafe with torch.topk's memset "
                                 "nodes on this runtime): see puzzlenet_amd/engine.py")
@@ -89,6 +89,13 @@ class TrainStep:
         self._plans_ahead = None
         self._saved_defer = getattr(model, "defer_emd_loss", False)
         model.defer_emd_loss = True
+        # FPS start indices: the reference draws them from torch's global CPU generator (pointnet_util.py:65) and so does
+        # this runner by default; the plan prefetch makes step k+1's draws before step k runs (and one unused set after
+        # the last step unless step(last=True) says so), which any other consumer of the global generator between steps
+        # would see as a shifted stream: hand in a private generator to keep the two apart
+        self._saved_fps_generator = getattr(model, "fps_generator", None)
+        if fps_generator is not None:
+            model.fps_generator = fps_generator
 
     def _fwd_bwd(self):
         self.grads.zero_()
@@ -116,9 +123,10 @@ class TrainStep:
             cur.wait_stream(side)
         return loss
 
-    def step(self, next_batch=None):
+    def step(self, next_batch=None, last=False):
         """One training step on self.batch.  next_batch: the batch of the FOLLOWING step when it differs (a data loader);
-        this runner then moves on to it.  With `prefetch` the coordinate-only part of the following step (FPS, centroid
+        this runner then moves on to it.  last: no step follows (nothing is prefetched, no start indices are drawn for
+        it).  With `prefetch` the coordinate-only part of the following step (FPS, centroid
         gathers, neighbour searches: model.prefetch_plans) is enqueued first, on a background stream, and runs beside
         this step's kernels instead of standing at the head of the next step; this step uses the plan the previous one
         left.  Work per step is unchanged (one sampling pass per step), only its place in the queue."""
@@ -128,7 +136,7 @@ class TrainStep:
                 self._plans_ahead = model.prefetch_plans(self.batch[0], self.batch[1])
             model.use_plans(self._plans_ahead)
             nb = self.batch if next_batch is None else next_batch
-            self._plans_ahead = model.prefetch_plans(nb[0], nb[1])
+            self._plans_ahead = None if last else model.prefetch_plans(nb[0], nb[1])
         self.loss = self._fwd_bwd()
         if self.world > 1:          # (an extra single-rank runner inside a multi-rank job must not join collectives)
             self.grads.all_reduce_mean()
@@ -140,6 +148,7 @@ class TrainStep:
     def close(self):
         """Give the model back as it was handed in (a later direct model.training_step() returns {'loss': ...} again)."""
         self.model.defer_emd_loss = self._saved_defer
+        self.model.fps_generator = self._saved_fps_generator
         self._plans_ahead = None
         if hasattr(self.model, "use_plans"):
             self.model.use_plans(None)

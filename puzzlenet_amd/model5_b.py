@@ -309,6 +309,7 @@ class TouchedRegraster(_Base):
         self._plan_stream = None
         self._plan_cache = None        # (fpc, mrpc, plans, event, versions) from prefetch_plans, handed over by use_plans
         self.grad_marker = None        # engine.TrainStep (N > 1), see _heads
+        self.fps_generator = None      # CPU generator of the FPS start indices (None = torch's global one, as the reference)
         self.defer_emd_loss = False    # see training_step: the EMD term as a separate backward root (engine.TrainStep)
 
     # ------------------------------------------------------------------ forward
@@ -523,8 +524,12 @@ class TouchedRegraster(_Base):
             return None, None
         B, N, _ = fpc.shape
         dev = fpc.device
-        d1, d2 = torch.randint(0, N, (B,), dtype=torch.long), torch.randint(0, 512, (B,), dtype=torch.long)
-        d3, d4 = torch.randint(0, N, (B,), dtype=torch.long), torch.randint(0, 512, (B,), dtype=torch.long)
+        # fps_generator (a CPU torch.Generator, default None = the global one the reference draws from): with the plan
+        # prefetch the draws of step k+1 are made before step k runs, which shifts the global stream for any other
+        # consumer between steps (a loader's augmentation); a private generator leaves the global one alone
+        gen = getattr(self, 'fps_generator', None)
+        d1, d2 = (torch.randint(0, n_, (B,), dtype=torch.long, generator=gen) for n_ in (N, 512))
+        d3, d4 = (torch.randint(0, n_, (B,), dtype=torch.long, generator=gen) for n_ in (N, 512))
         # ONE asynchronous upload from pinned memory: a pageable `.to(dev)` blocks the host until everything queued
         # before it has run (4 of them per step drained the launch queue at every step start)
         stage = torch.empty((4, B), dtype=torch.long, pin_memory=True)
