@@ -301,3 +301,53 @@ def test_training_step_n8192_bf16_attention(dev):
     assert abs(res[1][0] - ref_loss) <= 2e-2 * abs(ref_loss), (res[1][0], ref_loss)
     assert res[1][0] != res[0][0]                                   # the mode is really on
     np.testing.assert_allclose(res[1][3].numpy(), res[0][3].numpy(), rtol=5e-2, atol=5e-3)      # pose twist
+
+
+@pytest.mark.parametrize("N,B,mode", [(2048, 64, 0), (4096, 64, 0), (8192, 32, 0), (8192, 32, 1)])
+def test_full_per_gpu_batch_eval_vs_oracle_subset(dev, monkeypatch, N, B, mode):
+    """BASELINE configs[1] / [3] / [4] at their FULL per-GPU batch (64 / 64 / 256 / 8 = 32 pairs), checked against the
+    oracle: in eval mode every layer of predict5 is per sample (BatchNorm on running statistics), so samples 0, B / 2 and
+    B - 1 of the full-batch launch must equal the torch-CPU restatement run on those three samples alone - FPS picks of
+    both levels bit for bit, pose twist and boundary logits at the north star's 1e-4.  The start indices of
+    pointnet_util.py:65 are drawn per batch position, so both sides get the same fixed draw (index 0) instead; the
+    running statistics are given non-trivial values first.  mode 1 = configs[4] proper: the bf16 attention mode
+    (pzn_attn_set_precision(1)) against the same fp32 oracle at that mode's tolerance, picks still bit-exact."""
+    from puzzlenet_amd import _lib, synthetic
+    cfg = mr.Cfg(num_points=N, loss_mode=1)
+    lib = _lib.load()
+    old_mode = lib.pzn_attn_get_precision()
+    model, ref = _pair(cfg, dev)
+    with torch.no_grad():           # running statistics other than (0, 1): a pure function of the buffer's name order
+        bufs = [(n_, b_) for n_, b_ in sorted(model.named_buffers()) if b_.dtype.is_floating_point and b_.numel() > 1]
+        for k, (n_, b_) in enumerate(bufs):
+            i = torch.arange(b_.numel(), dtype=torch.float64)
+            u = torch.frac(torch.sin(i * 12.9898 + (k + 1) * 78.233) * 43758.5453).reshape(b_.shape)
+            b_.copy_((1.0 + 0.2 * u if n_.endswith("running_var") else 0.05 * u).to(b_.dtype))
+    ref.load_state_dict(model.state_dict(), strict=True)
+    batch = synthetic.make_batch(B, N, dev, seed=4242 + N)
+    pick = [0, B // 2, B - 1]
+    sub = [t[pick].cpu() for t in batch]
+    real_randint = torch.randint
+
+    def fixed(low, high=None, size=None, **kw):
+        kw.pop("generator", None)
+        return torch.zeros(size, dtype=kw.get("dtype", torch.long))
+    monkeypatch.setattr(torch, "randint", fixed)
+    try:
+        _lib.check(lib.pzn_attn_set_precision(mode), "pzn_attn_set_precision")
+        model.eval()
+        with torch.no_grad():
+            out = model.predict5(batch, B, need=True, training=False)
+            rout = ref.predict5(sub, training=False)
+    finally:
+        monkeypatch.setattr(torch, "randint", real_randint)
+        lib.pzn_attn_set_precision(old_mode)
+    assert np.array_equal(out[2][pick].cpu().numpy(), rout[2].numpy())          # x2 of fpc: FPS of FPS, bit-exact
+    assert np.array_equal(out[4][pick].cpu().numpy(), rout[4].numpy())          # x2 of mrpc
+    rt, at = (1e-4, 1.0) if mode == 0 else (5e-2, 50.0)                          # (bf16 attention: 8 mantissa bits per operand)
+    np.testing.assert_allclose(out[0][pick].cpu().numpy(), rout[0].numpy(), rtol=rt, atol=1e-5 * at)      # pose twist
+    np.testing.assert_allclose(out[3][pick].cpu().numpy(), rout[3].numpy(), rtol=rt, atol=1e-6 * at)      # attention map
+    np.testing.assert_allclose(out[6][pick].cpu().numpy(), rout[6].numpy(), rtol=rt, atol=1e-4 * at)      # boundary logits
+    np.testing.assert_allclose(out[7][pick].cpu().numpy(), rout[7].numpy(), rtol=rt, atol=1e-4 * at)
+    if mode == 1:                                                                # the mode is really on
+        assert not np.allclose(out[0][pick].cpu().numpy(), rout[0].numpy(), rtol=1e-6, atol=1e-8)
