@@ -139,6 +139,17 @@ int pzn_emd_fused_f32(const float* xyz1, const float* xyz2, int B, int n, int m,
                       float* cost, float* g1, float* g2, void* workspace,
                       pzn_stream_t stream);
 
+/* The double instantiation of the three calls (emd_kernel.cu:187, :273, :391 dispatch on the floating type;
+ * csrc/emd64.hip): same layouts in double, workspace of pzn_emd_workspace_bytes_f64(B,n,m) bytes.  model5_b never
+ * calls EMD in double; PyTorchEMD.emd.earth_mover_distance routes double clouds here. */
+size_t pzn_emd_workspace_bytes_f64(int B, int n, int m);
+int pzn_emd_approxmatch_f64(const double* xyz1, const double* xyz2, int B, int n, int m, double* match,
+                            void* workspace, pzn_stream_t stream);
+int pzn_emd_matchcost_f64(const double* xyz1, const double* xyz2, const double* match, int B, int n, int m,
+                          double* cost, pzn_stream_t stream);
+int pzn_emd_matchcost_grad_f64(const double* grad_cost, const double* xyz1, const double* xyz2, const double* match,
+                               int B, int n, int m, double* grad1, double* grad2, pzn_stream_t stream);
+
 /* Measurement aid (bench.py's EMD roofline): byte offset inside the workspace of 1024 uint64 counters the fused entry
  * point leaves behind; their sum x 64 = the (row, point) pair evaluations its passes executed (points without mass and
  * points outside a level's x window are not walked); (size_t)-1 on the single-workgroup path (n, m <= 256: 30 n m). */

@@ -40,10 +40,12 @@ def earth_mover_distance(xyz1, xyz2, transpose=True, materialize_match=False):
         xyz1 = xyz1.transpose(1, 2)
         xyz2 = xyz2.transpose(1, 2)
     assert xyz1.is_cuda and xyz2.is_cuda, "Only support cuda currently."
-    # emd_kernel.cu:187,273,391 dispatch on the floating type (AT_DISPATCH_FLOATING_TYPES).  The gfx950 kernels are fp32:
-    # double clouds are computed in fp32 and the cost (and, through the casts, the gradients) come back as double, so a
-    # caller written against the reference's double instantiation keeps its dtypes (model5_b never calls it in double).
+    # emd_kernel.cu:187,273,391 dispatch on the floating type (AT_DISPATCH_FLOATING_TYPES): float runs the fused gfx950
+    # path, double the literal three-call form on the double kernels (csrc/emd64.hip); anything else (half) is computed
+    # in fp32 and cast back.  model5_b never calls it in double.
     dtype = xyz1.dtype
+    if dtype == torch.float64 and xyz2.dtype == torch.float64:
+        return EarthMoverDistanceFunction.apply(xyz1, xyz2)
     if dtype != torch.float32:
         xyz1, xyz2 = xyz1.float(), xyz2.float()
     cost = EarthMoverDistanceFunction.apply(xyz1, xyz2) if materialize_match else ops.emd_fused(xyz1, xyz2)

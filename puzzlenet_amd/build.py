@@ -31,6 +31,7 @@ SOURCES = [
     ("knn.hip", ["-ffp-contract=off"]),
     ("group.hip", ["-ffp-contract=off"] + NOSLP),
     ("emd.hip", NOSLP),
+    ("emd64.hip", NOSLP),
     ("chamfer.hip", NOSLP),
     ("gemm.hip", NOSLP),
     ("attnfused.hip", NOSLP),

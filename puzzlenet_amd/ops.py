@@ -485,37 +485,50 @@ def _emd_shapes(xyz1, xyz2):
     return xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
 
 
+def _emd_suffix(*ts):
+    """emd_kernel.cu:187,273,391 dispatch on the floating type: fp32 (csrc/emd.hip) or double (csrc/emd64.hip)."""
+    if all(t.dtype == torch.float64 for t in ts):
+        return torch.float64, "f64"
+    return torch.float32, "f32"
+
+
 def emd_approxmatch(xyz1, xyz2):
     """emd_cuda.approxmatch_forward (emd.cpp:24, emd_kernel.cu:171-193) -> match[B,m,n]"""
-    xyz1, xyz2 = _f32(xyz1, "xyz1"), _f32(xyz2, "xyz2")
+    dt, suf = _emd_suffix(xyz1, xyz2)
+    xyz1, xyz2 = _req(xyz1, dt, "xyz1"), _req(xyz2, dt, "xyz2")
     B, n, m = _emd_shapes(xyz1, xyz2)
-    match = torch.empty((B, m, n), dtype=torch.float32, device=xyz1.device)
-    ws = _emd_ws(B, n, m, xyz1.device)
+    match = torch.empty((B, m, n), dtype=dt, device=xyz1.device)
+    if suf == "f64":
+        ws = torch.empty(_lib.load().pzn_emd_workspace_bytes_f64(B, n, m) // 8, dtype=torch.float64, device=xyz1.device)
+    else:
+        ws = _emd_ws(B, n, m, xyz1.device)
     with _on(xyz1.device):
-        _call("pzn_emd_approxmatch_f32", _p(xyz1), _p(xyz2), B, n, m, _p(match), _p(ws), _stream())
+        _call("pzn_emd_approxmatch_" + suf, _p(xyz1), _p(xyz2), B, n, m, _p(match), _p(ws), _stream())
     return match
 
 
 def emd_matchcost(xyz1, xyz2, match):
     """emd_cuda.matchcost_forward (emd.cpp:25, emd_kernel.cu:257-279) -> cost[B]"""
-    xyz1, xyz2, match = _f32(xyz1, "xyz1"), _f32(xyz2, "xyz2"), _f32(match, "match")
+    dt, suf = _emd_suffix(xyz1, xyz2, match)
+    xyz1, xyz2, match = _req(xyz1, dt, "xyz1"), _req(xyz2, dt, "xyz2"), _req(match, dt, "match")
     B, n, m = _emd_shapes(xyz1, xyz2)
-    cost = torch.empty((B,), dtype=torch.float32, device=xyz1.device)
+    cost = torch.empty((B,), dtype=dt, device=xyz1.device)
     with _on(xyz1.device):
-        _call("pzn_emd_matchcost_f32", _p(xyz1), _p(xyz2), _p(match), B, n, m, _p(cost), _stream())
+        _call("pzn_emd_matchcost_" + suf, _p(xyz1), _p(xyz2), _p(match), B, n, m, _p(cost), _stream())
     return cost
 
 
 def emd_matchcost_grad(grad_cost, xyz1, xyz2, match):
     """emd_cuda.matchcost_backward (emd.cpp:26, emd_kernel.cu:373-398) -> [grad1, grad2]"""
-    grad_cost = _f32(grad_cost, "grad_cost")
-    xyz1, xyz2, match = _f32(xyz1, "xyz1"), _f32(xyz2, "xyz2"), _f32(match, "match")
+    dt, suf = _emd_suffix(grad_cost, xyz1, xyz2, match)
+    grad_cost = _req(grad_cost, dt, "grad_cost")
+    xyz1, xyz2, match = _req(xyz1, dt, "xyz1"), _req(xyz2, dt, "xyz2"), _req(match, dt, "match")
     B, n, m = _emd_shapes(xyz1, xyz2)
-    g1 = torch.empty((B, n, 3), dtype=torch.float32, device=xyz1.device)
-    g2 = torch.empty((B, m, 3), dtype=torch.float32, device=xyz1.device)
+    g1 = torch.empty((B, n, 3), dtype=dt, device=xyz1.device)
+    g2 = torch.empty((B, m, 3), dtype=dt, device=xyz1.device)
     with _on(xyz1.device):
-        _call("pzn_emd_matchcost_grad_f32", _p(grad_cost), _p(xyz1), _p(xyz2), _p(match), B, n, m,
-                  _p(g1), _p(g2), _stream())
+        _call("pzn_emd_matchcost_grad_" + suf, _p(grad_cost), _p(xyz1), _p(xyz2), _p(match), B, n, m,
+              _p(g1), _p(g2), _stream())
     return [g1, g2]
 
 
