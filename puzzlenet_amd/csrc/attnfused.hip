@@ -48,11 +48,11 @@ namespace {
 #include "pzn_mfma16.h"
 
 constexpr int L = 256, E = 256, DK = 64;
-constexpr int QK_IMG = 2 * 3 * 16 * 1024;   // Rp16 image of a [256][64] operand, bytes per cloud (= the 32-row form's size)
-constexpr int V_IMG = 8 * 3 * 16 * 1024;    // Rp16 image of a [256][256] operand
+constexpr int QK_IMG = 2 * 3 * 16 * 1024;   // plane image of a [256][64] operand, bytes per cloud
+constexpr int V_IMG = 8 * 3 * 16 * 1024;    // plane image of a [256][256] operand
 
 // byte offsets inside one layer's weight-plane buffer: every matrix as a sequence of 24 KB slabs in consumption order,
-// slab = [plane][8 row tiles][lane][16 B]; same total size as the 32-row planes
+// slab = [plane][8 row tiles][lane][16 B]
 constexpr size_t W_QKV = 0;                          // rows n = (q | k), v[0:128], v[128:256] (3 groups), k = c: 8 x 3 slabs
 constexpr size_t W_O = W_QKV + 24 * SLAB;            // rows o (2 halves), k = c: 8 x 2 slabs
 constexpr size_t W_OT = W_O + 16 * SLAB;             // rows c, k = o
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NT16, 2) void attn_fwd_kernel(FwdArgs a) {
   // ---- S^T = K q^T
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    step_sync(c == 0 ? DPW : DPW);      // (the own-fragment loads are older than both slabs)
+    step_sync(DPW);      // (c == 0: the own-fragment loads are younger than slab 1's pieces: waiting them out is conservative)
     auto fill = [&](int t) {
       if (t < 3) issue1(c + 2, t);
     };
@@ -374,7 +374,13 @@ __global__ __launch_bounds__(NT16, 2) void attn_fwd_kernel(FwdArgs a) {
 }
 
 // ================================================================================================================
-// backward, query side (see attnfused.hip): dz, dt, da image, u = dr + dt, dP, P recomputed, delta, dS, dq
+// backward, query side: the wavefront's 16 points as QUERIES.
+//   dz = dr . gate;  dt^T = Wo^T dz^T;  da = -dt (image for the key-side pass);  dP^T = V da^T;  P^T recomputed;
+//   delta = sum_key P dP;  dS^T = P^T (dP^T - delta) / 8;  dq^T = K^T dS^T;  u = dr + dt (partial dx: the key-side pass
+//   adds dq Wq with its own terms).
+// dr (+ dr2) is read once - the gate is applied where dz is consumed: in the split of the B fragments and in the store of
+// dz, so dr is still there for u = dr + dt -, u is written once, in register order (tile image), and never more than
+// three 64-register accumulator sets are live.
 struct BwdQProb {
   const float* dr;
   const float* dr2;
@@ -554,7 +560,11 @@ __global__ __launch_bounds__(NT16, 2) void attn_bwd_q_kernel(BwdQArgs a) {
 }
 
 // ================================================================================================================
-// backward, key side (see attnfused.hip): the wavefront's 16 points as KEYS against all 256 queries of the cloud
+// backward, key side: the wavefront's 16 points as KEYS against all 256 queries of the cloud (whole-cloud accumulators:
+// every half-slab feeds 48 MFMAs per wavefront).
+//   S = q k^T (key on the lane, query in the registers), P = exp(S/8 - lse_q), dP = da v^T, dS = P (dP - delta_q) / 8,
+//   dk^T = q^T dS, dv^T = da^T P (in this order: dS dies before the dv accumulators are born);
+//   then dx = u + dq Wq + dk Wk + dv Wv for the wavefront's points (u = dr + dt and dq from the query-side pass)
 struct BwdKProb {
   const unsigned char *qrp, *krp, *vrp, *darp;
   const unsigned char* w;
