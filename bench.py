@@ -445,7 +445,7 @@ def main():
         }
         # (4) EMD: vector-ALU / transcendental bound.  The reference's schedule is 10 levels x 3 passes x n*m pair
         #     evaluations (emd_kernel.cu:46-154); the fused path walks only the cloud-2 points that still hold mass and lie
-        #     inside the level's x window, and counts what it evaluates (pzn_emd_walk_counter_offset: 1024 counters in
+        #     inside the level's x window, and counts what it evaluates (pzn_emd_walk_counter_offset: uint64 counters in
         #     units of 64 evaluations), so the evaluations EXECUTED are known (30 n m on the single-workgroup path).  The walks
         #     are packed (v_pk_*: two evaluations per instruction): per TWO evaluations 3 differences, 3 square / sum,
         #     1 scale, 2 v_exp_f32 (8 cycles = two issue slots each), 1 weight, 1-5 accumulations (pass C also sums cost

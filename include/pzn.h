@@ -150,10 +150,13 @@ int pzn_emd_matchcost_f64(const double* xyz1, const double* xyz2, const double* 
 int pzn_emd_matchcost_grad_f64(const double* grad_cost, const double* xyz1, const double* xyz2, const double* match,
                                int B, int n, int m, double* grad1, double* grad2, pzn_stream_t stream);
 
-/* Measurement aid (bench.py's EMD roofline): byte offset inside the workspace of 1024 uint64 counters the fused entry
- * point leaves behind; their sum x 64 = the (row, point) pair evaluations its passes executed (points without mass and
- * points outside a level's x window are not walked); (size_t)-1 on the single-workgroup path (n, m <= 256: 30 n m). */
+/* Measurement aid (bench.py's EMD roofline): byte offset inside the workspace of pzn_emd_walk_counter_count() uint64
+ * counters the fused entry point leaves behind; their sum x 64 = (row, point) evaluations executed (points of exhausted mass
+ * and points outside a level's x window are not walked); counters (16 i + s) * 16, s = 0..15, belong to launch i of the call
+ * (0 = first pass A, 1 + 2 k = pass B and 2 + 2 k = pass C of the k-th level); (size_t)-1 on the single-workgroup path
+ * (n, m <= 256: 30 n m). */
 size_t pzn_emd_walk_counter_offset(int B, int n, int m);
+int pzn_emd_walk_counter_count(void);
 
 /* ------------------------------------------------------------------------ */
 /* Loss tail: model5_b.py:1495-1505 chamfer_loss                            */

@@ -32,6 +32,7 @@ SIGNATURES = {
     "pzn_group_bwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f]),
     "pzn_emd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),
     "pzn_emd_walk_counter_offset": (_c_sz, [_c_i, _c_i, _c_i]),
+    "pzn_emd_walk_counter_count": (_c_i, []),
     "pzn_emd_approxmatch_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_emd_matchcost_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_emd_matchcost_grad_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),

@@ -532,7 +532,7 @@ def emd_matchcost_grad(grad_cost, xyz1, xyz2, match):
     return [g1, g2]
 
 
-EMD_WALK_STATS = None      # bench.py sets this to a list: every fused call appends (walk counters [1024] int64 or None, B, n, m)
+EMD_WALK_STATS = None      # bench.py sets this to a list: every fused call appends (walk counters int64 view or None, B, n, m)
 
 
 class _EmdFused(torch.autograd.Function):
@@ -551,7 +551,7 @@ class _EmdFused(torch.autograd.Function):
             _call("pzn_emd_fused_f32", _p(xyz1), _p(xyz2), B, n, m, _p(cost), _p(g1), _p(g2), _p(ws), _stream())
         if EMD_WALK_STATS is not None:       # measurement only (bench.py): lengths of the active lists the passes walked
             off = _lib.load().pzn_emd_walk_counter_offset(B, n, m)
-            ctr = None if off == 2 ** 64 - 1 else ws.view(torch.int64)[off // 8: off // 8 + 1024]
+            ctr = None if off == 2 ** 64 - 1 else ws.view(torch.int64)[off // 8: off // 8 + _lib.load().pzn_emd_walk_counter_count()]
             EMD_WALK_STATS.append((ctr, B, n, m))
         ctx.save_for_backward(g1, g2)
         return cost
