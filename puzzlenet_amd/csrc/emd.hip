@@ -815,7 +815,7 @@ __global__ __launch_bounds__(EF_T, 8) void emdf_k_kernel(int n, int m, float c, 
 // Pass B: the rows are the entries r of list `buf`; the walk covers all of cloud 1 inside the level's x window.  SUB = 1 ... 16
 // adjacent lanes share a row (64 ... 4 rows per workgroup), each taking every SUB-th point pair of its wavefront's
 // quarter tile; they meet by lane shuffles, the four wavefronts through LDS.  SUB is chosen per pair so that a launch
-// has about two workgroups per CU when the lists are short (emdf_b_kernel).
+// has at least 4 workgroups per CU however short the lists are (emdf_b_kernel; 2 / 4 / 8 per CU measured equal within noise).
 template <int SUB>
 __device__ __forceinline__ void emdf_b_rows(int n, int m, float c, const EmdF& w, int buf, int cnt, int rb,
                                             float4 (*tile)[EF_NP * 2], float win, int lid) {
@@ -928,7 +928,8 @@ __global__ __launch_bounds__(EF_T, 8) void emdf_b_kernel(int n, int m, float c, 
   EMD_STAMP_BEGIN();
   const int cnt = w.cnt[buf][blockIdx.y];
   const int gx = gridDim.x;
-  const int target = max(1, 512 / (int)gridDim.y);      // workgroups per pair that fill the chip twice over
+  const int target = max(1, 1024 / (int)gridDim.y);     // workgroups per pair: 4 - 8 per CU over the launch however short the lists (a workgroup is
+                                                        // then at most an eighth of a CU's share: the launch ends with its most loaded CU)
   int sub = 1;
   while (sub < 16 && ((cnt * sub + 63) >> 6) < target && ((cnt * sub * 2 + 63) >> 6) <= gx) sub <<= 1;
   // Workgroups are dealt round-robin over the XCDs and only the first few row blocks of a pair have rows: rotate the
@@ -998,7 +999,7 @@ int run_fused(const float* xyz1, const float* xyz2, int B, int n, int m, float* 
     const float c = cof(j);
     return c < 0.f ? sqrtf(win_bits / -c) : INFINITY;
   };
-  const int target = 512 / B > 1 ? 512 / B : 1;
+  const int target = 1024 / B > 1 ? 1024 / B : 1;
   const dim3 gb((unsigned)((m + 63) / 64 > target ? (m + 63) / 64 : target), B);
   // A(7); then per level B, the next list, and C fused with the next level's A; the last level ends with a plain C
   hipLaunchKernelGGL((emdf_k_kernel<0, false>), gk, dim3(EF_T), 0, st, n, m, 0.f, cof(7), w, 0, winf(7), 0);

@@ -66,7 +66,35 @@ struct PoolBwdArgs {
   // row pairs that hold a non-zero row (and fetches gates / runs hit loops only for those), and the list sum reads only
   // rows whose bit is set: ~40 % of the 2.1 GB of dh per step are neither written nor read.
   uint32_t* rowmask;
+#ifdef POOL_STAMPS
+  unsigned long long* stamps;   // diagnostic build (tools/pool_stamps.py): [launch % 16][workgroup][8] phase sums of wavefront 0
+#endif
 };
+
+#ifdef POOL_STAMPS
+// phase sums in core clocks (s_memtime), wavefront 0 of every workgroup: PS_MARK(i) adds the time since the previous mark to
+// phase i.  Record: 8 uint64 per workgroup {phases 0..5, groups walked, total}.
+unsigned long long* g_pool_stamps = nullptr;
+int g_pool_launch = 0;
+constexpr int PS_WGS = 1024, PS_LAUNCHES = 16;
+int g_pool_log[PS_LAUNCHES][4];      // {kind: 0 wgrad / 1 dgrad, G, C1, C2} of the launch that filled a slot
+#define PS_BEGIN() unsigned long long ps_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ps_last_ = __builtin_amdgcn_s_memtime(); const unsigned long long ps_t0_ = ps_last_
+#define PS_MARK(I) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ps_[I] += t_ - ps_last_; ps_last_ = t_; } while (0)
+#define PS_COUNT() ps_[6] += 1
+#define PS_END(P)                                                                                     \
+  do {                                                                                                \
+    const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                         \
+    if (threadIdx.x == 0 && (P).stamps && wg_ < PS_WGS) {                                             \
+      ps_[7] = __builtin_amdgcn_s_memtime() - ps_t0_;                                                 \
+      for (int i_ = 0; i_ < 8; ++i_) (P).stamps[(size_t)wg_ * 8 + i_] = ps_[i_];                      \
+    }                                                                                                 \
+  } while (0)
+#else
+#define PS_BEGIN() do {} while (0)
+#define PS_MARK(I) do {} while (0)
+#define PS_COUNT() do {} while (0)
+#define PS_END(P) do {} while (0)
+#endif
 
 __device__ __forceinline__ float4 pb_add_relu(float4 a, float4 q) {
   return make_float4(fmaxf(a.x + q.x, 0.f), fmaxf(a.y + q.y, 0.f), fmaxf(a.z + q.z, 0.f), fmaxf(a.w + q.w, 0.f));
@@ -81,6 +109,7 @@ __global__ __launch_bounds__(NWV * 64) void pool_wgrad_kernel(PoolBwdArgs p) {
   constexpr int T = NWV * 64;
   constexpr bool TWO = NWV == 8;      // two staging rows per thread
   __shared__ __attribute__((aligned(16))) float hbuf[2][32][PB_COLS];
+  PS_BEGIN();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col0 = blockIdx.y * PB_COLS;
   const int ch = wave * CPW + (lane < CPW ? lane : 0);  // this lane's channel in the per-group vector loads
@@ -130,6 +159,7 @@ __global__ __launch_bounds__(NWV * 64) void pool_wgrad_kernel(PoolBwdArgs p) {
   } while (0)
 #define PB_GROUP(buf, x0, x1, q_, av_, gv_, j0_, j1_, gnext)                        \
   do {                                                                              \
+    PS_MARK(0); /* (loop control, previous group's tail) */                        \
     if (regen) {                                                                    \
       x0 = pb_add_relu(x0, q_);                                                     \
       if (TWO) x1 = pb_add_relu(x1, q_);                                            \
@@ -138,9 +168,13 @@ __global__ __launch_bounds__(NWV * 64) void pool_wgrad_kernel(PoolBwdArgs p) {
     if (TWO) *reinterpret_cast<float4*>(&hbuf[buf][(srow + 16) & 31][scol]) = x1;   \
     const int av = av_;                                                             \
     const float gv = gv_;                                                           \
+    PS_MARK(1); /* rows landed (vmcnt), add + ReLU, tile write */                   \
     __syncthreads(); /* one barrier per group: the tile two groups back is free again by construction */ \
+    PS_MARK(2); /* barrier */                                                       \
     PB_ISSUE(gnext, x0, x1, q_, av_, gv_, j0_, j1_);  /* rows of gnext: their indices arrived a round ago */ \
     if (regen) PB_IDX((gnext) + 2 * gs_, j0_, j1_);   /* indices for the round after */ \
+    PS_MARK(3); /* issue of the next loads (address arithmetic; waits for the indices) */ \
+    PS_COUNT();                                                                     \
     dbacc += gv;                                                                    \
     _Pragma("unroll") for (int c = 0; c < CPW; ++c) {                               \
       const int a = __builtin_amdgcn_readlane(av, c);                               \
@@ -151,6 +185,7 @@ __global__ __launch_bounds__(NWV * 64) void pool_wgrad_kernel(PoolBwdArgs p) {
       if (CPW > 8 || gs != 0.f) hr = *reinterpret_cast<const v2f*>(&hbuf[buf][a][2 * lane]); \
       acc[c] += gs * hr;                                                            \
     }                                                                               \
+    PS_MARK(4); /* hit loop */                                                      \
   } while (0)
   // XCD-aware walk (round 3): workgroups x, x + 8, ... share an XCD; XCD x takes the contiguous eighth [x Gx, (x+1) Gx) of
   // the groups - whole clouds - so that a cloud's per-point table is gathered through ONE L2 (PMC: the strided walk fetched
@@ -187,6 +222,8 @@ __global__ __launch_bounds__(NWV * 64) void pool_wgrad_kernel(PoolBwdArgs p) {
     atomicAdd(o + 1, acc[c].y);
   }
   if (p.db && blockIdx.y == 0 && lane < CPW) atomicAdd(p.db + wave * CPW + lane, dbacc);
+  PS_MARK(5); /* atomics */
+  PS_END(p);
   (void)T;
 }
 
@@ -199,6 +236,7 @@ constexpr int PD_ROWS = PD_ROWS_N;  // rows of a group per trip of the row loop 
 template <int NQ>  // C2 = 64 * NQ
 __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];  // [C2][PB_COLS]
+  PS_BEGIN();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col0 = blockIdx.y * PB_COLS;
   const int C2 = NQ * 64;
@@ -208,6 +246,7 @@ __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
         *reinterpret_cast<const float4*>(p.W + (size_t)c * p.C1 + col0 + q4);
   }
   __syncthreads();  // the only barrier: from here on every wavefront walks its own groups
+  PS_MARK(5); /* W slice into LDS */
 
   // XCD-aware walk (see pool_wgrad_kernel): the wavefronts of XCD x stride through the x-th contiguous eighth of the groups
   int gw = blockIdx.x * (PD_T / 64) + wave, nw = gridDim.x * (PD_T / 64), g_end = p.G;
@@ -246,6 +285,8 @@ __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
     float gv[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) av[q] = av_n[q], gv[q] = gv_n[q];
+    PS_MARK(0); /* this group's (arg-max, gradient) vectors landed */
+    PS_COUNT();
     if (g + nw < g_end) PD_PREFETCH(g + nw);
     uint32_t rmask = 0xffffffffu;          // wave-uniform
     if (p.rowmask) {
@@ -324,14 +365,17 @@ __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
     // store the level-1 launch takes 0.122 of its 0.192 ms).
     const int odd = lane & 1;
     float* drow = p.dh + ((size_t)g * 32 + odd) * p.C1 + col0 + 4 * (lane >> 1);
+    PS_MARK(1); /* row mask, the group's indices / Q row / centre requested (and the index waited for) */
     for (int k = 0; k < 32; k += PD_ROWS) {  // PD_ROWS rows per trip: their gate rows are requested first and arrive under the hit loops
       const uint32_t m4 = (rmask >> k) & ((1u << PD_ROWS) - 1u);
       if (m4 == 0) continue;                 // no row of the trip won a channel: nothing fetched, nothing written
       v2f hg[PD_ROWS], ar[PD_ROWS];
 #pragma unroll
       for (int u = 0; u < PD_ROWS; ++u) hg[u] = (m4 >> u) & 1u ? gate_raw(k + u) : v2f{0.f, 0.f};
+      PS_MARK(2); /* gate rows requested */
 #pragma unroll
       for (int u = 0; u < PD_ROWS; ++u) ar[u] = (m4 >> u) & 1u ? row_acc(k + u) : v2f{0.f, 0.f};
+      PS_MARK(3); /* hit loops */
 #pragma unroll
       for (int u = 0; u < PD_ROWS; ++u) {
         if (p.gP) hg[u] = gate_of(hg[u], k + u);
@@ -351,6 +395,7 @@ __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
         o4.z = odd ? a1.x : rx_, o4.w = odd ? a1.y : ry_;      // odd lane: row k+1, partner's pair + own
         *reinterpret_cast<float4*>(drow + (size_t)(k + u) * p.C1) = o4;
       }
+      PS_MARK(4); /* gate rows landed, mask, lane-pair exchange, stores issued */
     }
     if (qform) sq_b += dq, sq_x += cgx * dq, sq_y += cgy * dq, sq_z += cgz * dq;
   }
@@ -374,6 +419,7 @@ __global__ __launch_bounds__(PD_T) void pool_dgrad_kernel(PoolBwdArgs p) {
       }
     }
   }
+  PS_END(p);
 }
 
 int launch_wgrad(const PoolBwdArgs& p, hipStream_t st) {
@@ -445,11 +491,40 @@ int pzn_pool_bwd_sparse(const float* dout, const int32_t* argmax, const float* o
     p.gQ = gs->Q, p.gdW1x = gs->dW1x, p.gdb1 = gs->db1;
     p.rowmask = gs->rowmask;
   }
+#ifdef POOL_STAMPS
+  p.stamps = nullptr;
+#endif
   if (dW && !h && !p.gQ) return PZN_EINVAL;      // the weight-gradient pass needs the rows or their source
   if (!dh && !dW) return PZN_EINVAL;
+#ifdef POOL_STAMPS
+  auto next_slot = [&](int kind) {
+    p.stamps = nullptr;
+    if (!g_pool_stamps) return;
+    const int slot = g_pool_launch++ % PS_LAUNCHES;
+    p.stamps = g_pool_stamps + (size_t)slot * PS_WGS * 8;
+    g_pool_log[slot][0] = kind, g_pool_log[slot][1] = G, g_pool_log[slot][2] = C1, g_pool_log[slot][3] = C2;
+  };
+#else
+  auto next_slot = [](int) {};
+#endif
   if (dW) {
+    next_slot(0);
     int rc = launch_wgrad(p, st);
     if (rc != PZN_OK) return rc;
   }
-  return dh ? launch_dgrad(p, st) : PZN_OK;
+  if (!dh) return PZN_OK;
+  next_slot(1);
+  return launch_dgrad(p, st);
 }
+
+#ifdef POOL_STAMPS
+// diagnostic build only: a device buffer of 16 x 1024 x 8 uint64 that the next launches fill in turn (wgrad, dgrad, ...)
+PZN_EXPORT void pzn_pool_bwd_set_stamps(void* buf) {
+  g_pool_stamps = static_cast<unsigned long long*>(buf);
+  if (buf) g_pool_launch = 0;
+}
+PZN_EXPORT int pzn_pool_bwd_stamp_log(int slot, int* out4) {
+  for (int i = 0; i < 4; ++i) out4[i] = g_pool_log[slot % PS_LAUNCHES][i];
+  return g_pool_launch;
+}
+#endif
