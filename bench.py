@@ -107,23 +107,27 @@ def time_knn_group_api(batch, dev, reps):
             torch.cuda.synchronize()
             stage.append((a.elapsed_time(b) / reps, 1 if fused else 2))
         # the same launches from COLD caches: a back-to-back replay re-reads its 50 MB of inputs from the 256 MB
-        # Infinity Cache; here 512 MB are written elsewhere first, then ONE launch is timed (median of 5)
-        cold = []
-        flush = torch.empty(128 << 20, dtype=torch.float32, device=dev)
+        # Infinity Cache; here 512 MB are written elsewhere first, then the FOUR launches of a step-equivalent (distinct
+        # inputs: two clouds x two levels) run back to back inside ONE event pair — no launch re-reads what another left
+        # in a cache, and no per-launch start-up gap is counted (median of 5)
+        calls = []
         for (s, x, f) in work:
             new_xyz = ops.index_points(x, pu.farthest_point_sample(x, s)).contiguous()
             fused = ops.knn_group_supported(x, f, 32)
-            call = (lambda: ops.knn_group(x, f, new_xyz)) if fused else (lambda: ops.group(x, f, new_xyz, ops.knn(x, new_xyz, 32)))
-            ts = []
-            for _ in range(5):
-                flush.fill_(1.0)
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
+            calls.append((lambda x=x, f=f, c=new_xyz: ops.knn_group(x, f, c)) if fused else
+                         (lambda x=x, f=f, c=new_xyz: ops.group(x, f, c, ops.knn(x, c, 32))))
+        flush = torch.empty(128 << 20, dtype=torch.float32, device=dev)
+        ts = []
+        for _ in range(5):
+            flush.fill_(1.0)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for call in calls:
                 call()
-                b.record()
-                torch.cuda.synchronize()
-                ts.append(a.elapsed_time(b))
-            cold.append(sorted(ts)[2])
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        cold = sorted(ts)[2]
         del flush
     return api, stage, cold
 
@@ -171,6 +175,56 @@ def cpu_baseline(N, pairs, iters):
     }
 
 
+def other_workload(dev, B, N, attn, warm=5, steps=10):
+    """BASELINE configs[3] / [4] at their per-GPU share, in this process after the headline's timed region: `warm` + `steps`
+    optimiser steps of the same runner, then two instrumented steps (EMD time) and the north-star stage on this workload's
+    clouds.  -> {workload, pairs_per_s, ms_per_step, knn_group_frac, knn_group_cold_frac, emd_ms}"""
+    from puzzlenet_amd import _lib, engine, model5_b, ops, synthetic
+    lib = _lib.load()
+    if attn == "bf16":
+        _lib.check(lib.pzn_attn_set_precision(1), "pzn_attn_set_precision")
+    try:
+        cfg = Cfg()
+        cfg.num_points = N
+        torch.manual_seed(0)
+        model = model5_b.TouchedRegraster(cfg).to(dev)
+        batch = synthetic.make_batch(B, N, dev, seed=1234)
+        torch.manual_seed(1000)
+        runner = engine.TrainStep(model, batch, cfg.lr, world=1)
+        for _ in range(warm):
+            runner.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            runner.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        runner.close()
+        model.two_streams = False
+        eager = engine.TrainStep(model, batch, cfg.lr, world=1)
+        eager.step()
+        torch.cuda.synchronize()
+        ops.KernelTimer.start()
+        for _ in range(2):
+            eager.step()
+        kern = ops.KernelTimer.stop()
+        eager.close()
+        _, stage, cold = time_knn_group_api(batch, dev, 10)
+        per_pair = 2 * (knn_group_bytes(N, 512, 32, 64) + knn_group_bytes(512, 256, 32, 128))
+        ms_kg = sum(ms for ms, _ in stage)
+        return {
+            "workload": f"N={N} points, {B} pairs/GPU, fp32 train step" + (", attention contractions bf16" if attn == "bf16" else ""),
+            "points": N, "batch": B, "attention": attn, "steps": steps, "warmup": warm,
+            "pairs_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3,
+            "knn_group_frac": per_pair * B / (ms_kg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "knn_group_cold_frac": per_pair * B / (cold * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "emd_ms": kern.get("pzn_emd_fused_f32", (0, 0.0))[1] / 2,
+        }
+    finally:
+        if attn == "bf16":
+            _lib.check(lib.pzn_attn_set_precision(0), "pzn_attn_set_precision")
+
+
 def build_id():
     """Hash of the sources libpzn.so is built from (csrc/*, include/pzn.h, build.py): PMC byte counts collected on another build
     are not attached to this run's numbers."""
@@ -185,7 +239,7 @@ def build_id():
     return h.hexdigest()[:16]
 
 
-ROUND = "r4"
+ROUND = "r5"
 
 
 def pmc_traffic(key, B, N):
@@ -202,6 +256,21 @@ def pmc_traffic(key, B, N):
     if (doc.get("batch"), doc.get("points")) != (B, N):
         return None, f"profiles/{name} was collected on another workload"
     return doc.get(key), f"profiles/{name} (build {doc.get('build_id')}, separate --pmc passes of bench.py)"
+
+
+def profile_matches(B, N, attn):
+    """The committed kernel summary is used only when it was collected on THIS build and workload: tools/collect_profiles.sh
+    writes profiles/<round>_kernel_stats.meta.json = {build_id, batch, points, attn} beside it.  -> (ok, why not)"""
+    meta = os.path.join(ROOT, "profiles", f"{ROUND}_kernel_stats.meta.json")
+    if not os.path.exists(os.path.join(ROOT, "profiles", f"{ROUND}_kernel_stats.csv")) or not os.path.exists(meta):
+        return False, f"no profiles/{ROUND}_kernel_stats.csv with its .meta.json committed"
+    doc = json.load(open(meta))
+    want = {"build_id": build_id(), "batch": B, "points": N, "attn": attn}
+    diff = {k: (doc.get(k), v) for k, v in want.items() if doc.get(k) != v}
+    if diff:
+        return False, f"profiles/{ROUND}_kernel_stats.csv was collected on another build / workload: " + ", ".join(
+            f"{k} {a} != {b}" for k, (a, b) in diff.items())
+    return True, ""
 
 
 def profile_top_rows(n):
@@ -244,6 +313,8 @@ def main():
                     help="attention products: f32 = the default split-precision path (fp32 results), bf16 = single bf16 "
                          "MFMAs with fp32 softmax / accumulation (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip config.other_workloads (BASELINE configs[3] / [4] at their per-GPU share, 5 + 10 steps each)")
     ap.add_argument("--cpu-pairs", type=int, default=8)
     ap.add_argument("--cpu-iters", type=int, default=3)
     args = ap.parse_args()
@@ -323,6 +394,19 @@ def main():
         dh_rows_bytes = sum(_bits(m) * c1 * 4 for m, c1 in rowmasks) / prof_steps if rowmasks else None
         kern_flops = dict(ops.KernelTimer.flops)
         eager.close()
+        # the same events with the two encoders on two streams, as in the timed loop (and in a rocprofv3 trace of it): a launch's
+        # duration then includes what it loses to the other stream's kernels on the same CUs.  `roofline` (the dominant
+        # kernel) is priced from THIS pass, so that its live average is the figure a kernel trace of this command averages to.
+        model.two_streams = True
+        eager2 = engine.TrainStep(model, batch, cfg.lr, world=1)
+        eager2.step()
+        torch.cuda.synchronize()
+        ops.KernelTimer.start()
+        for _ in range(prof_steps):
+            eager2.step()
+        kern2 = ops.KernelTimer.stop()
+        kern2_variants = dict(ops.KernelTimer.variants)
+        eager2.close()
         kern_api, stage_kg, cold_kg = time_knn_group_api(batch, dev, 20)
 
     if rank == 0:
@@ -403,12 +487,10 @@ def main():
             "avg_launch_ms": ms_kg / max(1, n_kg),
             "launch_ms": {"cloud0_level1": stage_kg[0][0], "cloud0_level2": stage_kg[1][0], "cloud1_level1": stage_kg[2][0],
                           "cloud1_level2": stage_kg[3][0]},
-            "cold": {"what": "the same four launches timed ONE at a time right after 512 MB were written elsewhere (inputs "
-                             "neither in L2 nor in the Infinity Cache; an event pair around a single launch also counts its "
-                             "start-up gap), median of 5",
-                     "ms_per_step": sum(cold_kg), "achieved": per_pair * B / (sum(cold_kg) * 1e-3) / 1e9 if sum(cold_kg) > 0 else 0.0,
-                     "frac": (per_pair * B / (sum(cold_kg) * 1e-3) / 1e9 / HBM_PEAK_GBS) if sum(cold_kg) > 0 else 0.0,
-                     "launch_ms": cold_kg},
+            "cold": {"what": "the same four launches back to back inside ONE event pair right after 512 MB were written elsewhere "
+                             "(inputs neither in L2 nor in the Infinity Cache; the four have distinct inputs), median of 5",
+                     "ms_per_step": cold_kg, "achieved": per_pair * B / (cold_kg * 1e-3) / 1e9 if cold_kg > 0 else 0.0,
+                     "frac": (per_pair * B / (cold_kg * 1e-3) / 1e9 / HBM_PEAK_GBS) if cold_kg > 0 else 0.0},
             "model_path_knn": {"entry": "pzn_knn_f32 (indices only; the encoder gathers per-point rows instead of "
                                         "materialising groups)", "launches_per_step": n_mk, "ms_per_step": ms_mk},
         }
@@ -447,21 +529,23 @@ def main():
         #     evaluations (emd_kernel.cu:46-154); the fused path walks only the cloud-2 points that still hold mass and lie
         #     inside the level's x window, and counts what it evaluates (pzn_emd_walk_counter_offset: uint64 counters in
         #     units of 64 evaluations), so the evaluations EXECUTED are known (30 n m on the single-workgroup path).  The walks
-        #     are packed (v_pk_*: two evaluations per instruction): per TWO evaluations 3 differences, 3 square / sum,
-        #     1 scale, 2 v_exp_f32 (8 cycles = two issue slots each), 1 weight, 1-5 accumulations (pass C also sums cost
-        #     and gradient) = 14.5 issue slots on average, i.e. 7.25 vector issue slots per evaluation.
-        #     Peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-slots/s (one wave64 instruction per 4 cycles).
+        #     are packed (v_pk_*: two evaluations per instruction).  Per TWO evaluations, round 5 (csrc/emd.hip): pass B 12 packed
+        #     instructions + 2 v_exp_f32, pass C + next A (one walk, counted ONCE by the device counters) 16 + 2 (the sharper
+        #     exponential is the softer one squared twice), first A 8 + 2; measured issue costs on this chip (tools/valu_rate.hip):
+        #     v_pk_* 4.4 cycles, v_exp_f32 8 = two 4-cycle slots.  Executed evaluations split about evenly between B and C + A, so
+        #     (12 + 4 + 16 + 4) / 2 / 2 = 9 issue slots per counted evaluation (round 4 priced 7.25 for three exponentials more per
+        #     two walks).  Peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-slots/s (one wave64 instruction per 4 cycles).
         n_e, ms_e = per_step("pzn_emd_fused_f32")
         ev_exec, ev_ref = 0.0, 0.0
         for ctr, eb, en, em in emd_walk:
             ev_ref += 30.0 * eb * en * em
             ev_exec += 30.0 * eb * en * em if ctr is None else 64.0 * float(ctr.sum().item())
         ev_exec, ev_ref = ev_exec / prof_steps, ev_ref / prof_steps
-        LANE_OPS = 7.25
+        LANE_OPS = 9.0
         e_ach = ev_exec * LANE_OPS / (ms_e * 1e-3) / 1e12 if ms_e > 0 else 0.0
         roofline_emd = {
-            "bound": "valu", "kernel": "emd_pass_b_list_kernel / emd_pass_ca_kernel / emd_pass_a_kernel / emd_small_fused_kernel behind "
-                                       "pzn_emd_fused_f32 (4 calls per step: N x N, B x B, 2 x 128 x 128)",
+            "bound": "valu", "kernel": "emdf_b_kernel / emdf_k_kernel<0|1|2> / emdf_compact_kernel / emd_sort_x_kernel / emd_small_fused_kernel "
+                                       "behind pzn_emd_fused_f32 (4 calls per step: N x N, B x B, 2 x 128 x 128)",
             "achieved": e_ach, "peak": 39.3, "unit": "T lane-slot/s", "frac": e_ach / 39.3, "traffic": None,
             "pair_evaluations_executed_per_step": ev_exec, "pair_evaluations_reference_schedule_per_step": ev_ref,
             "issue_slots_per_evaluation": LANE_OPS, "ms_per_step": ms_e, "launches_per_step": n_e,
@@ -531,22 +615,24 @@ def main():
             "pzn_attn_fused_proj": ("attn_proj_kernel", "csrc/attnfused.hip: q, k, v projection into bf16-plane images"),
             mp_entry: ("sa_level_stream_kernel", "csrc/salevel.hip: generated-row max-pool level (two instantiations: <128,4>, <256,8>)"),
             "pzn_outproj_maxpts_fwd_f32": ("outproj_maxpts_kernel", "csrc/outproj.hip: out projection of the five slices + max over the points"),
-            # two launches of the same instantiation per call (dWo = dz^T t, and dWq | dWk | dWv = [dq | dk | dv]^T x in one)
-            "pzn_attn_fused_wgrads": ("df_wgrad_kernel<2, 2, false, true>", "csrc/dfgemm.hip: the attention blocks' weight gradients, "
-                                      "direct-fragment kernel, reduction over the 16 384 rows of a cloud batch, atomic epilogue"),
+            # (pzn_attn_fused_wgrads is a SEQUENCE - a linear weight gradient, zero fills, two df_wgrad_kernel launches of
+            #  different shapes - so an event pair around it does not time one kernel: it is priced inside roofline_attention)
         }
-        launches_per_call = {"pzn_attn_fused_wgrads": 2}
-        cand = {e: per_step(e) for e in single if e in kern and kern_flops.get(e, 0) > 0}
+        launches_per_call = {}
+        cand = {e: per_step(e, kern2) for e in single if e in kern2 and kern_flops.get(e, 0) > 0}
+        cand_one_stream = {e: per_step(e) for e in cand}
         cand_fl = {e: kern_flops.get(e, 0) / prof_steps for e in cand}
         # an entry point with several kernel instantiations (the level kernel: <128, 4> and <256, 8>) competes per instantiation,
         # as in the rows of a rocprofv3 kernel summary
-        split_entries = {e for (e, _v) in kern_variants if e in cand}
-        for (e, var), (n_, ms_, fl_) in kern_variants.items():
+        split_entries = {e for (e, _v) in kern2_variants if e in cand}
+        for (e, var), (n_, ms_, fl_) in kern2_variants.items():
             if e in split_entries:
                 key = e + var
                 single[key] = (single[e][0] + var, single[e][1])
                 cand[key] = (n_ / prof_steps, ms_ / prof_steps)
                 cand_fl[key] = fl_ / prof_steps
+                n1, ms1, _ = kern_variants.get((e, var), (0, 0.0, 0))
+                cand_one_stream[key] = (n1 / prof_steps, ms1 / prof_steps)
         for e in split_entries:
             cand.pop(e)
         for e, k_ in launches_per_call.items():
@@ -557,9 +643,12 @@ def main():
         # as roofline_emd) are stepped over, so that two rows a tenth of a percent apart swapping places between collections
         # do not change the basis of the choice; without a committed summary: the candidate with the largest launch-time sum
         # per step in this pass.
-        how = "largest launch-time sum per step among the single-kernel entry points of the instrumented (one-stream) pass"
+        how = "largest launch-time sum per step among the single-kernel entry points of the instrumented two-stream pass"
         dom = max(cand, key=lambda e: cand[e][1])
-        top_rows = profile_top_rows(8)
+        prof_ok, prof_why = profile_matches(B, N, args.attn)
+        top_rows = profile_top_rows(8) if prof_ok else None
+        if not prof_ok:
+            how += f" ({prof_why})"
         if top_rows:
             by_kernel = {single[e][0]: e for e in cand}
             skipped = []
@@ -579,7 +668,7 @@ def main():
         dfl = cand_fl[dom]
         dom_peak = attn_peak if dom.startswith("pzn_attn_fused") else MFMA_X3_PEAK_TFLOPS
         dach = dfl / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
-        prof_rows = profile_kernel_rows(single[dom][0])
+        prof_rows = profile_kernel_rows(single[dom][0]) if prof_ok else None
         # HBM bytes per launch of that kernel from this build's committed PMC passes (per-kernel table of tools/pmc_summary.py)
         pk, pk_src = pmc_traffic("per_kernel", B, N)
         dom_traffic = None
@@ -596,8 +685,22 @@ def main():
                           else "dense bf16 MFMA rate (one bf16 MFMA per product in --attn bf16)"),
             "algorithmic_flops_per_step": dfl, "algorithmic_flops_per_launch": dfl / max(1.0, dn),
             "ms_per_step": dms, "launches_per_step": dn, "avg_launch_us": 1e3 * dms / max(1.0, dn),
+            "timed": "HIP events around every launch of the kernel on its own stream, the two encoders on two streams as in the timed "
+                     "loop (3 steps right after it); `one_stream` = the same launches with the encoders one after the other",
+            "one_stream": {"avg_launch_us": 1e3 * cand_one_stream[dom][1] / max(1.0, cand_one_stream[dom][0]),
+                           "frac": (dfl / (cand_one_stream[dom][1] * 1e-3) / 1e12 / dom_peak) if cand_one_stream[dom][1] > 0 else None},
             "how_chosen": how,
             "candidates_ms_per_step": {single[e][0]: cand[e][1] for e in sorted(cand, key=lambda e: -cand[e][1])},
+        }
+        # the stage BASELINE.json's north star prices (>= 60 % of the HBM roofline on kNN + group), inside `roofline` so that
+        # it travels with the headline object: replayed and cold fractions of 8 TB/s, time per step-equivalent, PMC traffic
+        roofline["north_star_stage"] = {
+            "stage": "kNN + group: pzn_knn_group_f32, what pointnet_util.sample_and_group(npoint, 0, 32, xyz, points, knn=True) "
+                     "launches after FPS (details: roofline_knn_group)",
+            "bound": "hbm", "frac": roofline_knn_group["frac"], "cold_frac": roofline_knn_group["cold"]["frac"],
+            "ms_per_step": roofline_knn_group["ms_per_step"], "cold_ms_per_step": roofline_knn_group["cold"]["ms_per_step"],
+            "algorithmic_bytes_per_step": roofline_knn_group["algorithmic_bytes_per_step"], "traffic": roofline_knn_group["traffic"],
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
         }
         if prof_rows:
             pavg = sum(r["avg_us"] * r["calls"] for r in prof_rows) / sum(r["calls"] for r in prof_rows)
@@ -633,6 +736,12 @@ def main():
             "stages_sample_and_group_dropin": stages_api,
             "loss": loss_val,
         }
+        if not args.no_other_workloads and world == 1 and (B, N, args.attn) == (64, 2048, "f32"):
+            # BASELINE configs[3] and [4] (1-GPU shares), measured by whoever runs this line: same process, after the headline
+            del model, batch, runner, eager, eager2
+            torch.cuda.empty_cache()
+            out["config"]["other_workloads"] = [other_workload(dev, 64, 4096, "f32"), other_workload(dev, 32, 8192, "f32"),
+                                                other_workload(dev, 32, 8192, "bf16")]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_pairs, args.cpu_iters)
         print(json.dumps(out))

@@ -50,6 +50,12 @@ def init_from_env(backend=None):
             if not kw:
                 raise
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        except RuntimeError as e:
+            if kw:      # the eager (device-bound) RCCL communicator failed: say which switch selects the lazy one
+                raise RuntimeError(f"{e}  [puzzlenet_amd: the process group was created with device_id={kw['device_id']} "
+                                   "(eager RCCL communicator); set PZN_DIST_LAZY_INIT=1 on ALL ranks to create it lazily at "
+                                   "the first collective instead]") from e
+            raise
     return rank, world, local
 
 

@@ -1232,12 +1232,18 @@ class _AttnChainFused(torch.autograd.Function):
         ctx.save_for_backward(*tosave)
         ctx.nprob = nprob
         ctx.dims = (B, L, E, dk, Nout)
+        # the kernels pick the one- or three-plane instantiation from the process-wide precision mode at every launch, and the
+        # single-plane projection leaves planes 1 and 2 of its images unwritten: the backward must run in the forward's mode
+        ctx.attn_mode = _lib.load().pzn_attn_get_precision()
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(*maps, *empties)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gout):
+        if _lib.load().pzn_attn_get_precision() != ctx.attn_mode:
+            raise _lib.PznError("pzn_attn_set_precision() changed between the forward and the backward of an attention chain "
+                                f"(forward: mode {ctx.attn_mode}): its bf16-plane images were written for the forward's mode")
         B, L, E, dk, Nout = ctx.dims
         nprob = ctx.nprob
         R = range(nprob)

@@ -45,8 +45,9 @@ def main():
         rec["early"].append(bool(runner.grads._early_done))
         rec["armed"].append((runner._gate.armed, runner._gate.fired))
     runner.close()
-    torch.save(rec, os.path.join(out_dir, f"rank{rank}.pt"))
     import torch.distributed as dist
+    rec["backend"], rec["device"] = dist.get_backend(), torch.cuda.current_device()
+    torch.save(rec, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 

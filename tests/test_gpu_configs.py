@@ -351,3 +351,42 @@ def test_full_per_gpu_batch_eval_vs_oracle_subset(dev, monkeypatch, N, B, mode):
     np.testing.assert_allclose(out[7][pick].cpu().numpy(), rout[7].numpy(), rtol=rt, atol=1e-4 * at)
     if mode == 1:                                                                # the mode is really on
         assert not np.allclose(out[0][pick].cpu().numpy(), rout[0].numpy(), rtol=1e-6, atol=1e-8)
+
+
+def test_full_batch_train_mode_forward_vs_oracle(dev, monkeypatch):
+    """BASELINE configs[1] as the bench runs it — predict5(training=True) on the full per-GPU batch, B = 64, N = 2048 —
+    against the torch-CPU restatement of the reference on the SAME 64 pairs: in train mode BatchNorm1d(num_points)
+    normalises every point slot over the batch's 64 x 64 values (model5_b.py:424, 447-448), so the samples are coupled
+    and only the full batch is a valid comparison.  FPS picks of both levels bit for bit, pose twist, attention map and
+    boundary logits at the north star's 1e-4.  Both sides get the same fixed start index (pointnet_util.py:65 draws one per
+    batch position).  No EMD is involved (forward only): about a minute of CPU."""
+    from puzzlenet_amd import synthetic
+    N, B = 2048, 64
+    cfg = mr.Cfg(num_points=N, loss_mode=1)
+    model, ref = _pair(cfg, dev)
+    batch = synthetic.make_batch(B, N, dev, seed=97)
+    cpu_batch = [t.cpu() for t in batch]
+    real_randint = torch.randint
+
+    def fixed(low, high=None, size=None, **kw):
+        kw.pop("generator", None)
+        return torch.zeros(size, dtype=kw.get("dtype", torch.long))
+    monkeypatch.setattr(torch, "randint", fixed)
+    try:
+        model.train()
+        ref.train()
+        with torch.no_grad():
+            out = model.predict5(batch, B, need=True, training=True)
+            rout = ref.predict5(cpu_batch, training=True)
+    finally:
+        monkeypatch.setattr(torch, "randint", real_randint)
+    assert np.array_equal(out[2].cpu().numpy(), rout[2].numpy())          # x2 of fpc: FPS of FPS, bit-exact on all 64 clouds
+    assert np.array_equal(out[4].cpu().numpy(), rout[4].numpy())          # x2 of mrpc
+    np.testing.assert_allclose(out[0].cpu().numpy(), rout[0].numpy(), rtol=1e-4, atol=1e-5)      # pose twist
+    np.testing.assert_allclose(out[3].cpu().numpy(), rout[3].numpy(), rtol=1e-4, atol=1e-6)      # attention map
+    np.testing.assert_allclose(out[6].cpu().numpy(), rout[6].numpy(), rtol=1e-4, atol=1e-4)      # boundary logits
+    np.testing.assert_allclose(out[7].cpu().numpy(), rout[7].numpy(), rtol=1e-4, atol=1e-4)
+    # the batch statistics really were the batch's: the running buffers moved the same way on both sides
+    for (n_, b_), (rn_, rb_) in zip(sorted(model.named_buffers()), sorted(ref.named_buffers())):
+        if b_.dtype.is_floating_point and b_.numel() > 1:
+            np.testing.assert_allclose(b_.cpu().numpy(), rb_.numpy(), rtol=1e-4, atol=1e-6, err_msg=n_)
