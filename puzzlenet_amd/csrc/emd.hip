@@ -452,8 +452,8 @@ __global__ __launch_bounds__(EMD_SMALL_T) void emd_small_fused_kernel(const floa
 //     the points that still hold mass — 57 % of them at level 5, 21 % at level 3, 2 % at level 0 on independent uniform
 //     clouds, 91 % / 81 % / 42 % on a cloud against its rigidly moved copy (the loss term under an untrained pose head).
 //     The list is COMPACTED: lst[r] = {x, y, z, remainR} of the r-th active point, ascending x, so that the walks stage
-//     contiguous records (no index indirection) and pass B writes its results in place; emdf_compact_kernel builds the
-//     next level's list from this level's;
+//     contiguous records (no index indirection) and pass B writes its results in place; an extra workgroup of the
+//     C + A launch builds the next level's list from this level's (emdf_compact_wg);
 //   * X WINDOW: at a level with scale c (in exp2 units) a point farther than sqrt(150 / -c) along x from every row of a
 //     workgroup contributes exp2(c d^2) = exactly +0 in fp32, so a wavefront skips a quarter tile that lies wholly
 //     outside the window of its rows.  Finer tests do not pay: on the loss term's clouds a window per 8 points instead
@@ -587,8 +587,12 @@ __global__ __launch_bounds__(EMD_ST) void emd_sort_x_kernel(const float* __restr
     skeys[i] = k;
   }
   __syncthreads();
+  // A thread handles elements tid, tid + 1024, ...: for j < 64 an element's partner i ^ j belongs to the same wavefront
+  // (same 64-aligned block), so those steps need no workgroup barrier - 15 of the 66 steps of a 2048-key sort do
+  // (j >= 64), and one more in front of each run of them.
   for (int k2 = 2; k2 <= pw; k2 <<= 1)
     for (int j = k2 >> 1; j > 0; j >>= 1) {
+      if (j >= 64) __syncthreads();       // partners in another wavefront's block: its previous step must be visible
       for (int i = tid; i < pw; i += EMD_ST) {
         const int p = i ^ j;
         if (p > i) {
@@ -597,8 +601,9 @@ __global__ __launch_bounds__(EMD_ST) void emd_sort_x_kernel(const float* __restr
           if ((a > c) == up) skeys[i] = c, skeys[p] = a;
         }
       }
-      __syncthreads();
+      if (j >= 64) __syncthreads(); else pzn::wave_lds_sync();
     }
+  __syncthreads();
   int* perm = (which ? perm1 : perm0) + (size_t)b * cnt;
   for (int i = tid; i < cnt; i += EMD_ST) perm[i] = (int)(uint32_t)skeys[i];
 }
@@ -625,40 +630,42 @@ __global__ __launch_bounds__(EF_T) void emdf_init_kernel(const float* __restrict
   }
 }
 
-// The next level's list: the entries of list `from` that still hold mass, in order.  One workgroup per pair.
-constexpr int EF_CT = 1024;
-__global__ __launch_bounds__(EF_CT) void emdf_compact_kernel(int m, EmdF w, int from) {
-  __shared__ int wsum[EF_CT / 64];
-  __shared__ int base_s;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, to = from ^ 1;
+// The next level's list: the entries of list `from` that still hold mass, in order.  One workgroup per pair — the EXTRA
+// workgroup (blockIdx.x == gridDim.x - 1) of the C + A launch of the level: that walk reads list `from` and nothing of the
+// new list, pass B of the next level is the first to need it, so the 5 us launch of a compaction kernel per level is gone
+// and the compaction itself (3 us of latency) disappears beside the walk.
+__device__ __forceinline__ void emdf_compact_wg(int m, const EmdF& w, int from, int* scratch) {
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, to = from ^ 1;
   const int cnt = w.cnt[from][b];
   const float4* __restrict__ src = w.lst[from] + (size_t)b * m;
   const int* __restrict__ sidx = w.lidx[from] + (size_t)b * m;
   float4* __restrict__ dst = w.lst[to] + (size_t)b * m;
   int* __restrict__ didx = w.lidx[to] + (size_t)b * m;
-  if (tid == 0) base_s = 0;
-  __syncthreads();
-  for (int i0 = 0; i0 < cnt; i0 += EF_CT) {
-    const int r = i0 + tid;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < cnt) v = src[r];
-    const bool on = v.w > 0.f;
-    const uint64_t bal = __ballot(on);
-    const int before = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wsum[wv] = __builtin_popcountll(bal);
-    __syncthreads();
-    int off = base_s, tot = 0;
-    for (int q = 0; q < EF_CT / 64; ++q) {
-      const int c = wsum[q];
-      off += q < wv ? c : 0;
-      tot += c;
-    }
-    if (on) dst[off + before] = v, didx[off + before] = sidx[r];
-    __syncthreads();
-    if (tid == 0) base_s += tot;
-    __syncthreads();
+  // thread t owns the contiguous run [t E, (t + 1) E) of the list: count, ONE prefix sum over the 256 threads, write in order
+  const int E = (cnt + EF_T - 1) / EF_T;
+  const int r0 = tid * E, r1 = min(cnt, r0 + E);
+  int mine = 0;
+  for (int r = r0; r < r1; ++r) mine += src[r].w > 0.f ? 1 : 0;
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, PZN_WAVE);
+    incl += lane >= o ? t : 0;
   }
-  if (tid == 0) w.cnt[to][b] = base_s;
+  if (lane == 63) scratch[wv] = incl;
+  __syncthreads();
+  int off = incl - mine, total = 0;
+#pragma unroll
+  for (int q = 0; q < EF_T / 64; ++q) {
+    const int c = scratch[q];
+    off += q < wv ? c : 0;
+    total += c;
+  }
+  for (int r = r0; r < r1; ++r) {
+    const float4 v = src[r];
+    if (v.w > 0.f) dst[off] = v, didx[off] = sidx[r], ++off;
+  }
+  if (tid == 0) w.cnt[to][b] = total;
 }
 
 // Rows = points k of cloud 1, walking list `buf` of cloud 2.
@@ -676,6 +683,12 @@ __global__ __launch_bounds__(EF_T, 8) void emdf_k_kernel(int n, int m, float c, 
   __shared__ float4 tile[2][EF_NP * NF4];
   static_assert(sizeof(float4) * 2 * EF_NP * NF4 >= sizeof(float) * (NV * EF_T + 4), "the partial sums reuse the tiles");
   EMD_STAMP_BEGIN();
+  const int gk = (n + 63) / 64;        // row blocks; MODE 1 launches gk + 1 workgroups per pair
+  if (MODE == 1 && (int)blockIdx.x == gk) {      // the extra one builds the next level's list beside the walk
+    emdf_compact_wg(m, w, buf, reinterpret_cast<int*>(&tile[0][0]));
+    EMD_STAMP_END(w, lid);
+    return;
+  }
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = blockIdx.x * 64 + lane;
@@ -802,7 +815,7 @@ __global__ __launch_bounds__(EF_T, 8) void emdf_k_kernel(int n, int m, float c, 
     }
     if (MODE != 0) {  // this wavefront holds the 64 row totals; the cell is this workgroup's own
       sc = pzn::wave_sum_f32(sc);
-      if (tid == 0) w.costp[(size_t)b * gridDim.x + blockIdx.x] += sc;
+      if (tid == 0) w.costp[(size_t)b * gk + blockIdx.x] += sc;
     }
     if (tid == 0) {
       const int* nv = reinterpret_cast<const int*>(red) + NV * EF_T;
@@ -986,7 +999,7 @@ int run_fused(const float* xyz1, const float* xyz2, int B, int n, int m, float* 
     return PZN_ELAUNCH;
   hipLaunchKernelGGL(emd_sort_x_kernel, dim3(2, B), dim3(EMD_ST), lds, st, xyz1, xyz2, n, m, npow, mpow, w.perm[0], w.perm[1]);
   const int mx = n > m ? n : m;
-  const dim3 gi((mx + EF_T - 1) / EF_T, B), gk((n + 63) / 64, B);
+  const dim3 gi((mx + EF_T - 1) / EF_T, B), gk((n + 63) / 64, B), gk1((n + 63) / 64 + 1, B);   // gk1: + the compaction workgroup
   hipLaunchKernelGGL(emdf_init_kernel, gi, dim3(EF_T), 0, st, xyz1, xyz2, n, m, multiL, multiR, w);
   auto cof = [](int j) {                                         // :47-50, * log2(e): __expf(level d) = exp2(level log2(e) d)
     const float level = j == -2 ? 0.f : -powf(4.0f, (float)j);
@@ -1001,20 +1014,19 @@ int run_fused(const float* xyz1, const float* xyz2, int B, int n, int m, float* 
   };
   const int target = 1024 / B > 1 ? 1024 / B : 1;
   const dim3 gb((unsigned)((m + 63) / 64 > target ? (m + 63) / 64 : target), B);
-  // A(7); then per level B, the next list, and C fused with the next level's A; the last level ends with a plain C
+  // A(7); then per level B, and C fused with the next level's A (+ the next list); the last level ends with a plain C
   hipLaunchKernelGGL((emdf_k_kernel<0, false>), gk, dim3(EF_T), 0, st, n, m, 0.f, cof(7), w, 0, winf(7), 0);
   for (int j = 7, buf = 0; j >= -2; --j, buf ^= 1) {  // list `buf` = points of cloud 2 with mass at the start of level j
     const int lb = 1 + 2 * (7 - j);
     hipLaunchKernelGGL(emdf_b_kernel, gb, dim3(EF_T), 0, st, n, m, cof(j), w, buf, winf(j), lb);
     if (j > -2) {
-      hipLaunchKernelGGL(emdf_compact_kernel, dim3(B), dim3(EF_CT), 0, st, m, w, buf);  // list buf ^ 1 for level j - 1
       // the walk covers the list of THIS level: ratioR of pass C is non-zero exactly there, the points pass B has just
       // exhausted carry remainR = 0 into the next level's sum; window of the SOFTER level: outside it both terms are +0
       if (j >= 0)
-        hipLaunchKernelGGL((emdf_k_kernel<1, true>), gk, dim3(EF_T), 0, st, n, m, cof(j), cof(j - 1), w, buf,
+        hipLaunchKernelGGL((emdf_k_kernel<1, true>), gk1, dim3(EF_T), 0, st, n, m, cof(j), cof(j - 1), w, buf,
                            winf(j - 1), lb + 1);
       else       // the next scale is 0: its exponential is 1, nothing to square
-        hipLaunchKernelGGL((emdf_k_kernel<1, false>), gk, dim3(EF_T), 0, st, n, m, cof(j), cof(j - 1), w, buf,
+        hipLaunchKernelGGL((emdf_k_kernel<1, false>), gk1, dim3(EF_T), 0, st, n, m, cof(j), cof(j - 1), w, buf,
                            winf(j - 1), lb + 1);
     } else {
       hipLaunchKernelGGL((emdf_k_kernel<2, false>), gk, dim3(EF_T), 0, st, n, m, cof(j), 0.f, w, buf, winf(j), lb + 1);
