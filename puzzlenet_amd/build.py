@@ -45,6 +45,7 @@ SOURCES = [
     ("optim.hip", ["-ffp-contract=off"] + NOSLP),
     ("se3.hip", NOSLP),
     ("sapoint.hip", NOSLP),
+    ("sapool.hip", NOSLP),
     ("bnpoints.hip", NOSLP),
     ("losstail.hip", NOSLP),
 ]

@@ -1,0 +1,312 @@
+// sapool.hip — input-gradient side of a set-abstraction level's backward, BY POINT (round 5).
+//
+// Level: rows h[(g,k),:] = relu(P'[idx[g,k],:] + Q[g,:]) (csrc/sapoint.hip), out[g,c] = max_k relu(h[(g,k),:] . W2[c,:] + b2[c])
+// (model5_b.py:452-454 / 459-461).  The gradient that reaches a row is sparse: one (row, channel) hit per live channel,
+//     dh[(g,k),:] = gate(g,k,:) * sum over the channels c with argmax[g,c] == k of dout[g,c] W2[c,:],
+// and all the caller needs of dh are its per-point sums dP[j,:] = sum over the rows (g,k) that gathered point j of dh[(g,k),:]
+// and three small reductions (dW1[:,0:3] += dh^T (xyz[j] - centre_g), db1 += column sums of dh).
+//
+// Rounds 2-4 ran this in two launches with dh in memory between them: pool_dgrad_kernel (csrc/poolbwd.hip) walked the groups,
+// found the channels of every row with 32 x C2/64 ballots per group AND column slice, regenerated 32 gate rows per group and
+// wrote the rows that exist (0.36-0.54 GB per launch); sa_point_l1_bwd_kernel (csrc/sapoint.hip) read them back through the
+// inverse neighbour lists and summed them per point: 0.52 + 0.37 ms of a 7.5 ms step, 1 GB of HBM traffic, both kernels
+// latency-bound (profiles/r5_pool_bwd_stamps.txt).  Here:
+//   * pool_hits_kernel: ONCE per group (a wavefront each), the live (channel, gradient) pairs sorted by their arg-max row,
+//     with the 33 row offsets — the ballots are paid once, not per column slice, and nothing else happens in that kernel;
+//   * pool_point_kernel: the walk of sa_point_l1_bwd_kernel — (row, point) pairs sorted by point, 64 per wavefront batch,
+//     running sum stored when the point changes — but the row is COMPUTED where it was loaded: the hit list of (g,k) (one
+//     coalesced 8-byte load per hit, several rows in flight), one W2 row from LDS per hit (the W2 column slice of the
+//     workgroup, [C2][128] floats), the gate from the P' row of the point and the Q row of the group.  dh is never written.
+// Arithmetic per element is that of the two kernels it replaces (sum of the hits in ascending channel order, gate, sum of the
+// rows of a point in list order).
+#include <stdlib.h>
+
+#include "pzn_common.h"
+#include "pzn_internal.h"
+
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int PH_T = 256;        // pool_hits_kernel: 4 wavefronts, a group each
+constexpr int PP_COLS = 128;     // columns of C1 per workgroup of pool_point_kernel
+constexpr int RS_LD = 34;        // row offsets per group: 33 used (uint16)
+
+// hits[g][0 .. rstart[g][32]) = {channel, gradient bits} of the channels with a non-zero gradient (out > 0: the ReLU of
+// the pooled layer), sorted by (arg-max row, channel); rstart[g][k] = first hit of row k.
+template <int NQ>  // C2 = 64 NQ
+__global__ __launch_bounds__(PH_T) void pool_hits_kernel(const float* __restrict__ dout, const int32_t* __restrict__ argmax,
+                                                         const float* __restrict__ out, int G, uint2* __restrict__ hits,
+                                                         uint16_t* __restrict__ rstart) {
+  constexpr int C2 = 64 * NQ;
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * (PH_T / 64) + (threadIdx.x >> 6), nw = gridDim.x * (PH_T / 64);
+  const uint64_t lt = (1ull << lane) - 1ull;
+  for (int g = gw; g < G; g += nw) {
+    int a[NQ];
+    float gv[NQ];
+    uint32_t rows = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const size_t o = (size_t)g * C2 + q * 64 + lane;
+      const float go = out[o], gd = dout[o];
+      gv[q] = go > 0.f ? gd : 0.f;
+      a[q] = gv[q] != 0.f ? (argmax[o] & 31) : -1;      // a dead channel is no hit of any row
+      rows |= a[q] >= 0 ? 1u << a[q] : 0u;
+    }
+    rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)pzn::wave_or_u32_dpp(rows));      // rows with at least one hit
+    uint2* hg = hits + (size_t)g * C2;
+    int base = 0;          // wave-uniform
+    int mystart = 0;       // lane k (and lane 32): rstart[k]
+    int prev = 0;
+    uint32_t todo = rows;
+    while (todo) {
+      const int k = __builtin_ctz(todo);
+      todo &= todo - 1;
+      // rows prev .. k start here (rows without hits are empty ranges)
+      mystart = (lane >= prev && lane <= k) ? base : mystart;
+      prev = k + 1;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const bool on = a[q] == k;
+        const uint64_t bal = __ballot(on);
+        if (on) hg[base + __builtin_popcountll(bal & lt)] = make_uint2((uint32_t)(q * 64 + lane), __float_as_uint(gv[q]));
+        base += __builtin_popcountll(bal);
+      }
+    }
+    mystart = (lane >= prev && lane <= 32) ? base : mystart;
+    if (lane <= 32) rstart[(size_t)g * RS_LD + lane] = (uint16_t)mystart;
+  }
+}
+
+__device__ __forceinline__ float bcastf(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+struct PointArgs {
+  const uint2* hits;        // [G][C2]
+  const uint16_t* rstart;   // [G][RS_LD]
+  const float* W2;          // [C2][C1]
+  const float* Pp;          // [B*N][C1]
+  const float* Q;           // [G][C1]
+  const float* xyz;         // [B*N][3]
+  const float* new_xyz;     // [G][3]
+  const int32_t* rows;      // [B*S*32] row of its cloud, sorted by point
+  const int32_t* pts;       // [B*S*32] point of its cloud
+  float* dP;                // [B*N][C1], zero-initialised (list ends are added)
+  float* dW1;               // [C1][ldw]: columns 0..2 += dh^T (xyz - centre)
+  float* db1;               // [C1] += column sums of dh (may be NULL)
+  int N, S, C1, C2, ldw;
+  long entries;
+};
+
+// NW wavefronts; lane l owns columns col0 + 2 l, 2 l + 1 of the workgroup's 128-column slice; GF rows in flight.
+template <int NW, int GF>
+__global__ __launch_bounds__(NW * 64) void pool_point_kernel(PointArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];      // [C2][PP_COLS], then reused for the final sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col0 = blockIdx.y * PP_COLS, C1 = p.C1, C2 = p.C2;
+  for (int f = tid; f < C2 * (PP_COLS / 4); f += NW * 64) {
+    const int c = f / (PP_COLS / 4), q4 = (f % (PP_COLS / 4)) * 4;
+    *reinterpret_cast<float4*>(&wlds[c * PP_COLS + q4]) = *reinterpret_cast<const float4*>(p.W2 + (size_t)c * C1 + col0 + q4);
+  }
+  __syncthreads();
+  const int SK = p.S * 32;
+  const long nbatch = (p.entries + 63) >> 6;
+  // XCD-aware walk: workgroups x, x + 8, ... share an XCD; XCD x takes the x-th contiguous eighth of the batches (whole
+  // clouds: their P' / Q tables and hit lists are gathered through ONE L2)
+  long bt = (long)blockIdx.x * NW + wave, nw = (long)gridDim.x * NW, bt_end = nbatch;
+  if ((gridDim.x & 7) == 0) {
+    const long per = (nbatch + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    bt = xcd * per + (long)(blockIdx.x >> 3) * NW + wave, nw = (long)(gridDim.x >> 3) * NW;
+    bt_end = (xcd + 1) * per < nbatch ? (xcd + 1) * per : nbatch;
+  }
+  v2f ax = {0.f, 0.f}, ay = ax, az = ax, ab = ax;
+  const float* wl = wlds + 2 * lane;
+  for (; bt < bt_end; bt += nw) {
+    const long e = bt * 64 + lane;
+    int gp = -1, grp = 0, nh = 0, hb = 0;      // global point, global group, hits of the row, first hit
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (e < p.entries) {
+      const long b = e / SK;
+      const int rid = p.rows[e], pj = p.pts[e];
+      grp = (int)(b * p.S + (rid >> 5));
+      gp = (int)(b * p.N + pj);
+      const uint16_t* rs = p.rstart + (size_t)grp * RS_LD + (rid & 31);
+      const int r0 = rs[0], r1 = rs[1];
+      nh = r1 - r0, hb = grp * C2 + r0;
+      const float* q = p.xyz + (size_t)gp * 3;
+      const float* c = p.new_xyz + (size_t)grp * 3;
+      dx = q[0] - c[0], dy = q[1] - c[1], dz = q[2] - c[2];
+    }
+    const int nr = (int)min((long)64, p.entries - bt * 64);
+    const int first = __builtin_amdgcn_readlane(gp, 0), last = __builtin_amdgcn_readlane(gp, nr - 1);
+    int cur = first;
+    v2f acc = {0.f, 0.f};
+    auto flush = [&](int point) {
+      float* o = p.dP + (size_t)point * C1 + col0 + 2 * lane;
+      if (point == first || point == last) {      // its list may continue in a neighbouring batch
+        atomicAdd(o, acc.x);
+        atomicAdd(o + 1, acc.y);
+      } else {
+        *reinterpret_cast<v2f*>(o) = acc;
+      }
+      ab += acc;
+      acc = v2f{0.f, 0.f};
+    };
+    // rows with hits, GF of them in flight: hit list (lane h holds hit h), Q row of the group and P' row of the point
+    uint64_t todo = __ballot(nh > 0);
+    while (todo) {      // wave-uniform
+      int ru[GF];
+      uint2 hv[GF];
+      v2f qv[GF], pv[GF];
+#pragma unroll
+      for (int u = 0; u < GF; ++u) {
+        ru[u] = todo ? __builtin_ctzll(todo) : -1;
+        todo &= todo - 1;
+      }
+#pragma unroll
+      for (int u = 0; u < GF; ++u) {
+        hv[u] = make_uint2(0u, 0u);
+        qv[u] = pv[u] = v2f{0.f, 0.f};
+        if (ru[u] >= 0) {
+          const int n_ = __builtin_amdgcn_readlane(nh, ru[u]), b_ = __builtin_amdgcn_readlane(hb, ru[u]);
+          if (lane < n_) hv[u] = p.hits[(size_t)b_ + lane];
+          qv[u] = *reinterpret_cast<const v2f*>(p.Q + (size_t)__builtin_amdgcn_readlane(grp, ru[u]) * C1 + col0 + 2 * lane);
+          pv[u] = *reinterpret_cast<const v2f*>(p.Pp + (size_t)__builtin_amdgcn_readlane(gp, ru[u]) * C1 + col0 + 2 * lane);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < GF; ++u) {
+        if (ru[u] < 0) continue;      // wave-uniform
+        const int r = ru[u];
+        const int n_ = __builtin_amdgcn_readlane(nh, r), b_ = __builtin_amdgcn_readlane(hb, r);
+        v2f s0 = {0.f, 0.f}, s1 = s0;
+        uint2 cur_h = hv[u];
+        for (int h0 = 0; h0 < n_; h0 += 64) {      // (more than 64 channels on one row: rare)
+          if (h0 > 0) cur_h = (h0 + lane < n_) ? p.hits[(size_t)b_ + h0 + lane] : make_uint2(0u, 0u);
+          const int m_ = min(64, n_ - h0);
+          int h = 0;
+          for (; h + 1 < m_; h += 2) {      // two hits per trip: two LDS reads in flight
+            const int c0 = __builtin_amdgcn_readlane((int)cur_h.x, h), c1 = __builtin_amdgcn_readlane((int)cur_h.x, h + 1);
+            const float g0 = bcastf(__uint_as_float(cur_h.y), h), g1 = bcastf(__uint_as_float(cur_h.y), h + 1);
+            const v2f w0 = *reinterpret_cast<const v2f*>(wl + c0 * PP_COLS);
+            const v2f w1 = *reinterpret_cast<const v2f*>(wl + c1 * PP_COLS);
+            s0 += g0 * w0;
+            s1 += g1 * w1;
+          }
+          if (h < m_) {
+            const int c0 = __builtin_amdgcn_readlane((int)cur_h.x, h);
+            const float g0 = bcastf(__uint_as_float(cur_h.y), h);
+            s0 += g0 * *reinterpret_cast<const v2f*>(wl + c0 * PP_COLS);
+          }
+        }
+        v2f row = s0 + s1;
+        const v2f gate = pv[u] + qv[u];      // the forward's own expression: relu(P'[j] + Q[g]) is on where this is > 0
+        row.x = gate.x > 0.f ? row.x : 0.f, row.y = gate.y > 0.f ? row.y : 0.f;
+        const int pj = __builtin_amdgcn_readlane(gp, r);
+        if (pj != cur) {  // wave-uniform
+          flush(cur);
+          cur = pj;
+        }
+        const float rx = bcastf(dx, r), ry = bcastf(dy, r), rz = bcastf(dz, r);
+        acc += row;
+        ax += rx * row, ay += ry * row, az += rz * row;
+      }
+    }
+    flush(cur);
+  }
+  // dW1[:, 0:3] and db1: the four per-column sums of the workgroup's wavefronts meet in LDS (the W2 slice is not needed
+  // any more), one set of atomics per workgroup
+  __syncthreads();
+  float* red = wlds;      // [NW][4][PP_COLS]
+  {
+    float* r = red + (size_t)wave * 4 * PP_COLS + 2 * lane;
+    *reinterpret_cast<v2f*>(r) = ax;
+    *reinterpret_cast<v2f*>(r + PP_COLS) = ay;
+    *reinterpret_cast<v2f*>(r + 2 * PP_COLS) = az;
+    *reinterpret_cast<v2f*>(r + 3 * PP_COLS) = ab;
+  }
+  __syncthreads();
+  for (int f = tid; f < 4 * PP_COLS; f += NW * 64) {
+    const int q = f / PP_COLS, c = f - q * PP_COLS;
+    float t = 0.f;
+    for (int w = 0; w < NW; ++w) t += red[(size_t)w * 4 * PP_COLS + q * PP_COLS + c];
+    if (q < 3)
+      atomicAdd(p.dW1 + (size_t)(col0 + c) * p.ldw + q, t);
+    else if (p.db1)
+      atomicAdd(p.db1 + col0 + c, t);
+  }
+}
+
+}  // namespace
+
+// workspace of pzn_sa_level_bwd_pt_f32: hit lists [B*S][C2] x 8 bytes + row offsets [B*S][34] x 2 bytes
+PZN_EXPORT size_t pzn_sa_level_bwd_pt_workspace_bytes(int B, int S, int C2) {
+  if (B <= 0 || S <= 0 || C2 <= 0) return 0;
+  const size_t G = (size_t)B * S;
+  return ((G * C2 * sizeof(uint2) + 255) / 256) * 256 + ((G * RS_LD * sizeof(uint16_t) + 255) / 256) * 256;
+}
+
+// Backward of the pooled level behind pzn_sa_level_fwd_*: dW2, db2 (overwritten, or added to when accumulate), the per-point
+// sums dP[B*N, C1] of the rows' gradient (overwritten; dh itself is never written), dW1[:, 0:3] += dh^T (xyz[idx] - centre)
+// and db1 += column sums of dh (dW1[C1, 3+D] and db1[C1] are ADDED to; db1 may be NULL).  rows / pts: the inverse neighbour
+// lists of idx (pzn_knn_inverse_lists).  PZN_EUNSUPPORTED for shapes the kernels do not take (C1 % 128, C2 not 64 / 128 / 256).
+PZN_EXPORT int pzn_sa_level_bwd_pt_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
+                                       const float* Pp, const float* Q, const int64_t* idx, const float* xyz,
+                                       const float* new_xyz, const int32_t* rows, const int32_t* pts, int B, int N, int S, int D,
+                                       int C1, int C2, float* dP, float* dW2, float* db2, float* dW1, float* db1, int accumulate,
+                                       void* workspace, pzn_stream_t stream) {
+  PZN_CHECK_ARG(dout && argmax && out && W2 && Pp && Q && idx && xyz && new_xyz && rows && pts && dP && dW2 && db2 && dW1 && workspace);
+  PZN_CHECK_ARG(B > 0 && N > 0 && S > 0 && D >= 0 && C1 > 0 && C2 > 0 && (long)B * N < 2147483647L);
+  PZN_CHECK_ARG((long)B * S * 32 < 2147483647L && (long)B * S * C2 < 2147483647L);
+  if (C1 % PP_COLS != 0 || !(C2 == 64 || C2 == 128 || C2 == 256)) return PZN_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(W2) & 15) || (reinterpret_cast<uintptr_t>(Pp) & 7) || (reinterpret_cast<uintptr_t>(Q) & 7) ||
+      (reinterpret_cast<uintptr_t>(dP) & 7) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return PZN_EUNSUPPORTED;
+  hipStream_t st = pzn_hip_stream(stream);
+  if (!accumulate) {
+    if (pzn_zero_async(dW2, (size_t)C2 * C1, st) != PZN_OK) return PZN_ELAUNCH;
+    if (pzn_zero_async(db2, (size_t)C2, st) != PZN_OK) return PZN_ELAUNCH;
+  }
+  const int G = B * S;
+  // weight gradient of the pooled layer: the sparse pass of csrc/poolbwd.hip on regenerated rows (dh == NULL: no input-gradient pass)
+  PznGateSource gs{Pp, idx, nullptr, new_xyz, nullptr, nullptr, 3 + D, N, S, Q, nullptr, nullptr};
+  int rc = pzn_pool_bwd_sparse(dout, argmax, out, W2, nullptr, nullptr, dW2, db2, G, C1, C2, st, &gs);
+  if (rc != PZN_OK) return rc;
+  uint2* hits = static_cast<uint2*>(workspace);
+  uint16_t* rstart = reinterpret_cast<uint16_t*>(static_cast<unsigned char*>(workspace) + (((size_t)G * C2 * sizeof(uint2) + 255) / 256) * 256);
+  const int hb = (G + PH_T / 64 - 1) / (PH_T / 64);
+  const dim3 hgrid((unsigned)(hb < 4096 ? hb : 4096));
+  if (C2 == 64)
+    hipLaunchKernelGGL((pool_hits_kernel<1>), hgrid, dim3(PH_T), 0, st, dout, argmax, out, G, hits, rstart);
+  else if (C2 == 128)
+    hipLaunchKernelGGL((pool_hits_kernel<2>), hgrid, dim3(PH_T), 0, st, dout, argmax, out, G, hits, rstart);
+  else
+    hipLaunchKernelGGL((pool_hits_kernel<4>), hgrid, dim3(PH_T), 0, st, dout, argmax, out, G, hits, rstart);
+  if (pzn_zero_async(dP, (size_t)B * N * C1, st) != PZN_OK) return PZN_ELAUNCH;      // points nobody gathered; list ends add
+  PointArgs a{hits, rstart, W2, Pp, Q, xyz, new_xyz, rows, pts, dP, dW1, db1, N, S, C1, C2, 3 + D, (long)B * S * 32};
+  const int ny = C1 / PP_COLS;
+  const size_t lds = (size_t)C2 * PP_COLS * sizeof(float);      // >= the final sums' 16 x 4 x 128 floats for C2 >= 64
+  static const int gf = [] { const char* e = getenv("PZN_PP_GF"); return e ? atoi(e) : 8; }();      // tuning aid: rows in flight
+  static const int wgs = [] { const char* e = getenv("PZN_PP_WGS"); return e ? atoi(e) : 0; }();    // tuning aid: workgroups per slice
+  const int per_cu = 1;      // 16 wavefronts of 92 registers: one workgroup per CU whatever the slice's size
+  int gx = wgs > 0 ? wgs : 256 * per_cu / ny;
+  if (gx < 8) gx = 8;
+  gx &= ~7;
+  const dim3 grid((unsigned)gx, (unsigned)ny);
+#define PZN_PP(GFV)                                                                                                        \
+  do {                                                                                                                    \
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_point_kernel<16, GFV>),                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)       \
+      return PZN_ELAUNCH;                                                                                                 \
+    hipLaunchKernelGGL((pool_point_kernel<16, GFV>), grid, dim3(1024), lds, st, a);                                       \
+  } while (0)
+  if (gf == 4)
+    PZN_PP(4);
+  else
+    PZN_PP(8);
+#undef PZN_PP
+  PZN_RETURN_LAUNCH_STATUS();
+}

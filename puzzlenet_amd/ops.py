@@ -1641,14 +1641,29 @@ class _SaLevelFused(torch.autograd.Function):
             db1 = torch.zeros((C1,), dtype=torch.float32, device=dev)
             dW2 = torch.empty_like(w2)
             db2 = torch.empty((C2,), dtype=torch.float32, device=dev)
-        dh = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
         off = torch.empty((B * (N + 1),), dtype=torch.int32, device=dev)
         rows = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
         pts = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
         dP = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
         dfeat = None
+        by_point = _SA_BYPOINT
+        if by_point:
+            # round 5 (csrc/sapool.hip): input-gradient pass and per-point sum in one walk by point, dh never in memory
+            with _on(dev):
+                _call("pzn_knn_inverse_lists", _p(idx), B, N, S, 32, _p(off), _p(rows), _p(pts), _stream())
+                ws = torch.empty((_lib.load().pzn_sa_level_bwd_pt_workspace_bytes(B, S, C2) + 3) // 4, dtype=torch.float32, device=dev)
+                try:
+                    _call("pzn_sa_level_bwd_pt_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(P), _p(Q), _p(idx), _p(xyz), _p(new_xyz),
+                          _p(rows), _p(pts), B, N, S, D, C1, C2, _p(dP), _p(dW2), _p(db2), _p(dW1), _p(db1), int(direct), _p(ws),
+                          _stream(), flops=2 * R * (2 * C1 * C2))
+                except _lib.PznUnsupported:
+                    by_point = False
+        if not by_point:
+            dh = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
         with _on(dev):
-            if _SA_ROWMASK:
+            if by_point:
+                pass
+            elif _SA_ROWMASK:
                 # rows of dh that won no channel are exactly zero (half of them at level 1): neither written nor read
                 rmask = torch.empty((R,), dtype=torch.int32, device=dev)
                 if SA_ROWMASK_STATS is not None:      # measurement only (bench.py): the masks, to count the rows that exist
@@ -1660,9 +1675,12 @@ class _SaLevelFused(torch.autograd.Function):
                 rmask = None
                 _call("pzn_sa_level_bwd_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(P), _p(Q), _p(idx), _p(new_xyz), B, N, S, D,
                       C1, C2, _p(dh), _p(dW2), _p(db2), _p(dW1), _p(db1), int(direct), _stream(), flops=2 * R * (2 * C1 * C2))
-            _call("pzn_knn_inverse_lists", _p(idx), B, N, S, 32, _p(off), _p(rows), _p(pts), _stream())
+            if not by_point:
+                _call("pzn_knn_inverse_lists", _p(idx), B, N, S, 32, _p(off), _p(rows), _p(pts), _stream())
             # dP = per-point sums of dh; dW1[:,0:3] += dh^T xyz[idx] (centres = NULL: their part went through Q above)
-            if rmask is not None:
+            if by_point:
+                pass
+            elif rmask is not None:
                 _call("pzn_sa_point_l1_bwd_rm_f32", _p(dh), _p(xyz), None, _p(rows), _p(pts), B, N, S, D, C1, _p(dP),
                       _p(dW1), None, _p(rmask), _stream())
             else:
@@ -1683,6 +1701,7 @@ class _SaLevelFused(torch.autograd.Function):
 SA_ROWMASK_STATS = None      # bench.py sets this to a list: every masked level backward appends (row mask [B*S] int32, C1)
 _SA_PACKED = os.environ.get("PZN_SA_PACKED", "1") != "0"     # tuning aid: 0 = weight split inside pzn_sa_level_fwd_ws_f32
 _SA_ROWMASK = os.environ.get("PZN_SA_ROWMASK", "1") != "0"     # tuning aid: 0 = every row of dh written and read
+_SA_BYPOINT = os.environ.get("PZN_SA_BYPOINT", "1") != "0"     # tuning aid: 0 = rounds 2-4's two launches with dh in memory between them
 _SA_REGEN = os.environ.get("PZN_SA_REGEN", "1") != "0"     # tuning aid: 0 = the pooled backward reads its gate from h
 _SA_POINT = os.environ.get("PZN_SA_POINT", "1") != "0"     # tuning aid: 0 = the grouped-row path (_SaMlpMax)
 _SA_FUSED = os.environ.get("PZN_SA_FUSED", "1") != "0"     # tuning aid: 0 = per-point first layer WITH its rows in memory (_SaMlpMaxPoint)
