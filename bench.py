@@ -355,6 +355,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = runner.step()
+    t_enq = time.perf_counter() - t0      # the host has enqueued the last step (nothing in a step synchronises)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -514,7 +515,12 @@ def main():
         g_ms = ms_gf + ms_gb
         g_ach = g_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
         g_traffic, g_src = pmc_traffic("sa_gather_stage_bytes_per_step", B, N)
-        roofline_sa_gather = {
+        if "pzn_sa_level_bwd_pt_f32" in kern:
+            roofline_sa_gather = {"bound": "hbm", "kernel": "none: round 5 folds the per-point sums into the input-gradient walk (pool_point_kernel, "
+                                                            "csrc/sapool.hip; priced in roofline_pool_bwd); dh and its list sum no longer exist",
+                                  "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+        else:
+          roofline_sa_gather = {
             "bound": "hbm", "kernel": "sa_point_l1_bwd_kernel (pzn_sa_point_l1_bwd[_rm]_f32: the per-point sums of dh over inverse neighbour "
                                       "lists; with the row mask (_rm, default) rows that won no channel - exactly zero, about half of level 1 and "
                                       "a third of level 2 - are not read: `algorithmic_bytes_per_step` counts the rows that exist (popcount of "
@@ -557,19 +563,31 @@ def main():
         #      one non-zero per (group, channel) = one row axpy of length C1 in each pass.  Two ceilings: the bytes it must
         #      move (dh[R*32, C1] written once, gate rows P'[idx] re-read from L2 not counted) and the vector lanes it must
         #      issue (hits x C1 multiply-adds per pass, one lane-slot each, against the chip's vector issue rate).
-        n_pb, ms_pb = per_step("pzn_sa_level_bwd_rm_f32" if "pzn_sa_level_bwd_rm_f32" in kern else "pzn_sa_level_bwd_f32")
+        by_point = "pzn_sa_level_bwd_pt_f32" in kern       # round 5 (csrc/sapool.hip): dh is never in memory
+        n_pb, ms_pb = per_step("pzn_sa_level_bwd_pt_f32" if by_point else
+                               ("pzn_sa_level_bwd_rm_f32" if "pzn_sa_level_bwd_rm_f32" in kern else "pzn_sa_level_bwd_f32"))
         lvl = ((B * 512, 128, 128), (B * 256, 256, 256))              # (groups R, C1, C2) of the two levels
         pb_bytes_dense = 2 * sum(4.0 * R_ * 32 * C1_ + 4.0 * R_ * C2_ * 2 + 4.0 * C1_ * C2_ for R_, C1_, C2_ in lvl)
         pb_bytes = pb_bytes_dense
+        if by_point:
+            # what the by-point form must move: the pooled tensors (arg-max, out, dout) once for the weight-gradient pass and once
+            # for the hit lists, the hit lists (8 bytes per live channel: upper bound = every channel) written once and read
+            # once per 128-column slice, dP written once (after its zero fill), the per-point sums; the P' / Q rows the gates are
+            # regenerated from are L2-resident re-reads and not counted, as before
+            pb_bytes = 2 * sum(2 * 12.0 * R_ * C2_ + 8.0 * R_ * C2_ * (1 + C1_ // 128) + 2 * 4.0 * (R_ // (512 if C1_ == 128 else 256)) *
+                               (N if C1_ == 128 else 512) * C1_ + 4.0 * C1_ * C2_ for R_, C1_, C2_ in lvl)
         if dh_rows_bytes is not None and "pzn_sa_level_bwd_rm_f32" in kern:
             # with the row mask only the rows that exist are written (rows are stored in pairs: this counts the rows with a bit)
             pb_bytes = pb_bytes_dense - 2 * sum(4.0 * R_ * 32 * C1_ for R_, C1_, C2_ in lvl) + dh_rows_bytes
         pb_fma = 2 * sum(2.0 * R_ * C2_ * C1_ for R_, C1_, C2_ in lvl)         # input-gradient + weight-gradient pass
         t_hbm, t_valu = pb_bytes / (HBM_PEAK_GBS * 1e9), pb_fma / VALU_LANE_SLOTS_PER_S
         roofline_pool_bwd = {
-            "bound": "hbm", "kernel": "pool_dgrad_kernel + pool_wgrad_kernel (csrc/poolbwd.hip) behind pzn_sa_level_bwd[_rm]_f32, "
+            "bound": "hbm", "kernel": ("pool_wgrad_kernel (csrc/poolbwd.hip) + pool_hits_kernel + pool_point_kernel (csrc/sapool.hip) behind "
+                                       "pzn_sa_level_bwd_pt_f32, 4 calls per step (2 levels x 2 clouds): the rows' gradient dh is computed by "
+                                       "point and never written; `dense_bytes_per_step` is what rounds 2-4 priced (dh written and read)") if by_point else
+                                      ("pool_dgrad_kernel + pool_wgrad_kernel (csrc/poolbwd.hip) behind pzn_sa_level_bwd[_rm]_f32, "
                                       "4 launches per step (2 levels x 2 clouds); with the row mask (_rm) the dh term of the bytes counts "
-                                      "the rows that exist (device popcount of the masks), `dense_bytes_per_step` is the figure without it",
+                                      "the rows that exist (device popcount of the masks), `dense_bytes_per_step` is the figure without it"),
             "achieved": pb_bytes / (ms_pb * 1e-3) / 1e9 if ms_pb > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (pb_bytes / (ms_pb * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_pb > 0 else 0.0, "traffic": None,
             "algorithmic_bytes_per_step": pb_bytes, "dense_bytes_per_step": pb_bytes_dense, "ms_per_step": ms_pb,
@@ -723,7 +741,10 @@ def main():
                                    f"(predict5 + loss_mode 1 losses incl. 4x EMD + backward + Adam)",
                        "global_batch": world * B, "points": N, "parallelism": f"dp{world}", "encoder_streams": 2,
                        "matrix_core_path": "bf16x3 split precision (fp32 results; six bf16 MFMAs per product)",
-                       "attention": args.attn, "build_id": build_id()},
+                       "attention": args.attn, "build_id": build_id(),
+                       # host time to ENQUEUE a step against the step itself: close to 1 = this box's host is the bottleneck
+                       "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+                       "host_enqueue_over_step": t_enq / dt},
             "roofline": roofline,
             "roofline_sa_level": roofline_sa_level,
             "roofline_mfma_family": roofline_mfma_family,

@@ -175,86 +175,7 @@ __global__ __launch_bounds__(KNN_WAVES* PZN_WAVE) void knn32_kernel(
 }
 
 // ------------------------------------------ K <= 32, distances kept in registers --
-// Same algorithm as knn32_kernel, for 64 <= N <= 64*R: the R distances a lane owns stay in VGPRs
-// between the two passes, so pass 2 is one v_cmp + ballot per row (a float pre-filter d <= tau_d,
-// exact key test only on the rare rows that pass) instead of recomputing every distance.
-template <int R>
-__global__ __launch_bounds__(KNN_WAVES* PZN_WAVE) void knn32_reg_kernel(
-    const float* __restrict__ xyz, const float* __restrict__ new_xyz, int N, int S, int K, int q_per_block,
-    int64_t* __restrict__ idx) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint64_t* cand_all = reinterpret_cast<uint64_t*>(smem_raw);
-  float* sx = reinterpret_cast<float*>(smem_raw + KNN_WAVES * KNN_CAND_CAP * sizeof(uint64_t));
-  const float* sy = sx + N;
-  const float* sz = sy + N;
-  const int b = blockIdx.y;
-  const int tid = threadIdx.x;
-  const int lane = tid & (PZN_WAVE - 1);
-  const int wave = tid / PZN_WAVE;
-  stage_cloud(xyz + (size_t)b * N * 3, N, sx, KNN_WAVES * PZN_WAVE, tid);
-  __syncthreads();
-  uint64_t* cand = cand_all + wave * KNN_CAND_CAP;
-  const int s_begin = blockIdx.x * q_per_block;
-  const int s_end = min(S, s_begin + q_per_block);
-
-  for (int s = s_begin + wave; s < s_end; s += KNN_WAVES) {
-    const float* q = new_xyz + ((size_t)b * S + s) * 3;
-    const float qx = q[0], qy = q[1], qz = q[2];
-    float d[R];
-    float md = INFINITY;
-    int mi = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      int j = r * PZN_WAVE + lane;
-      float v = INFINITY;
-      if (j < N) v = pzn::sqdist3(qx, qy, qz, sx[j], sy[j], sz[j]);
-      d[r] = v;
-      bool lt = v < md;  // strict: the lowest index of equal distances stays (rows ascend with the index)
-      md = lt ? v : md;
-      mi = lt ? j : mi;
-    }
-    const uint64_t lmin = md < INFINITY ? (((uint64_t)__float_as_uint(md) << 32) | (uint32_t)mi) : ~0ull;
-    uint64_t best = bitonic_sort64(lmin, lane);
-    uint64_t tau = bcast_u64(best, 31);
-    float tau_d = __uint_as_float((uint32_t)(tau >> 32));
-
-    int cnt = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (__ballot(d[r] <= tau_d) == 0) continue;  // the common case: nobody in this row can matter
-      int j = r * PZN_WAVE + lane;
-      uint64_t key = ((uint64_t)__float_as_uint(d[r]) << 32) | (uint32_t)j;
-      bool pred = d[r] < INFINITY && key < tau && key != lmin;
-      unsigned long long mask = __ballot(pred);
-      if (mask == 0) continue;
-      int pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-      if (pred) cand[pos] = key;
-      cnt += __popcll(mask);
-      while (cnt >= 32) {
-        pzn::wave_lds_sync();
-        uint64_t c = lane >= 32 ? cand[lane - 32] : best;
-        best = bitonic_sort64(c, lane);
-        tau = bcast_u64(best, 31);
-        tau_d = __uint_as_float((uint32_t)(tau >> 32));
-        uint64_t mv = (lane + 32 < cnt) ? cand[lane + 32] : 0;
-        pzn::wave_lds_sync();
-        if (lane + 32 < cnt) cand[lane] = mv;
-        cnt -= 32;
-        pzn::wave_lds_sync();
-      }
-    }
-    if (cnt > 0) {
-      pzn::wave_lds_sync();
-      uint64_t c = lane >= 32 ? ((lane - 32 < cnt) ? cand[lane - 32] : ~0ull) : best;
-      best = bitonic_sort64(c, lane);
-      pzn::wave_lds_sync();
-    }
-    if (lane < K) idx[((size_t)b * S + s) * K + lane] = (int64_t)(uint32_t)best;
-  }
-}
-
-// ------------------------------------- K = 32 neighbours + padded group, one kernel --
-// knn32_reg_kernel followed, per query, by the model-internal group write (group.hip,
+// Round-1 register search (R distances per lane in VGPRs, row-wise ballot collection) followed, per query, by the model-internal group write (group.hip,
 // group_pad_direct_kernel): rows {dx,dy,dz,0,f_0..f_{D-1}} of the 32 neighbours.  Selection is VALU work,
 // the group write is HBM work; in one kernel the wavefronts that are selecting hide behind the ones
 // that are streaming rows out, so the stage costs max(select, write) instead of their sum.
@@ -834,11 +755,6 @@ __global__ __launch_bounds__(KNN_WAVES* PZN_WAVE) void ball_kernel(
   }
 }
 
-// PZN_KNN_LEGACY=1: pzn_knn_f32 keeps the first-generation kernels (tuning aid / A-B measurements)
-inline bool pzn_knn_legacy() {
-  static const bool v = [] { const char* e = getenv("PZN_KNN_LEGACY"); return e && e[0] == '1'; }();
-  return v;
-}
 
 struct Geometry {
   dim3 grid;
@@ -956,27 +872,13 @@ PZN_EXPORT int pzn_knn_f32(const float* xyz, const float* new_xyz, int B, int N,
   PZN_CHECK_ARG(xyz && new_xyz && idx && B > 0 && N > 0 && S > 0 && K > 0 && K <= N && B <= 65535);
   hipStream_t st = pzn_hip_stream(stream);
   if (K <= 32) {
-    if (K <= N && N >= 64 && N <= 8192 && !pzn_knn_legacy()) {
+    if (K <= N && N >= 64 && N <= 8192) {
       int rc = launch_select<false>(xyz, nullptr, new_xyz, B, N, S, K, 0, idx, nullptr, nullptr, st);
       if (rc != PZN_EUNSUPPORTED) return rc;
     }
     Geometry g = geometry(B, N, S, KNN_WAVES * KNN_CAND_CAP * sizeof(uint64_t));
-    const int rows = (N + PZN_WAVE - 1) / PZN_WAVE;
-#define PZN_KNN_REG(RR)                                                                                          \
-  do {                                                                                                           \
-    if (set_lds(&knn32_reg_kernel<RR>, g.lds) != PZN_OK) return PZN_ELAUNCH;                                     \
-    hipLaunchKernelGGL((knn32_reg_kernel<RR>), g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K, \
-                       g.q_per_block, idx);                                                                      \
-  } while (0)
-    if (g.use_lds && N >= 64 && rows <= 8)
-      PZN_KNN_REG(8);
-    else if (g.use_lds && N >= 64 && rows <= 16)
-      PZN_KNN_REG(16);
-    else if (g.use_lds && N >= 64 && rows <= 32)
-      PZN_KNN_REG(32);
-    else if (g.use_lds && N >= 64 && rows <= 64)
-      PZN_KNN_REG(64);
-    else {
+    // any other N (clouds below 64 or beyond 8192 points): the general kernel, distances recomputed per round
+    {
       if (g.use_lds) {
         if (set_lds(&knn32_kernel<true>, g.lds) != PZN_OK) return PZN_ELAUNCH;
         hipLaunchKernelGGL(knn32_kernel<true>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
@@ -986,7 +888,6 @@ PZN_EXPORT int pzn_knn_f32(const float* xyz, const float* new_xyz, int B, int N,
                            g.q_per_block, idx);
       }
     }
-#undef PZN_KNN_REG
   } else {
     Geometry g = geometry(B, N, S, 0);
     if (g.use_lds) {

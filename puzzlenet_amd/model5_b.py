@@ -152,11 +152,9 @@ class PCTransformer_nonsort(nn.Module):
 
     def local_features(self, xyz):
         """:447-448, the per-point MLP in front of the set abstraction (does not need the sampling plan)."""
-        if xyz.is_cuda and _BN_FUSED:      # BatchNorm + ReLU as one launch each way (csrc/bnpoints.hip)
-            x_feature = ops.bn_points_relu(ops.linear(xyz, self.mlp1.weight, self.mlp1.bias), self.bn1)   # :447
-            return ops.bn_points_relu(ops.linear(x_feature, self.mlp2.weight, self.mlp2.bias), self.bn2)  # :448
-        x_feature = F.relu(self.bn1(ops.linear(xyz, self.mlp1.weight, self.mlp1.bias)))          # :447
-        return F.relu(self.bn2(ops.linear(x_feature, self.mlp2.weight, self.mlp2.bias)))        # :448
+        # BatchNorm + ReLU as one launch each way (csrc/bnpoints.hip); ops.* raise on CPU tensors: there is no eager path
+        x_feature = ops.bn_points_relu(ops.linear(xyz, self.mlp1.weight, self.mlp1.bias), self.bn1)   # :447
+        return ops.bn_points_relu(ops.linear(x_feature, self.mlp2.weight, self.mlp2.bias), self.bn2)  # :448
 
     def _block_params(self):
         return [(a.mlpq.weight, a.mlpq.bias, a.mlpk.weight, a.mlpk.bias, a.mlpv.weight, a.mlpv.bias, a.out.weight, a.out.bias)
@@ -215,7 +213,6 @@ class PCTransformer_nonsort(nn.Module):
         return f_global, x2, attention, out, x_feature
 
 
-_BN_FUSED = os.environ.get("PZN_BN_FUSED", "1") != "0"     # tuning aid
 _ATTN_CHAIN = os.environ.get("PZN_ATTN_CHAIN", "1") != "0"     # tuning aid: 0 = four autograd nodes + cat + linear
 _ATTN_FUSED = os.environ.get("PZN_ATTN_FUSED", "1") != "0"     # tuning aid: 0 = the composed block kernels (gemm.hip)
 # 1 = both encoders' chains in the same launches on one stream.  Measured slower than one chain per encoder and stream

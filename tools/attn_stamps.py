@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = os.path.join(ROOT, "puzzlenet_amd")
-STAMP_LIB = os.path.join(PKG, "libpzn_stamps.so")
+STAMP_LIB = os.path.join(PKG, "libpzn_diag.so")
 
 
 def build(extra=(), suffix=""):
