@@ -552,7 +552,8 @@ def main():
         roofline_emd = {
             "bound": "valu", "kernel": "emdf_b_kernel / emdf_k_kernel<0|1|2> / emdf_compact_kernel / emd_sort_x_kernel / emd_small_fused_kernel "
                                        "behind pzn_emd_fused_f32 (4 calls per step: N x N, B x B, 2 x 128 x 128)",
-            "achieved": e_ach, "peak": 39.3, "unit": "T lane-slot/s", "frac": e_ach / 39.3, "traffic": None,
+            "achieved": e_ach, "peak": 39.3, "unit": "T lane-slot/s", "frac": e_ach / 39.3,
+            "traffic": pmc_traffic("emd_bytes_per_step", B, N)[0],
             "pair_evaluations_executed_per_step": ev_exec, "pair_evaluations_reference_schedule_per_step": ev_ref,
             "issue_slots_per_evaluation": LANE_OPS, "ms_per_step": ms_e, "launches_per_step": n_e,
             "note": "executed evaluations counted on the device (active lists + x windows); the reference's schedule (30 n m per pair) "
@@ -589,7 +590,8 @@ def main():
                                       "4 launches per step (2 levels x 2 clouds); with the row mask (_rm) the dh term of the bytes counts "
                                       "the rows that exist (device popcount of the masks), `dense_bytes_per_step` is the figure without it"),
             "achieved": pb_bytes / (ms_pb * 1e-3) / 1e9 if ms_pb > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": (pb_bytes / (ms_pb * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_pb > 0 else 0.0, "traffic": None,
+            "frac": (pb_bytes / (ms_pb * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_pb > 0 else 0.0,
+            "traffic": pmc_traffic("pool_bwd_stage_bytes_per_step", B, N)[0],
             "algorithmic_bytes_per_step": pb_bytes, "dense_bytes_per_step": pb_bytes_dense, "ms_per_step": ms_pb,
             "launches_per_step": n_pb,
             "vector_issue": {"lane_multiply_adds_per_step": pb_fma, "peak_lane_slots_per_s": VALU_LANE_SLOTS_PER_S,

@@ -96,6 +96,11 @@ class TrainStep:
         self._saved_fps_generator = getattr(model, "fps_generator", None)
         if fps_generator is not None:
             model.fps_generator = fps_generator
+        # one device, one stream of Python backward functions: autograd's per-device worker thread only adds a hand-off per
+        # backward() and GIL traffic (host time of a step 5.3 -> 5.1 ms, tools/host_enqueue_time.py); restored by close()
+        self._saved_autograd_mt = torch.autograd.is_multithreading_enabled()
+        if os.environ.get("PZN_AUTOGRAD_MT", "0") != "1":
+            torch.autograd.set_multithreading_enabled(False)
 
     def _fwd_bwd(self):
         self.grads.zero_()
@@ -149,6 +154,7 @@ class TrainStep:
         """Give the model back as it was handed in (a later direct model.training_step() returns {'loss': ...} again)."""
         self.model.defer_emd_loss = self._saved_defer
         self.model.fps_generator = self._saved_fps_generator
+        torch.autograd.set_multithreading_enabled(self._saved_autograd_mt)
         self._plans_ahead = None
         if hasattr(self.model, "use_plans"):
             self.model.use_plans(None)

@@ -43,7 +43,8 @@ def main():
     ap.add_argument("out")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--points", type=int, default=2048)
-    ap.add_argument("--steps-in-trace", type=int, default=7, help="1 warm-up + 2 timed + 1 + 3 instrumented steps")
+    ap.add_argument("--steps-in-trace", type=int, default=11,
+                    help="1 warm-up + 2 timed + (1 + 3) one-stream instrumented + (1 + 3) two-stream instrumented steps")
     a = ap.parse_args()
     import bench
     f, w = load(a.fetch), load(a.write)
@@ -73,10 +74,15 @@ def main():
     # 0.48 GB per step of the figure then reported belonged to sa_prep_kernel)
     sa = sel(r"^(sa_point_l1_bwd_kernel|sa_point_l1_fwd_kernel)")
     sa_b = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sa.values()) / a.steps_in_trace) or None
+    # the set-abstraction backward by point (round 5): weight-gradient pass, hit lists, the walk by point
+    pb = sel(r"^(pool_wgrad_kernel|pool_hits_kernel|pool_point_kernel|pool_dgrad_kernel)")
+    pb_b = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in pb.values()) / a.steps_in_trace) or None
+    emd = sel(r"^(emdf_|emd_)")
+    emd_b = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in emd.values()) / a.steps_in_trace) or None
     prep = sel(r"^sa_prep_kernel")
     prep_b = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in prep.values()) / a.steps_in_trace) or None
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, python3 bench.py --steps 2 --warmup 1 "
-                     "--no-cpu-baseline",
+                     "--no-cpu-baseline --no-other-workloads",
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE half-count, MI355X_MICROARCH.md)",
            "build_id": bench.build_id(), "batch": a.batch, "points": a.points,
            "knn_group_stage_bytes_per_step": stage,
@@ -87,6 +93,8 @@ def main():
            "mfma_family_bytes_per_step": mfma,
            "sa_gather_stage_bytes_per_step": sa_b,
            "sa_prep_bytes_per_step": prep_b,
+           "pool_bwd_stage_bytes_per_step": pb_b,
+           "emd_bytes_per_step": emd_b,
            "per_kernel": per}
     json.dump(doc, open(a.out, "w"), indent=1)
     print(json.dumps({k: doc[k] for k in ("build_id", "knn_group_stage_bytes_per_step", "knn_group_stage_algorithmic_bytes_per_step",
