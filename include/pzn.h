@@ -390,6 +390,26 @@ int pzn_sa_level_bwd_pt_f32(const float* dout, const int32_t* argmax, const floa
                             float* dW2, float* db2, float* dW1, float* db1, int accumulate, void* workspace,
                             pzn_stream_t stream);
 
+/* The per-point stem of the encoder in one launch each way (csrc/stem.hip, model5_b.py:447-448):
+ *   out = relu(bn2(mlp2(relu(bn1(mlp1(xyz))))))   xyz[B,N,3], mlp1 = (W1[64,3], b1[64]), mlp2 = (W2[64,64], b2[64]),
+ * bn1 / bn2 = BatchNorm1d(N) over the POINT axis of [B,N,64] (weight / bias / running buffers [N]; any may be NULL as the module
+ * has them; training != 0: batch statistics, running buffers updated in place as torch does).  out[B,N,64]; mean1 / invstd1 /
+ * mean2 / invstd2 [N] (written) feed the backward, which recomputes every activation from xyz.  bwd: dW1[64,3], db1[64],
+ * dW2[64,64], db2[64] and the BatchNorm weight / bias gradients [N] (these may be NULL) are ADDED to; no gradient for xyz;
+ * workspace = pzn_stem_bwd_workspace_bytes(N) bytes, 16-byte aligned, need not be cleared (the workgroups' partial sums).
+ * PZN_EUNSUPPORTED for B > 64 or W2 not 16-byte aligned (compose pzn_linear_* + pzn_bn_points_relu_* then). */
+int pzn_stem_fwd_f32(const float* xyz, const float* W1, const float* b1, const float* bn1_weight, const float* bn1_bias,
+                     float* bn1_running_mean, float* bn1_running_var, float bn1_momentum, float bn1_eps, const float* W2,
+                     const float* b2, const float* bn2_weight, const float* bn2_bias, float* bn2_running_mean,
+                     float* bn2_running_var, float bn2_momentum, float bn2_eps, int training, int B, int N, float* out,
+                     float* mean1, float* invstd1, float* mean2, float* invstd2, pzn_stream_t stream);
+size_t pzn_stem_bwd_workspace_bytes(int N);
+int pzn_stem_bwd_f32(const float* xyz, const float* dout, const float* W1, const float* b1, const float* W2, const float* b2,
+                     const float* bn1_weight, const float* bn1_bias, const float* bn2_weight, const float* bn2_bias,
+                     const float* mean1, const float* invstd1, const float* mean2, const float* invstd2, int training, int B,
+                     int N, float* dW1, float* db1, float* dW2, float* db2, float* dbn1_weight, float* dbn1_bias,
+                     float* dbn2_weight, float* dbn2_bias, void* workspace, pzn_stream_t stream);
+
 /* relu(BatchNorm1d(num_points)(x)) of the per-point feature MLP (model5_b.py:424, :447-448): x[B,N,C], the BN
  * "channel" axis is the POINT index, statistics over the B*C values of a point.  training != 0: batch statistics
  * (biased variance), running_mean / running_var updated in place as torch does (momentum, unbiased variance; may be
@@ -457,8 +477,10 @@ int pzn_attn_block_bwd_f32(const float* x, const float* Wq, const float* Wk, con
  * Every entry point takes nprob = 1 or 2 independent problems as arrays of nprob pointers (the two encoders of
  * predict5, model5_b.py:700-707, in one launch); B clouds each; all buffers 16-byte aligned.
  *   fwd:    r = x + relu(Wo (x - softmax(q k^T / 8) v) + bo) [B*L,E];  t = x - attn v [B*L,E];  mask [B*L,8] u32 = gate
- *           bits of the ReLU;  lse [B*L];  map[i] (may be NULL) [B,L,L]: map = scale P, or map += scale P when
- *           map_accumulate (the mean of the four blocks' maps, model5_b.py:468-469).
+ *           bits of the ReLU;  lse [B*L];  map[i] (may be NULL): map_mode 0: [B,L,L] = scale P; 1: += scale P (the mean of the
+ *           four blocks' maps, model5_b.py:468-469); 2 / 3: the same for [B,L/16,L] = the column sums of P over each strip
+ *           of 16 query rows - all that a consumer of the map's mean over its rows needs (model5_b.py:937-942: 1/16 of the
+ *           bytes, no [B,L,L] tensor).
  *   bwd_q:  query side of the backward from dr (+ dr2 when non-NULL: rows of ld_dr / ld_dr2 floats, so a column slice of
  *           a wider gradient needs no copy and the sum of two gradients no add): dz = dr . gate, dq [B*L,dk], delta [B*L],
  *           the image of da = -dz Wo, and for bwd_k only: u = dr + dz Wo [B*L,E] and dq_tiles [B*L,dk] in the kernels'
@@ -482,7 +504,7 @@ int pzn_attn_fused_proj(int nprob, const float* const* x, const void* const* w,
 int pzn_attn_fused_fwd(int nprob, const float* const* x, const void* const* qrp,
                        const void* const* krp, const void* const* vrp, const void* const* w,
                        const float* const* bo, int B, float* const* r, float* const* t,
-                       void* const* mask, float* const* map, float* const* lse, int map_accumulate,
+                       void* const* mask, float* const* map, float* const* lse, int map_mode,
                        float map_scale, pzn_stream_t stream);
 int pzn_attn_fused_bwd_q(int nprob, const float* const* dr, int ld_dr, const float* const* dr2,
                          int ld_dr2, const void* const* mask,

@@ -47,6 +47,7 @@ SOURCES = [
     ("sapoint.hip", NOSLP),
     ("sapool.hip", NOSLP),
     ("bnpoints.hip", NOSLP),
+    ("stem.hip", NOSLP),
     ("losstail.hip", NOSLP),
 ]
 if _OFF:

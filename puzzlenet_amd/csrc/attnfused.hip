@@ -251,7 +251,7 @@ struct FwdProb {
 struct FwdArgs {
   FwdProb p[2];
   int nb;
-  int map_accumulate;
+  int map_mode;      // bit 0: add to what map holds; bit 1: map holds column sums per 16-row strip, [B][L / 16][L]
   float map_scale;
 };
 
@@ -305,10 +305,17 @@ __global__ __launch_bounds__(NT16, 2) void attn_fwd_kernel(FwdArgs a) {
   if (g == 0) P.lse[row] = lse;
   STAMPK(1, 2);
   if (P.map) {
-    if (a.map_accumulate)
+    if (a.map_mode & 2) {      // only the column sums of the wavefront's 16 rows: map is [B][L / 16][L]
+      float* strip = P.map + ((size_t)cloud * (L / 16) + rt) * L;
+      if (a.map_mode & 1)
+        store_colsum16<1>(strip, S, stg, lane, a.map_scale);
+      else
+        store_colsum16<0>(strip, S, stg, lane, a.map_scale);
+    } else if (a.map_mode & 1) {
       store_rows16<16, 1>(P.map, row0, L, S, stg, lane, a.map_scale);
-    else
+    } else {
       store_rows16<16, 0>(P.map, row0, L, S, stg, lane, a.map_scale);
+    }
   }
   STAMPK(1, 3);
   // ---- A^T = V^T P^T (8 k-steps over the keys, two feature halves each)
@@ -835,15 +842,17 @@ PZN_EXPORT int pzn_attn_fused_proj(int nprob, const float* const* x, const void*
 }
 
 // one block forward: r = x + relu(Wo (x - softmax(q k^T / 8) v) + bo); also t = x - attn v, the gate bits, ln-sum-exp per
-// row and (map[i] != NULL) the running mean map: map = scale P (accumulate = 0) or map += scale P
+// row and (map[i] != NULL) the running mean map: map = scale P (map_mode 0) or map += scale P (1); map_mode 2 / 3: the same
+// for the column sums of P over each strip of 16 query rows, map[i] = [B][L / 16][L] (what a mean over the rows needs)
 PZN_EXPORT int pzn_attn_fused_fwd(int nprob, const float* const* x, const void* const* qrp, const void* const* krp,
                                   const void* const* vrp, const void* const* w, const float* const* bo, int B,
                                   float* const* r, float* const* t, void* const* mask, float* const* map, float* const* lse,
-                                  int map_accumulate, float map_scale, pzn_stream_t stream) {
-  PZN_CHECK_ARG(nprob >= 1 && nprob <= 2 && B > 0 && x && qrp && krp && vrp && w && bo && r && t && mask && map && lse);
+                                  int map_mode, float map_scale, pzn_stream_t stream) {
+  PZN_CHECK_ARG(nprob >= 1 && nprob <= 2 && B > 0 && x && qrp && krp && vrp && w && bo && r && t && mask && map && lse &&
+                map_mode >= 0 && map_mode <= 3);
   FwdArgs a;
   a.nb = 2 * B;
-  a.map_accumulate = map_accumulate;
+  a.map_mode = map_mode;
   a.map_scale = map_scale;
   for (int i = 0; i < nprob; ++i) {
     PZN_CHECK_ARG(x[i] && qrp[i] && krp[i] && vrp[i] && w[i] && bo[i] && r[i] && t[i] && mask[i] && lse[i]);

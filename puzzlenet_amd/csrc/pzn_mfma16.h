@@ -218,6 +218,28 @@ __device__ __forceinline__ void store_rows16(float* base, long row0, int ld, con
     pzn::wave_lds_sync();
   }
 }
+// Column sums of the wavefront's 16 rows over FT = 16 tiles (256 features): dst[f] = (MODE ? dst[f] : 0) + scale * sum over the 16
+// rows of x[row][f].  Through the staging buffer like store_rows16 (a pass = 8 tiles = 128 features; lane l sums features
+// 2 l, 2 l + 1 of the pass down the 16 staged rows, in row order: the same sum every run).
+template <int MODE>
+__device__ __forceinline__ void store_colsum16(float* dst, const floatx4* x, float* stg, int lane, float scale) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    float2* d = reinterpret_cast<float2*>(dst + 128 * p + 2 * lane);
+    float2 old = make_float2(0.f, 0.f);
+    if (MODE == 1) old = *d;
+    stage_put16<8>(stg, x, 8 * p, lane);
+    pzn::wave_lds_sync();
+    float sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float2 v = *reinterpret_cast<const float2*>(stg + c * STG16_LD + 2 * lane);
+      sx += v.x, sy += v.y;
+    }
+    *d = make_float2(old.x + scale * sx, old.y + scale * sy);
+    pzn::wave_lds_sync();
+  }
+}
 // The loads of every pass are issued first (one memory round trip); until its pass is staged a loaded 16-byte unit waits
 // in the destination tile of the same index (x has exactly FT of them) - `tmp` for the adding form, which needs x itself.
 __device__ __forceinline__ float4 as_f4(const floatx4& v) { return make_float4(v[0], v[1], v[2], v[3]); }

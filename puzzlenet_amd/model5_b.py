@@ -129,6 +129,7 @@ class PCTransformer_nonsort(nn.Module):
         self.out = nn.Linear(gs2_feature_size * 2 * 5, 1024)
 
     fused_sa = True     # False: literally sample_and_group -> [B,S,K,3+D] -> shared MLP, as the reference composes it
+    attn_strips = False  # True: slot 2 (attention) is [B,16,256] strip column sums with the same mean over dim 1 (ops.attention_chain_fused)
     need_out = True     # False: slot 3 of the 5-tuple (the [B,256,1024] projection) is None; predict5 sets it around its calls
     grad_marker = None       # engine.TrainStep (N > 1): marker(tensor) registers "the backward has come this far" on it
 
@@ -152,6 +153,8 @@ class PCTransformer_nonsort(nn.Module):
 
     def local_features(self, xyz):
         """:447-448, the per-point MLP in front of the set abstraction (does not need the sampling plan)."""
+        if _STEM_FUSED and ops.stem_supported(xyz, self.mlp1, self.bn1, self.mlp2, self.bn2):
+            return ops.stem(xyz, self.mlp1, self.bn1, self.mlp2, self.bn2)      # both lines in one launch each way (csrc/stem.hip)
         # BatchNorm + ReLU as one launch each way (csrc/bnpoints.hip); ops.* raise on CPU tensors: there is no eager path
         x_feature = ops.bn_points_relu(ops.linear(xyz, self.mlp1.weight, self.mlp1.bias), self.bn1)   # :447
         return ops.bn_points_relu(ops.linear(x_feature, self.mlp2.weight, self.mlp2.bias), self.bn2)  # :448
@@ -189,7 +192,7 @@ class PCTransformer_nonsort(nn.Module):
             # :462-475 through the chained matrix-core kernels (csrc/attnfused.hip), one encoder per launch here
             # need_out = False (set by predict5, which uses only the maximum: :723): `out` is None, never written
             (out, attention, f_global), = ops.attention_chain_fused([f2f], [self._block_params()], [self.out.weight], [self.out.bias],
-                                                                   need_out=self.need_out)
+                                                                   need_out=self.need_out, map_strips=self.attn_strips)
             return f_global, x2, attention, out, x_feature
         if _ATTN_CHAIN and f2f.is_cuda and ops.attention_chain_supported(f2f, self.atten1.mlpq.weight.shape[0], self.out.weight):
             # :462-474 as one autograd node: no concatenation, no gradient-accumulation adds between the blocks
@@ -213,6 +216,7 @@ class PCTransformer_nonsort(nn.Module):
         return f_global, x2, attention, out, x_feature
 
 
+_ATTN_STRIPS = os.environ.get("PZN_ATTN_STRIPS", "1") != "0"     # tuning aid: 0 = training_step gets the full [B,256,256] mean maps too
 _ATTN_CHAIN = os.environ.get("PZN_ATTN_CHAIN", "1") != "0"     # tuning aid: 0 = four autograd nodes + cat + linear
 _ATTN_FUSED = os.environ.get("PZN_ATTN_FUSED", "1") != "0"     # tuning aid: 0 = the composed block kernels (gemm.hip)
 # 1 = both encoders' chains in the same launches on one stream.  Measured slower than one chain per encoder and stream
@@ -220,6 +224,11 @@ _ATTN_FUSED = os.environ.get("PZN_ATTN_FUSED", "1") != "0"     # tuning aid: 0 =
 # already fill the chip, and the joint launches take the stems' overlap away.
 _ATTN_DUAL = os.environ.get("PZN_ATTN_DUAL", "0") != "0"
 _EMD_OWN_STREAM = int(os.environ.get("PZN_EMD_OWN_STREAM", "0"))   # tuning aid: 1 = the N x N EMD on a third stream, 2 = a high-priority one
+# 1 = the per-point stem (:447-448) as one launch each way (csrc/stem.hip, ops.stem) instead of 2 linear + 2 BatchNorm launches
+# each way.  Off by default: 24 launches per step become 6 and 7 passes over the 33.5 MB activations become 2, but the kernels
+# are fp32 FMAs fed by LDS broadcasts (24 + 55 us per encoder against ~60 us of matrix-core GEMMs + BatchNorm passes) and they
+# take all 256 CUs while FPS runs beside them: 7.42 ms/step against 7.31 on the same box.
+_STEM_FUSED = os.environ.get("PZN_STEM_FUSED", "0") != "0"
 _EMD_SIDE = int(os.environ.get("PZN_EMD_SIDE", "2"))     # tuning aid: 0 = the N x N EMD on the main stream, 1 = forked right after the pose head, 2 = after the heads (measured best)
 
 
@@ -310,9 +319,12 @@ class TouchedRegraster(_Base):
         self.defer_emd_loss = False    # see training_step: the EMD term as a separate backward root (engine.TrainStep)
 
     # ------------------------------------------------------------------ forward
-    def predict5(self, batch, batch_indic, need=False, training=False, pose_hook=None):
+    def predict5(self, batch, batch_indic, need=False, training=False, pose_hook=None, attn_strips=False):
         """model5_b.py:672-759.  pose_hook(out): called as soon as the pose head has produced `out`, before the boundary
-        heads are enqueued (training_step starts the N x N EMD on the side stream from it)."""
+        heads are enqueued (training_step starts the N x N EMD on the side stream from it).  attn_strips (training_step
+        only, which takes nothing but the row mean of the two attention maps): on the fused attention path the maps come back
+        as [B,16,256] strip column sums with that same row mean (ops.attention_chain_fused); every other path and every other
+        caller gets the reference's [B,256,256] maps."""
         for m in (self.Encoder, self.Encoder2, self.tfMLP, self.fpc_decoder, self.rpc_decoder):
             m.train(training)                                                       # :677-690
         fpc, mrpc = batch[0], batch[1]
@@ -324,9 +336,11 @@ class TouchedRegraster(_Base):
         # the encoders' [B,256,1024] projection itself (5-tuple slot 3) is not used by predict5, only its max over the
         # points (:723): not materialised here (the encoder called on its own still returns it)
         self.Encoder.need_out = self.Encoder2.need_out = False
+        self.Encoder.attn_strips = self.Encoder2.attn_strips = bool(attn_strips)
         try:
             return self._predict5_encoders(fpc, mrpc, N, need, pose_hook)
         finally:
+            self.Encoder.attn_strips = self.Encoder2.attn_strips = False
             self.Encoder.need_out = self.Encoder2.need_out = True
 
     def _predict5_encoders(self, fpc, mrpc, N, need, pose_hook):
@@ -372,7 +386,7 @@ class TouchedRegraster(_Base):
                 rf, rm = ops.attention_chain_fused(
                     [f2f_f, f2f_m], [self.Encoder._block_params(), self.Encoder2._block_params()],
                     [self.Encoder.out.weight, self.Encoder2.out.weight], [self.Encoder.out.bias, self.Encoder2.out.bias],
-                    need_out=False)
+                    need_out=False, map_strips=self.Encoder.attn_strips)
                 ffpcs = (rf[2], x2_f, rf[1], rf[0], xf_f2)
                 fmrpcs = (rm[2], x2_m, rm[1], rm[0], xf_m2)
                 return self._heads(ffpcs, fmrpcs, N, need, pose_hook)
@@ -594,7 +608,7 @@ class TouchedRegraster(_Base):
                 fork_emd(o)
 
         out, t, x2, attention, mrpc_x2, mrpc_attention, de_fpcb, de_mrpcb = self.predict5(
-            batch, batch_size, training=True, need=True, pose_hook=pose_hook)      # :933
+            batch, batch_size, training=True, need=True, pose_hook=pose_hook, attn_strips=_ATTN_STRIPS)      # :933
         if _EMD_SIDE == 2:
             fork_emd(out)
 

@@ -1155,11 +1155,14 @@ class _AttnChainFused(torch.autograd.Function):
     per layer forward, two launches + the weight gradients per layer backward), the running mean of the four maps
     written by the block kernel, then — per encoder — the out projection over the five slices and the max over the
     points exactly as _AttnChainOut does them.
-    inputs: nprob, need_out (False: `out` is not materialised, an empty placeholder stands in the tuple), then per problem x[B,L,E], 4 x (wq,bq,wk,bk,wv,bv,wo,bo), w_out, b_out
+    inputs: nprob, flags (bit 0 clear: `out` is not materialised, an empty placeholder stands in the tuple; bit 1: the map as
+    column sums per strip of 16 rows, [B,L/16,L], whose mean over dim 1 IS the mean attention's mean over its rows), then per
+    problem x[B,L,E], 4 x (wq,bq,wk,bk,wv,bv,wo,bo), w_out, b_out
     -> per problem (out[B,L,Nout], attention[B,L,L], f_global[B,Nout])"""
 
     @staticmethod
-    def forward(ctx, nprob, need_out, *args):
+    def forward(ctx, nprob, flags, *args):
+        need_out, strips = bool(flags & 1), bool(flags & 2)
         per = 35
         xs = [_f32(args[per * i], "x") for i in range(nprob)]
         pss = [[_f32(t, "param") for t in args[per * i + 1: per * i + 35]] for i in range(nprob)]
@@ -1179,7 +1182,7 @@ class _AttnChainFused(torch.autograd.Function):
             for p in R:      # the four layers' weight planes in one launch per encoder
                 _call("pzn_attn_fused_prep_weights_n", 4, *[_ptrs([pss[p][8 * i + j] for i in range(4)]) for j in (0, 2, 4, 6)],
                       _ptrs(W[p]), st)
-            maps = [mk(B, L, L) for _ in R]
+            maps = [mk(B, L // 16, L) if strips else mk(B, L, L) for _ in R]
             cur = [x.reshape(M, E) for x in xs]
             saved = [[] for _ in R]
             for i in range(4):
@@ -1194,7 +1197,8 @@ class _AttnChainFused(torch.autograd.Function):
                 lse = [mk(M) for _ in R]
                 _call("pzn_attn_fused_fwd", nprob, _ptrs(cur), _ptrs([img[p][0] for p in R]), _ptrs([img[p][1] for p in R]),
                       _ptrs([img[p][2] for p in R]), _ptrs([W[p][i] for p in R]), _ptrs([pss[p][8 * i + 7] for p in R]), B,
-                      _ptrs(r), _ptrs(t), _ptrs(mask), _ptrs(maps), _ptrs(lse), int(i > 0), 0.25, st,
+                      _ptrs(r), _ptrs(t), _ptrs(mask), _ptrs(maps), _ptrs(lse), int(i > 0) | (2 if strips else 0),
+                      0.25 / 16 if strips else 0.25, st,
                       flops=nprob * (2 * M * E * E + 2 * B * L * L * (dk + E)))
                 for p in R:
                     saved[p].append((cur[p], t[p], mask[p], lse[p], img[p][0], img[p][1], img[p][2], W[p][i]))
@@ -1339,14 +1343,17 @@ class _AttnChainFused(torch.autograd.Function):
         return tuple(grads)
 
 
-def attention_chain_fused(xs, blocks_list, w_outs, b_outs, need_out=True):
+def attention_chain_fused(xs, blocks_list, w_outs, b_outs, need_out=True, map_strips=False):
     """xs: list of nprob inputs [B,L,E]; blocks_list[p]: four 8-tuples; -> list of (out, mean map, f_global) per problem.
     need_out=False: only f_global = max over the points of the out projection is wanted (predict5, model5_b.py:723);
-    `out` is then None and its 67 MB per encoder at B = 64 are never written."""
+    `out` is then None and its 67 MB per encoder at B = 64 are never written.
+    map_strips=True: the caller only takes the mean of the mean map over its rows (training_step, model5_b.py:937-942): the
+    second result is [B,L/16,L], each row the scaled column sums of a strip of 16 query rows, with
+    result.mean(dim=1) == mean_map.mean(dim=1); the [B,L,L] map (16.7 MB read + written per block and encoder) never exists."""
     flat = []
     for x, blocks, w, b in zip(xs, blocks_list, w_outs, b_outs):
         flat += [x] + [p_ for blk in blocks for p_ in blk] + [w, b]
-    res = _AttnChainFused.apply(len(xs), bool(need_out), *flat)
+    res = _AttnChainFused.apply(len(xs), int(bool(need_out)) | (2 if map_strips else 0), *flat)
     return [(res[3 * i] if res[3 * i].numel() else None, res[3 * i + 1], res[3 * i + 2]) for i in range(len(xs))]
 
 
@@ -1484,6 +1491,76 @@ def bn_points_relu(x, bn):
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return _BnPointsRelu.apply(x, bn.weight, bn.bias, rm, rv, use_batch, bn.momentum, bn.eps)
+
+
+class _StemFused(torch.autograd.Function):
+    """model5_b.py:447-448 in one launch each way (csrc/stem.hip): relu(bn2(mlp2(relu(bn1(mlp1(xyz)))))) with both
+    BatchNorm1d(num_points) over the point axis; the backward recomputes every activation from xyz and the saved statistics."""
+
+    @staticmethod
+    def forward(ctx, xyz, w1, b1, g1, o1, w2, b2, g2, o2, rm1, rv1, rm2, rv2, use_batch, mom1, eps1, mom2, eps2):
+        xyz = _f32(xyz, "xyz")
+        w1, b1, w2, b2 = _f32(w1, "w1"), _f32(b1, "b1"), _f32(w2, "w2"), _f32(b2, "b2")
+        B, N, _ = xyz.shape
+        dev = xyz.device
+        out = torch.empty((B, N, 64), dtype=torch.float32, device=dev)
+        stats = torch.empty((4, N), dtype=torch.float32, device=dev)
+        with _on(dev):
+            _call("pzn_stem_fwd_f32", _p(xyz), _p(w1), _p(b1), _p(g1), _p(o1), _p(rm1), _p(rv1), float(mom1), float(eps1),
+                  _p(w2), _p(b2), _p(g2), _p(o2), _p(rm2), _p(rv2), float(mom2), float(eps2), int(bool(use_batch)), B, N,
+                  _p(out), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), _stream(),
+                  flops=2 * B * N * 64 * (3 + 64))
+        ctx.save_for_backward(xyz, w1, b1, g1, o1, w2, b2, g2, o2, stats)
+        ctx.param_refs = (w1, b1, g1, o1, w2, b2, g2, o2)
+        ctx.use_batch = bool(use_batch)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xyz, w1, b1, g1, o1, w2, b2, g2, o2, stats = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise _lib.PznError("stem: gradients w.r.t. point coordinates are not provided on the fused stem; "
+                                "use ops.linear + ops.bn_points_relu")
+        B, N, _ = xyz.shape
+        dout = _f32(dout, "dout")
+        dev = dout.device
+        params = (w1, b1, g1, o1, w2, b2, g2, o2)
+        sinks = [None if t is None else _sink(t, ctx.needs_input_grad[1 + i]) for i, t in enumerate(params)]
+        direct = all(s_ is not None or t is None for s_, t in zip(sinks, params))
+        if direct:
+            grads = sinks
+        else:
+            grads = [None if t is None else torch.zeros_like(t) for t in params]      # the kernel adds into these
+        dw1, db1, dg1, do1, dw2, db2, dg2, do2 = grads
+        ws = torch.empty((_lib.load().pzn_stem_bwd_workspace_bytes(N) + 3) // 4, dtype=torch.float32, device=dev)
+        with _on(dev):
+            _call("pzn_stem_bwd_f32", _p(xyz), _p(dout), _p(w1), _p(b1), _p(w2), _p(b2), _p(g1), _p(o1), _p(g2), _p(o2),
+                  _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), int(ctx.use_batch), B, N, _p(dw1), _p(db1),
+                  _p(dw2), _p(db2), _p(dg1), _p(do1), _p(dg2), _p(do2), _p(ws), _stream(), flops=2 * B * N * 64 * (3 + 3 * 64))
+        if direct:
+            return (None,) * 18
+        return (None, dw1, db1, dg1, do1, dw2, db2, dg2, do2) + (None,) * 9
+
+
+def stem_supported(xyz, lin1, bn1, lin2, bn2):
+    return (xyz.is_cuda and xyz.dim() == 3 and xyz.shape[2] == 3 and xyz.shape[0] <= 64 and not xyz.requires_grad and
+            tuple(lin1.weight.shape) == (64, 3) and tuple(lin2.weight.shape) == (64, 64) and lin1.bias is not None and
+            lin2.bias is not None and bn1.num_features == xyz.shape[1] == bn2.num_features and bn1.momentum is not None and
+            bn2.momentum is not None and bn1.training == bn2.training and bn1.track_running_stats == bn2.track_running_stats)
+
+
+def stem(xyz, lin1, bn1, lin2, bn2):
+    """relu(bn2(lin2(relu(bn1(lin1(xyz)))))) for the encoder's shapes (stem_supported); the modules' running buffers are kept
+    exactly as the modules keep them."""
+    use_batch = bn1.training or not bn1.track_running_stats
+    track = bn1.track_running_stats
+    for bn in (bn1, bn2):
+        if bn.training and track and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+    return _StemFused.apply(xyz, lin1.weight, lin1.bias, bn1.weight, bn1.bias, lin2.weight, lin2.bias, bn2.weight, bn2.bias,
+                            bn1.running_mean if track else None, bn1.running_var if track else None,
+                            bn2.running_mean if track else None, bn2.running_var if track else None,
+                            use_batch, bn1.momentum, bn1.eps, bn2.momentum, bn2.eps)
 
 
 class _SaMlpMaxPoint(torch.autograd.Function):

@@ -668,6 +668,42 @@ def test_attention_fused_block_bf16_mode(dev, attn_bf16):
         assert _l2(a_, b_) < 5e-3, (name, _l2(a_, b_))
 
 
+@pytest.mark.parametrize("nprob", [1, 2])
+def test_attention_chain_fused_map_strips(dev, nprob):
+    """map_strips=True (what training_step asks for: model5_b.py:937-942 takes only the row mean of the mean map): the second
+    result is [B,16,256] whose mean over dim 1 equals the full [B,256,256] map's (1e-6 of its largest entry: the same 1024
+    terms in another order), colmean_argmax picks the same column, the other results are bit-identical and the gradients the
+    same (the map carries none)."""
+    from puzzlenet_amd import ops
+    B, L, E, dk, Nout = 5, 256, 256, 64, 1024
+    g = torch.Generator().manual_seed(23)
+    shapes = [(dk, E), (dk,), (dk, E), (dk,), (E, E), (E,), (E, E), (E,)]
+    xs = [(0.5 * torch.randn(B, L, E, generator=g)).to(dev).requires_grad_(True) for _ in range(nprob)]
+    blocks = [[tuple((torch.randn(*s, generator=g) / (math.sqrt(E) if len(s) == 2 else 4)).to(dev).requires_grad_(True)
+                     for s in shapes) for _ in range(4)] for _ in range(nprob)]
+    ws = [(torch.randn(Nout, 5 * E, generator=g) / math.sqrt(5 * E)).to(dev).requires_grad_(True) for _ in range(nprob)]
+    bs = [(0.1 * torch.randn(Nout, generator=g)).to(dev).requires_grad_(True) for _ in range(nprob)]
+    go = [torch.randn(B, Nout, generator=g).to(dev) for _ in range(nprob)]
+    leaves = xs + [p for bl in blocks for blk in bl for p in blk] + ws + bs
+    runs = []
+    for strips in (False, True):
+        for t in leaves:
+            t.grad = None
+        res = ops.attention_chain_fused(xs, blocks, ws, bs, need_out=False, map_strips=strips)
+        sum((r[2] * go_).sum() for r, go_ in zip(res, go)).backward()
+        runs.append((res, [t.grad.clone() for t in leaves]))
+    (full, gfull), (strip, gstrip) = runs
+    for p in range(nprob):
+        assert full[p][1].shape == (B, L, L) and strip[p][1].shape == (B, L // 16, L)
+        want, got = full[p][1].mean(dim=1), strip[p][1].mean(dim=1)
+        assert float((want - got).abs().max()) <= 1e-6 * float(want.abs().max())
+        assert torch.equal(ops.colmean_argmax(full[p][1])[1], ops.colmean_argmax(strip[p][1])[1])
+        assert torch.equal(full[p][2], strip[p][2]) and full[p][0] is None and strip[p][0] is None
+    for a, b in zip(gfull, gstrip):      # (the weight gradients end in atomic adds: equal to the order of a sum)
+        assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-9
+
+
+
 @pytest.mark.parametrize("nprob,use", [(1, "max"), (2, "max"), (2, "out")])
 def test_attention_chain_fused_vs_float64(dev, nprob, use):
     """ops.attention_chain_fused (model5_b.py:462-475 for one or two encoders in the same launches) against a float64

