@@ -543,13 +543,15 @@ int pzn_point_mlp3_fwd_f32(const float* x, long long M, int rows_per_cloud, cons
                            float* y, pzn_stream_t stream);
 /* Backward of the chain in one pass + a fixed-order sum of its partial results (timing-independent output):
  * dx[M, 64], dW1[64, ldw1] (columns 0..63 written), dW2[C2, 64], dW3[C3, C2], db2[C2], db3[C3] and db1 — [64], or with
- * b1_per_cloud != 0 one row of 64 per cloud (the gradient of the per-cloud bias) —, all OVERWRITTEN; x, h1, h2 as the
- * forward left them; workspace of pzn_point_mlp3_bwd_workspace_bytes() bytes (0 = unsupported shape). */
+ * b1_per_cloud != 0 one row of 64 per cloud (the gradient of the per-cloud bias) —: OVERWRITTEN (accumulate == 0) or, the
+ * parameter gradients, ADDED to (accumulate != 0: one owner per element, no atomics - e.g. straight into a flat gradient
+ * bucket; dx and a per-cloud db1 are overwritten either way); x, h1, h2 as the forward left them; workspace of
+ * pzn_point_mlp3_bwd_workspace_bytes() bytes (0 = unsupported shape). */
 size_t pzn_point_mlp3_bwd_workspace_bytes(long long M, int rows_per_cloud, int b1_per_cloud, int C2, int C3);
 int pzn_point_mlp3_bwd_f32(const float* dy, const float* x, const float* h1, const float* h2, long long M,
                            int rows_per_cloud, const float* W1, int ldw1, int b1_per_cloud, const float* W2,
                            const float* W3, int C2, int C3, float* dx, float* dW1, float* db1, float* dW2,
-                           float* db2, float* dW3, float* db3, void* workspace, pzn_stream_t stream);
+                           float* db2, float* dW3, float* db3, int accumulate, void* workspace, pzn_stream_t stream);
 
 /* The encoder's out projection and the max over the points in ONE launch (model5_b.py:466-475):
  *   out[b,l,:] = cat(x[0] .. x[nslice-1])[b,l,:] W^T + bias   (W[Nout, nslice*E]; the concatenation is never built),
@@ -610,12 +612,14 @@ int pzn_comp_bwd_f32(const float* g, const float* igt, const float* dloss, int B
  * softmax(logits, dim=1)[:, 1, :]): labels[B,N] hold 0 / 1 as floats (dataset.py:1363-1366).  fwd: prob1[B,N] (class-1
  * probability, what the top-128 selection ranks by), loss[0] (overwritten); loss points at PZN_BOUNDARY_CE_LOSS_FLOATS floats:
  * the value and the per-workgroup partial sums it is reduced from in a fixed order (bit-reproducible).
- * bwd: dlogits[B,2,N] = dloss[0] * d loss / d logits. */
+ * bwd: dlogits[B,2,N] = dloss[0] * d loss / d logits.
+ * points_major != 0: logits (and dlogits) are the heads' [B,N,2] output as it lies in memory - the [B,2,N] tensor the reference
+ * builds with permute(0,2,1) (model5_b.py:751-754) read through its strides, no transposed copy either way. */
 #define PZN_BOUNDARY_CE_LOSS_FLOATS 513
-int pzn_boundary_ce_fwd_f32(const float* logits, const float* labels, int B, int N, float* prob1, float* loss,
-                            pzn_stream_t stream);
+int pzn_boundary_ce_fwd_f32(const float* logits, const float* labels, int B, int N, int points_major, float* prob1,
+                            float* loss, pzn_stream_t stream);
 int pzn_boundary_ce_bwd_f32(const float* logits, const float* labels, const float* dloss, int B, int N,
-                            float* dlogits, pzn_stream_t stream);
+                            int points_major, float* dlogits, pzn_stream_t stream);
 /* torch.topk(x[R,N], K, dim=1)[1] (model5_b.py:1089-1091): indices of the K largest entries of every row, value
  * descending, equal values by ascending index.  K <= 256, N <= 16384 (PZN_EUNSUPPORTED beyond). */
 int pzn_topk_rows_f32(const float* x, int R, int N, int K, int64_t* idx, pzn_stream_t stream);

@@ -90,8 +90,8 @@ SIGNATURES = {
     "pzn_se3_transform_bwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_comp_fwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_f, _c_f]),
     "pzn_comp_bwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_f, _c_f]),
-    "pzn_boundary_ce_fwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_f, _c_f, _c_f]),
-    "pzn_boundary_ce_bwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_f, _c_f]),
+    "pzn_boundary_ce_fwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_boundary_ce_bwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_topk_rows_f32": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_avg4_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, ctypes.c_size_t, _c_f, _c_f]),
     "pzn_colmean_workspace_bytes": (_c_sz, [_c_i, _c_i]),
@@ -113,7 +113,7 @@ SIGNATURES = {
     "pzn_cloud_bias_relu_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f]),
     "pzn_point_mlp3_supported": (_c_i, [_c_i] * 4),
     "pzn_point_mlp3_bwd_workspace_bytes": (_c_sz, [_c_ll, _c_i, _c_i, _c_i, _c_i]),
-    "pzn_point_mlp3_bwd_f32": (_c_i, [_c_f] * 4 + [_c_ll, _c_i, _c_f, _c_i, _c_i, _c_f, _c_f, _c_i, _c_i] + [_c_f] * 9),
+    "pzn_point_mlp3_bwd_f32": (_c_i, [_c_f] * 4 + [_c_ll, _c_i, _c_f, _c_i, _c_i, _c_f, _c_f, _c_i, _c_i] + [_c_f] * 7 + [_c_i, _c_f, _c_f]),
     "pzn_point_mlp3_fwd_f32": (_c_i, [_c_f, _c_ll, _c_i, _c_f, _c_i, _c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f]),
     "pzn_cloud_gated_colsum_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_outproj_maxpts_fwd_f32": (_c_i, [_PP, _c_i, _c_f, _c_f] + [_c_i] * 4 + [_c_f] * 5),

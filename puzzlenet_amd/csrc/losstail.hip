@@ -131,17 +131,20 @@ __global__ __launch_bounds__(256) void comp_bwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------ boundary cross-entropy
-// logits [B,2,N], labels [B,N] (0 / 1 as floats, dataset.py:1363-1366).  prob1[b,n] = softmax over the two classes,
+// logits [B,2,N] as a view: logit of class c at point n of cloud b = logits[b 2N + c sc + n sn] ((sc, sn) = (N, 1): the tensor as
+// the reference holds it; (1, 2): the heads' [B,N,2] output seen through permute(0,2,1), model5_b.py:751-754, with no copy),
+// labels [B,N] (0 / 1 as floats, dataset.py:1363-1366).  prob1[b,n] = softmax over the two classes,
 // class 1 (model5_b.py:1085-1090); loss += sum over the block of (logsumexp - logit[label]) / (B N).
 __global__ __launch_bounds__(256) void boundary_ce_fwd_kernel(const float* __restrict__ logits,
-                                                              const float* __restrict__ labels, int N, long total,
+                                                              const float* __restrict__ labels, int N, long total, int sc, int sn,
                                                               float* __restrict__ prob1, float* __restrict__ loss) {
   __shared__ float sh[16];
   float s = 0.f;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const long b = e / N;
     const int n = (int)(e - b * N);
-    const float l0 = logits[(b * 2) * N + n], l1 = logits[(b * 2 + 1) * N + n];
+    const float* lp = logits + b * 2 * N + (long)n * sn;
+    const float l0 = lp[0], l1 = lp[sc];
     const float m = fmaxf(l0, l1);
     const float e0 = expf(l0 - m), e1 = expf(l1 - m), sum = e0 + e1;
     prob1[e] = e1 / sum;
@@ -162,18 +165,19 @@ __global__ __launch_bounds__(64) void boundary_ce_reduce_kernel(float* __restric
 
 __global__ __launch_bounds__(256) void boundary_ce_bwd_kernel(const float* __restrict__ logits,
                                                               const float* __restrict__ labels,
-                                                              const float* __restrict__ dloss, int N, long total,
-                                                              float* __restrict__ dlogits) {
-  const float sc = dloss[0] / (float)total;
+                                                              const float* __restrict__ dloss, int N, long total, int sc,
+                                                              int sn, float* __restrict__ dlogits) {
+  const float scale = dloss[0] / (float)total;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const long b = e / N;
     const int n = (int)(e - b * N);
-    const float l0 = logits[(b * 2) * N + n], l1 = logits[(b * 2 + 1) * N + n];
+    const long o = b * 2 * N + (long)n * sn;
+    const float l0 = logits[o], l1 = logits[o + sc];
     const float m = fmaxf(l0, l1);
     const float e0 = expf(l0 - m), e1 = expf(l1 - m), sum = e0 + e1;
     const bool one = labels[e] != 0.f;
-    dlogits[(b * 2) * N + n] = sc * (e0 / sum - (one ? 0.f : 1.f));
-    dlogits[(b * 2 + 1) * N + n] = sc * (e1 / sum - (one ? 1.f : 0.f));
+    dlogits[o] = scale * (e0 / sum - (one ? 0.f : 1.f));      // (same strides as logits)
+    dlogits[o + sc] = scale * (e1 / sum - (one ? 1.f : 0.f));
   }
 }
 
@@ -407,24 +411,26 @@ PZN_EXPORT int pzn_comp_bwd_f32(const float* g, const float* igt, const float* d
   PZN_RETURN_LAUNCH_STATUS();
 }
 
-PZN_EXPORT int pzn_boundary_ce_fwd_f32(const float* logits, const float* labels, int B, int N, float* prob1, float* loss,
-                                       pzn_stream_t stream) {
+PZN_EXPORT int pzn_boundary_ce_fwd_f32(const float* logits, const float* labels, int B, int N, int points_major, float* prob1,
+                                       float* loss, pzn_stream_t stream) {
   PZN_CHECK_ARG(logits && labels && prob1 && loss && B > 0 && N > 0);
+  const int sc = points_major ? 1 : N, sn = points_major ? 2 : 1;
   hipStream_t st = pzn_hip_stream(stream);
   const long total = (long)B * N;
   const int nparts = (int)grid_for(total, 256, 512);
-  hipLaunchKernelGGL(boundary_ce_fwd_kernel, dim3((unsigned)nparts), dim3(256), 0, st, logits, labels, N, total, prob1, loss);
+  hipLaunchKernelGGL(boundary_ce_fwd_kernel, dim3((unsigned)nparts), dim3(256), 0, st, logits, labels, N, total, sc, sn, prob1, loss);
   if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
   hipLaunchKernelGGL(boundary_ce_reduce_kernel, dim3(1), dim3(64), 0, st, loss, nparts, 1.f / (float)total);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
 PZN_EXPORT int pzn_boundary_ce_bwd_f32(const float* logits, const float* labels, const float* dloss, int B, int N,
-                                       float* dlogits, pzn_stream_t stream) {
+                                       int points_major, float* dlogits, pzn_stream_t stream) {
   PZN_CHECK_ARG(logits && labels && dloss && dlogits && B > 0 && N > 0);
+  const int sc = points_major ? 1 : N, sn = points_major ? 2 : 1;
   const long total = (long)B * N;
   hipLaunchKernelGGL(boundary_ce_bwd_kernel, dim3((unsigned)grid_for(total, 256, 512)), dim3(256), 0, pzn_hip_stream(stream),
-                     logits, labels, dloss, N, total, dlogits);
+                     logits, labels, dloss, N, total, sc, sn, dlogits);
   PZN_RETURN_LAUNCH_STATUS();
 }
 

@@ -555,6 +555,7 @@ struct PmRedArgs {
   const float *part_w, *part_b;
   float *dW1, *dW2, *dW3, *db1, *db2, *db3;
   int ldw1, nwg, nwaves, waves_per_cloud, nclouds;
+  int accumulate;      // != 0: the parameter gradients are ADDED to what is there (a per-cloud db1 is always overwritten)
 };
 // A workgroup = 64 consecutive outputs x 16 slices of the partial index; a thread adds its slice with four independent
 // chains (the loads of a chain do not wait for each other), the slices meet in LDS in a fixed order.
@@ -602,19 +603,22 @@ __global__ __launch_bounds__(1024) void point_mlp3_reduce_kernel(PmRedArgs a) {
   if (kind == 0) {
     const int t = idx >> 10, e = (idx >> 6) & 15, l = idx & 63;
     const int row = (e & 3) + 8 * (e >> 2) + 4 * (l >> 5), col = l & 31;
+    float* dst = nullptr;
     if (t < 4) {
-      a.dW1[(long)(32 * (t >> 1) + row) * a.ldw1 + 32 * (t & 1) + col] = s;
+      dst = a.dW1 + (long)(32 * (t >> 1) + row) * a.ldw1 + 32 * (t & 1) + col;
     } else if (t < 4 + 2 * T2) {
       const int m = t - 4;
-      a.dW2[(32 * (m >> 1) + row) * 64 + 32 * (m & 1) + col] = s;
+      dst = a.dW2 + (32 * (m >> 1) + row) * 64 + 32 * (m & 1) + col;
     } else {
       const int m = t - 4 - 2 * T2, oo = 32 * (m / T2) + row;
-      if (oo < C3) a.dW3[oo * C2 + 32 * (m % T2) + col] = s;
+      if (oo < C3) dst = a.dW3 + oo * C2 + 32 * (m % T2) + col;
     }
+    if (dst) *dst = a.accumulate ? *dst + s : s;
   } else if (kind == 1) {
-    a.db1[idx] = s;
+    a.db1[idx] = (a.accumulate && !a.waves_per_cloud) ? a.db1[idx] + s : s;
   } else {
-    (kind == 2 ? a.db2 : a.db3)[idx] = s;
+    float* dst = (kind == 2 ? a.db2 : a.db3) + idx;
+    *dst = a.accumulate ? *dst + s : s;
   }
 }
 
@@ -711,12 +715,14 @@ PZN_EXPORT size_t pzn_point_mlp3_bwd_workspace_bytes(long long M, int rows_per_c
 }
 
 // Backward of pzn_point_mlp3_fwd_f32: dx[M, 64], dW1[64, ldw1] (columns 0..63 written), dW2[C2, 64], dW3[C3, C2], db2[C2],
-// db3[C3] and db1 — [64], or with b1_per_cloud one row per cloud: the gradient of the per-cloud bias —, all OVERWRITTEN;
-// x, h1, h2 as the forward left them.  Two launches (the pass and the fixed-order sum of its partial results).
+// db3[C3] and db1 — [64], or with b1_per_cloud one row per cloud: the gradient of the per-cloud bias —: OVERWRITTEN, or with
+// accumulate != 0 ADDED to (one owner per element, no atomics: e.g. straight into a flat gradient bucket; dx and a per-cloud
+// db1 are always overwritten).  x, h1, h2 as the forward left them.  Two launches (the pass and the fixed-order sum of its
+// partial results).
 PZN_EXPORT int pzn_point_mlp3_bwd_f32(const float* dy, const float* x, const float* h1, const float* h2, long long M,
                                       int rows_per_cloud, const float* W1, int ldw1, int b1_per_cloud, const float* W2,
                                       const float* W3, int C2, int C3, float* dx, float* dW1, float* db1, float* dW2,
-                                      float* db2, float* dW3, float* db3, void* workspace, pzn_stream_t stream) {
+                                      float* db2, float* dW3, float* db3, int accumulate, void* workspace, pzn_stream_t stream) {
   PZN_CHECK_ARG(dy && x && h1 && h2 && W1 && W2 && W3 && dx && dW1 && db1 && dW2 && db2 && dW3 && db3 && workspace && ldw1 >= 64);
   PmGeom g;
   if (!pzn_point_mlp3_supported(64, 64, C2, C3)) return PZN_EUNSUPPORTED;
@@ -728,7 +734,7 @@ PZN_EXPORT int pzn_point_mlp3_bwd_f32(const float* dy, const float* x, const flo
   float* part_b = part_w + (size_t)g.nwg * nacc * 1024;
   PmBwdArgs a{dy, x, h1, h2, W1, W2, W3, dx, part_w, part_b, ldw1, g.ntiles, g.T};
   PmRedArgs ra{part_w, part_b, dW1, dW2, dW3, db1, db2, db3, ldw1, g.nwg, g.nwg * 4,
-               b1_per_cloud ? (rows_per_cloud / 32) / g.T : 0, b1_per_cloud ? (int)(M / rows_per_cloud) : 0};
+               b1_per_cloud ? (rows_per_cloud / 32) / g.T : 0, b1_per_cloud ? (int)(M / rows_per_cloud) : 0, accumulate};
   hipStream_t st = pzn_hip_stream(stream);
   return C2 == 64 ? pm_launch_bwd<64, 64>(a, ra, g.nwg, st) : pm_launch_bwd<32, 2>(a, ra, g.nwg, st);
 }

@@ -319,26 +319,38 @@ class _BoundaryCE(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, labels):
-        logits, labels = _f32(logits, "logits"), _f32(labels, "labels")
+        labels = _f32(labels, "labels")
+        if not isinstance(logits, torch.Tensor) or logits.dim() != 3:
+            raise _lib.PznError("boundary_ce expects logits[B,2,N]")
         B, C, N = logits.shape
+        # the heads' [B,N,2] output seen through permute(0,2,1) (model5_b.py:751-754) is read through its strides: no transposed
+        # copy here, and the gradient goes back in the same layout (contiguous for the heads' backward)
+        pm = logits.is_cuda and logits.dtype == torch.float32 and C == 2 and logits.stride() == (2 * N, 1, 2)
+        if not pm:
+            logits = _f32(logits, "logits")
         if C != 2 or tuple(labels.shape) != (B, N):
             raise _lib.PznError(f"boundary_ce expects logits[B,2,N], labels[B,N]; got {tuple(logits.shape)}, {tuple(labels.shape)}")
         prob1 = torch.empty((B, N), dtype=torch.float32, device=logits.device)
         loss = torch.empty((513,), dtype=torch.float32, device=logits.device)   # PZN_BOUNDARY_CE_LOSS_FLOATS: value + partials
         with _on(logits.device):
-            _call("pzn_boundary_ce_fwd_f32", _p(logits), _p(labels), B, N, _p(prob1), _p(loss), _stream())
+            _call("pzn_boundary_ce_fwd_f32", _p(logits), _p(labels), B, N, int(pm), _p(prob1), _p(loss), _stream())
         ctx.save_for_backward(logits, labels)
+        ctx.points_major = pm
         ctx.mark_non_differentiable(prob1)
+        ctx.set_materialize_grads(False)      # (prob1 carries no gradient: no zero-filled [B,N] stand-in for it)
         return loss[0], prob1
 
     @staticmethod
     def backward(ctx, dloss, _dprob):
         logits, labels = ctx.saved_tensors
+        if dloss is None:
+            return None, None
         B, _, N = logits.shape
         dl = _f32(dloss, "dloss").reshape(1)
-        dlogits = torch.empty_like(logits)
+        pm = ctx.points_major
+        dlogits = torch.empty((B, N, 2), dtype=torch.float32, device=logits.device).permute(0, 2, 1) if pm else torch.empty_like(logits)
         with _on(logits.device):
-            _call("pzn_boundary_ce_bwd_f32", _p(logits), _p(labels), _p(dl), B, N, _p(dlogits), _stream())
+            _call("pzn_boundary_ce_bwd_f32", _p(logits), _p(labels), _p(dl), B, N, int(pm), _p(dlogits), _stream())
         return dlogits, None
 
 
@@ -588,6 +600,7 @@ class _Chamfer(torch.autograd.Function):
             _call("pzn_chamfer_fwd_f32", _p(a), _p(b), B, n, m, _p(moa), _p(aoa), _p(mob), _p(aob), _p(ws), _stream())
         ctx.save_for_backward(a, b, aoa, aob)
         ctx.mark_non_differentiable(aoa, aob)
+        ctx.set_materialize_grads(False)      # (the arg-min outputs carry no gradient: no zero-filled stand-ins for them)
         return moa, mob, aoa, aob
 
     @staticmethod
@@ -596,8 +609,10 @@ class _Chamfer(torch.autograd.Function):
         B, n, m = a.shape[0], a.shape[1], b.shape[1]
         g_moa = None if g_moa is None else _f32(g_moa, "g_over_a")
         g_mob = None if g_mob is None else _f32(g_mob, "g_over_b")
-        ga = torch.zeros_like(a)
-        gb = torch.zeros_like(b)
+        if g_moa is None and g_mob is None:
+            return None, None
+        both = torch.zeros((B * (n + m) * 3,), dtype=torch.float32, device=a.device)      # one fill for the two atomic targets
+        ga, gb = both[:B * n * 3].view(B, n, 3), both[B * n * 3:].view(B, m, 3)
         with _on(a.device):
             _call("pzn_chamfer_bwd_f32", _p(a), _p(b), B, n, m, _p(g_moa), _p(aoa), _p(g_mob), _p(aob),
                   _p(ga), _p(gb), _stream())
@@ -792,15 +807,15 @@ class _PointMlp3(torch.autograd.Function):
                 Cg = g2.shape[1]
                 if w1.shape[1] != Cg + C:
                     raise _lib.PznError(f"point_mlp3: w1{tuple(w1.shape)} vs {Cg} + {C} input columns")
-                w_g = w1[:, :Cg].contiguous()
-                bias1 = mk(B, 64)
-                _call("pzn_linear_fwd_f32", _p(g2), _p(w_g), _p(b1), B, Cg, 64, 0, _p(bias1), st, flops=2 * B * Cg * 64)
+                bias1 = mk(B, 64)      # g W1[:, :Cg]^T + b1, the columns read in place (rows of Cg + C floats)
+                _call("pzn_linear_slice_fwd_f32", _p(g2), _p(w1), Cg + C, _p(b1), B, Cg, 64, 0, _p(bias1), st, flops=2 * B * Cg * 64)
             else:
                 bias1 = b1
             _call("pzn_point_mlp3_fwd_f32", _p(x2), M, N, _p(w1) + 4 * Cg, w1.shape[1], _p(bias1), 1 if g is not None else 0,
                   _p(w2), _p(b2), _p(w3), _p(b3), C2, C3, _p(h1), _p(h2), _p(y), st,
                   flops=2 * M * (64 * 64 + 64 * C2 + C2 * C3))
         ctx.save_for_backward(x2, g2, w_g, w1, w2, w3, h1, h2)
+        ctx.bias_refs = (b1, b2, b3)      # (for their registered gradient buffers; parameters, alive anyway)
         ctx.dims = (B, N, C2, C3, Cg)
         ctx.g_shape = None if g is None else g.shape
         return y.view(B, N, C3)
@@ -816,24 +831,39 @@ class _PointMlp3(torch.autograd.Function):
         per_cloud = 1 if g2 is not None else 0
         nws = _lib.load().pzn_point_mlp3_bwd_workspace_bytes(M, N, per_cloud, C2, C3)
         ws = torch.empty((max(16, nws),), dtype=torch.uint8, device=dev)
-        dx, dW1, dW2, dW3, db2, db3 = mk(M, 64), mk(64, Cg + 64), mk(C2, 64), mk(C3, C2), mk(C2), mk(C3)
-        db1 = mk(B, 64) if per_cloud else mk(64)
+        # the six parameter gradients straight into their registered buffers (ops.register_grad_sinks) when all six have one:
+        # no six AccumulateGrad adds per head behind the node
+        b1p, b2p, b3p = ctx.bias_refs
+        sinks = [_sink(t, ctx.needs_input_grad[2 + i]) for i, t in enumerate((w1, b1p, w2, b2p, w3, b3p))]
+        direct = all(s_ is not None for s_ in sinks)
+        dx = mk(M, 64)
+        if direct:
+            dW1, db1_out, dW2, db2, dW3, db3 = sinks
+        else:
+            dW1, dW2, dW3, db2, db3, db1_out = mk(64, Cg + 64), mk(C2, 64), mk(C3, C2), mk(C2), mk(C3), mk(64)
+        db1 = mk(B, 64) if per_cloud else db1_out
         dg = None
         with _on(dev):
             st = _stream()
             _call("pzn_point_mlp3_bwd_f32", _p(dy), _p(x2), _p(h1), _p(h2), M, N, _p(w1) + 4 * Cg, Cg + 64, per_cloud, _p(w2),
-                  _p(w3), C2, C3, _p(dx), _p(dW1) + 4 * Cg, _p(db1), _p(dW2), _p(db2), _p(dW3), _p(db3), _p(ws), st,
+                  _p(w3), C2, C3, _p(dx), _p(dW1) + 4 * Cg, _p(db1), _p(dW2), _p(db2), _p(dW3), _p(db3), int(direct), _p(ws), st,
                   flops=4 * M * (64 * 64 + 64 * C2 + C2 * C3))
             if per_cloud:       # the global half of the first layer: [B, Cg] products on the per-cloud bias gradient
-                dcb, db1 = db1, mk(64)
-                dWg = mk(64, Cg)
-                _call("pzn_linear_wgrad_f32", _p(dcb), None, _p(g2), B, Cg, 64, _p(dWg), _p(db1), 0, st, flops=2 * B * Cg * 64)
-                dW1[:, :Cg] = dWg
+                dcb = db1
+                if direct:      # += into the first Cg columns of the registered dW1 and into db1
+                    _call("pzn_linear_slice_wgrad_f32", _p(dcb), _p(g2), B, Cg, 64, _p(dW1), Cg + 64, _p(db1_out), st,
+                          flops=2 * B * Cg * 64)
+                else:
+                    dWg = mk(64, Cg)
+                    _call("pzn_linear_wgrad_f32", _p(dcb), None, _p(g2), B, Cg, 64, _p(dWg), _p(db1_out), 0, st, flops=2 * B * Cg * 64)
+                    dW1[:, :Cg] = dWg
                 if ctx.needs_input_grad[1]:
                     dg = mk(B, Cg)
-                    _call("pzn_linear_dgrad_f32", _p(dcb), None, _p(w_g), B, Cg, 64, None, _p(dg), st, flops=2 * B * Cg * 64)
+                    _call("pzn_linear_slice_dgrad_f32", _p(dcb), _p(w1), Cg + 64, B, Cg, 64, None, _p(dg), st, flops=2 * B * Cg * 64)
                     dg = dg.view(ctx.g_shape)
-        return dx.view(B, N, 64), dg, dW1, db1, dW2, db2, dW3, db3
+        if direct:
+            return dx.view(B, N, 64), dg, None, None, None, None, None, None
+        return dx.view(B, N, 64), dg, dW1, db1_out, dW2, db2, dW3, db3
 
 
 def point_mlp3_available(C0, C1, C2, C3):

@@ -955,8 +955,18 @@ def test_point_mlp3_full_size_c_abi(dev, C2, C3, per_cloud):
     dx, dW1, dW2, dW3, db2, db3 = mk(M, 64), mk(64, 64), mk(C2, 64), mk(C3, C2), mk(C2), mk(C3)
     db1 = mk(B, 64) if per_cloud else mk(64)
     _lib.check(lib.pzn_point_mlp3_bwd_f32(p(d["dy"]), p(d["x"]), p(h1), p(h2), M, N, p(d["W1"]), 64, int(per_cloud), p(d["W2"]),
-                                          p(d["W3"]), C2, C3, p(dx), p(dW1), p(db1), p(dW2), p(db2), p(dW3), p(db3), p(ws), st), "bwd")
+                                          p(d["W3"]), C2, C3, p(dx), p(dW1), p(db1), p(dW2), p(db2), p(dW3), p(db3), 0, p(ws), st), "bwd")
+    # accumulate != 0: the parameter gradients are added to what the buffers hold (here: 1.0 everywhere -> the result + 1);
+    # dx and the per-cloud db1 are overwritten either way
+    acc = [torch.ones_like(t) for t in (dW1, db1, dW2, db2, dW3, db3)]
+    dx2 = torch.full_like(dx, 7.0)
+    _lib.check(lib.pzn_point_mlp3_bwd_f32(p(d["dy"]), p(d["x"]), p(h1), p(h2), M, N, p(d["W1"]), 64, int(per_cloud), p(d["W2"]),
+                                          p(d["W3"]), C2, C3, p(dx2), p(acc[0]), p(acc[1]), p(acc[2]), p(acc[3]), p(acc[4]),
+                                          p(acc[5]), 1, p(ws), st), "bwd accumulate")
     torch.cuda.synchronize()
+    assert torch.equal(dx2, dx)
+    for t, want, fresh in zip(acc, (dW1, db1, dW2, db2, dW3, db3), (False, bool(per_cloud), False, False, False, False)):
+        assert torch.equal(t, want if fresh else want + 1.0)
     r = {k: v.double().requires_grad_(k != "dy") for k, v in dict(x=x, W1=W1, b1=b1, W2=W2, b2=b2, W3=W3, b3=b3, dy=dy).items()}
     bias1 = r["b1"].repeat_interleave(N, 0) if per_cloud else r["b1"]
     z1 = r["x"] @ r["W1"].t() + bias1

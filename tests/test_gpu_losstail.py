@@ -74,6 +74,30 @@ def test_boundary_ce_vs_torch(B, N):
     assert _rel(ld.grad, lr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("B,N", [(64, 2048), (3, 77)])
+def test_boundary_ce_on_the_permuted_head_output(B, N):
+    """The heads produce [B,N,2]; the reference permutes to [B,2,N] (model5_b.py:751-754).  ops.boundary_ce reads that VIEW through
+    its strides (no transposed copy) and returns the gradient in the same layout: same loss / probabilities / gradient as on a
+    contiguous copy, bit for bit, and the gradient that reaches the head output is contiguous."""
+    from puzzlenet_amd import ops
+    gen = torch.Generator().manual_seed(B + N)
+    head = (3 * torch.randn(B, N, 2, generator=gen)).to(DEV)
+    labels = (torch.rand(B, N, generator=gen) < 0.07).float().to(DEV)
+    a = head.clone().requires_grad_(True)
+    la, pa = ops.boundary_ce(a.permute(0, 2, 1), labels)
+    b = head.permute(0, 2, 1).contiguous().requires_grad_(True)
+    lb, pb = ops.boundary_ce(b, labels)
+    assert torch.equal(la, lb) and torch.equal(pa, pb)
+    seen = {}
+    def hook(g):
+        seen["contig"] = g.is_contiguous()      # (a hook that returns a value replaces the gradient)
+    a.register_hook(hook)
+    (3.0 * la).backward()
+    (3.0 * lb).backward()
+    assert torch.equal(a.grad.permute(0, 2, 1), b.grad)
+    assert seen["contig"]
+
+
 @pytest.mark.parametrize("R,N,K", [(128, 2048, 128), (5, 100, 7), (3, 16384, 256), (2, 4096, 128), (4, 300, 300 - 44)])
 def test_topk_rows_vs_torch(R, N, K):
     """model5_b.py:1089-1091 torch.topk(x, K, 1)[1]: random rows (no ties: the same indices in the same order), rows with

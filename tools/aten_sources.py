@@ -1,5 +1,6 @@
 """Which lines of puzzlenet_amd launch the ATen kernels of a step (copy_, add, mean, fill_, index ...): torch.profiler on the CPU
-side with stacks, grouped by (op, input shapes, innermost frame inside the package).  The device cost of each group is in the
+side, grouped by (op, input shapes, innermost frame inside the package or - where the build records no Python stacks - the
+enclosing profiler events: the autograd node whose backward ran the op).  The device cost of each group is in the
 rocprofv3 kernel table; this names the call sites.   python tools/aten_sources.py [steps]"""
 import collections
 import os
@@ -35,11 +36,18 @@ if __name__ == "__main__":
     for ev in prof.events():
         if ev.name not in want:
             continue
-        where = "(autograd engine / no package frame)"
+        where = ""
         for fr in ev.stack or []:
             if "puzzlenet_amd" in fr or "bench.py" in fr:
                 where = fr.strip()
                 break
+        if not where:      # no Python stack (the backward runs in the engine): name the enclosing profiler events instead
+            chain, par = [], ev.cpu_parent
+            while par is not None and len(chain) < 3:
+                if not par.name.startswith("aten::"):
+                    chain.append(par.name.replace("autograd::engine::evaluate_function: ", "bwd of "))
+                par = par.cpu_parent
+            where = " < ".join(chain) or "(top level)"
         shapes = str([tuple(s) for s in (ev.input_shapes or []) if s])[:70]
         groups[(ev.name, shapes, where[-110:])] += 1
     for (name, shapes, where), c in sorted(groups.items(), key=lambda t: (-t[1], t[0])):
