@@ -5,33 +5,48 @@
 // the BatchNorm "channel" is the POINT index n, its statistics run over the B x 64 values of the point (model5_b.py:424).
 // Everything a point needs is therefore local to the point: its B coordinates (B x 12 bytes), the two small weight
 // matrices, its own BatchNorm parameters.  Rounds 1-4 ran this as 2 linear + 2 BatchNorm launches forward and 5 launches
-// backward per encoder, ~9 passes over 33.5 MB tensors (0.42 ms of launches per step).  Here one workgroup = one point at a
-// time (512 threads: wavefront w holds the samples b = w, w + 8, ... of the point, lane = channel), persistent over the
-// points of its share:
-//   forward : y1 = W1 xyz + b1 (3 fma per value) -> statistics 1 -> a1 = relu(bn1(y1)) -> LDS tile [B][64] ->
-//             y2 = W2 a1 + b2 (the wavefront's sample row broadcast from LDS against the lane's W2 row in registers,
-//             64 fma per value) -> statistics 2 -> a2 = relu(bn2(y2)) stored.  Reads xyz, writes a2: nothing else.
+// backward per encoder, ~9 passes over 33.5 MB tensors.  Here one workgroup (8 wavefronts) = one point at a time, persistent over
+// the points of its share; the point's [B x 64] tiles live in LDS ([sample][channel], rows ST_LD floats apart):
+//   forward : y1 = W1 xyz + b1 (3 fma per value; wavefront w holds samples w, w + 8, ..., lane = channel) -> statistics 1 ->
+//             a1 = relu(bn1(y1)) -> tile -> y2 = a1 W2^T + b2 on the matrix cores in EXACT fp32 (v_mfma_f32_16x16x4_f32: a
+//             k-ordered fmaf chain; wavefront = one 16-channel column block x the 16-sample row blocks) -> statistics 2 ->
+//             a2 = relu(bn2(y2)) stored from the accumulator layout.  Reads xyz, writes a2: nothing else.
 //   backward: y1, a1, y2 RECOMPUTED from xyz and the saved statistics (no activation is kept), then
-//             g2 = da2 gated -> BatchNorm-2 backward (two sums over the point) -> dy2;  dW2 += dy2^T a1 (accumulators of
-//             the lane's W2 row stay in registers over all points of the workgroup);  da1 = dy2 W2 (dy2 rows broadcast
-//             from LDS against the lane's W2 column);  BatchNorm-1 backward -> dy1;  dW1 += dy1^T xyz, db1, db2; the
-//             BatchNorm weight / bias gradients of the point.  Reads xyz and da2, writes parameter gradients only.
-// Arithmetic: fp32 vector fma in the reference's order of operations per element (products summed over the input channel
-// in ascending order); BatchNorm as torch computes it (biased variance for the batch, unbiased for the running buffer).
+//             g2 = da2 gated -> BatchNorm-2 backward (two sums over the point) -> dy2 -> tile;  dW2 += dy2^T a1 (16 output
+//             tiles, two per wavefront, accumulators in registers over all points of the workgroup);  da1 = dy2 W2;
+//             BatchNorm-1 backward -> dy1;  dW1 += dy1^T xyz, db1, db2; the BatchNorm weight / bias gradients of the point.
+//             Reads xyz and da2, writes parameter gradients only (per-workgroup parts, summed by stem_reduce_kernel).
+// The first version of this file fed fp32 vector FMAs from LDS broadcasts (one 16-byte broadcast read per four FMAs): the LDS
+// pipe bounded it at 24 + 55 us for B = 32, N = 1024 and it lost to the four launches it replaces; the matrix-core form reads
+// each tile element once per wavefront that needs it.
+// Arithmetic: fp32 throughout; the products of a row are summed over the input channel in the order 0, 16, 32, 48, 1, 17, ...
+// (the MFMA's k order with lane group q holding channels 16 q ... 16 q + 15); BatchNorm as torch computes it (biased variance
+// for the batch, unbiased for the running buffer).
 #include "pzn_common.h"
 
 namespace {
 
-constexpr int ST_W = 8;     // wavefronts per workgroup: wavefront w holds the samples w, w + 8, ... (8 per lane: with 4 wavefronts
-                            // and 16 samples per lane the backward needed more than the 512 registers a lane can have)
-constexpr int ST_T = 64 * ST_W;
-constexpr int ST_R = 64 / ST_W;    // samples per wavefront: B <= 64
-constexpr int ST_C = 64;    // hidden = output width
+typedef float st_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float st_lane0(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
+constexpr int ST_W = 8;     // wavefronts per workgroup
+constexpr int ST_T = 64 * ST_W;
+constexpr int ST_R = 64 / ST_W;    // samples per wavefront in the per-sample phases: B <= 64
+constexpr int ST_C = 64;    // hidden = output width
+// Row stride of the LDS tiles: an MFMA A-fragment is read as lane (row m = lane & 15, k-group q = lane >> 4) taking 16
+// consecutive floats at [row m][16 q]: 16-byte reads whose 16 lanes of a pass sit 68 floats apart = 4 banks apart, all 64 banks.
+constexpr int ST_LD = ST_C + 4;
+
+// sum over the wavefront, the same value in every lane: DPP / swizzle steps inside the halves, two v_readlane for the halves
+// (no ds_bpermute round trips: the sums sit between barriers on the per-point critical path)
+__device__ __forceinline__ float st_x(float v, uint32_t bits) { return v + __builtin_bit_cast(float, bits); }
 __device__ __forceinline__ float st_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, PZN_WAVE);
-  return v;
+  v = st_x(v, pzn::xor_lane<1>(__builtin_bit_cast(uint32_t, v)));
+  v = st_x(v, pzn::xor_lane<2>(__builtin_bit_cast(uint32_t, v)));
+  v = st_x(v, pzn::xor_lane<4>(__builtin_bit_cast(uint32_t, v)));
+  v = st_x(v, pzn::xor_lane<8>(__builtin_bit_cast(uint32_t, v)));
+  v = st_x(v, pzn::xor_lane<16>(__builtin_bit_cast(uint32_t, v)));
+  return st_lane0(v, 0) + st_lane0(v, 32);
 }
 __device__ __forceinline__ float st_block_sum(float v, float* red) {
   v = st_wave_sum(v);
@@ -42,6 +57,16 @@ __device__ __forceinline__ float st_block_sum(float v, float* red) {
 #pragma unroll
   for (int q = 0; q < ST_W; ++q) t += red[q];
   return t;
+}
+// two sums behind one pair of barriers (red: 2 * ST_W floats)
+__device__ __forceinline__ void st_block_sum2(float& a, float& b, float* red) {
+  a = st_wave_sum(a), b = st_wave_sum(b);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a, red[ST_W + (threadIdx.x >> 6)] = b;
+  __syncthreads();
+  a = b = 0.f;
+#pragma unroll
+  for (int q = 0; q < ST_W; ++q) a += red[q], b += red[ST_W + q];
 }
 
 struct StemBn {
@@ -63,7 +88,7 @@ struct StemFwdArgs {
 };
 
 // What a point needs from global memory, fetched ONE POINT AHEAD (a workgroup walks its points one after the other: every load
-// issued at the place of use was a full memory latency on the critical path, a dozen per point in the first version):
+// issued at the place of use is a full memory latency on the critical path):
 //   crd: lane 3 i + k (i < ST_R, k < 3) holds coordinate k of the wavefront's sample w + ST_W i;
 //   par: lanes 0..7 hold the point's eight per-point scalars (which ones: the caller's table).
 struct StemPoint {
@@ -81,23 +106,42 @@ __device__ __forceinline__ StemPoint stem_fetch(const float* __restrict__ xyz, i
   return r;
 }
 
-// statistics of the point's B x 64 values held as v[i] (sample w + ST_W i, channel lane); -> mean, invstd.  old_mean / old_var:
-// the running buffers' values for this point (prefetched).
-__device__ __forceinline__ void stem_stats(const float (&v)[ST_R], int B, int w, int n, const StemBn& bn, int training, float* red,
-                                           float old_mean, float old_var, float& mean, float& invstd) {
+// statistics of the point's B x 64 values, of which this lane holds v[i] (bit i of `valid`: v[i] is a value of the batch; nw =
+// how many values the WAVEFRONT holds); -> mean, invstd.  Each wavefront takes mean and sum of squared deviations of its own
+// values (two passes, no barrier), the eight (count, mean, M2) triples meet in LDS once and every thread combines them
+// (M2 = sum of M2_w + n_w (mean_w - mean)^2: the two-pass result to rounding, one barrier pair instead of two).
+// old_mean / old_var: the running buffers' values for this point (prefetched).  red: 3 * ST_W floats.
+template <int NV>
+__device__ __forceinline__ void stem_stats(const float (&v)[NV], uint32_t valid, float nw, int B, int n, const StemBn& bn,
+                                           int training, float* red, float old_mean, float old_var, float& mean, float& invstd) {
   if (training) {
     const float cnt = (float)B * (float)ST_C;
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < ST_R; ++i) s += (w + ST_W * i < B) ? v[i] : 0.f;
-    mean = st_block_sum(s, red) / cnt;
+    for (int i = 0; i < NV; ++i) s += ((valid >> i) & 1u) ? v[i] : 0.f;
+    const float mw = nw > 0.f ? st_wave_sum(s) / nw : 0.f;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < ST_R; ++i) {
-      const float d = v[i] - mean;
-      q = (w + ST_W * i < B) ? fmaf(d, d, q) : q;
+    for (int i = 0; i < NV; ++i) {
+      const float d = v[i] - mw;
+      q = ((valid >> i) & 1u) ? fmaf(d, d, q) : q;
     }
-    const float var = st_block_sum(q, red) / cnt;  // biased: what normalises the batch
+    q = st_wave_sum(q);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();      // red may still be read from the previous exchange
+    if ((threadIdx.x & 63) == 0) red[w] = nw, red[ST_W + w] = mw, red[2 * ST_W + w] = q;
+    __syncthreads();
+    float sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < ST_W; ++k) sm = fmaf(red[k], red[ST_W + k], sm);
+    mean = sm / cnt;
+    float m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < ST_W; ++k) {
+      const float d = red[ST_W + k] - mean;
+      m2 += fmaf(red[k] * d, d, red[2 * ST_W + k]);
+    }
+    const float var = m2 / cnt;  // biased: what normalises the batch
     invstd = 1.0f / sqrtf(var + bn.eps);
     if (threadIdx.x == 0) {
       if (bn.running_mean) bn.running_mean[n] = (1.f - bn.momentum) * old_mean + bn.momentum * mean;
@@ -112,45 +156,55 @@ __device__ __forceinline__ void stem_stats(const float (&v)[ST_R], int B, int w,
   }
 }
 
-// y2[i] = b2[lane] + sum_c W2[lane][c] a[b][c]: the sample's row of the LDS tile is a broadcast read, the W2 row sits in registers
-__device__ __forceinline__ void stem_layer2(const float* __restrict__ tile, const float (&wrow)[ST_C], float bb, int w, int B,
-                                            float (&y2)[ST_R]) {
+// 16 consecutive floats of an LDS tile row (an MFMA operand fragment of this lane: k = 16 q + s, s = 0..15)
+__device__ __forceinline__ void st_frag(const float* __restrict__ p, float (&f)[16]) {
 #pragma unroll
-  for (int i = 0; i < ST_R; ++i) {
-    y2[i] = 0.f;
-    if (ST_W * i >= B) continue;      // a whole round of the wavefronts beyond the batch (uniform)
-    const float4* row = reinterpret_cast<const float4*>(tile + (w + ST_W * i) * ST_C);
-    float acc = bb;
-#pragma unroll
-    for (int c4 = 0; c4 < ST_C / 4; ++c4) {
-      const float4 a = row[c4];
-      acc = fmaf(wrow[4 * c4], a.x, acc);
-      acc = fmaf(wrow[4 * c4 + 1], a.y, acc);
-      acc = fmaf(wrow[4 * c4 + 2], a.z, acc);
-      acc = fmaf(wrow[4 * c4 + 3], a.w, acc);
-      if ((c4 & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four row reads in flight, not all 16 x ST_R of the unrolled nest
-    }
-    y2[i] = acc;
+  for (int j = 0; j < 4; ++j) {
+    const float4 t = *reinterpret_cast<const float4*>(p + 4 * j);
+    f[4 * j] = t.x, f[4 * j + 1] = t.y, f[4 * j + 2] = t.z, f[4 * j + 3] = t.w;
   }
 }
 
-__global__ __launch_bounds__(ST_T) void stem_fwd_kernel(StemFwdArgs p) {
-  __shared__ __attribute__((aligned(16))) float tile[64 * ST_C];
-  __shared__ float red[ST_W];
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int B = p.B, N = p.N;
-  const float wx = p.W1[lane * 3], wy = p.W1[lane * 3 + 1], wz = p.W1[lane * 3 + 2], bb1 = p.b1[lane], bb2 = p.b2[lane];
-  float wrow[ST_C];
+// The matrix-core geometry shared by the two kernels.  v_mfma_f32_16x16x4_f32: A[m = lane & 15][k = lane >> 4],
+// B[k = lane >> 4][n = lane & 15], D[m = 4 (lane >> 4) + r][n = lane & 15] in register r.  A product over 64 channels takes 16
+// instructions; at instruction s lane group q = lane >> 4 contributes channel 16 q + s (both operands: any order of k is the
+// same sum), so a lane's fragment is 16 consecutive floats.  Wavefront w owns the 16-wide column block ct = w & 3 of every
+// [sample][channel] product and the 16-sample row blocks bt = (w >> 2), (w >> 2) + 2 (B <= 64: at most 4 row blocks).
+
+// (128 registers: two workgroups per CU - each marches through its barriers in lock step, the other one fills the gaps)
+__global__ __launch_bounds__(ST_T, 4) void stem_fwd_kernel(StemFwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float t0[64 * ST_LD];      // a1 [sample][channel]
+  __shared__ float red[3 * ST_W];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), q = lane >> 4, col = lane & 15;
+  const int B = p.B, N = p.N, nbt = (B + 15) >> 4;
+  const int ct = w & 3, bt0 = w >> 2;
+  const float wx = p.W1[lane * 3], wy = p.W1[lane * 3 + 1], wz = p.W1[lane * 3 + 2], bb1 = p.b1[lane];
+  float bw[16];      // B operand of y2 = a1 W2^T: W2[16 ct + col][16 q + s]
 #pragma unroll
-  for (int c4 = 0; c4 < ST_C / 4; ++c4) {
-    const float4 t = *reinterpret_cast<const float4*>(p.W2 + (size_t)lane * ST_C + 4 * c4);
-    wrow[4 * c4] = t.x, wrow[4 * c4 + 1] = t.y, wrow[4 * c4 + 2] = t.z, wrow[4 * c4 + 3] = t.w;
+  for (int j = 0; j < 4; ++j) {
+    const float4 t = *reinterpret_cast<const float4*>(p.W2 + (size_t)(16 * ct + col) * ST_C + 16 * q + 4 * j);
+    bw[4 * j] = t.x, bw[4 * j + 1] = t.y, bw[4 * j + 2] = t.z, bw[4 * j + 3] = t.w;
   }
+  const float bias2 = p.b2[16 * ct + col];
+  for (int i = B * ST_LD + threadIdx.x; i < 16 * nbt * ST_LD; i += ST_T) t0[i] = 0.f;      // the rows past the batch: zero operands
   // the per-point scalars of lanes 0..7: running mean / variance of bn1, of bn2, then weight / bias of bn1, of bn2
   const float* sp = lane == 0 ? p.bn1.running_mean : lane == 1 ? p.bn1.running_var : lane == 2 ? p.bn2.running_mean
                     : lane == 3 ? p.bn2.running_var : lane == 4 ? p.bn1.weight : lane == 5 ? p.bn1.bias
                     : lane == 6 ? p.bn2.weight : lane == 7 ? p.bn2.bias : nullptr;
   const float dflt = (lane == 1 || lane == 3 || lane == 4 || lane == 6) ? 1.f : 0.f;
+  uint32_t valid1 = 0, valid2 = 0;      // which of the lane's values exist: per-sample phase, accumulator layout
+#pragma unroll
+  for (int i = 0; i < ST_R; ++i) valid1 |= (w + ST_W * i < B ? 1u : 0u) << i;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) valid2 |= (16 * (bt0 + 2 * (i >> 2)) + 4 * q + (i & 3) < B ? 1u : 0u) << i;
+  // values of the batch held by this wavefront in the two layouts (for the statistics)
+  const float nw1 = 64.f * (float)__popc(valid1);
+  float nw2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rows = B - 16 * (bt0 + 2 * j);
+    nw2 += 16.f * (float)(rows < 0 ? 0 : rows > 16 ? 16 : rows);
+  }
   StemPoint nxt = stem_fetch(p.xyz, B, N, blockIdx.x, w, lane, sp, dflt);
   for (int n = blockIdx.x; n < N; n += gridDim.x) {
     const StemPoint cur = nxt;
@@ -160,27 +214,44 @@ __global__ __launch_bounds__(ST_T) void stem_fwd_kernel(StemFwdArgs p) {
     for (int i = 0; i < ST_R; ++i)      // (((b + wx x) + wy y) + wz z)
       y1[i] = fmaf(wz, st_lane(cur.crd, 3 * i + 2), fmaf(wy, st_lane(cur.crd, 3 * i + 1), fmaf(wx, st_lane(cur.crd, 3 * i), bb1)));
     float mean, invstd;
-    stem_stats(y1, B, w, n, p.bn1, p.training, red, st_lane(cur.par, 0), st_lane(cur.par, 1), mean, invstd);
+    stem_stats(y1, valid1, nw1, B, n, p.bn1, p.training, red, st_lane(cur.par, 0), st_lane(cur.par, 1), mean, invstd);
     if (threadIdx.x == 0) p.mean1[n] = mean, p.invstd1[n] = invstd;
     const float g1 = st_lane(cur.par, 4), o1 = st_lane(cur.par, 5);
     __syncthreads();      // the previous point's tile reads are done
 #pragma unroll
     for (int i = 0; i < ST_R; ++i) {
       const float t = fmaf((y1[i] - mean) * invstd, g1, o1);
-      tile[(w + ST_W * i) * ST_C + lane] = t > 0.f ? t : 0.f;
+      if ((valid1 >> i) & 1u) t0[(w + ST_W * i) * ST_LD + lane] = t > 0.f ? t : 0.f;
     }
     __syncthreads();
-    float y2[ST_R];
-    stem_layer2(tile, wrow, bb2, w, B, y2);
-    stem_stats(y2, B, w, n, p.bn2, p.training, red, st_lane(cur.par, 2), st_lane(cur.par, 3), mean, invstd);
+    // ---- y2 = a1 W2^T + b2 for the wavefront's (up to) two 16 x 16 blocks
+    float y2[8];
+    {
+      st_f4 acc[2];
+      float af[2][16];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[j] = st_f4{bias2, bias2, bias2, bias2};
+        if (bt0 + 2 * j < nbt) st_frag(t0 + (16 * (bt0 + 2 * j) + col) * ST_LD + 16 * q, af[j]);
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (bt0 + 2 * j < nbt) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][s], bw[s], acc[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) y2[i] = acc[i >> 2][i & 3];
+    }
+    stem_stats(y2, valid2, nw2, B, n, p.bn2, p.training, red, st_lane(cur.par, 2), st_lane(cur.par, 3), mean, invstd);
     if (threadIdx.x == 0) p.mean2[n] = mean, p.invstd2[n] = invstd;
     const float g2 = st_lane(cur.par, 6), o2 = st_lane(cur.par, 7);
 #pragma unroll
-    for (int i = 0; i < ST_R; ++i) {
-      const int b = w + ST_W * i;
-      if (b < B) {
+    for (int i = 0; i < 8; ++i) {
+      if ((valid2 >> i) & 1u) {
+        const int b = 16 * (bt0 + 2 * (i >> 2)) + 4 * q + (i & 3);
         const float t = fmaf((y2[i] - mean) * invstd, g2, o2);
-        p.out[((size_t)b * N + n) * ST_C + lane] = t > 0.f ? t : 0.f;
+        p.out[((size_t)b * N + n) * ST_C + 16 * ct + col] = t > 0.f ? t : 0.f;
       }
     }
   }
@@ -200,208 +271,188 @@ struct StemBwdArgs {
 
 // One workgroup's parameter-gradient sums: dW2 row-major [64][64], then db2[64], db1[64], dW1 [64][3].  (256 workgroups adding
 // these with atomics put a million adds on 128 cache lines: ~0.4 ms, ten times the arithmetic of the kernel.)
-// LDS row stride of W2 in the backward kernel: a lane reads ITS row 16 bytes at a time; rows 64 floats apart put all 64 lanes on the
-// same four banks (a 16-way conflict on each of the 16 reads per point and wavefront — it was most of the kernel), 68 apart spread
-// each group of 16 lanes over all 64 banks.  Column reads (lane = column) are conflict-free either way.
-constexpr int ST_WS = ST_C + 4;
 constexpr int ST_PART = ST_C * ST_C + 2 * ST_C + 3 * ST_C;
 
-// Per-sample values of the point live in LDS tiles [sample][channel] and the loops over the wavefront's samples are ROLLED: with
-// the samples in register arrays (as in the forward kernel) the unrolled nest of the three 64 x 64 x 64 products needed more
-// registers than a lane has (512 at four wavefronts, 256 + 1.9 KB of spills at eight).
 __global__ __launch_bounds__(ST_T) void stem_bwd_kernel(StemBwdArgs p) {
-  __shared__ __attribute__((aligned(16))) float t0[64 * ST_C];      // a1, later the normalised y1
-  __shared__ __attribute__((aligned(16))) float t1[64 * ST_C];      // gated dout, then dy2
-  __shared__ __attribute__((aligned(16))) float t2[64 * ST_C];      // normalised y2, later gated da1
-  __shared__ __attribute__((aligned(16))) float w2s[ST_C * ST_WS];  // W2 row-major, rows ST_WS apart (see there)
-  __shared__ float xs[ST_W * ST_R * 3];                             // the point's coordinates, [wavefront][round][3]
-  __shared__ float red[ST_W];
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int B = p.B, N = p.N, Bp = (p.B + ST_W - 1) / ST_W * ST_W;      // samples, rounded up to whole rounds of the wavefronts
-  const float wx = p.W1[lane * 3], wy = p.W1[lane * 3 + 1], wz = p.W1[lane * 3 + 2], bb1 = p.b1[lane], bb2 = p.b2[lane];
-  for (int f = threadIdx.x; f < ST_C * ST_C / 4; f += ST_T)
-    *reinterpret_cast<float4*>(w2s + (f / (ST_C / 4)) * ST_WS + 4 * (f % (ST_C / 4))) = reinterpret_cast<const float4*>(p.W2)[f];
-  float dw2[ST_C];      // dW2[lane][:] over the points of this workgroup
+  __shared__ __attribute__((aligned(16))) float t0[64 * ST_LD];      // a1 [sample][channel]
+  __shared__ __attribute__((aligned(16))) float t1[64 * ST_LD];      // dy2 [sample][channel]
+  __shared__ float xs[64 * 3];                                        // the point's coordinates [sample][3]
+  __shared__ float red[2 * ST_W];
+  __shared__ float colsum[5 * ST_C];                                  // end of kernel: db2 | db1 | dW1 x, y, z per channel
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), q = lane >> 4, col = lane & 15;
+  const int B = p.B, N = p.N, nbt = (B + 15) >> 4;
+  const int ct = w & 3, bt0 = w >> 2, ch = 16 * ct + col;      // ch: the channel of this lane in the accumulator layout
+  // per-sample phase (lane = channel) and accumulator-layout (channel ch) copies of layer 1
+  const float wx = p.W1[lane * 3], wy = p.W1[lane * 3 + 1], wz = p.W1[lane * 3 + 2], bb1 = p.b1[lane];
+  const float wxc = p.W1[ch * 3], wyc = p.W1[ch * 3 + 1], wzc = p.W1[ch * 3 + 2], bb1c = p.b1[ch];
+  float bw[16], bt[16];      // B operands: y2 = a1 W2^T: W2[ch][16 q + s];  da1 = dy2 W2: W2[16 q + s][ch]
 #pragma unroll
-  for (int c = 0; c < ST_C; ++c) dw2[c] = 0.f;
-  float db2 = 0.f, db1 = 0.f, dwx = 0.f, dwy = 0.f, dwz = 0.f;
+  for (int j = 0; j < 4; ++j) {
+    const float4 t = *reinterpret_cast<const float4*>(p.W2 + (size_t)ch * ST_C + 16 * q + 4 * j);
+    bw[4 * j] = t.x, bw[4 * j + 1] = t.y, bw[4 * j + 2] = t.z, bw[4 * j + 3] = t.w;
+  }
+#pragma unroll
+  for (int s = 0; s < 16; ++s) bt[s] = p.W2[(size_t)(16 * q + s) * ST_C + ch];
+  const float bias2 = p.b2[ch];
+  for (int i = B * ST_LD + threadIdx.x; i < 16 * nbt * ST_LD; i += ST_T) t0[i] = 0.f, t1[i] = 0.f;
+  st_f4 dw2[2];      // dW2[16 (bt0 + 2 j) + 4 q + r][ch] over the points of this workgroup
+  dw2[0] = dw2[1] = st_f4{0.f, 0.f, 0.f, 0.f};
+  float db2 = 0.f, db1 = 0.f, dwx = 0.f, dwy = 0.f, dwz = 0.f;      // this lane's part of channel ch
   const float cnt = (float)B * (float)ST_C;
-  __syncthreads();
   // the per-point scalars of lanes 0..7: mean / invstd of layer 1, of layer 2, then weight / bias of bn1, of bn2
   const float* sp = lane == 0 ? p.mean1 : lane == 1 ? p.invstd1 : lane == 2 ? p.mean2 : lane == 3 ? p.invstd2 : lane == 4 ? p.bn1w
                     : lane == 5 ? p.bn1b : lane == 6 ? p.bn2w : lane == 7 ? p.bn2b : nullptr;
   const float dflt = (lane == 4 || lane == 6) ? 1.f : 0.f;
-  StemPoint nxt = stem_fetch(p.xyz, B, N, blockIdx.x, w, lane, sp, dflt);
-  float nd[ST_R];      // the output gradient of the NEXT point for the wavefront's samples
+  uint32_t valid1 = 0, valid2 = 0;
 #pragma unroll
-  for (int i = 0; i < ST_R; ++i) nd[i] = (w + ST_W * i < B) ? p.dout[((size_t)(w + ST_W * i) * N + blockIdx.x) * ST_C + lane] : 0.f;
-  for (int n = blockIdx.x; n < N; n += gridDim.x) {
-    const float m1 = st_lane(nxt.par, 0), is1 = st_lane(nxt.par, 1), m2 = st_lane(nxt.par, 2), is2 = st_lane(nxt.par, 3);
-    const float g1 = st_lane(nxt.par, 4), o1 = st_lane(nxt.par, 5), g2 = st_lane(nxt.par, 6), o2 = st_lane(nxt.par, 7);
-    // (W2's row and column of the lane are re-read from LDS for every point — 16 + 64 reads — behind an offset the optimiser
-    //  cannot see through: hoisted out of the point loop they would be 128 registers held beside the 64 of dw2)
-    int zoff = 0;
-    asm volatile("" : "+v"(zoff));
-    __syncthreads();      // the previous point's tiles are done with
-    // ---- stage what was fetched (own elements / own rows only: no barrier), then fetch the next point's
-    if (lane < 3 * ST_R) xs[w * 3 * ST_R + lane] = nxt.crd;      // [wavefront][round][3]
+  for (int i = 0; i < ST_R; ++i) valid1 |= (w + ST_W * i < B ? 1u : 0u) << i;
 #pragma unroll
-    for (int i = 0; i < ST_R; ++i)
-      if (ST_W * i < Bp) t1[(w + ST_W * i) * ST_C + lane] = nd[i];
-    if (n + (int)gridDim.x < N) {
-      const int n2 = n + gridDim.x;
-      nxt = stem_fetch(p.xyz, B, N, n2, w, lane, sp, dflt);
+  for (int i = 0; i < 8; ++i) valid2 |= (16 * (bt0 + 2 * (i >> 2)) + 4 * q + (i & 3) < B ? 1u : 0u) << i;
+  auto fetch_dout = [&](int n, float (&d)[8]) {      // the output gradient in the accumulator layout (64-byte row segments)
 #pragma unroll
-      for (int i = 0; i < ST_R; ++i) nd[i] = (w + ST_W * i < B) ? p.dout[((size_t)(w + ST_W * i) * N + n2) * ST_C + lane] : 0.f;
+    for (int i = 0; i < 8; ++i) {
+      const int b = 16 * (bt0 + 2 * (i >> 2)) + 4 * q + (i & 3);
+      d[i] = ((valid2 >> i) & 1u) ? p.dout[((size_t)b * N + n) * ST_C + ch] : 0.f;
     }
-    // ---- A: recompute layer 1: a1 -> t0
-#pragma unroll 1
-    for (int b = w, i = 0; b < Bp; b += ST_W, ++i) {
-      const float* q = xs + (w * ST_R + i) * 3;
-      const float y1 = fmaf(wz, q[2], fmaf(wy, q[1], fmaf(wx, q[0], bb1)));
+  };
+  StemPoint nxt = stem_fetch(p.xyz, B, N, blockIdx.x, w, lane, sp, dflt);
+  float nd[8];
+  fetch_dout(blockIdx.x, nd);
+  for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    const StemPoint cur = nxt;
+    float gd[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gd[i] = nd[i];
+    if (n + (int)gridDim.x < N) {
+      nxt = stem_fetch(p.xyz, B, N, n + gridDim.x, w, lane, sp, dflt);
+      fetch_dout(n + gridDim.x, nd);
+    }
+    const float m1 = st_lane(cur.par, 0), is1 = st_lane(cur.par, 1), m2 = st_lane(cur.par, 2), is2 = st_lane(cur.par, 3);
+    const float g1 = st_lane(cur.par, 4), o1 = st_lane(cur.par, 5), g2 = st_lane(cur.par, 6), o2 = st_lane(cur.par, 7);
+    __syncthreads();      // the previous point's tiles and coordinates are done with
+    // ---- A: the coordinates -> xs, layer 1 recomputed: a1 -> t0
+    if (lane < 3 * ST_R) xs[(w + ST_W * (lane / 3)) * 3 + lane % 3] = cur.crd;      // (zero past the batch)
+#pragma unroll
+    for (int i = 0; i < ST_R; ++i) {
+      const float y1 = fmaf(wz, st_lane(cur.crd, 3 * i + 2), fmaf(wy, st_lane(cur.crd, 3 * i + 1), fmaf(wx, st_lane(cur.crd, 3 * i), bb1)));
       const float t = fmaf((y1 - m1) * is1, g1, o1);
-      t0[b * ST_C + lane] = t > 0.f ? t : 0.f;
+      if ((valid1 >> i) & 1u) t0[(w + ST_W * i) * ST_LD + lane] = t > 0.f ? t : 0.f;
     }
     __syncthreads();
-    // ---- B: y2 = W2 a1 + b2, its normalised value -> t2, the gated output gradient -> t1, the two sums of BatchNorm 2
+    // ---- B: y2 = a1 W2^T + b2 recomputed; BatchNorm 2 backward: dy2 -> t1, db2
+    float xh[8], g[8];
     float sg = 0.f, sgx = 0.f;
     {
-      float wrow[ST_C];      // W2[lane][:]
+      st_f4 acc[2];
+      float af[2][16];
 #pragma unroll
-      for (int c4 = 0; c4 < ST_C / 4; ++c4) {
-        const float4 t = *reinterpret_cast<const float4*>(w2s + zoff + lane * ST_WS + 4 * c4);
-        wrow[4 * c4] = t.x, wrow[4 * c4 + 1] = t.y, wrow[4 * c4 + 2] = t.z, wrow[4 * c4 + 3] = t.w;
+      for (int j = 0; j < 2; ++j) {
+        acc[j] = st_f4{bias2, bias2, bias2, bias2};
+        if (bt0 + 2 * j < nbt) st_frag(t0 + (16 * (bt0 + 2 * j) + col) * ST_LD + 16 * q, af[j]);
       }
-#pragma unroll 2
-      for (int b = w; b < Bp; b += ST_W) {
-        const float4* row = reinterpret_cast<const float4*>(t0 + b * ST_C);
-        float acc = bb2;
 #pragma unroll
-        for (int c4 = 0; c4 < ST_C / 4; ++c4) {
-          const float4 a = row[c4];
-          acc = fmaf(wrow[4 * c4], a.x, acc);
-          acc = fmaf(wrow[4 * c4 + 1], a.y, acc);
-          acc = fmaf(wrow[4 * c4 + 2], a.z, acc);
-          acc = fmaf(wrow[4 * c4 + 3], a.w, acc);
-        }
-        const float xh = b < B ? (acc - m2) * is2 : 0.f;
-        const float gi = t1[b * ST_C + lane];      // (zero beyond the batch)
-        const float g = (b < B && fmaf(xh, g2, o2) > 0.f) ? gi : 0.f;      // ReLU gate recomputed
-        t1[b * ST_C + lane] = g;
-        t2[b * ST_C + lane] = xh;
-        sg += g;
-        sgx = fmaf(g, xh, sgx);
+      for (int s = 0; s < 16; ++s) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (bt0 + 2 * j < nbt) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][s], bw[s], acc[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool ok = (valid2 >> i) & 1u;
+        xh[i] = ok ? (acc[i >> 2][i & 3] - m2) * is2 : 0.f;
+        g[i] = (ok && fmaf(xh[i], g2, o2) > 0.f) ? gd[i] : 0.f;      // ReLU gate recomputed
+        sg += g[i];
+        sgx = fmaf(g[i], xh[i], sgx);
       }
     }
-    sg = st_block_sum(sg, red);
-    sgx = st_block_sum(sgx, red);
+    st_block_sum2(sg, sgx, red);
     if (threadIdx.x == 0) {
       if (p.dbn2w) atomicAdd(p.dbn2w + n, sgx);
       if (p.dbn2b) atomicAdd(p.dbn2b + n, sg);
     }
-    // ---- C: dy2 -> t1 (own elements), db2, dW2[lane][c] += sum_b dy2[b][lane] a1[b][c]   (a1 rows broadcast from t0)
     {
       const float k = g2 * is2, a1_ = p.training ? sg / cnt : 0.f, a2_ = p.training ? sgx / cnt : 0.f;
-#pragma unroll 2
-      for (int b = w; b < Bp; b += ST_W) {
-        const float d = b < B ? k * (t1[b * ST_C + lane] - a1_ - t2[b * ST_C + lane] * a2_) : 0.f;      // dy2[b][lane]
-        t1[b * ST_C + lane] = d;
-        db2 += d;
-        const float4* row = reinterpret_cast<const float4*>(t0 + b * ST_C);
 #pragma unroll
-        for (int c4 = 0; c4 < ST_C / 4; ++c4) {
-          const float4 a = row[c4];
-          dw2[4 * c4] = fmaf(d, a.x, dw2[4 * c4]);
-          dw2[4 * c4 + 1] = fmaf(d, a.y, dw2[4 * c4 + 1]);
-          dw2[4 * c4 + 2] = fmaf(d, a.z, dw2[4 * c4 + 2]);
-          dw2[4 * c4 + 3] = fmaf(d, a.w, dw2[4 * c4 + 3]);
-        }
+      for (int i = 0; i < 8; ++i) {
+        const float d = ((valid2 >> i) & 1u) ? k * (g[i] - a1_ - xh[i] * a2_) : 0.f;      // dy2[b][ch]
+        db2 += d;
+        if (bt0 + 2 * (i >> 2) < nbt) t1[(16 * (bt0 + 2 * (i >> 2)) + 4 * q + (i & 3)) * ST_LD + ch] = d;
       }
     }
-    __syncthreads();      // dy2 complete in t1; t0 (a1) and t2 (normalised y2) are free
-    // ---- D: da1[b][lane] = sum_c' dy2[b][c'] W2[c'][lane], gated by layer 1's ReLU -> t2; normalised y1 -> t0; BatchNorm 1's sums
+    __syncthreads();      // dy2 complete in t1
+    // ---- C: dW2[c'][c] += sum_b dy2[b][c'] a1[b][c]: k = the samples, four per instruction (sample 4 s + q at instruction s);
+    //         the wavefront's two output blocks are rows 16 (bt0 + 2 j) .. of columns 16 ct ..: they share the a1 operand
+    for (int s = 0; s < 4 * nbt; ++s) {
+      const int b = 4 * s + q;
+      const float a1v = t0[b * ST_LD + ch];
+      dw2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(t1[b * ST_LD + 16 * bt0 + col], a1v, dw2[0], 0, 0, 0);
+      dw2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(t1[b * ST_LD + 16 * (bt0 + 2) + col], a1v, dw2[1], 0, 0, 0);
+    }
+    // ---- D: da1 = dy2 W2 gated by layer 1's ReLU; BatchNorm 1 backward: dy1 -> db1, dW1
     sg = 0.f, sgx = 0.f;
     {
-      float wcol[ST_C];      // W2[:][lane]
+      st_f4 acc[2];
+      float af[2][16];
 #pragma unroll
-      for (int c = 0; c < ST_C; ++c) wcol[c] = w2s[zoff + c * ST_WS + lane];
-#pragma unroll 2
-      for (int b = w, i = 0; b < Bp; b += ST_W, ++i) {
-        const float4* row = reinterpret_cast<const float4*>(t1 + b * ST_C);
-        float acc = 0.f;
+      for (int j = 0; j < 2; ++j) {
+        acc[j] = st_f4{0.f, 0.f, 0.f, 0.f};
+        if (bt0 + 2 * j < nbt) st_frag(t1 + (16 * (bt0 + 2 * j) + col) * ST_LD + 16 * q, af[j]);
+      }
 #pragma unroll
-        for (int c4 = 0; c4 < ST_C / 4; ++c4) {
-          const float4 d = row[c4];
-          acc = fmaf(d.x, wcol[4 * c4], acc);
-          acc = fmaf(d.y, wcol[4 * c4 + 1], acc);
-          acc = fmaf(d.z, wcol[4 * c4 + 2], acc);
-          acc = fmaf(d.w, wcol[4 * c4 + 3], acc);
-        }
-        const float* q = xs + (w * ST_R + i) * 3;
-        const float y1 = fmaf(wz, q[2], fmaf(wy, q[1], fmaf(wx, q[0], bb1)));
-        const float xh = b < B ? (y1 - m1) * is1 : 0.f;
-        const float g = (b < B && fmaf(xh, g1, o1) > 0.f) ? acc : 0.f;
-        t2[b * ST_C + lane] = g;
-        t0[b * ST_C + lane] = xh;
-        sg += g;
-        sgx = fmaf(g, xh, sgx);
+      for (int s = 0; s < 16; ++s) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (bt0 + 2 * j < nbt) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][s], bt[s], acc[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool ok = (valid2 >> i) & 1u;
+        const float* c = xs + (16 * (bt0 + 2 * (i >> 2)) + 4 * q + (i & 3)) * 3;
+        const float y1 = ok ? fmaf(wzc, c[2], fmaf(wyc, c[1], fmaf(wxc, c[0], bb1c))) : 0.f;
+        xh[i] = ok ? (y1 - m1) * is1 : 0.f;
+        g[i] = (ok && fmaf(xh[i], g1, o1) > 0.f) ? acc[i >> 2][i & 3] : 0.f;
+        sg += g[i];
+        sgx = fmaf(g[i], xh[i], sgx);
       }
     }
-    sg = st_block_sum(sg, red);
-    sgx = st_block_sum(sgx, red);
+    st_block_sum2(sg, sgx, red);
     if (threadIdx.x == 0) {
       if (p.dbn1w) atomicAdd(p.dbn1w + n, sgx);
       if (p.dbn1b) atomicAdd(p.dbn1b + n, sg);
     }
-    // ---- E: dy1, db1, dW1 += dy1^T xyz   (own elements of t2 / t0)
     {
       const float k = g1 * is1, a1_ = p.training ? sg / cnt : 0.f, a2_ = p.training ? sgx / cnt : 0.f;
-#pragma unroll 1
-      for (int b = w, i = 0; b < B; b += ST_W, ++i) {
-        const float d = k * (t2[b * ST_C + lane] - a1_ - t0[b * ST_C + lane] * a2_);      // dy1[b][lane]
-        const float* q = xs + (w * ST_R + i) * 3;
-        db1 += d;
-        dwx = fmaf(d, q[0], dwx), dwy = fmaf(d, q[1], dwy), dwz = fmaf(d, q[2], dwz);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if ((valid2 >> i) & 1u) {
+          const float* c = xs + (16 * (bt0 + 2 * (i >> 2)) + 4 * q + (i & 3)) * 3;
+          const float d = k * (g[i] - a1_ - xh[i] * a2_);      // dy1[b][ch]
+          db1 += d;
+          dwx = fmaf(d, c[0], dwx), dwy = fmaf(d, c[1], dwy), dwz = fmaf(d, c[2], dwz);
+        }
       }
     }
   }
-  // ---- the workgroup's parameter gradients: the wavefronts meet in LDS (W2 is not needed any more), one set of atomics
-  __syncthreads();
+  // ---- the workgroup's parameter gradients -> its part (summed over the workgroups by stem_reduce_kernel)
   float* part = p.part + (size_t)blockIdx.x * ST_PART;
-  float* acc = w2s;      // [ST_W][CB][64]: CB columns of dW2 at a time
-  constexpr int CB = ST_C * ST_C / (ST_W * 64);
-  // dW2: wavefront w holds partial dW2[lane][:] of its samples: sum the wavefronts column block by column block
 #pragma unroll
-  for (int c0 = 0; c0 < ST_C; c0 += CB) {      // (unrolled: dw2 is a register array)
-    __syncthreads();
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int c = 0; c < CB; ++c) acc[(w * CB + c) * ST_C + lane] = dw2[c0 + c];      // [w][c][lane]
-    __syncthreads();
-    for (int f = threadIdx.x; f < CB * ST_C; f += ST_T) {
-      const int c = f / ST_C, l = f % ST_C;
-      float t = 0.f;
-#pragma unroll
-      for (int q = 0; q < ST_W; ++q) t += acc[(q * CB + c) * ST_C + l];
-      part[l * ST_C + c0 + c] = t;
-    }
-  }
+    for (int r = 0; r < 4; ++r) part[(16 * (bt0 + 2 * j) + 4 * q + r) * ST_C + ch] = dw2[j][r];      // every block has one owner
+  for (int f = threadIdx.x; f < 5 * ST_C; f += ST_T) colsum[f] = 0.f;
   __syncthreads();
-  float* r5 = t0;      // [5][ST_W][64]: db2, db1, dwx, dwy, dwz
-  r5[(0 * ST_W + w) * 64 + lane] = db2;
-  r5[(1 * ST_W + w) * 64 + lane] = db1;
-  r5[(2 * ST_W + w) * 64 + lane] = dwx;
-  r5[(3 * ST_W + w) * 64 + lane] = dwy;
-  r5[(4 * ST_W + w) * 64 + lane] = dwz;
+  atomicAdd(colsum + ch, db2);      // (eight lanes per channel: four lane groups x two wavefronts)
+  atomicAdd(colsum + ST_C + ch, db1);
+  atomicAdd(colsum + 2 * ST_C + ch, dwx);
+  atomicAdd(colsum + 3 * ST_C + ch, dwy);
+  atomicAdd(colsum + 4 * ST_C + ch, dwz);
   __syncthreads();
-  for (int f = threadIdx.x; f < 5 * 64; f += ST_T) {
-    const int q = f / 64, l = f % 64;
-    float t = 0.f;
-#pragma unroll
-    for (int u = 0; u < ST_W; ++u) t += r5[(q * ST_W + u) * 64 + l];
-    if (q < 2)
-      part[ST_C * ST_C + q * ST_C + l] = t;
+  for (int f = threadIdx.x; f < 5 * ST_C; f += ST_T) {
+    const int k = f / ST_C, l = f % ST_C;
+    if (k < 2)
+      part[ST_C * ST_C + k * ST_C + l] = colsum[f];
     else
-      part[ST_C * ST_C + 2 * ST_C + l * 3 + (q - 2)] = t;
+      part[ST_C * ST_C + 2 * ST_C + l * 3 + (k - 2)] = colsum[f];
   }
 }
 
@@ -426,8 +477,9 @@ __global__ __launch_bounds__(1024) void stem_reduce_kernel(const float* __restri
   }
 }
 
-int stem_grid(int N) {
-  int g = N < 256 ? N : 256;      // one workgroup of 8 wavefronts per CU, each walking N / 256 points with its W2 row / gradient in registers
+int stem_grid(int N, int per_cu) {      // workgroups of 8 wavefronts, per_cu on each CU, each walking its share of the points
+  const int cap = 256 * per_cu;
+  const int g = N < cap ? N : cap;
   return g < 1 ? 1 : g;
 }
 
@@ -450,11 +502,11 @@ PZN_EXPORT int pzn_stem_fwd_f32(const float* xyz, const float* W1, const float* 
                 {bn1_weight, bn1_bias, bn1_running_mean, bn1_running_var, bn1_momentum, bn1_eps},
                 {bn2_weight, bn2_bias, bn2_running_mean, bn2_running_var, bn2_momentum, bn2_eps},
                 training, B, N, out, mean1, invstd1, mean2, invstd2};
-  hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)stem_grid(N)), dim3(ST_T), 0, pzn_hip_stream(stream), a);
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)stem_grid(N, 2)), dim3(ST_T), 0, pzn_hip_stream(stream), a);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
-PZN_EXPORT size_t pzn_stem_bwd_workspace_bytes(int N) { return (size_t)stem_grid(N) * ST_PART * sizeof(float); }
+PZN_EXPORT size_t pzn_stem_bwd_workspace_bytes(int N) { return (size_t)stem_grid(N, 1) * ST_PART * sizeof(float); }
 
 // Backward of pzn_stem_fwd_f32 from dout[B, N, 64]: dW1[64,3], db1[64], dW2[64,64], db2[64] and the BatchNorm weight / bias
 // gradients [N] are ADDED to (the BatchNorm ones may be NULL); nothing is returned for xyz.  Activations are recomputed from xyz
@@ -470,7 +522,7 @@ PZN_EXPORT int pzn_stem_bwd_f32(const float* xyz, const float* dout, const float
   if (B > 64 || (reinterpret_cast<uintptr_t>(W2) & 15)) return PZN_EUNSUPPORTED;
   StemBwdArgs a{xyz, dout, W1, b1, W2, b2, bn1_weight, bn1_bias, bn2_weight, bn2_bias, mean1, invstd1, mean2, invstd2, training, B, N,
                 dW1, db1, dW2, db2, dbn1_weight, dbn1_bias, dbn2_weight, dbn2_bias, static_cast<float*>(workspace)};
-  const int grid = stem_grid(N);
+  const int grid = stem_grid(N, 1);
   hipLaunchKernelGGL(stem_bwd_kernel, dim3((unsigned)grid), dim3(ST_T), 0, pzn_hip_stream(stream), a);
   static_assert(ST_PART % 64 == 0, "stem_reduce_kernel: 64 outputs per workgroup");
   hipLaunchKernelGGL(stem_reduce_kernel, dim3(ST_PART / 64), dim3(1024), 0, pzn_hip_stream(stream), a.part, grid, dW2, db2, db1, dW1);

@@ -225,10 +225,9 @@ _ATTN_FUSED = os.environ.get("PZN_ATTN_FUSED", "1") != "0"     # tuning aid: 0 =
 _ATTN_DUAL = os.environ.get("PZN_ATTN_DUAL", "0") != "0"
 _EMD_OWN_STREAM = int(os.environ.get("PZN_EMD_OWN_STREAM", "0"))   # tuning aid: 1 = the N x N EMD on a third stream, 2 = a high-priority one
 # 1 = the per-point stem (:447-448) as one launch each way (csrc/stem.hip, ops.stem) instead of 2 linear + 2 BatchNorm launches
-# each way.  Off by default: 24 launches per step become 6 and 7 passes over the 33.5 MB activations become 2, but the kernels
-# are fp32 FMAs fed by LDS broadcasts (24 + 55 us per encoder against ~60 us of matrix-core GEMMs + BatchNorm passes) and they
-# take all 256 CUs while FPS runs beside them: 7.42 ms/step against 7.31 on the same box.
-_STEM_FUSED = os.environ.get("PZN_STEM_FUSED", "0") != "0"
+# each way: 24 launches per step become 6, 7 passes over the 33.5 MB activations become 2; 7.02 against 7.10 ms per step on the
+# same box (its first form, vector FMAs fed by LDS broadcasts, lost: 7.42 against 7.31).  0 = the four launches.
+_STEM_FUSED = os.environ.get("PZN_STEM_FUSED", "1") != "0"
 _EMD_SIDE = int(os.environ.get("PZN_EMD_SIDE", "2"))     # tuning aid: 0 = the N x N EMD on the main stream, 1 = forked right after the pose head, 2 = after the heads (measured best)
 
 

@@ -3,7 +3,7 @@ tests/test_gpu_model.py::test_training_step_full_gradients_vs_oracle asserts), w
   python tests/_grad_rows.py [loss_mode [two_streams]]
   JITTER=1e-7 [JSEED=k]  relative noise on Encoder2's per-point features (how sensitive is the gradient to their last bits?)
   XF_FROM_DEVICE=1       the oracle computes downstream of the DEVICE's per-point features
-  PZN_STEM_FUSED=1       the one-launch stem (csrc/stem.hip)
+  PZN_STEM_FUSED=0       the four-launch stem
 A diagnostic that lives in tests/ because it imports the oracle (only tests/, smoke() and bench.py's cpu_baseline may)."""
 import os
 import sys

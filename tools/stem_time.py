@@ -10,8 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 if __name__ == "__main__":
     from puzzlenet_amd import ops
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-    N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     xyz = torch.rand(B, N, 3, device=dev) * 2 - 1
