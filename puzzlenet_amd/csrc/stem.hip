@@ -58,15 +58,16 @@ __device__ __forceinline__ float st_block_sum(float v, float* red) {
   for (int q = 0; q < ST_W; ++q) t += red[q];
   return t;
 }
-// two sums behind one pair of barriers (red: 2 * ST_W floats)
+// two sums over a workgroup of W wavefronts behind one pair of barriers (red: 2 * W floats)
+template <int W>
 __device__ __forceinline__ void st_block_sum2(float& a, float& b, float* red) {
   a = st_wave_sum(a), b = st_wave_sum(b);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a, red[ST_W + (threadIdx.x >> 6)] = b;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a, red[W + (threadIdx.x >> 6)] = b;
   __syncthreads();
   a = b = 0.f;
 #pragma unroll
-  for (int q = 0; q < ST_W; ++q) a += red[q], b += red[ST_W + q];
+  for (int q = 0; q < W; ++q) a += red[q], b += red[W + q];
 }
 
 struct StemBn {
@@ -89,7 +90,7 @@ struct StemFwdArgs {
 
 // What a point needs from global memory, fetched ONE POINT AHEAD (a workgroup walks its points one after the other: every load
 // issued at the place of use is a full memory latency on the critical path):
-//   crd: lane 3 i + k (i < ST_R, k < 3) holds coordinate k of the wavefront's sample w + ST_W i;
+//   crd: lane 3 i + k (i < 64 / W, k < 3) holds coordinate k of the wavefront's sample w + W i (W wavefronts per workgroup);
 //   par: lanes 0..7 hold the point's eight per-point scalars (which ones: the caller's table).
 struct StemPoint {
   float crd, par;
@@ -97,11 +98,12 @@ struct StemPoint {
 
 __device__ __forceinline__ float st_lane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
+template <int W>
 __device__ __forceinline__ StemPoint stem_fetch(const float* __restrict__ xyz, int B, int N, int n, int w, int lane,
                                                 const float* sp, float dflt) {
   StemPoint r;
-  const int i = lane / 3, k = lane - 3 * i, b = w + ST_W * i;
-  r.crd = (lane < 3 * ST_R && b < B) ? xyz[((size_t)b * N + n) * 3 + k] : 0.f;
+  const int i = lane / 3, k = lane - 3 * i, b = w + W * i;
+  r.crd = (lane < 3 * (64 / W) && b < B) ? xyz[((size_t)b * N + n) * 3 + k] : 0.f;
   r.par = sp ? sp[n] : dflt;
   return r;
 }
@@ -205,10 +207,10 @@ __global__ __launch_bounds__(ST_T, 4) void stem_fwd_kernel(StemFwdArgs p) {
     const int rows = B - 16 * (bt0 + 2 * j);
     nw2 += 16.f * (float)(rows < 0 ? 0 : rows > 16 ? 16 : rows);
   }
-  StemPoint nxt = stem_fetch(p.xyz, B, N, blockIdx.x, w, lane, sp, dflt);
+  StemPoint nxt = stem_fetch<ST_W>(p.xyz, B, N, blockIdx.x, w, lane, sp, dflt);
   for (int n = blockIdx.x; n < N; n += gridDim.x) {
     const StemPoint cur = nxt;
-    if (n + (int)gridDim.x < N) nxt = stem_fetch(p.xyz, B, N, n + gridDim.x, w, lane, sp, dflt);
+    if (n + (int)gridDim.x < N) nxt = stem_fetch<ST_W>(p.xyz, B, N, n + gridDim.x, w, lane, sp, dflt);
     float y1[ST_R];
 #pragma unroll
     for (int i = 0; i < ST_R; ++i)      // (((b + wx x) + wy y) + wz z)
@@ -273,99 +275,110 @@ struct StemBwdArgs {
 // these with atomics put a million adds on 128 cache lines: ~0.4 ms, ten times the arithmetic of the kernel.)
 constexpr int ST_PART = ST_C * ST_C + 2 * ST_C + 3 * ST_C;
 
-__global__ __launch_bounds__(ST_T) void stem_bwd_kernel(StemBwdArgs p) {
+// Four wavefronts per workgroup here, two workgroups per CU: the same eight wavefronts a CU holds at this register count, but as two
+// barrier domains (a workgroup marches through seven barriers per point in lock step; the other one fills its gaps: the
+// forward gained a third that way).  Wavefront w owns column block ct = w of every product and all (up to four) 16-sample row
+// blocks, two at a time; of dW2 it owns the four 16 x 16 blocks of its 16 columns.
+constexpr int SB_W = 4, SB_T = 64 * SB_W, SB_R = 64 / SB_W;
+
+__global__ __launch_bounds__(SB_T, 2) void stem_bwd_kernel(StemBwdArgs p) {
   __shared__ __attribute__((aligned(16))) float t0[64 * ST_LD];      // a1 [sample][channel]
   __shared__ __attribute__((aligned(16))) float t1[64 * ST_LD];      // dy2 [sample][channel]
+  __shared__ __attribute__((aligned(16))) float w2s[64 * ST_LD];     // W2 [output channel][input channel]
+  __shared__ __attribute__((aligned(16))) float w2t[64 * ST_LD];     // W2 transposed: [input channel][output channel]
   __shared__ float xs[64 * 3];                                        // the point's coordinates [sample][3]
-  __shared__ float red[2 * ST_W];
+  __shared__ float red[2 * SB_W];
   __shared__ float colsum[5 * ST_C];                                  // end of kernel: db2 | db1 | dW1 x, y, z per channel
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), q = lane >> 4, col = lane & 15;
   const int B = p.B, N = p.N, nbt = (B + 15) >> 4;
-  const int ct = w & 3, bt0 = w >> 2, ch = 16 * ct + col;      // ch: the channel of this lane in the accumulator layout
+  const int ch = 16 * w + col;      // the channel of this lane in the accumulator layout
   // per-sample phase (lane = channel) and accumulator-layout (channel ch) copies of layer 1
   const float wx = p.W1[lane * 3], wy = p.W1[lane * 3 + 1], wz = p.W1[lane * 3 + 2], bb1 = p.b1[lane];
   const float wxc = p.W1[ch * 3], wyc = p.W1[ch * 3 + 1], wzc = p.W1[ch * 3 + 2], bb1c = p.b1[ch];
-  float bw[16], bt[16];      // B operands: y2 = a1 W2^T: W2[ch][16 q + s];  da1 = dy2 W2: W2[16 q + s][ch]
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float4 t = *reinterpret_cast<const float4*>(p.W2 + (size_t)ch * ST_C + 16 * q + 4 * j);
-    bw[4 * j] = t.x, bw[4 * j + 1] = t.y, bw[4 * j + 2] = t.z, bw[4 * j + 3] = t.w;
+  // The B operands - y2 = a1 W2^T: W2[ch][16 q + s]; da1 = dy2 W2: W2[16 q + s][ch] - are re-read from two LDS copies of W2
+  // at every point (four 16-byte reads each): held in registers beside the rest they pushed the kernel past the 256
+  // registers that let two workgroups share a CU.
+  for (int i = threadIdx.x; i < ST_C * ST_C; i += SB_T) {
+    const float v = p.W2[i];
+    w2s[(i / ST_C) * ST_LD + i % ST_C] = v;
+    w2t[(i % ST_C) * ST_LD + i / ST_C] = v;
   }
-#pragma unroll
-  for (int s = 0; s < 16; ++s) bt[s] = p.W2[(size_t)(16 * q + s) * ST_C + ch];
   const float bias2 = p.b2[ch];
-  for (int i = B * ST_LD + threadIdx.x; i < 16 * nbt * ST_LD; i += ST_T) t0[i] = 0.f, t1[i] = 0.f;
-  st_f4 dw2[2];      // dW2[16 (bt0 + 2 j) + 4 q + r][ch] over the points of this workgroup
-  dw2[0] = dw2[1] = st_f4{0.f, 0.f, 0.f, 0.f};
+  for (int i = B * ST_LD + threadIdx.x; i < 16 * nbt * ST_LD; i += SB_T) t0[i] = 0.f, t1[i] = 0.f;
+  st_f4 dw2[4];      // dW2[16 m + 4 q + r][ch], m = 0..3, over the points of this workgroup
+#pragma unroll
+  for (int m = 0; m < 4; ++m) dw2[m] = st_f4{0.f, 0.f, 0.f, 0.f};
   float db2 = 0.f, db1 = 0.f, dwx = 0.f, dwy = 0.f, dwz = 0.f;      // this lane's part of channel ch
   const float cnt = (float)B * (float)ST_C;
   // the per-point scalars of lanes 0..7: mean / invstd of layer 1, of layer 2, then weight / bias of bn1, of bn2
   const float* sp = lane == 0 ? p.mean1 : lane == 1 ? p.invstd1 : lane == 2 ? p.mean2 : lane == 3 ? p.invstd2 : lane == 4 ? p.bn1w
                     : lane == 5 ? p.bn1b : lane == 6 ? p.bn2w : lane == 7 ? p.bn2b : nullptr;
   const float dflt = (lane == 4 || lane == 6) ? 1.f : 0.f;
-  uint32_t valid1 = 0, valid2 = 0;
+  uint32_t valid1 = 0, valid2 = 0;      // per-sample phase: sample w + 4 i; accumulator layout: value i = row block i >> 2, register i & 3
 #pragma unroll
-  for (int i = 0; i < ST_R; ++i) valid1 |= (w + ST_W * i < B ? 1u : 0u) << i;
+  for (int i = 0; i < SB_R; ++i) valid1 |= (w + SB_W * i < B ? 1u : 0u) << i;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) valid2 |= (16 * (bt0 + 2 * (i >> 2)) + 4 * q + (i & 3) < B ? 1u : 0u) << i;
-  auto fetch_dout = [&](int n, float (&d)[8]) {      // the output gradient in the accumulator layout (64-byte row segments)
+  for (int i = 0; i < 16; ++i) valid2 |= (16 * (i >> 2) + 4 * q + (i & 3) < B ? 1u : 0u) << i;
+  auto fetch_dout = [&](int n, float (&d)[16]) {      // the output gradient in the accumulator layout (64-byte row segments)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int b = 16 * (bt0 + 2 * (i >> 2)) + 4 * q + (i & 3);
+    for (int i = 0; i < 16; ++i) {
+      const int b = 16 * (i >> 2) + 4 * q + (i & 3);
       d[i] = ((valid2 >> i) & 1u) ? p.dout[((size_t)b * N + n) * ST_C + ch] : 0.f;
     }
   };
-  StemPoint nxt = stem_fetch(p.xyz, B, N, blockIdx.x, w, lane, sp, dflt);
-  float nd[8];
-  fetch_dout(blockIdx.x, nd);
+  StemPoint nxt = stem_fetch<SB_W>(p.xyz, B, N, blockIdx.x, w, lane, sp, dflt);
   for (int n = blockIdx.x; n < N; n += gridDim.x) {
     const StemPoint cur = nxt;
-    float gd[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) gd[i] = nd[i];
-    if (n + (int)gridDim.x < N) {
-      nxt = stem_fetch(p.xyz, B, N, n + gridDim.x, w, lane, sp, dflt);
-      fetch_dout(n + gridDim.x, nd);
-    }
+    // the output gradient of THIS point (then the gated one, then layer 1's): first used behind phase A, a barrier and the 32
+    // matrix instructions of phase B, which is where its latency goes (a copy fetched one point ahead cost 16 registers more)
+    float g[16];
+    fetch_dout(n, g);
+    if (n + (int)gridDim.x < N) nxt = stem_fetch<SB_W>(p.xyz, B, N, n + gridDim.x, w, lane, sp, dflt);
     const float m1 = st_lane(cur.par, 0), is1 = st_lane(cur.par, 1), m2 = st_lane(cur.par, 2), is2 = st_lane(cur.par, 3);
     const float g1 = st_lane(cur.par, 4), o1 = st_lane(cur.par, 5), g2 = st_lane(cur.par, 6), o2 = st_lane(cur.par, 7);
     __syncthreads();      // the previous point's tiles and coordinates are done with
     // ---- A: the coordinates -> xs, layer 1 recomputed: a1 -> t0
-    if (lane < 3 * ST_R) xs[(w + ST_W * (lane / 3)) * 3 + lane % 3] = cur.crd;      // (zero past the batch)
+    if (lane < 3 * SB_R) xs[(w + SB_W * (lane / 3)) * 3 + lane % 3] = cur.crd;      // (zero past the batch)
 #pragma unroll
-    for (int i = 0; i < ST_R; ++i) {
+    for (int i = 0; i < SB_R; ++i) {
       const float y1 = fmaf(wz, st_lane(cur.crd, 3 * i + 2), fmaf(wy, st_lane(cur.crd, 3 * i + 1), fmaf(wx, st_lane(cur.crd, 3 * i), bb1)));
       const float t = fmaf((y1 - m1) * is1, g1, o1);
-      if ((valid1 >> i) & 1u) t0[(w + ST_W * i) * ST_LD + lane] = t > 0.f ? t : 0.f;
+      if ((valid1 >> i) & 1u) t0[(w + SB_W * i) * ST_LD + lane] = t > 0.f ? t : 0.f;
     }
     __syncthreads();
     // ---- B: y2 = a1 W2^T + b2 recomputed; BatchNorm 2 backward: dy2 -> t1, db2
-    float xh[8], g[8];
+    float xh[16];
     float sg = 0.f, sgx = 0.f;
-    {
+    int zoff = 0;
+    asm volatile("" : "+v"(zoff));      // (keeps the operand loads inside the point loop)
+    float bw[16];
+    st_frag(w2s + zoff + ch * ST_LD + 16 * q, bw);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {      // row blocks 2 h, 2 h + 1
       st_f4 acc[2];
       float af[2][16];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         acc[j] = st_f4{bias2, bias2, bias2, bias2};
-        if (bt0 + 2 * j < nbt) st_frag(t0 + (16 * (bt0 + 2 * j) + col) * ST_LD + 16 * q, af[j]);
+        if (2 * h + j < nbt) st_frag(t0 + (16 * (2 * h + j) + col) * ST_LD + 16 * q, af[j]);
       }
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          if (bt0 + 2 * j < nbt) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][s], bw[s], acc[j], 0, 0, 0);
+          if (2 * h + j < nbt) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][s], bw[s], acc[j], 0, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int k = 0; k < 8; ++k) {
+        const int i = 8 * h + k;
         const bool ok = (valid2 >> i) & 1u;
-        xh[i] = ok ? (acc[i >> 2][i & 3] - m2) * is2 : 0.f;
-        g[i] = (ok && fmaf(xh[i], g2, o2) > 0.f) ? gd[i] : 0.f;      // ReLU gate recomputed
+        xh[i] = ok ? (acc[k >> 2][k & 3] - m2) * is2 : 0.f;
+        g[i] = (ok && fmaf(xh[i], g2, o2) > 0.f) ? g[i] : 0.f;      // ReLU gate recomputed
         sg += g[i];
         sgx = fmaf(g[i], xh[i], sgx);
       }
     }
-    st_block_sum2(sg, sgx, red);
+    st_block_sum2<SB_W>(sg, sgx, red);
     if (threadIdx.x == 0) {
       if (p.dbn2w) atomicAdd(p.dbn2w + n, sgx);
       if (p.dbn2b) atomicAdd(p.dbn2b + n, sg);
@@ -373,49 +386,53 @@ __global__ __launch_bounds__(ST_T) void stem_bwd_kernel(StemBwdArgs p) {
     {
       const float k = g2 * is2, a1_ = p.training ? sg / cnt : 0.f, a2_ = p.training ? sgx / cnt : 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < 16; ++i) {
         const float d = ((valid2 >> i) & 1u) ? k * (g[i] - a1_ - xh[i] * a2_) : 0.f;      // dy2[b][ch]
         db2 += d;
-        if (bt0 + 2 * (i >> 2) < nbt) t1[(16 * (bt0 + 2 * (i >> 2)) + 4 * q + (i & 3)) * ST_LD + ch] = d;
+        if ((i >> 2) < nbt) t1[(16 * (i >> 2) + 4 * q + (i & 3)) * ST_LD + ch] = d;
       }
     }
     __syncthreads();      // dy2 complete in t1
     // ---- C: dW2[c'][c] += sum_b dy2[b][c'] a1[b][c]: k = the samples, four per instruction (sample 4 s + q at instruction s);
-    //         the wavefront's two output blocks are rows 16 (bt0 + 2 j) .. of columns 16 ct ..: they share the a1 operand
+    //         the wavefront's four output blocks (rows 16 m .. of columns 16 w ..) share the a1 operand
     for (int s = 0; s < 4 * nbt; ++s) {
       const int b = 4 * s + q;
       const float a1v = t0[b * ST_LD + ch];
-      dw2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(t1[b * ST_LD + 16 * bt0 + col], a1v, dw2[0], 0, 0, 0);
-      dw2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(t1[b * ST_LD + 16 * (bt0 + 2) + col], a1v, dw2[1], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) dw2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t1[b * ST_LD + 16 * m + col], a1v, dw2[m], 0, 0, 0);
     }
     // ---- D: da1 = dy2 W2 gated by layer 1's ReLU; BatchNorm 1 backward: dy1 -> db1, dW1
     sg = 0.f, sgx = 0.f;
-    {
+    float bt[16];
+    st_frag(w2t + zoff + ch * ST_LD + 16 * q, bt);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
       st_f4 acc[2];
       float af[2][16];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         acc[j] = st_f4{0.f, 0.f, 0.f, 0.f};
-        if (bt0 + 2 * j < nbt) st_frag(t1 + (16 * (bt0 + 2 * j) + col) * ST_LD + 16 * q, af[j]);
+        if (2 * h + j < nbt) st_frag(t1 + (16 * (2 * h + j) + col) * ST_LD + 16 * q, af[j]);
       }
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          if (bt0 + 2 * j < nbt) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][s], bt[s], acc[j], 0, 0, 0);
+          if (2 * h + j < nbt) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][s], bt[s], acc[j], 0, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int k = 0; k < 8; ++k) {
+        const int i = 8 * h + k;
         const bool ok = (valid2 >> i) & 1u;
-        const float* c = xs + (16 * (bt0 + 2 * (i >> 2)) + 4 * q + (i & 3)) * 3;
+        const float* c = xs + (16 * (i >> 2) + 4 * q + (i & 3)) * 3;
         const float y1 = ok ? fmaf(wzc, c[2], fmaf(wyc, c[1], fmaf(wxc, c[0], bb1c))) : 0.f;
         xh[i] = ok ? (y1 - m1) * is1 : 0.f;
-        g[i] = (ok && fmaf(xh[i], g1, o1) > 0.f) ? acc[i >> 2][i & 3] : 0.f;
+        g[i] = (ok && fmaf(xh[i], g1, o1) > 0.f) ? acc[k >> 2][k & 3] : 0.f;
         sg += g[i];
         sgx = fmaf(g[i], xh[i], sgx);
       }
     }
-    st_block_sum2(sg, sgx, red);
+    st_block_sum2<SB_W>(sg, sgx, red);
     if (threadIdx.x == 0) {
       if (p.dbn1w) atomicAdd(p.dbn1w + n, sgx);
       if (p.dbn1b) atomicAdd(p.dbn1b + n, sg);
@@ -423,9 +440,9 @@ __global__ __launch_bounds__(ST_T) void stem_bwd_kernel(StemBwdArgs p) {
     {
       const float k = g1 * is1, a1_ = p.training ? sg / cnt : 0.f, a2_ = p.training ? sgx / cnt : 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < 16; ++i) {
         if ((valid2 >> i) & 1u) {
-          const float* c = xs + (16 * (bt0 + 2 * (i >> 2)) + 4 * q + (i & 3)) * 3;
+          const float* c = xs + (16 * (i >> 2) + 4 * q + (i & 3)) * 3;
           const float d = k * (g[i] - a1_ - xh[i] * a2_);      // dy1[b][ch]
           db1 += d;
           dwx = fmaf(d, c[0], dwx), dwy = fmaf(d, c[1], dwy), dwz = fmaf(d, c[2], dwz);
@@ -436,18 +453,18 @@ __global__ __launch_bounds__(ST_T) void stem_bwd_kernel(StemBwdArgs p) {
   // ---- the workgroup's parameter gradients -> its part (summed over the workgroups by stem_reduce_kernel)
   float* part = p.part + (size_t)blockIdx.x * ST_PART;
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) part[(16 * (bt0 + 2 * j) + 4 * q + r) * ST_C + ch] = dw2[j][r];      // every block has one owner
-  for (int f = threadIdx.x; f < 5 * ST_C; f += ST_T) colsum[f] = 0.f;
+    for (int r = 0; r < 4; ++r) part[(16 * m + 4 * q + r) * ST_C + ch] = dw2[m][r];      // every block has one owner
+  for (int f = threadIdx.x; f < 5 * ST_C; f += SB_T) colsum[f] = 0.f;
   __syncthreads();
-  atomicAdd(colsum + ch, db2);      // (eight lanes per channel: four lane groups x two wavefronts)
+  atomicAdd(colsum + ch, db2);      // (four lanes per channel: the lane groups)
   atomicAdd(colsum + ST_C + ch, db1);
   atomicAdd(colsum + 2 * ST_C + ch, dwx);
   atomicAdd(colsum + 3 * ST_C + ch, dwy);
   atomicAdd(colsum + 4 * ST_C + ch, dwz);
   __syncthreads();
-  for (int f = threadIdx.x; f < 5 * ST_C; f += ST_T) {
+  for (int f = threadIdx.x; f < 5 * ST_C; f += SB_T) {
     const int k = f / ST_C, l = f % ST_C;
     if (k < 2)
       part[ST_C * ST_C + k * ST_C + l] = colsum[f];
@@ -506,7 +523,7 @@ PZN_EXPORT int pzn_stem_fwd_f32(const float* xyz, const float* W1, const float* 
   PZN_RETURN_LAUNCH_STATUS();
 }
 
-PZN_EXPORT size_t pzn_stem_bwd_workspace_bytes(int N) { return (size_t)stem_grid(N, 1) * ST_PART * sizeof(float); }
+PZN_EXPORT size_t pzn_stem_bwd_workspace_bytes(int N) { return (size_t)stem_grid(N, 2) * ST_PART * sizeof(float); }
 
 // Backward of pzn_stem_fwd_f32 from dout[B, N, 64]: dW1[64,3], db1[64], dW2[64,64], db2[64] and the BatchNorm weight / bias
 // gradients [N] are ADDED to (the BatchNorm ones may be NULL); nothing is returned for xyz.  Activations are recomputed from xyz
@@ -522,8 +539,8 @@ PZN_EXPORT int pzn_stem_bwd_f32(const float* xyz, const float* dout, const float
   if (B > 64 || (reinterpret_cast<uintptr_t>(W2) & 15)) return PZN_EUNSUPPORTED;
   StemBwdArgs a{xyz, dout, W1, b1, W2, b2, bn1_weight, bn1_bias, bn2_weight, bn2_bias, mean1, invstd1, mean2, invstd2, training, B, N,
                 dW1, db1, dW2, db2, dbn1_weight, dbn1_bias, dbn2_weight, dbn2_bias, static_cast<float*>(workspace)};
-  const int grid = stem_grid(N, 1);
-  hipLaunchKernelGGL(stem_bwd_kernel, dim3((unsigned)grid), dim3(ST_T), 0, pzn_hip_stream(stream), a);
+  const int grid = stem_grid(N, 2);
+  hipLaunchKernelGGL(stem_bwd_kernel, dim3((unsigned)grid), dim3(SB_T), 0, pzn_hip_stream(stream), a);
   static_assert(ST_PART % 64 == 0, "stem_reduce_kernel: 64 outputs per workgroup");
   hipLaunchKernelGGL(stem_reduce_kernel, dim3(ST_PART / 64), dim3(1024), 0, pzn_hip_stream(stream), a.part, grid, dW2, db2, db1, dW1);
   PZN_RETURN_LAUNCH_STATUS();
