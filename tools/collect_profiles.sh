@@ -19,7 +19,7 @@ python3 tools/pmc_summary.py $O/fetch $O/write $O/pmc_traffic.json > $O/pmc_traf
 cat $O/pmc_traffic.txt
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/sq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads > $O/pmc_sq.log 2>&1 || exit 1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/grbm -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads > $O/pmc_grbm.log 2>&1 || exit 1
-python3 tools/pmc_kernel_table.py $O/sq "sa_level_stream_kernel|outproj_maxpts_kernel|point_mlp3|attn_fwd_kernel|attn_bwd|attn_proj|ws_gemm_kernel|knn_select_kernel|gemm_kernel<128|emdf_|pool_" > $O/sq_table.txt
+python3 tools/pmc_kernel_table.py $O/sq "sa_level_stream_kernel|outproj_maxpts_kernel|point_mlp3|attn_fwd_kernel|attn_bwd|attn_proj|ws_gemm_kernel|knn_select_kernel|gemm_kernel<128|emdf_|pool_|stem_" > $O/sq_table.txt
 python3 tools/pmc_kernel_table.py $O/grbm "sa_level_stream_kernel|outproj_maxpts_kernel|attn_fwd_kernel|attn_bwd|ws_gemm_kernel|knn_select_kernel" > $O/grbm_table.txt
 cat $O/sq_table.txt | cut -c1-250
 rm -f $O/*/*/*.db $O/*/*.db
