@@ -169,7 +169,12 @@ SPILL_FREE = {   # source -> kernels (substring of the mangled name) that must n
     "salevel.hip": ("sa_level_stream_kernel",),
     "outproj.hip": ("outproj_maxpts_kernel",),
     "pointmlp.hip": ("point_mlp3_fwd_kernel", "point_mlp3_bwd_kernel"),
+    # the per-point stem (round 5): its two-workgroups-per-CU occupancy rests on 128 / 256 registers without scratch
+    "stem.hip": ("stem_fwd_kernel", "stem_bwd_kernel"),
 }
+
+# register ceilings that an occupancy argument in the source rests on: kernel -> architected + accumulation registers
+REGISTER_CAPS = {"stem.hip": {"stem_fwd_kernel": 128, "stem_bwd_kernel": 256}}
 
 
 def test_matrix_core_kernels_do_not_spill():
@@ -198,4 +203,8 @@ def test_matrix_core_kernels_do_not_spill():
             spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", entry).group(1))
             scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", entry).group(1))
             assert spills == 0 and scratch == 0, f"{name}: {spills} spilled registers, {scratch} bytes of scratch per lane"
+            cap = REGISTER_CAPS.get(source, {}).get(which[0])
+            if cap is not None:
+                regs = int(re.search(r"\.vgpr_count:\s+(\d+)", entry).group(1)) + int(re.search(r"\.agpr_count:\s+(\d+)", entry).group(1))
+                assert regs <= cap, f"{name}: {regs} registers, the occupancy it is launched for needs <= {cap}"
         assert seen == set(kernels), (source, seen)
