@@ -396,7 +396,8 @@ int pzn_sa_level_bwd_pt_f32(const float* dout, const int32_t* argmax, const floa
  * has them; training != 0: batch statistics, running buffers updated in place as torch does).  out[B,N,64]; mean1 / invstd1 /
  * mean2 / invstd2 [N] (written) feed the backward, which recomputes every activation from xyz.  bwd: dW1[64,3], db1[64],
  * dW2[64,64], db2[64] and the BatchNorm weight / bias gradients [N] (these may be NULL) are ADDED to; no gradient for xyz;
- * workspace = pzn_stem_bwd_workspace_bytes(N) bytes, 16-byte aligned, need not be cleared (the workgroups' partial sums).
+ * workspace = pzn_stem_bwd_workspace_bytes(N) bytes, 16-byte aligned, need not be cleared (the workgroups' partial sums);
+ * dout2 (may be NULL): a second gradient of the same output, added to dout while loading (two consumers of the features).
  * PZN_EUNSUPPORTED for B > 64 or W2 not 16-byte aligned (compose pzn_linear_* + pzn_bn_points_relu_* then). */
 int pzn_stem_fwd_f32(const float* xyz, const float* W1, const float* b1, const float* bn1_weight, const float* bn1_bias,
                      float* bn1_running_mean, float* bn1_running_var, float bn1_momentum, float bn1_eps, const float* W2,
@@ -404,7 +405,7 @@ int pzn_stem_fwd_f32(const float* xyz, const float* W1, const float* b1, const f
                      float* bn2_running_var, float bn2_momentum, float bn2_eps, int training, int B, int N, float* out,
                      float* mean1, float* invstd1, float* mean2, float* invstd2, pzn_stream_t stream);
 size_t pzn_stem_bwd_workspace_bytes(int N);
-int pzn_stem_bwd_f32(const float* xyz, const float* dout, const float* W1, const float* b1, const float* W2, const float* b2,
+int pzn_stem_bwd_f32(const float* xyz, const float* dout, const float* dout2, const float* W1, const float* b1, const float* W2, const float* b2,
                      const float* bn1_weight, const float* bn1_bias, const float* bn2_weight, const float* bn2_bias,
                      const float* mean1, const float* invstd1, const float* mean2, const float* invstd2, int training, int B,
                      int N, float* dW1, float* db1, float* dW2, float* db2, float* dbn1_weight, float* dbn1_bias,

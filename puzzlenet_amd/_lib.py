@@ -101,7 +101,7 @@ SIGNATURES = {
     "pzn_bn_points_relu_fwd_f32": (_c_i, [_c_f] * 5 + [_c_i, _c_fl, _c_fl, _c_i, _c_i, _c_i] + [_c_f] * 4),
     "pzn_stem_fwd_f32": (_c_i, [_c_f] * 7 + [_c_fl, _c_fl] + [_c_f] * 6 + [_c_fl, _c_fl, _c_i, _c_i, _c_i] + [_c_f] * 6),
     "pzn_stem_bwd_workspace_bytes": (_c_sz, [_c_i]),
-    "pzn_stem_bwd_f32": (_c_i, [_c_f] * 14 + [_c_i, _c_i, _c_i] + [_c_f] * 10),
+    "pzn_stem_bwd_f32": (_c_i, [_c_f] * 15 + [_c_i, _c_i, _c_i] + [_c_f] * 10),
     "pzn_bn_points_relu_bwd_f32": (_c_i, [_c_f] * 6 + [_c_i] * 4 + [_c_f] * 4),
     "pzn_sa_prep_f32": (_c_i, [_c_f] * 4 + [_c_i] * 5 + [_c_f] * 3),
     "pzn_sa_level_fwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 5 + [_c_f] * 3),

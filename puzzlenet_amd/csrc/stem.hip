@@ -262,6 +262,7 @@ __global__ __launch_bounds__(ST_T, 4) void stem_fwd_kernel(StemFwdArgs p) {
 struct StemBwdArgs {
   const float* xyz;      // [B, N, 3]
   const float* dout;     // [B, N, 64]
+  const float* dout2;    // a second gradient of the same output (another consumer's) or NULL: added while loading
   const float *W1, *b1, *W2, *b2;
   const float *bn1w, *bn1b, *bn2w, *bn2b;      // [N] or NULL
   const float *mean1, *invstd1, *mean2, *invstd2;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(SB_T, 2) void stem_bwd_kernel(StemBwdArgs p) {
   __shared__ __attribute__((aligned(16))) float w2t[64 * ST_LD];     // W2 transposed: [input channel][output channel]
   __shared__ float xs[64 * 3];                                        // the point's coordinates [sample][3]
   __shared__ float red[2 * SB_W];
-  __shared__ float colsum[5 * ST_C];                                  // end of kernel: db2 | db1 | dW1 x, y, z per channel
+  __shared__ float colsum[5 * 4 * ST_C];                              // end of kernel: db2 | db1 | dW1 x, y, z per lane group and channel
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), q = lane >> 4, col = lane & 15;
   const int B = p.B, N = p.N, nbt = (B + 15) >> 4;
   const int ch = 16 * w + col;      // the channel of this lane in the accumulator layout
@@ -324,6 +325,13 @@ __global__ __launch_bounds__(SB_T, 2) void stem_bwd_kernel(StemBwdArgs p) {
     for (int i = 0; i < 16; ++i) {
       const int b = 16 * (i >> 2) + 4 * q + (i & 3);
       d[i] = ((valid2 >> i) & 1u) ? p.dout[((size_t)b * N + n) * ST_C + ch] : 0.f;
+    }
+    if (p.dout2) {      // (uniform)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int b = 16 * (i >> 2) + 4 * q + (i & 3);
+        if ((valid2 >> i) & 1u) d[i] += p.dout2[((size_t)b * N + n) * ST_C + ch];
+      }
     }
   };
   StemPoint nxt = stem_fetch<SB_W>(p.xyz, B, N, blockIdx.x, w, lane, sp, dflt);
@@ -456,20 +464,21 @@ __global__ __launch_bounds__(SB_T, 2) void stem_bwd_kernel(StemBwdArgs p) {
   for (int m = 0; m < 4; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) part[(16 * m + 4 * q + r) * ST_C + ch] = dw2[m][r];      // every block has one owner
-  for (int f = threadIdx.x; f < 5 * ST_C; f += SB_T) colsum[f] = 0.f;
-  __syncthreads();
-  atomicAdd(colsum + ch, db2);      // (four lanes per channel: the lane groups)
-  atomicAdd(colsum + ST_C + ch, db1);
-  atomicAdd(colsum + 2 * ST_C + ch, dwx);
-  atomicAdd(colsum + 3 * ST_C + ch, dwy);
-  atomicAdd(colsum + 4 * ST_C + ch, dwz);
+  // four lanes per channel (the lane groups): met in LDS and summed in a fixed order (no atomics: the same bits every run)
+  colsum[(0 * 4 + q) * ST_C + ch] = db2;
+  colsum[(1 * 4 + q) * ST_C + ch] = db1;
+  colsum[(2 * 4 + q) * ST_C + ch] = dwx;
+  colsum[(3 * 4 + q) * ST_C + ch] = dwy;
+  colsum[(4 * 4 + q) * ST_C + ch] = dwz;
   __syncthreads();
   for (int f = threadIdx.x; f < 5 * ST_C; f += SB_T) {
     const int k = f / ST_C, l = f % ST_C;
+    const float* c4 = colsum + k * 4 * ST_C + l;
+    const float v = (c4[0] + c4[ST_C]) + (c4[2 * ST_C] + c4[3 * ST_C]);
     if (k < 2)
-      part[ST_C * ST_C + k * ST_C + l] = colsum[f];
+      part[ST_C * ST_C + k * ST_C + l] = v;
     else
-      part[ST_C * ST_C + 2 * ST_C + l * 3 + (k - 2)] = colsum[f];
+      part[ST_C * ST_C + 2 * ST_C + l * 3 + (k - 2)] = v;
   }
 }
 
@@ -525,10 +534,11 @@ PZN_EXPORT int pzn_stem_fwd_f32(const float* xyz, const float* W1, const float* 
 
 PZN_EXPORT size_t pzn_stem_bwd_workspace_bytes(int N) { return (size_t)stem_grid(N, 2) * ST_PART * sizeof(float); }
 
-// Backward of pzn_stem_fwd_f32 from dout[B, N, 64]: dW1[64,3], db1[64], dW2[64,64], db2[64] and the BatchNorm weight / bias
+// Backward of pzn_stem_fwd_f32 from dout[B, N, 64] (+ dout2 when non-NULL: the output had two consumers; their gradients are
+// added while loading instead of by a separate pass over two 33.5 MB tensors): dW1[64,3], db1[64], dW2[64,64], db2[64] and the BatchNorm weight / bias
 // gradients [N] are ADDED to (the BatchNorm ones may be NULL); nothing is returned for xyz.  Activations are recomputed from xyz
 // and the saved statistics.  workspace: pzn_stem_bwd_workspace_bytes(N) bytes, 16-byte aligned (need not be cleared).
-PZN_EXPORT int pzn_stem_bwd_f32(const float* xyz, const float* dout, const float* W1, const float* b1, const float* W2,
+PZN_EXPORT int pzn_stem_bwd_f32(const float* xyz, const float* dout, const float* dout2, const float* W1, const float* b1, const float* W2,
                                 const float* b2, const float* bn1_weight, const float* bn1_bias, const float* bn2_weight,
                                 const float* bn2_bias, const float* mean1, const float* invstd1, const float* mean2,
                                 const float* invstd2, int training, int B, int N, float* dW1, float* db1, float* dW2, float* db2,
@@ -537,7 +547,7 @@ PZN_EXPORT int pzn_stem_bwd_f32(const float* xyz, const float* dout, const float
   PZN_CHECK_ARG(xyz && dout && W1 && b1 && W2 && b2 && mean1 && invstd1 && mean2 && invstd2 && dW1 && db1 && dW2 && db2 && B > 0 &&
                 N > 0 && workspace && !(reinterpret_cast<uintptr_t>(workspace) & 15));
   if (B > 64 || (reinterpret_cast<uintptr_t>(W2) & 15)) return PZN_EUNSUPPORTED;
-  StemBwdArgs a{xyz, dout, W1, b1, W2, b2, bn1_weight, bn1_bias, bn2_weight, bn2_bias, mean1, invstd1, mean2, invstd2, training, B, N,
+  StemBwdArgs a{xyz, dout, dout2, W1, b1, W2, b2, bn1_weight, bn1_bias, bn2_weight, bn2_bias, mean1, invstd1, mean2, invstd2, training, B, N,
                 dW1, db1, dW2, db2, dbn1_weight, dbn1_bias, dbn2_weight, dbn2_bias, static_cast<float*>(workspace)};
   const int grid = stem_grid(N, 2);
   hipLaunchKernelGGL(stem_bwd_kernel, dim3((unsigned)grid), dim3(SB_T), 0, pzn_hip_stream(stream), a);

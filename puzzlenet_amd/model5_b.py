@@ -154,7 +154,14 @@ class PCTransformer_nonsort(nn.Module):
     def local_features(self, xyz):
         """:447-448, the per-point MLP in front of the set abstraction (does not need the sampling plan)."""
         if _STEM_FUSED and ops.stem_supported(xyz, self.mlp1, self.bn1, self.mlp2, self.bn2):
-            return ops.stem(xyz, self.mlp1, self.bn1, self.mlp2, self.bn2)      # both lines in one launch each way (csrc/stem.hip)
+            # both lines in one launch each way (csrc/stem.hip).  The features have two consumers (the first set-abstraction
+            # level here, the boundary branch of the heads through slot 4 of the encoder's tuple): each gets its own name
+            # for them and the stem's backward adds their gradients while it loads them
+            if not _STEM_TWO:
+                return ops.stem(xyz, self.mlp1, self.bn1, self.mlp2, self.bn2)
+            x_feature, second = ops.stem(xyz, self.mlp1, self.bn1, self.mlp2, self.bn2, two=True)
+            x_feature._pzn_second_name = second
+            return x_feature
         # BatchNorm + ReLU as one launch each way (csrc/bnpoints.hip); ops.* raise on CPU tensors: there is no eager path
         x_feature = ops.bn_points_relu(ops.linear(xyz, self.mlp1.weight, self.mlp1.bias), self.bn1)   # :447
         return ops.bn_points_relu(ops.linear(x_feature, self.mlp2.weight, self.mlp2.bias), self.bn2)  # :448
@@ -228,6 +235,7 @@ _EMD_OWN_STREAM = int(os.environ.get("PZN_EMD_OWN_STREAM", "0"))   # tuning aid:
 # each way: 24 launches per step become 6, 7 passes over the 33.5 MB activations become 2; 7.02 against 7.10 ms per step on the
 # same box (its first form, vector FMAs fed by LDS broadcasts, lost: 7.42 against 7.31).  0 = the four launches.
 _STEM_FUSED = os.environ.get("PZN_STEM_FUSED", "1") != "0"
+_STEM_TWO = os.environ.get("PZN_STEM_TWO", "1") != "0"     # tuning aid: 0 = one name for the stem's output, autograd adds its two gradients
 _EMD_SIDE = int(os.environ.get("PZN_EMD_SIDE", "2"))     # tuning aid: 0 = the N x N EMD on the main stream, 1 = forked right after the pose head, 2 = after the heads (measured best)
 
 

@@ -1528,7 +1528,7 @@ class _StemFused(torch.autograd.Function):
     BatchNorm1d(num_points) over the point axis; the backward recomputes every activation from xyz and the saved statistics."""
 
     @staticmethod
-    def forward(ctx, xyz, w1, b1, g1, o1, w2, b2, g2, o2, rm1, rv1, rm2, rv2, use_batch, mom1, eps1, mom2, eps2):
+    def forward(ctx, xyz, w1, b1, g1, o1, w2, b2, g2, o2, rm1, rv1, rm2, rv2, use_batch, mom1, eps1, mom2, eps2, two=False):
         xyz = _f32(xyz, "xyz")
         w1, b1, w2, b2 = _f32(w1, "w1"), _f32(b1, "b1"), _f32(w2, "w2"), _f32(b2, "b2")
         B, N, _ = xyz.shape
@@ -1543,16 +1543,24 @@ class _StemFused(torch.autograd.Function):
         ctx.save_for_backward(xyz, w1, b1, g1, o1, w2, b2, g2, o2, stats)
         ctx.param_refs = (w1, b1, g1, o1, w2, b2, g2, o2)
         ctx.use_batch = bool(use_batch)
+        ctx.set_materialize_grads(False)
+        if two:      # the same features under two names: each consumer's gradient arrives on its own and the kernel adds them
+            return out, out.view_as(out)
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dout2=None):
         xyz, w1, b1, g1, o1, w2, b2, g2, o2, stats = ctx.saved_tensors
         if ctx.needs_input_grad[0]:
             raise _lib.PznError("stem: gradients w.r.t. point coordinates are not provided on the fused stem; "
                                 "use ops.linear + ops.bn_points_relu")
+        if dout is None:
+            dout, dout2 = dout2, None
+        if dout is None:
+            return (None,) * 19
         B, N, _ = xyz.shape
         dout = _f32(dout, "dout")
+        dout2 = None if dout2 is None else _f32(dout2, "dout2")
         dev = dout.device
         params = (w1, b1, g1, o1, w2, b2, g2, o2)
         sinks = [None if t is None else _sink(t, ctx.needs_input_grad[1 + i]) for i, t in enumerate(params)]
@@ -1564,12 +1572,12 @@ class _StemFused(torch.autograd.Function):
         dw1, db1, dg1, do1, dw2, db2, dg2, do2 = grads
         ws = torch.empty((_lib.load().pzn_stem_bwd_workspace_bytes(N) + 3) // 4, dtype=torch.float32, device=dev)
         with _on(dev):
-            _call("pzn_stem_bwd_f32", _p(xyz), _p(dout), _p(w1), _p(b1), _p(w2), _p(b2), _p(g1), _p(o1), _p(g2), _p(o2),
+            _call("pzn_stem_bwd_f32", _p(xyz), _p(dout), _p(dout2), _p(w1), _p(b1), _p(w2), _p(b2), _p(g1), _p(o1), _p(g2), _p(o2),
                   _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), int(ctx.use_batch), B, N, _p(dw1), _p(db1),
                   _p(dw2), _p(db2), _p(dg1), _p(do1), _p(dg2), _p(do2), _p(ws), _stream(), flops=2 * B * N * 64 * (3 + 3 * 64))
         if direct:
-            return (None,) * 18
-        return (None, dw1, db1, dg1, do1, dw2, db2, dg2, do2) + (None,) * 9
+            return (None,) * 19
+        return (None, dw1, db1, dg1, do1, dw2, db2, dg2, do2) + (None,) * 10
 
 
 def stem_supported(xyz, lin1, bn1, lin2, bn2):
@@ -1579,9 +1587,11 @@ def stem_supported(xyz, lin1, bn1, lin2, bn2):
             bn2.momentum is not None and bn1.training == bn2.training and bn1.track_running_stats == bn2.track_running_stats)
 
 
-def stem(xyz, lin1, bn1, lin2, bn2):
+def stem(xyz, lin1, bn1, lin2, bn2, two=False):
     """relu(bn2(lin2(relu(bn1(lin1(xyz)))))) for the encoder's shapes (stem_supported); the modules' running buffers are kept
-    exactly as the modules keep them."""
+    exactly as the modules keep them.  two=True: -> (features, the same features under a second name): hand each of two consumers
+    its own name and their gradients are added inside the backward launch instead of by autograd's pass over two 33.5 MB
+    tensors."""
     use_batch = bn1.training or not bn1.track_running_stats
     track = bn1.track_running_stats
     for bn in (bn1, bn2):
@@ -1590,7 +1600,7 @@ def stem(xyz, lin1, bn1, lin2, bn2):
     return _StemFused.apply(xyz, lin1.weight, lin1.bias, bn1.weight, bn1.bias, lin2.weight, lin2.bias, bn2.weight, bn2.bias,
                             bn1.running_mean if track else None, bn1.running_var if track else None,
                             bn2.running_mean if track else None, bn2.running_var if track else None,
-                            use_batch, bn1.momentum, bn1.eps, bn2.momentum, bn2.eps)
+                            use_batch, bn1.momentum, bn1.eps, bn2.momentum, bn2.eps, bool(two))
 
 
 class _SaMlpMaxPoint(torch.autograd.Function):

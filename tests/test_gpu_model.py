@@ -432,8 +432,12 @@ def test_train_step_private_fps_generator_leaves_the_global_one_alone(golden_los
 
     (la, sa), (lb, sb) = run(21), run(21)
     assert torch.equal(sa, sb)
-    for a, b in zip(la, lb):
-        assert abs(a - b) <= 1e-4 * abs(a), (la, lb)
+    # the same draws -> the same first loss to the rounding of the kernels' atomic sums.  The second step sits behind an Adam
+    # update (which turns rounding noise in near-zero gradients into +-lr) and a max-pool winner of this batch that is ahead by
+    # less than that noise: its loss takes one of two values 1.1e-4 apart from run to run (17236.2 / 17238.1); wrong draws
+    # would move it by percents
+    assert abs(la[0] - lb[0]) <= 1e-5 * abs(la[0]), (la, lb)
+    assert abs(la[1] - lb[1]) <= 1e-3 * abs(la[1]), (la, lb)
     # two steps = two sets of four draws, not three: the generator is where 2 x 4 draws of 64 leave it
     ref = torch.Generator().manual_seed(21)
     for _ in range(2):

@@ -86,6 +86,30 @@ def test_stem_matches_the_unfused_ops():
         assert _rel(m.weight.grad, 2 * f) < 1e-3      # (the running statistics moved; the batch statistics did not)
 
 
+def test_stem_two_names_add_their_gradients_in_the_launch():
+    """ops.stem(two=True) returns the features under two names; gradients arriving through both are added inside the backward
+    launch: the parameter gradients equal those of one name fed the sum, and one unused name is as good as none."""
+    from puzzlenet_amd import ops
+    dev = torch.device("cuda:0")
+    B, N = 7, 130
+    g = torch.Generator().manual_seed(5)
+    xyz = (torch.rand(B, N, 3, generator=g) * 2 - 1).to(dev)
+    ga, gb = (torch.randn(B, N, 64, generator=g).to(dev) for _ in range(2))
+    one = [m.to(dev).train() for m in _modules(N, 2, torch.float32)]
+    two = [m.to(dev).train() for m in _modules(N, 2, torch.float32)]
+    only = [m.to(dev).train() for m in _modules(N, 2, torch.float32)]
+    y = ops.stem(xyz, *one)
+    (y * (ga + gb)).sum().backward()
+    a, b = ops.stem(xyz, *two, two=True)
+    assert a.data_ptr() == b.data_ptr() and torch.equal(a, y)
+    ((a * ga).sum() + (b * gb).sum()).backward()
+    _, b2 = ops.stem(xyz, *only, two=True)
+    (b2 * (ga + gb)).sum().backward()
+    for m1, m2, m3 in zip(one, two, only):
+        assert _rel(m2.weight.grad, m1.weight.grad) < 1e-5 and _rel(m2.bias.grad, m1.bias.grad) < 1e-5
+        assert _rel(m3.weight.grad, m1.weight.grad) < 1e-5 and _rel(m3.bias.grad, m1.bias.grad) < 1e-5
+
+
 def test_stem_refuses_coordinate_gradients():
     from puzzlenet_amd import ops
     dev = torch.device("cuda:0")
