@@ -110,7 +110,27 @@ class LayerAttention(nn.Module):
         return x + F.relu(self.out(r)), attn
 
 
+def _pool(x, dim, pins, key):
+    """torch.max(x, dim)[0], or - with `pins` = {"winners": {key: int64 index tensor}, "flips": {}} - the entries of x AT the
+    given winners (the checked implementation's arg-max) instead: the function downstream, and its gradient, is then the one
+    of exactly those winners, whatever rounding did to a near-tie.  pins["flips"][key] = (entries whose own arg-max differs,
+    the largest gap max - x[winner] among them relative to the largest |max|): the caller bounds both."""
+    best, own = torch.max(x, dim)
+    if pins is None or key not in pins["winners"]:
+        if pins is not None:
+            pins.setdefault("own", {})[key] = own
+        return best
+    w = pins["winners"][key].to(torch.long)
+    got = torch.gather(x, dim, w.unsqueeze(dim)).squeeze(dim)
+    diff = (own != w) & (best != got)         # (equal values: a tie, either index is an arg-max)
+    gap = float(((best - got) * diff).detach().max() / best.detach().abs().max().clamp_min(1e-30)) if bool(diff.any()) else 0.0
+    pins["flips"][key] = (int(diff.sum()), gap, own.numel())
+    return got
+
+
 class Encoder(nn.Module):
+    pins, tag = None, ""      # tests: see _pool
+
     def __init__(self, num_points=1024):
         super().__init__()
         self.mlp1, self.mlp2 = nn.Linear(3, 64), nn.Linear(64, 64)
@@ -124,16 +144,16 @@ class Encoder(nn.Module):
         xf = F.relu(self.bn1(self.mlp1(xyz)))
         xf = F.relu(self.bn2(self.mlp2(xf)))
         x, f1 = sample_and_group(512, 0, 32, xyz, xf, False, True)
-        f1f = torch.max(F.relu(self.mlp4(F.relu(self.mlp3(f1)))), dim=-2)[0]
+        f1f = _pool(F.relu(self.mlp4(F.relu(self.mlp3(f1)))), 2, self.pins, self.tag + "sa1")
         x2, f2 = sample_and_group(256, 0, 32, x, f1f, False, True)
-        f2f = torch.max(F.relu(self.mlp6(F.relu(self.mlp5(f2)))), dim=-2)[0]
+        f2f = _pool(F.relu(self.mlp6(F.relu(self.mlp5(f2)))), 2, self.pins, self.tag + "sa2")
         a1, w1 = self.atten1(f2f)
         a2, w2 = self.atten2(a1)
         a3, w3 = self.atten3(a2)
         a4, w4 = self.atten4(a3)
         attention = (w1 + w2 + w3 + w4) / 4
         out = self.out(torch.cat([a1, a2, a3, a4, f2f], dim=-1))
-        return torch.max(out, dim=1)[0], x2, attention, out, xf
+        return _pool(out, 1, self.pins, self.tag + "gmax"), x2, attention, out, xf
 
 
 class _Dec(nn.Module):
@@ -195,11 +215,20 @@ class RefModel(nn.Module):
         self.C = config
         n = int(getattr(config, "num_points", 1024))
         self.Encoder, self.Encoder2 = Encoder(n), Encoder(n)
+        self.Encoder.tag, self.Encoder2.tag = "Encoder.", "Encoder2."
+        self.pins = None
         self.fpc_decoder, self.rpc_decoder = _Dec(), _Dec()
         self.dt = nn.Parameter(torch.full((1, 6), 1.0e-2))
         self.tfMLP = _seq(2048, 1024, 512, 512, 256, 6)
         self.MLPLocalPreRpc, self.MLPLocalPreFpc = _seq(64, 64, 64, 64), _seq(64, 64, 64, 64)
         self.MLPRpcb, self.MLPFpcb = _seq(128, 64, 32, 2), _seq(128, 64, 32, 2)
+
+    def pin_winners(self, winners):
+        """Tests: force the max-pools to the given winners ({"Encoder.sa1": [B,512,128], "Encoder.sa2", "Encoder.gmax",
+        "Encoder2.*", "heads.gmax"}: index tensors; see _pool).  -> the dict whose "flips" the next forward fills."""
+        self.pins = None if winners is None else {"winners": dict(winners), "flips": {}}
+        self.Encoder.pins = self.Encoder2.pins = self.pins
+        return self.pins
 
     def predict5(self, batch, training=False):
         for m in (self.Encoder, self.Encoder2, self.tfMLP, self.fpc_decoder, self.rpc_decoder):
@@ -211,8 +240,8 @@ class RefModel(nn.Module):
         out = self.tfMLP(torch.cat([ff[0], fm[0]], dim=-1))
         lf = self.MLPLocalPreFpc(ff[4])
         lm = self.MLPLocalPreRpc(fm[4])
-        gf = torch.max(lm, dim=1, keepdim=True)[0].repeat(1, N, 1)       # model5_b.py:741 (the reference's bug)
-        gm = torch.max(lm, dim=1, keepdim=True)[0].repeat(1, N, 1)
+        gf = _pool(lm, 1, self.pins, "heads.gmax").unsqueeze(1).repeat(1, N, 1)       # model5_b.py:741 (the reference's bug)
+        gm = gf.clone()
         de_fpcb = self.MLPFpcb(torch.cat([gm, lf], dim=-1)).permute(0, 2, 1)
         de_mrpcb = self.MLPRpcb(torch.cat([gf, lm], dim=-1)).permute(0, 2, 1)
         return out, [0], ff[1], ff[2], fm[1], fm[2], de_fpcb, de_mrpcb

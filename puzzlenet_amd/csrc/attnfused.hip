@@ -810,7 +810,7 @@ PZN_EXPORT int pzn_attn_fused_prep_weights_n(int n, const float* const* Wq, cons
     PZN_CHECK_ARG(Wq[i] && Wk[i] && Wv[i] && Wo[i] && planes[i] && aligned16(planes[i]));
     pack_jobs(a, 8 * i, Wq[i], Wk[i], Wv[i], Wo[i], static_cast<unsigned char*>(planes[i]));
   }
-  hipLaunchKernelGGL(pack_rp_kernel, dim3(12, a.njobs), dim3(256), 0, pzn_hip_stream(stream), a);
+  PZN_LAUNCH(pack_rp_kernel, dim3(12, a.njobs), dim3(256), 0, pzn_hip_stream(stream), a);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
@@ -835,9 +835,9 @@ PZN_EXPORT int pzn_attn_fused_proj(int nprob, const float* const* x, const void*
                       static_cast<unsigned char*>(vrp[i])};
   }
   if (pzn_attn_precision_mode() == 1)
-    hipLaunchKernelGGL(attn_proj_kernel<1>, dim3(a.nb * nprob), dim3(NT16), 0, pzn_hip_stream(stream), a);
+    PZN_LAUNCH(attn_proj_kernel<1>, dim3(a.nb * nprob), dim3(NT16), 0, pzn_hip_stream(stream), a);
   else
-    hipLaunchKernelGGL(attn_proj_kernel<3>, dim3(a.nb * nprob), dim3(NT16), 0, pzn_hip_stream(stream), a);
+    PZN_LAUNCH(attn_proj_kernel<3>, dim3(a.nb * nprob), dim3(NT16), 0, pzn_hip_stream(stream), a);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
@@ -863,9 +863,9 @@ PZN_EXPORT int pzn_attn_fused_fwd(int nprob, const float* const* x, const void* 
                      static_cast<uint32_t*>(mask[i]), map[i], lse[i]};
   }
   if (pzn_attn_precision_mode() == 1)
-    hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(a.nb * nprob), dim3(NT16), 0, pzn_hip_stream(stream), a);
+    PZN_LAUNCH(attn_fwd_kernel<1>, dim3(a.nb * nprob), dim3(NT16), 0, pzn_hip_stream(stream), a);
   else
-    hipLaunchKernelGGL(attn_fwd_kernel<3>, dim3(a.nb * nprob), dim3(NT16), 0, pzn_hip_stream(stream), a);
+    PZN_LAUNCH(attn_fwd_kernel<3>, dim3(a.nb * nprob), dim3(NT16), 0, pzn_hip_stream(stream), a);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
@@ -891,9 +891,9 @@ PZN_EXPORT int pzn_attn_fused_bwd_q(int nprob, const float* const* dr, int ld_dr
                       dqt[i], static_cast<unsigned char*>(darp[i]), delta[i]};
   }
   if (pzn_attn_precision_mode() == 1)
-    hipLaunchKernelGGL(attn_bwd_q_kernel<1>, dim3(a.nb * nprob), dim3(NT16), 0, pzn_hip_stream(stream), a);
+    PZN_LAUNCH(attn_bwd_q_kernel<1>, dim3(a.nb * nprob), dim3(NT16), 0, pzn_hip_stream(stream), a);
   else
-    hipLaunchKernelGGL(attn_bwd_q_kernel<3>, dim3(a.nb * nprob), dim3(NT16), 0, pzn_hip_stream(stream), a);
+    PZN_LAUNCH(attn_bwd_q_kernel<3>, dim3(a.nb * nprob), dim3(NT16), 0, pzn_hip_stream(stream), a);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
@@ -915,8 +915,8 @@ PZN_EXPORT int pzn_attn_fused_bwd_k(int nprob, const void* const* qrp, const voi
                       static_cast<const unsigned char*>(w[i]), lse[i], delta[i], u[i], dq[i], dk[i], dv[i], dx[i]};
   }
   if (pzn_attn_precision_mode() == 1)
-    hipLaunchKernelGGL(attn_bwd_k_kernel<1>, dim3(a.nb * nprob), dim3(NT16), 0, pzn_hip_stream(stream), a);
+    PZN_LAUNCH(attn_bwd_k_kernel<1>, dim3(a.nb * nprob), dim3(NT16), 0, pzn_hip_stream(stream), a);
   else
-    hipLaunchKernelGGL(attn_bwd_k_kernel<3>, dim3(a.nb * nprob), dim3(NT16), 0, pzn_hip_stream(stream), a);
+    PZN_LAUNCH(attn_bwd_k_kernel<3>, dim3(a.nb * nprob), dim3(NT16), 0, pzn_hip_stream(stream), a);
   PZN_RETURN_LAUNCH_STATUS();
 }

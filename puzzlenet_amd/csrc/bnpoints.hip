@@ -241,10 +241,10 @@ PZN_EXPORT int pzn_bn_points_relu_fwd_f32(const float* x, const float* weight, c
   PZN_CHECK_ARG(x && y && B > 0 && N > 0 && C > 0 && eps >= 0.f);
   PZN_CHECK_ARG(training || (running_mean && running_var));
   if (B <= 4 * BN_R && C <= 64)
-    hipLaunchKernelGGL(bn_point_block_fwd_kernel, dim3((unsigned)N), dim3(BN_T), 0, pzn_hip_stream(stream), x, weight, bias,
+    PZN_LAUNCH(bn_point_block_fwd_kernel, dim3((unsigned)N), dim3(BN_T), 0, pzn_hip_stream(stream), x, weight, bias,
                        running_mean, running_var, training, momentum, eps, B, N, C, y, save_mean, save_invstd);
   else
-    hipLaunchKernelGGL(bn_points_relu_fwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(BN_T), 0, pzn_hip_stream(stream), x,
+    PZN_LAUNCH(bn_points_relu_fwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(BN_T), 0, pzn_hip_stream(stream), x,
                        weight, bias, running_mean, running_var, training, momentum, eps, B, N, C, y, save_mean,
                        save_invstd);
   PZN_RETURN_LAUNCH_STATUS();
@@ -255,10 +255,10 @@ PZN_EXPORT int pzn_bn_points_relu_bwd_f32(const float* x, const float* dy, const
                                           int C, float* dx, float* dweight, float* dbias, pzn_stream_t stream) {
   PZN_CHECK_ARG(x && dy && save_mean && save_invstd && B > 0 && N > 0 && C > 0);
   if (B <= 4 * BN_R && C <= 64)
-    hipLaunchKernelGGL(bn_point_block_bwd_kernel, dim3((unsigned)N), dim3(BN_T), 0, pzn_hip_stream(stream), x, dy, weight,
+    PZN_LAUNCH(bn_point_block_bwd_kernel, dim3((unsigned)N), dim3(BN_T), 0, pzn_hip_stream(stream), x, dy, weight,
                        bias, save_mean, save_invstd, training, B, N, C, dx, dweight, dbias);
   else
-    hipLaunchKernelGGL(bn_points_relu_bwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(BN_T), 0, pzn_hip_stream(stream), x,
+    PZN_LAUNCH(bn_points_relu_bwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(BN_T), 0, pzn_hip_stream(stream), x,
                        dy, weight, bias, save_mean, save_invstd, training, B, N, C, dx, dweight, dbias);
   PZN_RETURN_LAUNCH_STATUS();
 }

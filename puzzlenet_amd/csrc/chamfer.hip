@@ -153,13 +153,13 @@ PZN_EXPORT int pzn_chamfer_fwd_f32(const float* a, const float* b, int B, int n,
   float4* pb = reinterpret_cast<float4*>(static_cast<unsigned char*>(workspace) +
                                          align_up(sizeof(float4) * (size_t)B * n, 256));
   long na = (long)B * n, nb = (long)B * m, mx = na > nb ? na : nb;
-  hipLaunchKernelGGL(chamfer_pack_kernel, dim3((unsigned)((mx + CH_T - 1) / CH_T)), dim3(CH_T), 0, st, a, b, na, nb, pa,
+  PZN_LAUNCH(chamfer_pack_kernel, dim3((unsigned)((mx + CH_T - 1) / CH_T)), dim3(CH_T), 0, st, a, b, na, nb, pa,
                      pb);
   // torch.min(P, 2): per a-point, min over b
-  hipLaunchKernelGGL(chamfer_rowmin_kernel, dim3((n + CH_ROWS - 1) / CH_ROWS, B), dim3(CH_T), 0, st, pa, pb, n, m,
+  PZN_LAUNCH(chamfer_rowmin_kernel, dim3((n + CH_ROWS - 1) / CH_ROWS, B), dim3(CH_T), 0, st, pa, pb, n, m,
                      min_over_b, arg_over_b);
   // torch.min(P, 1): per b-point, min over a
-  hipLaunchKernelGGL(chamfer_rowmin_kernel, dim3((m + CH_ROWS - 1) / CH_ROWS, B), dim3(CH_T), 0, st, pb, pa, m, n,
+  PZN_LAUNCH(chamfer_rowmin_kernel, dim3((m + CH_ROWS - 1) / CH_ROWS, B), dim3(CH_T), 0, st, pb, pa, m, n,
                      min_over_a, arg_over_a);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -170,7 +170,7 @@ PZN_EXPORT int pzn_chamfer_bwd_f32(const float* a, const float* b, int B, int n,
   PZN_CHECK_ARG(a && b && grad_a && grad_b && B > 0 && n > 0 && m > 0 && B <= 65535);
   PZN_CHECK_ARG((!g_over_a || arg_over_a) && (!g_over_b || arg_over_b));
   int mx = n > m ? n : m;
-  hipLaunchKernelGGL(chamfer_bwd_kernel, dim3((mx + CH_T - 1) / CH_T, B), dim3(CH_T), 0, pzn_hip_stream(stream), a, b,
+  PZN_LAUNCH(chamfer_bwd_kernel, dim3((mx + CH_T - 1) / CH_T, B), dim3(CH_T), 0, pzn_hip_stream(stream), a, b,
                      n, m, g_over_a, arg_over_a, g_over_b, arg_over_b, grad_a, grad_b);
   PZN_RETURN_LAUNCH_STATUS();
 }

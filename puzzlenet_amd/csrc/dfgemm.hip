@@ -306,13 +306,13 @@ int launch_ij(DfArgs p, hipStream_t st) {
   }
   const dim3 grid((unsigned)wgs, (unsigned)groups), block(waves * 64);
   if (p.genY && p.db)
-    hipLaunchKernelGGL((df_wgrad_kernel<TI, TJ, true, true>), grid, block, lds, st, p);
+    PZN_LAUNCH((df_wgrad_kernel<TI, TJ, true, true>), grid, block, lds, st, p);
   else if (p.genY)
-    hipLaunchKernelGGL((df_wgrad_kernel<TI, TJ, true, false>), grid, block, lds, st, p);
+    PZN_LAUNCH((df_wgrad_kernel<TI, TJ, true, false>), grid, block, lds, st, p);
   else if (p.db)
-    hipLaunchKernelGGL((df_wgrad_kernel<TI, TJ, false, true>), grid, block, lds, st, p);
+    PZN_LAUNCH((df_wgrad_kernel<TI, TJ, false, true>), grid, block, lds, st, p);
   else
-    hipLaunchKernelGGL((df_wgrad_kernel<TI, TJ, false, false>), grid, block, lds, st, p);
+    PZN_LAUNCH((df_wgrad_kernel<TI, TJ, false, false>), grid, block, lds, st, p);
   PZN_RETURN_LAUNCH_STATUS();
 }
 

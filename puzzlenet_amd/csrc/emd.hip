@@ -997,10 +997,10 @@ int run_fused(const float* xyz1, const float* xyz2, int B, int n, int m, float* 
   if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(emd_sort_x_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PZN_ELAUNCH;
-  hipLaunchKernelGGL(emd_sort_x_kernel, dim3(2, B), dim3(EMD_ST), lds, st, xyz1, xyz2, n, m, npow, mpow, w.perm[0], w.perm[1]);
+  PZN_LAUNCH(emd_sort_x_kernel, dim3(2, B), dim3(EMD_ST), lds, st, xyz1, xyz2, n, m, npow, mpow, w.perm[0], w.perm[1]);
   const int mx = n > m ? n : m;
   const dim3 gi((mx + EF_T - 1) / EF_T, B), gk((n + 63) / 64, B), gk1((n + 63) / 64 + 1, B);   // gk1: + the compaction workgroup
-  hipLaunchKernelGGL(emdf_init_kernel, gi, dim3(EF_T), 0, st, xyz1, xyz2, n, m, multiL, multiR, w);
+  PZN_LAUNCH(emdf_init_kernel, gi, dim3(EF_T), 0, st, xyz1, xyz2, n, m, multiL, multiR, w);
   auto cof = [](int j) {                                         // :47-50, * log2(e): __expf(level d) = exp2(level log2(e) d)
     const float level = j == -2 ? 0.f : -powf(4.0f, (float)j);
     return level * 1.44269504088896340736f;
@@ -1015,24 +1015,24 @@ int run_fused(const float* xyz1, const float* xyz2, int B, int n, int m, float* 
   const int target = 1024 / B > 1 ? 1024 / B : 1;
   const dim3 gb((unsigned)((m + 63) / 64 > target ? (m + 63) / 64 : target), B);
   // A(7); then per level B, and C fused with the next level's A (+ the next list); the last level ends with a plain C
-  hipLaunchKernelGGL((emdf_k_kernel<0, false>), gk, dim3(EF_T), 0, st, n, m, 0.f, cof(7), w, 0, winf(7), 0);
+  PZN_LAUNCH((emdf_k_kernel<0, false>), gk, dim3(EF_T), 0, st, n, m, 0.f, cof(7), w, 0, winf(7), 0);
   for (int j = 7, buf = 0; j >= -2; --j, buf ^= 1) {  // list `buf` = points of cloud 2 with mass at the start of level j
     const int lb = 1 + 2 * (7 - j);
-    hipLaunchKernelGGL(emdf_b_kernel, gb, dim3(EF_T), 0, st, n, m, cof(j), w, buf, winf(j), lb);
+    PZN_LAUNCH(emdf_b_kernel, gb, dim3(EF_T), 0, st, n, m, cof(j), w, buf, winf(j), lb);
     if (j > -2) {
       // the walk covers the list of THIS level: ratioR of pass C is non-zero exactly there, the points pass B has just
       // exhausted carry remainR = 0 into the next level's sum; window of the SOFTER level: outside it both terms are +0
       if (j >= 0)
-        hipLaunchKernelGGL((emdf_k_kernel<1, true>), gk1, dim3(EF_T), 0, st, n, m, cof(j), cof(j - 1), w, buf,
+        PZN_LAUNCH((emdf_k_kernel<1, true>), gk1, dim3(EF_T), 0, st, n, m, cof(j), cof(j - 1), w, buf,
                            winf(j - 1), lb + 1);
       else       // the next scale is 0: its exponential is 1, nothing to square
-        hipLaunchKernelGGL((emdf_k_kernel<1, false>), gk1, dim3(EF_T), 0, st, n, m, cof(j), cof(j - 1), w, buf,
+        PZN_LAUNCH((emdf_k_kernel<1, false>), gk1, dim3(EF_T), 0, st, n, m, cof(j), cof(j - 1), w, buf,
                            winf(j - 1), lb + 1);
     } else {
-      hipLaunchKernelGGL((emdf_k_kernel<2, false>), gk, dim3(EF_T), 0, st, n, m, cof(j), 0.f, w, buf, winf(j), lb + 1);
+      PZN_LAUNCH((emdf_k_kernel<2, false>), gk, dim3(EF_T), 0, st, n, m, cof(j), 0.f, w, buf, winf(j), lb + 1);
     }
   }
-  hipLaunchKernelGGL(emdf_finish_kernel, gi, dim3(EF_T), 0, st, n, m, w, cost, g1, g2);
+  PZN_LAUNCH(emdf_finish_kernel, gi, dim3(EF_T), 0, st, n, m, w, cost, g1, g2);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
@@ -1041,14 +1041,14 @@ int run_match(const float* xyz1, const float* xyz2, int B, int n, int m, float* 
   const float multiL = n >= m ? 1.f : (float)(m / n), multiR = n >= m ? (float)(n / m) : 1.f;  // :29-35 (integer division)
   const int mx = n > m ? n : m;
   dim3 gi((mx + EMD_T - 1) / EMD_T, B), gk((n + EMD_ROWS - 1) / EMD_ROWS, B), gl((m + EMD_ROWS - 1) / EMD_ROWS, B);
-  hipLaunchKernelGGL(emd_init_kernel, gi, dim3(EMD_T), 0, st, xyz1, xyz2, n, m, multiL, multiR, w);
+  PZN_LAUNCH(emd_init_kernel, gi, dim3(EMD_T), 0, st, xyz1, xyz2, n, m, multiL, multiR, w);
   if (pzn_zero_async(match, (size_t)B * n * m, st) != PZN_OK) return PZN_ELAUNCH;  // :39-40
   for (int j = 7; j >= -2; --j) {                                // :46
     const float level = j == -2 ? 0.f : -powf(4.0f, (float)j);   // :47-50
     const float c = level * 1.44269504088896340736f;
-    hipLaunchKernelGGL(emd_pass_a_kernel, gk, dim3(EMD_T), 0, st, n, m, c, w);
-    hipLaunchKernelGGL(emd_pass_b_kernel, gl, dim3(EMD_T), 0, st, n, m, c, w);
-    hipLaunchKernelGGL(emd_pass_c_kernel, gk, dim3(EMD_T), 0, st, n, m, c, w, match);
+    PZN_LAUNCH(emd_pass_a_kernel, gk, dim3(EMD_T), 0, st, n, m, c, w);
+    PZN_LAUNCH(emd_pass_b_kernel, gl, dim3(EMD_T), 0, st, n, m, c, w);
+    PZN_LAUNCH(emd_pass_c_kernel, gk, dim3(EMD_T), 0, st, n, m, c, w, match);
   }
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -1090,7 +1090,7 @@ PZN_EXPORT int pzn_emd_fused_f32(const float* xyz1, const float* xyz2, int B, in
     while (rows < (n > m ? n : m)) rows <<= 1;
     int shift = 0;
     while ((rows << shift) < EMD_SMALL_T && shift < 6) ++shift;  // lanes sharing a row stay inside one wavefront
-    hipLaunchKernelGGL(emd_small_fused_kernel, dim3((unsigned)B), dim3(EMD_SMALL_T), 0, pzn_hip_stream(stream), xyz1, xyz2,
+    PZN_LAUNCH(emd_small_fused_kernel, dim3((unsigned)B), dim3(EMD_SMALL_T), 0, pzn_hip_stream(stream), xyz1, xyz2,
                        n, m, multiL, multiR, shift, cost, g1, g2);
     PZN_RETURN_LAUNCH_STATUS();
   }
@@ -1104,7 +1104,7 @@ PZN_EXPORT int pzn_emd_matchcost_f32(const float* xyz1, const float* xyz2, const
   if (pzn_zero_async(cost, (size_t)B, st) != PZN_OK) return PZN_ELAUNCH;
   dim3 grid((n + EMD_T - 1) / EMD_T, (m + MC_LSLAB - 1) / MC_LSLAB, B);
   PZN_CHECK_ARG(grid.y <= 65535);
-  hipLaunchKernelGGL(emd_matchcost_kernel, grid, dim3(EMD_T), 0, st, xyz1, xyz2, match, n, m, cost);
+  PZN_LAUNCH(emd_matchcost_kernel, grid, dim3(EMD_T), 0, st, xyz1, xyz2, match, n, m, cost);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
@@ -1113,10 +1113,10 @@ PZN_EXPORT int pzn_emd_matchcost_grad_f32(const float* grad_cost, const float* x
                                           pzn_stream_t stream) {
   PZN_CHECK_ARG(grad_cost && xyz1 && xyz2 && match && grad1 && grad2 && B > 0 && n > 0 && m > 0 && B <= 65535);
   hipStream_t st = pzn_hip_stream(stream);
-  hipLaunchKernelGGL(emd_grad1_kernel, dim3((n + EMD_T - 1) / EMD_T, B), dim3(EMD_T), 0, st, grad_cost, xyz1, xyz2,
+  PZN_LAUNCH(emd_grad1_kernel, dim3((n + EMD_T - 1) / EMD_T, B), dim3(EMD_T), 0, st, grad_cost, xyz1, xyz2,
                      match, n, m, grad1);
   constexpr int LPB = EMD_T / PZN_WAVE;
-  hipLaunchKernelGGL(emd_grad2_kernel, dim3((m + LPB - 1) / LPB, B), dim3(EMD_T), 0, st, grad_cost, xyz1, xyz2, match,
+  PZN_LAUNCH(emd_grad2_kernel, dim3((m + LPB - 1) / LPB, B), dim3(EMD_T), 0, st, grad_cost, xyz1, xyz2, match,
                      n, m, grad2);
   PZN_RETURN_LAUNCH_STATUS();
 }

@@ -187,16 +187,16 @@ PZN_EXPORT int pzn_emd_approxmatch_f64(const double* xyz1, const double* xyz2, i
   const double multiL = n >= m ? 1.0 : (double)(m / n), multiR = n >= m ? (double)(n / m) : 1.0;
   if (hipMemsetAsync(match, 0, sizeof(double) * (size_t)B * n * m, st) != hipSuccess) return PZN_ELAUNCH;
   const size_t nl = (size_t)B * n, nr = (size_t)B * m, nmax = nl > nr ? nl : nr;
-  hipLaunchKernelGGL(emd64_fill_kernel, dim3((unsigned)((nmax + T64 - 1) / T64)), dim3(T64), 0, st, w.remainL, nl, multiL,
+  PZN_LAUNCH(emd64_fill_kernel, dim3((unsigned)((nmax + T64 - 1) / T64)), dim3(T64), 0, st, w.remainL, nl, multiL,
                      w.remainR, nr, multiR);
   const dim3 g1((n + T64 - 1) / T64, B), g2((m + T64 - 1) / T64, B);
   for (int j = 7; j >= -2; --j) {
     const double level = j == -2 ? 0.0 : -(double)powf(4.0f, (float)j);        // :47-50
-    hipLaunchKernelGGL(emd64_pass_kernel<0>, g1, dim3(T64), 0, st, xyz1, xyz2, n, m, level, w.remainR, w.remainL, nullptr,
+    PZN_LAUNCH(emd64_pass_kernel<0>, g1, dim3(T64), 0, st, xyz1, xyz2, n, m, level, w.remainR, w.remainL, nullptr,
                        w.ratioL, nullptr);
-    hipLaunchKernelGGL(emd64_pass_kernel<1>, g2, dim3(T64), 0, st, xyz2, xyz1, m, n, level, w.ratioL, w.remainR, nullptr,
+    PZN_LAUNCH(emd64_pass_kernel<1>, g2, dim3(T64), 0, st, xyz2, xyz1, m, n, level, w.ratioL, w.remainR, nullptr,
                        w.ratioR, nullptr);
-    hipLaunchKernelGGL(emd64_pass_kernel<2>, g1, dim3(T64), 0, st, xyz1, xyz2, n, m, level, w.ratioR, w.remainL, w.ratioL,
+    PZN_LAUNCH(emd64_pass_kernel<2>, g1, dim3(T64), 0, st, xyz1, xyz2, n, m, level, w.ratioR, w.remainL, w.ratioL,
                        nullptr, match);
   }
   PZN_RETURN_LAUNCH_STATUS();
@@ -206,7 +206,7 @@ PZN_EXPORT int pzn_emd_matchcost_f64(const double* xyz1, const double* xyz2, con
                                      double* cost, pzn_stream_t stream) {
   PZN_CHECK_ARG(xyz1 && xyz2 && match && cost && B > 0 && n > 0 && m > 0);
   PZN_CHECK_ARG(aligned8(xyz1) && aligned8(xyz2) && aligned8(match) && aligned8(cost));
-  hipLaunchKernelGGL(emd64_cost_kernel, dim3(B), dim3(T64), 0, pzn_hip_stream(stream), xyz1, xyz2, match, n, m, cost);
+  PZN_LAUNCH(emd64_cost_kernel, dim3(B), dim3(T64), 0, pzn_hip_stream(stream), xyz1, xyz2, match, n, m, cost);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
@@ -216,9 +216,9 @@ PZN_EXPORT int pzn_emd_matchcost_grad_f64(const double* grad_cost, const double*
   PZN_CHECK_ARG(grad_cost && xyz1 && xyz2 && match && grad1 && grad2 && B > 0 && n > 0 && m > 0 && B <= 65535);
   PZN_CHECK_ARG(aligned8(grad_cost) && aligned8(xyz1) && aligned8(xyz2) && aligned8(match) && aligned8(grad1) && aligned8(grad2));
   hipStream_t st = pzn_hip_stream(stream);
-  hipLaunchKernelGGL(emd64_grad1_kernel, dim3((n + T64 - 1) / T64, B), dim3(T64), 0, st, grad_cost, xyz1, xyz2, match, n, m,
+  PZN_LAUNCH(emd64_grad1_kernel, dim3((n + T64 - 1) / T64, B), dim3(T64), 0, st, grad_cost, xyz1, xyz2, match, n, m,
                      grad1);
-  hipLaunchKernelGGL(emd64_grad2_kernel, dim3((m + T64 / 64 - 1) / (T64 / 64), B), dim3(T64), 0, st, grad_cost, xyz1, xyz2,
+  PZN_LAUNCH(emd64_grad2_kernel, dim3((m + T64 / 64 - 1) / (T64 / 64), B), dim3(T64), 0, st, grad_cost, xyz1, xyz2,
                      match, n, m, grad2);
   PZN_RETURN_LAUNCH_STATUS();
 }

@@ -161,9 +161,9 @@ int launch(const float* xyz, int B, int N, int npoint, const int64_t* start, int
         hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_kernel<T, PPT, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return PZN_ELAUNCH;
-    hipLaunchKernelGGL((fps_kernel<T, PPT, true>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out);
+    PZN_LAUNCH((fps_kernel<T, PPT, true>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out);
   } else {
-    hipLaunchKernelGGL((fps_kernel<T, PPT, false>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out);
+    PZN_LAUNCH((fps_kernel<T, PPT, false>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out);
   }
   PZN_RETURN_LAUNCH_STATUS();
 }

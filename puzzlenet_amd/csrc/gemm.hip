@@ -644,14 +644,14 @@ void launch_cfg(const GemmArgs& p, int batch, hipStream_t st) {
   const bool x3 = mode != 0;  // auto == bf16x3 on every product (the split-K grid is sized for it, choose_splits)
   if constexpr (EPI == EPI_STORE) {
     if (x3 && p.plain_bf16) {
-      hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI, true, true>), grid, dim3(GT), 0, st, p);
+      PZN_LAUNCH((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI, true, true>), grid, dim3(GT), 0, st, p);
       return;
     }
   }
   if (x3)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI, true>), grid, dim3(GT), 0, st, p);
+    PZN_LAUNCH((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI, true>), grid, dim3(GT), 0, st, p);
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI, false>), grid, dim3(GT), 0, st, p);
+    PZN_LAUNCH((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, EPI, false>), grid, dim3(GT), 0, st, p);
 }
 
 template <bool A_KC, bool B_KC, int EPI>
@@ -740,7 +740,7 @@ PZN_EXPORT int pzn_linear_fwd_f32(const float* x, const float* W, const float* b
     launch<true, true, EPI_ATOMIC>(p, 1, st);
     if (bias || relu) {
       const long total = (long)M * Nout;
-      hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, y, bias, total, Nout,
+      PZN_LAUNCH(bias_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, y, bias, total, Nout,
                          relu);
     }
     PZN_RETURN_LAUNCH_STATUS();
@@ -1031,11 +1031,11 @@ __global__ __launch_bounds__(256) void softmax_bwd_reg_kernel(const float* __res
 void launch_softmax_fwd(float* io, long rows, int cols, float div, hipStream_t st) {
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   if (cols <= 256)
-    hipLaunchKernelGGL(softmax_fwd_reg_kernel<4>, grid, block, 0, st, io, rows, cols, div);
+    PZN_LAUNCH(softmax_fwd_reg_kernel<4>, grid, block, 0, st, io, rows, cols, div);
   else if (cols <= 512)
-    hipLaunchKernelGGL(softmax_fwd_reg_kernel<8>, grid, block, 0, st, io, rows, cols, div);
+    PZN_LAUNCH(softmax_fwd_reg_kernel<8>, grid, block, 0, st, io, rows, cols, div);
   else
-    hipLaunchKernelGGL(softmax_fwd_kernel, grid, block, 0, st, io, rows, cols, div);
+    PZN_LAUNCH(softmax_fwd_kernel, grid, block, 0, st, io, rows, cols, div);
 }
 
 // bwd: io[r,:] (= dAttn, optionally + extra) -> dLogits = attn * (dAttn - sum(dAttn * attn)) / div
@@ -1062,11 +1062,11 @@ void launch_softmax_bwd(const float* attn, float* io, const float* extra, long r
                         hipStream_t st) {
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   if (cols <= 256)
-    hipLaunchKernelGGL(softmax_bwd_reg_kernel<4>, grid, block, 0, st, attn, io, extra, rows, cols, div);
+    PZN_LAUNCH(softmax_bwd_reg_kernel<4>, grid, block, 0, st, attn, io, extra, rows, cols, div);
   else if (cols <= 512)
-    hipLaunchKernelGGL(softmax_bwd_reg_kernel<8>, grid, block, 0, st, attn, io, extra, rows, cols, div);
+    PZN_LAUNCH(softmax_bwd_reg_kernel<8>, grid, block, 0, st, attn, io, extra, rows, cols, div);
   else
-    hipLaunchKernelGGL(softmax_bwd_kernel, grid, block, 0, st, attn, io, extra, rows, cols, div);
+    PZN_LAUNCH(softmax_bwd_kernel, grid, block, 0, st, attn, io, extra, rows, cols, div);
 }
 
 }  // namespace

@@ -201,11 +201,11 @@ PZN_EXPORT int pzn_group_fwd_f32(const float* xyz, const float* feat, const floa
     long blocks = (total_q + GRP_WAVES - 1) / GRP_WAVES;
     long cap = 256L * 8;
     int grid = (int)(blocks < cap ? blocks : cap);
-    hipLaunchKernelGGL(group_fwd_vec_kernel<0>, dim3(grid), dim3(GRP_WAVES * PZN_WAVE), lds, st, xyz, feat, new_xyz, idx,
+    PZN_LAUNCH(group_fwd_vec_kernel<0>, dim3(grid), dim3(GRP_WAVES * PZN_WAVE), lds, st, xyz, feat, new_xyz, idx,
                        N, S, K, D, total_q, out, grouped_xyz);
   } else {
     long total = total_q * K * W;
-    hipLaunchKernelGGL(group_fwd_any_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, st, xyz, feat, new_xyz, idx, N,
+    PZN_LAUNCH(group_fwd_any_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, st, xyz, feat, new_xyz, idx, N,
                        S, K, D, total, out, grouped_xyz);
   }
   PZN_RETURN_LAUNCH_STATUS();
@@ -221,7 +221,7 @@ PZN_EXPORT int pzn_group_bwd_f32(const float* grad_out, const int64_t* idx, int 
   long blocks = (total_q + GRP_WAVES - 1) / GRP_WAVES;
   long cap = 256L * 8;
   int grid = (int)(blocks < cap ? blocks : cap);
-  hipLaunchKernelGGL(group_bwd_kernel, dim3(grid), dim3(GRP_WAVES * PZN_WAVE), 0, st, grad_out, idx, N, S, K, D,
+  PZN_LAUNCH(group_bwd_kernel, dim3(grid), dim3(GRP_WAVES * PZN_WAVE), 0, st, grad_out, idx, N, S, K, D,
                      total_q, grad_xyz, grad_feat, grad_new_xyz);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -230,7 +230,7 @@ PZN_EXPORT int pzn_gather_fwd_f32(const float* points, const int64_t* idx, int B
                                   pzn_stream_t stream) {
   PZN_CHECK_ARG(points && idx && out && B > 0 && N > 0 && M > 0 && C > 0);
   long total = (long)B * M * C;
-  hipLaunchKernelGGL(gather_fwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, pzn_hip_stream(stream), points, idx,
+  PZN_LAUNCH(gather_fwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, pzn_hip_stream(stream), points, idx,
                      N, M, C, total, out);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -239,7 +239,7 @@ PZN_EXPORT int pzn_gather_bwd_f32(const float* grad_out, const int64_t* idx, int
                                   float* grad_points, pzn_stream_t stream) {
   PZN_CHECK_ARG(grad_out && idx && grad_points && B > 0 && N > 0 && M > 0 && C > 0);
   long total = (long)B * M * C;
-  hipLaunchKernelGGL(gather_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, pzn_hip_stream(stream), grad_out,
+  PZN_LAUNCH(gather_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, pzn_hip_stream(stream), grad_out,
                      idx, N, M, C, total, grad_points);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -248,7 +248,7 @@ PZN_EXPORT int pzn_square_distance_f32(const float* src, const float* dst, int B
                                        pzn_stream_t stream) {
   PZN_CHECK_ARG(src && dst && out && B > 0 && S > 0 && N > 0);
   long total = (long)B * S * N;
-  hipLaunchKernelGGL(sqdist_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, pzn_hip_stream(stream), src, dst, S, N,
+  PZN_LAUNCH(sqdist_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, pzn_hip_stream(stream), src, dst, S, N,
                      total, out);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -303,7 +303,7 @@ PZN_EXPORT int pzn_group_pad_fwd_f32(const float* xyz, const float* feat, const 
   long cap = 256L * 16;
   int grid = (int)(blocks < cap ? blocks : cap);
   if (grid >= 64) grid &= ~7;  // multiple of 8 for the XCD remap (the grid-stride loop covers the remainder)
-  hipLaunchKernelGGL(group_pad_direct_kernel, dim3(grid), dim3(256), 0, pzn_hip_stream(stream), xyz, feat, new_xyz, idx,
+  PZN_LAUNCH(group_pad_direct_kernel, dim3(grid), dim3(256), 0, pzn_hip_stream(stream), xyz, feat, new_xyz, idx,
                      N, S, K, D, total_q, out);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -338,7 +338,7 @@ PZN_EXPORT int pzn_group_feat_bwd_f32(const float* rows, const int64_t* idx, int
   long blocks = (total_q + GRP_WAVES - 1) / GRP_WAVES;
   long cap = 256L * 8;
   int grid = (int)(blocks < cap ? blocks : cap);
-  hipLaunchKernelGGL(group_feat_bwd_kernel, dim3(grid), dim3(GRP_WAVES * PZN_WAVE), 0, pzn_hip_stream(stream), rows, idx,
+  PZN_LAUNCH(group_feat_bwd_kernel, dim3(grid), dim3(GRP_WAVES * PZN_WAVE), 0, pzn_hip_stream(stream), rows, idx,
                      N, S, K, D, total_q, grad_feat);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -451,11 +451,11 @@ PZN_EXPORT int pzn_maxpool_points_fwd_f32(const float* x, int B, int L, int C, f
                                           pzn_stream_t stream) {
   PZN_CHECK_ARG(x && out && idx && B > 0 && B <= 65535 && L > 0 && C > 0);
   if ((C & 3) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) {
-    hipLaunchKernelGGL(maxpts_fwd_scalar_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0,
+    PZN_LAUNCH(maxpts_fwd_scalar_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0,
                        pzn_hip_stream(stream), x, L, C, out, idx);
     PZN_RETURN_LAUNCH_STATUS();
   }
-  hipLaunchKernelGGL(maxpts_fwd_kernel, dim3((unsigned)((C + 127) / 128), (unsigned)B), dim3(MAXPTS_T), 0,
+  PZN_LAUNCH(maxpts_fwd_kernel, dim3((unsigned)((C + 127) / 128), (unsigned)B), dim3(MAXPTS_T), 0,
                      pzn_hip_stream(stream), x, L, C, out, idx);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -465,14 +465,14 @@ PZN_EXPORT int pzn_maxpool_points_bwd_f32(const float* dout, const int32_t* idx,
   PZN_CHECK_ARG(dout && idx && dx && B > 0 && B <= 65535 && L > 0 && C > 0);
   if ((C & 3) != 0 ||
       ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(dx)) & 15) != 0) {
-    hipLaunchKernelGGL(maxpts_bwd_scalar_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0,
+    PZN_LAUNCH(maxpts_bwd_scalar_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0,
                        pzn_hip_stream(stream), dout, idx, L, C, dx);
     PZN_RETURN_LAUNCH_STATUS();
   }
   const size_t per_batch = (size_t)L * (C >> 2);
   size_t gx = (per_batch + 255) / 256;
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(maxpts_bwd_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, pzn_hip_stream(stream), dout, idx, L,
+  PZN_LAUNCH(maxpts_bwd_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, pzn_hip_stream(stream), dout, idx, L,
                      C, dx);
   PZN_RETURN_LAUNCH_STATUS();
 }

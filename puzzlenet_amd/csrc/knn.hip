@@ -836,7 +836,7 @@ int launch_select(const float* xyz, const float* feat, const float* new_xyz, int
 #define PZN_SEL_K(RR, DTT, KPP, NTT)                                                                                      \
   do {                                                                                                                \
     if (set_lds(&knn_select_kernel<RR, SEL_WAVES, GROUP, DTT, KPP, NTT>, lds) != PZN_OK) return PZN_ELAUNCH;               \
-    hipLaunchKernelGGL((knn_select_kernel<RR, SEL_WAVES, GROUP, DTT, KPP, NTT>), dim3((unsigned)nb),                       \
+    PZN_LAUNCH((knn_select_kernel<RR, SEL_WAVES, GROUP, DTT, KPP, NTT>), dim3((unsigned)nb),                       \
                        dim3(SEL_WAVES * PZN_WAVE), lds, st, xyz, feat, new_xyz, N, S, K, D, dshift, kp, qpb, bpc, idx, \
                        out, grouped_xyz);                                                                             \
   } while (0)
@@ -881,10 +881,10 @@ PZN_EXPORT int pzn_knn_f32(const float* xyz, const float* new_xyz, int B, int N,
     {
       if (g.use_lds) {
         if (set_lds(&knn32_kernel<true>, g.lds) != PZN_OK) return PZN_ELAUNCH;
-        hipLaunchKernelGGL(knn32_kernel<true>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
+        PZN_LAUNCH(knn32_kernel<true>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
                            g.q_per_block, idx);
       } else {
-        hipLaunchKernelGGL(knn32_kernel<false>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
+        PZN_LAUNCH(knn32_kernel<false>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
                            g.q_per_block, idx);
       }
     }
@@ -892,10 +892,10 @@ PZN_EXPORT int pzn_knn_f32(const float* xyz, const float* new_xyz, int B, int N,
     Geometry g = geometry(B, N, S, 0);
     if (g.use_lds) {
       if (set_lds(&knn_any_kernel<true>, g.lds) != PZN_OK) return PZN_ELAUNCH;
-      hipLaunchKernelGGL(knn_any_kernel<true>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
+      PZN_LAUNCH(knn_any_kernel<true>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
                          g.q_per_block, idx);
     } else {
-      hipLaunchKernelGGL(knn_any_kernel<false>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
+      PZN_LAUNCH(knn_any_kernel<false>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, K,
                          g.q_per_block, idx);
     }
   }
@@ -921,10 +921,10 @@ PZN_EXPORT int pzn_ball_query_f32(float radius2, int nsample, const float* xyz, 
   Geometry g = geometry(B, N, S, 0);
   if (g.use_lds) {      // (compile-time variants: a run-time choice of address space turns every point fetch into a flat load)
     if (set_lds(&ball_kernel<true>, g.lds) != PZN_OK) return PZN_ELAUNCH;
-    hipLaunchKernelGGL(ball_kernel<true>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, nsample,
+    PZN_LAUNCH(ball_kernel<true>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, nsample,
                        radius2, g.q_per_block, idx);
   } else {
-    hipLaunchKernelGGL(ball_kernel<false>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, nsample,
+    PZN_LAUNCH(ball_kernel<false>, g.grid, dim3(KNN_WAVES * PZN_WAVE), g.lds, st, xyz, new_xyz, N, S, nsample,
                        radius2, g.q_per_block, idx);
   }
   PZN_RETURN_LAUNCH_STATUS();
@@ -948,7 +948,7 @@ PZN_EXPORT int pzn_knn_group_pad_f32(const float* xyz, const float* feat, const 
 #define PZN_KG(RR)                                                                                              \
   do {                                                                                                          \
     if (set_lds(&knn_group_pad_kernel<RR, KGW>, g.lds) != PZN_OK) return PZN_ELAUNCH;                           \
-    hipLaunchKernelGGL((knn_group_pad_kernel<RR, KGW>), dim3(nb), dim3(KGW * PZN_WAVE), g.lds, st, xyz, feat,   \
+    PZN_LAUNCH((knn_group_pad_kernel<RR, KGW>), dim3(nb), dim3(KGW * PZN_WAVE), g.lds, st, xyz, feat,   \
                        new_xyz, N, S, D, g.q_per_block, bpc, idx, out);                                         \
   } while (0)
   if (rows <= 8)

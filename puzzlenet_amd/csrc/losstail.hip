@@ -384,7 +384,7 @@ inline int grid_for(long total, int block, int cap = 2048) {
 
 PZN_EXPORT int pzn_se3_transform_fwd_f32(const float* g, const float* p, int B, int N, float* out, pzn_stream_t stream) {
   PZN_CHECK_ARG(g && p && out && B > 0 && B <= 65535 && N > 0);
-  hipLaunchKernelGGL(se3_transform_fwd_kernel, dim3((unsigned)grid_for(N, 256, 64), (unsigned)B), dim3(256), 0,
+  PZN_LAUNCH(se3_transform_fwd_kernel, dim3((unsigned)grid_for(N, 256, 64), (unsigned)B), dim3(256), 0,
                      pzn_hip_stream(stream), g, p, N, out);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -392,21 +392,21 @@ PZN_EXPORT int pzn_se3_transform_fwd_f32(const float* g, const float* p, int B, 
 PZN_EXPORT int pzn_se3_transform_bwd_f32(const float* g, const float* p, const float* dout, int B, int N, float* dp,
                                          float* dg, pzn_stream_t stream) {
   PZN_CHECK_ARG(g && p && dout && (dp || dg) && B > 0 && N > 0);
-  hipLaunchKernelGGL(se3_transform_bwd_kernel, dim3((unsigned)B), dim3(256), 0, pzn_hip_stream(stream), g, p, dout, N, dp,
+  PZN_LAUNCH(se3_transform_bwd_kernel, dim3((unsigned)B), dim3(256), 0, pzn_hip_stream(stream), g, p, dout, N, dp,
                      dg);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
 PZN_EXPORT int pzn_comp_fwd_f32(const float* g, const float* igt, int B, float* loss, pzn_stream_t stream) {
   PZN_CHECK_ARG(g && igt && loss && B > 0);
-  hipLaunchKernelGGL(comp_fwd_kernel, dim3(1), dim3(256), 0, pzn_hip_stream(stream), g, igt, B, loss);
+  PZN_LAUNCH(comp_fwd_kernel, dim3(1), dim3(256), 0, pzn_hip_stream(stream), g, igt, B, loss);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
 PZN_EXPORT int pzn_comp_bwd_f32(const float* g, const float* igt, const float* dloss, int B, float* dg,
                                 pzn_stream_t stream) {
   PZN_CHECK_ARG(g && igt && dloss && dg && B > 0);
-  hipLaunchKernelGGL(comp_bwd_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, pzn_hip_stream(stream), g, igt, dloss,
+  PZN_LAUNCH(comp_bwd_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, pzn_hip_stream(stream), g, igt, dloss,
                      B, dg);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -418,9 +418,9 @@ PZN_EXPORT int pzn_boundary_ce_fwd_f32(const float* logits, const float* labels,
   hipStream_t st = pzn_hip_stream(stream);
   const long total = (long)B * N;
   const int nparts = (int)grid_for(total, 256, 512);
-  hipLaunchKernelGGL(boundary_ce_fwd_kernel, dim3((unsigned)nparts), dim3(256), 0, st, logits, labels, N, total, sc, sn, prob1, loss);
+  PZN_LAUNCH(boundary_ce_fwd_kernel, dim3((unsigned)nparts), dim3(256), 0, st, logits, labels, N, total, sc, sn, prob1, loss);
   if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
-  hipLaunchKernelGGL(boundary_ce_reduce_kernel, dim3(1), dim3(64), 0, st, loss, nparts, 1.f / (float)total);
+  PZN_LAUNCH(boundary_ce_reduce_kernel, dim3(1), dim3(64), 0, st, loss, nparts, 1.f / (float)total);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
@@ -429,7 +429,7 @@ PZN_EXPORT int pzn_boundary_ce_bwd_f32(const float* logits, const float* labels,
   PZN_CHECK_ARG(logits && labels && dloss && dlogits && B > 0 && N > 0);
   const int sc = points_major ? 1 : N, sn = points_major ? 2 : 1;
   const long total = (long)B * N;
-  hipLaunchKernelGGL(boundary_ce_bwd_kernel, dim3((unsigned)grid_for(total, 256, 512)), dim3(256), 0, pzn_hip_stream(stream),
+  PZN_LAUNCH(boundary_ce_bwd_kernel, dim3((unsigned)grid_for(total, 256, 512)), dim3(256), 0, pzn_hip_stream(stream),
                      logits, labels, dloss, N, total, sc, sn, dlogits);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -437,7 +437,7 @@ PZN_EXPORT int pzn_boundary_ce_bwd_f32(const float* logits, const float* labels,
 PZN_EXPORT int pzn_topk_rows_f32(const float* x, int R, int N, int K, int64_t* idx, pzn_stream_t stream) {
   PZN_CHECK_ARG(x && idx && R > 0 && N > 0 && K > 0 && K <= N);
   if (K > TK_T || N > 16384) return PZN_EUNSUPPORTED;
-  hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)R), dim3(TK_T), (size_t)N * sizeof(uint32_t), pzn_hip_stream(stream), x,
+  PZN_LAUNCH(topk_rows_kernel, dim3((unsigned)R), dim3(TK_T), (size_t)N * sizeof(uint32_t), pzn_hip_stream(stream), x,
                      N, K, idx);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -448,7 +448,7 @@ PZN_EXPORT int pzn_avg4_f32(const float* a, const float* b, const float* c, cons
   if ((n & 3) || ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
                    reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(out)) & 15))
     return PZN_EUNSUPPORTED;
-  hipLaunchKernelGGL(avg4_kernel, dim3((unsigned)grid_for((long)(n >> 2), 256, 4096)), dim3(256), 0, pzn_hip_stream(stream),
+  PZN_LAUNCH(avg4_kernel, dim3((unsigned)grid_for((long)(n >> 2), 256, 4096)), dim3(256), 0, pzn_hip_stream(stream),
                      reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b), reinterpret_cast<const float4*>(c),
                      reinterpret_cast<const float4*>(d), (long)(n >> 2), reinterpret_cast<float4*>(out));
   PZN_RETURN_LAUNCH_STATUS();
@@ -458,7 +458,7 @@ PZN_EXPORT int pzn_cloud_bias_relu_f32(float* y, const float* cb, int B, int N, 
   PZN_CHECK_ARG(y && cb && B > 0 && N > 0 && C > 0);
   if ((C & 3) || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(cb)) & 15)) return PZN_EUNSUPPORTED;
   const long n4 = (long)B * N * (C / 4);
-  hipLaunchKernelGGL(cloud_bias_relu_kernel, dim3((unsigned)grid_for(n4, 256, 4096)), dim3(256), 0, pzn_hip_stream(stream),
+  PZN_LAUNCH(cloud_bias_relu_kernel, dim3((unsigned)grid_for(n4, 256, 4096)), dim3(256), 0, pzn_hip_stream(stream),
                      reinterpret_cast<float4*>(y), reinterpret_cast<const float4*>(cb), n4, C / 4, (long)N * (C / 4));
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -470,7 +470,7 @@ PZN_EXPORT int pzn_cloud_gated_colsum_f32(const float* dy, const float* y, int B
       ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dcb)) & 15))
     return PZN_EUNSUPPORTED;
   hipStream_t st = pzn_hip_stream(stream);
-  hipLaunchKernelGGL(cloud_gated_colsum_kernel, dim3((unsigned)B), dim3(1024), 0, st,
+  PZN_LAUNCH(cloud_gated_colsum_kernel, dim3((unsigned)B), dim3(1024), 0, st,
                      reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(y), N, C / 4, dcb);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -486,7 +486,7 @@ PZN_EXPORT int pzn_colmean_argmax_f32(const float* a, int B, int R, int C, float
   const int threads = ((C + 63) / 64) * 64;
   hipStream_t st = pzn_hip_stream(stream);
   float* part = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)B, CM_CHUNKS), dim3((unsigned)threads), 0, st, a, R, C, part);
-  hipLaunchKernelGGL(colmean_argmax_kernel, dim3((unsigned)B), dim3((unsigned)threads), 0, st, part, R, C, mean, arg);
+  PZN_LAUNCH(colsum_partial_kernel, dim3((unsigned)B, CM_CHUNKS), dim3((unsigned)threads), 0, st, a, R, C, part);
+  PZN_LAUNCH(colmean_argmax_kernel, dim3((unsigned)B), dim3((unsigned)threads), 0, st, part, R, C, mean, arg);
   PZN_RETURN_LAUNCH_STATUS();
 }

@@ -217,10 +217,10 @@ PZN_EXPORT int pzn_linear_maxpts_dgrad_f32(const float* dg, const int32_t* arg, 
     attr_set = true;
   }
   uint32_t* sorted = static_cast<uint32_t*>(workspace);
-  hipLaunchKernelGGL(maxpts_sort_kernel, dim3((unsigned)B), dim3(1024), (size_t)npad * sizeof(uint32_t), pzn_hip_stream(stream),
+  PZN_LAUNCH(maxpts_sort_kernel, dim3((unsigned)B), dim3(1024), (size_t)npad * sizeof(uint32_t), pzn_hip_stream(stream),
                      arg, L, Nout, npad, sorted);
   if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
-  hipLaunchKernelGGL(maxpts_lin_dgrad_kernel, dim3((unsigned)B, (unsigned)(Kin / MD_COLS)), dim3(MD_THREADS), lds,
+  PZN_LAUNCH(maxpts_lin_dgrad_kernel, dim3((unsigned)B, (unsigned)(Kin / MD_COLS)), dim3(MD_THREADS), lds,
                      pzn_hip_stream(stream), dg, sorted, W, L, Kin, Nout, dx);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -241,7 +241,7 @@ PZN_EXPORT int pzn_linear_maxpts_wgrad_f32(const float* dg, const int32_t* arg, 
   const int cblocks = (seg_cols + 255) / 256;
   const long long gy = (long long)nseg * cblocks;
   PZN_CHECK_ARG(gy <= 65535);
-  hipLaunchKernelGGL(maxpts_lin_wgrad_kernel, dim3((unsigned)Nout, (unsigned)gy), dim3(256), 0, pzn_hip_stream(stream), dg,
+  PZN_LAUNCH(maxpts_lin_wgrad_kernel, dim3((unsigned)Nout, (unsigned)gy), dim3(256), 0, pzn_hip_stream(stream), dg,
                      arg, xs, seg_cols, cblocks, B, L, Nout, nseg * seg_cols, dW, db);
   PZN_RETURN_LAUNCH_STATUS();
 }

@@ -56,7 +56,7 @@ PZN_EXPORT int pzn_adam_step_f32(float* param, const float* grad, float* exp_avg
   size_t blocks = ((n >> 2) + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, pzn_hip_stream(stream), param, grad, exp_avg,
+  PZN_LAUNCH(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, pzn_hip_stream(stream), param, grad, exp_avg,
                      exp_avg_sq, n, step_size, inv_bc2_sqrt, beta1, beta2, eps);
   PZN_RETURN_LAUNCH_STATUS();
 }

@@ -247,12 +247,12 @@ int pzn_outproj_maxpts(const float* const* x, const float* W, const float* bias,
   for (int i = 0; i < OP_SLICES; ++i) al |= reinterpret_cast<uintptr_t>(x[i]);
   if ((al & 15) != 0) return PZN_EUNSUPPORTED;
   unsigned char* w = static_cast<unsigned char*>(workspace);
-  hipLaunchKernelGGL(op_pack_w_kernel, dim3(512), dim3(256), 0, st, W, w);
+  PZN_LAUNCH(op_pack_w_kernel, dim3(512), dim3(256), 0, st, W, w);
   if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
   OpArgs a;
   for (int i = 0; i < OP_SLICES; ++i) a.x[i] = x[i];
   a.w = w, a.bias = bias, a.out = out, a.fmax = fmax, a.arg = arg, a.B = B;
-  hipLaunchKernelGGL(outproj_maxpts_kernel, dim3(OP_GROUPS * B), dim3(OP_WAVES * 64), 0, st, a);
+  PZN_LAUNCH(outproj_maxpts_kernel, dim3(OP_GROUPS * B), dim3(OP_WAVES * 64), 0, st, a);
   PZN_RETURN_LAUNCH_STATUS();
 }
 

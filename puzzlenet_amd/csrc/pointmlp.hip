@@ -663,11 +663,11 @@ PZN_EXPORT int pzn_point_mlp3_fwd_f32(const float* x, long long M, int rows_per_
   if (C2 == 64) {
     constexpr int lds = pm_fwd_lds<64, 64>();
     if (pm_set_lds(point_mlp3_fwd_kernel<64, 64>, lds) != PZN_OK) return PZN_ELAUNCH;
-    hipLaunchKernelGGL((point_mlp3_fwd_kernel<64, 64>), grid, block, lds, st, a);
+    PZN_LAUNCH((point_mlp3_fwd_kernel<64, 64>), grid, block, lds, st, a);
   } else {
     constexpr int lds = pm_fwd_lds<32, 2>();
     if (pm_set_lds(point_mlp3_fwd_kernel<32, 2>, lds) != PZN_OK) return PZN_ELAUNCH;
-    hipLaunchKernelGGL((point_mlp3_fwd_kernel<32, 2>), grid, block, lds, st, a);
+    PZN_LAUNCH((point_mlp3_fwd_kernel<32, 2>), grid, block, lds, st, a);
   }
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -698,10 +698,10 @@ template <int C2, int C3>
 int pm_launch_bwd(const PmBwdArgs& a, const PmRedArgs& ra, int nwg, hipStream_t st) {
   using S = PmShape<C2, C3>;
   if (pm_set_lds(point_mlp3_bwd_kernel<C2, C3>, S::LDS) != PZN_OK) return PZN_ELAUNCH;
-  hipLaunchKernelGGL((point_mlp3_bwd_kernel<C2, C3>), dim3(nwg), dim3(256), S::LDS, st, a);
+  PZN_LAUNCH((point_mlp3_bwd_kernel<C2, C3>), dim3(nwg), dim3(256), S::LDS, st, a);
   if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
   const int ngroups = S::NACC * 16 + (ra.waves_per_cloud ? ra.nclouds : 1) + 2;     // of 64 outputs: dW | db1 | db2 | db3
-  hipLaunchKernelGGL((point_mlp3_reduce_kernel<C2, C3>), dim3(ngroups), dim3(1024), 0, st, ra);
+  PZN_LAUNCH((point_mlp3_reduce_kernel<C2, C3>), dim3(ngroups), dim3(1024), 0, st, ra);
   PZN_RETURN_LAUNCH_STATUS();
 }
 

@@ -432,21 +432,21 @@ int launch_wgrad(const PoolBwdArgs& p, hipStream_t st) {
   if (w16 && p.C2 % 16 == 0 && p.C2 / 16 >= 4) {      // 16 wavefronts, C2 / 16 channels each
     const int cpw = p.C2 / 16;
     if (cpw == 4)
-      hipLaunchKernelGGL((pool_wgrad_kernel<4, 16>), grid, dim3(1024), 0, st, p);
+      PZN_LAUNCH((pool_wgrad_kernel<4, 16>), grid, dim3(1024), 0, st, p);
     else if (cpw == 8)
-      hipLaunchKernelGGL((pool_wgrad_kernel<8, 16>), grid, dim3(1024), 0, st, p);
+      PZN_LAUNCH((pool_wgrad_kernel<8, 16>), grid, dim3(1024), 0, st, p);
     else
-      hipLaunchKernelGGL((pool_wgrad_kernel<16, 16>), grid, dim3(1024), 0, st, p);
+      PZN_LAUNCH((pool_wgrad_kernel<16, 16>), grid, dim3(1024), 0, st, p);
     PZN_RETURN_LAUNCH_STATUS();
   }
   const dim3 block(PB_T);
   const int cpw = p.C2 / PB_W;
   if (cpw == 8)
-    hipLaunchKernelGGL((pool_wgrad_kernel<8, 8>), grid, block, 0, st, p);
+    PZN_LAUNCH((pool_wgrad_kernel<8, 8>), grid, block, 0, st, p);
   else if (cpw == 16)
-    hipLaunchKernelGGL((pool_wgrad_kernel<16, 8>), grid, block, 0, st, p);
+    PZN_LAUNCH((pool_wgrad_kernel<16, 8>), grid, block, 0, st, p);
   else
-    hipLaunchKernelGGL((pool_wgrad_kernel<32, 8>), grid, block, 0, st, p);
+    PZN_LAUNCH((pool_wgrad_kernel<32, 8>), grid, block, 0, st, p);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
@@ -462,7 +462,7 @@ int launch_dgrad_nq(const PoolBwdArgs& p, hipStream_t st) {
   int gx = 256 * per_cu / ny;
   if (gx < 1) gx = 1;
   if (gx > p.G) gx = p.G;
-  hipLaunchKernelGGL((pool_dgrad_kernel<NQ>), dim3((unsigned)gx, (unsigned)ny), dim3(PD_T), lds, st, p);
+  PZN_LAUNCH((pool_dgrad_kernel<NQ>), dim3((unsigned)gx, (unsigned)ny), dim3(PD_T), lds, st, p);
   PZN_RETURN_LAUNCH_STATUS();
 }
 

@@ -22,6 +22,29 @@
 
 static inline hipStream_t pzn_hip_stream(pzn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Per-KERNEL timing (measurement only, core.hip; pzn_ktimer_* in include/pzn.h): every launch of the library goes through
+// PZN_LAUNCH, which - when pzn_ktimer_enable(1) was called - brackets it with a HIP event pair on the launch's own stream
+// under the kernel's name (hipKernelNameRefByPtr: the name a rocprofv3 kernel trace shows, template arguments included).
+// Off (the default) it costs one relaxed load per launch.
+extern "C" int pzn_ktimer_is_on;
+namespace pzn {
+struct KSpan {
+  void* rec = nullptr;
+  hipStream_t st;
+  KSpan(const void* fn, const char* text, hipStream_t s);
+  ~KSpan();
+};
+}  // namespace pzn
+#define PZN_LAUNCH(kernel, grid, block, shmem, stream, ...)                                    \
+  do {                                                                                         \
+    if (__builtin_expect(pzn_ktimer_is_on, 0)) {                                               \
+      pzn::KSpan _span(reinterpret_cast<const void*>(&kernel), #kernel, stream);               \
+      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                     \
+    } else {                                                                                   \
+      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                     \
+    }                                                                                          \
+  } while (0)
+
 // Zero-fill as a KERNEL, not hipMemsetAsync: inside a captured HIP graph (ROCm 7.0 runtime shipped
 // with torch) memset nodes were observed to run out of stream order relative to kernels that reuse the
 // same allocation, so accumulators were zeroed too early.  A kernel node keeps the stream order.
@@ -34,7 +57,7 @@ static inline int pzn_zero_async(float* p, size_t n, hipStream_t st) {
   if (n == 0) return PZN_OK;
   size_t blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(pzn_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n);
+  PZN_LAUNCH(pzn_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n);
   return hipGetLastError() == hipSuccess ? PZN_OK : PZN_ELAUNCH;
 }
 

@@ -340,7 +340,7 @@ int pzn_sa_level_stream_pack(const float* W2, int C1, int C2, void* workspace, h
   if (!sa_stream_on() || !workspace || pzn_sa_level_stream_workspace_bytes(C1, C2) == 0 ||
       (reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
     return PZN_EUNSUPPORTED;
-  hipLaunchKernelGGL(sa_pack_w_kernel, dim3(64), dim3(256), 0, st, W2, C1, C2, static_cast<unsigned char*>(workspace));
+  PZN_LAUNCH(sa_pack_w_kernel, dim3(64), dim3(256), 0, st, W2, C1, C2, static_cast<unsigned char*>(workspace));
   PZN_RETURN_LAUNCH_STATUS();
 }
 
@@ -351,7 +351,7 @@ int pzn_sa_level_stream(const float* Pp, const float* Q, const int64_t* idx, con
     return PZN_EUNSUPPORTED;
   unsigned char* w = static_cast<unsigned char*>(workspace);
   if (!prepacked) {
-    hipLaunchKernelGGL(sa_pack_w_kernel, dim3(64), dim3(256), 0, st, W2, C1, C2, w);
+    PZN_LAUNCH(sa_pack_w_kernel, dim3(64), dim3(256), 0, st, W2, C1, C2, w);
     if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
   }
   SaArgs a{Pp, Q, idx, w, b2, out, argmax, G, N, S, nullptr};
@@ -365,9 +365,9 @@ int pzn_sa_level_stream(const float* Pp, const float* Q, const int64_t* idx, con
   int gx = (G + SA_WAVES - 1) / SA_WAVES;
   if (gx > 256) gx = 256;
   if (C1 == 256)
-    hipLaunchKernelGGL((sa_level_stream_kernel<256, 8>), dim3(gx), dim3(SA_WAVES * 64), 0, st, a);
+    PZN_LAUNCH((sa_level_stream_kernel<256, 8>), dim3(gx), dim3(SA_WAVES * 64), 0, st, a);
   else
-    hipLaunchKernelGGL((sa_level_stream_kernel<128, 4>), dim3(gx), dim3(SA_WAVES * 64), 0, st, a);
+    PZN_LAUNCH((sa_level_stream_kernel<128, 4>), dim3(gx), dim3(SA_WAVES * 64), 0, st, a);
 #ifdef SA_STAMPS
   {
     long long hst[17];

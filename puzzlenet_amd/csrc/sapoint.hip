@@ -424,7 +424,7 @@ PZN_EXPORT int pzn_sa_prep_f32(const float* xyz, const float* new_xyz, const flo
   if (blocks > 4096) blocks = 4096;
   if (C1 > 4096) return PZN_EUNSUPPORTED;      // (4 planes of C1 floats in LDS)
   if (blocks > 1024) blocks = 1024;             // a few rows per thread: the LDS prologue is paid per workgroup
-  hipLaunchKernelGGL(sa_prep_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * C1 * sizeof(float), pzn_hip_stream(stream),
+  PZN_LAUNCH(sa_prep_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * C1 * sizeof(float), pzn_hip_stream(stream),
                      xyz, new_xyz, W1, 3 + D, b1, prow, groups, C1, P, Q);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -451,13 +451,13 @@ PZN_EXPORT int pzn_sa_point_l1_fwd_f32(const float* xyz, const float* new_xyz, c
   const dim3 grid((unsigned)blocks), block(SP_T);
   const int ldw = 3 + D;
   if (C1 == 64)
-    hipLaunchKernelGGL((sa_point_l1_fwd_kernel<4, 4>), grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h,
+    PZN_LAUNCH((sa_point_l1_fwd_kernel<4, 4>), grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h,
                        xmap);
   else if (C1 == 128)
-    hipLaunchKernelGGL((sa_point_l1_fwd_kernel<4, 2>), grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h,
+    PZN_LAUNCH((sa_point_l1_fwd_kernel<4, 2>), grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h,
                        xmap);
   else
-    hipLaunchKernelGGL((sa_point_l1_fwd_kernel<4, 1>), grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h,
+    PZN_LAUNCH((sa_point_l1_fwd_kernel<4, 1>), grid, block, 0, st, xyz, new_xyz, idx, P, W1, ldw, b1, N, S, rows, h,
                        xmap);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -472,7 +472,7 @@ PZN_EXPORT int pzn_knn_inverse_lists(const int64_t* idx, int B, int N, int S, in
       hipFuncSetAttribute((const void*)sa_inverse_lists_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
           hipSuccess)
     return PZN_ELAUNCH;
-  hipLaunchKernelGGL(sa_inverse_lists_kernel, dim3((unsigned)B), dim3(INV_T), lds, pzn_hip_stream(stream), idx, N, S * K,
+  PZN_LAUNCH(sa_inverse_lists_kernel, dim3((unsigned)B), dim3(INV_T), lds, pzn_hip_stream(stream), idx, N, S * K,
                      off, rows, pts);
   PZN_RETURN_LAUNCH_STATUS();
 }
@@ -515,7 +515,7 @@ static int sa_point_l1_bwd(const float* dh, const float* xyz, const float* new_x
   const dim3 grid((unsigned)blocks), block(SP_T);
   const int ldw = 3 + D;
 #define PZN_SP_BWD(VV, GG)                                                                                              \
-  hipLaunchKernelGGL((sa_point_l1_bwd_kernel<VV, GG>), grid, block, 0, st, dh, xyz, new_xyz, rows, pts, N, S, entries, dP, \
+  PZN_LAUNCH((sa_point_l1_bwd_kernel<VV, GG>), grid, block, 0, st, dh, xyz, new_xyz, rows, pts, N, S, entries, dP, \
                      dW1, ldw, db1, rowmask)
   if (C1 == 64) {
     if (g8 == 16) PZN_SP_BWD(1, 16); else if (g8 == 8) PZN_SP_BWD(1, 8); else PZN_SP_BWD(1, 4);

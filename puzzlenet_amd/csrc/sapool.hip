@@ -280,11 +280,11 @@ PZN_EXPORT int pzn_sa_level_bwd_pt_f32(const float* dout, const int32_t* argmax,
   const int hb = (G + PH_T / 64 - 1) / (PH_T / 64);
   const dim3 hgrid((unsigned)(hb < 4096 ? hb : 4096));
   if (C2 == 64)
-    hipLaunchKernelGGL((pool_hits_kernel<1>), hgrid, dim3(PH_T), 0, st, dout, argmax, out, G, hits, rstart);
+    PZN_LAUNCH((pool_hits_kernel<1>), hgrid, dim3(PH_T), 0, st, dout, argmax, out, G, hits, rstart);
   else if (C2 == 128)
-    hipLaunchKernelGGL((pool_hits_kernel<2>), hgrid, dim3(PH_T), 0, st, dout, argmax, out, G, hits, rstart);
+    PZN_LAUNCH((pool_hits_kernel<2>), hgrid, dim3(PH_T), 0, st, dout, argmax, out, G, hits, rstart);
   else
-    hipLaunchKernelGGL((pool_hits_kernel<4>), hgrid, dim3(PH_T), 0, st, dout, argmax, out, G, hits, rstart);
+    PZN_LAUNCH((pool_hits_kernel<4>), hgrid, dim3(PH_T), 0, st, dout, argmax, out, G, hits, rstart);
   if (pzn_zero_async(dP, (size_t)B * N * C1, st) != PZN_OK) return PZN_ELAUNCH;      // points nobody gathered; list ends add
   PointArgs a{hits, rstart, W2, Pp, Q, xyz, new_xyz, rows, pts, dP, dW1, db1, N, S, C1, C2, 3 + D, (long)B * S * 32};
   const int ny = C1 / PP_COLS;
@@ -301,7 +301,7 @@ PZN_EXPORT int pzn_sa_level_bwd_pt_f32(const float* dout, const int32_t* argmax,
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_point_kernel<16, GFV>),                 \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)       \
       return PZN_ELAUNCH;                                                                                                 \
-    hipLaunchKernelGGL((pool_point_kernel<16, GFV>), grid, dim3(1024), lds, st, a);                                       \
+    PZN_LAUNCH((pool_point_kernel<16, GFV>), grid, dim3(1024), lds, st, a);                                       \
   } while (0)
   if (gf == 4)
     PZN_PP(4);

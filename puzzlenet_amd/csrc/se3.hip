@@ -126,13 +126,13 @@ __global__ void se3_exp_bwd_kernel(const float* __restrict__ x, const float* __r
 
 PZN_EXPORT int pzn_se3_exp_fwd_f32(const float* twist, int B, float* g, pzn_stream_t stream) {
   PZN_CHECK_ARG(twist && g && B > 0);
-  hipLaunchKernelGGL(se3_exp_fwd_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, pzn_hip_stream(stream), twist, B, g);
+  PZN_LAUNCH(se3_exp_fwd_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, pzn_hip_stream(stream), twist, B, g);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
 PZN_EXPORT int pzn_se3_exp_bwd_f32(const float* twist, const float* dg, int B, float* dtwist, pzn_stream_t stream) {
   PZN_CHECK_ARG(twist && dg && dtwist && B > 0);
-  hipLaunchKernelGGL(se3_exp_bwd_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, pzn_hip_stream(stream), twist, dg,
+  PZN_LAUNCH(se3_exp_bwd_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, pzn_hip_stream(stream), twist, dg,
                      B, dtwist);
   PZN_RETURN_LAUNCH_STATUS();
 }

@@ -528,7 +528,7 @@ PZN_EXPORT int pzn_stem_fwd_f32(const float* xyz, const float* W1, const float* 
                 {bn1_weight, bn1_bias, bn1_running_mean, bn1_running_var, bn1_momentum, bn1_eps},
                 {bn2_weight, bn2_bias, bn2_running_mean, bn2_running_var, bn2_momentum, bn2_eps},
                 training, B, N, out, mean1, invstd1, mean2, invstd2};
-  hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)stem_grid(N, 2)), dim3(ST_T), 0, pzn_hip_stream(stream), a);
+  PZN_LAUNCH(stem_fwd_kernel, dim3((unsigned)stem_grid(N, 2)), dim3(ST_T), 0, pzn_hip_stream(stream), a);
   PZN_RETURN_LAUNCH_STATUS();
 }
 
@@ -550,8 +550,8 @@ PZN_EXPORT int pzn_stem_bwd_f32(const float* xyz, const float* dout, const float
   StemBwdArgs a{xyz, dout, dout2, W1, b1, W2, b2, bn1_weight, bn1_bias, bn2_weight, bn2_bias, mean1, invstd1, mean2, invstd2, training, B, N,
                 dW1, db1, dW2, db2, dbn1_weight, dbn1_bias, dbn2_weight, dbn2_bias, static_cast<float*>(workspace)};
   const int grid = stem_grid(N, 2);
-  hipLaunchKernelGGL(stem_bwd_kernel, dim3((unsigned)grid), dim3(SB_T), 0, pzn_hip_stream(stream), a);
+  PZN_LAUNCH(stem_bwd_kernel, dim3((unsigned)grid), dim3(SB_T), 0, pzn_hip_stream(stream), a);
   static_assert(ST_PART % 64 == 0, "stem_reduce_kernel: 64 outputs per workgroup");
-  hipLaunchKernelGGL(stem_reduce_kernel, dim3(ST_PART / 64), dim3(1024), 0, pzn_hip_stream(stream), a.part, grid, dW2, db2, db1, dW1);
+  PZN_LAUNCH(stem_reduce_kernel, dim3(ST_PART / 64), dim3(1024), 0, pzn_hip_stream(stream), a.part, grid, dW2, db2, db1, dW1);
   PZN_RETURN_LAUNCH_STATUS();
 }

@@ -406,7 +406,7 @@ int launch_nt_fw(const WsArgs& p, hipStream_t st) {
   gx = gx < 8 ? 8 : (gx / 8) * 8;  // multiple of 8: the slices of one row range land on one XCD (shared L2)
   const int ntiles = (p.M + 31) / 32, need = (ntiles + NW - 1) / NW;
   if (gx > need) gx = need;
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)nslices), dim3(NW * 64), lds, st, p);
+  PZN_LAUNCH(kern, dim3((unsigned)gx, (unsigned)nslices), dim3(NW * 64), lds, st, p);
   PZN_RETURN_LAUNCH_STATUS();
 }
 

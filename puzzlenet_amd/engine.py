@@ -97,10 +97,9 @@ class TrainStep:
         if fps_generator is not None:
             model.fps_generator = fps_generator
         # one device, one stream of Python backward functions: autograd's per-device worker thread only adds a hand-off per
-        # backward() and GIL traffic (host time of a step 5.3 -> 5.1 ms, tools/host_enqueue_time.py); restored by close()
-        self._saved_autograd_mt = torch.autograd.is_multithreading_enabled()
-        if os.environ.get("PZN_AUTOGRAD_MT", "0") != "1":
-            torch.autograd.set_multithreading_enabled(False)
+        # backward() and GIL traffic (host time of a step 5.3 -> 5.1 ms, tools/host_enqueue_time.py).  Scoped to the backward
+        # calls of a step (_fwd_bwd): nothing process-wide is left behind by a runner that is dropped or raises.
+        self._autograd_mt = False
 
     def _fwd_bwd(self):
         self.grads.zero_()
@@ -109,12 +108,14 @@ class TrainStep:
         cur = torch.cuda.current_stream()
         if "loss" in out:
             loss = out["loss"]
-            loss.backward()
+            with torch.autograd.set_multithreading_enabled(self._autograd_mt):
+                loss.backward()
         else:
             # the N x N EMD term is still running on the side stream: both parts are backward roots, so the backward of
             # the boundary terms and heads starts without waiting for it
             terms = list(out["loss_terms"])
-            torch.autograd.backward(terms)
+            with torch.autograd.set_multithreading_enabled(self._autograd_mt):
+                torch.autograd.backward(terms)
             if out.get("join_stream") is not None:
                 cur.wait_stream(out["join_stream"])
             loss = terms[0]
@@ -154,7 +155,6 @@ class TrainStep:
         """Give the model back as it was handed in (a later direct model.training_step() returns {'loss': ...} again)."""
         self.model.defer_emd_loss = self._saved_defer
         self.model.fps_generator = self._saved_fps_generator
-        torch.autograd.set_multithreading_enabled(self._saved_autograd_mt)
         self._plans_ahead = None
         if hasattr(self.model, "use_plans"):
             self.model.use_plans(None)

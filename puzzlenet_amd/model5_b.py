@@ -159,9 +159,8 @@ class PCTransformer_nonsort(nn.Module):
             # for them and the stem's backward adds their gradients while it loads them
             if not _STEM_TWO:
                 return ops.stem(xyz, self.mlp1, self.bn1, self.mlp2, self.bn2)
-            x_feature, second = ops.stem(xyz, self.mlp1, self.bn1, self.mlp2, self.bn2, two=True)
-            x_feature._pzn_second_name = second
-            return x_feature
+            # -> (name for the set-abstraction level, name for the boundary branch): stem() below hands each on
+            return ops.stem(xyz, self.mlp1, self.bn1, self.mlp2, self.bn2, two=True)
         # BatchNorm + ReLU as one launch each way (csrc/bnpoints.hip); ops.* raise on CPU tensors: there is no eager path
         x_feature = ops.bn_points_relu(ops.linear(xyz, self.mlp1.weight, self.mlp1.bias), self.bn1)   # :447
         return ops.bn_points_relu(ops.linear(x_feature, self.mlp2.weight, self.mlp2.bias), self.bn2)  # :448
@@ -171,9 +170,14 @@ class PCTransformer_nonsort(nn.Module):
                 for a in (self.atten1, self.atten2, self.atten3, self.atten4)]
 
     def stem(self, xyz, sa_plan=None, x_feature=None):
-        """:447-461: per-point MLP and the two set-abstraction levels -> (x2, f2f, x_feature)."""
+        """:447-461: per-point MLP and the two set-abstraction levels -> (x2, f2f, x_feature).  x_feature may be the pair of
+        names local_features() returns for the fused stem: the first feeds the set abstraction, the second is what comes back
+        (slot 4 of the encoder's tuple, the boundary branch's input)."""
         if x_feature is None:
             x_feature = self.local_features(xyz)
+        second = x_feature
+        if isinstance(x_feature, tuple):
+            x_feature, second = x_feature
         if self.fused_sa and not xyz.requires_grad:
             p1, p2 = sa_plan if sa_plan is not None else (None, None)
             x, f1f = self._set_abstraction(512, 32, xyz, x_feature, self.mlp3, self.mlp4, p1)
@@ -183,7 +187,7 @@ class PCTransformer_nonsort(nn.Module):
             f1f = ops.shared_mlp_max(f1, self.mlp3.weight, self.mlp3.bias, self.mlp4.weight, self.mlp4.bias)  # :452-454
             x2, f2 = self.sg2(256, 0, 32, x, f1f, False, True)                                    # :456
             f2f = ops.shared_mlp_max(f2, self.mlp5.weight, self.mlp5.bias, self.mlp6.weight, self.mlp6.bias)  # :459-461
-        return x2, self._mark_f2f(f2f), x_feature
+        return x2, self._mark_f2f(f2f), second
 
     def chain_fused_ok(self, f2f):
         return _ATTN_FUSED and f2f.is_cuda and ops.attention_chain_fused_supported(
@@ -380,7 +384,8 @@ class TouchedRegraster(_Base):
             if plan_f is not None:
                 for lvl in plan_f:
                     lvl[0].record_stream(cur)
-            xf_m.record_stream(side)
+            for t_ in (xf_m if isinstance(xf_m, tuple) else (xf_m,)):
+                t_.record_stream(side)
             if _ATTN_FUSED and _ATTN_DUAL and ops.attention_chain_fused_available():
                 # the two encoders' stems on two streams, then BOTH attention chains in the same launches on this one
                 # (a launch of one encoder is 128 workgroups of eight wavefronts, one per CU: half the chip)

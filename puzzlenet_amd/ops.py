@@ -84,6 +84,12 @@ class KernelTimer:
         return out
 
 
+# tests set this to a list: every max-pool of the model path appends (kind, address of the layer's weight or None, arg-max
+# tensor) - "sa": [B,S,C2] neighbour slots of a set-abstraction level (weight = its second layer's), "gmax": [B,Nout] rows of
+# the out projection's max over the points (weight = the projection's), "maxpts": [B,C] rows of max_over_points
+WINNER_CAPTURE = None
+
+
 def _call(name, *args, flops=0, variant=None):
     """Invoke a C-ABI entry point; `flops` = algorithmic 2*M*N*K of the dense entry points (bench accounting); `variant` =
     the template arguments of the kernel this call launches, where one entry point has several instantiations."""
@@ -215,6 +221,8 @@ class _MaxOverPoints(torch.autograd.Function):
         idx = torch.empty((B, C), dtype=torch.int32, device=x.device)
         with _on(x.device):
             _call("pzn_maxpool_points_fwd_f32", _p(x), B, L, C, _p(out), _p(idx), _stream())
+        if WINNER_CAPTURE is not None:
+            WINNER_CAPTURE.append(("maxpts", None, idx))
         ctx.save_for_backward(idx)
         ctx.dims = (B, L, C)
         return out
@@ -1263,6 +1271,8 @@ class _AttnChainFused(torch.autograd.Function):
                 else:
                     outs += [y.view(B, L, Nout), maps[p], f_global]
                 tosave += [t_ for blk in saved[p] for t_ in blk] + [cur[p]] + pss[p] + [arg]
+                if WINNER_CAPTURE is not None:
+                    WINNER_CAPTURE.append(("gmax", args[per * p + 33].data_ptr(), arg))
         ctx.save_for_backward(*tosave)
         ctx.nprob = nprob
         ctx.dims = (B, L, E, dk, Nout)
@@ -1734,6 +1744,8 @@ class _SaLevelFused(torch.autograd.Function):
             if not done:
                 _call("pzn_sa_level_fwd_ws_f32", _p(P), _p(Q), _p(idx), _p(w2), _p(b2), B, N, S, C1, C2, _p(out), _p(arg),
                       _p(ws), _stream(), flops=2 * R * 32 * C1 * C2)
+        if WINNER_CAPTURE is not None:
+            WINNER_CAPTURE.append(("sa", w2.data_ptr(), arg.view(B, S, C2)))
         ctx.save_for_backward(xyz, feat, new_xyz, idx, w1, w_f, w2, out, arg, P, Q)
         ctx.dims = (B, N, S, D, R, C1, C2)
         ctx.param_refs = (w1, b1, w2, b2)

@@ -23,6 +23,7 @@ if __name__ == "__main__":
     flags = {} if loss_mode == 0 else dict(use_emd2=True, use_cd2=True, use_emd3=True)
     cfg = mr.Cfg(loss_mode=loss_mode, **flags)
     ops.clear_grad_sinks()
+    mb._STEM_TWO = False      # the wrappers below take and return ONE tensor
     m = mb.TouchedRegraster(cfg)
     mr.fill_params(m)
     ref = mr.RefModel(cfg)

@@ -88,6 +88,7 @@ def test_encoder_stages_repeatable(golden_model, dev):
     xyz = _t(G["p5_batch0"], dev)
     with torch.no_grad():
         xf = enc.local_features(xyz)
+        xf = xf[0] if isinstance(xf, tuple) else xf      # (the fused stem returns its output under two names)
         f1 = ops.farthest_point_sample(xyz, 512, torch.zeros(xyz.shape[0], dtype=torch.long, device=dev))
         x1 = ops.index_points(xyz, f1)
         f2 = ops.farthest_point_sample(x1, 256, torch.zeros(xyz.shape[0], dtype=torch.long, device=dev))
@@ -95,6 +96,7 @@ def test_encoder_stages_repeatable(golden_model, dev):
         first = None
         for r in range(REPS):
             xf_r = enc.local_features(xyz)
+            xf_r = xf_r[0] if isinstance(xf_r, tuple) else xf_r
             a = ops.sa_mlp_max(xyz, xf, x1, None, enc.mlp3.weight, enc.mlp3.bias, enc.mlp4.weight, enc.mlp4.bias)
             b = ops.sa_mlp_max(x1, a, x2, None, enc.mlp5.weight, enc.mlp5.bias, enc.mlp6.weight, enc.mlp6.bias)
             cur = {"local_features": xf_r, "sa1": a, "sa2": b}

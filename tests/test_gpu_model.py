@@ -153,19 +153,49 @@ def test_training_step_vs_reference(golden_loss, dev, loss_mode):
                                    err_msg=str(name))
 
 
+def _device_winners(m, capture):
+    """ops.WINNER_CAPTURE of one forward of the product model -> the keys oracle.model_ref.RefModel.pin_winners takes."""
+    owner = {}
+    for tag, enc in (("Encoder.", m.Encoder), ("Encoder2.", m.Encoder2)):
+        owner[enc.mlp4.weight.data_ptr()] = tag + "sa1"
+        owner[enc.mlp6.weight.data_ptr()] = tag + "sa2"
+        owner[enc.out.weight.data_ptr()] = tag + "gmax"
+    win = {}
+    for kind, ptr, arg in capture:
+        key = "heads.gmax" if kind == "maxpts" else owner[ptr]
+        assert key not in win, key
+        win[key] = arg.detach().cpu().to(torch.long)
+    assert len(win) == 7, sorted(win)
+    return win
+
+
+def _check_flips(pins, max_flips=16, max_gap=1e-5):
+    """The oracle's own arg-max differs from the pinned (device) winner only on near-ties: a handful of entries, each with
+    the two candidates closer than fp32 rounding of the sums in front of them."""
+    total = 0
+    for key, (n, gap, of) in sorted(pins["flips"].items()):
+        total += n
+        assert gap <= max_gap, (key, n, gap)
+    print("max-pool winners that differ from the oracle's own:", {k: v[0] for k, v in pins["flips"].items() if v[0]}, "of",
+          sum(v[2] for v in pins["flips"].values()))
+    assert total <= max_flips, pins["flips"]
+    return total
+
+
 @pytest.mark.parametrize("loss_mode", [0, 1])
 def test_training_step_full_gradients_vs_oracle(golden_loss, dev, loss_mode):
     """The whole gradient of one training_step, every entry of every parameter, against the torch-CPU restatement run
     on the same batch (oracle/model_ref.py, itself pinned to the reference's training_step by tests/test_oracle_model.py):
     the fingerprint test above holds norms and 8 samples per tensor to percents; this one holds the full 8,059,220-entry
-    gradient to 4e-4 in L2, every tensor to 3e-2 of its own norm and four tensors in five to 2e-3, above a floor of 1e-6
-    of the total (the key biases of the attention blocks have a mathematically zero gradient: noise on both sides).
+    gradient to 2e-4 in L2 and every tensor to 1e-2 of its own norm, above a floor of 1e-6 of the total (the key biases of
+    the attention blocks have a mathematically zero gradient: noise on both sides).
     The function is not continuous: the global max over points sends a channel's whole gradient through ONE point, and a
-    max-pool winner further down that is ahead by less than fp32 rounding may fall the other way under a different
-    summation order — one such flip on a heavy path moves ~1 % of one encoder's gradients (tests/_grad_rows.py prints the
-    rows).  Measured with the one-launch stem: 1.9e-4 whole / 1.3e-2 worst tensor / 80th percentile 1.2e-4 (one flip, in
-    sample 0 of Encoder2); with the four-launch stem 2.8e-5 / 5.2e-3 / 7e-5 — and the four-launch path fed the one-launch
-    stem's VALUES reproduces its gradients to 7e-7 (tests/test_gpu_stem.py), so the difference is the flip, not the stem."""
+    max-pool winner that is ahead by less than fp32 rounding may fall the other way under a different summation order - one
+    such flip on a heavy path moves ~1 % of one encoder's gradients (tests/_grad_rows.py prints the rows).  The comparison is
+    therefore made flip-aware instead of loose: the product's arg-max tensors (both set-abstraction levels and the global max
+    of both encoders, the heads' max: ops.WINNER_CAPTURE) are handed to the oracle, which evaluates the function OF THOSE
+    WINNERS (model_ref._pool) and reports where its own arg-max differs: at most a handful of entries (printed), each a
+    near-tie (gap <= 1e-5 of the tensor's largest maximum) - and then the old bounds hold for every tensor."""
     from puzzlenet_amd import model5_b as mb, ops
     G = golden_loss
     flags = {} if loss_mode == 0 else dict(use_emd2=True, use_cd2=True, use_emd3=True)
@@ -178,10 +208,17 @@ def test_training_step_full_gradients_vs_oracle(golden_loss, dev, loss_mode):
     m.to(dev)
     batch = [_t(G[f"ts_batch{i}"], dev) for i in range(8)]
     torch.manual_seed(99)
+    ops.WINNER_CAPTURE = []
+    try:
+        loss = m.training_step(batch, 0)["loss"]
+        capture, ops.WINNER_CAPTURE = ops.WINNER_CAPTURE, None
+    finally:
+        ops.WINNER_CAPTURE = None
+    pins = ref.pin_winners(_device_winners(m, capture))
+    torch.manual_seed(99)
     ref_loss = ref.training_step([t.cpu() for t in batch])
     ref_loss = ref_loss[0] if isinstance(ref_loss, tuple) else ref_loss
-    torch.manual_seed(99)
-    loss = m.training_step(batch, 0)["loss"]
+    _check_flips(pins)
     assert abs(loss.item() - ref_loss.item()) <= 1e-4 * abs(ref_loss.item())
     loss.backward()
     ref_loss.backward()
@@ -196,11 +233,9 @@ def test_training_step_full_gradients_vs_oracle(golden_loss, dev, loss_mode):
         err2, ref2 = err2 + e * e, ref2 + r * r
         rows.append((name, e, r))
     total = ref2 ** 0.5
-    assert err2 ** 0.5 <= 4e-4 * total, (err2 ** 0.5 / total)
+    assert err2 ** 0.5 <= 2e-4 * total, (err2 ** 0.5 / total)
     for name, e, r in rows:
-        assert e <= 3e-2 * r + 1e-6 * total, (name, e, r)
-    tight = sum(e <= 2e-3 * r + 1e-6 * total for _, e, r in rows)
-    assert tight >= 0.8 * len(rows), (tight, len(rows))
+        assert e <= 1e-2 * r + 1e-6 * total, (name, e, r)
 
 
 def test_gradient_sinks_match_autograd_accumulation(golden_loss, dev):
@@ -421,26 +456,75 @@ def test_train_step_private_fps_generator_leaves_the_global_one_alone(golden_los
         gen = torch.Generator().manual_seed(seed)
         torch.manual_seed(5)
         before = torch.get_rng_state()
-        with engine.TrainStep(m, batch, 1e-3, world=1, prefetch=True, fps_generator=gen) as r:
-            losses = [float(r.step()), float(r.step(last=True))]
-            assert r._plans_ahead is None                   # nothing prefetched behind the last step
-            state_after_last = gen.get_state()
-        torch.cuda.synchronize()
+        ops.WINNER_CAPTURE = []
+        try:
+            with engine.TrainStep(m, batch, 1e-3, world=1, prefetch=True, fps_generator=gen) as r:
+                losses = [float(r.step()), float(r.step(last=True))]
+                assert r._plans_ahead is None                   # nothing prefetched behind the last step
+                state_after_last = gen.get_state()
+            torch.cuda.synchronize()
+            winners = [_device_winners(m, ops.WINNER_CAPTURE[7 * i: 7 * i + 7]) for i in range(2)]
+        finally:
+            ops.WINNER_CAPTURE = None
         assert torch.equal(torch.get_rng_state(), before)    # the global generator was never drawn from
         assert m.fps_generator is None                       # handed back
-        return losses, state_after_last
+        return losses, state_after_last, winners
 
-    (la, sa), (lb, sb) = run(21), run(21)
+    (la, sa, wa), (lb, sb, wb) = run(21), run(21)
     assert torch.equal(sa, sb)
-    # the same draws -> the same first loss to the rounding of the kernels' atomic sums.  The second step sits behind an Adam
-    # update (which turns rounding noise in near-zero gradients into +-lr) and a max-pool winner of this batch that is ahead by
-    # less than that noise: its loss takes one of two values 1.1e-4 apart from run to run (17236.2 / 17238.1); wrong draws
-    # would move it by percents
+    # the same draws -> the same first loss to the rounding of the kernels' atomic sums, and the same max-pool winners
     assert abs(la[0] - lb[0]) <= 1e-5 * abs(la[0]), (la, lb)
-    assert abs(la[1] - lb[1]) <= 1e-3 * abs(la[1]), (la, lb)
+    assert all(torch.equal(wa[0][k], wb[0][k]) for k in wa[0]), "first-step max-pool winners differ between two seeded runs"
+    # The second step sits behind an Adam update, which turns the rounding noise of atomic sums in near-zero gradients into
+    # +-lr: a max-pool winner of this batch that is ahead by less than that may fall either way, and one flip on a heavy path
+    # moves the loss by ~1e-4 (17236.2 / 17238.1 were seen, with 121 of 1 057 024 winners different).  So: count the winners
+    # that differ between the two runs' second steps - at most one in a thousand - and hold the loss to 1e-4 when there is
+    # none, to 1e-3 when there are some (wrong draws pick other centroids: every winner of the cloud changes and the loss
+    # moves by percents).
+    flips = sum(int((wa[1][k] != wb[1][k]).sum()) for k in wa[1])
+    total = sum(wa[1][k].numel() for k in wa[1])
+    print("second-step max-pool winners that differ between the two runs:", flips, "of", total, "losses", la[1], lb[1])
+    assert flips <= total // 1000, (flips, total)
+    assert abs(la[1] - lb[1]) <= (1e-4 if flips == 0 else 1e-3) * abs(la[1]), (la, lb, flips)
     # two steps = two sets of four draws, not three: the generator is where 2 x 4 draws of 64 leave it
     ref = torch.Generator().manual_seed(21)
     for _ in range(2):
         for n_ in (batch[0].shape[1], 512, batch[0].shape[1], 512):
             torch.randint(0, n_, (batch[0].shape[0],), dtype=torch.long, generator=ref)
     assert torch.equal(sa, ref.get_state())
+
+
+def test_memory_is_flat_over_steps(dev):
+    """ADVICE (round 5): nothing a step allocates outlives it - neither TrainStep.step (fused stem under two names, saved
+    statistics, prefetched plans) nor predict5 under no_grad.  The stem's second name used to hang in the first one's
+    __dict__ (a cycle through the view's base that Python's collector cannot see): 2 x 4 MB per step at this shape."""
+    import gc
+    from puzzlenet_amd import engine, model5_b as mb, ops, synthetic
+    B, N = 8, 1024
+    ops.clear_grad_sinks()
+    m = mb.TouchedRegraster(mr.Cfg(num_points=N, loss_mode=1)).to(dev)
+    batch = synthetic.make_batch(B, N, dev, seed=3)
+    assert mb._STEM_FUSED and ops.stem_supported(batch[0], m.Encoder.mlp1, m.Encoder.bn1, m.Encoder.mlp2, m.Encoder.bn2)
+
+    def settled():
+        torch.cuda.synchronize()
+        gc.collect()
+        return torch.cuda.memory_allocated()
+
+    with engine.TrainStep(m, batch, 1e-3, world=1) as r:
+        for _ in range(4):
+            r.step()
+        base = settled()
+        for _ in range(20):
+            r.step()
+        after = settled()
+    assert after - base <= (1 << 20), (base, after)      # (2 x B x N x 64 x 4 = 4 MB per step would be 84 MB here)
+    ops.clear_grad_sinks()
+    with torch.no_grad():
+        for _ in range(3):
+            m.predict5(batch, B, training=False)
+        base = settled()
+        for _ in range(20):
+            m.predict5(batch, B, training=False)
+        after = settled()
+    assert after - base <= (1 << 20), (base, after)

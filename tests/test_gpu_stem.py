@@ -131,7 +131,8 @@ def test_model_gradients_fused_stem_equals_unfused_on_the_same_values(golden_los
     cfg = mr.Cfg(loss_mode=0)
     batch = [torch.from_numpy(np.ascontiguousarray(golden_loss[f"ts_batch{i}"])).to(dev) for i in range(8)]
     runs = []
-    was = mb._STEM_FUSED
+    was, was_two = mb._STEM_FUSED, mb._STEM_TWO
+    mb._STEM_TWO = False      # one name for the features: the hook below sees their whole gradient
     try:
         for fused in (True, False):
             mb._STEM_FUSED = fused
@@ -159,7 +160,7 @@ def test_model_gradients_fused_stem_equals_unfused_on_the_same_values(golden_los
                     cap[n_] = p.grad.detach().clone()
             runs.append(cap)
     finally:
-        mb._STEM_FUSED = was
+        mb._STEM_FUSED, mb._STEM_TWO = was, was_two
     a, b = runs
     for name in ("Encoder", "Encoder2"):
         assert float((a[name + ".xf"] - b[name + ".xf"]).abs().max()) < 1e-6
