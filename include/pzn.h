@@ -44,6 +44,14 @@ const char* pzn_strerror(int status);
 /* 0 when a gfx950 device is usable by this process, PZN_ENODEVICE otherwise. */
 int pzn_device_check(void);
 
+/* Measurement only (bench.py; no counterpart in the reference): per-KERNEL device time.  pzn_ktimer_enable(1): every kernel
+ * the library launches from now on is bracketed by a HIP event pair on its own stream, under the name a rocprofv3 kernel
+ * trace shows (template arguments included).  pzn_ktimer_collect() waits for the recorded launches and folds them into
+ * rows -> number of rows; pzn_ktimer_row(i, ...) reads one (name, launches, summed milliseconds).  Off by default. */
+int pzn_ktimer_enable(int on);
+int pzn_ktimer_collect(void);
+int pzn_ktimer_row(int i, char* name, int cap, int* launches, double* ms);
+
 /* ------------------------------------------------------------------------ */
 /* Point ops: pointnet_util.py                                              */
 /* ------------------------------------------------------------------------ */
@@ -61,6 +69,13 @@ int pzn_square_distance_f32(const float* src, const float* dst, int B, int S,
 int pzn_fps_f32(const float* xyz, int B, int N, int npoint,
                 const int64_t* start_idx, int64_t* out_idx,
                 pzn_stream_t stream);
+/* dataset.py:1147-1163 (`fps` of a raw piece in the loader processes) as a background job beside a training step: the same
+ * picks bit for bit, but no LDS image of the cloud (1.2 KB of LDS per workgroup instead of up to 150 KB), so the step's
+ * LDS-tiled kernels keep their CUs.  N <= 32768.  counts (NULL or int64 [B]): rows >= counts[b] of cloud b are padding
+ * (copies of row 0, which never win) and are left out of the rounds. */
+int pzn_fps_background_f32(const float* xyz, int B, int N, int npoint,
+                           const int64_t* start_idx, int64_t* out_idx,
+                           const int64_t* counts, pzn_stream_t stream);
 
 /* pointnet_util.py:118-119  dists.argsort()[:, :, :K] fused with the distance:
  * idx[B,S,K] = the K nearest points of xyz[B,N,3] to each new_xyz[B,S,3],
@@ -641,6 +656,22 @@ int pzn_colmean_argmax_f32(const float* a, int B, int R, int C, float* mean, int
 int pzn_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                       size_t n, float lr, float beta1, float beta2, float eps, int step,
                       pzn_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* Data pipeline on the GPU: dataset.py                        */
+/* ------------------------------------------------------------------------ */
+
+/* dataset.py:761-775 + 1176-1180 (CADDataset.slice with its re-draw loop) for a batch, one launch: K candidate planes per sample
+ * (normals float64 [B,K,3] = np.random.rand(3,1), zs float64 [B,K] = np.random.rand(1)/3), the FIRST that leaves >= n_min points
+ * on both sides is taken (none: the most balanced one, ok = 0).  pieces [2B,cap,3]: rows 0..B-1 the `up` pieces
+ * (points . normal + z >= 0, float64, no fma), rows B..2B-1 the `down` pieces, each in the cloud's point order and padded with
+ * copies of its first row; counts int64 [2B]; start int64 [2B] = floor(u * count) (u float64 [B,2]: uniform draws standing in for
+ * np.random.randint(0, n_piece), dataset.py:1153); plane float64 [B,4] = (normal, z) taken; ok uint8 [B]. */
+int pzn_cut_compact_f32(const float* raw, const double* normals, const double* zs, const double* u, int B, int M,
+                        int K, int n_min, int cap, float* pieces, int64_t* counts, int64_t* start, double* plane,
+                        uint8_t* ok, pzn_stream_t stream);
+/* dataset.py:1363-1366: 0/1 masks [R,N] with ones at the k picked rows idx int64 [R,k] of each cloud. */
+int pzn_pick_mask_f32(const int64_t* idx, int R, int k, int N, float* mask, pzn_stream_t stream);
 
 #ifdef __cplusplus
 }

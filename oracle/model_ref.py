@@ -15,7 +15,26 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import contextlib
+import time
+
 from . import point_ops as orc
+
+# bench.py's cpu_baseline sets this to a dict: host seconds per stage of the forward pass, accumulated over the steps
+# (fps / knn / group / mlp / attention / heads / chamfer / emd / emd_backward / loss_tail)
+STAGE_CLOCK = None
+
+
+@contextlib.contextmanager
+def _stage(name):
+    if STAGE_CLOCK is None:
+        yield
+        return
+    t0 = time.perf_counter()
+    try:
+        yield
+    finally:
+        STAGE_CLOCK[name] = STAGE_CLOCK.get(name, 0.0) + time.perf_counter() - t0
 
 
 # ---- pointnet_util.py ------------------------------------------------------------------
@@ -48,17 +67,20 @@ def farthest_point_sample(xyz, npoint):
 def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, knn=False):
     B, N, C = xyz.shape
     S = npoint
-    fps_idx = farthest_point_sample(xyz, npoint)
-    new_xyz = index_points(xyz, fps_idx)
+    with _stage("fps"):
+        fps_idx = farthest_point_sample(xyz, npoint)
+        new_xyz = index_points(xyz, fps_idx)
     assert knn, "model5_b only uses knn=True (model5_b.py:449,456)"
-    dists = square_distance(new_xyz, xyz)
-    idx = dists.argsort(stable=True)[:, :, :nsample]       # stable: ties -> ascending index
-    grouped_xyz = index_points(xyz, idx)
-    grouped_xyz_norm = grouped_xyz - new_xyz.view(B, S, 1, C)
-    if points is not None:
-        new_points = torch.cat([grouped_xyz_norm, index_points(points, idx)], dim=-1)
-    else:
-        new_points = grouped_xyz_norm
+    with _stage("knn"):
+        dists = square_distance(new_xyz, xyz)
+        idx = dists.argsort(stable=True)[:, :, :nsample]       # stable: ties -> ascending index
+    with _stage("group"):
+        grouped_xyz = index_points(xyz, idx)
+        grouped_xyz_norm = grouped_xyz - new_xyz.view(B, S, 1, C)
+        if points is not None:
+            new_points = torch.cat([grouped_xyz_norm, index_points(points, idx)], dim=-1)
+        else:
+            new_points = grouped_xyz_norm
     if returnfps:
         return new_xyz, new_points, grouped_xyz, fps_idx
     return new_xyz, new_points
@@ -141,19 +163,24 @@ class Encoder(nn.Module):
         self.out = nn.Linear(1280, 1024)
 
     def forward(self, xyz):
-        xf = F.relu(self.bn1(self.mlp1(xyz)))
-        xf = F.relu(self.bn2(self.mlp2(xf)))
+        with _stage("mlp"):
+            xf = F.relu(self.bn1(self.mlp1(xyz)))
+            xf = F.relu(self.bn2(self.mlp2(xf)))
         x, f1 = sample_and_group(512, 0, 32, xyz, xf, False, True)
-        f1f = _pool(F.relu(self.mlp4(F.relu(self.mlp3(f1)))), 2, self.pins, self.tag + "sa1")
+        with _stage("mlp"):
+            f1f = _pool(F.relu(self.mlp4(F.relu(self.mlp3(f1)))), 2, self.pins, self.tag + "sa1")
         x2, f2 = sample_and_group(256, 0, 32, x, f1f, False, True)
-        f2f = _pool(F.relu(self.mlp6(F.relu(self.mlp5(f2)))), 2, self.pins, self.tag + "sa2")
-        a1, w1 = self.atten1(f2f)
-        a2, w2 = self.atten2(a1)
-        a3, w3 = self.atten3(a2)
-        a4, w4 = self.atten4(a3)
-        attention = (w1 + w2 + w3 + w4) / 4
-        out = self.out(torch.cat([a1, a2, a3, a4, f2f], dim=-1))
-        return _pool(out, 1, self.pins, self.tag + "gmax"), x2, attention, out, xf
+        with _stage("mlp"):
+            f2f = _pool(F.relu(self.mlp6(F.relu(self.mlp5(f2)))), 2, self.pins, self.tag + "sa2")
+        with _stage("attention"):
+            a1, w1 = self.atten1(f2f)
+            a2, w2 = self.atten2(a1)
+            a3, w3 = self.atten3(a2)
+            a4, w4 = self.atten4(a3)
+            attention = (w1 + w2 + w3 + w4) / 4
+        with _stage("mlp"):
+            out = self.out(torch.cat([a1, a2, a3, a4, f2f], dim=-1))
+            return _pool(out, 1, self.pins, self.tag + "gmax"), x2, attention, out, xf
 
 
 class _Dec(nn.Module):
@@ -174,16 +201,18 @@ def _seq(*d):
 class _OracleEMD(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2):
-        a1, a2 = x1.detach().contiguous().numpy(), x2.detach().contiguous().numpy()
-        match = orc.emd_approxmatch(a1, a2)
-        ctx.save_for_backward(x1, x2, torch.from_numpy(match))
-        return torch.from_numpy(orc.emd_matchcost(a1, a2, match))
+        with _stage("emd"):
+            a1, a2 = x1.detach().contiguous().numpy(), x2.detach().contiguous().numpy()
+            match = orc.emd_approxmatch(a1, a2)
+            ctx.save_for_backward(x1, x2, torch.from_numpy(match))
+            return torch.from_numpy(orc.emd_matchcost(a1, a2, match))
 
     @staticmethod
     def backward(ctx, gc):
         x1, x2, match = ctx.saved_tensors
-        g1, g2 = orc.emd_matchcost_grad(gc.contiguous().numpy(), x1.detach().contiguous().numpy(),
-                                        x2.detach().contiguous().numpy(), match.numpy())
+        with _stage("emd_backward"):
+            g1, g2 = orc.emd_matchcost_grad(gc.contiguous().numpy(), x1.detach().contiguous().numpy(),
+                                            x2.detach().contiguous().numpy(), match.numpy())
         return torch.from_numpy(g1), torch.from_numpy(g2)
 
 
@@ -192,13 +221,14 @@ def earth_mover_distance(x1, x2):
 
 
 def chamfer_loss(x, y):
-    n = x.size(1)
-    xx, yy, zz = torch.bmm(x, x.transpose(2, 1)), torch.bmm(y, y.transpose(2, 1)), torch.bmm(x, y.transpose(2, 1))
-    d = torch.arange(0, n)
-    rx = xx[:, d, d].unsqueeze(1).expand_as(xx)
-    ry = yy[:, d, d].unsqueeze(1).expand_as(yy)
-    P = rx.transpose(2, 1) + ry - 2 * zz
-    return torch.min(P, 1)[0], torch.min(P, 2)[0]
+    with _stage("chamfer"):
+        n = x.size(1)
+        xx, yy, zz = torch.bmm(x, x.transpose(2, 1)), torch.bmm(y, y.transpose(2, 1)), torch.bmm(x, y.transpose(2, 1))
+        d = torch.arange(0, n)
+        rx = xx[:, d, d].unsqueeze(1).expand_as(xx)
+        ry = yy[:, d, d].unsqueeze(1).expand_as(yy)
+        P = rx.transpose(2, 1) + ry - 2 * zz
+        return torch.min(P, 1)[0], torch.min(P, 2)[0]
 
 
 def comp(g, igt):
@@ -237,16 +267,21 @@ class RefModel(nn.Module):
         N = fpc.shape[1]
         ff = self.Encoder(fpc)
         fm = self.Encoder2(mrpc)
-        out = self.tfMLP(torch.cat([ff[0], fm[0]], dim=-1))
-        lf = self.MLPLocalPreFpc(ff[4])
-        lm = self.MLPLocalPreRpc(fm[4])
-        gf = _pool(lm, 1, self.pins, "heads.gmax").unsqueeze(1).repeat(1, N, 1)       # model5_b.py:741 (the reference's bug)
-        gm = gf.clone()
-        de_fpcb = self.MLPFpcb(torch.cat([gm, lf], dim=-1)).permute(0, 2, 1)
-        de_mrpcb = self.MLPRpcb(torch.cat([gf, lm], dim=-1)).permute(0, 2, 1)
+        with _stage("heads"):
+            out = self.tfMLP(torch.cat([ff[0], fm[0]], dim=-1))
+            lf = self.MLPLocalPreFpc(ff[4])
+            lm = self.MLPLocalPreRpc(fm[4])
+            gf = _pool(lm, 1, self.pins, "heads.gmax").unsqueeze(1).repeat(1, N, 1)       # model5_b.py:741 (the reference's bug)
+            gm = gf
+            de_fpcb = self.MLPFpcb(torch.cat([gm, lf], dim=-1)).permute(0, 2, 1)
+            de_mrpcb = self.MLPRpcb(torch.cat([gf, lm], dim=-1)).permute(0, 2, 1)
         return out, [0], ff[1], ff[2], fm[1], fm[2], de_fpcb, de_mrpcb
 
     def training_step(self, batch, return_terms=False):
+        with _stage("forward_total"):
+            return self._training_step(batch, return_terms)
+
+    def _training_step(self, batch, return_terms=False):
         fpc, mrpc, igt, rpc, fpcb, rpcb, fpc_idx, rpc_idx = batch
         C = self.C
         N = fpc.shape[1]

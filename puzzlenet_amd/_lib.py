@@ -22,8 +22,12 @@ SIGNATURES = {
     "pzn_version": (_c_i, []),
     "pzn_strerror": (ctypes.c_char_p, [_c_i]),
     "pzn_device_check": (_c_i, []),
+    "pzn_ktimer_enable": (_c_i, [_c_i]),
+    "pzn_ktimer_collect": (_c_i, []),
+    "pzn_ktimer_row": (_c_i, [_c_i, ctypes.c_char_p, _c_i, ctypes.POINTER(_c_i), ctypes.POINTER(ctypes.c_double)]),
     "pzn_square_distance_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_fps_f32": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "pzn_fps_background_f32": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f]),
     "pzn_knn_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_ball_query_f32": (_c_i, [_c_fl, _c_i, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_gather_fwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),
@@ -131,6 +135,8 @@ SIGNATURES = {
     "pzn_attn_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_attn_bwd_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i]),
     "pzn_attn_bwd_f32": (_c_i, [_c_f] * 6 + [_c_i] * 4 + [_c_f] * 5),
+    "pzn_cut_compact_f32": (_c_i, [_c_f] * 4 + [_c_i] * 5 + [_c_f] * 6),
+    "pzn_pick_mask_f32": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_chamfer_bwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f]),
 }
 

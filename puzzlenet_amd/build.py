@@ -49,6 +49,7 @@ SOURCES = [
     ("bnpoints.hip", NOSLP),
     ("stem.hip", NOSLP),
     ("losstail.hip", NOSLP),
+    ("datapipe.hip", ["-ffp-contract=off"] + NOSLP),
 ]
 if _OFF:
     SOURCES = [(f, [x for x in fl if x not in NOSLP]) for f, fl in SOURCES]

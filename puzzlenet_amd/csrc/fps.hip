@@ -29,7 +29,7 @@ constexpr int FPS_OUT_CHUNK = 256;      // picks buffered in LDS between write-o
 template <int T, int PPT, bool use_lds>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int N, int npoint,
                                                 const int64_t* __restrict__ start,
-                                                int64_t* __restrict__ out) {
+                                                int64_t* __restrict__ out, const int64_t* __restrict__ counts) {
   constexpr int W = T / PZN_WAVE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t* slots = reinterpret_cast<uint64_t*>(smem_raw);             // [2][W]
@@ -69,7 +69,12 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     dist[p] = 1e10f;  // pointnet_util.py:64
   }
 
-  const bool full = N == T * PPT;      // every thread's every point exists: no bounds tests in the rounds
+  // counts (the data pipeline's padded pieces): only the first counts[b] rows of the cloud are real, the rest are copies of
+  // row 0, which can never be picked (distance 0 after the first round at the latest, and any tie goes to the lower index);
+  // the rounds then leave out every register slot that holds padding only (a workgroup-uniform bound)
+  const int nreal = counts ? (int)(counts[b] < 1 ? 1 : (counts[b] > N ? N : counts[b])) : N;
+  const int pmax = (nreal + T - 1) / T;
+  const bool full = N == T * PPT && nreal == N;      // every thread's every point exists: no bounds tests in the rounds
   int far = (int)start[b];  // pointnet_util.py:65 (the caller's randint draw)
   far = far < 0 ? 0 : (far >= N ? N - 1 : far);
   int64_t* o = out + (size_t)b * npoint;
@@ -126,13 +131,15 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
       best = 0;  // below every real key: real keys have ~j >= 1
 #pragma unroll
       for (int p = 0; p < PPT; ++p) {
-        int j = tid + p * T;
-        float d = pzn::sqdist3(px[p], py[p], pz[p], cx, cy, cz);  // :70
-        float nd = d < dist[p] ? d : dist[p];                     // :71
-        dist[p] = nd;
-        uint64_t key = ((uint64_t)__float_as_uint(nd) << 32) | (uint32_t)(~(uint32_t)j);
-        key = j < N ? key : 0ull;
-        best = key > best ? key : best;
+        if (p < pmax) {      // (workgroup-uniform: slots at and beyond pmax hold padding only)
+          int j = tid + p * T;
+          float d = pzn::sqdist3(px[p], py[p], pz[p], cx, cy, cz);  // :70
+          float nd = d < dist[p] ? d : dist[p];                     // :71
+          dist[p] = nd;
+          uint64_t key = ((uint64_t)__float_as_uint(nd) << 32) | (uint32_t)(~(uint32_t)j);
+          key = j < N ? key : 0ull;
+          best = key > best ? key : best;
+        }
       }
       best = pzn::wave_max_u64_dpp(best);
     }
@@ -150,25 +157,43 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
 }
 
 template <int T, int PPT>
-int launch(const float* xyz, int B, int N, int npoint, const int64_t* start, int64_t* out, hipStream_t st) {
+int launch(const float* xyz, int B, int N, int npoint, const int64_t* start, int64_t* out, hipStream_t st, bool image = true,
+           const int64_t* counts = nullptr) {
   constexpr int W = T / PZN_WAVE;
   size_t lds_xyz = (size_t)3 * N * sizeof(float);
   size_t lds = 2 * W * sizeof(uint64_t) + FPS_OUT_CHUNK * sizeof(int);
-  int use_lds = lds + lds_xyz <= 150 * 1024;
+  int use_lds = image && lds + lds_xyz <= 150 * 1024;
   if (use_lds) lds += lds_xyz;
   if (use_lds) {
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_kernel<T, PPT, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return PZN_ELAUNCH;
-    PZN_LAUNCH((fps_kernel<T, PPT, true>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out);
+    PZN_LAUNCH((fps_kernel<T, PPT, true>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out, counts);
   } else {
-    PZN_LAUNCH((fps_kernel<T, PPT, false>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out);
+    PZN_LAUNCH((fps_kernel<T, PPT, false>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out, counts);
   }
   PZN_RETURN_LAUNCH_STATUS();
 }
 
 }  // namespace
+
+// The same sampling as a BACKGROUND job (datapipe.PairFeeder: pieces of up to 32768 raw points sampled on a side stream while
+// a training step owns the chip): no LDS image of the cloud - the centroid of a round is fetched from global memory (L2) -, so
+// a workgroup holds 1.2 KB of LDS instead of up to 150 KB and the step's LDS-tiled kernels keep their CUs; 512 threads for
+// N <= 16384.  counts (may be NULL): int64 [B], the number of REAL rows of each cloud when the rest is padding with copies of
+// row 0 (datapipe._compact): the rounds skip the padding.  Same picks bit for bit (the arithmetic is the same code).
+PZN_EXPORT int pzn_fps_background_f32(const float* xyz, int B, int N, int npoint, const int64_t* start_idx,
+                                      int64_t* out_idx, const int64_t* counts, pzn_stream_t stream) {
+  PZN_CHECK_ARG(xyz && start_idx && out_idx && B > 0 && N > 0 && npoint > 0);
+  hipStream_t st = pzn_hip_stream(stream);
+  if (N <= 2048) return launch<256, 8>(xyz, B, N, npoint, start_idx, out_idx, st, false, counts);
+  if (N <= 4096) return launch<256, 16>(xyz, B, N, npoint, start_idx, out_idx, st, false, counts);
+  if (N <= 8192) return launch<512, 16>(xyz, B, N, npoint, start_idx, out_idx, st, false, counts);
+  if (N <= 16384) return launch<512, 32>(xyz, B, N, npoint, start_idx, out_idx, st, false, counts);
+  if (N <= 32768) return launch<1024, 32>(xyz, B, N, npoint, start_idx, out_idx, st, false, counts);
+  return PZN_EUNSUPPORTED;
+}
 
 PZN_EXPORT int pzn_fps_f32(const float* xyz, int B, int N, int npoint, const int64_t* start_idx,
                            int64_t* out_idx, pzn_stream_t stream) {

@@ -34,11 +34,14 @@ struct KSpan {
   KSpan(const void* fn, const char* text, hipStream_t s);
   ~KSpan();
 };
+// the host function behind a launch expression: a kernel's name (decays to a pointer) or a variable holding such a pointer
+template <class T>
+static inline const void* kernel_address(T* f) { return reinterpret_cast<const void*>(f); }
 }  // namespace pzn
 #define PZN_LAUNCH(kernel, grid, block, shmem, stream, ...)                                    \
   do {                                                                                         \
     if (__builtin_expect(pzn_ktimer_is_on, 0)) {                                               \
-      pzn::KSpan _span(reinterpret_cast<const void*>(&kernel), #kernel, stream);               \
+      pzn::KSpan _span(pzn::kernel_address(kernel), #kernel, stream);                          \
       hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                     \
     } else {                                                                                   \
       hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                     \

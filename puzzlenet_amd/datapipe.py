@@ -205,12 +205,12 @@ def _compact(raw, mask, cap):
     return torch.where((pos < count.unsqueeze(1)).unsqueeze(-1), packed, first.expand(-1, cap, -1)).contiguous(), count
 
 
-def fps_to_n(piece, count, start, n):
+def fps_to_n(piece, count, start, n, background=False):
     """dataset.py:1147-1163 on every piece of the batch: farthest point sampling from `start`, points returned in
     selection order.  piece [B,cap,3] from _compact (padding = copies of row 0)."""
     if int(piece.shape[1]) > 32768:
         raise _lib.PznUnsupported(f"fps_to_n: pieces of up to {piece.shape[1]} points (the FPS kernel holds <= 32768)")
-    idx = ops.farthest_point_sample(piece, n, start.to(torch.int64))
+    idx = ops.farthest_point_sample(piece, n, start.to(torch.int64), background=background, counts=count if background else None)
     return torch.gather(piece, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
 
 
@@ -234,10 +234,11 @@ def move(up, twist):
     return moved, g
 
 
-def make_pairs(raw, normal, z, start_up, start_down, twist, n=1024, k=128, cap=None):
+def make_pairs(raw, normal, z, start_up, start_down, twist, n=1024, k=128, cap=None, background=False):
     """raw [B,M,3] fp32 on the GPU + the draws -> the 8-tuple (down, moved_up, igt, up, down_boundary, up_boundary,
     down_mask, up_mask) and `ok` [B] (both pieces of the cut hold >= n points: the reference re-draws the cut
-    otherwise, dataset.py:1176-1180 — the caller re-draws for the rows where ok is False)."""
+    otherwise, dataset.py:1176-1180 — the caller re-draws for the rows where ok is False).  background=True: the sampling as
+    the small-footprint launch that skips the padding (for a side stream beside a training step: PairFeeder)."""
     if not raw.is_cuda:
         raise _lib.PznError("datapipe.make_pairs runs on the GPU (puzzlenet_amd has no CPU fallback)")
     raw = raw.to(torch.float32).contiguous()
@@ -249,11 +250,102 @@ def make_pairs(raw, normal, z, start_up, start_down, twist, n=1024, k=128, cap=N
     ok = (n_up >= n) & (n_down >= n) & (n_up <= cap) & (n_down <= cap)      # (a piece larger than `cap` would be truncated)
     # one FPS launch for both pieces of every sample (a workgroup per piece: 2B workgroups instead of 2 x B)
     both = fps_to_n(torch.cat([up_piece, down_piece], 0), torch.cat([n_up, n_down], 0),
-                    torch.cat([start_up.reshape(-1), start_down.reshape(-1)], 0), n)
+                    torch.cat([start_up.reshape(-1), start_down.reshape(-1)], 0), n, background=background)
     up, down = both[:B].contiguous(), both[B:].contiguous()
     downb, upb, down_mask, up_mask = boundary(down, up, k)
     moved, igt = move(up, twist)
     return (down, moved, igt, up, downb, upb, down_mask, up_mask), ok
+
+
+def cut_pairs(raw, normals, zs, u, twist, n=1024, k=128, cap=None):
+    """make_pairs for a loader that runs BESIDE the training step (PairFeeder): the cut with its re-draw (K candidate planes per
+    sample, the first valid one taken on the device), both pieces compacted and padded, the FPS start indices - one launch
+    (csrc/datapipe.hip, ops.cut_compact); sampling by the small-footprint FPS that skips the padding; boundary picks by
+    ops.topk_rows; masks by one launch.  raw [B,M,3]; normals [B,K,3], zs [B,K], u [B,2] float64 draws; twist [B,6].
+    -> ((down, moved_up, igt, up, down_boundary, up_boundary, down_mask, up_mask), ok [B], plane [B,4])"""
+    if not raw.is_cuda:
+        raise _lib.PznError("datapipe.cut_pairs runs on the GPU (puzzlenet_amd has no CPU fallback)")
+    B, M, _ = raw.shape
+    cap = M if cap is None else int(cap)
+    if cap > 32768:
+        raise _lib.PznUnsupported(f"cut_pairs: pieces of up to {cap} points (the FPS kernel holds <= 32768)")
+    pieces, counts, start, plane, ok = ops.cut_compact(raw, normals, zs, u, n, cap)
+    idx = ops.farthest_point_sample(pieces, n, start, background=True, counts=counts)          # dataset.py:1147-1163
+    both = ops.index_points(pieces, idx)
+    up, down = both[:B], both[B:]
+    cd_over_up, cd_over_down = ops.chamfer(down, up)                                             # dataset.py:1357-1367
+    top = ops.topk_rows(torch.cat([cd_over_up, cd_over_down], 0).neg_(), k)                      # [2B,k]: up picks, down picks
+    bnd = ops.index_points(both, top)
+    masks = ops.pick_mask(top, n)
+    g = se3.exp(twist.to(torch.float32))                                                         # transforms.py:176-186
+    moved = se3.transform_points(g, up)
+    return (down, moved, g, up, bnd[B:], bnd[:B], masks[B:], masks[:B]), ok & (counts[:B] >= n) & (counts[B:] >= n), plane
+
+
+class PairBatch(list):
+    """The 8-tuple of a training batch + `ready`: the event behind which its tensors exist (they were produced on the
+    feeder's stream), + `ok` [B] (a valid plane was among the candidates)."""
+    ready = None
+    ok = None
+    plane = None      # (normal [B,3], z [B]) float64: the plane each sample was cut with
+
+
+class PairFeeder:
+    """What the reference's DataLoader(num_workers=64) over CADDataset + MovedCADDataset2 does for the trainer (train.py:101-104,
+    dataset.py:1165-1190, 98-105): a FRESH batch of pairs per step from resident raw clouds - plane cut with re-draw, FPS of
+    both pieces to n points, boundary labels, random rigid motion - built by cut_pairs on a background stream, so that batch
+    k + 1 is cut and sampled while step k trains.  The host part of a batch is a handful of draws (K candidate planes, two
+    uniform numbers for the FPS start points, a twist) from PRIVATE generators and one pinned, asynchronous upload: nothing
+    in next_batch() waits for the device.  engine.TrainStep.step(next_batch=feeder.next_batch()) orders its streams behind
+    `ready` and keeps the tensors alive across the streams that read them."""
+
+    def __init__(self, raw, device, n=1024, k=128, mag=0.8, candidates=16, seed=0):
+        raw = torch.as_tensor(raw, dtype=torch.float32)
+        if raw.dim() != 3 or raw.shape[2] != 3:
+            raise _lib.PznError("PairFeeder: raw clouds as [B, M, 3]")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.PznError("PairFeeder runs on the GPU (puzzlenet_amd has no CPU fallback)")
+        self.raw = raw.to(self.device).contiguous()
+        self.n, self.k, self.mag, self.K = int(n), int(k), float(mag), int(candidates)
+        self.rng = np.random.RandomState(seed)
+        self.gen = torch.Generator().manual_seed(seed)
+        self.stream = torch.cuda.Stream(device=self.device)
+        B = self.raw.shape[0]
+        # one pinned staging block per batch in flight (two: the upload of batch k + 1 may still be queued when k + 2 is drawn)
+        self._width = self.K * 3 + self.K + 2 + 6
+        self._stage = [torch.empty((B, self._width), dtype=torch.float64, pin_memory=True) for _ in range(3)]
+        self._turn = 0
+        self._busy = [None] * 3
+
+    def next_batch(self):
+        B, K, n = self.raw.shape[0], self.K, self.n
+        st = self._stage[self._turn]
+        if self._busy[self._turn] is not None:
+            self._busy[self._turn].synchronize()          # (three batches back: long done)
+        h = st.numpy()
+        h[:, :3 * K] = self.rng.rand(B, 3 * K)                                  # plane normals, dataset.py:767
+        h[:, 3 * K:4 * K] = self.rng.rand(B, K) / 3                             # plane offsets, :769
+        h[:, 4 * K:4 * K + 2] = self.rng.rand(B, 2)                             # FPS start points as fractions of the piece sizes, :1153
+        x = torch.randn(B, 6, generator=self.gen, dtype=torch.float64)          # transforms.py:163-168
+        h[:, 4 * K + 2:] = (x / x.norm(p=2, dim=1, keepdim=True) * self.mag).numpy()
+        with torch.cuda.stream(self.stream):
+            d = st.to(self.device, non_blocking=True)
+            up_ev = torch.cuda.Event()
+            up_ev.record(self.stream)
+            self._busy[self._turn] = up_ev
+            tensors, ok, plane = cut_pairs(self.raw, d[:, :3 * K].reshape(B, K, 3), d[:, 3 * K:4 * K], d[:, 4 * K:4 * K + 2],
+                                           d[:, 4 * K + 2:], n=n, k=self.k)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        self._turn = (self._turn + 1) % 3
+        out = PairBatch(tensors)
+        out.ready, out.ok, out.plane = ready, ok, (plane[:, :3], plane[:, 3])
+        return out
+
+    def close(self):
+        self.stream.synchronize()
+        self._busy = [None] * 3
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -137,6 +137,9 @@ class TrainStep:
         this step's kernels instead of standing at the head of the next step; this step uses the plan the previous one
         left.  Work per step is unchanged (one sampling pass per step), only its place in the queue."""
         model = self.model
+        self._adopt(self.batch)
+        if next_batch is not None:
+            self._adopt(next_batch, plans_only=True)
         if self.prefetch and hasattr(model, "prefetch_plans"):
             if self._plans_ahead is None:      # first step: its own plan first (the start indices keep their order of draw)
                 self._plans_ahead = model.prefetch_plans(self.batch[0], self.batch[1])
@@ -150,6 +153,31 @@ class TrainStep:
         if next_batch is not None:
             self.batch = next_batch
         return self.loss
+
+    def _adopt(self, batch, plans_only=False):
+        """A batch produced on another stream (datapipe.PairBatch: `ready` event): its consumers' streams wait for it and the
+        caching allocator is told who reads it.  plans_only: the batch of the FOLLOWING step, which only the plan-prefetch
+        stream touches during this one."""
+        ready = getattr(batch, "ready", None)
+        if ready is None:
+            return
+        model = self.model
+        ps = getattr(model, "_plan_stream", None)
+        if plans_only:
+            if ps is None and self.prefetch and hasattr(model, "prefetch_plans"):
+                ps = model._plan_stream = torch.cuda.Stream()
+            streams = [ps] if ps is not None else []
+        else:
+            if getattr(model, "two_streams", False) and hasattr(model, "side_stream"):
+                model.side_stream()
+            streams = [torch.cuda.current_stream()] + [s_ for s_ in (getattr(model, "_side_stream", None),
+                                                                   getattr(model, "_emd_stream", None)) if s_ is not None]
+            batch.ready = None          # (adopted: from here on ordinary stream order covers it)
+        for s_ in streams:
+            s_.wait_event(ready)
+            for t in batch:
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(s_)
 
     def close(self):
         """Give the model back as it was handed in (a later direct model.training_step() returns {'loss': ...} again)."""

@@ -361,12 +361,7 @@ class TouchedRegraster(_Base):
             # to the side stream (the two are independent and most of their launches do not fill 256 CUs; autograd
             # replays each backward node on its forward stream, so the backward passes overlap as well).
             cur = torch.cuda.current_stream()
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream()
-                _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-                if _quiet is not None:
-                    _quiet(False)
-            side = self._side_stream
+            side = self.side_stream()
             side.wait_stream(cur)
             taken = self._take_plans(fpc, mrpc, (cur, side))
             if taken is not None:          # sampling + searches were done ahead (prefetch_plans): both encoders start at once
@@ -424,6 +419,15 @@ class TouchedRegraster(_Base):
         ffpcs = self.Encoder(fpc, plan_f)                                           # :710
         fmrpcs = self.Encoder2(mrpc, plan_m)                                        # :716
         return self._heads(ffpcs, fmrpcs, N, need, pose_hook)
+
+    def side_stream(self):
+        """The stream Encoder2 (and the N x N EMD) runs on, created on first use."""
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+            _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if _quiet is not None:
+                _quiet(False)
+        return self._side_stream
 
     def _heads(self, ffpcs, fmrpcs, N, need, pose_hook=None, side=None):
         """:723-759: pose head on the two global features, boundary heads on the per-point features.

@@ -84,6 +84,29 @@ class KernelTimer:
         return out
 
 
+def ktimer_start():
+    """Per-KERNEL device time from inside the library (pzn_ktimer_*, csrc/core.hip): from here on every kernel libpzn.so
+    launches is bracketed by its own HIP event pair on its own stream.  Measurement only (bench.py)."""
+    _lib.check(_lib.load().pzn_ktimer_collect() < 0, "pzn_ktimer_collect")      # (drop spans of an earlier window)
+    _lib.check(_lib.load().pzn_ktimer_enable(1), "pzn_ktimer_enable")
+
+
+def ktimer_stop():
+    """-> {kernel name as in a rocprofv3 trace (template arguments included): (launches, summed milliseconds)}."""
+    lib = _lib.load()
+    _lib.check(lib.pzn_ktimer_enable(0), "pzn_ktimer_enable")
+    n = lib.pzn_ktimer_collect()
+    if n < 0:
+        _lib.check(n, "pzn_ktimer_collect")
+    out = {}
+    buf = ctypes.create_string_buffer(512)
+    cnt, ms = ctypes.c_int(0), ctypes.c_double(0.0)
+    for i in range(n):
+        _lib.check(lib.pzn_ktimer_row(i, buf, 512, ctypes.byref(cnt), ctypes.byref(ms)), "pzn_ktimer_row")
+        out[buf.value.decode()] = (cnt.value, ms.value)
+    return out
+
+
 # tests set this to a list: every max-pool of the model path appends (kind, address of the layer's weight or None, arg-max
 # tensor) - "sa": [B,S,C2] neighbour slots of a set-abstraction level (weight = its second layer's), "gmax": [B,Nout] rows of
 # the out projection's max over the points (weight = the projection's), "maxpts": [B,C] rows of max_over_points
@@ -143,7 +166,10 @@ def square_distance(src, dst):
     return out
 
 
-def farthest_point_sample(xyz, npoint, start_idx):
+def farthest_point_sample(xyz, npoint, start_idx, background=False, counts=None):
+    """background=True: the same picks from the small-footprint launch (no LDS image of the cloud; pzn_fps_background_f32):
+    for sampling that runs on a side stream beside a training step (datapipe.PairFeeder); counts [B] int64: rows >= counts[b]
+    of cloud b are padding copies of its row 0 and are skipped."""
     xyz = _f32(xyz, "xyz")
     B, N, C = xyz.shape
     if C != 3:
@@ -151,7 +177,11 @@ def farthest_point_sample(xyz, npoint, start_idx):
     start_idx = _i64(start_idx, "start_idx")
     out = torch.empty((B, npoint), dtype=torch.int64, device=xyz.device)
     with _on(xyz.device):
-        _call("pzn_fps_f32", _p(xyz), B, N, int(npoint), _p(start_idx), _p(out), _stream())
+        if background:
+            counts = None if counts is None else _i64(counts, "counts")
+            _call("pzn_fps_background_f32", _p(xyz), B, N, int(npoint), _p(start_idx), _p(out), _p(counts), _stream())
+        else:
+            _call("pzn_fps_f32", _p(xyz), B, N, int(npoint), _p(start_idx), _p(out), _stream())
     return out
 
 
@@ -375,6 +405,36 @@ def topk_rows(x, k):
     with _on(x.device):
         _call("pzn_topk_rows_f32", _p(x), R, N, int(k), _p(idx), _stream())
     return idx
+
+
+def cut_compact(raw, normals, zs, u, n_min, cap):
+    """dataset.py:761-775 + 1176-1180 for a batch in one launch (pzn_cut_compact_f32): raw [B,M,3] f32, K candidate planes per
+    sample (normals [B,K,3], zs [B,K], float64), start fractions u [B,2] float64
+    -> (pieces [2B,cap,3]: up pieces then down pieces, counts [2B] int64, start [2B] int64, plane [B,4] float64, ok [B] bool)"""
+    raw = _f32(raw, "raw")
+    normals, zs, u = (_req(t, torch.float64, n_) for t, n_ in ((normals, "normals"), (zs, "zs"), (u, "u")))
+    B, M, _ = raw.shape
+    K = normals.shape[1]
+    dev = raw.device
+    pieces = torch.empty((2 * B, int(cap), 3), dtype=torch.float32, device=dev)
+    counts = torch.empty((2 * B,), dtype=torch.int64, device=dev)
+    start = torch.empty((2 * B,), dtype=torch.int64, device=dev)
+    plane = torch.empty((B, 4), dtype=torch.float64, device=dev)
+    ok = torch.empty((B,), dtype=torch.uint8, device=dev)
+    with _on(dev):
+        _call("pzn_cut_compact_f32", _p(raw), _p(normals), _p(zs), _p(u), B, M, K, int(n_min), int(cap), _p(pieces), _p(counts),
+              _p(start), _p(plane), _p(ok), _stream())
+    return pieces, counts, start, plane, ok.to(torch.bool)
+
+
+def pick_mask(idx, N):
+    """0/1 float masks [R,N] with ones at idx [R,k] (dataset.py:1363-1366), one launch."""
+    idx = _i64(idx, "idx")
+    R, k = idx.shape
+    mask = torch.empty((R, int(N)), dtype=torch.float32, device=idx.device)
+    with _on(idx.device):
+        _call("pzn_pick_mask_f32", _p(idx), R, k, int(N), _p(mask), _stream())
+    return mask
 
 
 class _Avg4(torch.autograd.Function):

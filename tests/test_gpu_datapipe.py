@@ -165,3 +165,95 @@ def test_make_pairs_solid_cuts(kind):
     np.testing.assert_allclose(igt.cpu().numpy(), g.cpu().numpy(), rtol=1e-6, atol=1e-6)
     want = torch.einsum("bij,bnj->bni", g[:, :3, :3], up) + g[:, :3, 3].unsqueeze(1)
     np.testing.assert_allclose(moved.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_pair_feeder_builds_fresh_batches_beside_the_training_step():
+    """datapipe.PairFeeder (the DataLoader's role, train.py:101-104): every next_batch() is a new valid 8-tuple cut from the
+    resident raw clouds on a background stream (each piece on its side of the chosen plane, rigid motion, 128-point boundary
+    masks), reproducible from the seed, and TrainStep.step(next_batch=...) trains on them without a host synchronisation."""
+    from oracle import model_ref as mr
+    from puzzlenet_amd import datapipe, engine
+    from puzzlenet_amd import model5_b as mb
+    dev = torch.device("cuda:0")
+    B, M, N = 6, 5000, 1024
+    rng = np.random.RandomState(3)
+    u = rng.randn(B, M, 3).astype(np.float32)
+    u /= np.linalg.norm(u, axis=2, keepdims=True)
+    raw = u * (0.25 + 0.2 * rng.rand(B, 1, 3).astype(np.float32))
+
+    def take(seed, count):
+        f = datapipe.PairFeeder(raw, dev, n=N, seed=seed, candidates=32)
+        out = [f.next_batch() for _ in range(count)]
+        f.close()
+        return out
+
+    a, b = take(11, 3), take(11, 3)
+    for x, y in zip(a, b):
+        assert all(torch.equal(s, t) for s, t in zip(x, y))                      # same seed, same batches
+    assert not torch.equal(a[0][0], a[1][0])                                       # a fresh cut every time
+    for batch in a:
+        assert bool(batch.ok.all())
+        down, moved, igt, up, downb, upb, down_mask, up_mask = batch
+        normal, z = batch.plane
+        side = lambda p: (p.double() * normal.unsqueeze(1)).sum(-1) + z.reshape(-1, 1)
+        assert bool((side(up) >= 0).all()) and bool((side(down) < 0).all())
+        assert down.shape == up.shape == (B, N, 3) and float((igt[:, 3] - torch.tensor([0., 0., 0., 1.], device=dev)).abs().max()) == 0
+        R = igt[:, :3, :3]
+        assert float((R.transpose(1, 2) @ R - torch.eye(3, device=dev)).abs().max()) < 1e-5
+        want = (R @ up.transpose(1, 2) + igt[:, :3, 3:]).transpose(1, 2)
+        assert float((moved - want).abs().max()) < 1e-5
+        assert bool((down_mask.sum(1) == 128).all()) and bool((up_mask.sum(1) == 128).all())
+        # every sampled point is one of the raw cloud's
+        rs = {tuple(r) for r in raw[0].tolist()}
+        assert all(tuple(r) in rs for r in up[0].cpu().tolist()[:50] + down[0].cpu().tolist()[:50])
+    feeder = datapipe.PairFeeder(raw, dev, n=N, seed=5)
+    torch.manual_seed(0)
+    model = mb.TouchedRegraster(mr.Cfg(loss_mode=1, num_points=N)).to(dev)
+    runner = engine.TrainStep(model, feeder.next_batch(), 1e-3, world=1)
+    losses = []
+    for _ in range(4):
+        losses.append(runner.step(next_batch=feeder.next_batch()))
+    torch.cuda.synchronize()
+    assert all(np.isfinite(float(l)) for l in losses) and len({round(float(l), 3) for l in losses}) > 1
+    assert bool(torch.isfinite(runner.grads.flat).all())
+    runner.close()
+    feeder.close()
+
+
+@pytest.mark.parametrize("B,M,K,n_min,cap", [(5, 5000, 8, 1024, 5000), (3, 777, 4, 100, 777), (2, 3000, 3, 1400, 2000), (1, 64, 2, 1, 64)])
+def test_cut_compact_equals_the_tensor_form(B, M, K, n_min, cap):
+    """ops.cut_compact (one launch: first valid of K candidate planes, stable partition, padding, start indices) against the
+    tensor statement of the same thing: plane_cut_mask (float64, numpy's summation order) per candidate, the first valid one,
+    datapipe._compact of both sides - pieces, counts, plane and ok bit for bit."""
+    from puzzlenet_amd import datapipe, ops
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(B * 131 + M)
+    raw = torch.from_numpy((rng.rand(B, M, 3).astype(np.float32) - 0.3)).to(dev)
+    normals = torch.from_numpy(rng.rand(B, K, 3)).to(dev)
+    zs = torch.from_numpy(rng.rand(B, K) / 3).to(dev)
+    u = torch.from_numpy(rng.rand(B, 2)).to(dev)
+    pieces, counts, start, plane, ok = ops.cut_compact(raw, normals, zs, u, n_min, cap)
+    torch.cuda.synchronize()
+    for b in range(B):
+        pick, valid, best = None, False, (-1, 0)
+        for k in range(K):
+            m = datapipe.plane_cut_mask(raw[b:b + 1], normals[b:b + 1, k], zs[b:b + 1, k])
+            up = int(m.sum())
+            if min(up, M - up) > best[0]:
+                best = (min(up, M - up), k)
+            if up >= n_min and M - up >= n_min:
+                pick, valid = k, True
+                break
+        pick = best[1] if pick is None else pick
+        assert plane[b].tolist() == normals[b, pick].tolist() + [float(zs[b, pick])]
+        m = datapipe.plane_cut_mask(raw[b:b + 1], normals[b:b + 1, pick], zs[b:b + 1, pick])
+        n_up = int(m.sum())
+        assert counts[b].item() == n_up and counts[B + b].item() == M - n_up
+        assert bool(ok[b]) == (valid and n_up <= cap and M - n_up <= cap)
+        for piece, mask, cnt in ((pieces[b], m, n_up), (pieces[B + b], ~m, M - n_up)):
+            if 0 < cnt <= cap:
+                want, _ = datapipe._compact(raw[b:b + 1], mask, cap)
+                assert torch.equal(piece, want[0])
+        for half, cnt in ((0, n_up), (1, M - n_up)):
+            s = start[half * B + b].item()
+            assert s == max(0, min(cnt - 1, int(np.floor(float(u[b, half]) * cnt))))

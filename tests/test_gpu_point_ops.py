@@ -132,7 +132,21 @@ def test_fps_vs_oracle(dev, B, N, S):
         xyz[:, N // 2] = xyz[:, 1]                      # an exact duplicate: tie in the arg-max
     start = rng.integers(0, N, size=B)
     got = ops.farthest_point_sample(_t(xyz, dev), S, _t(start, dev)).cpu().numpy()
-    assert np.array_equal(got, orc.farthest_point_sample(xyz, S, start))
+    want = orc.farthest_point_sample(xyz, S, start)
+    assert np.array_equal(got, want)
+    # the small-footprint launch of the data pipeline (no LDS image of the cloud): the same picks
+    got_bg = ops.farthest_point_sample(_t(xyz, dev), S, _t(start, dev), background=True).cpu().numpy()
+    assert np.array_equal(got_bg, want)
+    # ... and with padding declared (rows >= counts[b] are copies of row 0, datapipe._compact): the picks of the real rows alone
+    c = N // 2 + 3
+    if S <= c:
+        padded = xyz.copy()
+        padded[:, c:] = padded[:, :1]
+        st_c = start % c
+        got_c = ops.farthest_point_sample(_t(padded, dev), S, _t(st_c, dev), background=True,
+                                          counts=torch.full((B,), c, dtype=torch.int64, device=dev)).cpu().numpy()
+        assert np.array_equal(got_c, orc.farthest_point_sample(np.ascontiguousarray(xyz[:, :c]), S, st_c))
+        assert np.array_equal(got_c, ops.farthest_point_sample(_t(padded, dev), S, _t(st_c, dev)).cpu().numpy())
 
 
 @pytest.mark.parametrize("B,N,S,K", [(2, 1024, 512, 32), (2, 2048, 512, 32), (2, 512, 256, 32), (1, 4096, 512, 32),
