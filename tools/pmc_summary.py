@@ -43,8 +43,8 @@ def main():
     ap.add_argument("out")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--points", type=int, default=2048)
-    ap.add_argument("--steps-in-trace", type=int, default=11,
-                    help="1 warm-up + 2 timed + (1 + 3) one-stream instrumented + (1 + 3) two-stream instrumented steps")
+    ap.add_argument("--steps-in-trace", type=int, default=15,
+                    help="1 warm-up + 2 timed + (1 + 3) entry-point pass + (1 + 3) one-stream kernel pass + (1 + 3) two-stream kernel pass")
     a = ap.parse_args()
     import bench
     f, w = load(a.fetch), load(a.write)
