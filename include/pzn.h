@@ -396,13 +396,14 @@ int pzn_sa_level_bwd_rm_f32(const float* dout, const int32_t* argmax, const floa
  * dP[B*N, C1] (overwritten) — what pzn_sa_point_l1_bwd_f32 would make of dh — with dW1[:, 0:3] += dh^T (xyz[idx] - centre) and
  * db1 += column sums of dh (both ADDED to, db1 may be NULL).  The rows' gradient is computed where the two-launch form
  * loaded it (hit lists per group, sorted by arg-max row; W2 slice in LDS; gate from Pp and Q) and never written.
- * rows / pts: pzn_knn_inverse_lists of idx.  workspace: pzn_sa_level_bwd_pt_workspace_bytes(B, S, C2) bytes, 16-byte
+ * off / rows / pts: pzn_knn_inverse_lists of idx.  A wavefront owns whole points (round 6): every row of dP is written exactly
+ * once by plain stores, the rows of a point are summed in ascending row order: dP is the same bit for bit in every run.  workspace: pzn_sa_level_bwd_pt_workspace_bytes(B, S, C2) bytes, 16-byte
  * aligned.  PZN_EUNSUPPORTED for C1 % 128 != 0 or C2 not in {64, 128, 256}. */
 size_t pzn_sa_level_bwd_pt_workspace_bytes(int B, int S, int C2);
 int pzn_sa_level_bwd_pt_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
                             const float* Pp, const float* Q, const int64_t* idx, const float* xyz, const float* new_xyz,
-                            const int32_t* rows, const int32_t* pts, int B, int N, int S, int D, int C1, int C2, float* dP,
-                            float* dW2, float* db2, float* dW1, float* db1, int accumulate, void* workspace,
+                            const int32_t* off, const int32_t* rows, const int32_t* pts, int B, int N, int S, int D, int C1,
+                            int C2, float* dP, float* dW2, float* db2, float* dW1, float* db1, int accumulate, void* workspace,
                             pzn_stream_t stream);
 
 /* The per-point stem of the encoder in one launch each way (csrc/stem.hip, model5_b.py:447-448):

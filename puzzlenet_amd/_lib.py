@@ -124,7 +124,7 @@ SIGNATURES = {
     "pzn_sa_level_bwd_f32": (_c_i, [_c_f] * 8 + [_c_i] * 6 + [_c_f] * 5 + [_c_i, _c_f]),
     "pzn_sa_level_bwd_rm_f32": (_c_i, [_c_f] * 8 + [_c_i] * 6 + [_c_f] * 5 + [_c_i, _c_f, _c_f]),
     "pzn_sa_level_bwd_pt_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),
-    "pzn_sa_level_bwd_pt_f32": (_c_i, [_c_f] * 11 + [_c_i] * 6 + [_c_f] * 5 + [_c_i, _c_f, _c_f]),
+    "pzn_sa_level_bwd_pt_f32": (_c_i, [_c_f] * 12 + [_c_i] * 6 + [_c_f] * 5 + [_c_i, _c_f, _c_f]),
     "pzn_sa_point_l1_fwd_f32": (_c_i, [_c_f] * 6 + [_c_i] * 5 + [_c_f, _c_f]),
     "pzn_knn_inverse_lists": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f]),
     "pzn_sa_point_l1_bwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 5 + [_c_f] * 4),

@@ -153,14 +153,18 @@ __global__ __launch_bounds__(SP_T) void sa_point_l1_fwd_kernel(const float* __re
 }
 
 // Inverse neighbour lists of one cloud per workgroup: off[b][0..N] (exclusive prefix of the reference counts) and
-// rows[b][.] = the in-cloud row numbers (s*32 + k) grouped by the point they gathered.  Counters live in LDS.
+// rows[b][.] = the in-cloud row numbers (s*32 + k) grouped by the point they gathered, ascending within a point.  Counters live in LDS.
 constexpr int INV_T = 1024;
+// LROWS: the lists are built and sorted in LDS ([SK] ints behind the counters) and leave in one coalesced pass; otherwise (a
+// cloud whose S * K rows do not fit) they are built in global memory and sorted there.
+template <bool LROWS>
 __global__ __launch_bounds__(INV_T) void sa_inverse_lists_kernel(const int64_t* __restrict__ idx, int N, int SK,
                                                                  int32_t* __restrict__ off,
-                                                                 int32_t* __restrict__ rows,
+                                                                 int32_t* rows,
                                                                  int32_t* __restrict__ pts) {
-  extern __shared__ int cnt[];  // [N] counters, then [INV_T] scan scratch
+  extern __shared__ int cnt[];  // [N] counters, then [INV_T] scan scratch, then (LROWS) [SK] rows
   int* scan = cnt + N;
+  int* lrows = scan + INV_T;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int64_t* ib = idx + (size_t)b * SK;
   for (int j = tid; j < N; j += INV_T) cnt[j] = 0;
@@ -193,6 +197,7 @@ __global__ __launch_bounds__(INV_T) void sa_inverse_lists_kernel(const int64_t* 
     __syncthreads();
   }
   int run = scan[tid] - local;
+  const int first = run;              // this thread's points own the entries [first, last)
   int32_t* ob = off + (size_t)b * (N + 1);
   for (int j = j0; j < j1; ++j) {
     const int c = cnt[j];
@@ -200,24 +205,38 @@ __global__ __launch_bounds__(INV_T) void sa_inverse_lists_kernel(const int64_t* 
     cnt[j] = run;  // becomes the fill cursor
     run += c;
   }
+  const int last = run;
   if (tid == INV_T - 1) ob[N] = scan[INV_T - 1];
   __syncthreads();
   int32_t* rb = rows + (size_t)b * SK;
-  int32_t* pb = pts ? pts + (size_t)b * SK : nullptr;
+  int* dst = LROWS ? lrows : rb;
 #pragma unroll
   for (int u = 0; u < INV_R; ++u) {
     const int j = mine[u];
-    if (j >= 0) {
-      const int pos = atomicAdd(&cnt[j], 1);
-      rb[pos] = tid + u * INV_T;
-      if (pb) pb[pos] = j;
-    }
+    if (j >= 0) dst[atomicAdd(&cnt[j], 1)] = tid + u * INV_T;
   }
-  for (int i = tid + INV_R * INV_T; i < SK; i += INV_T) {
-    const int j = (int)ib[i];
-    const int pos = atomicAdd(&cnt[j], 1);
-    rb[pos] = i;
-    if (pb) pb[pos] = j;
+  for (int i = tid + INV_R * INV_T; i < SK; i += INV_T) dst[atomicAdd(&cnt[(int)ib[i]], 1)] = i;
+  // The fill places a point's rows in the order the atomic cursors were taken; sorted ascending, the per-point sums that walk
+  // these lists (csrc/sapool.hip) add in the same order in every run.  Thread t sorts the lists of its own points (8-16 rows
+  // each in the model: an insertion sort in place) and names the point of each of its entries.
+  __syncthreads();
+  int at = first;
+  for (int j = j0; j < j1; ++j) {
+    const int hi = cnt[j];            // (the cursor stands at the end of point j's list)
+    for (int i = at + 1; i < hi; ++i) {
+      const int v = dst[i];
+      int k = i - 1;
+      while (k >= at && dst[k] > v) dst[k + 1] = dst[k], --k;
+      dst[k + 1] = v;
+    }
+    if (pts)
+      for (int i = at; i < hi; ++i) pts[(size_t)b * SK + i] = j;
+    at = hi;
+  }
+  (void)last;
+  if (LROWS) {
+    __syncthreads();
+    for (int i = tid; i < SK; i += INV_T) rb[i] = lrows[i];
   }
 }
 
@@ -466,14 +485,20 @@ PZN_EXPORT int pzn_knn_inverse_lists(const int64_t* idx, int B, int N, int S, in
                                      int32_t* pts, pzn_stream_t stream) {
   PZN_CHECK_ARG(idx && off && rows && B > 0 && N > 0 && S > 0 && K > 0 && B <= 65535);
   PZN_CHECK_ARG((long)S * K < 2147483647L);
-  const size_t lds = sizeof(int) * ((size_t)N + INV_T);
-  if (lds > 150 * 1024) return PZN_EUNSUPPORTED;
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute((const void*)sa_inverse_lists_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-          hipSuccess)
+  const size_t base = sizeof(int) * ((size_t)N + INV_T);
+  if (base > 150 * 1024) return PZN_EUNSUPPORTED;
+  const size_t with_rows = base + sizeof(int) * (size_t)S * K;
+  const bool lrows = with_rows <= 150 * 1024;
+  const size_t lds = lrows ? with_rows : base;
+  const void* fn = lrows ? (const void*)sa_inverse_lists_kernel<true> : (const void*)sa_inverse_lists_kernel<false>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PZN_ELAUNCH;
-  PZN_LAUNCH(sa_inverse_lists_kernel, dim3((unsigned)B), dim3(INV_T), lds, pzn_hip_stream(stream), idx, N, S * K,
-                     off, rows, pts);
+  if (lrows)
+    PZN_LAUNCH(sa_inverse_lists_kernel<true>, dim3((unsigned)B), dim3(INV_T), lds, pzn_hip_stream(stream), idx, N, S * K, off,
+               rows, pts);
+  else
+    PZN_LAUNCH(sa_inverse_lists_kernel<false>, dim3((unsigned)B), dim3(INV_T), lds, pzn_hip_stream(stream), idx, N, S * K, off,
+               rows, pts);
   PZN_RETURN_LAUNCH_STATUS();
 }
 

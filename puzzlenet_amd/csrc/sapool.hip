@@ -91,16 +91,22 @@ struct PointArgs {
   const float* Q;           // [G][C1]
   const float* xyz;         // [B*N][3]
   const float* new_xyz;     // [G][3]
-  const int32_t* rows;      // [B*S*32] row of its cloud, sorted by point
+  const int32_t* off;       // [B][N+1] first list entry of every point of its cloud (pzn_knn_inverse_lists)
+  const int32_t* rows;      // [B*S*32] row of its cloud, sorted by point (rows of a point in ascending order)
   const int32_t* pts;       // [B*S*32] point of its cloud
-  float* dP;                // [B*N][C1], zero-initialised (list ends are added)
+  float* dP;                // [B*N][C1]: every row written exactly once, by the wavefront that owns the point
   float* dW1;               // [C1][ldw]: columns 0..2 += dh^T (xyz - centre)
   float* db1;               // [C1] += column sums of dh (may be NULL)
-  int N, S, C1, C2, ldw;
-  long entries;
+  int B, N, S, C1, C2, ldw;
+  int pc;                   // points per chunk (a wavefront's unit of work: whole points, ~64 list entries)
 };
 
 // NW wavefronts; lane l owns columns col0 + 2 l, 2 l + 1 of the workgroup's 128-column slice; GF rows in flight.
+// A wavefront owns WHOLE points (round 6): chunks of `pc` consecutive points of a cloud, their list entries walked in
+// order - the running sum of a point is stored once, by plain stores, when the walk moves on (points without a hit get their
+// zeros from the same wavefront): no atomics on dP, no zero fill in front of the launch, and - the lists being sorted -
+// the same summation order in every run.  (Round 5 walked 64-entry batches: a point whose list crossed a batch boundary
+// was added atomically by two wavefronts into a zero-filled row, three writes per such row.)
 template <int NW, int GF>
 __global__ __launch_bounds__(NW * 64) void pool_point_kernel(PointArgs p) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];      // [C2][PP_COLS], then reused for the final sums
@@ -112,110 +118,112 @@ __global__ __launch_bounds__(NW * 64) void pool_point_kernel(PointArgs p) {
   }
   __syncthreads();
   const int SK = p.S * 32;
-  const long nbatch = (p.entries + 63) >> 6;
-  // XCD-aware walk: workgroups x, x + 8, ... share an XCD; XCD x takes the x-th contiguous eighth of the batches (whole
+  const int cpc = (p.N + p.pc - 1) / p.pc;                  // chunks per cloud
+  const long nchunk = (long)p.B * cpc;
+  // XCD-aware walk: workgroups x, x + 8, ... share an XCD; XCD x takes the x-th contiguous eighth of the chunks (whole
   // clouds: their P' / Q tables and hit lists are gathered through ONE L2)
-  long bt = (long)blockIdx.x * NW + wave, nw = (long)gridDim.x * NW, bt_end = nbatch;
+  long ck = (long)blockIdx.x * NW + wave, nw = (long)gridDim.x * NW, ck_end = nchunk;
   if ((gridDim.x & 7) == 0) {
-    const long per = (nbatch + 7) >> 3;
+    const long per = (nchunk + 7) >> 3;
     const int xcd = blockIdx.x & 7;
-    bt = xcd * per + (long)(blockIdx.x >> 3) * NW + wave, nw = (long)(gridDim.x >> 3) * NW;
-    bt_end = (xcd + 1) * per < nbatch ? (xcd + 1) * per : nbatch;
+    ck = xcd * per + (long)(blockIdx.x >> 3) * NW + wave, nw = (long)(gridDim.x >> 3) * NW;
+    ck_end = (xcd + 1) * per < nchunk ? (xcd + 1) * per : nchunk;
   }
   v2f ax = {0.f, 0.f}, ay = ax, az = ax, ab = ax;
   const float* wl = wlds + 2 * lane;
-  for (; bt < bt_end; bt += nw) {
-    const long e = bt * 64 + lane;
-    int gp = -1, grp = 0, nh = 0, hb = 0;      // global point, global group, hits of the row, first hit
-    float dx = 0.f, dy = 0.f, dz = 0.f;
-    if (e < p.entries) {
-      const long b = e / SK;
-      const int rid = p.rows[e], pj = p.pts[e];
-      grp = (int)(b * p.S + (rid >> 5));
-      gp = (int)(b * p.N + pj);
-      const uint16_t* rs = p.rstart + (size_t)grp * RS_LD + (rid & 31);
-      const int r0 = rs[0], r1 = rs[1];
-      nh = r1 - r0, hb = grp * C2 + r0;
-      const float* q = p.xyz + (size_t)gp * 3;
-      const float* c = p.new_xyz + (size_t)grp * 3;
-      dx = q[0] - c[0], dy = q[1] - c[1], dz = q[2] - c[2];
-    }
-    const int nr = (int)min((long)64, p.entries - bt * 64);
-    const int first = __builtin_amdgcn_readlane(gp, 0), last = __builtin_amdgcn_readlane(gp, nr - 1);
-    int cur = first;
+  for (; ck < ck_end; ck += nw) {
+    const int b = (int)(ck / cpc);
+    const int q0 = (int)(ck - (long)b * cpc) * p.pc, q1 = q0 + p.pc < p.N ? q0 + p.pc : p.N;
+    const int32_t* ob = p.off + (size_t)b * (p.N + 1);
+    const int e0 = ob[q0], e1 = ob[q1];                     // (scalar loads: the chunk's entries, in-cloud numbering)
+    const int gq0 = b * p.N + q0, gq1 = b * p.N + q1;
+    int cur = gq0;                                          // the point whose sum `acc` holds; every point < cur is written
     v2f acc = {0.f, 0.f};
-    auto flush = [&](int point) {
-      float* o = p.dP + (size_t)point * C1 + col0 + 2 * lane;
-      if (point == first || point == last) {      // its list may continue in a neighbouring batch
-        atomicAdd(o, acc.x);
-        atomicAdd(o + 1, acc.y);
-      } else {
-        *reinterpret_cast<v2f*>(o) = acc;
+    float* dcol = p.dP + col0 + 2 * lane;
+    for (int eb = e0; eb < e1; eb += 64) {                  // usually one trip
+      const int e = eb + lane;
+      int gp = -1, grp = 0, nh = 0, hb = 0;      // global point, global group, hits of the row, first hit
+      float dx = 0.f, dy = 0.f, dz = 0.f;
+      if (e < e1) {
+        const int rid = p.rows[(size_t)b * SK + e];
+        grp = b * p.S + (rid >> 5);
+        gp = b * p.N + p.pts[(size_t)b * SK + e];
+        const uint16_t* rs = p.rstart + (size_t)grp * RS_LD + (rid & 31);
+        const int r0 = rs[0], r1 = rs[1];
+        nh = r1 - r0, hb = grp * C2 + r0;
+        const float* qp = p.xyz + (size_t)gp * 3;
+        const float* c = p.new_xyz + (size_t)grp * 3;
+        dx = qp[0] - c[0], dy = qp[1] - c[1], dz = qp[2] - c[2];
       }
-      ab += acc;
-      acc = v2f{0.f, 0.f};
-    };
-    // rows with hits, GF of them in flight: hit list (lane h holds hit h), Q row of the group and P' row of the point
-    uint64_t todo = __ballot(nh > 0);
-    while (todo) {      // wave-uniform
-      int ru[GF];
-      uint2 hv[GF];
-      v2f qv[GF], pv[GF];
+      // rows with hits, GF of them in flight: hit list (lane h holds hit h), Q row of the group and P' row of the point
+      uint64_t todo = __ballot(nh > 0);
+      while (todo) {      // wave-uniform
+        int ru[GF];
+        uint2 hv[GF];
+        v2f qv[GF], pv[GF];
 #pragma unroll
-      for (int u = 0; u < GF; ++u) {
-        ru[u] = todo ? __builtin_ctzll(todo) : -1;
-        todo &= todo - 1;
-      }
-#pragma unroll
-      for (int u = 0; u < GF; ++u) {
-        hv[u] = make_uint2(0u, 0u);
-        qv[u] = pv[u] = v2f{0.f, 0.f};
-        if (ru[u] >= 0) {
-          const int n_ = __builtin_amdgcn_readlane(nh, ru[u]), b_ = __builtin_amdgcn_readlane(hb, ru[u]);
-          if (lane < n_) hv[u] = p.hits[(size_t)b_ + lane];
-          qv[u] = *reinterpret_cast<const v2f*>(p.Q + (size_t)__builtin_amdgcn_readlane(grp, ru[u]) * C1 + col0 + 2 * lane);
-          pv[u] = *reinterpret_cast<const v2f*>(p.Pp + (size_t)__builtin_amdgcn_readlane(gp, ru[u]) * C1 + col0 + 2 * lane);
+        for (int u = 0; u < GF; ++u) {
+          ru[u] = todo ? __builtin_ctzll(todo) : -1;
+          todo &= todo - 1;
         }
-      }
 #pragma unroll
-      for (int u = 0; u < GF; ++u) {
-        if (ru[u] < 0) continue;      // wave-uniform
-        const int r = ru[u];
-        const int n_ = __builtin_amdgcn_readlane(nh, r), b_ = __builtin_amdgcn_readlane(hb, r);
-        v2f s0 = {0.f, 0.f}, s1 = s0;
-        uint2 cur_h = hv[u];
-        for (int h0 = 0; h0 < n_; h0 += 64) {      // (more than 64 channels on one row: rare)
-          if (h0 > 0) cur_h = (h0 + lane < n_) ? p.hits[(size_t)b_ + h0 + lane] : make_uint2(0u, 0u);
-          const int m_ = min(64, n_ - h0);
-          int h = 0;
-          for (; h + 1 < m_; h += 2) {      // two hits per trip: two LDS reads in flight
-            const int c0 = __builtin_amdgcn_readlane((int)cur_h.x, h), c1 = __builtin_amdgcn_readlane((int)cur_h.x, h + 1);
-            const float g0 = bcastf(__uint_as_float(cur_h.y), h), g1 = bcastf(__uint_as_float(cur_h.y), h + 1);
-            const v2f w0 = *reinterpret_cast<const v2f*>(wl + c0 * PP_COLS);
-            const v2f w1 = *reinterpret_cast<const v2f*>(wl + c1 * PP_COLS);
-            s0 += g0 * w0;
-            s1 += g1 * w1;
-          }
-          if (h < m_) {
-            const int c0 = __builtin_amdgcn_readlane((int)cur_h.x, h);
-            const float g0 = bcastf(__uint_as_float(cur_h.y), h);
-            s0 += g0 * *reinterpret_cast<const v2f*>(wl + c0 * PP_COLS);
+        for (int u = 0; u < GF; ++u) {
+          hv[u] = make_uint2(0u, 0u);
+          qv[u] = pv[u] = v2f{0.f, 0.f};
+          if (ru[u] >= 0) {
+            const int n_ = __builtin_amdgcn_readlane(nh, ru[u]), b_ = __builtin_amdgcn_readlane(hb, ru[u]);
+            if (lane < n_) hv[u] = p.hits[(size_t)b_ + lane];
+            qv[u] = *reinterpret_cast<const v2f*>(p.Q + (size_t)__builtin_amdgcn_readlane(grp, ru[u]) * C1 + col0 + 2 * lane);
+            pv[u] = *reinterpret_cast<const v2f*>(p.Pp + (size_t)__builtin_amdgcn_readlane(gp, ru[u]) * C1 + col0 + 2 * lane);
           }
         }
-        v2f row = s0 + s1;
-        const v2f gate = pv[u] + qv[u];      // the forward's own expression: relu(P'[j] + Q[g]) is on where this is > 0
-        row.x = gate.x > 0.f ? row.x : 0.f, row.y = gate.y > 0.f ? row.y : 0.f;
-        const int pj = __builtin_amdgcn_readlane(gp, r);
-        if (pj != cur) {  // wave-uniform
-          flush(cur);
-          cur = pj;
+#pragma unroll
+        for (int u = 0; u < GF; ++u) {
+          if (ru[u] < 0) continue;      // wave-uniform
+          const int r = ru[u];
+          const int n_ = __builtin_amdgcn_readlane(nh, r), b_ = __builtin_amdgcn_readlane(hb, r);
+          v2f s0 = {0.f, 0.f}, s1 = s0;
+          uint2 cur_h = hv[u];
+          for (int h0 = 0; h0 < n_; h0 += 64) {      // (more than 64 channels on one row: rare)
+            if (h0 > 0) cur_h = (h0 + lane < n_) ? p.hits[(size_t)b_ + h0 + lane] : make_uint2(0u, 0u);
+            const int m_ = min(64, n_ - h0);
+            int h = 0;
+            for (; h + 1 < m_; h += 2) {      // two hits per trip: two LDS reads in flight
+              const int c0 = __builtin_amdgcn_readlane((int)cur_h.x, h), c1 = __builtin_amdgcn_readlane((int)cur_h.x, h + 1);
+              const float g0 = bcastf(__uint_as_float(cur_h.y), h), g1 = bcastf(__uint_as_float(cur_h.y), h + 1);
+              const v2f w0 = *reinterpret_cast<const v2f*>(wl + c0 * PP_COLS);
+              const v2f w1 = *reinterpret_cast<const v2f*>(wl + c1 * PP_COLS);
+              s0 += g0 * w0;
+              s1 += g1 * w1;
+            }
+            if (h < m_) {
+              const int c0 = __builtin_amdgcn_readlane((int)cur_h.x, h);
+              const float g0 = bcastf(__uint_as_float(cur_h.y), h);
+              s0 += g0 * *reinterpret_cast<const v2f*>(wl + c0 * PP_COLS);
+            }
+          }
+          v2f row = s0 + s1;
+          const v2f gate = pv[u] + qv[u];      // the forward's own expression: relu(P'[j] + Q[g]) is on where this is > 0
+          row.x = gate.x > 0.f ? row.x : 0.f, row.y = gate.y > 0.f ? row.y : 0.f;
+          const int pj = __builtin_amdgcn_readlane(gp, r);
+          if (pj != cur) {  // wave-uniform: the walk has left `cur` (and every point up to pj - 1 has no further row)
+            *reinterpret_cast<v2f*>(dcol + (size_t)cur * C1) = acc;
+            ab += acc;
+            acc = v2f{0.f, 0.f};
+            for (int t = cur + 1; t < pj; ++t) *reinterpret_cast<v2f*>(dcol + (size_t)t * C1) = acc;
+            cur = pj;
+          }
+          const float rx = bcastf(dx, r), ry = bcastf(dy, r), rz = bcastf(dz, r);
+          acc += row;
+          ax += rx * row, ay += ry * row, az += rz * row;
         }
-        const float rx = bcastf(dx, r), ry = bcastf(dy, r), rz = bcastf(dz, r);
-        acc += row;
-        ax += rx * row, ay += ry * row, az += rz * row;
       }
     }
-    flush(cur);
+    // the chunk's last points: the running sum, then zeros for the points nobody gathered or that won no channel
+    *reinterpret_cast<v2f*>(dcol + (size_t)cur * C1) = acc;
+    ab += acc;
+    acc = v2f{0.f, 0.f};
+    for (int t = cur + 1; t < gq1; ++t) *reinterpret_cast<v2f*>(dcol + (size_t)t * C1) = acc;
   }
   // dW1[:, 0:3] and db1: the four per-column sums of the workgroup's wavefronts meet in LDS (the W2 slice is not needed
   // any more), one set of atomics per workgroup
@@ -255,10 +263,11 @@ PZN_EXPORT size_t pzn_sa_level_bwd_pt_workspace_bytes(int B, int S, int C2) {
 // lists of idx (pzn_knn_inverse_lists).  PZN_EUNSUPPORTED for shapes the kernels do not take (C1 % 128, C2 not 64 / 128 / 256).
 PZN_EXPORT int pzn_sa_level_bwd_pt_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
                                        const float* Pp, const float* Q, const int64_t* idx, const float* xyz,
-                                       const float* new_xyz, const int32_t* rows, const int32_t* pts, int B, int N, int S, int D,
+                                       const float* new_xyz, const int32_t* off, const int32_t* rows, const int32_t* pts, int B, int N,
+                                       int S, int D,
                                        int C1, int C2, float* dP, float* dW2, float* db2, float* dW1, float* db1, int accumulate,
                                        void* workspace, pzn_stream_t stream) {
-  PZN_CHECK_ARG(dout && argmax && out && W2 && Pp && Q && idx && xyz && new_xyz && rows && pts && dP && dW2 && db2 && dW1 && workspace);
+  PZN_CHECK_ARG(dout && argmax && out && W2 && Pp && Q && idx && xyz && new_xyz && off && rows && pts && dP && dW2 && db2 && dW1 && workspace);
   PZN_CHECK_ARG(B > 0 && N > 0 && S > 0 && D >= 0 && C1 > 0 && C2 > 0 && (long)B * N < 2147483647L);
   PZN_CHECK_ARG((long)B * S * 32 < 2147483647L && (long)B * S * C2 < 2147483647L);
   if (C1 % PP_COLS != 0 || !(C2 == 64 || C2 == 128 || C2 == 256)) return PZN_EUNSUPPORTED;
@@ -285,8 +294,10 @@ PZN_EXPORT int pzn_sa_level_bwd_pt_f32(const float* dout, const int32_t* argmax,
     PZN_LAUNCH((pool_hits_kernel<2>), hgrid, dim3(PH_T), 0, st, dout, argmax, out, G, hits, rstart);
   else
     PZN_LAUNCH((pool_hits_kernel<4>), hgrid, dim3(PH_T), 0, st, dout, argmax, out, G, hits, rstart);
-  if (pzn_zero_async(dP, (size_t)B * N * C1, st) != PZN_OK) return PZN_ELAUNCH;      // points nobody gathered; list ends add
-  PointArgs a{hits, rstart, W2, Pp, Q, xyz, new_xyz, rows, pts, dP, dW1, db1, N, S, C1, C2, 3 + D, (long)B * S * 32};
+  // points per chunk: ~64 list entries (S * 32 / N per point on average)
+  int pc = (int)(64L * N / ((long)S * 32));
+  pc = pc < 1 ? 1 : (pc > 32 ? 32 : pc);
+  PointArgs a{hits, rstart, W2, Pp, Q, xyz, new_xyz, off, rows, pts, dP, dW1, db1, B, N, S, C1, C2, 3 + D, pc};
   const int ny = C1 / PP_COLS;
   const size_t lds = (size_t)C2 * PP_COLS * sizeof(float);      // >= the final sums' 16 x 4 x 128 floats for C2 >= 64
   static const int gf = [] { const char* e = getenv("PZN_PP_GF"); return e ? atoi(e) : 8; }();      // tuning aid: rows in flight

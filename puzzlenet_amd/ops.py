@@ -1843,7 +1843,7 @@ class _SaLevelFused(torch.autograd.Function):
                 ws = torch.empty((_lib.load().pzn_sa_level_bwd_pt_workspace_bytes(B, S, C2) + 3) // 4, dtype=torch.float32, device=dev)
                 try:
                     _call("pzn_sa_level_bwd_pt_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(P), _p(Q), _p(idx), _p(xyz), _p(new_xyz),
-                          _p(rows), _p(pts), B, N, S, D, C1, C2, _p(dP), _p(dW2), _p(db2), _p(dW1), _p(db1), int(direct), _p(ws),
+                          _p(off), _p(rows), _p(pts), B, N, S, D, C1, C2, _p(dP), _p(dW2), _p(db2), _p(dW1), _p(db1), int(direct), _p(ws),
                           _stream(), flops=2 * R * (2 * C1 * C2))
                 except _lib.PznUnsupported:
                     by_point = False
