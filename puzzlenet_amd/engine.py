@@ -170,8 +170,7 @@ class TrainStep:
         else:
             if getattr(model, "two_streams", False) and hasattr(model, "side_stream"):
                 model.side_stream()
-            streams = [torch.cuda.current_stream()] + [s_ for s_ in (getattr(model, "_side_stream", None),
-                                                                   getattr(model, "_emd_stream", None)) if s_ is not None]
+            streams = [torch.cuda.current_stream()] + [s_ for s_ in (getattr(model, "_side_stream", None),) if s_ is not None]
             batch.ready = None          # (adopted: from here on ordinary stream order covers it)
         for s_ in streams:
             s_.wait_event(ready)

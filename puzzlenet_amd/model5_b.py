@@ -190,7 +190,7 @@ class PCTransformer_nonsort(nn.Module):
         return x2, self._mark_f2f(f2f), second
 
     def chain_fused_ok(self, f2f):
-        return _ATTN_FUSED and f2f.is_cuda and ops.attention_chain_fused_supported(
+        return f2f.is_cuda and ops.attention_chain_fused_supported(
             f2f, self.atten1.mlpq.weight.shape[0], self.out.weight)
 
     def forward(self, xyz, sa_plan=None, x_feature=None):
@@ -205,13 +205,7 @@ class PCTransformer_nonsort(nn.Module):
             (out, attention, f_global), = ops.attention_chain_fused([f2f], [self._block_params()], [self.out.weight], [self.out.bias],
                                                                    need_out=self.need_out, map_strips=self.attn_strips)
             return f_global, x2, attention, out, x_feature
-        if _ATTN_CHAIN and f2f.is_cuda and ops.attention_chain_supported(f2f, self.atten1.mlpq.weight.shape[0], self.out.weight):
-            # :462-474 as one autograd node: no concatenation, no gradient-accumulation adds between the blocks
-            out, attention, f_global = ops.attention_chain_out(
-                f2f, [(a.mlpq.weight, a.mlpq.bias, a.mlpk.weight, a.mlpk.bias, a.mlpv.weight, a.mlpv.bias, a.out.weight,
-                       a.out.bias) for a in blocks], self.out.weight, self.out.bias)
-            return f_global, x2, attention, out, x_feature                                       # (:475 inside the node)
-        else:
+        if True:      # any other shape: the four blocks as modules, as the reference composes them
             att1, attention1 = self.atten1(f2f)
             att2, attention2 = self.atten2(att1)
             att3, attention3 = self.atten3(att2)
@@ -227,20 +221,13 @@ class PCTransformer_nonsort(nn.Module):
         return f_global, x2, attention, out, x_feature
 
 
-_ATTN_STRIPS = os.environ.get("PZN_ATTN_STRIPS", "1") != "0"     # tuning aid: 0 = training_step gets the full [B,256,256] mean maps too
-_ATTN_CHAIN = os.environ.get("PZN_ATTN_CHAIN", "1") != "0"     # tuning aid: 0 = four autograd nodes + cat + linear
-_ATTN_FUSED = os.environ.get("PZN_ATTN_FUSED", "1") != "0"     # tuning aid: 0 = the composed block kernels (gemm.hip)
-# 1 = both encoders' chains in the same launches on one stream.  Measured slower than one chain per encoder and stream
-# (10.5 vs 10.2 ms per step in round 3, 8.2 vs 7.9 in round 4): a single encoder's launch is 128 workgroups, one per CU, so the two streams
-# already fill the chip, and the joint launches take the stems' overlap away.
-_ATTN_DUAL = os.environ.get("PZN_ATTN_DUAL", "0") != "0"
-_EMD_OWN_STREAM = int(os.environ.get("PZN_EMD_OWN_STREAM", "0"))   # tuning aid: 1 = the N x N EMD on a third stream, 2 = a high-priority one
-# 1 = the per-point stem (:447-448) as one launch each way (csrc/stem.hip, ops.stem) instead of 2 linear + 2 BatchNorm launches
-# each way: 24 launches per step become 6, 7 passes over the 33.5 MB activations become 2; 7.02 against 7.10 ms per step on the
-# same box (its first form, vector FMAs fed by LDS broadcasts, lost: 7.42 against 7.31).  0 = the four launches.
-_STEM_FUSED = os.environ.get("PZN_STEM_FUSED", "1") != "0"
-_STEM_TWO = os.environ.get("PZN_STEM_TWO", "1") != "0"     # tuning aid: 0 = one name for the stem's output, autograd adds its two gradients
-_EMD_SIDE = int(os.environ.get("PZN_EMD_SIDE", "2"))     # tuning aid: 0 = the N x N EMD on the main stream, 1 = forked right after the pose head, 2 = after the heads (measured best)
+# training_step takes nothing but the row mean of the two attention maps (model5_b.py:937-942): on the fused attention path it
+# asks for them as [B,16,256] strip column sums with that same row mean (tests compare both forms through this flag)
+_ATTN_STRIPS = True
+# the per-point stem (:447-448) as one launch each way (csrc/stem.hip, ops.stem) where its shape is supported (B <= 64); False =
+# always the four launches (2 linear + 2 BatchNorm) it replaces, which larger batches use (tests compare the two through this flag)
+_STEM_FUSED = True
+_STEM_TWO = True     # the stem's output under two names (set abstraction / boundary branch): their gradients are added inside its backward launch
 
 
 def _seq(*dims):
@@ -294,13 +281,6 @@ def _run_seq_cat_global(seq, x, g):
     return _run_seq(mods[2:], y)
 
 
-# 1 = stem / tail of the two encoders enqueued alternately.  Measured 1.5 % slower (10.23 vs 10.08 ms per step, same box): the
-# host runs ahead of the GPU in steady state, so the enqueue order buys nothing and the finer interleaving overlaps worse.
-_ENC_INTERLEAVE = os.environ.get("PZN_ENC_INTERLEAVE", "0") != "0"
-_HEAD_STREAMS = os.environ.get("PZN_HEAD_STREAMS", "1") != "0"     # tuning aid: 0 = both boundary heads on the main stream
-_HEAD_SPLIT = os.environ.get("PZN_HEAD_SPLIT", "1") != "0"     # tuning aid: 0 = repeat + cat + Linear as the reference composes it
-
-
 class TouchedRegraster(_Base):
     """model5_b.py:519-1519 (live path only)."""
 
@@ -322,7 +302,6 @@ class TouchedRegraster(_Base):
         self.MLPFpcb = _seq(128, 64, 32, 2)
         self.two_streams = True        # Encoder2 on a side stream (GPU only); False = everything on the current stream
         self._side_stream = None
-        self._emd_stream = None
         self._plan_stream = None
         self._plan_cache = None        # (fpc, mrpc, plans, event, versions) from prefetch_plans, handed over by use_plans
         self.grad_marker = None        # engine.TrainStep (N > 1), see _heads
@@ -381,40 +360,19 @@ class TouchedRegraster(_Base):
                     lvl[0].record_stream(cur)
             for t_ in (xf_m if isinstance(xf_m, tuple) else (xf_m,)):
                 t_.record_stream(side)
-            if _ATTN_FUSED and _ATTN_DUAL and ops.attention_chain_fused_available():
-                # the two encoders' stems on two streams, then BOTH attention chains in the same launches on this one
-                # (a launch of one encoder is 128 workgroups of eight wavefronts, one per CU: half the chip)
+            if plan_f is None:
+                # no hoisted sampling (fused_sa off, or clouds that carry gradients): each sample_and_group draws its own FPS
+                # start indices, so the encoders are CALLED in the reference's order (:710 before :716) - the draws of a
+                # seeded run are the reference's; the streams are the same either way
+                ffpcs = self.Encoder(fpc, plan_f, xf_f)                         # :710
                 with torch.cuda.stream(side):
-                    x2_m, f2f_m, xf_m2 = self.Encoder2.stem(mrpc, plan_m, xf_m)
-                x2_f, f2f_f, xf_f2 = self.Encoder.stem(fpc, plan_f, xf_f)
-                cur.wait_stream(side)
-                for t in (x2_m, f2f_m, xf_m2):
-                    t.record_stream(cur)
-                rf, rm = ops.attention_chain_fused(
-                    [f2f_f, f2f_m], [self.Encoder._block_params(), self.Encoder2._block_params()],
-                    [self.Encoder.out.weight, self.Encoder2.out.weight], [self.Encoder.out.bias, self.Encoder2.out.bias],
-                    need_out=False, map_strips=self.Encoder.attn_strips)
-                ffpcs = (rf[2], x2_f, rf[1], rf[0], xf_f2)
-                fmrpcs = (rm[2], x2_m, rm[1], rm[0], xf_m2)
-                return self._heads(ffpcs, fmrpcs, N, need, pose_hook)
-            if _ENC_INTERLEAVE:
-                stem_f = self.Encoder.stem(fpc, plan_f, xf_f)                       # :710
-                with torch.cuda.stream(side):
-                    stem_m = self.Encoder2.stem(mrpc, plan_m, xf_m)                 # :716
-                ffpcs = self.Encoder.tail(*stem_f)
-                with torch.cuda.stream(side):
-                    fmrpcs = self.Encoder2.tail(*stem_m)
+                    fmrpcs = self.Encoder2(mrpc, plan_m, xf_m)                  # :716
             else:
                 with torch.cuda.stream(side):
-                    fmrpcs = self.Encoder2(mrpc, plan_m, xf_m)                      # :716
-                ffpcs = self.Encoder(fpc, plan_f, xf_f)                             # :710
-            if _HEAD_STREAMS and _HEAD_SPLIT:
-                return self._heads(ffpcs, fmrpcs, N, need, pose_hook, side=side)
-            cur.wait_stream(side)
-            for t in fmrpcs:
-                if isinstance(t, torch.Tensor):
-                    t.record_stream(cur)
-            return self._heads(ffpcs, fmrpcs, N, need, pose_hook)
+                    fmrpcs = self.Encoder2(mrpc, plan_m, xf_m)                  # :716
+                ffpcs = self.Encoder(fpc, plan_f, xf_f)                         # :710
+            # Encoder2's outputs are joined inside _heads: the second cloud's boundary head stays on the side stream
+            return self._heads(ffpcs, fmrpcs, N, need, pose_hook, side=side)
         plan_f, plan_m = self._sa_plans(fpc, mrpc)
         ffpcs = self.Encoder(fpc, plan_f)                                           # :710
         fmrpcs = self.Encoder2(mrpc, plan_m)                                        # :716
@@ -478,7 +436,7 @@ class TouchedRegraster(_Base):
         non_sg_fmrpc = _run_seq(self.MLPLocalPreRpc, non_sg_fmrpc)                  # :739
         # :741 — the reference takes the max of non_sg_fmrpc for BOTH globals (its bug, kept)
         g_max = ops.max_over_points(non_sg_fmrpc).unsqueeze(1)      # one reduction serves both (identical) globals
-        if _HEAD_SPLIT and non_sg_ffpc.is_cuda:
+        if non_sg_ffpc.is_cuda:
             # :745-752 without the repeat and the concatenation: the first layer of a head = a per-point product on the
             # local features + a per-cloud bias from the global one (ops._CatGlobalLinearRelu)
             de_fpcb = _run_seq_cat_global(self.MLPFpcb, non_sg_ffpc, g_max).permute(0, 2, 1)      # :748, :751-752
@@ -603,13 +561,9 @@ class TouchedRegraster(_Base):
         pose = {}
 
         def fork_emd(o):
-            if _EMD_SIDE and self.two_streams and o.is_cuda and self._side_stream is not None:
+            if self.two_streams and o.is_cuda and self._side_stream is not None:
                 cur = torch.cuda.current_stream()
                 side = self._side_stream
-                if _EMD_OWN_STREAM:      # not behind / in front of the second cloud's boundary head and its backward
-                    if self._emd_stream is None:
-                        self._emd_stream = torch.cuda.Stream(priority=-1 if _EMD_OWN_STREAM == 2 else 0)
-                    side = self._emd_stream
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     pose['emd'] = earth_mover_distance(pose['de_mrpc'], rpc, transpose=False)
@@ -620,13 +574,10 @@ class TouchedRegraster(_Base):
         def pose_hook(o):
             pose['mat'] = se3.exp(o).to(mrpc)                                       # :947
             pose['de_mrpc'] = se3.transform_points(pose['mat'], mrpc)               # :948-952 (transform of the transposed view)
-            if _EMD_SIDE == 1:
-                fork_emd(o)
 
         out, t, x2, attention, mrpc_x2, mrpc_attention, de_fpcb, de_mrpcb = self.predict5(
             batch, batch_size, training=True, need=True, pose_hook=pose_hook, attn_strips=_ATTN_STRIPS)      # :933
-        if _EMD_SIDE == 2:
-            fork_emd(out)
+        fork_emd(out)      # forked after the heads were enqueued (right after the pose head measured slower)
 
         if attention.is_cuda:      # :937-942: only the FIRST of the 32 top-k indices is used: mean over rows + arg-max, one launch
             x2att1 = x2[:, ops.colmean_argmax(attention)[1]]

@@ -1090,137 +1090,6 @@ def attention_block(x, wq, bq, wk, bk, wv, bv, wo, bo):
     return _AttentionBlock.apply(x, wq, bq, wk, bk, wv, bv, wo, bo)
 
 
-class _AttnChainOut(torch.autograd.Function):
-    """model5_b.py:462-474 as ONE autograd node: the four chained layerAttention blocks, the mean of their four maps, and
-    the out projection of cat([att1, att2, att3, att4, f2f]).  The concatenation is never built — out = sum_i x_i W_i^T + b
-    over the five 256-column slices of W_out (pzn_linear_slice_fwd / _wgrad) — and the backward forms dy W_out once and
-    adds each block's input gradient to its slice (one add per block instead of autograd's narrow copies + accumulations).
-    The max over the points (:475) is part of the node: when `out` itself carries no gradient — the case in predict5,
-    which uses only the maximum — the projection's backward is one non-zero per (cloud, channel) and runs as sparse row
-    operations (pzn_linear_maxpts_*: 168 MFLOP instead of 2 x 43 GFLOP per encoder).
-    inputs: x[B,L,E], 4 x (wq,bq,wk,bk,wv,bv,wo,bo), w_out[Nout, 5E], b_out
-    -> (out[B,L,Nout], attention[B,L,L], f_global[B,Nout])"""
-
-    @staticmethod
-    def forward(ctx, x, *params):
-        x = _f32(x, "x")
-        ps = [_f32(t, "param") for t in params]
-        blocks = [ps[8 * i: 8 * i + 8] for i in range(4)]
-        w_out, b_out = ps[32], ps[33]
-        B, L, E = x.shape
-        dk = blocks[0][0].shape[0]
-        Nout = w_out.shape[0]
-        dev = x.device
-        M = B * L
-        mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
-        saved, cur = [], x.reshape(M, E)
-        with _on(dev):
-            for (wq, bq, wk, bk, wv, bv, wo, bo) in blocks:
-                q, k, v = mk(M, dk), mk(M, dk), mk(M, E)
-                attn, r, yo, out = mk(B, L, L), mk(M, E), mk(M, E), mk(M, E)
-                _call("pzn_attn_block_fwd_f32", _p(cur), _p(wq), _p(bq), _p(wk), _p(bk), _p(wv), _p(bv), _p(wo), _p(bo),
-                      B, L, E, dk, _p(q), _p(k), _p(v), _p(attn), _p(r), _p(yo), _p(out), _stream(),
-                      flops=2 * M * E * (2 * dk + 2 * E) + 2 * B * L * L * (dk + E))
-                saved.append((cur, q, k, v, attn, r, yo))
-                cur = out
-            attention = mk(B, L, L)
-            _call("pzn_avg4_f32", _p(saved[0][4]), _p(saved[1][4]), _p(saved[2][4]), _p(saved[3][4]), attention.numel(),
-                  _p(attention), _stream())
-            y = mk(M, Nout)
-            xs = [saved[1][0], saved[2][0], saved[3][0], cur, x.reshape(M, E)]      # att1 .. att4, f2f (cat order, :466)
-            for i, xi in enumerate(xs):
-                _call("pzn_linear_slice_fwd_f32", _p(xi), w_out.data_ptr() + 4 * E * i, 5 * E, _p(b_out), M, E, Nout,
-                      int(i > 0), _p(y), _stream(), flops=2 * M * E * Nout)
-            f_global = mk(B, Nout)                                                  # :475 torch.max(out, dim=1)[0]
-            arg = torch.empty((B, Nout), dtype=torch.int32, device=dev)
-            _call("pzn_maxpool_points_fwd_f32", _p(y), B, L, Nout, _p(f_global), _p(arg), _stream())
-        ctx.save_for_backward(*([t for blk in saved for t in blk] + [cur] + ps + [arg]))
-        ctx.dims = (B, L, E, dk, Nout)
-        ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(attention)      # (it only feeds an arg-max; its gradient would be zero)
-        return y.view(B, L, Nout), attention, f_global
-
-    @staticmethod
-    def backward(ctx, dy, _dattention, dfg):
-        B, L, E, dk, Nout = ctx.dims
-        t = ctx.saved_tensors
-        saved = [t[7 * i: 7 * i + 7] for i in range(4)]
-        att4 = t[28]
-        ps = t[29:63]
-        arg = t[63]
-        blocks = [ps[8 * i: 8 * i + 8] for i in range(4)]
-        w_out, b_out = ps[32], ps[33]
-        dev = att4.device
-        M = B * L
-        mk = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
-        # Only f_global used downstream (predict5, model5_b.py:723): the gradient of `out` has one non-zero per
-        # (cloud, channel) and both products of the out projection are sparse row operations (csrc/maxptsbwd.hip).
-        sparse = dy is None and dfg is not None and (5 * E) % 64 == 0 and L <= 600
-        if sparse:
-            dfg = _f32(dfg, "df_global")
-        else:
-            if dfg is not None:      # `out` itself carries a gradient too: dense products on the summed gradient
-                dmax = mk(B, L, Nout)
-                with _on(dev):
-                    _call("pzn_maxpool_points_bwd_f32", _p(_f32(dfg, "df_global")), _p(arg), B, L, Nout, _p(dmax), _stream())
-                dy = dmax if dy is None else dy + dmax
-            if dy is None:
-                dy = torch.zeros((M, Nout), dtype=torch.float32, device=dev)
-            dy = _f32(dy, "dy").reshape(M, Nout)
-        xs = [saved[1][0], saved[2][0], saved[3][0], att4, saved[0][0]]           # inputs of the five slice products
-        sink_w, sink_b = _sink(w_out, ctx.needs_input_grad[33]), _sink(b_out, ctx.needs_input_grad[34])
-        direct_out = sink_w is not None and sink_b is not None
-        dW_out = sink_w if direct_out else torch.zeros_like(w_out)
-        db_out = sink_b if direct_out else torch.zeros_like(b_out)
-        grads = [None] * 34
-        nbytes = _lib.load().pzn_attn_block_bwd_workspace_bytes(B, L, E, dk)
-        ws = mk((nbytes + 3) // 4)
-        with _on(dev):
-            G = mk(M, 5 * E)
-            if sparse:
-                segs = (ctypes.c_void_p * 5)(*[_p(xi) for xi in xs])
-                _call("pzn_linear_maxpts_wgrad_f32", _p(dfg), _p(arg), segs, 5, E, B, L, Nout, _p(dW_out), _p(db_out), _stream())
-                mws = torch.empty((_lib.load().pzn_linear_maxpts_workspace_bytes(B, Nout) + 3) // 4, dtype=torch.int32, device=dev)
-                _call("pzn_linear_maxpts_dgrad_f32", _p(dfg), _p(arg), _p(w_out), B, L, 5 * E, Nout, _p(mws), _p(G), _stream())
-            else:
-                for i, xi in enumerate(xs):      # dW_out[:, slice i] += dy^T x_i;  db_out += column sums (once)
-                    _call("pzn_linear_slice_wgrad_f32", _p(dy), _p(xi), M, E, Nout, dW_out.data_ptr() + 4 * E * i, 5 * E,
-                          _p(db_out) if i == 0 else None, _stream(), flops=2 * M * E * Nout)
-                # dy W_out for all five slices in ONE product (a product per slice would stream dy five times)
-                _call("pzn_linear_dgrad_f32", _p(dy), None, _p(w_out), M, 5 * E, Nout, None, _p(G), _stream(),
-                      flops=2 * M * 5 * E * Nout)
-            g = G[:, 3 * E: 4 * E].contiguous()      # gradient of att4: its slice of the projection only
-            for i in (3, 2, 1, 0):
-                xin, q, k, v, attn, r, yo = saved[i]
-                wq, bq, wk, bk, wv, bv, wo, bo = blocks[i]
-                sinks = [_sink(p_, ctx.needs_input_grad[1 + 8 * i + j]) for j, p_ in enumerate(blocks[i])]
-                direct = all(s_ is not None for s_ in sinks)
-                gp = sinks if direct else [torch.empty_like(p_) for p_ in blocks[i]]
-                dx = mk(M, E)
-                _call("pzn_attn_block_bwd_f32", _p(xin), _p(wq), _p(wk), _p(wv), _p(wo), _p(q), _p(k), _p(v), _p(attn), _p(r),
-                      _p(yo), _p(g), None, B, L, E, dk, _p(ws), _p(dx), *[_p(z) for z in gp], int(direct), _stream(),
-                      flops=2 * (2 * M * E * (2 * dk + 2 * E)) + 2 * B * L * L * (2 * dk + 2 * E))
-                if not direct:
-                    grads[8 * i: 8 * i + 8] = gp
-                # gradient of this block's input = its slice of the projection + what the block passed back
-                sl = i - 1 if i > 0 else 4            # att_i sits in slice i-1, f2f in slice 4
-                g = torch.add(G[:, sl * E: (sl + 1) * E], dx)
-        if not direct_out:
-            grads[32], grads[33] = dW_out, db_out
-        return (g.view(B, L, E),) + tuple(grads)
-
-
-def attention_chain_out(x, blocks, w_out, b_out):
-    """blocks: four 8-tuples (wq, bq, wk, bk, wv, bv, wo, bo)
-    -> (out[B,L,Nout], mean attention map[B,L,L], f_global[B,Nout] = max of out over the points)"""
-    flat = [p_ for blk in blocks for p_ in blk]
-    return _AttnChainOut.apply(x, *flat, w_out, b_out)
-
-
-def attention_chain_supported(x, dk, w_out):
-    return attention_block_supported(x, dk) and w_out.shape[1] == 5 * x.shape[2] and x.shape[2] % 4 == 0
-
-
 def _ptrs(ts):
     """Array of device pointers, one per problem, for the nprob entry points."""
     return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
@@ -1457,86 +1326,6 @@ def attention_chain_fused(xs, blocks_list, w_outs, b_outs, need_out=True, map_st
     return [(res[3 * i] if res[3 * i].numel() else None, res[3 * i + 1], res[3 * i + 2]) for i in range(len(xs))]
 
 
-class _SaMlpMax(torch.autograd.Function):
-    """Set abstraction as the encoder runs it (model5_b.py:449-454 / :456-461): group the K=32 neighbours
-    (pointnet_util.py:123-132), two shared-MLP layers, max over K — on padded rows {dx,dy,dz,0,f...}, with
-    the first layer's feature block as clean D-wide GEMMs.  idx=None: the kNN search (pointnet_util.py:118-119)
-    runs fused with the grouping in one launch.  Gradients: features and weights (the point coordinates
-    carry none on this path)."""
-
-    @staticmethod
-    def forward(ctx, xyz, feat, new_xyz, idx, w1, b1, w2, b2):
-        xyz, feat, new_xyz = _f32(xyz, "xyz"), _f32(feat, "points"), _f32(new_xyz, "new_xyz")
-        idx = None if idx is None else _i64(idx, "idx")
-        w1, b1, w2, b2 = _f32(w1, "w1"), _f32(b1, "b1"), _f32(w2, "w2"), _f32(b2, "b2")
-        B, N, _ = xyz.shape
-        S = new_xyz.shape[1]
-        K = 32 if idx is None else idx.shape[2]
-        D = feat.shape[-1]
-        C1, C2 = w1.shape[0], w2.shape[0]
-        if K != 32 or D % 4 != 0 or w1.shape[1] != 3 + D:
-            raise _lib.PznError(f"sa_mlp_max: needs K=32, D%4==0, w1[C1,3+D]; got K={K}, D={D}, w1{tuple(w1.shape)}")
-        dev = xyz.device
-        R = B * S
-        xg = torch.empty((R * 32, 4 + D), dtype=torch.float32, device=dev)
-        fuse_knn = idx is None
-        if fuse_knn:
-            idx = torch.empty((B, S, 32), dtype=torch.int64, device=dev)
-        w1p = torch.cat([w1[:, :3], torch.zeros((C1, 1), dtype=torch.float32, device=dev), w1[:, 3:]], dim=1).contiguous()
-        h = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
-        out = torch.empty((R, C2), dtype=torch.float32, device=dev)
-        arg = torch.empty((R, C2), dtype=torch.int32, device=dev)
-        with _on(dev):
-            if fuse_knn:     # neighbour search + group in one launch (idx is an output)
-                _call("pzn_knn_group_pad_f32", _p(xyz), _p(feat), _p(new_xyz), B, N, S, D, _p(idx), _p(xg), _stream())
-            else:
-                _call("pzn_group_pad_fwd_f32", _p(xyz), _p(feat), _p(new_xyz), _p(idx), B, N, S, K, D, _p(xg), _stream())
-            _call("pzn_sharedmlp_max_fwd_f32", _p(xg), _p(w1p), _p(b1), _p(w2), _p(b2), R, 4 + D, C1, C2,
-                  _p(h), _p(out), _p(arg), _stream(), flops=2 * R * 32 * ((3 + D) * C1 + C1 * C2))
-        ctx.save_for_backward(xg, w1p, w2, h, out, arg, idx)
-        ctx.dims = (B, N, S, K, D, R, C1, C2)
-        ctx.param_refs = (w1, b1, w2, b2)
-        return out.reshape(B, S, C2)
-
-    @staticmethod
-    def backward(ctx, dout):
-        xg, w1p, w2, h, out, arg, idx = ctx.saved_tensors
-        B, N, S, K, D, R, C1, C2 = ctx.dims
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
-            raise _lib.PznError("sa_mlp_max: gradients w.r.t. point coordinates are not provided on the fused "
-                                "encoder path; use pointnet_util.sample_and_group + ops.shared_mlp_max")
-        dout = _f32(dout, "dout").reshape(R, C2)
-        dev = dout.device
-        need_feat = ctx.needs_input_grad[1]
-        dh = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
-        sinks = [_sink(t, ctx.needs_input_grad[4 + i]) for i, t in enumerate(ctx.param_refs)]
-        direct = all(s_ is not None for s_ in sinks)
-        if direct:
-            dW1, db1, dW2, db2 = sinks
-        else:
-            dW1 = torch.empty((C1, 3 + D), dtype=torch.float32, device=dev)
-            db1 = torch.empty((C1,), dtype=torch.float32, device=dev)
-            dW2 = torch.empty_like(w2)
-            db2 = torch.empty((C2,), dtype=torch.float32, device=dev)
-        dfeat = None
-        # layer 2 is the sparse pass (one non-zero per group and channel: R*C2 row-axpys each way), layer 1 the
-        # dense matrix-core products
-        fl = 2 * R * (2 * C1 * C2) + 2 * R * 32 * ((3 + D) * C1 + (D * C1 if need_feat else 0))
-        with _on(dev):
-            if need_feat:   # feature gradient scatter-added from the GEMM epilogue: the [R*32, D] rows are never written
-                dfeat = torch.zeros((B, N, D), dtype=torch.float32, device=dev)
-                rows_ws = torch.empty((R * 32, D), dtype=torch.float32, device=dev)   # fallback scratch (allocator only)
-                _call("pzn_sa_mlp_max_bwd_scatter_f32", _p(xg), _p(w1p), _p(w2), _p(h), _p(out), _p(arg), _p(dout),
-                      _p(idx), B, N, S, D, C1, C2, _p(dh), _p(rows_ws), _p(dfeat), _p(dW1), _p(db1), _p(dW2), _p(db2),
-                      int(direct), _stream(), flops=fl)
-            else:
-                _call("pzn_sa_mlp_max_bwd_f32", _p(xg), _p(w1p), _p(w2), _p(h), _p(out), _p(arg), _p(dout), R, D, C1, C2,
-                      _p(dh), None, _p(dW1), _p(db1), _p(dW2), _p(db2), int(direct), _stream(), flops=fl)
-        if direct:
-            return None, dfeat, None, None, None, None, None, None
-        return None, dfeat, None, None, dW1, db1, dW2, db2
-
-
 class _BnPointsRelu(torch.autograd.Function):
     """relu(BatchNorm1d(num_points)(x)) for x[B, N, C] (model5_b.py:424, :447-448: the BN channel axis is the point
     index) as one launch each way (csrc/bnpoints.hip) instead of BN + clamp and their two backward kernels."""
@@ -1673,98 +1462,12 @@ def stem(xyz, lin1, bn1, lin2, bn2, two=False):
                             use_batch, bn1.momentum, bn1.eps, bn2.momentum, bn2.eps, bool(two))
 
 
-class _SaMlpMaxPoint(torch.autograd.Function):
-    """The same set-abstraction level (model5_b.py:449-454 / :456-461) with the first shared-MLP layer computed per
-    POINT (csrc/sapoint.hip): a grouped row is {xyz[j] - centre, feat[j]}, so W1 row = W1[:,0:3] (xyz[j] - centre) +
-    (feat W1[:,3:]^T)[j]: the feature product runs on B*N rows instead of B*S*32, the grouped tensor is never written
-    and the layer becomes a gather of per-point rows; backward sums dh over each point's inverse neighbour list.
-    Same result as _SaMlpMax up to the order of the fp32 sum."""
-
-    @staticmethod
-    def forward(ctx, xyz, feat, new_xyz, idx, w1, b1, w2, b2):
-        xyz, feat, new_xyz = _f32(xyz, "xyz"), _f32(feat, "points"), _f32(new_xyz, "new_xyz")
-        idx = None if idx is None else _i64(idx, "idx")
-        w1, b1, w2, b2 = _f32(w1, "w1"), _f32(b1, "b1"), _f32(w2, "w2"), _f32(b2, "b2")
-        B, N, _ = xyz.shape
-        S = new_xyz.shape[1]
-        D = feat.shape[-1]
-        C1, C2 = w1.shape[0], w2.shape[0]
-        dev = xyz.device
-        R = B * S
-        w_f = w1[:, 3:].contiguous()
-        P = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
-        h = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
-        out = torch.empty((R, C2), dtype=torch.float32, device=dev)
-        arg = torch.empty((R, C2), dtype=torch.int32, device=dev)
-        with _on(dev):
-            _call("pzn_linear_fwd_f32", _p(feat), _p(w_f), None, B * N, D, C1, 0, _p(P), _stream(),
-                  flops=2 * B * N * D * C1)
-            if idx is None:
-                idx = torch.empty((B, S, 32), dtype=torch.int64, device=dev)
-                _call("pzn_knn_f32", _p(xyz), _p(new_xyz), B, N, S, 32, _p(idx), _stream())
-            _call("pzn_sa_point_l1_fwd_f32", _p(xyz), _p(new_xyz), _p(idx), _p(P), _p(w1), _p(b1), B, N, S, D, C1,
-                  _p(h), _stream())
-            _call("pzn_linear_maxpool_fwd_f32", _p(h), _p(w2), _p(b2), R, C1, C2, _p(out), _p(arg), _stream(),
-                  flops=2 * R * 32 * C1 * C2)
-        ctx.save_for_backward(xyz, feat, new_xyz, idx, w1, w_f, w2, h, out, arg, P, b1)
-        ctx.dims = (B, N, S, D, R, C1, C2)
-        ctx.param_refs = (w1, b1, w2, b2)
-        return out.reshape(B, S, C2)
-
-    @staticmethod
-    def backward(ctx, dout):
-        xyz, feat, new_xyz, idx, w1, w_f, w2, h, out, arg, P, b1 = ctx.saved_tensors
-        B, N, S, D, R, C1, C2 = ctx.dims
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
-            raise _lib.PznError("sa_mlp_max: gradients w.r.t. point coordinates are not provided on the fused "
-                                "encoder path; use pointnet_util.sample_and_group + ops.shared_mlp_max")
-        dout = _f32(dout, "dout").reshape(R, C2)
-        dev = dout.device
-        need_feat = ctx.needs_input_grad[1]
-        sinks = [_sink(t, ctx.needs_input_grad[4 + i]) for i, t in enumerate(ctx.param_refs)]
-        direct = all(s_ is not None for s_ in sinks)
-        if direct:
-            dW1, db1, dW2, db2 = sinks
-        else:
-            dW1 = torch.zeros((C1, 3 + D), dtype=torch.float32, device=dev)    # the per-point kernel adds into these
-            db1 = torch.zeros((C1,), dtype=torch.float32, device=dev)
-            dW2 = torch.empty_like(w2)
-            db2 = torch.empty((C2,), dtype=torch.float32, device=dev)
-        dh = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
-        off = torch.empty((B * (N + 1),), dtype=torch.int32, device=dev)
-        rows = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
-        pts = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
-        dP = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
-        dfeat = None
-        with _on(dev):
-            if _SA_REGEN:    # the ReLU gate of h regenerated from P / idx (L2) instead of read from h (HBM)
-                _call("pzn_sa_pooled_layer_bwd_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(h), _p(P), _p(idx), _p(xyz),
-                      _p(new_xyz), _p(w1), _p(b1), B, N, S, D, C1, C2, _p(dh), _p(dW2), _p(db2), int(direct), _stream(),
-                      flops=2 * R * (2 * C1 * C2))
-            else:
-                _call("pzn_pooled_layer_bwd_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(h), R, C1, C2, _p(dh), _p(dW2),
-                      _p(db2), int(direct), _stream(), flops=2 * R * (2 * C1 * C2))
-            _call("pzn_knn_inverse_lists", _p(idx), B, N, S, 32, _p(off), _p(rows), _p(pts), _stream())
-            _call("pzn_sa_point_l1_bwd_f32", _p(dh), _p(xyz), _p(new_xyz), _p(rows), _p(pts), B, N, S, D, C1, _p(dP),
-                  _p(dW1), _p(db1), _stream())
-            if need_feat:
-                dfeat = torch.empty((B, N, D), dtype=torch.float32, device=dev)
-                _call("pzn_linear_dgrad_f32", _p(dP), None, _p(w_f), B * N, D, C1, None, _p(dfeat), _stream(),
-                      flops=2 * B * N * D * C1)
-            # dW1[:, 3:] += dP^T feat, straight into the parameter's column slice (no temporary, no tensor add)
-            _call("pzn_linear_slice_wgrad_f32", _p(dP), _p(feat), B * N, D, C1, dW1.data_ptr() + 12, 3 + D, None, _stream(),
-                  flops=2 * B * N * D * C1)
-        if direct:
-            return None, dfeat, None, None, None, None, None, None
-        return None, dfeat, None, None, dW1, db1, dW2, db2
-
-
 class _SaLevelFused(torch.autograd.Function):
     """The set-abstraction level (model5_b.py:449-454 / :456-461) with the first layer per point and its rows never in
     memory: W1[:,0:3] (xyz[j] - centre) is split into a per-point and a per-group part, so a grouped row is
     relu(Pp[idx] + Q[group]) with Pp = feat W1[:,3:]^T + W1[:,0:3] xyz and Q = b1 - W1[:,0:3] centre; the rows are generated
     inside the matrix-core kernel's operand loader forward (pzn_sa_level_fwd_f32) and inside both sparse passes backward
-    (pzn_sa_level_bwd_f32).  Same result as _SaMlpMaxPoint / _SaMlpMax up to the order of the fp32 sum; no h tensor
+    (pzn_sa_level_bwd_pt_f32).  Same result as group + shared_mlp_max up to the order of the fp32 sum; no h tensor
     (537 MB per level and cloud at B = 64)."""
 
     @staticmethod
@@ -1793,7 +1496,7 @@ class _SaLevelFused(torch.autograd.Function):
             ws_bytes = _lib.load().pzn_sa_level_fwd_workspace_bytes(C1, C2)
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
             done = False
-            if ws is not None and _SA_PACKED:      # streamed-weights kernel: the weight split and the level as two entry points
+            if ws is not None:      # streamed-weights kernel: the weight split and the level as two entry points
                 try:
                     _call("pzn_sa_level_prep_weights_f32", _p(w2), C1, C2, _p(ws), _stream())
                     _call("pzn_sa_level_fwd_packed_f32", _p(P), _p(Q), _p(idx), _p(b2), B, N, S, C1, C2, _p(out), _p(arg),
@@ -1835,46 +1538,14 @@ class _SaLevelFused(torch.autograd.Function):
         pts = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
         dP = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
         dfeat = None
-        by_point = _SA_BYPOINT
-        if by_point:
-            # round 5 (csrc/sapool.hip): input-gradient pass and per-point sum in one walk by point, dh never in memory
-            with _on(dev):
-                _call("pzn_knn_inverse_lists", _p(idx), B, N, S, 32, _p(off), _p(rows), _p(pts), _stream())
-                ws = torch.empty((_lib.load().pzn_sa_level_bwd_pt_workspace_bytes(B, S, C2) + 3) // 4, dtype=torch.float32, device=dev)
-                try:
-                    _call("pzn_sa_level_bwd_pt_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(P), _p(Q), _p(idx), _p(xyz), _p(new_xyz),
-                          _p(off), _p(rows), _p(pts), B, N, S, D, C1, C2, _p(dP), _p(dW2), _p(db2), _p(dW1), _p(db1), int(direct), _p(ws),
-                          _stream(), flops=2 * R * (2 * C1 * C2))
-                except _lib.PznUnsupported:
-                    by_point = False
-        if not by_point:
-            dh = torch.empty((R * 32, C1), dtype=torch.float32, device=dev)
         with _on(dev):
-            if by_point:
-                pass
-            elif _SA_ROWMASK:
-                # rows of dh that won no channel are exactly zero (half of them at level 1): neither written nor read
-                rmask = torch.empty((R,), dtype=torch.int32, device=dev)
-                if SA_ROWMASK_STATS is not None:      # measurement only (bench.py): the masks, to count the rows that exist
-                    SA_ROWMASK_STATS.append((rmask, C1))
-                _call("pzn_sa_level_bwd_rm_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(P), _p(Q), _p(idx), _p(new_xyz), B, N, S,
-                      D, C1, C2, _p(dh), _p(dW2), _p(db2), _p(dW1), _p(db1), int(direct), _p(rmask), _stream(),
-                      flops=2 * R * (2 * C1 * C2))
-            else:
-                rmask = None
-                _call("pzn_sa_level_bwd_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(P), _p(Q), _p(idx), _p(new_xyz), B, N, S, D,
-                      C1, C2, _p(dh), _p(dW2), _p(db2), _p(dW1), _p(db1), int(direct), _stream(), flops=2 * R * (2 * C1 * C2))
-            if not by_point:
-                _call("pzn_knn_inverse_lists", _p(idx), B, N, S, 32, _p(off), _p(rows), _p(pts), _stream())
-            # dP = per-point sums of dh; dW1[:,0:3] += dh^T xyz[idx] (centres = NULL: their part went through Q above)
-            if by_point:
-                pass
-            elif rmask is not None:
-                _call("pzn_sa_point_l1_bwd_rm_f32", _p(dh), _p(xyz), None, _p(rows), _p(pts), B, N, S, D, C1, _p(dP),
-                      _p(dW1), None, _p(rmask), _stream())
-            else:
-                _call("pzn_sa_point_l1_bwd_f32", _p(dh), _p(xyz), None, _p(rows), _p(pts), B, N, S, D, C1, _p(dP),
-                      _p(dW1), None, _stream())
+            # csrc/sapool.hip: weight gradients of the pooled layer + the rows' gradient summed per point in one walk by point
+            # (the rows' gradient itself is never in memory); sa_mlp_max() has checked the shapes the kernels take
+            _call("pzn_knn_inverse_lists", _p(idx), B, N, S, 32, _p(off), _p(rows), _p(pts), _stream())
+            ws = torch.empty((_lib.load().pzn_sa_level_bwd_pt_workspace_bytes(B, S, C2) + 3) // 4, dtype=torch.float32, device=dev)
+            _call("pzn_sa_level_bwd_pt_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(P), _p(Q), _p(idx), _p(xyz), _p(new_xyz),
+                  _p(off), _p(rows), _p(pts), B, N, S, D, C1, C2, _p(dP), _p(dW2), _p(db2), _p(dW1), _p(db1), int(direct), _p(ws),
+                  _stream(), flops=2 * R * (2 * C1 * C2))
             if need_feat:
                 dfeat = torch.empty((B, N, D), dtype=torch.float32, device=dev)
                 _call("pzn_linear_dgrad_f32", _p(dP), None, _p(w_f), B * N, D, C1, None, _p(dfeat), _stream(),
@@ -1887,23 +1558,27 @@ class _SaLevelFused(torch.autograd.Function):
         return None, dfeat, None, None, dW1, db1, dW2, db2
 
 
-SA_ROWMASK_STATS = None      # bench.py sets this to a list: every masked level backward appends (row mask [B*S] int32, C1)
-_SA_PACKED = os.environ.get("PZN_SA_PACKED", "1") != "0"     # tuning aid: 0 = weight split inside pzn_sa_level_fwd_ws_f32
-_SA_ROWMASK = os.environ.get("PZN_SA_ROWMASK", "1") != "0"     # tuning aid: 0 = every row of dh written and read
-_SA_BYPOINT = os.environ.get("PZN_SA_BYPOINT", "1") != "0"     # tuning aid: 0 = rounds 2-4's two launches with dh in memory between them
-_SA_REGEN = os.environ.get("PZN_SA_REGEN", "1") != "0"     # tuning aid: 0 = the pooled backward reads its gate from h
-_SA_POINT = os.environ.get("PZN_SA_POINT", "1") != "0"     # tuning aid: 0 = the grouped-row path (_SaMlpMax)
-_SA_FUSED = os.environ.get("PZN_SA_FUSED", "1") != "0"     # tuning aid: 0 = per-point first layer WITH its rows in memory (_SaMlpMaxPoint)
+def sa_level_fused_supported(feat, idx, w1, w2):
+    """The shapes the per-point set-abstraction kernels take, decided BEFORE anything is launched (forward: pzn_sa_prep_f32 +
+    pzn_sa_level_fwd_*; backward: pzn_sa_level_bwd_pt_f32): 32 neighbours, a first layer of 128 or 256 channels over
+    [xyz | features], a second layer of 64 / 128 / 256 channels, the split-precision matrix-core path."""
+    K = 32 if idx is None else idx.shape[2]
+    return (K == 32 and w1.shape[0] in (128, 256) and w1.shape[1] == 3 + feat.shape[-1] and w2.shape[0] in (64, 128, 256)
+            and w2.shape[1] == w1.shape[0] and _lib.load().pzn_gemm_get_precision() != 0)
 
 
 def sa_mlp_max(xyz, feat, new_xyz, idx, w1, b1, w2, b2):
-    K = 32 if idx is None else idx.shape[2]
-    if _SA_POINT and K == 32 and w1.shape[0] in (64, 128, 256) and w1.shape[1] == 3 + feat.shape[-1]:
-        if _SA_FUSED and w1.shape[0] % 128 == 0 and w2.shape[0] in (64, 128, 256) and w2.shape[1] == w1.shape[0] \
-                and _lib.load().pzn_gemm_get_precision() != 0:
-            try:
-                return _SaLevelFused.apply(xyz, feat, new_xyz, idx, w1, b1, w2, b2)
-            except _lib.PznUnsupported:
-                pass        # PZN_WS_GEMM=0, or a table beyond the 32-bit buffer offsets: the written-rows form below
-        return _SaMlpMaxPoint.apply(xyz, feat, new_xyz, idx, w1, b1, w2, b2)
-    return _SaMlpMax.apply(xyz, feat, new_xyz, idx, w1, b1, w2, b2)
+    """sample_and_group(.., knn=True)'s grouping (pointnet_util.py:117-132) + relu(lin_a) + relu(lin_b) + max over the
+    neighbours (model5_b.py:449-454 / :456-461) for given centroids.  The encoder's shapes run per point with no grouped tensor
+    in memory (_SaLevelFused); anything else is composed as the reference composes it: the [B,S,K,3+D] group tensor (search
+    fused with the group write when idx is None) and the shared MLP + max on its rows."""
+    if sa_level_fused_supported(feat, idx, w1, w2):
+        try:
+            return _SaLevelFused.apply(xyz, feat, new_xyz, idx, w1, b1, w2, b2)
+        except _lib.PznUnsupported:
+            pass        # a table beyond the 32-bit buffer offsets: the composed form below
+    if idx is None and knn_group_supported(xyz, feat, 32):
+        grouped = knn_group(xyz, feat, new_xyz)[0]
+    else:
+        grouped = group(xyz, feat, new_xyz, knn(xyz, new_xyz, 32) if idx is None else idx)
+    return shared_mlp_max(grouped, w1, b1, w2, b2)

@@ -164,27 +164,28 @@ def test_emd_8192_invariants(dev):
 
 def test_full_batch_step_all_kernel_paths(dev):
     """configs[1] at its real size, B = 64, N = 2048: the whole training_step through (a) the default set-abstraction
-    path (first layer per point, rows generated inside the kernels), (a') the same with the rows written to memory
-    (PZN_SA_FUSED=0), (b) the grouped-row path (PZN_SA_POINT=0) and (c) the exact-fp32 MFMA mode.  They share
-    every discrete decision (FPS picks; kNN indices feed the same gathers), so the losses agree to rounding; every
-    gradient is finite and the per-parameter gradients of (a) and (b) agree in norm."""
+    path (first layer per point, rows generated inside the kernels), (b) the composition the reference writes (the
+    drop-in sample_and_group's [B,S,32,3+D] tensor + shared MLP + max on its rows: `fused_sa = False`) and (c) the
+    exact-fp32 MFMA mode (which takes the composed form too).  They share every discrete decision (FPS picks; kNN indices feed
+    the same gathers), so the losses agree to rounding; every gradient is finite and the per-parameter gradients of (a) and
+    (b) agree in norm."""
     from puzzlenet_amd import _lib, ops, synthetic
     B, N = 64, 2048
     cfg = mr.Cfg(num_points=N, loss_mode=1)
     lib = _lib.load()
     batch = synthetic.make_batch(B, N, dev, seed=2048)
-    old_point, old_fused, old_prec = ops._SA_POINT, ops._SA_FUSED, lib.pzn_gemm_get_precision()
+    old_prec = lib.pzn_gemm_get_precision()
     results = {}
     try:
-        for tag, per_point, fused, prec in (("point", True, True, 2), ("unfused", True, False, 2), ("rows", False, True, 2),
-                                            ("f32", True, True, 0)):
-            ops._SA_POINT, ops._SA_FUSED = per_point, fused
+        for tag, fused, prec in (("point", True, 2), ("rows", False, 2), ("f32", True, 0)):
             _lib.check(lib.pzn_gemm_set_precision(prec), "set_precision")
             model, _ = _pair(cfg, dev)
+            model.Encoder.fused_sa = model.Encoder2.fused_sa = fused
             torch.manual_seed(77)
             with torch.no_grad():
                 picks = model.predict5(batch, B, need=True, training=True)
             model, _ = _pair(cfg, dev)              # fresh BatchNorm buffers for the step itself
+            model.Encoder.fused_sa = model.Encoder2.fused_sa = fused
             torch.manual_seed(77)
             loss = model.training_step(batch, 0)["loss"]
             loss.backward()
@@ -193,10 +194,9 @@ def test_full_batch_step_all_kernel_paths(dev):
             results[tag] = (float(loss), picks[2].cpu(), picks[4].cpu(), grads)
             del model
     finally:
-        ops._SA_POINT, ops._SA_FUSED = old_point, old_fused
         lib.pzn_gemm_set_precision(old_prec)
     l0, x2f, x2m, g0 = results["point"]
-    for tag in ("unfused", "rows", "f32"):
+    for tag in ("rows", "f32"):
         l1, y2f, y2m, g1 = results[tag]
         assert torch.equal(x2f, y2f) and torch.equal(x2m, y2m), tag                       # same FPS picks
         assert abs(l1 - l0) <= 1e-5 * abs(l0), (tag, l0, l1)
@@ -210,8 +210,9 @@ def test_full_batch_step_all_kernel_paths(dev):
 
 def test_sa_level_production_shape(dev):
     """The first set-abstraction level on its production shape (B = 64, N = 2048, S = 512, D = 64: 1,048,576 grouped
-    rows): per-point kernels (sapoint.hip, pooled max-pool layer, sparse pooled backward, inverse lists) against the
-    grouped-row kernels on the same indices, and 48 sampled groups against an fp64 restatement on the CPU."""
+    rows): per-point kernels (sapoint.hip, generated-row max-pool level, backward by point, inverse lists) against the
+    composition on grouped rows (group + shared MLP + max) on the same indices, and 48 sampled groups against an fp64
+    restatement on the CPU."""
     from puzzlenet_amd import ops
     B, N, S, D, C1, C2 = 64, 2048, 512, 64, 128, 128
     g = torch.Generator().manual_seed(9)
@@ -224,29 +225,24 @@ def test_sa_level_production_shape(dev):
     go = torch.randn(B, S, C2, generator=g)
     xyz_d, new_xyz = xyz.to(dev), xyz[:, :S].contiguous().to(dev)
     idx = ops.knn(xyz_d, new_xyz, 32)
-    old, old_f = ops._SA_POINT, ops._SA_FUSED
     outs = {}
-    try:
-        for tag, per_point, fused in (("point", True, True), ("unfused", True, False), ("rows", False, False)):
-            ops._SA_POINT, ops._SA_FUSED = per_point, fused
-            f = feat.to(dev).requires_grad_(True)
-            ps = [t.to(dev).requires_grad_(True) for t in (w1, b1, w2, b2)]
+    for tag in ("point", "rows"):
+        f = feat.to(dev).requires_grad_(True)
+        ps = [t.to(dev).requires_grad_(True) for t in (w1, b1, w2, b2)]
+        if tag == "point":
+            assert ops.sa_level_fused_supported(f, idx, ps[0], ps[2])
             out = ops.sa_mlp_max(xyz_d, f, new_xyz, idx, *ps)
-            (out * go.to(dev)).sum().backward()
-            outs[tag] = (out.detach(), f.grad, [p.grad for p in ps])
-    finally:
-        ops._SA_POINT, ops._SA_FUSED = old, old_f
+        else:
+            out = ops.shared_mlp_max(ops.group(xyz_d, f, new_xyz, idx), *ps)
+        (out * go.to(dev)).sum().backward()
+        outs[tag] = (out.detach(), f.grad, [p.grad for p in ps])
     (o0, f0, p0), (o1, f1, p1) = outs["point"], outs["rows"]
-    (o2, f2, p2) = outs["unfused"]
 
     def l2(a, b):
         return float((a.double() - b.double()).norm() / b.double().norm())
     assert l2(o0, o1) < 1e-5 and float((o0 - o1).abs().max()) <= 1e-4 * float(o1.abs().max())
     assert l2(f0, f1) < 1e-3      # (a handful of the 4 M arg-max rows flip between the two summation orders)
     for a, b in zip(p0, p1):
-        assert l2(a, b) < 1e-3
-    assert l2(o0, o2) < 1e-5 and l2(f0, f2) < 1e-3
-    for a, b in zip(p0, p2):
         assert l2(a, b) < 1e-3
     # sampled groups in fp64
     sel_b = torch.randint(0, B, (48,), generator=g)

@@ -182,16 +182,12 @@ def test_chamfer_identity_and_symmetry(dev):
 @pytest.mark.parametrize("B,N,S,D,C1,C2", [(2, 300, 40, 64, 128, 128), (2, 128, 24, 128, 256, 256), (1, 64, 5, 8, 16, 24),
                                               (4, 600, 64, 64, 128, 128), (2, 400, 96, 128, 256, 256),
                                               (3, 97, 33, 12, 64, 40)])
-@pytest.mark.parametrize("path", ["rows", "point", "fused"])
-def test_sa_mlp_max_fused_vs_composed(dev, precision, monkeypatch, path, B, N, S, D, C1, C2):
-    """Set-abstraction level == group -> shared MLP -> max composed from fp64 torch ops, on its three kernel paths:
-    "rows" = the first layer on grouped rows; "point" = as a per-point product + gather that writes its rows
-    (csrc/sapoint.hip, C1 in {64,128,256}); "fused" = the rows generated inside the matrix-core kernel and the sparse
-    backward passes, never in memory (the default where C1 % 128 == 0; other shapes fall back to "point")."""
+def test_sa_mlp_max_fused_vs_composed(dev, precision, B, N, S, D, C1, C2):
+    """Set-abstraction level (ops.sa_mlp_max) == group -> shared MLP -> max composed from fp64 torch ops: the encoder's
+    shapes (C1 in {128, 256}) through the per-point kernels - rows generated inside the matrix-core kernel and the backward
+    by point, never in memory -, every other shape through the grouped-row composition the function falls back to."""
     from oracle import point_ops as orc
     from puzzlenet_amd import ops
-    monkeypatch.setattr(ops, "_SA_POINT", path != "rows")
-    monkeypatch.setattr(ops, "_SA_FUSED", path == "fused")
     rng = np.random.default_rng(D + S)
     xyz = rng.random((B, N, 3), dtype=np.float32)
     feat = rng.standard_normal((B, N, D)).astype(np.float32)
@@ -218,7 +214,7 @@ def test_sa_mlp_max_fused_vs_composed(dev, precision, monkeypatch, path, B, N, S
     for a, r, name in zip(d, ref, ("w1", "b1", "w2", "b2")):
         assert _rel(a.grad, r.grad) < 1e-4, name
     if N >= 64:
-        # idx=None: neighbour search fused with the group write (pzn_knn_group_pad_f32) — same values
+        # idx=None: the neighbour search runs inside the call — same values
         d2 = [t.to(dev).requires_grad_(True) for t in (w1, b1, w2, b2)]
         f2 = torch.from_numpy(feat).to(dev).requires_grad_(True)
         y2 = ops.sa_mlp_max(torch.from_numpy(xyz).to(dev), f2, torch.from_numpy(new_xyz).to(dev), None, *d2)
@@ -355,64 +351,6 @@ def test_attention_block_bf16_mode(dev, attn_bf16):
         # (the key bias has a mathematically zero gradient — softmax is shift-invariant — and collects the bf16 rounding
         # noise of 5120 rows instead: absolute floor)
         assert float((p_.grad.cpu().double() - q_.grad).abs().max()) < 2 * BF16_BWD_TOL * max(float(q_.grad.abs().max()), 0.25)
-
-
-@pytest.mark.parametrize("use", ["max", "out", "both"])
-@pytest.mark.parametrize("sinks", [False, True])
-def test_attention_chain_node_vs_composed(dev, sinks, use):
-    """ops.attention_chain_out (model5_b.py:462-474 as one autograd node: four blocks, mean of the maps, out projection
-    of the never-built concatenation) against the same thing composed from attention_block + avg4 + cat + linear:
-    outputs and every gradient (35 tensors), also with the parameter gradients going into registered sinks.
-    use = "max": only f_global = max over the points carries a gradient, as in predict5 — the out projection's backward
-    then runs as sparse row operations (csrc/maxptsbwd.hip); "out" / "both": the dense products."""
-    from puzzlenet_amd import ops
-    B, L, E, dk, Nout = 20, 256, 256, 64, 1024
-    g = torch.Generator().manual_seed(7)
-    x0 = (0.5 * torch.randn(B, L, E, generator=g)).to(dev)
-    shapes = [(dk, E), (dk,), (dk, E), (dk,), (E, E), (E,), (E, E), (E,)]
-    blocks0 = [[(torch.randn(*s, generator=g) / (math.sqrt(E) if len(s) == 2 else 4)).to(dev) for s in shapes] for _ in range(4)]
-    w0 = (torch.randn(Nout, 5 * E, generator=g) / math.sqrt(5 * E)).to(dev)
-    b0 = (0.1 * torch.randn(Nout, generator=g)).to(dev)
-    wy = torch.randn(B, L, Nout, generator=g).to(dev)
-    wg = torch.randn(B, Nout, generator=g).to(dev)
-
-    def run(chain):
-        x = x0.clone().requires_grad_(True)
-        blocks = [[p.clone().requires_grad_(True) for p in blk] for blk in blocks0]
-        w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
-        flat = [p for blk in blocks for p in blk] + [w, b]
-        ops.clear_grad_sinks()
-        if sinks:
-            for p in flat:
-                p.grad = torch.full_like(p, 0.125)          # pre-existing content: the kernels must ADD to it
-            ops.register_grad_sinks(flat)
-        if chain:
-            assert ops.attention_chain_supported(x, dk, w)
-            y, a, fg = ops.attention_chain_out(x, blocks, w, b)
-        else:
-            cur, maps, outs = x, [], []
-            for blk in blocks:
-                cur, m = ops.attention_block(cur, *blk)
-                maps.append(m)
-                outs.append(cur)
-            a = ops.avg4(*maps)
-            y = ops.linear(torch.cat(outs + [x], dim=-1), w, b)
-            fg = ops.max_over_points(y)
-        loss = 0
-        if use in ("max", "both"):
-            loss = loss + (fg * wg).sum()
-        if use in ("out", "both"):
-            loss = loss + (y * wy).sum()
-        loss.backward()
-        ops.clear_grad_sinks()
-        return y.detach(), a.detach(), x.grad, [p.grad for p in flat], fg.detach()
-
-    yc, ac, gxc, gpc, fc = run(True)
-    yr, ar, gxr, gpr, fr = run(False)
-    assert _rel(yc, yr) < 1e-5 and torch.equal(ac, ar) and _rel(fc, fr) < 1e-5
-    assert _rel(gxc, gxr) < 1e-4
-    for a_, b_ in zip(gpc, gpr):
-        assert float((a_ - b_).abs().max()) < 2e-4 * max(float(b_.abs().max()), 5e-2)
 
 
 @pytest.mark.parametrize("M,E,Nout,nsl", [(16384, 256, 1024, 5), (1000, 64, 96, 3), (4096, 128, 128, 2)])
@@ -873,7 +811,7 @@ def test_sa_level_streamed_vs_float64(dev, B, N, S, C):
     assert float((picked - rmax).abs().max()) < 1e-5
     # the two halves as their own entry points (weight split, then the level on the prepared workspace): the same bits
     import os
-    if os.environ.get("PZN_SA_STREAM", "1") != "0" and R >= 8:
+    if R >= 8:
         ws2 = torch.empty_like(ws)
         o2 = torch.full((R, C), float("nan"), device=dev)
         a2 = torch.full((R, C), -1, dtype=torch.int32, device=dev)
