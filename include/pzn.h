@@ -260,10 +260,6 @@ int pzn_gemm_get_precision(void);
  * attn with MFMA").  The q / k / v / out projections keep the fp32-accurate path.  Also PZN_ATTN_PRECISION=bf16. */
 int pzn_attn_set_precision(int mode);
 int pzn_attn_get_precision(void);
-/* Batched C[b] = alpha op(A[b]) op(B[b]), dense row-major.
- * mode 0 "NT": A[M,K] B[N,K];  1 "NN": A[M,K] B[K,N];  2 "TN": A[K,M] B[K,N]. */
-int pzn_bgemm_f32(int mode, const float* A, const float* B, float* C, int batch,
-                  int M, int N, int K, float alpha, pzn_stream_t stream);
 
 /* Shared MLP + max over the K=32 neighbours, model5_b.py:452-454 / :459-461:
  *   h = relu(x[R*32,C0] W1^T + b1)  (kept: the backward reads it);
@@ -281,85 +277,25 @@ int pzn_sharedmlp_max_bwd_f32(const float* x, const float* W1, const float* W2,
                               float* dW1, float* db1, float* dW2, float* db2,
                               int accumulate, pzn_stream_t stream);
 
-/* Model-internal set-abstraction path (the drop-in sample_and_group keeps the reference's
- * [B,S,K,3+D] layout; this one is what model5_b's encoder runs):
- * rows {dx,dy,dz,0,f_0..f_{D-1}} (16-byte aligned, feature block on a 16-byte boundary). */
-int pzn_group_pad_fwd_f32(const float* xyz, const float* feat, const float* new_xyz,
-                          const int64_t* idx, int B, int N, int S, int K, int D,
-                          float* out, pzn_stream_t stream);
-/* pzn_knn_f32 (K = 32) and pzn_group_pad_fwd_f32 in ONE launch (pointnet_util.py:117-132 on the
- * encoder path): selection is VALU work, the group write is HBM work, and inside one kernel they
- * overlap.  64 <= N <= 4096, D % 4 == 0.  idx[B,S,32] is kept for the backward. */
-int pzn_knn_group_pad_f32(const float* xyz, const float* feat, const float* new_xyz,
-                          int B, int N, int S, int D, int64_t* idx, float* out,
-                          pzn_stream_t stream);
-/* grad_feat[b, idx[b,s,k], :] += rows[b,s,k,:], rows D wide; grad_feat zero-initialised
- * by the caller. */
-int pzn_group_feat_bwd_f32(const float* rows, const int64_t* idx, int B, int N, int S,
-                           int K, int D, float* grad_feat, pzn_stream_t stream);
-/* Backward of pzn_sharedmlp_max_fwd_f32 run on padded rows xg[R*32,4+D] with
- * W1p[C1,4+D] = {W1[:,0:3], 0, W1[:,3:]} (model5_b.py:452-454 / :459-461 with the grouping of
- * pointnet_util.py:123-132 folded in): dW1 in the PARAMETER layout [C1,3+D]; dW1, db1, dW2,
- * db2 overwritten (accumulate == 0) or added to; dfeat_rows[R*32,D] (gradient of the gathered
- * feature block only; may be NULL); dh_ws[R*32,C1] scratch. */
-int pzn_sa_mlp_max_bwd_f32(const float* xg, const float* W1p, const float* W2,
-                           const float* h, const float* out, const int32_t* argmax,
-                           const float* dout, int R, int D, int C1, int C2, float* dh_ws,
-                           float* dfeat_rows, float* dW1, float* db1, float* dW2,
-                           float* db2, int accumulate, pzn_stream_t stream);
-/* Same backward with the feature gradient scattered straight into grad_feat[B,N,D]
- * (index_points backward, pointnet_util.py:39-50 under :123-126):
- * grad_feat[b, idx[b,s,k], :] += (dh W1p[:,4:])[b,s,k,:]; grad_feat zero-initialised (or
- * already holding other contributions) by the caller; R = B*S groups of K = 32 rows.
- * rows_ws[B*S*32, D] is scratch for shapes the fused epilogue does not cover (may be NULL:
- * PZN_EUNSUPPORTED is returned for those). */
-int pzn_sa_mlp_max_bwd_scatter_f32(const float* xg, const float* W1p, const float* W2,
-                                   const float* h, const float* out, const int32_t* argmax,
-                                   const float* dout, const int64_t* idx, int B, int N, int S,
-                                   int D, int C1, int C2, float* dh_ws, float* rows_ws,
-                                   float* grad_feat, float* dW1, float* db1, float* dW2,
-                                   float* db2, int accumulate, pzn_stream_t stream);
-
 /* The same set-abstraction level with its first layer computed PER POINT (csrc/sapoint.hip): a grouped row is
  * {xyz[j] - centre, feat[j]} (pointnet_util.py:123-132), so its product with W1[C1,3+D] (model5_b.py:452 / :459)
- * is  W1[:,0:3] (xyz[j] - centre) + P[b,j,:]  with  P = feat W1[:,3:]^T  computed once per point; the grouped
- * tensor is never materialised.  Same result up to the order of the fp32 sum.  K = 32, C1 in {64,128,256}.
- *   fwd:  h[B*S*32, C1] = relu(W1[:,0:3] (xyz[idx] - new_xyz) + P[idx] + b1);  W1 in the PARAMETER layout
- *         [C1, 3+D] (only its first three columns are read), P[B*N, C1], idx[B,S,32] from pzn_knn_f32.
+ * is a per-point term plus a per-group term (below); the grouped tensor is never materialised.
  *   pzn_knn_inverse_lists: the B*S*K (row, point) pairs of idx sorted by point, per cloud: rows[B, S*K] = in-cloud
- *         row numbers (s*K + k), pts[B, S*K] = the point each gathered (may be NULL), off[B, N+1] = where every
- *         point's rows start (index_points backward without atomics on rows).
- *   bwd:  dP[B*N, C1] = sum of dh over the rows that gathered each point;  dW1[:,0:3] += dh^T (xyz[idx] -
- *         new_xyz), db1 += column sums (both ADDED to; db1 may be NULL).  dfeat = dP W1[:,3:] and
- *         dW1[:,3:] += dP^T feat are plain pzn_linear_dgrad / wgrad calls on B*N rows. */
-int pzn_sa_point_l1_fwd_f32(const float* xyz, const float* new_xyz, const int64_t* idx,
-                            const float* P, const float* W1, const float* b1, int B, int N,
-                            int S, int D, int C1, float* h, pzn_stream_t stream);
+ *         row numbers (s*K + k), ascending within a point, pts[B, S*K] = the point each gathered (may be NULL),
+ *         off[B, N+1] = where every point's rows start (index_points backward without atomics on rows). */
 int pzn_knn_inverse_lists(const int64_t* idx, int B, int N, int S, int K, int32_t* off,
                           int32_t* rows, int32_t* pts, pzn_stream_t stream);
-int pzn_sa_point_l1_bwd_f32(const float* dh, const float* xyz, const float* new_xyz,
-                            const int32_t* rows, const int32_t* pts, int B, int N, int S, int D,
-                            int C1, float* dP, float* dW1, float* db1, pzn_stream_t stream);
-int pzn_sa_point_l1_bwd_rm_f32(const float* dh, const float* xyz, const float* new_xyz, const int32_t* rows,
-                               const int32_t* pts, int B, int N, int S, int D, int C1, float* dP, float* dW1, float* db1,
-                               const uint32_t* rowmask, pzn_stream_t stream);
-/* Second (pooled) layer backward alone (model5_b.py:453-454 / :460-461): dh[R*32,C1] = ReLU-masked (by h)
- * gradient of the first layer's output, dW2[C2,C1], db2[C2] (overwritten, or added to when accumulate). */
-int pzn_pooled_layer_bwd_f32(const float* dout, const int32_t* argmax, const float* out,
-                             const float* W2, const float* h, int R, int C1, int C2, float* dh,
-                             float* dW2, float* db2, int accumulate, pzn_stream_t stream);
 
 /* The same level with the first layer's rows NEVER in memory (what model5_b's encoder runs by default).  The coordinate
  * term is split:  W1[:,0:3] (xyz[j] - centre) = W1[:,0:3] xyz[j] - W1[:,0:3] centre,  so with
  *   Pp[B*N, C1] = feat W1[:,3:]^T + W1[:,0:3] xyz      (pzn_linear_fwd_f32, then pzn_sa_prep_f32 adds the xyz term in place)
  *   Q [B*S, C1] = b1 - W1[:,0:3] new_xyz                (pzn_sa_prep_f32)
  * a grouped row of the first layer is relu(Pp[idx] + Q[group]) — generated inside the operand loader of the
- * weight-stationary matrix-core kernel (fwd) and inside both sparse backward passes; same result as the forms above up to
+ * weight-stationary matrix-core kernel (fwd) and inside the backward passes; same result as the grouped-row form above up to
  * the order of the fp32 sum.  K = 32, C1 % 128 == 0 backward (C1 % 32 == 0 forward), C2 in {64,128,256}.
  *   fwd:  out[B*S, C2] = max_k relu(relu(Pp[idx[.,k]] + Q) W2^T + b2), argmax[B*S, C2]
- *   bwd:  dh[B*S*32, C1] (ReLU-masked gradient of the generated rows, written for pzn_sa_point_l1_bwd_f32 — called with
- *         new_xyz = NULL: the factor of dW1[:,0:3] is then the point itself), dW2 / db2 (overwritten, or added to when
- *         accumulate), and dW1[:,0:3] -= dq^T new_xyz, db1 += column sums of dq, dq[g] = sum_k dh[g,k] (ADDED to). */
+ *   bwd:  pzn_sa_level_bwd_pt_f32 below (the rows' gradient dh[B*S*32, C1] is summed per point where it is computed and
+ *         never written; rounds 2-4 wrote it: pzn_sa_level_bwd_f32 + pzn_sa_point_l1_bwd_f32, removed in round 6). */
 int pzn_sa_prep_f32(const float* xyz, const float* new_xyz, const float* W1, const float* b1, int B, int N, int S,
                     int D, int C1, float* P, float* Q, pzn_stream_t stream);
 int pzn_sa_level_fwd_f32(const float* Pp, const float* Q, const int64_t* idx, const float* W2, const float* b2,
@@ -380,25 +316,14 @@ int pzn_sa_level_prep_weights_f32(const float* W2, int C1, int C2, void* workspa
 int pzn_sa_level_fwd_packed_f32(const float* Pp, const float* Q, const int64_t* idx, const float* b2, int B, int N,
                                 int S, int C1, int C2, float* out, int32_t* argmax, const void* workspace,
                                 pzn_stream_t stream);
-int pzn_sa_level_bwd_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
-                         const float* Pp, const float* Q, const int64_t* idx, const float* new_xyz, int B, int N,
-                         int S, int D, int C1, int C2, float* dh, float* dW2, float* db2, float* dW1, float* db1,
-                         int accumulate, pzn_stream_t stream);
-/* The same with a row mask: about half the rows of a level-1 group (a third at level 2) win no channel and their dh row is
- * exactly zero.  rowmask[B*S] (written): bit k of word g = row (g, k) is non-zero; row PAIRS (2i, 2i+1) without a bit are
- * not written at all, and pzn_sa_point_l1_bwd_rm_f32 reads only rows whose bit is set. */
-int pzn_sa_level_bwd_rm_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
-                            const float* Pp, const float* Q, const int64_t* idx, const float* new_xyz, int B, int N,
-                            int S, int D, int C1, int C2, float* dh, float* dW2, float* db2, float* dW1, float* db1,
-                            int accumulate, uint32_t* rowmask, pzn_stream_t stream);
 
-/* The level's backward BY POINT (csrc/sapool.hip, round 5): dW2 / db2 as above, and INSTEAD of dh its per-point sums
- * dP[B*N, C1] (overwritten) — what pzn_sa_point_l1_bwd_f32 would make of dh — with dW1[:, 0:3] += dh^T (xyz[idx] - centre) and
- * db1 += column sums of dh (both ADDED to, db1 may be NULL).  The rows' gradient is computed where the two-launch form
- * loaded it (hit lists per group, sorted by arg-max row; W2 slice in LDS; gate from Pp and Q) and never written.
- * off / rows / pts: pzn_knn_inverse_lists of idx.  A wavefront owns whole points (round 6): every row of dP is written exactly
- * once by plain stores, the rows of a point are summed in ascending row order: dP is the same bit for bit in every run.  workspace: pzn_sa_level_bwd_pt_workspace_bytes(B, S, C2) bytes, 16-byte
- * aligned.  PZN_EUNSUPPORTED for C1 % 128 != 0 or C2 not in {64, 128, 256}. */
+/* The level's backward BY POINT (csrc/sapool.hip): dW2[C2,C1] / db2[C2] (overwritten, or added to when accumulate), the
+ * per-point sums dP[B*N, C1] of the rows' gradient dh (overwritten), dW1[:, 0:3] += dh^T (xyz[idx] - centre) and db1 += column
+ * sums of dh (both ADDED to, db1 may be NULL).  dh itself is computed by point (hit lists per group, sorted by arg-max row;
+ * W2 slice in LDS; gate from Pp and Q) and never written.  off / rows / pts: pzn_knn_inverse_lists of idx.  A wavefront owns
+ * whole points: every row of dP is written exactly once by plain stores and the rows of a point are summed in ascending row
+ * order, so dP is the same bit for bit in every run.  workspace: pzn_sa_level_bwd_pt_workspace_bytes(B, S, C2) bytes,
+ * 16-byte aligned.  PZN_EUNSUPPORTED for C1 % 128 != 0 or C2 not in {64, 128, 256}. */
 size_t pzn_sa_level_bwd_pt_workspace_bytes(int B, int S, int C2);
 int pzn_sa_level_bwd_pt_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
                             const float* Pp, const float* Q, const int64_t* idx, const float* xyz, const float* new_xyz,
@@ -440,15 +365,6 @@ int pzn_bn_points_relu_bwd_f32(const float* x, const float* dy, const float* wei
                                const float* bias, const float* save_mean,
                                const float* save_invstd, int training, int B, int N, int C,
                                float* dx, float* dweight, float* dbias, pzn_stream_t stream);
-
-/* pzn_pooled_layer_bwd_f32 behind the per-point first layer: h is a pure function of P, idx and the centre offsets
- * (pzn_sa_point_l1_fwd_f32), so the input-gradient pass regenerates the ReLU gate of every row from those (L2-resident)
- * with the forward's own expression instead of reading h[B*S*32, C1] from HBM; the weight-gradient pass reads h. */
-int pzn_sa_pooled_layer_bwd_f32(const float* dout, const int32_t* argmax, const float* out,
-                                const float* W2, const float* h, const float* P, const int64_t* idx,
-                                const float* xyz, const float* new_xyz, const float* W1,
-                                const float* b1, int B, int N, int S, int D, int C1, int C2, float* dh,
-                                float* dW2, float* db2, int accumulate, pzn_stream_t stream);
 
 /* scaled_dot_production of layerAttention, model5_b.py:67-75:
  * attn[B,L,L] = softmax(q[B,L,dk] k[B,L,dk]^T / sqrt(dk)), out[B,L,dv] = attn v.

@@ -261,17 +261,17 @@ int launch_ij(DfArgs p, hipStream_t st) {
   const int types = types_n * p.types_k;
   constexpr int MAXW = 12;  // wavefronts per workgroup (<= 168 registers each)
   const int nsteps = p.M / 16;
-  static const int forced = [] { const char* e = getenv("PZN_DF_WGS"); return e ? atoi(e) : 0; }();  // tuning aid
+  constexpr int forced = 0;  // tuning aid
   // long streams: all types of a row range in one workgroup (they re-read the same rows out of L1 / L2); >= 8 steps
   // per wave.
-  static const int tpw_cap = [] { const char* e = getenv("PZN_DF_TPW"); return e ? atoi(e) : 12; }();  // tuning aid (12 = all types together measured best)
+  constexpr int tpw_cap = 12;  // tuning aid (12 = all types together measured best)
   // short row counts (M <= 65536: the attention projections, 16384 rows) are bound by the epilogue atomics — every
   // wave ends with TI*TJ*4 KB of them after only a few steps of rows: ONE tile block per workgroup, eight row replicas
   // that meet in LDS (halving rounds) and >= 8 steps per wave cut the atomics 8x against four tile blocks x two
   // replicas (attention block backward 0.30 -> 0.27 ms); long streams keep every tile block of a row range together
   // (L1 / L2 re-use of the rows)
-  static const int short_tpw = [] { const char* e = getenv("PZN_DF_SHORT_TPW"); return e ? atoi(e) : 1; }();    // tuning aid
-  static const int short_reps = [] { const char* e = getenv("PZN_DF_SHORT_REPS"); return e ? atoi(e) : 8; }();  // tuning aid
+  constexpr int short_tpw = 1;    // tuning aid
+  constexpr int short_reps = 8;  // tuning aid
   const bool short_m = p.M <= 65536;
   const int want = short_m ? short_tpw : tpw_cap;
   const int cap = want < MAXW ? want : MAXW;
@@ -286,11 +286,11 @@ int launch_ij(DfArgs p, hipStream_t st) {
   } else {
     while (p.reps > 2 && nsteps / (256 * p.reps) < 4) p.reps >>= 1;
   }
-  static const int reps_cap = [] { const char* e = getenv("PZN_DF_REPS"); return e ? atoi(e) : 0; }();  // tuning aid
+  constexpr int reps_cap = 0;  // tuning aid
   while (reps_cap > 0 && p.reps > reps_cap) p.reps >>= 1;
   int wgs = 256;
-  static const int min_steps = [] { const char* e = getenv("PZN_DF_MINSTEPS"); return e ? atoi(e) : 8; }();  // tuning aid
-  static const int short_min = [] { const char* e = getenv("PZN_DF_SHORT_MINSTEPS"); return e ? atoi(e) : 8; }();  // tuning aid
+  constexpr int min_steps = 8;  // tuning aid
+  constexpr int short_min = 8;  // tuning aid
   const int max_by_steps = nsteps / ((short_m ? short_min : (p.reps > 2 ? 4 : min_steps)) * p.reps);
   if (wgs > max_by_steps) wgs = max_by_steps;
   if (forced) wgs = forced;
@@ -317,7 +317,7 @@ int launch_ij(DfArgs p, hipStream_t st) {
 }
 
 bool df_enabled() {
-  static const bool on = [] { const char* e = getenv("PZN_DF_GEMM"); return !(e && e[0] == '0'); }();  // tuning aid
+  constexpr bool on = true;  // tuning aid
   return on;
 }
 

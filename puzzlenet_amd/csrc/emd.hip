@@ -1007,7 +1007,7 @@ int run_fused(const float* xyz1, const float* xyz2, int B, int n, int m, float* 
   };
   // x window of a level: exp2(c d^2) with c d^2 <= -150 is exactly +0 in fp32 (below the smallest denormal), and
   // d^2 >= (x distance)^2: points farther than sqrt(150 / -c) along x are not walked (level 0: no window)
-  static const float win_bits = [] { const char* e = getenv("PZN_EMD_WIN_BITS"); return e ? (float)atof(e) : 150.f; }();  // tuning aid
+  constexpr float win_bits = 150.f;  // tuning aid
   auto winf = [&](int j) {
     const float c = cof(j);
     return c < 0.f ? sqrtf(win_bits / -c) : INFINITY;

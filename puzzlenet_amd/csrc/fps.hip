@@ -200,27 +200,16 @@ PZN_EXPORT int pzn_fps_f32(const float* xyz, int B, int N, int npoint, const int
   PZN_CHECK_ARG(xyz && start_idx && out_idx && B > 0 && N > 0 && npoint > 0);
   hipStream_t st = pzn_hip_stream(stream);
   // Fewer, fatter wavefronts: the round is a dependent chain (fetch the pick, update, wave reduction, barrier, re-reduce
-  // the per-wave slots), and the cross-wave part grows with the wave count while the per-thread update is cheap
-  // (PZN_FPS_T: tuning aid).  Measured per round at N = 2048: 1024 threads 1.35 us, 512 0.75, 256 0.62, 128 see tools/bench_fps.py
-  static const int tsel = [] { const char* e = getenv("PZN_FPS_T"); return e ? atoi(e) : 0; }();
+  // the per-wave slots), and the cross-wave part grows with the wave count while the per-thread update is cheap.  Measured
+  // per round at N = 2048: 1024 threads 1.35 us, 512 0.75, 256 0.62 (tools/bench_fps.py)
   if (N <= 64) return launch<64, 1>(xyz, B, N, npoint, start_idx, out_idx, st);
   if (N <= 128) return launch<128, 1>(xyz, B, N, npoint, start_idx, out_idx, st);
-  if (N <= 256) return tsel == 128 ? launch<128, 2>(xyz, B, N, npoint, start_idx, out_idx, st)
-                                   : launch<256, 1>(xyz, B, N, npoint, start_idx, out_idx, st);
-  if (N <= 512) return tsel == 128 ? launch<128, 4>(xyz, B, N, npoint, start_idx, out_idx, st)
-                                   : launch<256, 2>(xyz, B, N, npoint, start_idx, out_idx, st);
-  if (N <= 1024) return tsel == 128 ? launch<128, 8>(xyz, B, N, npoint, start_idx, out_idx, st)
-                                    : launch<256, 4>(xyz, B, N, npoint, start_idx, out_idx, st);
-  if (N <= 2048) {
-    if (tsel == 128) return launch<128, 16>(xyz, B, N, npoint, start_idx, out_idx, st);
-    if (tsel == 512) return launch<512, 4>(xyz, B, N, npoint, start_idx, out_idx, st);
-    if (tsel == 1024) return launch<1024, 2>(xyz, B, N, npoint, start_idx, out_idx, st);
-    return launch<256, 8>(xyz, B, N, npoint, start_idx, out_idx, st);
-  }
-  if (N <= 4096) return tsel == 512 ? launch<512, 8>(xyz, B, N, npoint, start_idx, out_idx, st)
-                                    : launch<256, 16>(xyz, B, N, npoint, start_idx, out_idx, st);
-  if (N <= 8192) return tsel == 1024 ? launch<1024, 8>(xyz, B, N, npoint, start_idx, out_idx, st)
-                                     : launch<512, 16>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 256) return launch<256, 1>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 512) return launch<256, 2>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 1024) return launch<256, 4>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 2048) return launch<256, 8>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 4096) return launch<256, 16>(xyz, B, N, npoint, start_idx, out_idx, st);
+  if (N <= 8192) return launch<512, 16>(xyz, B, N, npoint, start_idx, out_idx, st);
   if (N <= 16384) return launch<1024, 16>(xyz, B, N, npoint, start_idx, out_idx, st);
   if (N <= 32768) return launch<1024, 32>(xyz, B, N, npoint, start_idx, out_idx, st);
   return PZN_EUNSUPPORTED;

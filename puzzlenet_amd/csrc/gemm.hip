@@ -659,7 +659,7 @@ void launch(const GemmArgs& p, int batch, hipStream_t st) {
   if constexpr (EPI == EPI_STORE) {
     // batched small products (the attention maps: 64 x (256 x 256 x 64..256)): 128 x 128 tiles give one 4-wave
     // workgroup per CU, i.e. nothing to hide a load behind; 64 x 128 tiles double the resident wavefronts
-    static const bool small_tiles = [] { const char* e = getenv("PZN_BGEMM_SMALL"); return !(e && e[0] == '0'); }();
+    constexpr bool small_tiles = true;
     if (small_tiles && batch > 1 && p.N > 64 && p.M <= 512 && p.splits <= 1) {
       launch_cfg<64, 128, 2, 2, A_KC, B_KC, EPI>(p, batch, st);
       return;
@@ -686,7 +686,7 @@ void choose_splits(GemmArgs& p) {
   long tiles = (long)((p.N + 127) / 128) * ((p.M + 127) / 128);
   // one full wave of resident workgroups: the bf16x3 TN kernel holds 61 KB of LDS (2 per CU), the fp32 one 3 per CU;
   // a grid of 1.5 waves costs as much as 2 (measured: 0.86 -> 0.69 ms on a 256x256x524288 weight gradient)
-  static const long forced = [] { const char* e = getenv("PZN_SPLIT_TARGET"); return e ? atol(e) : 0L; }();  // tuning aid
+  constexpr long forced = 0;
   const long target = forced ? forced : (gemm_precision() == 0 ? 768L : 512L);
   long want = target / (tiles > 0 ? tiles : 1);
   long ksteps = (p.K + BK - 1) / BK;
@@ -788,8 +788,7 @@ PZN_EXPORT int pzn_linear_maxpool_dgrad_f32(const float* dout, const int32_t* ar
                                             int R, int Kin, int Nout, const float* x_relu, float* dx,
                                             pzn_stream_t stream) {
   PZN_CHECK_ARG(dout && argmax && out && W && dx && R > 0 && Kin > 0 && Nout > 0);
-  if (pzn_pool_bwd_supported(Kin, Nout, W, x_relu, dx))  // one non-zero per (group, channel): sparse pass
-    return pzn_pool_bwd_sparse(dout, argmax, out, W, x_relu, dx, nullptr, nullptr, R, Kin, Nout, pzn_hip_stream(stream));
+  // (the encoder's levels never take this: their rows' gradient is summed per point where it is computed, csrc/sapool.hip)
   GemmArgs p = base_args(R * 32, Kin, Nout);
   p.A = dout, p.lda = Nout, p.B = W, p.ldb = Kin, p.C = dx, p.ldc = Kin;
   p.gen = GEN_MAXPOOL, p.genArg = argmax, p.genOut = out;
@@ -878,13 +877,13 @@ PZN_EXPORT int pzn_linear_maxpool_wgrad_f32(const float* dout, const int32_t* ar
                                             int R, int Kin, int Nout, float* dW, float* db, int accumulate,
                                             pzn_stream_t stream) {
   PZN_CHECK_ARG(dout && argmax && out && x && dW && R > 0 && Kin > 0 && Nout > 0);
-  if (pzn_pool_bwd_supported(Kin, Nout, x, x, nullptr)) {
+  if (pzn_pool_wgrad_supported(Kin, Nout, x)) {      // one non-zero per (group, channel): the sparse pass of poolbwd.hip
     hipStream_t st = pzn_hip_stream(stream);
     if (!accumulate) {
       if (pzn_zero_async(dW, (size_t)Nout * Kin, st) != PZN_OK) return PZN_ELAUNCH;
       if (db && pzn_zero_async(db, (size_t)Nout, st) != PZN_OK) return PZN_ELAUNCH;
     }
-    return pzn_pool_bwd_sparse(dout, argmax, out, nullptr, x, nullptr, dW, db, R, Kin, Nout, st);
+    return pzn_pool_wgrad_sparse(dout, argmax, out, x, dW, db, R, Kin, Nout, st);
   }
   GemmArgs p = base_args(Nout, Kin, R * 32);
   p.A = dout, p.lda = Nout, p.gen = GEN_MAXPOOL, p.genArg = argmax, p.genOut = out;
@@ -938,12 +937,6 @@ PZN_EXPORT int pzn_attn_set_precision(int mode) {
 }
 PZN_EXPORT int pzn_attn_get_precision(void) { return attn_precision(); }
 int pzn_attn_precision_mode() { return attn_precision(); }
-
-PZN_EXPORT int pzn_bgemm_f32(int mode, const float* A, const float* B, float* C, int batch, int M, int N, int K,
-                             float alpha, pzn_stream_t stream) {
-  PZN_CHECK_ARG(A && B && C && batch > 0 && batch <= 65535 && M > 0 && N > 0 && K > 0 && mode >= 0 && mode <= 2);
-  return bgemm_impl(mode, A, B, C, batch, M, N, K, alpha, 0, pzn_hip_stream(stream));
-}
 
 // ------------------------------------------------------------------ softmax rows (attention) --
 namespace {
@@ -1264,42 +1257,14 @@ PZN_EXPORT int pzn_sharedmlp_max_fwd_f32(const float* x, const float* W1, const 
   return pzn_linear_maxpool_fwd_f32(h, W2, b2, R, C1, C2, out, argmax, stream);
 }
 
-// Second-layer backward of the pooled shared MLP: dh (ReLU-masked by h), dW2, db2 — one sparse pass when the
-// shape allows (poolbwd.hip), else the two generated-operand GEMMs.
+// Second-layer backward of the pooled shared MLP (rows h in memory: the grouped-row composition): dh (ReLU-masked by h) from
+// the generated-operand GEMM, dW2 / db2 from the sparse pass of poolbwd.hip where the shape allows (else the GEMM form).
 static int pool_layer_bwd(const float* dout, const int32_t* argmax, const float* out, const float* W2, const float* h,
                           int R, int C1, int C2, float* dh_ws, float* dW2, float* db2, int accumulate,
-                          pzn_stream_t stream, const PznGateSource* gs = nullptr) {
-  if (pzn_pool_bwd_supported(C1, C2, W2, h, dh_ws)) {
-    hipStream_t st = pzn_hip_stream(stream);
-    if (!accumulate) {
-      if (pzn_zero_async(dW2, (size_t)C2 * C1, st) != PZN_OK) return PZN_ELAUNCH;
-      if (pzn_zero_async(db2, (size_t)C2, st) != PZN_OK) return PZN_ELAUNCH;
-    }
-    return pzn_pool_bwd_sparse(dout, argmax, out, W2, h, dh_ws, dW2, db2, R, C1, C2, st, gs);
-  }
+                          pzn_stream_t stream) {
   int rc = pzn_linear_maxpool_dgrad_f32(dout, argmax, out, W2, R, C1, C2, h, dh_ws, stream);
   if (rc != PZN_OK) return rc;
   return pzn_linear_maxpool_wgrad_f32(dout, argmax, out, h, R, C1, C2, dW2, db2, accumulate, stream);
-}
-
-PZN_EXPORT int pzn_pooled_layer_bwd_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
-                                        const float* h, int R, int C1, int C2, float* dh, float* dW2, float* db2,
-                                        int accumulate, pzn_stream_t stream) {
-  PZN_CHECK_ARG(dout && argmax && out && W2 && h && dh && dW2 && db2 && R > 0 && C1 > 0 && C2 > 0);
-  return pool_layer_bwd(dout, argmax, out, W2, h, R, C1, C2, dh, dW2, db2, accumulate, stream);
-}
-
-// The same pass behind the per-point first layer (csrc/sapoint.hip): the ReLU gate of h is regenerated from P, idx and
-// the centre offsets (L2-resident) instead of read from h.
-PZN_EXPORT int pzn_sa_pooled_layer_bwd_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
-                                           const float* h, const float* P, const int64_t* idx, const float* xyz,
-                                           const float* new_xyz, const float* W1, const float* b1, int B, int N, int S,
-                                           int D, int C1, int C2, float* dh, float* dW2, float* db2, int accumulate,
-                                           pzn_stream_t stream) {
-  PZN_CHECK_ARG(dout && argmax && out && W2 && h && P && idx && xyz && new_xyz && W1 && dh && dW2 && db2);
-  PZN_CHECK_ARG(B > 0 && N > 0 && S > 0 && D >= 0 && C1 > 0 && C2 > 0 && (long)B * N < 2147483647L);
-  const PznGateSource gs{P, idx, xyz, new_xyz, W1, b1, 3 + D, N, S};
-  return pool_layer_bwd(dout, argmax, out, W2, h, B * S, C1, C2, dh, dW2, db2, accumulate, stream, &gs);
 }
 
 // Set-abstraction level with the first layer per point AND never in memory (model5_b.py:449-454 / :456-461): the
@@ -1352,51 +1317,6 @@ PZN_EXPORT int pzn_sa_level_fwd_packed_f32(const float* Pp, const float* Q, cons
                              pzn_hip_stream(stream), 1);
 }
 
-// Backward of the pooled layer behind pzn_sa_level_fwd_f32: dh[B*S*32, C1] (the ReLU-masked gradient of the generated
-// rows: written, the per-point sum pzn_sa_point_l1_bwd_f32 reads it), dW2, db2 (overwritten, or added to when
-// accumulate), and what flows through Q: dW1[:, 0:3] -= dq^T new_xyz, db1 += column sums of dq (dq[g] = sum_k dh[g,k]);
-// dW1[C1, 3+D] and db1[C1] are ADDED to.  Both sparse passes regenerate the rows from Pp / Q / idx: h does not exist.
-static int sa_level_bwd(const float* dout, const int32_t* argmax, const float* out, const float* W2, const float* Pp,
-                        const float* Q, const int64_t* idx, const float* new_xyz, int B, int N, int S, int D, int C1, int C2,
-                        float* dh, float* dW2, float* db2, float* dW1, float* db1, int accumulate, uint32_t* rowmask,
-                        pzn_stream_t stream);
-
-PZN_EXPORT int pzn_sa_level_bwd_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
-                                    const float* Pp, const float* Q, const int64_t* idx, const float* new_xyz, int B,
-                                    int N, int S, int D, int C1, int C2, float* dh, float* dW2, float* db2, float* dW1,
-                                    float* db1, int accumulate, pzn_stream_t stream) {
-  return sa_level_bwd(dout, argmax, out, W2, Pp, Q, idx, new_xyz, B, N, S, D, C1, C2, dh, dW2, db2, dW1, db1, accumulate,
-                      nullptr, stream);
-}
-
-// The same with a row mask (rowmask[B*S] words, written): bit k of word g = row (g, k) of dh is non-zero.  Rows whose pair
-// (2i, 2i+1) holds no non-zero row are NOT written; the reader (pzn_sa_point_l1_bwd_rm_f32) skips rows without their bit.
-PZN_EXPORT int pzn_sa_level_bwd_rm_f32(const float* dout, const int32_t* argmax, const float* out, const float* W2,
-                                       const float* Pp, const float* Q, const int64_t* idx, const float* new_xyz, int B,
-                                       int N, int S, int D, int C1, int C2, float* dh, float* dW2, float* db2, float* dW1,
-                                       float* db1, int accumulate, uint32_t* rowmask, pzn_stream_t stream) {
-  PZN_CHECK_ARG(rowmask != nullptr);
-  return sa_level_bwd(dout, argmax, out, W2, Pp, Q, idx, new_xyz, B, N, S, D, C1, C2, dh, dW2, db2, dW1, db1, accumulate,
-                      rowmask, stream);
-}
-
-static int sa_level_bwd(const float* dout, const int32_t* argmax, const float* out, const float* W2, const float* Pp,
-                        const float* Q, const int64_t* idx, const float* new_xyz, int B, int N, int S, int D, int C1, int C2,
-                        float* dh, float* dW2, float* db2, float* dW1, float* db1, int accumulate, uint32_t* rowmask,
-                        pzn_stream_t stream) {
-  PZN_CHECK_ARG(dout && argmax && out && W2 && Pp && Q && idx && new_xyz && dh && dW2 && db2 && dW1);
-  PZN_CHECK_ARG(B > 0 && N > 0 && S > 0 && D >= 0 && C1 > 0 && C2 > 0 && (long)B * N < 2147483647L);
-  if (!pzn_pool_bwd_supported(C1, C2, W2, nullptr, dh)) return PZN_EUNSUPPORTED;
-  hipStream_t st = pzn_hip_stream(stream);
-  if (!accumulate) {
-    if (pzn_zero_async(dW2, (size_t)C2 * C1, st) != PZN_OK) return PZN_ELAUNCH;
-    if (pzn_zero_async(db2, (size_t)C2, st) != PZN_OK) return PZN_ELAUNCH;
-  }
-  PznGateSource gs{Pp, idx, nullptr, new_xyz, nullptr, nullptr, 3 + D, N, S, Q, dW1, db1};
-  gs.rowmask = rowmask;
-  return pzn_pool_bwd_sparse(dout, argmax, out, W2, nullptr, dh, dW2, db2, B * S, C1, C2, st, &gs);
-}
-
 // Backward: dh_ws is [R*32, C1] scratch; dx may be NULL.  dW*, db* are overwritten.
 PZN_EXPORT int pzn_sharedmlp_max_bwd_f32(const float* x, const float* W1, const float* W2, const float* h,
                                          const float* out, const int32_t* argmax, const float* dout, int R, int C0,
@@ -1409,83 +1329,6 @@ PZN_EXPORT int pzn_sharedmlp_max_bwd_f32(const float* x, const float* W1, const 
   if (rc != PZN_OK) return rc;
   if (dx) rc = pzn_linear_dgrad_f32(dh_ws, nullptr, W1, R * 32, C0, C1, nullptr, dx, stream);
   return rc;
-}
-
-// Set-abstraction MLP on the model-internal padded rows xg[R*32, 4+D] = {dx,dy,dz,0,f...} (group.hip):
-// forward = pzn_sharedmlp_max_fwd_f32 with C0 = 4+D and W1p[C1,4+D] = {W1[:,0:3], 0, W1[:,3:]}.
-// Backward: feature part of the first layer as clean D-wide GEMMs (no 67/131-wide tiles), the three xyz
-// columns and the bias from the A stream, input gradient only for the D feature columns (xyz needs none).
-//   dh_ws[R*32,C1] scratch; dfeat_rows[R*32,D] may be NULL; dW1 is in the PARAMETER layout [C1,3+D];
-//   dW1, db1, dW2, db2 are overwritten, or added to when accumulate != 0.
-static int sa_mlp_max_bwd(const float* xg, const float* W1p, const float* W2, const float* h, const float* out,
-                          const int32_t* argmax, const float* dout, int R, int D, int C1, int C2, float* dh_ws,
-                          float* dfeat_rows, const int64_t* idx, int rows_in, int rows_out, float* dfeat, float* dW1,
-                          float* db1, float* dW2, float* db2, int accumulate, pzn_stream_t stream) {
-  hipStream_t st = pzn_hip_stream(stream);
-  const int ldx = 4 + D, ldw = 3 + D, M = R * 32;
-  int rc = pool_layer_bwd(dout, argmax, out, W2, h, R, C1, C2, dh_ws, dW2, db2, accumulate, stream);
-  if (rc != PZN_OK) return rc;
-  if (!accumulate) {
-    if (pzn_zero_async(dW1, (size_t)C1 * ldw, st) != PZN_OK) return PZN_ELAUNCH;
-    if (pzn_zero_async(db1, (size_t)C1, st) != PZN_OK) return PZN_ELAUNCH;
-  }
-  if (gemm_precision() != 0 && pzn_df_wgrad_supported(M, C1, ldx)) {
-    // dW1 = dh^T xg over all 4+D columns of the padded rows, the pad column dropped at the store
-    rc = pzn_df_wgrad(dh_ws, C1, nullptr, xg, ldx, M, C1, ldx, dW1, ldw, db1, 3, st);
-    if (rc != PZN_OK) return rc;
-  } else {  // dW1[:, 3:] = dh^T xg[:, 4:];  dW1[:, 0:3] and db1 from the streamed dh tiles
-    GemmArgs p = base_args(C1, D, M);
-    p.A = dh_ws, p.lda = C1, p.B = xg + 4, p.ldb = ldx, p.C = dW1 + 3, p.ldc = ldw;
-    p.bias_grad = db1;
-    p.side = xg, p.ld_side = ldx, p.side_out = dW1, p.ld_side_out = ldw;
-    choose_splits(p);
-    if (p.splits == 1) p.splits = 2, p.k_chunk = ((p.K + 2 * BK - 1) / (2 * BK)) * BK;
-    launch<false, false, EPI_ATOMIC>(p, 1, st);
-    if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
-  }
-  if (!dfeat_rows && !dfeat) return PZN_OK;
-  const bool ws = gemm_precision() != 0 && pzn_ws_gemm_supported(M, D, C1, dh_ws, C1, nullptr, false);
-  if (dfeat && ws)  // dh W1p[:, 4:] scatter-added row by row into grad_feat: the [M, D] rows are never written
-    return pzn_ws_gemm(dh_ws, C1, W1p + 4, ldx, 1, dfeat, D, M, D, C1, nullptr, 0, nullptr, nullptr, nullptr, idx, rows_in,
-                       rows_out, st);
-  if (!dfeat_rows) return PZN_EUNSUPPORTED;
-  if (ws) {
-    rc = pzn_ws_gemm(dh_ws, C1, W1p + 4, ldx, 1, dfeat_rows, D, M, D, C1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0,
-                     0, st);
-    if (rc != PZN_OK) return rc;
-  } else {  // dfeat_rows[M, D] = dh W1p[:, 4:]
-    GemmArgs p = base_args(M, D, C1);
-    p.A = dh_ws, p.lda = C1, p.B = W1p + 4, p.ldb = ldx, p.C = dfeat_rows, p.ldc = D;
-    launch<true, false, EPI_STORE>(p, 1, st);
-    if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
-  }
-  if (dfeat)
-    return pzn_group_feat_bwd_f32(dfeat_rows, idx, rows_out ? M / rows_in : 1, rows_out, rows_in / 32, 32, D, dfeat, stream);
-  return PZN_OK;
-}
-
-PZN_EXPORT int pzn_sa_mlp_max_bwd_f32(const float* xg, const float* W1p, const float* W2, const float* h,
-                                      const float* out, const int32_t* argmax, const float* dout, int R, int D, int C1,
-                                      int C2, float* dh_ws, float* dfeat_rows, float* dW1, float* db1, float* dW2,
-                                      float* db2, int accumulate, pzn_stream_t stream) {
-  PZN_CHECK_ARG(xg && W1p && W2 && h && out && argmax && dout && dh_ws && dW1 && db1 && dW2 && db2);
-  PZN_CHECK_ARG(R > 0 && D > 0 && (D & 3) == 0 && C1 > 0 && C2 > 0);
-  return sa_mlp_max_bwd(xg, W1p, W2, h, out, argmax, dout, R, D, C1, C2, dh_ws, dfeat_rows, nullptr, 0, 0, nullptr, dW1,
-                        db1, dW2, db2, accumulate, stream);
-}
-
-// Same, with the feature gradient scattered straight into grad_feat[B, N, D] (+=; zero-initialised by the
-// caller): grad_feat[b, idx[b,s,k], :] += (dh W1p[:, 4:])[b,s,k,:].  rows_ws[B*S*32, D] is scratch for the
-// shapes the fused epilogue does not cover (may be NULL: PZN_EUNSUPPORTED is returned for those).
-PZN_EXPORT int pzn_sa_mlp_max_bwd_scatter_f32(const float* xg, const float* W1p, const float* W2, const float* h,
-                                              const float* out, const int32_t* argmax, const float* dout,
-                                              const int64_t* idx, int B, int N, int S, int D, int C1, int C2,
-                                              float* dh_ws, float* rows_ws, float* grad_feat, float* dW1, float* db1,
-                                              float* dW2, float* db2, int accumulate, pzn_stream_t stream) {
-  PZN_CHECK_ARG(xg && W1p && W2 && h && out && argmax && dout && idx && dh_ws && grad_feat && dW1 && db1 && dW2 && db2);
-  PZN_CHECK_ARG(B > 0 && N > 0 && S > 0 && D > 0 && (D & 3) == 0 && C1 > 0 && C2 > 0);
-  return sa_mlp_max_bwd(xg, W1p, W2, h, out, argmax, dout, B * S, D, C1, C2, dh_ws, rows_ws, idx, S * 32, N, grad_feat, dW1,
-                        db1, dW2, db2, accumulate, stream);
 }
 
 // 0 = exact-fp32 MFMA everywhere, 1 = bf16x3 split precision everywhere, 2 = auto (default; see gemm.hip).

@@ -253,96 +253,6 @@ PZN_EXPORT int pzn_square_distance_f32(const float* src, const float* dst, int B
   PZN_RETURN_LAUNCH_STATUS();
 }
 
-// Model-internal variants (the drop-in sample_and_group keeps the reference layout above).
-namespace {
-// Padded rows {dx,dy,dz,0,f...}: every row and its feature block start on a 16-byte boundary, so a
-// wavefront moves a neighbourhood with 16-byte loads and 16-byte stores straight through registers —
-// no LDS image (the 3+D layout needs one to turn 268-byte rows into aligned stores), hence no LDS
-// occupancy limit: 8 waves per SIMD keep ~8 x 1 KiB gathers in flight per wave.
-__global__ __launch_bounds__(256) void group_pad_direct_kernel(const float* __restrict__ xyz,
-                                                               const float* __restrict__ feat,
-                                                               const float* __restrict__ new_xyz,
-                                                               const int64_t* __restrict__ idx, int N, int S, int K,
-                                                               int D, long total_q, float* __restrict__ out) {
-  const int lane = threadIdx.x & (PZN_WAVE - 1);
-  const int wave = threadIdx.x / PZN_WAVE;
-  const int V = D >> 2, W4 = 1 + V;  // float4 per row
-  const long q_stride = (long)gridDim.x * 4;
-  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Give each
-  // XCD a contiguous run of queries, i.e. whole clouds: a cloud's feature table (N*D*4 B <= 1 MB) is read
-  // S*K/N = 8 times by its own queries, and that reuse should hit ONE 4 MB L2 instead of eight.
-  const int nb = gridDim.x;
-  const int vb = (nb & 7) == 0 ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  for (long qi = (long)vb * 4 + wave; qi < total_q; qi += q_stride) {
-    const long b = qi / S;
-    const float4* cf = reinterpret_cast<const float4*>(feat + (size_t)b * N * D);
-    float4* o4 = reinterpret_cast<float4*>(out) + qi * K * W4;
-    // K <= 64: lane k owns neighbour k's index; everyone else fetches it with a lane broadcast
-    int myj = lane < K ? clamp_idx(idx[qi * K + lane], N) : 0;
-    for (int t = lane; t < K * V; t += PZN_WAVE) {
-      int k = t / V, v = t - k * V;
-      int j = __shfl(myj, k, PZN_WAVE);
-      o4[k * W4 + 1 + v] = cf[(size_t)j * V + v];
-    }
-    if (lane < K) {
-      const float* p = xyz + ((size_t)b * N + myj) * 3;
-      const float* c = new_xyz + qi * 3;
-      o4[lane * W4] = make_float4(__fsub_rn(p[0], c[0]), __fsub_rn(p[1], c[1]), __fsub_rn(p[2], c[2]), 0.f);
-    }
-  }
-}
-}  // namespace
-
-PZN_EXPORT int pzn_group_pad_fwd_f32(const float* xyz, const float* feat, const float* new_xyz, const int64_t* idx,
-                                     int B, int N, int S, int K, int D, float* out, pzn_stream_t stream) {
-  PZN_CHECK_ARG(xyz && feat && new_xyz && idx && out && B > 0 && N > 0 && S > 0 && K > 0 && K <= 64 && D > 0);
-  PZN_CHECK_ARG((D & 3) == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0 &&
-                (reinterpret_cast<uintptr_t>(out) & 15) == 0);
-  const long total_q = (long)B * S;
-  long blocks = (total_q + 3) / 4;
-  long cap = 256L * 16;
-  int grid = (int)(blocks < cap ? blocks : cap);
-  if (grid >= 64) grid &= ~7;  // multiple of 8 for the XCD remap (the grid-stride loop covers the remainder)
-  PZN_LAUNCH(group_pad_direct_kernel, dim3(grid), dim3(256), 0, pzn_hip_stream(stream), xyz, feat, new_xyz, idx,
-                     N, S, K, D, total_q, out);
-  PZN_RETURN_LAUNCH_STATUS();
-}
-
-namespace {
-// grad_feat[b, idx[b,s,k], :] += rows[b,s,k,:]   (rows are D wide: the feature block only)
-__global__ __launch_bounds__(GRP_WAVES* PZN_WAVE) void group_feat_bwd_kernel(const float* __restrict__ rows,
-                                                                             const int64_t* __restrict__ idx, int N,
-                                                                             int S, int K, int D, long total_q,
-                                                                             float* __restrict__ grad_feat) {
-  const int lane = threadIdx.x & (PZN_WAVE - 1);
-  const int wave = threadIdx.x / PZN_WAVE;
-  const long q_stride = (long)gridDim.x * GRP_WAVES;
-  for (long qi = (long)blockIdx.x * GRP_WAVES + wave; qi < total_q; qi += q_stride) {
-    const long b = qi / S;
-    const int64_t* qidx = idx + qi * K;
-    const float* go = rows + qi * K * D;
-    for (int k = 0; k < K; ++k) {
-      int j = clamp_idx(qidx[k], N);
-      float* dst = grad_feat + ((size_t)b * N + j) * D;
-      const float* g = go + (size_t)k * D;
-      for (int c = lane; c < D; c += PZN_WAVE) atomicAdd(dst + c, g[c]);
-    }
-  }
-}
-}  // namespace
-
-PZN_EXPORT int pzn_group_feat_bwd_f32(const float* rows, const int64_t* idx, int B, int N, int S, int K, int D,
-                                      float* grad_feat, pzn_stream_t stream) {
-  PZN_CHECK_ARG(rows && idx && grad_feat && B > 0 && N > 0 && S > 0 && K > 0 && D > 0);
-  const long total_q = (long)B * S;
-  long blocks = (total_q + GRP_WAVES - 1) / GRP_WAVES;
-  long cap = 256L * 8;
-  int grid = (int)(blocks < cap ? blocks : cap);
-  PZN_LAUNCH(group_feat_bwd_kernel, dim3(grid), dim3(GRP_WAVES * PZN_WAVE), 0, pzn_hip_stream(stream), rows, idx,
-                     N, S, K, D, total_q, grad_feat);
-  PZN_RETURN_LAUNCH_STATUS();
-}
-
 // ------------------------------------------------------- max over the point axis (model5_b.py:475, :741)
 // out[b, c] = max_l x[b, l, c] with the arg-max row (lowest row on ties), and its backward
 // dx[b, l, c] = (l == idx[b, c]) ? dout[b, c] : 0 written as one streaming pass (no separate zero fill).

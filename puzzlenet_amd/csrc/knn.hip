@@ -174,102 +174,6 @@ __global__ __launch_bounds__(KNN_WAVES* PZN_WAVE) void knn32_kernel(
   }
 }
 
-// ------------------------------------------ K <= 32, distances kept in registers --
-// Round-1 register search (R distances per lane in VGPRs, row-wise ballot collection) followed, per query, by the model-internal group write (group.hip,
-// group_pad_direct_kernel): rows {dx,dy,dz,0,f_0..f_{D-1}} of the 32 neighbours.  Selection is VALU work,
-// the group write is HBM work; in one kernel the wavefronts that are selecting hide behind the ones
-// that are streaming rows out, so the stage costs max(select, write) instead of their sum.
-// 1-D grid with the XCD-aware order of the group kernel (whole clouds per XCD: the feature table of a
-// cloud is re-read S*K/N = 8 times and should hit one L2).
-template <int R, int WAVES>
-__global__ __launch_bounds__(WAVES* PZN_WAVE) void knn_group_pad_kernel(
-    const float* __restrict__ xyz, const float* __restrict__ feat, const float* __restrict__ new_xyz, int N, int S,
-    int D, int q_per_block, int blocks_per_cloud, int64_t* __restrict__ idx, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint64_t* cand_all = reinterpret_cast<uint64_t*>(smem_raw);
-  float* sx = reinterpret_cast<float*>(smem_raw + WAVES * KNN_CAND_CAP * sizeof(uint64_t));
-  const float* sy = sx + N;
-  const float* sz = sy + N;
-  const int nb = gridDim.x;
-  const int vb = (nb & 7) == 0 ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  const int b = vb / blocks_per_cloud;
-  const int tid = threadIdx.x;
-  const int lane = tid & (PZN_WAVE - 1);
-  const int wave = tid / PZN_WAVE;
-  stage_cloud(xyz + (size_t)b * N * 3, N, sx, WAVES * PZN_WAVE, tid);
-  __syncthreads();
-  uint64_t* cand = cand_all + wave * KNN_CAND_CAP;
-  const int s_begin = (vb % blocks_per_cloud) * q_per_block;
-  const int s_end = min(S, s_begin + q_per_block);
-  const int V = D >> 2, W4 = 1 + V;
-  const float4* cf = reinterpret_cast<const float4*>(feat + (size_t)b * N * D);
-
-  for (int s = s_begin + wave; s < s_end; s += WAVES) {
-    const long qi = (long)b * S + s;
-    const float* q = new_xyz + qi * 3;
-    const float qx = q[0], qy = q[1], qz = q[2];
-    float d[R];
-    float md = INFINITY;
-    int mi = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      int j = r * PZN_WAVE + lane;
-      float v = INFINITY;
-      if (j < N) v = pzn::sqdist3(qx, qy, qz, sx[j], sy[j], sz[j]);
-      d[r] = v;
-      bool lt = v < md;
-      md = lt ? v : md;
-      mi = lt ? j : mi;
-    }
-    const uint64_t lmin = md < INFINITY ? (((uint64_t)__float_as_uint(md) << 32) | (uint32_t)mi) : ~0ull;
-    uint64_t best = bitonic_sort64(lmin, lane);
-    uint64_t tau = bcast_u64(best, 31);
-    float tau_d = __uint_as_float((uint32_t)(tau >> 32));
-    int cnt = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (__ballot(d[r] <= tau_d) == 0) continue;
-      int j = r * PZN_WAVE + lane;
-      uint64_t key = ((uint64_t)__float_as_uint(d[r]) << 32) | (uint32_t)j;
-      bool pred = d[r] < INFINITY && key < tau && key != lmin;
-      unsigned long long mask = __ballot(pred);
-      if (mask == 0) continue;
-      int pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-      if (pred) cand[pos] = key;
-      cnt += __popcll(mask);
-      while (cnt >= 32) {
-        pzn::wave_lds_sync();
-        uint64_t c = lane >= 32 ? cand[lane - 32] : best;
-        best = bitonic_sort64(c, lane);
-        tau = bcast_u64(best, 31);
-        tau_d = __uint_as_float((uint32_t)(tau >> 32));
-        uint64_t mv = (lane + 32 < cnt) ? cand[lane + 32] : 0;
-        pzn::wave_lds_sync();
-        if (lane + 32 < cnt) cand[lane] = mv;
-        cnt -= 32;
-        pzn::wave_lds_sync();
-      }
-    }
-    if (cnt > 0) {
-      pzn::wave_lds_sync();
-      uint64_t c = lane >= 32 ? ((lane - 32 < cnt) ? cand[lane - 32] : ~0ull) : best;
-      best = bitonic_sort64(c, lane);
-      pzn::wave_lds_sync();
-    }
-    // ---- group write for this query (K = 32): lane k < 32 owns neighbour k
-    const int myj = lane < 32 ? (int)(uint32_t)best : 0;
-    if (lane < 32) idx[qi * 32 + lane] = (int64_t)myj;
-    float4* o4 = reinterpret_cast<float4*>(out) + qi * 32 * W4;
-    for (int t = lane; t < 32 * V; t += PZN_WAVE) {
-      int k = t / V, v = t - k * V;
-      int j = __shfl(myj, k, PZN_WAVE);
-      o4[k * W4 + 1 + v] = cf[(size_t)j * V + v];
-    }
-    if (lane < 32)
-      o4[lane * W4] = make_float4(__fsub_rn(sx[myj], qx), __fsub_rn(sy[myj], qy), __fsub_rn(sz[myj], qz), 0.f);
-  }
-}
-
 // --------------------------------------- K = 32: threshold selection (+ reference-layout group write) --
 // Second-generation selection, exact like the kernels above but with ~40 % fewer vector instructions per query:
 //   pass 1   the cloud image in LDS is padded to 64*R points with +INF; a lane owns the point PAIRS
@@ -819,7 +723,7 @@ int launch_select(const float* xyz, const float* feat, const float* new_xyz, int
   if (GROUP && D == 128 && fixed + (size_t)SEL_WAVES * 8 * W * sizeof(float) <= 150 * 1024) dt = 128, kp = 8;
   const size_t lds = fixed + (GROUP ? (size_t)SEL_WAVES * kp * W * sizeof(float) : 0);
   // ~2 workgroups per CU in ONE round (512 measured better than 1024 for the fused launch); PZN_KG_BLOCKS: tuning aid
-  static const int target = [] { const char* e = getenv("PZN_KG_BLOCKS"); return e ? atoi(e) : 512; }();
+  constexpr int target = 512;
   int qpb = 64;
   while (qpb > SEL_WAVES && (long)B * ((S + qpb - 1) / qpb) < target) qpb >>= 1;
   const int bpc = (S + qpb - 1) / qpb;
@@ -829,7 +733,7 @@ int launch_select(const float* xyz, const float* feat, const float* new_xyz, int
   // workgroups, whole clouds per XCD) fill its 4 MB L2: the write stream then evicts the tables it is gathering from
   // (measured at N = 2048, D = 64: 0.082 -> 0.075 ms per launch; at N = 512, D = 128 the tables fit and plain stores win)
   const long clouds_per_xcd = (64 + bpc - 1) / bpc;
-  static const int nt_force = [] { const char* e = getenv("PZN_KG_NT"); return e ? atoi(e) : -1; }();  // tuning aid
+  constexpr int nt_force = -1;  // tuning aid
   const bool nt = GROUP && (nt_force >= 0 ? nt_force != 0 : clouds_per_xcd * (long)N * D * 4 > 3L * 1024 * 1024);
   int dshift = -1;  // log2(D) when D is a power of two
   if (GROUP && D > 0 && (D & (D - 1)) == 0) dshift = __builtin_ctz((unsigned)D);
@@ -930,35 +834,3 @@ PZN_EXPORT int pzn_ball_query_f32(float radius2, int nsample, const float* xyz, 
   PZN_RETURN_LAUNCH_STATUS();
 }
 
-// pointnet_util.py:117-132 for the encoder path in ONE launch: idx[B,S,32] = the 32 nearest neighbours
-// (stable (distance, index) order, as pzn_knn_f32) and out[B,S,32,4+D] = the padded grouped rows
-// (as pzn_group_pad_fwd_f32).  Needs 64 <= N <= 4096, N*12 B of LDS, D % 4 == 0.
-PZN_EXPORT int pzn_knn_group_pad_f32(const float* xyz, const float* feat, const float* new_xyz, int B, int N, int S,
-                                     int D, int64_t* idx, float* out, pzn_stream_t stream) {
-  PZN_CHECK_ARG(xyz && feat && new_xyz && idx && out && B > 0 && N >= 64 && S > 0 && D > 0 && (D & 3) == 0);
-  PZN_CHECK_ARG((reinterpret_cast<uintptr_t>(feat) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0);
-  const int rows = (N + PZN_WAVE - 1) / PZN_WAVE;
-  if (rows > 64) return PZN_EUNSUPPORTED;
-  hipStream_t st = pzn_hip_stream(stream);
-  constexpr int KGW = 4;  // wavefronts per workgroup (8 measured the same: the kernel is not occupancy-limited)
-  Geometry g = geometry(B, N, S, KGW * KNN_CAND_CAP * sizeof(uint64_t));
-  if (!g.use_lds) return PZN_EUNSUPPORTED;
-  const int bpc = (S + g.q_per_block - 1) / g.q_per_block;
-  const int nb = B * bpc;
-#define PZN_KG(RR)                                                                                              \
-  do {                                                                                                          \
-    if (set_lds(&knn_group_pad_kernel<RR, KGW>, g.lds) != PZN_OK) return PZN_ELAUNCH;                           \
-    PZN_LAUNCH((knn_group_pad_kernel<RR, KGW>), dim3(nb), dim3(KGW * PZN_WAVE), g.lds, st, xyz, feat,   \
-                       new_xyz, N, S, D, g.q_per_block, bpc, idx, out);                                         \
-  } while (0)
-  if (rows <= 8)
-    PZN_KG(8);
-  else if (rows <= 16)
-    PZN_KG(16);
-  else if (rows <= 32)
-    PZN_KG(32);
-  else
-    PZN_KG(64);
-#undef PZN_KG
-  PZN_RETURN_LAUNCH_STATUS();
-}

@@ -241,7 +241,7 @@ size_t pzn_outproj_maxpts_ws_bytes(int L, int E, int nslice, int Nout) {
 // -> PZN_EUNSUPPORTED for shapes it does not take (the caller composes slices + pzn_maxpool_points_fwd_f32 then)
 int pzn_outproj_maxpts(const float* const* x, const float* W, const float* bias, int B, int L, int E, int nslice, int Nout,
                        float* out, float* fmax, int32_t* arg, void* workspace, hipStream_t st) {
-  static const bool on = [] { const char* e = getenv("PZN_OUTPROJ_FUSED"); return !(e && e[0] == '0'); }();   // tuning aid
+  constexpr bool on = true;   // tuning aid
   if (!on || !workspace || pzn_outproj_maxpts_ws_bytes(L, E, nslice, Nout) == 0) return PZN_EUNSUPPORTED;
   uintptr_t al = reinterpret_cast<uintptr_t>(workspace);
   for (int i = 0; i < OP_SLICES; ++i) al |= reinterpret_cast<uintptr_t>(x[i]);

@@ -6,33 +6,19 @@
 // gemm.hip: 0 = attention products on the split-precision path (fp32 results), 1 = single bf16 MFMAs (pzn_attn_set_precision)
 int pzn_attn_precision_mode();
 
-// poolbwd.hip: sparse backward of linear + ReLU + max over 32 neighbours.
-//   dh != NULL: dh[G*32, C1] = scatter(dout) W, ReLU-masked by h when h != NULL (overwritten)
-//   dW != NULL: dW[C2, C1] += scatter(dout)^T h,  db[C2] += column sums (db may be NULL)
-bool pzn_pool_bwd_supported(int C1, int C2, const float* W, const float* h, const float* dh);
-// Where the sparse passes can regenerate the first layer's rows from (per-point first layer, csrc/sapoint.hip):
-//   h[(g, k), :] = relu(P[(g / S) * N + idx[g*32 + k], :] + Q[g, :])
-// Q == NULL: the round-1 form  relu(W1[:,0:3] (xyz[idx] - centre) + P[idx] + b1)  (gate of the input-gradient pass only).
-// Q != NULL: P is the per-point table WITH the coordinate term folded in and Q = b1 - W1[:,0:3] centre (pzn_sa_prep_f32):
-//   the input-gradient pass regenerates its gate, the weight-gradient pass regenerates the rows themselves (h == NULL),
-//   and the input-gradient pass also accumulates the gradients that flow through Q: dW1x[c, 0:3] -= sum_g dq[g,c] centre_g,
-//   db1[c] += sum_g dq[g,c] with dq[g,:] = sum_k dh[(g,k),:] (both may be NULL).
+// poolbwd.hip: weight-gradient pass of "linear + ReLU + max over 32 neighbours" as the sparse problem it is:
+//   dW[C2, C1] += scatter(dout)^T h,  db[C2] += column sums (db may be NULL), one non-zero of scatter(dout) per (group, channel).
+// h[G*32, C1] = the rows, or NULL with a gate source: the rows are then regenerated from the per-point first layer
+// (csrc/sapoint.hip, pzn_sa_prep_f32):  h[(g, k), :] = relu(P[(g / S) * N + idx[g*32 + k], :] + Q[g, :]).
 struct PznGateSource {
-  const float* P;
-  const int64_t* idx;
-  const float* xyz;
-  const float* new_xyz;
-  const float* W1;
-  const float* b1;
-  int ldw, N, S;
-  const float* Q;
-  float* dW1x;   // [C1, ldw] (columns 0..2 are added to)
-  float* db1;    // [C1]
-  uint32_t* rowmask = nullptr;   // [G] or NULL: bit k of word g = row (g, k) of dh is non-zero; rows whose PAIR (2i, 2i+1) has no
-                                 // bit set are then NOT written (the reader skips rows without their bit)
+  const float* P;        // [B*N, C1]
+  const int64_t* idx;    // [G*32]
+  const float* Q;        // [G, C1]
+  int N, S;
 };
-int pzn_pool_bwd_sparse(const float* dout, const int32_t* argmax, const float* out, const float* W, const float* h,
-                        float* dh, float* dW, float* db, int G, int C1, int C2, hipStream_t st, const PznGateSource* gs = nullptr);
+bool pzn_pool_wgrad_supported(int C1, int C2, const float* h);
+int pzn_pool_wgrad_sparse(const float* dout, const int32_t* argmax, const float* out, const float* h, float* dW, float* db,
+                          int G, int C1, int C2, hipStream_t st, const PznGateSource* gs = nullptr);
 
 // wsgemm.hip: weight-stationary bf16x3 GEMM for skinny layers.  C[M,N] = epi(A[M,K] W^T), W[n*ldw+k]
 // (w_kmajor = 0) or W[k*ldw+n] (w_kmajor = 1); genY masks A by genY > 0, maskH masks C, argmax != NULL

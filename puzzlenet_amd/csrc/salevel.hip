@@ -331,7 +331,7 @@ size_t pzn_sa_level_stream_workspace_bytes(int C1, int C2) {
 
 // -> PZN_EUNSUPPORTED for shapes it does not take (the weight-stationary kernel then)
 static bool sa_stream_on() {
-  static const bool on = [] { const char* e = getenv("PZN_SA_STREAM"); return !(e && e[0] == '0'); }();   // tuning aid
+  constexpr bool on = true;   // tuning aid
   return on;
 }
 

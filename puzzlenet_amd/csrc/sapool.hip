@@ -280,9 +280,9 @@ PZN_EXPORT int pzn_sa_level_bwd_pt_f32(const float* dout, const int32_t* argmax,
     if (pzn_zero_async(db2, (size_t)C2, st) != PZN_OK) return PZN_ELAUNCH;
   }
   const int G = B * S;
-  // weight gradient of the pooled layer: the sparse pass of csrc/poolbwd.hip on regenerated rows (dh == NULL: no input-gradient pass)
-  PznGateSource gs{Pp, idx, nullptr, new_xyz, nullptr, nullptr, 3 + D, N, S, Q, nullptr, nullptr};
-  int rc = pzn_pool_bwd_sparse(dout, argmax, out, W2, nullptr, nullptr, dW2, db2, G, C1, C2, st, &gs);
+  // weight gradient of the pooled layer: the sparse pass of csrc/poolbwd.hip on regenerated rows
+  PznGateSource gs{Pp, idx, Q, N, S};
+  int rc = pzn_pool_wgrad_sparse(dout, argmax, out, nullptr, dW2, db2, G, C1, C2, st, &gs);
   if (rc != PZN_OK) return rc;
   uint2* hits = static_cast<uint2*>(workspace);
   uint16_t* rstart = reinterpret_cast<uint16_t*>(static_cast<unsigned char*>(workspace) + (((size_t)G * C2 * sizeof(uint2) + 255) / 256) * 256);
@@ -300,24 +300,15 @@ PZN_EXPORT int pzn_sa_level_bwd_pt_f32(const float* dout, const int32_t* argmax,
   PointArgs a{hits, rstart, W2, Pp, Q, xyz, new_xyz, off, rows, pts, dP, dW1, db1, B, N, S, C1, C2, 3 + D, pc};
   const int ny = C1 / PP_COLS;
   const size_t lds = (size_t)C2 * PP_COLS * sizeof(float);      // >= the final sums' 16 x 4 x 128 floats for C2 >= 64
-  static const int gf = [] { const char* e = getenv("PZN_PP_GF"); return e ? atoi(e) : 8; }();      // tuning aid: rows in flight
-  static const int wgs = [] { const char* e = getenv("PZN_PP_WGS"); return e ? atoi(e) : 0; }();    // tuning aid: workgroups per slice
   const int per_cu = 1;      // 16 wavefronts of 92 registers: one workgroup per CU whatever the slice's size
-  int gx = wgs > 0 ? wgs : 256 * per_cu / ny;
+  int gx = 256 * per_cu / ny;
   if (gx < 8) gx = 8;
   gx &= ~7;
   const dim3 grid((unsigned)gx, (unsigned)ny);
-#define PZN_PP(GFV)                                                                                                        \
-  do {                                                                                                                    \
-    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_point_kernel<16, GFV>),                 \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)       \
-      return PZN_ELAUNCH;                                                                                                 \
-    PZN_LAUNCH((pool_point_kernel<16, GFV>), grid, dim3(1024), lds, st, a);                                       \
-  } while (0)
-  if (gf == 4)
-    PZN_PP(4);
-  else
-    PZN_PP(8);
-#undef PZN_PP
+  // eight rows in flight per wavefront (4 and 16 measured the same or slower)
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_point_kernel<16, 8>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PZN_ELAUNCH;
+  PZN_LAUNCH((pool_point_kernel<16, 8>), grid, dim3(1024), lds, st, a);
   PZN_RETURN_LAUNCH_STATUS();
 }

@@ -734,8 +734,6 @@ def test_outproj_maxpts_vs_float64(dev, B, need_out):
     two identical points in every cloud pin the tie rule (the lower point wins, as torch.max)."""
     import os
     from puzzlenet_amd import _lib, ops
-    if os.environ.get("PZN_OUTPROJ_FUSED", "1") == "0":
-        pytest.skip("the tuning switch PZN_OUTPROJ_FUSED=0 turns this kernel off (it then reports PZN_E_UNSUPPORTED)")
     L, E, Nout = 256, 256, 1024
     M = B * L
     g = torch.Generator().manual_seed(21 + B)

@@ -255,29 +255,6 @@ def test_full_size_properties(dev):
     assert torch.equal(new_points[:, :, :, :3], grouped_xyz - new_xyz[:, :, None])
 
 
-@pytest.mark.parametrize("B,N,S,D", [(3, 2048, 512, 64), (2, 512, 256, 128), (2, 200, 33, 8), (1, 4096, 64, 16)])
-def test_knn_group_pad_fused_vs_oracle(dev, B, N, S, D):
-    """pzn_knn_group_pad_f32 == oracle kNN (bit-exact idx) + oracle group in the padded layout."""
-    from puzzlenet_amd import _lib, ops
-    rng = np.random.default_rng(N + D)
-    xyz = rng.random((B, N, 3), dtype=np.float32)
-    xyz[:, 5:15] = xyz[:, 40:50]                                    # duplicates: ties
-    feat = rng.standard_normal((B, N, D)).astype(np.float32)
-    q = xyz[:, rng.permutation(N)[:S]].copy()
-    idx = torch.empty((B, S, 32), dtype=torch.int64, device=dev)
-    out = torch.empty((B, S, 32, 4 + D), dtype=torch.float32, device=dev)
-    txyz, tfeat, tq = _t(xyz, dev), _t(feat, dev), _t(q, dev)
-    _lib.call("pzn_knn_group_pad_f32", txyz.data_ptr(), tfeat.data_ptr(), tq.data_ptr(), B, N, S, D,
-              idx.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    want_idx = orc.knn(xyz, q, 32)
-    assert np.array_equal(idx.cpu().numpy(), want_idx)
-    g = orc.group(xyz, feat, q, want_idx)                            # [B,S,32,3+D]
-    o = out.cpu().numpy()
-    assert np.array_equal(o[..., :3].view(np.uint32), g[..., :3].view(np.uint32))
-    assert (o[..., 3] == 0).all()
-    assert np.array_equal(o[..., 4:].view(np.uint32), g[..., 3:].view(np.uint32))
-
-
 @pytest.mark.parametrize("B,N,S,D", [(3, 2048, 512, 64), (2, 512, 256, 128), (2, 200, 33, 8), (1, 4096, 64, 16),
                                      (2, 64, 10, 4), (1, 1000, 77, 12), (2, 130, 130, 20), (1, 3000, 19, 256),
                                      (1, 8192, 96, 64), (1, 6000, 50, 128)])

@@ -37,15 +37,12 @@ def main():
         new_xyz = ops.index_points(xyz, fps).contiguous()
         idx = torch.empty((B, S, 32), dtype=torch.int64, device=dev)
         out = torch.empty((B, S, 32, 3 + D), dtype=torch.float32, device=dev)
-        outp = torch.empty((B, S, 32, 4 + D), dtype=torch.float32, device=dev)
         p = ops._p
         st = ops._stream()
         calls = {
             "knn": lambda: _lib.call("pzn_knn_f32", p(xyz), p(new_xyz), B, N, S, 32, p(idx), st),
             "group": lambda: _lib.call("pzn_group_fwd_f32", p(xyz), p(feat), p(new_xyz), p(idx), B, N, S, 32, D, p(out),
                                        None, st),
-            "knn_group_pad": lambda: _lib.call("pzn_knn_group_pad_f32", p(xyz), p(feat), p(new_xyz), B, N, S, D, p(idx),
-                                               p(outp), st),
         }
         if hasattr(lib, "pzn_knn_group_f32"):
             calls["knn_group"] = lambda: _lib.call("pzn_knn_group_f32", p(xyz), p(feat), p(new_xyz), B, N, S, D, p(idx),
