@@ -331,6 +331,28 @@ int pzn_sa_level_bwd_pt_f32(const float* dout, const int32_t* argmax, const floa
                             int C2, float* dP, float* dW2, float* db2, float* dW1, float* db1, int accumulate, void* workspace,
                             pzn_stream_t stream);
 
+/* One set-abstraction level of the encoder behind one entry point each way (csrc/sachain.hip): the sequences
+ *   fwd:  P' = feat W1[:,3:]^T (pzn_linear_fwd_f32) -> neighbour search when idx == NULL (pzn_knn_f32) -> pzn_sa_prep_f32 ->
+ *         pzn_sa_level_prep_weights_f32 -> pzn_sa_level_fwd_packed_f32
+ *   bwd:  pzn_knn_inverse_lists -> pzn_sa_level_bwd_pt_f32 -> dfeat = dP W1[:,3:] (pzn_linear_dgrad_f32) ->
+ *         dW1[:,3:] += dP^T feat (pzn_linear_slice_wgrad_f32)
+ * enqueued by the library on one caller-owned buffer per direction (same kernels, order and operands as the caller-composed
+ * form: 2 calls and 2 allocations per level instead of 9 and ~13).  xyz[B,N,3], feat[B,N,D], new_xyz[B,S,3], idx[B,S,32] or NULL,
+ * W1[C1,3+D], b1[C1], W2[C2,C1], b2[C2]; out[B*S,C2], argmax[B*S,C2]; saved / scratch: pzn_sa_level_chain_saved_bytes /
+ * _scratch_bytes, 256-byte aligned; the backward gets the idx the forward got (NULL: the searched indices live in `saved`).
+ * accumulate != 0: the four parameter gradients are ADDED to; 0: overwritten.  dfeat[B,N,D] overwritten, may be NULL.
+ * C1 % 128 == 0, C2 in {64,128,256}: PZN_EUNSUPPORTED otherwise, before anything is launched. */
+size_t pzn_sa_level_chain_saved_bytes(int B, int N, int S, int D, int C1, int C2);
+size_t pzn_sa_level_chain_scratch_bytes(int B, int N, int S, int C1, int C2);
+int pzn_sa_level_chain_fwd_f32(const float* xyz, const float* feat, const float* new_xyz, const int64_t* idx,
+                               const float* W1, const float* b1, const float* W2, const float* b2, int B, int N, int S,
+                               int D, int C1, int C2, float* out, int32_t* argmax, void* saved, pzn_stream_t stream);
+int pzn_sa_level_chain_bwd_f32(const float* dout, const int32_t* argmax, const float* out, const float* xyz,
+                               const float* feat, const float* new_xyz, const int64_t* idx, const float* W1,
+                               const float* W2, const void* saved, int B, int N, int S, int D, int C1, int C2,
+                               float* dfeat, float* dW1, float* db1, float* dW2, float* db2, int accumulate,
+                               void* scratch, pzn_stream_t stream);
+
 /* The per-point stem of the encoder in one launch each way (csrc/stem.hip, model5_b.py:447-448):
  *   out = relu(bn2(mlp2(relu(bn1(mlp1(xyz))))))   xyz[B,N,3], mlp1 = (W1[64,3], b1[64]), mlp2 = (W2[64,64], b2[64]),
  * bn1 / bn2 = BatchNorm1d(N) over the POINT axis of [B,N,64] (weight / bias / running buffers [N]; any may be NULL as the module
@@ -454,6 +476,27 @@ int pzn_attn_fused_wgrads(const float* dz, const float* t, const float* dq, cons
                           const float* dv, const float* x, int M, int E, int dk_dim, float* dWq,
                           float* dbq, float* dWk, float* dbk, float* dWv, float* dbv, float* dWo,
                           float* dbo, int accumulate, pzn_stream_t stream);
+
+/* model5_b.py:462-475 of ONE encoder behind one entry point each way (csrc/attnchain.hip): the four layerAttention blocks, the
+ * mean of their maps, the out projection over the five un-concatenated slices and the max over the points, enqueued by the
+ * library on one caller-owned buffer per direction (the same kernels, in the same order, on the same operands as the entry
+ * points above composed by the caller: 2 calls and 2 allocations per encoder and training step instead of 24 and ~100).
+ *   params: HOST array of 34 device pointers in the module's order: per block (Wq, bq, Wk, bk, Wv, bv, Wo, bo) x 4, then the out
+ *           projection's W[1024, 1280] and bias[1024].   x[B*256, 256].
+ *   fwd:  map = the mean map, [B,256,256] (strips == 0) or its strip column sums [B,16,256] (strips != 0, see pzn_attn_fused_fwd);
+ *         out[B*256, 1024] or NULL; fmax[B,1024], arg[B,1024]; saved: pzn_attn_chain_saved_bytes(B) bytes, 256-byte aligned,
+ *         kept for the backward.
+ *   bwd:  the case predict5 creates - only the maximum carries a gradient, dfg[B,1024]; grads: HOST array of 34 device pointers
+ *         (accumulate != 0: all ADDED to; 0: the blocks' overwritten, the out projection's two zero-initialised by the caller);
+ *         dx[B*256, 256] overwritten; scratch: pzn_attn_chain_scratch_bytes(B) bytes, 256-byte aligned.
+ * The precision mode (pzn_attn_set_precision) must be the same for both calls. */
+size_t pzn_attn_chain_saved_bytes(int B);
+size_t pzn_attn_chain_scratch_bytes(int B);
+int pzn_attn_chain_fwd_f32(const float* x, const float* const* params, int B, int strips, float* map, float* out,
+                           float* fmax, int32_t* arg, void* saved, pzn_stream_t stream);
+int pzn_attn_chain_bwd_f32(const float* x, const float* const* params, const void* saved, const int32_t* arg,
+                           const float* dfg, int B, float* const* grads, int accumulate, float* dx, void* scratch,
+                           pzn_stream_t stream);
 
 /* First layer of the boundary heads without the concatenation (model5_b.py:745-752: Linear(cat([g.repeat(1,N,1), x], -1))
  * = x W[:,Cg:]^T per point + (g W[:,:Cg]^T + b) per cloud):

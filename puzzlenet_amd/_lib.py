@@ -74,6 +74,10 @@ SIGNATURES = {
     "pzn_attn_fused_fwd": (_c_i, [_c_i] + [_PP] * 6 + [_c_i] + [_PP] * 5 + [_c_i, _c_fl, _c_f]),
     "pzn_attn_fused_bwd_q": (_c_i, [_c_i, _PP, _c_i, _PP, _c_i] + [_PP] * 5 + [_c_i] + [_PP] * 6 + [_c_f]),
     "pzn_attn_fused_bwd_k": (_c_i, [_c_i] + [_PP] * 9 + [_c_i] + [_PP] * 3 + [_c_f]),
+    "pzn_attn_chain_saved_bytes": (_c_sz, [_c_i]),
+    "pzn_attn_chain_scratch_bytes": (_c_sz, [_c_i]),
+    "pzn_attn_chain_fwd_f32": (_c_i, [_c_f, _PP, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f]),
+    "pzn_attn_chain_bwd_f32": (_c_i, [_c_f, _PP, _c_f, _c_f, _c_f, _c_i, _PP, _c_i, _c_f, _c_f, _c_f]),
     "pzn_attn_fused_wgrads": (_c_i, [_c_f] * 6 + [_c_i] * 3 + [_c_f] * 8 + [_c_i, _c_f]),
     "pzn_sharedmlp_max_fwd_f32": (_c_i, [_c_f] * 5 + [_c_i] * 4 + [_c_f] * 4),
     "pzn_sharedmlp_max_bwd_f32": (_c_i, [_c_f] * 7 + [_c_i] * 4 + [_c_f] * 6 + [_c_i, _c_f]),
@@ -116,6 +120,10 @@ SIGNATURES = {
     "pzn_point_mlp3_fwd_f32": (_c_i, [_c_f, _c_ll, _c_i, _c_f, _c_i, _c_f, _c_i, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f]),
     "pzn_cloud_gated_colsum_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_outproj_maxpts_fwd_f32": (_c_i, [_PP, _c_i, _c_f, _c_f] + [_c_i] * 4 + [_c_f] * 5),
+    "pzn_sa_level_chain_saved_bytes": (_c_sz, [_c_i] * 6),
+    "pzn_sa_level_chain_scratch_bytes": (_c_sz, [_c_i] * 5),
+    "pzn_sa_level_chain_fwd_f32": (_c_i, [_c_f] * 8 + [_c_i] * 6 + [_c_f] * 4),
+    "pzn_sa_level_chain_bwd_f32": (_c_i, [_c_f] * 10 + [_c_i] * 6 + [_c_f] * 5 + [_c_i, _c_f, _c_f]),
     "pzn_sa_level_bwd_pt_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),
     "pzn_sa_level_bwd_pt_f32": (_c_i, [_c_f] * 12 + [_c_i] * 6 + [_c_f] * 5 + [_c_i, _c_f, _c_f]),
     "pzn_knn_inverse_lists": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f]),

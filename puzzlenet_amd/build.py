@@ -24,7 +24,6 @@ LIB = os.path.join(HERE, "libpzn.so")
 # vector types) is not touched by the flag.  wsgemm / dfgemm / poolbwd keep the default: their code has no op_sel
 # packed forms (checked in the ISA) and the generated-row max-pool kernel measured 3-5 % slower without the pairing.
 NOSLP = ["-fno-slp-vectorize"]
-_OFF = os.environ.get("PZN_BUILD_SLP", "") == "1"      # tuning aid: build with the compiler's default again
 SOURCES = [
     ("core.hip", NOSLP),
     ("fps.hip", ["-ffp-contract=off"] + NOSLP),
@@ -35,6 +34,7 @@ SOURCES = [
     ("chamfer.hip", NOSLP),
     ("gemm.hip", NOSLP),
     ("attnfused.hip", NOSLP),
+    ("attnchain.hip", NOSLP),
     ("salevel.hip", NOSLP),
     ("outproj.hip", NOSLP),
     ("pointmlp.hip", NOSLP),
@@ -46,13 +46,12 @@ SOURCES = [
     ("se3.hip", NOSLP),
     ("sapoint.hip", NOSLP),
     ("sapool.hip", NOSLP),
+    ("sachain.hip", NOSLP),
     ("bnpoints.hip", NOSLP),
     ("stem.hip", NOSLP),
     ("losstail.hip", NOSLP),
     ("datapipe.hip", ["-ffp-contract=off"] + NOSLP),
 ]
-if _OFF:
-    SOURCES = [(f, [x for x in fl if x not in NOSLP]) for f, fl in SOURCES]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 

@@ -1312,6 +1312,72 @@ class _AttnChainFused(torch.autograd.Function):
         return tuple(grads)
 
 
+class _AttnChainOne(torch.autograd.Function):
+    """model5_b.py:462-475 of ONE encoder behind one C entry point each way (csrc/attnchain.hip: the kernels of
+    _AttnChainFused, enqueued by the library on one caller-owned buffer per direction) for the case predict5 creates: `out` is
+    not wanted and only f_global = max over the points carries a gradient.  inputs: strips flag, x[B,L,E], the 34 parameters
+    -> (mean map [B,L,L] or its strip column sums [B,L/16,L], f_global[B,Nout])."""
+
+    @staticmethod
+    def forward(ctx, strips, x, *params):
+        x = _f32(x, "x")
+        ps = [_f32(t, "param") for t in params]
+        B, L, E = x.shape
+        Nout = ps[32].shape[0]
+        dev = x.device
+        lib = _lib.load()
+        amap = torch.empty((B, L // 16, L) if strips else (B, L, L), dtype=torch.float32, device=dev)
+        f_global = torch.empty((B, Nout), dtype=torch.float32, device=dev)
+        arg = torch.empty((B, Nout), dtype=torch.int32, device=dev)
+        saved = torch.empty((lib.pzn_attn_chain_saved_bytes(B),), dtype=torch.uint8, device=dev)
+        with _on(dev):
+            _call("pzn_attn_chain_fwd_f32", _p(x), _ptrs(ps), B, int(bool(strips)), _p(amap), None, _p(f_global), _p(arg),
+                  _p(saved), _stream(),
+                  flops=4 * (2 * B * L * E * (2 * (E // 4) + E) + 2 * B * L * E * E + 2 * B * L * L * (E // 4 + E)) + 2 * B * L * 5 * E * Nout)
+        if WINNER_CAPTURE is not None:
+            WINNER_CAPTURE.append(("gmax", params[32].data_ptr(), arg))
+        ctx.save_for_backward(x, saved, arg, *ps)
+        ctx.attn_mode = lib.pzn_attn_get_precision()
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(amap)
+        return amap, f_global
+
+    @staticmethod
+    def backward(ctx, _dmap, dfg):
+        lib = _lib.load()
+        if lib.pzn_attn_get_precision() != ctx.attn_mode:
+            raise _lib.PznError("pzn_attn_set_precision() changed between the forward and the backward of an attention chain "
+                                f"(forward: mode {ctx.attn_mode}): its bf16-plane images were written for the forward's mode")
+        x, saved, arg = ctx.saved_tensors[:3]
+        ps = list(ctx.saved_tensors[3:])
+        if dfg is None:
+            return (None,) * 36
+        B, L, E = x.shape
+        dev = x.device
+        dfg = _f32(dfg, "df_global")
+        sinks = [_sink(p_, ctx.needs_input_grad[2 + j]) for j, p_ in enumerate(ps)]
+        direct = all(s_ is not None for s_ in sinks)
+        if direct:
+            gp = sinks
+        else:      # (the out projection's sparse backward ADDS: zero-initialised; the blocks' gradients are overwritten)
+            gp = [torch.empty_like(p_) for p_ in ps[:32]] + [torch.zeros_like(ps[32]), torch.zeros_like(ps[33])]
+        dx = torch.empty((B, L, E), dtype=torch.float32, device=dev)
+        scratch = torch.empty((lib.pzn_attn_chain_scratch_bytes(B),), dtype=torch.uint8, device=dev)
+        with _on(dev):
+            _call("pzn_attn_chain_bwd_f32", _p(x), _ptrs(ps), _p(saved), _p(arg), _p(dfg), B, _ptrs(gp), int(direct), _p(dx),
+                  _p(scratch), _stream())
+        if direct:
+            return (None, dx) + (None,) * 34
+        return (None, dx) + tuple(gp)
+
+
+def attention_chain_one_supported(x, dk, w_out):
+    """The shape the one-call chain takes: the encoder's (256 points, E = 256, dk = 64, a 1280 -> 1024 out projection) on the
+    split-precision matrix-core path, 16-byte aligned."""
+    return (attention_chain_fused_supported(x, dk, w_out) and tuple(w_out.shape) == (1024, 1280) and
+            _lib.load().pzn_outproj_maxpts_workspace_bytes(256, 256, 5, 1024) > 0 and _lib.load().pzn_gemm_get_precision() != 0)
+
+
 def attention_chain_fused(xs, blocks_list, w_outs, b_outs, need_out=True, map_strips=False):
     """xs: list of nprob inputs [B,L,E]; blocks_list[p]: four 8-tuples; -> list of (out, mean map, f_global) per problem.
     need_out=False: only f_global = max over the points of the out projection is wanted (predict5, model5_b.py:723);
@@ -1319,6 +1385,15 @@ def attention_chain_fused(xs, blocks_list, w_outs, b_outs, need_out=True, map_st
     map_strips=True: the caller only takes the mean of the mean map over its rows (training_step, model5_b.py:937-942): the
     second result is [B,L/16,L], each row the scaled column sums of a strip of 16 query rows, with
     result.mean(dim=1) == mean_map.mean(dim=1); the [B,L,L] map (16.7 MB read + written per block and encoder) never exists."""
+    if not need_out and not KernelTimer.enabled and all(
+            attention_chain_one_supported(x, blocks[0][0].shape[0], w) for x, blocks, w in zip(xs, blocks_list, w_outs)):
+        # what predict5 asks for (only the maximum of the projection): one C call per encoder and direction.  (With the
+        # entry-point timer on - bench.py's `stages` - the chain is composed here, so that every kernel's entry point is timed.)
+        res = []
+        for x, blocks, w, b in zip(xs, blocks_list, w_outs, b_outs):
+            amap, fg = _AttnChainOne.apply(bool(map_strips), x, *[p_ for blk in blocks for p_ in blk], w, b)
+            res.append((None, amap, fg))
+        return res
     flat = []
     for x, blocks, w, b in zip(xs, blocks_list, w_outs, b_outs):
         flat += [x] + [p_ for blk in blocks for p_ in blk] + [w, b]
@@ -1466,9 +1541,10 @@ class _SaLevelFused(torch.autograd.Function):
     """The set-abstraction level (model5_b.py:449-454 / :456-461) with the first layer per point and its rows never in
     memory: W1[:,0:3] (xyz[j] - centre) is split into a per-point and a per-group part, so a grouped row is
     relu(Pp[idx] + Q[group]) with Pp = feat W1[:,3:]^T + W1[:,0:3] xyz and Q = b1 - W1[:,0:3] centre; the rows are generated
-    inside the matrix-core kernel's operand loader forward (pzn_sa_level_fwd_f32) and inside both sparse passes backward
-    (pzn_sa_level_bwd_pt_f32).  Same result as group + shared_mlp_max up to the order of the fp32 sum; no h tensor
-    (537 MB per level and cloud at B = 64)."""
+    inside the matrix-core kernel's operand loader forward and inside the backward passes (weight gradients of the pooled
+    layer, walk by point).  Same result as group + shared_mlp_max up to the order of the fp32 sum; no h tensor (537 MB per
+    level and cloud at B = 64).  One C entry point each way (csrc/sachain.hip) on one buffer per direction; with the
+    entry-point timer on the same launches are made one by one from here."""
 
     @staticmethod
     def forward(ctx, xyz, feat, new_xyz, idx, w1, b1, w2, b2):
@@ -1481,22 +1557,44 @@ class _SaLevelFused(torch.autograd.Function):
         C1, C2 = w1.shape[0], w2.shape[0]
         dev = xyz.device
         R = B * S
+        lib = _lib.load()
+        out = torch.empty((R, C2), dtype=torch.float32, device=dev)
+        arg = torch.empty((R, C2), dtype=torch.int32, device=dev)
+        ctx.stepwise = KernelTimer.enabled
+        if ctx.stepwise:
+            saved = _SaLevelFused._forward_stepwise(xyz, feat, new_xyz, idx, w1, b1, w2, b2, out, arg)
+        else:
+            saved = (torch.empty((lib.pzn_sa_level_chain_saved_bytes(B, N, S, D, C1, C2),), dtype=torch.uint8, device=dev),)
+            with _on(dev):
+                _call("pzn_sa_level_chain_fwd_f32", _p(xyz), _p(feat), _p(new_xyz), _p(idx), _p(w1), _p(b1), _p(w2), _p(b2),
+                      B, N, S, D, C1, C2, _p(out), _p(arg), _p(saved[0]), _stream())
+        if WINNER_CAPTURE is not None:
+            WINNER_CAPTURE.append(("sa", w2.data_ptr(), arg.view(B, S, C2)))
+        ctx.have_idx = idx is not None
+        ctx.save_for_backward(xyz, feat, new_xyz, idx if idx is not None else xyz.new_empty(0), w1, w2, out, arg, *saved)
+        ctx.dims = (B, N, S, D, R, C1, C2)
+        ctx.param_refs = (w1, b1, w2, b2)
+        return out.reshape(B, S, C2)
+
+    @staticmethod
+    def _forward_stepwise(xyz, feat, new_xyz, idx, w1, b1, w2, b2, out, arg):
+        """The forward's launches one entry point at a time (bench.py's `stages`) -> (idx, w_f, P, Q) for the backward."""
+        B, N, _ = xyz.shape
+        S, D, C1, C2 = new_xyz.shape[1], feat.shape[-1], w1.shape[0], w2.shape[0]
+        dev, R = xyz.device, B * new_xyz.shape[1]
         w_f = w1[:, 3:].contiguous()
         P = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
         Q = torch.empty((R, C1), dtype=torch.float32, device=dev)
-        out = torch.empty((R, C2), dtype=torch.float32, device=dev)
-        arg = torch.empty((R, C2), dtype=torch.int32, device=dev)
         with _on(dev):
-            _call("pzn_linear_fwd_f32", _p(feat), _p(w_f), None, B * N, D, C1, 0, _p(P), _stream(),
-                  flops=2 * B * N * D * C1)
+            _call("pzn_linear_fwd_f32", _p(feat), _p(w_f), None, B * N, D, C1, 0, _p(P), _stream(), flops=2 * B * N * D * C1)
             if idx is None:
                 idx = torch.empty((B, S, 32), dtype=torch.int64, device=dev)
                 _call("pzn_knn_f32", _p(xyz), _p(new_xyz), B, N, S, 32, _p(idx), _stream())
             _call("pzn_sa_prep_f32", _p(xyz), _p(new_xyz), _p(w1), _p(b1), B, N, S, D, C1, _p(P), _p(Q), _stream())
             ws_bytes = _lib.load().pzn_sa_level_fwd_workspace_bytes(C1, C2)
-            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
+            ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
             done = False
-            if ws is not None:      # streamed-weights kernel: the weight split and the level as two entry points
+            if ws_bytes:      # streamed-weights kernel: the weight split and the level as two entry points
                 try:
                     _call("pzn_sa_level_prep_weights_f32", _p(w2), C1, C2, _p(ws), _stream())
                     _call("pzn_sa_level_fwd_packed_f32", _p(P), _p(Q), _p(idx), _p(b2), B, N, S, C1, C2, _p(out), _p(arg),
@@ -1507,16 +1605,11 @@ class _SaLevelFused(torch.autograd.Function):
             if not done:
                 _call("pzn_sa_level_fwd_ws_f32", _p(P), _p(Q), _p(idx), _p(w2), _p(b2), B, N, S, C1, C2, _p(out), _p(arg),
                       _p(ws), _stream(), flops=2 * R * 32 * C1 * C2)
-        if WINNER_CAPTURE is not None:
-            WINNER_CAPTURE.append(("sa", w2.data_ptr(), arg.view(B, S, C2)))
-        ctx.save_for_backward(xyz, feat, new_xyz, idx, w1, w_f, w2, out, arg, P, Q)
-        ctx.dims = (B, N, S, D, R, C1, C2)
-        ctx.param_refs = (w1, b1, w2, b2)
-        return out.reshape(B, S, C2)
+        return idx, w_f, P, Q
 
     @staticmethod
     def backward(ctx, dout):
-        xyz, feat, new_xyz, idx, w1, w_f, w2, out, arg, P, Q = ctx.saved_tensors
+        xyz, feat, new_xyz, idx, w1, w2, out, arg = ctx.saved_tensors[:8]
         B, N, S, D, R, C1, C2 = ctx.dims
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
             raise _lib.PznError("sa_mlp_max: gradients w.r.t. point coordinates are not provided on the fused "
@@ -1528,31 +1621,38 @@ class _SaLevelFused(torch.autograd.Function):
         direct = all(s_ is not None for s_ in sinks)
         if direct:
             dW1, db1, dW2, db2 = sinks
-        else:
-            dW1 = torch.zeros((C1, 3 + D), dtype=torch.float32, device=dev)    # the kernels add into these
-            db1 = torch.zeros((C1,), dtype=torch.float32, device=dev)
+        else:      # (the stepwise kernels ADD into dW1 / db1: zero-filled here; the one-call form fills them itself)
+            mk1 = torch.zeros if ctx.stepwise else torch.empty
+            dW1 = mk1((C1, 3 + D), dtype=torch.float32, device=dev)
+            db1 = mk1((C1,), dtype=torch.float32, device=dev)
             dW2 = torch.empty_like(w2)
             db2 = torch.empty((C2,), dtype=torch.float32, device=dev)
-        off = torch.empty((B * (N + 1),), dtype=torch.int32, device=dev)
-        rows = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
-        pts = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
-        dP = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
-        dfeat = None
-        with _on(dev):
-            # csrc/sapool.hip: weight gradients of the pooled layer + the rows' gradient summed per point in one walk by point
-            # (the rows' gradient itself is never in memory); sa_mlp_max() has checked the shapes the kernels take
-            _call("pzn_knn_inverse_lists", _p(idx), B, N, S, 32, _p(off), _p(rows), _p(pts), _stream())
-            ws = torch.empty((_lib.load().pzn_sa_level_bwd_pt_workspace_bytes(B, S, C2) + 3) // 4, dtype=torch.float32, device=dev)
-            _call("pzn_sa_level_bwd_pt_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(P), _p(Q), _p(idx), _p(xyz), _p(new_xyz),
-                  _p(off), _p(rows), _p(pts), B, N, S, D, C1, C2, _p(dP), _p(dW2), _p(db2), _p(dW1), _p(db1), int(direct), _p(ws),
-                  _stream(), flops=2 * R * (2 * C1 * C2))
-            if need_feat:
-                dfeat = torch.empty((B, N, D), dtype=torch.float32, device=dev)
-                _call("pzn_linear_dgrad_f32", _p(dP), None, _p(w_f), B * N, D, C1, None, _p(dfeat), _stream(),
+        dfeat = torch.empty((B, N, D), dtype=torch.float32, device=dev) if need_feat else None
+        lib = _lib.load()
+        if not ctx.stepwise:
+            saved = ctx.saved_tensors[8]
+            scratch = torch.empty((lib.pzn_sa_level_chain_scratch_bytes(B, N, S, C1, C2),), dtype=torch.uint8, device=dev)
+            with _on(dev):
+                _call("pzn_sa_level_chain_bwd_f32", _p(dout), _p(arg), _p(out), _p(xyz), _p(feat), _p(new_xyz),
+                      _p(idx) if ctx.have_idx else None, _p(w1), _p(w2), _p(saved), B, N, S, D, C1, C2, _p(dfeat), _p(dW1),
+                      _p(db1), _p(dW2), _p(db2), int(direct), _p(scratch), _stream())
+        else:
+            idx_s, w_f, P, Q = ctx.saved_tensors[8:12]
+            off = torch.empty((B * (N + 1),), dtype=torch.int32, device=dev)
+            rows = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
+            pts = torch.empty((B * S * 32,), dtype=torch.int32, device=dev)
+            dP = torch.empty((B * N, C1), dtype=torch.float32, device=dev)
+            with _on(dev):
+                _call("pzn_knn_inverse_lists", _p(idx_s), B, N, S, 32, _p(off), _p(rows), _p(pts), _stream())
+                ws = torch.empty((lib.pzn_sa_level_bwd_pt_workspace_bytes(B, S, C2) + 3) // 4, dtype=torch.float32, device=dev)
+                _call("pzn_sa_level_bwd_pt_f32", _p(dout), _p(arg), _p(out), _p(w2), _p(P), _p(Q), _p(idx_s), _p(xyz), _p(new_xyz),
+                      _p(off), _p(rows), _p(pts), B, N, S, D, C1, C2, _p(dP), _p(dW2), _p(db2), _p(dW1), _p(db1), int(direct),
+                      _p(ws), _stream(), flops=2 * R * (2 * C1 * C2))
+                if need_feat:
+                    _call("pzn_linear_dgrad_f32", _p(dP), None, _p(w_f), B * N, D, C1, None, _p(dfeat), _stream(),
+                          flops=2 * B * N * D * C1)
+                _call("pzn_linear_slice_wgrad_f32", _p(dP), _p(feat), B * N, D, C1, dW1.data_ptr() + 12, 3 + D, None, _stream(),
                       flops=2 * B * N * D * C1)
-            # dW1[:, 3:] += dP^T feat, straight into the parameter's column slice (no temporary, no tensor add)
-            _call("pzn_linear_slice_wgrad_f32", _p(dP), _p(feat), B * N, D, C1, dW1.data_ptr() + 12, 3 + D, None, _stream(),
-                  flops=2 * B * N * D * C1)
         if direct:
             return None, dfeat, None, None, None, None, None, None
         return None, dfeat, None, None, dW1, db1, dW2, db2

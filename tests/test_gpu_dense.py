@@ -642,6 +642,46 @@ def test_attention_chain_fused_map_strips(dev, nprob):
 
 
 
+@pytest.mark.parametrize("strips", [False, True])
+@pytest.mark.parametrize("sinks", [False, True])
+def test_attention_chain_one_call_equals_the_composition(dev, strips, sinks):
+    """ops._AttnChainOne (csrc/attnchain.hip: the encoder's attention chain enqueued by the library behind one C call each
+    way) against ops._AttnChainFused (the same kernels enqueued one by one from Python) in the case predict5 creates
+    (no `out`, gradient through the maximum only): map and maximum bit-identical, the input gradient bit-identical, the 34
+    parameter gradients equal to the order of their atomic sums - also when they are added into registered sinks."""
+    from puzzlenet_amd import ops
+    B, L, E, dk, Nout = 6, 256, 256, 64, 1024
+    g = torch.Generator().manual_seed(31)
+    shapes = [(dk, E), (dk,), (dk, E), (dk,), (E, E), (E,), (E, E), (E,)]
+    x0 = (0.5 * torch.randn(B, L, E, generator=g)).to(dev)
+    flat0 = [(torch.randn(*s, generator=g) / (math.sqrt(E) if len(s) == 2 else 4)).to(dev) for _ in range(4) for s in shapes]
+    flat0 += [(torch.randn(Nout, 5 * E, generator=g) / math.sqrt(5 * E)).to(dev), (0.1 * torch.randn(Nout, generator=g)).to(dev)]
+    go = torch.randn(B, Nout, generator=g).to(dev)
+
+    def run(one):
+        x = x0.clone().requires_grad_(True)
+        flat = [p.clone().requires_grad_(True) for p in flat0]
+        ops.clear_grad_sinks()
+        if sinks:
+            for p in flat:
+                p.grad = torch.full_like(p, 0.125)          # pre-existing content: the kernels must ADD to it
+            ops.register_grad_sinks(flat)
+        if one:
+            assert ops.attention_chain_one_supported(x, dk, flat[32])
+            amap, fg = ops._AttnChainOne.apply(strips, x, *flat)
+        else:
+            _, amap, fg = ops._AttnChainFused.apply(1, 2 if strips else 0, x, *flat)
+        (fg * go).sum().backward()
+        ops.clear_grad_sinks()
+        return amap.detach(), fg.detach(), x.grad, [p.grad for p in flat]
+
+    m1, f1, gx1, gp1 = run(True)
+    m0, f0, gx0, gp0 = run(False)
+    assert torch.equal(m1, m0) and torch.equal(f1, f0) and torch.equal(gx1, gx0)
+    for a, b in zip(gp1, gp0):
+        assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-9
+
+
 @pytest.mark.parametrize("nprob,use", [(1, "max"), (2, "max"), (2, "out")])
 def test_attention_chain_fused_vs_float64(dev, nprob, use):
     """ops.attention_chain_fused (model5_b.py:462-475 for one or two encoders in the same launches) against a float64
