@@ -28,8 +28,6 @@ def main():
     batch = synthetic.make_batch(64, cfg.num_points, dev, seed=1234)
     torch.manual_seed(1000)
     runner = engine.TrainStep(model, batch, cfg.lr, world=1)
-    if os.environ.get("PZN_AUTOGRAD_MT") == "0":
-        torch.autograd.set_multithreading_enabled(False)
     for _ in range(5):
         runner.step()
     torch.cuda.synchronize()

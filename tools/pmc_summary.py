@@ -63,19 +63,14 @@ def main():
     kg = sel(r"^knn_select_kernel<\d+, \d+, true")
     stage = round(2 * sum(v["hbm_bytes_per_launch"] for v in kg.values())) if len(kg) == 2 else None
     # the named matrix-core kernel (max-pool variant with the generated operand): 2 clouds x (level 1 + level 2)
-    # (round 3: the streamed-weights kernel of salevel.hip + its weight split; the weight-stationary GATH variant when
-    # PZN_SA_STREAM=0)
+    # (the streamed-weights kernel of salevel.hip; the weight-stationary GATH variant for shapes it does not take)
     mp = sel(r"^sa_level_stream_kernel<") or sel(r"^ws_gemm_kernel<\d+, true, false, \d+, true, (true|false), true>")
     maxpool = round(2 * sum(v["hbm_bytes_per_launch"] for v in mp.values())) if len(mp) == 2 else None
     fam = sel(r"^(ws_gemm_kernel|df_wgrad_kernel|gemm_kernel|sa_level_stream_kernel|outproj_maxpts_kernel|point_mlp3_(fwd|bwd)_kernel|attn_(proj|fwd|bwd_q|bwd_k)_kernel)")
     mfma = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam.values()) / a.steps_in_trace) or None
-    # the list sum of the model path (what roofline_sa_gather prices: its algorithmic bytes are the backward's only, the forward
-    # writes no rows since round 2); the forward prep kernel (P', Q) is listed beside it, not inside it (it was until round 3:
-    # 0.48 GB per step of the figure then reported belonged to sa_prep_kernel)
-    sa = sel(r"^(sa_point_l1_bwd_kernel|sa_point_l1_fwd_kernel)")
-    sa_b = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sa.values()) / a.steps_in_trace) or None
+    sa_b = None      # (rounds 2-4 priced the list sum of dh here; dh has not existed since round 5)
     # the set-abstraction backward by point (round 5): weight-gradient pass, hit lists, the walk by point
-    pb = sel(r"^(pool_wgrad_kernel|pool_hits_kernel|pool_point_kernel|pool_dgrad_kernel)")
+    pb = sel(r"^(pool_wgrad_kernel|pool_hits_kernel|pool_point_kernel)")
     pb_b = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in pb.values()) / a.steps_in_trace) or None
     emd = sel(r"^(emdf_|emd_)")
     emd_b = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in emd.values()) / a.steps_in_trace) or None
