@@ -647,11 +647,18 @@ def main():
     n_pb, ms_pb = per_step("pzn_sa_level_bwd_pt_f32")
     lvl = ((B * 512, 128, 128, N), (B * 256, 256, 256, 512))              # (groups R, C1, C2, points per cloud)
     pb_bytes = 2 * sum(2 * 12.0 * R_ * C2_ + 2 * 8.0 * R_ * C2_ + 4.0 * B * n_ * C1_ + 4.0 * C1_ * C2_ for R_, C1_, C2_, n_ in lvl)
+    # (round 5 priced more bytes: hit lists read once per 128-column slice, dP written twice - zero fill + rows; kept beside the
+    # new figure so that the two rounds compare like for like)
+    pb_bytes_r5 = 2 * sum(2 * 12.0 * R_ * C2_ + 8.0 * R_ * C2_ * (1 + C1_ // 128) + 2 * 4.0 * B * n_ * C1_ + 4.0 * C1_ * C2_
+                          for R_, C1_, C2_, n_ in lvl)
     pb_fma = 2 * sum(2.0 * R_ * C2_ * C1_ for R_, C1_, C2_, n_ in lvl)         # input-gradient + weight-gradient pass
     pb_traffic = pmc_traffic("pool_bwd_stage_bytes_per_step", B, N)[0]
     roofline.update({"pool_bwd_ms": ms_pb, "pool_bwd_frac": (pb_bytes / (ms_pb * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_pb else None,
                      "pool_bwd_vector_issue_frac": (pb_fma / (ms_pb * 1e-3) / VALU_LANE_SLOTS_PER_S) if ms_pb else None,
-                     "pool_bwd_bytes": pb_bytes, "pool_bwd_traffic": pb_traffic,
+                     "pool_bwd_bytes": pb_bytes, "pool_bwd_bytes_r5_accounting": pb_bytes_r5,
+                     "pool_bwd_frac_r5_accounting": (pb_bytes_r5 / (ms_pb * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_pb else None,
+                     "pool_bwd_traffic_over_r5_accounting": (pb_traffic / pb_bytes_r5) if pb_traffic else None,
+                     "pool_bwd_traffic": pb_traffic,
                      "pool_bwd_traffic_over_algorithmic": (pb_traffic / pb_bytes) if pb_traffic else None})
 
     stages = {k: {"launches_per_step": n / prof_steps, "ms_per_step": ms / prof_steps} for k, (n, ms) in sorted(kern.items())}
