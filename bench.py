@@ -521,6 +521,8 @@ def main():
     # summary of THIS build the choice is read from it (largest total time among the kernels with a work model): every run of
     # this build then prices the same kernel, and the live average is checked against the file's.  Without one: live.
     how = "largest exclusive device time per step among kernels with a work model (this run's kernel timer)"
+    if not cands:
+        raise SystemExit("bench: the kernel timer saw no kernel with a work model (kernel_work): nothing to price")
     dom = max(cands, key=lambda k: cands[k][1])
     if rows1:
         tot = {}
