@@ -42,6 +42,7 @@ SOURCES = [
     ("maxptsbwd.hip", NOSLP),
     ("wsgemm.hip", []),
     ("dfgemm.hip", []),
+    ("attnwgrad.hip", NOSLP),
     ("optim.hip", ["-ffp-contract=off"] + NOSLP),
     ("se3.hip", NOSLP),
     ("sapoint.hip", NOSLP),

@@ -11,8 +11,9 @@
 // forward buffer ("saved": the backward reads it):  per layer  W planes | q image | k image | v image | r [M,E] | t [M,E] |
 //   gate bits [M,8] | ln-sum-exp [M];  then the out projection's plane workspace.
 // backward buffer (scratch):  G [M,5E] | dz | u | dx0 | dx1 [M,E each] | dq | dqt | dk [M,dk each] | dv [M,E] | da image |
-//   delta [M] | sort workspace of the sparse out-projection backward.
+//   delta [M] | sort workspace of the sparse out-projection backward | partial tiles of the weight gradients (attnwgrad.hip).
 #include "pzn_common.h"
+#include "pzn_internal.h"
 
 namespace {
 
@@ -44,7 +45,7 @@ FwdLayout fwd_layout(int B) {
 }
 
 struct BwdLayout {
-  size_t G, dz, u, dx0, dx1, dq, dqt, dk, dv, da, delta, sort, total;
+  size_t G, dz, u, dx0, dx1, dq, dqt, dk, dv, da, delta, sort, wg, wg_bytes, total;
 };
 
 BwdLayout bwd_layout(int B) {
@@ -63,6 +64,8 @@ BwdLayout bwd_layout(int B) {
   b.da = at, at += up256(pzn_attn_fused_v_image_bytes(B));
   b.delta = at, at += up256(M * 4);
   b.sort = at, at += up256(pzn_linear_maxpts_workspace_bytes(B, NOUT));
+  b.wg_bytes = pzn_attn_wgrad_ws_bytes((int)M);
+  b.wg = at, at += up256(b.wg_bytes);
   b.total = at;
   return b;
 }
@@ -177,8 +180,8 @@ PZN_EXPORT int pzn_attn_chain_bwd_f32(const float* x, const float* const* params
     rc = pzn_attn_fused_bwd_k(1, &q, &k, &v, &dac, &wp, &lse, &deltac, &uc, &dqtc, B, &dkk, &dvv, &dxa, stream);
     if (rc != PZN_OK) return rc;
     float* const* gp = grads + 8 * i;      // (gq, gbq, gk, gbk, gv, gbv, go, gbo)
-    rc = pzn_attn_fused_wgrads(dz, t, dq, dkk, dvv, xin, M, E, DK, gp[0], gp[1], gp[2], gp[3], gp[4], gp[5], gp[6], gp[7],
-                               accumulate, stream);
+    rc = pzn_attn_fused_wgrads_ws(dz, t, dq, dkk, dvv, xin, M, E, DK, gp[0], gp[1], gp[2], gp[3], gp[4], gp[5], gp[6], gp[7],
+                                  accumulate, w + b.wg, b.wg_bytes, stream);
     if (rc != PZN_OK) return rc;
     const int sl = i > 0 ? i - 1 : 4;      // att_i sits in slice i-1 of the concatenation, f2f in slice 4
     g = G + (size_t)sl * E;

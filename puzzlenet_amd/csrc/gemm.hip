@@ -1223,9 +1223,18 @@ PZN_EXPORT int pzn_attn_block_bwd_f32(const float* x, const float* Wq, const flo
 PZN_EXPORT int pzn_attn_fused_wgrads(const float* dz, const float* t, const float* dq, const float* dkk, const float* dvv,
                                      const float* x, int M, int E, int dk, float* dWq, float* dbq, float* dWk, float* dbk,
                                      float* dWv, float* dbv, float* dWo, float* dbo, int accumulate, pzn_stream_t stream) {
+  return pzn_attn_fused_wgrads_ws(dz, t, dq, dkk, dvv, x, M, E, dk, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, accumulate, nullptr, 0,
+                                  stream);
+}
+
+int pzn_attn_fused_wgrads_ws(const float* dz, const float* t, const float* dq, const float* dkk, const float* dvv, const float* x,
+                             int M, int E, int dk, float* dWq, float* dbq, float* dWk, float* dbk, float* dWv, float* dbv,
+                             float* dWo, float* dbo, int accumulate, void* ws, size_t ws_bytes, pzn_stream_t stream) {
   PZN_CHECK_ARG(dz && t && dq && dkk && dvv && x && dWq && dbq && dWk && dbk && dWv && dbv && dWo && dbo && M > 0 && E > 0 &&
                 dk > 0);
   hipStream_t st = pzn_hip_stream(stream);
+  if (E == 256 && dk == 64 && (M & 63) == 0 && gemm_precision() != 0)      // the encoder's shape: one launch (csrc/attnwgrad.hip)
+    return pzn_attn_wgrad_tiled(dz, t, dq, dkk, dvv, x, M, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, accumulate, ws, ws_bytes, st);
   int rc = pzn_linear_wgrad_f32(dz, nullptr, t, M, E, E, dWo, dbo, accumulate, stream);
   if (rc != PZN_OK) return rc;
   const float* const dys[3] = {dq, dkk, dvv};

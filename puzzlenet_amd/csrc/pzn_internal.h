@@ -20,6 +20,18 @@ bool pzn_pool_wgrad_supported(int C1, int C2, const float* h);
 int pzn_pool_wgrad_sparse(const float* dout, const int32_t* argmax, const float* out, const float* h, float* dW, float* db,
                           int G, int C1, int C2, hipStream_t st, const PznGateSource* gs = nullptr);
 
+// attnwgrad.hip: the four weight gradients of one attention block (E = 256, dk = 64) in one launch of LDS-shared 128 x 128 tiles
+// (+ a fixed-order reduction of the row ranges' partial tiles when the caller has a workspace of pzn_attn_wgrad_ws_bytes(M)
+// bytes; ws == NULL: fp32 atomics).  PZN_EUNSUPPORTED unless M % 64 == 0.
+size_t pzn_attn_wgrad_ws_bytes(int M);
+int pzn_attn_wgrad_tiled(const float* dz, const float* t, const float* dq, const float* dkk, const float* dvv, const float* x,
+                         int M, float* dWq, float* dbq, float* dWk, float* dbk, float* dWv, float* dbv, float* dWo, float* dbo,
+                         int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+// gemm.hip: pzn_attn_fused_wgrads with that workspace (ws_bytes = 0: none)
+int pzn_attn_fused_wgrads_ws(const float* dz, const float* t, const float* dq, const float* dkk, const float* dvv, const float* x,
+                             int M, int E, int dk, float* dWq, float* dbq, float* dWk, float* dbk, float* dWv, float* dbv,
+                             float* dWo, float* dbo, int accumulate, void* ws, size_t ws_bytes, pzn_stream_t stream);
+
 // wsgemm.hip: weight-stationary bf16x3 GEMM for skinny layers.  C[M,N] = epi(A[M,K] W^T), W[n*ldw+k]
 // (w_kmajor = 0) or W[k*ldw+n] (w_kmajor = 1); genY masks A by genY > 0, maskH masks C, argmax != NULL
 // selects the max-over-32-rows epilogue (C is then [M/32, N]); scat != NULL adds row m atomically into C row

@@ -637,8 +637,9 @@ def test_attention_chain_fused_map_strips(dev, nprob):
         assert float((want - got).abs().max()) <= 1e-6 * float(want.abs().max())
         assert torch.equal(ops.colmean_argmax(full[p][1])[1], ops.colmean_argmax(strip[p][1])[1])
         assert torch.equal(full[p][2], strip[p][2]) and full[p][0] is None and strip[p][0] is None
-    for a, b in zip(gfull, gstrip):      # (the weight gradients end in atomic adds: equal to the order of a sum)
-        assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-9
+    top = max(float(b.norm()) for b in gstrip)
+    for a, b in zip(gfull, gstrip):      # (the weight gradients end in atomic adds: equal to the order of a sum; the key biases'
+        assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-7 * top      #  gradient is mathematically zero: rounding noise)
 
 
 
@@ -678,8 +679,39 @@ def test_attention_chain_one_call_equals_the_composition(dev, strips, sinks):
     m1, f1, gx1, gp1 = run(True)
     m0, f0, gx0, gp0 = run(False)
     assert torch.equal(m1, m0) and torch.equal(f1, f0) and torch.equal(gx1, gx0)
+    top = max(float(b.norm()) for b in gp0)
     for a, b in zip(gp1, gp0):
-        assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-9
+        assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-7 * top
+    # the one-call form sums the blocks' weight gradients from partial tiles in a fixed order (csrc/attnwgrad.hip with the
+    # chain's workspace): the same bits on a second run
+    gp2 = run(True)[3]
+    for a, b in zip(gp1[:32], gp2[:32]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M", [64, 1280, 1600, 16384])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_attention_weight_gradients_one_launch(dev, M, accumulate):
+    """pzn_attn_fused_wgrads at the encoder's shape (E = 256, dk = 64: csrc/attnwgrad.hip, one launch of LDS-shared tiles; without
+    a workspace the row ranges meet in atomics) against float64 products: dWo = dz^T t, dWq/k/v = dq/dk/dv^T x and the four
+    column sums (backward of model5_b.py:83-101), overwriting and adding to what is there.  M = 64: one row range of four steps;
+    1280, 1600: ragged last range; 16 384: the bench shape."""
+    from puzzlenet_amd import _lib
+    E, dk = 256, 64
+    g = torch.Generator().manual_seed(M + int(accumulate))
+    dz, t, dv, x = ((torch.randn(M, E, generator=g) * (1 + 3 * torch.rand(1, E, generator=g))).to(dev) for _ in range(4))
+    dq, dkk = (torch.randn(M, dk, generator=g).to(dev) for _ in range(2))
+    outs = [torch.full(s, 0.5 if accumulate else float("nan"), device=dev)
+            for s in ((dk, E), (dk,), (dk, E), (dk,), (E, E), (E,), (E, E), (E,))]      # dWq dbq dWk dbk dWv dbv dWo dbo
+    _lib.call("pzn_attn_fused_wgrads", dz.data_ptr(), t.data_ptr(), dq.data_ptr(), dkk.data_ptr(), dv.data_ptr(), x.data_ptr(), M,
+              E, dk, *[o.data_ptr() for o in outs], int(accumulate), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    d = lambda a: a.double()
+    want = [d(dq).T @ d(x), d(dq).sum(0), d(dkk).T @ d(x), d(dkk).sum(0), d(dv).T @ d(x), d(dv).sum(0), d(dz).T @ d(t), d(dz).sum(0)]
+    for name, got, w in zip("dWq dbq dWk dbk dWv dbv dWo dbo".split(), outs, want):
+        w = w + (0.5 if accumulate else 0.0)
+        err = float((d(got) - w).abs().max())
+        assert err <= 1e-5 * float(w.abs().max()), (name, err, float(w.abs().max()))
 
 
 @pytest.mark.parametrize("nprob,use", [(1, "max"), (2, "max"), (2, "out")])
