@@ -98,6 +98,9 @@ def kernel_work(name, B, N):
         return mf(2 * M * E * (E + dk) + 2 * B * L * L * (2 * dk + 2 * E), "key side of one block's backward")
     if name.startswith("attn_wgrad_kernel"):
         return mf(2 * M * E * (2 * dk + 2 * E), "the four weight gradients of one block")
+    if name.startswith("attn_wgrad_reduce_kernel"):
+        rows = -(-(M // 64) // 24) * 64                                   # csrc/attnwgrad.hip: 24 row ranges of whole 64-row units
+        return hb(4.0 * (640 * 256 + 640) * (-(-M // rows) + 2), "partial tiles of the row ranges read, the gradients read and written")
     if name.startswith("pool_point_kernel"):       # both levels through one instantiation: mean of the two launch sizes
         by = sum(8.0 * G * C2 + 4.0 * B * n_ * C1 for G, C1, C2, n_ in (lv1, lv2)) / 2
         return hb(by, "hit records read + per-point gradient rows written, once (mean of level 1 / 2 launches)")

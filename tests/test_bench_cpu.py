@@ -19,6 +19,9 @@ def test_kernel_work_model():
     assert bench.kernel_work("outproj_maxpts_kernel", 64, 2048)[1] == 2.0 * 64 * 256 * 1280 * 1024
     b, w, unit, peak, punit, _ = bench.kernel_work("pool_point_kernel<16, 8>", 64, 2048)
     assert (b, unit, peak, punit) == ("hbm", "B", 8000.0, "GB/s") and w > 0
+    assert bench.kernel_work("attn_wgrad_kernel", 64, 2048)[1] == 2.0 * 64 * 256 * 256 * (2 * 64 + 2 * 256)
+    b, w, *_ = bench.kernel_work("attn_wgrad_reduce_kernel", 64, 2048)               # 24 partial tiles + the gradients in and out
+    assert b == "hbm" and w == 4.0 * (640 * 256 + 640) * 26
     assert bench.kernel_work("emdf_k_kernel<1, true>", 64, 2048) is None          # priced as a stage (vector issue), not here
     # the north-star stage's bytes per pair
     assert 2 * (bench.knn_group_bytes(2048, 512, 32, 64) + bench.knn_group_bytes(512, 256, 32, 128)) == 19412992

@@ -66,7 +66,7 @@ def main():
     # (the streamed-weights kernel of salevel.hip; the weight-stationary GATH variant for shapes it does not take)
     mp = sel(r"^sa_level_stream_kernel<") or sel(r"^ws_gemm_kernel<\d+, true, false, \d+, true, (true|false), true>")
     maxpool = round(2 * sum(v["hbm_bytes_per_launch"] for v in mp.values())) if len(mp) == 2 else None
-    fam = sel(r"^(ws_gemm_kernel|df_wgrad_kernel|gemm_kernel|sa_level_stream_kernel|outproj_maxpts_kernel|point_mlp3_(fwd|bwd)_kernel|attn_(proj|fwd|bwd_q|bwd_k)_kernel)")
+    fam = sel(r"^(ws_gemm_kernel|df_wgrad_kernel|attn_wgrad_kernel|gemm_kernel|sa_level_stream_kernel|outproj_maxpts_kernel|point_mlp3_(fwd|bwd)_kernel|attn_(proj|fwd|bwd_q|bwd_k)_kernel)")
     mfma = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam.values()) / a.steps_in_trace) or None
     sa_b = None      # (rounds 2-4 priced the list sum of dh here; dh has not existed since round 5)
     # the set-abstraction backward by point (round 5): weight-gradient pass, hit lists, the walk by point
