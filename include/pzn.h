@@ -472,6 +472,10 @@ int pzn_attn_fused_bwd_k(int nprob, const void* const* qrp, const void* const* k
                          const float* const* lse, const float* const* delta, const float* const* u,
                          const float* const* dq, int B, float* const* dk, float* const* dv,
                          float* const* dx, pzn_stream_t stream);
+/* The four weight gradients and four bias gradients of one block from what the chained kernels leave in memory: dWo (+)= dz^T t,
+ * dWq/k/v (+)= dq/dk/dv^T x, the biases' = column sums (accumulate == 0: overwritten).  E = 256, dk = 64, M % 64 == 0: one launch
+ * of LDS-shared 128 x 128 tiles over 24 row ranges (csrc/attnwgrad.hip), which meet in fp32 atomics here and in a fixed-order sum
+ * inside pzn_attn_chain_bwd_f32 (its scratch holds their partial tiles); other shapes: the general weight-gradient kernels. */
 int pzn_attn_fused_wgrads(const float* dz, const float* t, const float* dq, const float* dk,
                           const float* dv, const float* x, int M, int E, int dk_dim, float* dWq,
                           float* dbq, float* dWk, float* dbk, float* dWv, float* dbv, float* dWo,
