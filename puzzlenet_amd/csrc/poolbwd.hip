@@ -44,6 +44,9 @@ struct PoolBwdArgs {
   const int64_t* gidx;    // [G*32]
   const float* gQ;        // [G, C1]
   int gN, gS;
+  // partial results of the workgroups ([gridDim.y][gridDim.x][C2][128] floats, then [gridDim.x][C2] for db), summed in a fixed
+  // order by pool_wgrad_reduce_kernel; NULL: the workgroups add into dW / db with atomics
+  float* partials;
 };
 
 __device__ __forceinline__ float4 pb_add_relu(float4 a, float4 q) {
@@ -158,21 +161,87 @@ __global__ __launch_bounds__(NWV * 64) void pool_wgrad_kernel(PoolBwdArgs p) {
 #undef PB_ISSUE
 #undef PB_IDX
 
+  if (p.partials) {
+    float* part = p.partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * p.C2 * PB_COLS;
 #pragma unroll
-  for (int c = 0; c < CPW; ++c) {
-    float* o = p.dW + (size_t)(wave * CPW + c) * p.C1 + col0 + 2 * lane;
-    atomicAdd(o, acc[c].x);
-    atomicAdd(o + 1, acc[c].y);
+    for (int c = 0; c < CPW; ++c) *reinterpret_cast<v2f*>(part + (size_t)(wave * CPW + c) * PB_COLS + 2 * lane) = acc[c];
+    if (blockIdx.y == 0 && lane < CPW)
+      p.partials[(size_t)gridDim.y * gridDim.x * p.C2 * PB_COLS + (size_t)blockIdx.x * p.C2 + wave * CPW + lane] = dbacc;
+  } else {
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      float* o = p.dW + (size_t)(wave * CPW + c) * p.C1 + col0 + 2 * lane;
+      atomicAdd(o, acc[c].x);
+      atomicAdd(o + 1, acc[c].y);
+    }
+    if (p.db && blockIdx.y == 0 && lane < CPW) atomicAdd(p.db + wave * CPW + lane, dbacc);
   }
-  if (p.db && blockIdx.y == 0 && lane < CPW) atomicAdd(p.db + wave * CPW + lane, dbacc);
   (void)T;
 }
 
-int launch_wgrad(const PoolBwdArgs& p, hipStream_t st) {
+// dW[c, :] += the workgroups' partial tiles, db[c] += their partial sums, in workgroup order (the same bits in every run; the
+// atomics they replace were 33.5 MB per level-2 launch, all at the end of the kernel: ~1 us per 0.65 MB as measured on the
+// attention weight gradients).  A workgroup of 16 wavefronts owns 64 float4 outputs; wavefront w sums partials w, w + 16, ...
+// - all its loads in flight - and the sixteen meet in LDS.  The last C2 / 64 workgroups: 64 bias entries each.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(1024) void pool_wgrad_reduce_kernel(const float* __restrict__ partials, int nx, int ny, int C1, int C2,
+                                                                 float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ f32x4 red[15][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n4 = C2 * C1 / 4, nwg = n4 / 64;
+  if ((int)blockIdx.x < nwg) {
+    const int o = blockIdx.x * 64 + lane;
+    const int c = o / (C1 / 4), rem = o - c * (C1 / 4), y = rem >> 5, col4 = rem & 31;
+    const size_t stride4 = (size_t)C2 * PB_COLS / 4;
+    const f32x4* src = reinterpret_cast<const f32x4*>(partials) + (size_t)y * nx * stride4 + (size_t)c * (PB_COLS / 4) + col4;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    int x = w;
+    for (; x + 48 < nx; x += 64) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(src + (size_t)(x + 16 * u) * stride4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sum += v[u];
+    }
+    for (; x < nx; x += 16) sum += __builtin_nontemporal_load(src + (size_t)x * stride4);
+    if (w) red[w - 1][lane] = sum;
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+      for (int u = 0; u < 15; ++u) sum += red[u][lane];
+      f32x4* dst = reinterpret_cast<f32x4*>(dW + (size_t)c * C1 + y * PB_COLS) + col4;
+      *dst += sum;
+    }
+  } else if (db) {
+    const int c = ((int)blockIdx.x - nwg) * 64 + lane;
+    const float* src = partials + (size_t)ny * nx * C2 * PB_COLS + c;
+    float sum = 0.f;
+    for (int x = w; x < nx; x += 16) sum += src[(size_t)x * C2];
+    float* redf = reinterpret_cast<float*>(&red[0][0]);
+    if (w) redf[(w - 1) * 64 + lane] = sum;
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+      for (int u = 0; u < 15; ++u) sum += redf[u * 64 + lane];
+      db[c] += sum;
+    }
+  }
+}
+
+int wgrad_grid_x(int G, int C1) {
+  const int ny = C1 / PB_COLS;
+  int gx = 256 / ny;  // workgroups in flight (one per CU measured best)
+  return gx > G ? G : gx;
+}
+
+int launch_wgrad(PoolBwdArgs p, hipStream_t st, void* ws, size_t ws_bytes) {
   const int ny = p.C1 / PB_COLS;
-  int gx = 256 / ny;  // workgroups in flight (one per CU measured best); each ends with C2*128 atomic adds into dW
-  if (gx > p.G) gx = p.G;
+  const int gx = wgrad_grid_x(p.G, p.C1);
   const dim3 grid((unsigned)gx, (unsigned)ny);
+  p.partials = (ws && ws_bytes >= pzn_pool_wgrad_ws_bytes(p.G, p.C1, p.C2) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(p.dW) & 15) == 0)
+                   ? static_cast<float*>(ws)
+                   : nullptr;
   if (p.C2 % 16 == 0 && p.C2 / 16 >= 4) {      // 16 wavefronts, C2 / 16 channels each
     const int cpw = p.C2 / 16;
     if (cpw == 4)
@@ -181,17 +250,24 @@ int launch_wgrad(const PoolBwdArgs& p, hipStream_t st) {
       PZN_LAUNCH((pool_wgrad_kernel<8, 16>), grid, dim3(1024), 0, st, p);
     else
       PZN_LAUNCH((pool_wgrad_kernel<16, 16>), grid, dim3(1024), 0, st, p);
-    PZN_RETURN_LAUNCH_STATUS();
+  } else {
+    const dim3 block(PB_T);
+    const int cpw = p.C2 / PB_W;
+    if (cpw == 8)
+      PZN_LAUNCH((pool_wgrad_kernel<8, 8>), grid, block, 0, st, p);
+    else if (cpw == 16)
+      PZN_LAUNCH((pool_wgrad_kernel<16, 8>), grid, block, 0, st, p);
+    else
+      PZN_LAUNCH((pool_wgrad_kernel<32, 8>), grid, block, 0, st, p);
   }
-  const dim3 block(PB_T);
-  const int cpw = p.C2 / PB_W;
-  if (cpw == 8)
-    PZN_LAUNCH((pool_wgrad_kernel<8, 8>), grid, block, 0, st, p);
-  else if (cpw == 16)
-    PZN_LAUNCH((pool_wgrad_kernel<16, 8>), grid, block, 0, st, p);
-  else
-    PZN_LAUNCH((pool_wgrad_kernel<32, 8>), grid, block, 0, st, p);
-  PZN_RETURN_LAUNCH_STATUS();
+  if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
+  if (p.partials) {
+    const int nwg = p.C2 * p.C1 / 256;
+    PZN_LAUNCH(pool_wgrad_reduce_kernel, dim3((unsigned)(nwg + (p.db ? p.C2 / 64 : 0))), dim3(1024), 0, st, p.partials, gx, ny,
+               p.C1, p.C2, p.dW, p.db);
+    if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
+  }
+  return PZN_OK;
 }
 
 bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -202,10 +278,19 @@ bool pzn_pool_wgrad_supported(int C1, int C2, const float* h) {
   return C1 > 0 && C1 % PB_COLS == 0 && (C2 == 64 || C2 == 128 || C2 == 256) && aligned16(h);      // (h may be NULL: regenerated rows)
 }
 
+// bytes of the optional workspace: one [C2][128] tile (+ C2 bias sums) per workgroup
+size_t pzn_pool_wgrad_ws_bytes(int G, int C1, int C2) {
+  if (G <= 0 || C1 <= 0 || C1 % PB_COLS != 0 || C2 % 64 != 0) return 0;
+  const size_t nx = (size_t)wgrad_grid_x(G, C1), ny = (size_t)(C1 / PB_COLS);
+  return (ny * nx * C2 * PB_COLS + nx * C2) * sizeof(float);
+}
+
+// dW / db are ADDED to.  ws (pzn_pool_wgrad_ws_bytes, 16-byte aligned; may be NULL): the workgroups' partial results, summed in
+// a fixed order; without it they meet in fp32 atomics.
 int pzn_pool_wgrad_sparse(const float* dout, const int32_t* argmax, const float* out, const float* h, float* dW, float* db,
-                          int G, int C1, int C2, hipStream_t st, const PznGateSource* gs) {
-  PoolBwdArgs p{dout, argmax, out, h, dW, db, G, C1, C2, nullptr, nullptr, nullptr, 0, 0};
+                          int G, int C1, int C2, hipStream_t st, const PznGateSource* gs, void* ws, size_t ws_bytes) {
+  PoolBwdArgs p{dout, argmax, out, h, dW, db, G, C1, C2, nullptr, nullptr, nullptr, 0, 0, nullptr};
   if (gs && gs->P) p.gP = gs->P, p.gidx = gs->idx, p.gQ = gs->Q, p.gN = gs->N, p.gS = gs->S;
   if (!dW || (!h && !p.gQ)) return PZN_EINVAL;      // the pass needs the rows or their source
-  return launch_wgrad(p, st);
+  return launch_wgrad(p, st, ws, ws_bytes);
 }

@@ -17,8 +17,11 @@ struct PznGateSource {
   int N, S;
 };
 bool pzn_pool_wgrad_supported(int C1, int C2, const float* h);
+// ws (optional, pzn_pool_wgrad_ws_bytes): the workgroups' partial tiles, summed in a fixed order; NULL: fp32 atomics
+size_t pzn_pool_wgrad_ws_bytes(int G, int C1, int C2);
 int pzn_pool_wgrad_sparse(const float* dout, const int32_t* argmax, const float* out, const float* h, float* dW, float* db,
-                          int G, int C1, int C2, hipStream_t st, const PznGateSource* gs = nullptr);
+                          int G, int C1, int C2, hipStream_t st, const PznGateSource* gs = nullptr, void* ws = nullptr,
+                          size_t ws_bytes = 0);
 
 // attnwgrad.hip: the four weight gradients of one attention block (E = 256, dk = 64) in one launch of LDS-shared 128 x 128 tiles
 // (+ a fixed-order reduction of the row ranges' partial tiles when the caller has a workspace of pzn_attn_wgrad_ws_bytes(M)

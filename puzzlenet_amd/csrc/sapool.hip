@@ -250,11 +250,19 @@ __global__ __launch_bounds__(NW * 64) void pool_point_kernel(PointArgs p) {
 
 }  // namespace
 
-// workspace of pzn_sa_level_bwd_pt_f32: hit lists [B*S][C2] x 8 bytes + row offsets [B*S][34] x 2 bytes
+// workspace of pzn_sa_level_bwd_pt_f32: hit lists [B*S][C2] x 8 bytes + row offsets [B*S][34] x 2 bytes; the weight-gradient
+// pass, which runs first, parks its workgroups' partial tiles in the same bytes (at B = 64 the two are the same 33.5 MB)
+static size_t sa_bwd_pt_hits_bytes(size_t G, int C2) {
+  return ((G * C2 * sizeof(uint2) + 255) / 256) * 256 + ((G * RS_LD * sizeof(uint16_t) + 255) / 256) * 256;
+}
+static size_t sa_bwd_pt_ws_bytes(size_t G, int C2) {
+  const size_t hits = sa_bwd_pt_hits_bytes(G, C2);
+  const size_t parts = (size_t)C2 * (256 * 128 + 256) * sizeof(float);      // >= pzn_pool_wgrad_ws_bytes for every C1: <= 256 tiles of [C2][128] + bias sums
+  return hits > parts ? hits : parts;
+}
 PZN_EXPORT size_t pzn_sa_level_bwd_pt_workspace_bytes(int B, int S, int C2) {
   if (B <= 0 || S <= 0 || C2 <= 0) return 0;
-  const size_t G = (size_t)B * S;
-  return ((G * C2 * sizeof(uint2) + 255) / 256) * 256 + ((G * RS_LD * sizeof(uint16_t) + 255) / 256) * 256;
+  return sa_bwd_pt_ws_bytes((size_t)B * S, C2);
 }
 
 // Backward of the pooled level behind pzn_sa_level_fwd_*: dW2, db2 (overwritten, or added to when accumulate), the per-point
@@ -282,7 +290,7 @@ PZN_EXPORT int pzn_sa_level_bwd_pt_f32(const float* dout, const int32_t* argmax,
   const int G = B * S;
   // weight gradient of the pooled layer: the sparse pass of csrc/poolbwd.hip on regenerated rows
   PznGateSource gs{Pp, idx, Q, N, S};
-  int rc = pzn_pool_wgrad_sparse(dout, argmax, out, nullptr, dW2, db2, G, C1, C2, st, &gs);
+  int rc = pzn_pool_wgrad_sparse(dout, argmax, out, nullptr, dW2, db2, G, C1, C2, st, &gs, workspace, sa_bwd_pt_ws_bytes((size_t)G, C2));
   if (rc != PZN_OK) return rc;
   uint2* hits = static_cast<uint2*>(workspace);
   uint16_t* rstart = reinterpret_cast<uint16_t*>(static_cast<unsigned char*>(workspace) + (((size_t)G * C2 * sizeof(uint2) + 255) / 256) * 256);
