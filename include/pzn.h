@@ -72,10 +72,12 @@ int pzn_fps_f32(const float* xyz, int B, int N, int npoint,
 /* dataset.py:1147-1163 (`fps` of a raw piece in the loader processes) as a background job beside a training step: the same
  * picks bit for bit, but no LDS image of the cloud (1.2 KB of LDS per workgroup instead of up to 150 KB), so the step's
  * LDS-tiled kernels keep their CUs.  N <= 32768.  counts (NULL or int64 [B]): rows >= counts[b] of cloud b are padding
- * (copies of row 0, which never win) and are left out of the rounds. */
+ * (copies of row 0, which never win) and are left out of the rounds.  max_count (0: unknown): the caller's promise that
+ * counts[b] <= max_count for every cloud - a cut piece holds at most M - n of the raw cloud's M points - which lets the
+ * launch hold only that many rows in registers (fewer, faster wavefronts); rows beyond it are never read. */
 int pzn_fps_background_f32(const float* xyz, int B, int N, int npoint,
                            const int64_t* start_idx, int64_t* out_idx,
-                           const int64_t* counts, pzn_stream_t stream);
+                           const int64_t* counts, int max_count, pzn_stream_t stream);
 
 /* pointnet_util.py:118-119  dists.argsort()[:, :, :K] fused with the distance:
  * idx[B,S,K] = the K nearest points of xyz[B,N,3] to each new_xyz[B,S,3],

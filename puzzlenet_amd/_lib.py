@@ -27,7 +27,7 @@ SIGNATURES = {
     "pzn_ktimer_row": (_c_i, [_c_i, ctypes.c_char_p, _c_i, ctypes.POINTER(_c_i), ctypes.POINTER(ctypes.c_double)]),
     "pzn_square_distance_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_fps_f32": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
-    "pzn_fps_background_f32": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f]),
+    "pzn_fps_background_f32": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_i, _c_f]),
     "pzn_knn_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_ball_query_f32": (_c_i, [_c_fl, _c_i, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_gather_fwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),

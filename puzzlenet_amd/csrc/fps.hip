@@ -18,9 +18,26 @@
 // launch is B workgroups, i.e. parallel over clouds only.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pzn_common.h"
 
 namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// f(0), f(1), ... while q < n, q < Q1, as NESTED ifs on compile-time q: the first failing guard jumps past all the rest (an
+// unrolled loop with one guard per body jumps over every unused body in turn; with `break` the loop is not unrolled at all and
+// the register arrays are indexed dynamically)
+template <int Q, int Q1, typename F>
+__device__ __forceinline__ void nested_while_below(int n, F&& f) {
+  if constexpr (Q < Q1) {
+    if (Q < n) {
+      f(std::integral_constant<int, Q>{});
+      nested_while_below<Q + 1, Q1>(n, f);
+    }
+  }
+}
 
 constexpr int FPS_OUT_CHUNK = 256;      // picks buffered in LDS between write-outs (power of two)
 
@@ -37,6 +54,10 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
   float* sx = reinterpret_cast<float*>(smem_raw + 2 * W * sizeof(uint64_t) + FPS_OUT_CHUNK * sizeof(int));
   float* sy = sx + N;
   float* sz = sy + N;
+  // without the image (PPT > 4): every wavefront publishes its best point's coordinates beside its key, [2][W] x 16 bytes
+  // where the image would start (the pick's owner has them in registers: no fetch from memory in the round's dependent chain)
+  float4* scoord = reinterpret_cast<float4*>(sx);
+  constexpr bool publish = !use_lds && PPT > 4;
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -45,6 +66,11 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
   const float* g = xyz + (size_t)b * N * 3;
 
   float px[PPT], py[PPT], pz[PPT], dist[PPT];
+  // the no-image form keeps its points as PAIRS of register slots (2q, 2q + 1): the distance update is packed fp32 - two points
+  // per instruction, every operation individually rounded as in sqdist3 (this file is built with -ffp-contract=off) -: with
+  // up to 16 slots per thread and 8 wavefronts the round is bound by vector issue, not by its dependent latencies
+  constexpr int PQ = (!use_lds && PPT > 4) ? PPT / 2 : 1;
+  v2f qx[PQ], qy[PQ], qz[PQ], qd[PQ];
   if (use_lds) {
     for (int i = tid; i < 3 * N; i += T) {
       float v = g[i];
@@ -53,8 +79,21 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     }
     __syncthreads();
   }
+  if constexpr (!use_lds && PPT > 4) {
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const int j = tid + p * T;
+      const bool ok = j < N;
+      // (a slot without a point: distance 0 for ever - it can only tie at 0, and ties go to the lower, i.e. a real, index)
+      qx[p >> 1][p & 1] = ok ? g[(size_t)j * 3 + 0] : 0.f;
+      qy[p >> 1][p & 1] = ok ? g[(size_t)j * 3 + 1] : 0.f;
+      qz[p >> 1][p & 1] = ok ? g[(size_t)j * 3 + 2] : 0.f;
+      qd[p >> 1][p & 1] = ok ? 1e10f : 0.f;  // pointnet_util.py:64
+    }
+  }
 #pragma unroll
   for (int p = 0; p < PPT; ++p) {
+    if (!use_lds && PPT > 4) break;
     int j = tid + p * T;
     bool ok = j < N;
     if (use_lds) {
@@ -72,12 +111,15 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
   // counts (the data pipeline's padded pieces): only the first counts[b] rows of the cloud are real, the rest are copies of
   // row 0, which can never be picked (distance 0 after the first round at the latest, and any tie goes to the lower index);
   // the rounds then leave out every register slot that holds padding only (a workgroup-uniform bound)
-  const int nreal = counts ? (int)(counts[b] < 1 ? 1 : (counts[b] > N ? N : counts[b])) : N;
+  constexpr int CAP = T * PPT;      // (the background form may hold fewer slots than the buffer has rows: max_count)
+  const int nmax = N < CAP ? N : CAP;
+  const int nreal = counts ? (int)(counts[b] < 1 ? 1 : (counts[b] > nmax ? nmax : counts[b])) : nmax;
   const int pmax = (nreal + T - 1) / T;
   const bool full = N == T * PPT && nreal == N;      // every thread's every point exists: no bounds tests in the rounds
   int far = (int)start[b];  // pointnet_util.py:65 (the caller's randint draw)
   far = far < 0 ? 0 : (far >= N ? N - 1 : far);
   int64_t* o = out + (size_t)b * npoint;
+  float ncx = 0.f, ncy = 0.f, ncz = 0.f;      // (publish) the next round's centroid
 
   for (int i = 0; i < npoint; ++i) {
     // :68 — the pick goes to LDS and leaves in chunks: a global store inside the loop keeps a vector-memory operation
@@ -94,6 +136,8 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
       cx = sx[far];
       cy = sy[far];
       cz = sz[far];
+    } else if (publish && i > 0) {
+      cx = ncx, cy = ncy, cz = ncz;      // published by the owner's wavefront in the round before
     } else {
       cx = g[(size_t)far * 3 + 0];
       cy = g[(size_t)far * 3 + 1];
@@ -127,6 +171,39 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
       else
         wj = pzn::wave_min_u32_dpp(tied ? bj : 0xffffffffu);
       best = ((uint64_t)wm << 32) | (uint32_t)(~wj);
+    } else if constexpr (publish) {
+      // packed distances, 32-bit keys with the slot number deferred (as the small-cloud form above): 8 vector instructions
+      // per point instead of 13
+      const v2f c2x = v2f{cx, cx}, c2y = v2f{cy, cy}, c2z = v2f{cz, cz};
+      const int qmax = (pmax + 1) >> 1;      // (workgroup-uniform; an odd pmax evaluates one slot of padding: harmless, see above)
+      uint32_t bd = 0, bp = 0;
+      nested_while_below<0, PQ>(qmax, [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const v2f dx = qx[q] - c2x, dy = qy[q] - c2y, dz = qz[q] - c2z;      // :70
+        const v2f d = (dx * dx + dy * dy) + dz * dz;
+        v2f nd;                                                             // :71
+        nd.x = d.x < qd[q].x ? d.x : qd[q].x;
+        nd.y = d.y < qd[q].y ? d.y : qd[q].y;
+        qd[q] = nd;
+        const uint32_t n0 = __float_as_uint(nd.x), n1 = __float_as_uint(nd.y);
+        // strict >: the lower slot (= lower index) of equal distances stays; the thread's first slot is always taken
+        const bool t0 = q == 0 ? true : n0 > bd;
+        bd = t0 ? n0 : bd;
+        bp = t0 ? (uint32_t)(2 * q) : bp;
+        const bool t1 = n1 > bd;
+        bd = t1 ? n1 : bd;
+        bp = t1 ? (uint32_t)(2 * q + 1) : bp;
+      });
+      const uint32_t bj = (uint32_t)tid + bp * (uint32_t)T;
+      const uint32_t wm = pzn::wave_max_u32_dpp(bd);
+      const bool tied = bd == wm;
+      const unsigned long long tmask = __ballot(tied);
+      uint32_t wj;
+      if (__popcll(tmask) == 1)
+        wj = (uint32_t)__builtin_amdgcn_readlane((int)bj, __builtin_ctzll(tmask));
+      else
+        wj = pzn::wave_min_u32_dpp(tied ? bj : 0xffffffffu);
+      best = ((uint64_t)wm << 32) | (uint32_t)(~wj);
     } else {      // many points per thread: the 64-bit key (distance, ~index) per point measured faster there
       best = 0;  // below every real key: real keys have ~j >= 1
 #pragma unroll
@@ -144,15 +221,46 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
       best = pzn::wave_max_u64_dpp(best);
     }
     uint64_t* sl = slots + (i & 1) * W;
-    if (lane == 0) sl[wave] = best;
+    if constexpr (publish) {
+      // the wavefront's best point j = tid' + ps T sits in register slot ps (wavefront-uniform) of lane j & 63
+      const uint32_t wj = ~(uint32_t)best;
+      const int ps = __builtin_amdgcn_readfirstlane((int)(wj / T));
+      const int qs = ps >> 1;
+      v2f sx2 = qx[0], sy2 = qy[0], sz2 = qz[0];
+      nested_while_below<1, PQ>((pmax + 1) >> 1, [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const bool s = q == qs;
+        sx2.x = s ? qx[q].x : sx2.x, sx2.y = s ? qx[q].y : sx2.y;
+        sy2.x = s ? qy[q].x : sy2.x, sy2.y = s ? qy[q].y : sy2.y;
+        sz2.x = s ? qz[q].x : sz2.x, sz2.y = s ? qz[q].y : sz2.y;
+      });
+      const bool hi = (ps & 1) != 0;
+      const float bx = hi ? sx2.y : sx2.x, by = hi ? sy2.y : sy2.x, bz = hi ? sz2.y : sz2.x;
+      const int ol = (int)(wj & (PZN_WAVE - 1));
+      const float ox = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bx), ol));
+      const float oy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, by), ol));
+      const float oz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bz), ol));
+      if (lane == 0) {
+        sl[wave] = best;
+        scoord[(i & 1) * W + wave] = make_float4(ox, oy, oz, 0.f);
+      }
+    } else {
+      if (lane == 0) sl[wave] = best;
+    }
     __syncthreads();
     uint64_t m = sl[0];
+    int mw = 0;
 #pragma unroll
     for (int w = 1; w < W; ++w) {
       uint64_t v = sl[w];
+      mw = v > m ? w : mw;
       m = v > m ? v : m;
     }
     far = (int)(~(uint32_t)m);  // :72 first (lowest-index) maximum
+    if constexpr (publish) {
+      const float4 c = scoord[(i & 1) * W + mw];
+      ncx = c.x, ncy = c.y, ncz = c.z;
+    }
   }
 }
 
@@ -163,7 +271,7 @@ int launch(const float* xyz, int B, int N, int npoint, const int64_t* start, int
   size_t lds_xyz = (size_t)3 * N * sizeof(float);
   size_t lds = 2 * W * sizeof(uint64_t) + FPS_OUT_CHUNK * sizeof(int);
   int use_lds = image && lds + lds_xyz <= 150 * 1024;
-  if (use_lds) lds += lds_xyz;
+  lds += use_lds ? lds_xyz : 2 * W * sizeof(float4);      // the image, or the wavefronts' published coordinates
   if (use_lds) {
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_kernel<T, PPT, true>),
@@ -179,19 +287,26 @@ int launch(const float* xyz, int B, int N, int npoint, const int64_t* start, int
 }  // namespace
 
 // The same sampling as a BACKGROUND job (datapipe.PairFeeder: pieces of up to 32768 raw points sampled on a side stream while
-// a training step owns the chip): no LDS image of the cloud - the centroid of a round is fetched from global memory (L2) -, so
-// a workgroup holds 1.2 KB of LDS instead of up to 150 KB and the step's LDS-tiled kernels keep their CUs; 512 threads for
+// a training step owns the chip): no LDS image of the cloud - every wavefront publishes its best point's coordinates beside its
+// key, so the next round's centroid comes from the owner's registers through 16 bytes of LDS, not from memory -, so
+// a workgroup holds 1.5 KB of LDS instead of up to 150 KB and the step's LDS-tiled kernels keep their CUs; 512 threads for
 // N <= 16384.  counts (may be NULL): int64 [B], the number of REAL rows of each cloud when the rest is padding with copies of
 // row 0 (datapipe._compact): the rounds skip the padding.  Same picks bit for bit (the arithmetic is the same code).
 PZN_EXPORT int pzn_fps_background_f32(const float* xyz, int B, int N, int npoint, const int64_t* start_idx,
-                                      int64_t* out_idx, const int64_t* counts, pzn_stream_t stream) {
-  PZN_CHECK_ARG(xyz && start_idx && out_idx && B > 0 && N > 0 && npoint > 0);
+                                      int64_t* out_idx, const int64_t* counts, int max_count, pzn_stream_t stream) {
+  PZN_CHECK_ARG(xyz && start_idx && out_idx && B > 0 && N > 0 && npoint > 0 && max_count >= 0);
   hipStream_t st = pzn_hip_stream(stream);
-  if (N <= 2048) return launch<256, 8>(xyz, B, N, npoint, start_idx, out_idx, st, false, counts);
-  if (N <= 4096) return launch<256, 16>(xyz, B, N, npoint, start_idx, out_idx, st, false, counts);
-  if (N <= 8192) return launch<512, 16>(xyz, B, N, npoint, start_idx, out_idx, st, false, counts);
-  if (N <= 16384) return launch<512, 32>(xyz, B, N, npoint, start_idx, out_idx, st, false, counts);
-  if (N <= 32768) return launch<1024, 32>(xyz, B, N, npoint, start_idx, out_idx, st, false, counts);
+  // Threads x register slots by the number of rows that can be REAL (max_count: the caller's promise counts[b] <= max_count;
+  // 0 or no counts: N): four wavefronts wherever the points fit 32 slots - the round's fixed part (wave reductions, barrier,
+  // re-reduction of the per-wave slots) grows with the wavefront count: per round on 2048 real points 1.16 us with eight
+  // wavefronts against 0.77 with four, and 0.07 us per 512 points either way (tools/bench_fps.py).  Rows at and beyond
+  // threads x slots are never looked at (padding by the promise).
+  const int cap = (counts && max_count > 0 && max_count < N) ? max_count : N;
+  if (cap <= 2048) return launch<256, 8>(xyz, B, N, npoint, start_idx, out_idx, st, false, counts);
+  if (cap <= 4096) return launch<256, 16>(xyz, B, N, npoint, start_idx, out_idx, st, false, counts);
+  if (cap <= 8192) return launch<256, 32>(xyz, B, N, npoint, start_idx, out_idx, st, false, counts);
+  if (cap <= 16384) return launch<512, 32>(xyz, B, N, npoint, start_idx, out_idx, st, false, counts);
+  if (cap <= 32768) return launch<1024, 32>(xyz, B, N, npoint, start_idx, out_idx, st, false, counts);
   return PZN_EUNSUPPORTED;
 }
 

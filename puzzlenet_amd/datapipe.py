@@ -270,7 +270,8 @@ def cut_pairs(raw, normals, zs, u, twist, n=1024, k=128, cap=None):
     if cap > 32768:
         raise _lib.PznUnsupported(f"cut_pairs: pieces of up to {cap} points (the FPS kernel holds <= 32768)")
     pieces, counts, start, plane, ok = ops.cut_compact(raw, normals, zs, u, n, cap)
-    idx = ops.farthest_point_sample(pieces, n, start, background=True, counts=counts)          # dataset.py:1147-1163
+    # (a valid cut leaves >= n points on either side, so a piece holds <= M - n; rows of samples without a valid cut are re-drawn)
+    idx = ops.farthest_point_sample(pieces, n, start, background=True, counts=counts, max_count=max(M - n, n))      # dataset.py:1147-1163
     both = ops.index_points(pieces, idx)
     up, down = both[:B], both[B:]
     cd_over_up, cd_over_down = ops.chamfer(down, up)                                             # dataset.py:1357-1367

@@ -166,10 +166,10 @@ def square_distance(src, dst):
     return out
 
 
-def farthest_point_sample(xyz, npoint, start_idx, background=False, counts=None):
+def farthest_point_sample(xyz, npoint, start_idx, background=False, counts=None, max_count=0):
     """background=True: the same picks from the small-footprint launch (no LDS image of the cloud; pzn_fps_background_f32):
     for sampling that runs on a side stream beside a training step (datapipe.PairFeeder); counts [B] int64: rows >= counts[b]
-    of cloud b are padding copies of its row 0 and are skipped."""
+    of cloud b are padding copies of its row 0 and are skipped; max_count: the caller's promise counts <= max_count (0: none)."""
     xyz = _f32(xyz, "xyz")
     B, N, C = xyz.shape
     if C != 3:
@@ -179,7 +179,7 @@ def farthest_point_sample(xyz, npoint, start_idx, background=False, counts=None)
     with _on(xyz.device):
         if background:
             counts = None if counts is None else _i64(counts, "counts")
-            _call("pzn_fps_background_f32", _p(xyz), B, N, int(npoint), _p(start_idx), _p(out), _p(counts), _stream())
+            _call("pzn_fps_background_f32", _p(xyz), B, N, int(npoint), _p(start_idx), _p(out), _p(counts), int(max_count), _stream())
         else:
             _call("pzn_fps_f32", _p(xyz), B, N, int(npoint), _p(start_idx), _p(out), _stream())
     return out

@@ -147,6 +147,11 @@ def test_fps_vs_oracle(dev, B, N, S):
                                           counts=torch.full((B,), c, dtype=torch.int64, device=dev)).cpu().numpy()
         assert np.array_equal(got_c, orc.farthest_point_sample(np.ascontiguousarray(xyz[:, :c]), S, st_c))
         assert np.array_equal(got_c, ops.farthest_point_sample(_t(padded, dev), S, _t(st_c, dev)).cpu().numpy())
+        # ... and with the caller's bound on the counts (the launch then holds only that many rows: fewer wavefronts)
+        for bound in (c, c + 100):
+            got_m = ops.farthest_point_sample(_t(padded, dev), S, _t(st_c, dev), background=True, max_count=bound,
+                                              counts=torch.full((B,), c, dtype=torch.int64, device=dev)).cpu().numpy()
+            assert np.array_equal(got_m, got_c)
 
 
 @pytest.mark.parametrize("B,N,S,K", [(2, 1024, 512, 32), (2, 2048, 512, 32), (2, 512, 256, 32), (1, 4096, 512, 32),
