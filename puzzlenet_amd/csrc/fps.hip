@@ -174,7 +174,11 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     } else if constexpr (publish) {
       // packed distances, 32-bit keys with the slot number deferred (as the small-cloud form above): 8 vector instructions
       // per point instead of 13
-      const v2f c2x = v2f{cx, cx}, c2y = v2f{cy, cy}, c2z = v2f{cz, cz};
+      // the centroid as three real register pairs (the asm is empty: it only keeps the compiler from broadcasting one half of a
+      // pair with op_sel on src1 - the packed form that returns wrong results beside AGPR-accumulator MFMAs, DESIGN.md section 4,
+      // tests/test_isa_forms.py)
+      v2f c2x = v2f{cx, cx}, c2y = v2f{cy, cy}, c2z = v2f{cz, cz};
+      asm volatile("" : "+v"(c2x), "+v"(c2y), "+v"(c2z));
       const int qmax = (pmax + 1) >> 1;      // (workgroup-uniform; an odd pmax evaluates one slot of padding: harmless, see above)
       uint32_t bd = 0, bp = 0;
       nested_while_below<0, PQ>(qmax, [&](auto qc) {
