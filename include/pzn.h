@@ -155,6 +155,12 @@ int pzn_emd_matchcost_grad_f32(const float* grad_cost, const float* xyz1,
 int pzn_emd_fused_f32(const float* xyz1, const float* xyz2, int B, int n, int m,
                       float* cost, float* g1, float* g2, void* workspace,
                       pzn_stream_t stream);
+/* 1..4 SMALL calls of the function above (n, m <= 256 each: model5_b.py:1012 and :1123-1125, the three small terms of the loss) as
+ * ONE launch of single-workgroup auctions; HOST arrays of device pointers / sizes, one entry per call; results bit-identical to
+ * the separate calls.  PZN_EUNSUPPORTED when one of them is larger. */
+int pzn_emd_fused_small_multi_f32(int count, const float* const* xyz1, const float* const* xyz2,
+                                  const int* B, const int* n, const int* m, float* const* cost,
+                                  float* const* g1, float* const* g2, pzn_stream_t stream);
 
 /* The double instantiation of the three calls (emd_kernel.cu:187, :273, :391 dispatch on the floating type;
  * csrc/emd64.hip): same layouts in double, workspace of pzn_emd_workspace_bytes_f64(B,n,m) bytes.  model5_b never

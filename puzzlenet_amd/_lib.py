@@ -45,6 +45,7 @@ SIGNATURES = {
     "pzn_emd_matchcost_f64": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "pzn_emd_matchcost_grad_f64": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
     "pzn_emd_fused_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f]),
+    "pzn_emd_fused_small_multi_f32": (_c_i, [_c_i] + [_c_f] * 8 + [_c_f]),
     "pzn_chamfer_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i]),
     "pzn_chamfer_fwd_f32": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f]),
     "pzn_linear_fwd_f32": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),

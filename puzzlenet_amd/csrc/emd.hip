@@ -328,17 +328,41 @@ __global__ __launch_bounds__(EMD_T) void emd_grad2_kernel(const float* __restric
 
 constexpr int EMD_SMALL_T = 1024;  // 16 wavefronts per pair: the walk is a dependent VALU / exp chain per lane
 
-__global__ __launch_bounds__(EMD_SMALL_T) void emd_small_fused_kernel(const float* __restrict__ xyz1,
-                                                              const float* __restrict__ xyz2, int n, int m,
-                                                              float multiL, float multiR, int tpr_shift,
-                                                              float* __restrict__ cost, float* __restrict__ g1,
-                                                              float* __restrict__ g2) {
+// Up to EMD_SMALL_NP independent calls in one launch (the three small terms of the loss: model5_b.py:1012, :1123-1125): workgroup
+// blockIdx.x belongs to the problem whose range [first, first + B) holds it.
+constexpr int EMD_SMALL_NP = 4;
+struct EmdSmallProblem {
+  const float* xyz1;
+  const float* xyz2;
+  float* cost;
+  float* g1;
+  float* g2;
+  int n, m, tpr_shift, first;      // first: the problem's first workgroup
+  float multiL, multiR;
+};
+struct EmdSmallArgs {
+  EmdSmallProblem pr[EMD_SMALL_NP];
+  int count;
+};
+
+__global__ __launch_bounds__(EMD_SMALL_T) void emd_small_fused_kernel(EmdSmallArgs args) {
+  int which = 0;
+#pragma unroll
+  for (int i = 1; i < EMD_SMALL_NP; ++i) which = (i < args.count && (int)blockIdx.x >= args.pr[i].first) ? i : which;
+  const EmdSmallProblem& pr = args.pr[which];
+  const float* __restrict__ xyz1 = pr.xyz1;
+  const float* __restrict__ xyz2 = pr.xyz2;
+  float* __restrict__ cost = pr.cost;
+  float* __restrict__ g1 = pr.g1;
+  float* __restrict__ g2 = pr.g2;
+  const int n = pr.n, m = pr.m, tpr_shift = pr.tpr_shift;
+  const float multiL = pr.multiL, multiR = pr.multiR;
   __shared__ float4 p1[EMD_SMALL_MAX];   // {x1, y1, z1, ratioL}
   __shared__ float4 p2[EMD_SMALL_MAX];   // {x2, y2, z2, remainR}
   __shared__ float rr[EMD_SMALL_MAX];    // ratioR
   __shared__ float rl[EMD_SMALL_MAX];    // remainL
   __shared__ float csum[EMD_SMALL_T / 64];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = (int)blockIdx.x - pr.first, tid = threadIdx.x;
   const int tpr = 1 << tpr_shift, row = tid >> tpr_shift, part = tid & (tpr - 1);
   for (int i = tid; i < n; i += EMD_SMALL_T) {
     const float* q = xyz1 + ((size_t)b * n + i) * 3;
@@ -1080,18 +1104,49 @@ PZN_EXPORT int pzn_emd_approxmatch_f32(const float* xyz1, const float* xyz2, int
   return run_match(xyz1, xyz2, B, n, m, match, workspace, pzn_hip_stream(stream));
 }
 
+static EmdSmallProblem emd_small_problem(const float* xyz1, const float* xyz2, int n, int m, float* cost, float* g1, float* g2,
+                                         int first) {
+  EmdSmallProblem p;
+  p.xyz1 = xyz1, p.xyz2 = xyz2, p.cost = cost, p.g1 = g1, p.g2 = g2, p.n = n, p.m = m, p.first = first;
+  p.multiL = n >= m ? 1.f : (float)(m / n), p.multiR = n >= m ? (float)(n / m) : 1.f;  // :29-35
+  int rows = 1;
+  while (rows < (n > m ? n : m)) rows <<= 1;
+  int shift = 0;
+  while ((rows << shift) < EMD_SMALL_T && shift < 6) ++shift;  // lanes sharing a row stay inside one wavefront
+  p.tpr_shift = shift;
+  return p;
+}
+
+// Several small calls (n, m <= 256 each; 1 <= count <= 4) of pzn_emd_fused_f32 as ONE launch: problem i is xyz1[i][B[i], n[i], 3]
+// against xyz2[i][B[i], m[i], 3] -> cost[i][B[i]], g1[i], g2[i] (HOST arrays of device pointers / sizes).  The results are those
+// of count separate calls, bit for bit.  PZN_EUNSUPPORTED when a problem is larger (callers then make the calls one by one).
+PZN_EXPORT int pzn_emd_fused_small_multi_f32(int count, const float* const* xyz1, const float* const* xyz2, const int* B,
+                                             const int* n, const int* m, float* const* cost, float* const* g1,
+                                             float* const* g2, pzn_stream_t stream) {
+  PZN_CHECK_ARG(count >= 1 && count <= EMD_SMALL_NP && xyz1 && xyz2 && B && n && m && cost && g1 && g2);
+  EmdSmallArgs a;
+  a.count = count;
+  int first = 0;
+  for (int i = 0; i < count; ++i) {
+    PZN_CHECK_ARG(xyz1[i] && xyz2[i] && cost[i] && g1[i] && g2[i] && B[i] > 0 && n[i] > 0 && m[i] > 0 && B[i] <= 65535);
+    if (n[i] > EMD_SMALL_MAX || m[i] > EMD_SMALL_MAX) return PZN_EUNSUPPORTED;
+    a.pr[i] = emd_small_problem(xyz1[i], xyz2[i], n[i], m[i], cost[i], g1[i], g2[i], first);
+    first += B[i];
+  }
+  for (int i = count; i < EMD_SMALL_NP; ++i) a.pr[i] = a.pr[0];
+  PZN_LAUNCH(emd_small_fused_kernel, dim3((unsigned)first), dim3(EMD_SMALL_T), 0, pzn_hip_stream(stream), a);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
 PZN_EXPORT int pzn_emd_fused_f32(const float* xyz1, const float* xyz2, int B, int n, int m, float* cost, float* g1,
                                  float* g2, void* workspace, pzn_stream_t stream) {
   PZN_CHECK_ARG(xyz1 && xyz2 && cost && g1 && g2 && workspace && B > 0 && n > 0 && m > 0 && B <= 65535);
   PZN_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 15) == 0);
   if (n <= EMD_SMALL_MAX && m <= EMD_SMALL_MAX) {  // one workgroup per pair, one launch for the whole auction
-    const float multiL = n >= m ? 1.f : (float)(m / n), multiR = n >= m ? (float)(n / m) : 1.f;  // :29-35
-    int rows = 1;
-    while (rows < (n > m ? n : m)) rows <<= 1;
-    int shift = 0;
-    while ((rows << shift) < EMD_SMALL_T && shift < 6) ++shift;  // lanes sharing a row stay inside one wavefront
-    PZN_LAUNCH(emd_small_fused_kernel, dim3((unsigned)B), dim3(EMD_SMALL_T), 0, pzn_hip_stream(stream), xyz1, xyz2,
-                       n, m, multiL, multiR, shift, cost, g1, g2);
+    EmdSmallArgs a;
+    a.count = 1;
+    a.pr[0] = emd_small_problem(xyz1, xyz2, n, m, cost, g1, g2, 0);
+    PZN_LAUNCH(emd_small_fused_kernel, dim3((unsigned)B), dim3(EMD_SMALL_T), 0, pzn_hip_stream(stream), a);
     PZN_RETURN_LAUNCH_STATUS();
   }
   return run_fused(xyz1, xyz2, B, n, m, cost, g1, g2, workspace, pzn_hip_stream(stream));

@@ -616,9 +616,8 @@ class TouchedRegraster(_Base):
         else:
             loss_cd2 = torch.mean(dg_att1_dist1) + torch.mean(dg_att1_dist2)
         self.log('train/cd2', loss_cd2)
-        emd2 = earth_mover_distance(x2att1, x2att2, transpose=False)                # :1012
-        emd2 = torch.sum(emd2)                                                      # :1033
-        self.log('train_emd2', emd2)
+        # :1012 emd2 = earth_mover_distance(x2att1, x2att2) is evaluated further down, in one launch with the two other small
+        # terms (:1123-1125); nothing in between reads it
 
         if de_fpcb.is_cuda:
             # :1063-1064 cross entropy and :1085-1090 class-1 probability in one launch per head, :1089-1091 top-128 as
@@ -658,8 +657,16 @@ class TouchedRegraster(_Base):
         loss_mrpcb = torch.mean(cd_mrpcb1) + torch.mean(cd_mrpcb2)
         self.log('train/loss_rpcb', loss_mrpcb)
 
-        emd_fpcb = torch.mean(earth_mover_distance(de_fpcb_pts, fpcb, transpose=False))         # :1123-1126
-        emd_mrpcb = torch.mean(earth_mover_distance(inverse_de_mrpcb, rpcb, transpose=False))
+        small = [(x2att1, x2att2), (de_fpcb_pts, fpcb), (inverse_de_mrpcb, rpcb)]      # :1012, :1123, :1125
+        if all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.shape[1] <= ops.EMD_SMALL_MAX for pr in small for t in pr):
+            # the three single-workgroup auctions as ONE launch (3 B workgroups instead of B three times; csrc/emd.hip)
+            emd2, e_fpcb, e_mrpcb = ops.emd_fused_small_multi(small)
+        else:
+            emd2, e_fpcb, e_mrpcb = (earth_mover_distance(a_, b_, transpose=False) for a_, b_ in small)
+        emd2 = torch.sum(emd2)                                                      # :1033
+        self.log('train_emd2', emd2)
+        emd_fpcb = torch.mean(e_fpcb)                                               # :1123-1126
+        emd_mrpcb = torch.mean(e_mrpcb)
         self.log('train/loss_emd_fpcb', emd_fpcb)
         self.log('train/loss_emc_mrpcb', emd_mrpcb)
 

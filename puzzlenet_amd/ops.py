@@ -647,6 +647,51 @@ def emd_fused(xyz1, xyz2):
     return _EmdFused.apply(xyz1, xyz2)
 
 
+EMD_SMALL_MAX = 256      # csrc/emd.hip: n, m up to here run as one workgroup per pair
+
+
+class _EmdFusedSmallMulti(torch.autograd.Function):
+    """Several small EarthMoverDistanceFunction calls (PyTorchEMD/emd.py:5-21; n, m <= 256 each) in one launch:
+    apply(a1, b1, a2, b2, ...) -> (cost1, cost2, ...), each what _EmdFused gives for its pair, bit for bit."""
+
+    @staticmethod
+    def forward(ctx, *clouds):
+        k = len(clouds) // 2
+        a = [_f32(t, "xyz1") for t in clouds[0::2]]
+        b = [_f32(t, "xyz2") for t in clouds[1::2]]
+        shapes = [_emd_shapes(x, y) for x, y in zip(a, b)]
+        dev = a[0].device
+        cost = [torch.empty((B,), dtype=torch.float32, device=dev) for B, _, _ in shapes]
+        g1 = [torch.empty((B, n, 3), dtype=torch.float32, device=dev) for B, n, _ in shapes]
+        g2 = [torch.empty((B, m, 3), dtype=torch.float32, device=dev) for B, _, m in shapes]
+        ints = lambda j: (ctypes.c_int * k)(*[int(sh[j]) for sh in shapes])
+        with _on(dev):
+            _call("pzn_emd_fused_small_multi_f32", k, _ptrs(a), _ptrs(b), ints(0), ints(1), ints(2), _ptrs(cost), _ptrs(g1),
+                  _ptrs(g2), _stream())
+        ctx.save_for_backward(*g1, *g2)
+        ctx.k = k
+        return tuple(cost)
+
+    @staticmethod
+    def backward(ctx, *grad_cost):
+        k = ctx.k
+        g1, g2 = ctx.saved_tensors[:k], ctx.saved_tensors[k:]
+        out = []
+        for i in range(k):
+            if grad_cost[i] is None:
+                out += [None, None]
+            else:
+                gc = grad_cost[i].contiguous().view(-1, 1, 1)
+                out += [g1[i] * gc, g2[i] * gc]
+        return tuple(out)
+
+
+def emd_fused_small_multi(pairs):
+    """[(xyz1, xyz2), ...] (1..4 pairs, every cloud of at most 256 points) -> [cost[B], ...] from one launch."""
+    flat = [t for pr in pairs for t in pr]
+    return list(_EmdFusedSmallMulti.apply(*flat))
+
+
 # --------------------------------------------------------------------------- chamfer
 
 class _Chamfer(torch.autograd.Function):

@@ -266,3 +266,26 @@ def test_double_known_answer(dev):
     d = earth_mover_distance(p1, p2, transpose=False)
     assert d.dtype == torch.float64
     np.testing.assert_allclose(d.cpu().numpy(), [0.71] * 3, rtol=1e-6)
+
+
+def test_small_calls_in_one_launch(dev):
+    """ops.emd_fused_small_multi (pzn_emd_fused_small_multi_f32: the three small terms of the loss, model5_b.py:1012 and
+    :1123-1125, as ONE launch of single-workgroup auctions) against the same calls made one by one: costs and both gradients
+    bit-identical; shapes of the loss (64 x 64, 128 x 128 twice), a ragged one (n != m, different batch) and a single problem."""
+    from puzzlenet_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for shapes in ([(6, 64, 64), (6, 128, 128), (6, 128, 128)], [(3, 100, 50), (5, 17, 256), (2, 256, 256), (4, 1, 7)], [(2, 33, 33)]):
+        pairs = [(torch.rand(B, n, 3, generator=g).to(dev).requires_grad_(True), torch.rand(B, m, 3, generator=g).to(dev).requires_grad_(True))
+                 for B, n, m in shapes]
+        ws = [torch.rand(B, generator=g).to(dev) for B, _, _ in shapes]
+        costs = ops.emd_fused_small_multi(pairs)
+        sum((c * w).sum() for c, w in zip(costs, ws)).backward()
+        got = [(c.detach().clone(), a.grad.clone(), b.grad.clone()) for c, (a, b) in zip(costs, pairs)]
+        for (a, b), w, (c1, ga, gb) in zip(pairs, ws, got):
+            a.grad = b.grad = None
+            c0 = ops.emd_fused(a, b)
+            (c0 * w).sum().backward()
+            assert torch.equal(c0, c1) and torch.equal(a.grad, ga) and torch.equal(b.grad, gb)
+    big = [(torch.rand(1, 300, 3).to(dev), torch.rand(1, 300, 3).to(dev))]
+    with pytest.raises(Exception):
+        ops.emd_fused_small_multi(big)
