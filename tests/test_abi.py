@@ -68,3 +68,22 @@ def test_product_does_not_import_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "pzn_oracle" in txt:
                     bad.append(f)
     assert not bad, bad
+
+
+def test_integration_md_names_every_exported_symbol():
+    """INTEGRATION.md is the index a maintainer binds from: every entry point include/pzn.h declares appears there (as its full
+    name, inside a `pzn_x_{a,b}_f32` brace group, or as a ` / suffix` alternative of a named one)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "pzn.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    syms = set(re.findall(r"\b(pzn_[a-z0-9_]+)\s*\(", header))
+    names = set(re.findall(r"pzn_[a-z0-9_]+", doc))
+    for m in re.finditer(r"(pzn_[a-z0-9_]*)\{([^}]*)\}([a-z0-9_]*)", doc):
+        names.update(m.group(1) + alt.strip() + m.group(3) for alt in m.group(2).split(","))
+    for m in re.finditer(r"(pzn_[a-z0-9_]+)((?:\s*/\s*_?[a-z0-9_]+)+)", doc):
+        toks = m.group(1).split("_")
+        for alt in (q.strip().lstrip("_") for q in m.group(2).split("/") if q.strip()):
+            names.update("_".join(toks[:k]) + "_" + alt for k in range(1, len(toks)))
+    missing = sorted(syms - names)
+    assert not missing, f"entry points of include/pzn.h that INTEGRATION.md does not name: {missing}"
