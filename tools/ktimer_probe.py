@@ -14,7 +14,7 @@ model = model5_b.TouchedRegraster(cfg).to(dev)
 model.two_streams = os.environ.get("TWO", "0") == "1"
 batch = synthetic.make_batch(B, N, dev, seed=1234)
 r = engine.TrainStep(model, batch, cfg.lr, world=1)
-for _ in range(3):
+for _ in range(int(os.environ.get("WARM", 3))):
     r.step()
 torch.cuda.synchronize()
 steps = 3
