@@ -43,12 +43,17 @@ constexpr int FPS_OUT_CHUNK = 256;      // picks buffered in LDS between write-o
 
 // LDS: the cloud's SoA image fits in LDS (compile-time: with a run-time choice the centroid fetch became three flat_load
 // instructions waited for with vmcnt(0) lgkmcnt(0) in the middle of every round's dependent chain)
-template <int T, int PPT, bool use_lds>
-__global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int N, int npoint,
-                                                const int64_t* __restrict__ start,
-                                                int64_t* __restrict__ out, const int64_t* __restrict__ counts) {
+// G clouds per workgroup (T threads each; cloud blockIdx.x + g gridDim.x): the background form packs the two pieces of a cut
+// into one workgroup - they share nothing but the barrier of a round -, so that the loader holds half as many CUs beside a
+// training step (two or four such 4-wavefront groups on a CU run as fast as one: the round is a latency chain).
+template <int T, int PPT, bool use_lds, int G = 1>
+__global__ __launch_bounds__(T * G) void fps_kernel(const float* __restrict__ xyz, int N, int npoint,
+                                                    const int64_t* __restrict__ start,
+                                                    int64_t* __restrict__ out, const int64_t* __restrict__ counts, int lds_per_cloud) {
   constexpr int W = T / PZN_WAVE;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  const int grp = G > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / T) : 0;
+  unsigned char* smem_raw = smem_all + (size_t)grp * lds_per_cloud;
   uint64_t* slots = reinterpret_cast<uint64_t*>(smem_raw);             // [2][W]
   int* sout = reinterpret_cast<int*>(smem_raw + 2 * W * sizeof(uint64_t));      // [FPS_OUT_CHUNK] picks not yet written out
   float* sx = reinterpret_cast<float*>(smem_raw + 2 * W * sizeof(uint64_t) + FPS_OUT_CHUNK * sizeof(int));
@@ -59,8 +64,8 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
   float4* scoord = reinterpret_cast<float4*>(sx);
   constexpr bool publish = !use_lds && PPT > 4;
 
-  const int b = blockIdx.x;
-  const int tid = threadIdx.x;
+  const int b = blockIdx.x + grp * gridDim.x;
+  const int tid = G > 1 ? (int)threadIdx.x - grp * T : (int)threadIdx.x;
   const int lane = tid & (PZN_WAVE - 1);
   const int wave = tid / PZN_WAVE;
   const float* g = xyz + (size_t)b * N * 3;
@@ -281,9 +286,14 @@ int launch(const float* xyz, int B, int N, int npoint, const int64_t* start, int
         hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_kernel<T, PPT, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return PZN_ELAUNCH;
-    PZN_LAUNCH((fps_kernel<T, PPT, true>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out, counts);
+    PZN_LAUNCH((fps_kernel<T, PPT, true>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out, counts, (int)lds);
+  } else if constexpr (T == 256 && PPT > 4) {      // the background form: clouds b and b + B / 2 (the two pieces of a cut) per workgroup
+    if (B % 2 == 0)
+      PZN_LAUNCH((fps_kernel<T, PPT, false, 2>), dim3(B / 2), dim3(2 * T), 2 * lds, st, xyz, N, npoint, start, out, counts, (int)lds);
+    else
+      PZN_LAUNCH((fps_kernel<T, PPT, false>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out, counts, (int)lds);
   } else {
-    PZN_LAUNCH((fps_kernel<T, PPT, false>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out, counts);
+    PZN_LAUNCH((fps_kernel<T, PPT, false>), dim3(B), dim3(T), lds, st, xyz, N, npoint, start, out, counts, (int)lds);
   }
   PZN_RETURN_LAUNCH_STATUS();
 }
