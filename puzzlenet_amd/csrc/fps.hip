@@ -39,6 +39,17 @@ __device__ __forceinline__ void nested_while_below(int n, F&& f) {
   }
 }
 
+// f(q) for the one compile-time q in [Q, Q1) that equals the (wavefront-uniform) n
+template <int Q, int Q1, typename F>
+__device__ __forceinline__ void uniform_pick(int n, F&& f) {
+  if constexpr (Q < Q1) {
+    if (n == Q)
+      f(std::integral_constant<int, Q>{});
+    else
+      uniform_pick<Q + 1, Q1>(n, f);
+  }
+}
+
 constexpr int FPS_OUT_CHUNK = 256;      // picks buffered in LDS between write-outs (power of two)
 
 // LDS: the cloud's SoA image fits in LDS (compile-time: with a run-time choice the centroid fetch became three flat_load
@@ -235,13 +246,13 @@ __global__ __launch_bounds__(T * G) void fps_kernel(const float* __restrict__ xy
       const uint32_t wj = ~(uint32_t)best;
       const int ps = __builtin_amdgcn_readfirstlane((int)(wj / T));
       const int qs = ps >> 1;
+      // slot pair qs is wavefront-uniform: a chain of scalar compares with ONE taken body instead of six selects per pair on
+      // every lane (the empty asm keeps the compiler from turning the bodies back into selects)
       v2f sx2 = qx[0], sy2 = qy[0], sz2 = qz[0];
-      nested_while_below<1, PQ>((pmax + 1) >> 1, [&](auto qc) {
+      uniform_pick<1, PQ>(qs, [&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        const bool s = q == qs;
-        sx2.x = s ? qx[q].x : sx2.x, sx2.y = s ? qx[q].y : sx2.y;
-        sy2.x = s ? qy[q].x : sy2.x, sy2.y = s ? qy[q].y : sy2.y;
-        sz2.x = s ? qz[q].x : sz2.x, sz2.y = s ? qz[q].y : sz2.y;
+        sx2 = qx[q], sy2 = qy[q], sz2 = qz[q];
+        asm volatile("" : "+v"(sx2), "+v"(sy2), "+v"(sz2));
       });
       const bool hi = (ps & 1) != 0;
       const float bx = hi ? sx2.y : sx2.x, by = hi ? sy2.y : sy2.x, bz = hi ? sz2.y : sz2.x;
