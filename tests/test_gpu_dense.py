@@ -221,6 +221,11 @@ def test_sa_mlp_max_fused_vs_composed(dev, precision, B, N, S, D, C1, C2):
         assert torch.equal(y2, y)
         (y2 * go.to(dev)).sum().backward()
         assert _rel(f2.grad, featr.grad) < 1e-4
+        if ops.sa_level_fused_supported(f2, None, d2[0], d2[2]):
+            # the per-point path sums dP by owner and the pooled layer's dW2 / db2 from the workgroups' partial tiles in a fixed
+            # order (csrc/poolbwd.hip: no atomics): the same bits as the first run (idx given or searched: the same indices)
+            assert torch.equal(f2.grad, fd.grad)
+            assert torch.equal(d2[2].grad, d[2].grad) and torch.equal(d2[3].grad, d[3].grad)
 
 
 @pytest.mark.parametrize("sinks", [False, True])
