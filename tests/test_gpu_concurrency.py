@@ -39,6 +39,7 @@ def rig():
     yg = torch.empty(4096, 1024, device=dev)
     side = torch.cuda.Stream()
     bg = torch.zeros(1024, device=dev)
+    fps_counts = torch.full((B,), N - 100, dtype=torch.int64, device=dev)
 
     def chain():      # the four blocks of an encoder as chained kernels (csrc/attnfused.hip: AGPR accumulators) + out projection
         return ops.attention_chain_fused([xa], [[tuple(aw)] * 4], [wg], [bg])[0]
@@ -67,6 +68,10 @@ def rig():
         "knn": lambda: ops.knn(xyz, new_xyz, 32),
         "knn_group": lambda: ops.knn_group(xyz, feat, new_xyz)[0],
         "fps": lambda: ops.farthest_point_sample(xyz, 256, torch.zeros(B, dtype=torch.long, device=dev)),
+        # the data pipeline's form (csrc/fps.hip: packed fp32 distance update - the instruction family of the fault this file is
+        # about -, two clouds per workgroup): what runs beside a training step when it is fed from raw clouds
+        "fps_background": lambda: ops.farthest_point_sample(xyz, 256, torch.zeros(B, dtype=torch.long, device=dev), background=True,
+                                                            counts=fps_counts, max_count=N - 100),
         "ball_query": lambda: ops.ball_query(0.2, 32, xyz, new_xyz),
         "sa_level": lambda: ops.sa_mlp_max(xyz, feat, new_xyz, None, w1, b1, w2, b2),
         "chamfer": lambda: torch.cat([t.reshape(-1).float() for t in ops.chamfer(a_pts, b_pts)]),
