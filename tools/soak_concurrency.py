@@ -55,6 +55,8 @@ victims = {
     "knn": lambda: ops.knn(xyz, new_xyz, 32),
     "knn_group": lambda: ops.knn_group(xyz, feat, new_xyz)[0],
     "fps": lambda: ops.farthest_point_sample(xyz, 256, torch.zeros(B, dtype=torch.long, device=dev)),
+    "fps_background": lambda: ops.farthest_point_sample(xyz, 256, torch.zeros(B, dtype=torch.long, device=dev), background=True,
+                                                        counts=torch.full((B,), N - 100, dtype=torch.int64, device=dev), max_count=N - 100),
     "ball_query": lambda: ops.ball_query(0.2, 32, xyz, new_xyz),
     "sa_level": lambda: ops.sa_mlp_max(xyz, feat, new_xyz, None, w1, b1, w2, b2),
     "chamfer": lambda: torch.cat([t.reshape(-1).float() for t in ops.chamfer(a_pts, b_pts)]),
