@@ -28,14 +28,18 @@ model = model5_b.TouchedRegraster(cfg).to(dev)
 feeder = datapipe.PairFeeder(raw, dev, n=N, seed=0)
 runner = engine.TrainStep(model, feeder.next_batch(), cfg.lr, world=1)
 nxt = feeder.next_batch()
-losses = []
+losses, mem = [], []
 for it in range(a.steps + 3):
     if it == 3:
         torch.cuda.synchronize(); t0 = time.perf_counter()
     losses.append(runner.step(next_batch=nxt))
     nxt = feeder.next_batch()
+    if it % 50 == 0:
+        mem.append(torch.cuda.memory_allocated() >> 20)      # (no synchronisation: the allocator's own count)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print("loss first / last: %.4f / %.4f" % (float(losses[0]), float(losses[-1])))
+ls = torch.stack([l.detach().float().reshape(()) for l in losses])
+print("every loss finite:", bool(torch.isfinite(ls).all()), " MiB allocated every 50 steps:", mem)
 print("%.2f ms per step of %d fresh pairs from %d-point raw clouds = %.0f pairs/s" % (1e3 * dt / a.steps, B, M, B * a.steps / dt))
 runner.close(); feeder.close()
