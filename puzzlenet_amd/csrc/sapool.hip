@@ -110,6 +110,7 @@ struct PointArgs {
 template <int NW, int GF>
 __global__ __launch_bounds__(NW * 64) void pool_point_kernel(PointArgs p) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];      // [C2][PP_COLS], then reused for the final sums
+  __shared__ __attribute__((aligned(16))) uint2 hslot[NW][64];      // per wavefront: the hit pairs of the row it is summing
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col0 = blockIdx.y * PP_COLS, C1 = p.C1, C2 = p.C2;
   for (int f = tid; f < C2 * (PP_COLS / 4); f += NW * 64) {
@@ -187,19 +188,21 @@ __global__ __launch_bounds__(NW * 64) void pool_point_kernel(PointArgs p) {
           for (int h0 = 0; h0 < n_; h0 += 64) {      // (more than 64 channels on one row: rare)
             if (h0 > 0) cur_h = (h0 + lane < n_) ? p.hits[(size_t)b_ + h0 + lane] : make_uint2(0u, 0u);
             const int m_ = min(64, n_ - h0);
+            // the row's (channel, gradient) pairs go through a wavefront-private 512 bytes of LDS and come back as BROADCAST
+            // reads (every lane the same address): the two v_readlane per hit and their wait states were half the hit's issue
+            // slots (same wavefront writes and reads: in order, no barrier)
+            hslot[wave][lane] = cur_h;
             int h = 0;
             for (; h + 1 < m_; h += 2) {      // two hits per trip: two LDS reads in flight
-              const int c0 = __builtin_amdgcn_readlane((int)cur_h.x, h), c1 = __builtin_amdgcn_readlane((int)cur_h.x, h + 1);
-              const float g0 = bcastf(__uint_as_float(cur_h.y), h), g1 = bcastf(__uint_as_float(cur_h.y), h + 1);
-              const v2f w0 = *reinterpret_cast<const v2f*>(wl + c0 * PP_COLS);
-              const v2f w1 = *reinterpret_cast<const v2f*>(wl + c1 * PP_COLS);
-              s0 += g0 * w0;
-              s1 += g1 * w1;
+              const uint4 two = *reinterpret_cast<const uint4*>(&hslot[wave][h]);
+              const v2f w0 = *reinterpret_cast<const v2f*>(wl + (int)two.x * PP_COLS);
+              const v2f w1 = *reinterpret_cast<const v2f*>(wl + (int)two.z * PP_COLS);
+              s0 += __uint_as_float(two.y) * w0;
+              s1 += __uint_as_float(two.w) * w1;
             }
             if (h < m_) {
-              const int c0 = __builtin_amdgcn_readlane((int)cur_h.x, h);
-              const float g0 = bcastf(__uint_as_float(cur_h.y), h);
-              s0 += g0 * *reinterpret_cast<const v2f*>(wl + c0 * PP_COLS);
+              const uint2 one = hslot[wave][h];
+              s0 += __uint_as_float(one.y) * *reinterpret_cast<const v2f*>(wl + (int)one.x * PP_COLS);
             }
           }
           v2f row = s0 + s1;
