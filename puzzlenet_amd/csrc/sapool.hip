@@ -197,12 +197,18 @@ __global__ __launch_bounds__(NW * 64) void pool_point_kernel(PointArgs p) {
               const uint4 two = *reinterpret_cast<const uint4*>(&hslot[wave][h]);
               const v2f w0 = *reinterpret_cast<const v2f*>(wl + (int)two.x * PP_COLS);
               const v2f w1 = *reinterpret_cast<const v2f*>(wl + (int)two.z * PP_COLS);
-              s0 += __uint_as_float(two.y) * w0;
-              s1 += __uint_as_float(two.w) * w1;
+              // (the gradients as registers of their own: taken straight from the high halves of the loaded pairs the packed fma
+              // gets op_sel on src1 - the form that is wrong beside AGPR-accumulator MFMAs, tests/test_isa_forms.py)
+              float g0 = __uint_as_float(two.y), g1 = __uint_as_float(two.w);
+              asm volatile("" : "+v"(g0), "+v"(g1));
+              s0 += g0 * w0;
+              s1 += g1 * w1;
             }
             if (h < m_) {
               const uint2 one = hslot[wave][h];
-              s0 += __uint_as_float(one.y) * *reinterpret_cast<const v2f*>(wl + (int)one.x * PP_COLS);
+              float g0 = __uint_as_float(one.y);
+              asm volatile("" : "+v"(g0));
+              s0 += g0 * *reinterpret_cast<const v2f*>(wl + (int)one.x * PP_COLS);
             }
           }
           v2f row = s0 + s1;

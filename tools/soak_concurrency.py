@@ -50,6 +50,12 @@ def point_mlp():
     return torch.cat([y.detach().reshape(-1)] + [t.reshape(-1) for t in grads])
 
 
+def sa_backward_victim():      # the level's backward by point (csrc/sapool.hip, poolbwd.hip): the order-fixed gradients (dP -> feat,
+    with torch.enable_grad():   # dW2, db2; the first layer's weight gradients end in float atomics and are left out)
+        leaves = [t.detach().requires_grad_(True) for t in (feat, w1, b1, w2, b2)]
+        y = ops.sa_mlp_max(xyz, leaves[0], new_xyz, None, *leaves[1:])
+        gf, _, _, gw2, gb2 = torch.autograd.grad(y, leaves, torch.ones_like(y))
+    return torch.cat([gf.reshape(-1), gw2.reshape(-1), gb2.reshape(-1)])
 victims = {
     "point_mlp3": point_mlp,
     "knn": lambda: ops.knn(xyz, new_xyz, 32),
@@ -59,6 +65,7 @@ victims = {
                                                         counts=torch.full((B,), N - 100, dtype=torch.int64, device=dev), max_count=N - 100),
     "ball_query": lambda: ops.ball_query(0.2, 32, xyz, new_xyz),
     "sa_level": lambda: ops.sa_mlp_max(xyz, feat, new_xyz, None, w1, b1, w2, b2),
+    "sa_level_backward": sa_backward_victim,
     "chamfer": lambda: torch.cat([t.reshape(-1).float() for t in ops.chamfer(a_pts, b_pts)]),
     "attention_block": lambda: ops.attention_block(xa, *aw)[0],
     "linear_weight_stationary": lambda: ops.linear(xl, wl, bl, relu=True),
