@@ -155,6 +155,11 @@ def test_training_step_vs_reference(golden_loss, dev, loss_mode):
 
 def _device_winners(m, capture):
     """ops.WINNER_CAPTURE of one forward of the product model -> the keys oracle.model_ref.RefModel.pin_winners takes."""
+    from puzzlenet_amd import _lib
+    if _lib.load().pzn_gemm_get_precision() == 0:
+        # (PZN_GEMM_PRECISION=f32: the encoders' global max then goes through the plain max over points, whose captures carry no
+        # owner - three of them could not be told apart below; the fingerprint test covers that mode)
+        pytest.skip("the winner pinning needs the split-precision paths' captures (default mode)")
     owner = {}
     for tag, enc in (("Encoder.", m.Encoder), ("Encoder2.", m.Encoder2)):
         owner[enc.mlp4.weight.data_ptr()] = tag + "sa1"
