@@ -51,6 +51,13 @@ int pzn_ws_gemm_ex(const float* A, int lda, const float* W, int ldw, int w_kmajo
                    const int64_t* scat, int scat_in, int scat_out, const float* residual, float* C2, int accumulate,
                    hipStream_t st);
 
+// C[M, N] = A W^T + xyz[M, 3] (wx | wy | wz)[N] (planes contiguous): the coordinate columns of a layer over [xyz | features] in
+// the store epilogue, with sa_prep_kernel's arithmetic (bit-identical to the product followed by pzn_sa_prep_f32's pass)
+int pzn_ws_gemm_r3(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, const float* xyz,
+                   const float* planes, hipStream_t st);
+// sapoint.hip: only the Q table of pzn_sa_prep_f32 (Q[g, :] = b1 - W1[:, 0:3] new_xyz[g])
+int pzn_sa_prep_q(const float* new_xyz, const float* W1, const float* b1, int B, int S, int D, int C1, float* Q, hipStream_t st);
+
 // salevel.hip: the generated-row max-pool level with W2 streamed through LDS; PZN_EUNSUPPORTED for other shapes
 size_t pzn_sa_level_stream_workspace_bytes(int C1, int C2);
 int pzn_sa_level_stream(const float* Pp, const float* Q, const int64_t* idx, const float* W2, const float* b2, int G, int N,

@@ -12,13 +12,14 @@
 // forward buffer ("saved"):  P' [B*N, C1] | Q [B*S, C1] | W1[:, 3:] dense [C1, D] | idx [B*S*32] int64 (when searched here) |
 //   planes of W2.        backward buffer:  off [B*(N+1)] | rows [B*S*32] | pts [B*S*32] (int32) | dP [B*N, C1] | hit lists.
 #include "pzn_common.h"
+#include "pzn_internal.h"
 
 namespace {
 
 size_t up256(size_t n) { return (n + 255) / 256 * 256; }
 
 struct SaFwdLayout {
-  size_t P, Q, wf, idx, planes, total;
+  size_t P, Q, wf, wx, idx, planes, total;
 };
 
 SaFwdLayout sa_fwd_layout(int B, int N, int S, int D, int C1, int C2) {
@@ -27,6 +28,7 @@ SaFwdLayout sa_fwd_layout(int B, int N, int S, int D, int C1, int C2) {
   f.P = at, at += up256((size_t)B * N * C1 * 4);
   f.Q = at, at += up256((size_t)B * S * C1 * 4);
   f.wf = at, at += up256((size_t)C1 * D * 4);
+  f.wx = at, at += up256((size_t)3 * C1 * 4);
   f.idx = at, at += up256((size_t)B * S * 32 * 8);
   f.planes = at, at += up256(pzn_sa_level_fwd_workspace_bytes(C1, C2));
   f.total = at;
@@ -50,12 +52,18 @@ SaBwdLayout sa_bwd_layout(int B, int N, int S, int C1, int C2) {
 }
 
 // dst[c, 0:D] = W1[c, 3:3+D]: the feature block of the first layer's weight as a dense matrix (the products on it want
-// 16-byte aligned rows; W1 + 3 is not)
-__global__ __launch_bounds__(256) void w1_features_kernel(const float* __restrict__ W1, int C1, int D, float* __restrict__ dst) {
+// 16-byte aligned rows; W1 + 3 is not); wx[q][c] = W1[c, q], q = 0..2: its coordinate columns as planes
+__global__ __launch_bounds__(256) void w1_features_kernel(const float* __restrict__ W1, int C1, int D, float* __restrict__ dst,
+                                                          float* __restrict__ wx) {
   const int n = C1 * D;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int c = i / D, d = i - c * D;
-    dst[i] = W1[(size_t)c * (3 + D) + 3 + d];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n + 3 * C1; i += gridDim.x * blockDim.x) {
+    if (i < n) {
+      const int c = i / D, d = i - c * D;
+      dst[i] = W1[(size_t)c * (3 + D) + 3 + d];
+    } else {
+      const int q = (i - n) / C1, c = (i - n) - q * C1;
+      wx[q * C1 + c] = W1[(size_t)c * (3 + D) + q];
+    }
   }
 }
 
@@ -84,9 +92,15 @@ PZN_EXPORT int pzn_sa_level_chain_fwd_f32(const float* xyz, const float* feat, c
   float* Q = reinterpret_cast<float*>(base + f.Q);
   float* wf = reinterpret_cast<float*>(base + f.wf);
   hipStream_t st = pzn_hip_stream(stream);
-  PZN_LAUNCH(w1_features_kernel, dim3((unsigned)((C1 * D + 255) / 256)), dim3(256), 0, st, W1, C1, D, wf);
+  float* wx = reinterpret_cast<float*>(base + f.wx);
+  PZN_LAUNCH(w1_features_kernel, dim3((unsigned)((C1 * (D + 3) + 255) / 256)), dim3(256), 0, st, W1, C1, D, wf, wx);
   if (hipGetLastError() != hipSuccess) return PZN_ELAUNCH;
-  int rc = pzn_linear_fwd_f32(feat, wf, nullptr, B * N, D, C1, 0, P, stream);
+  // P' = feat W1[:, 3:]^T + xyz W1[:, 0:3]^T: the coordinate columns in the product's store epilogue where the skinny-layer
+  // kernel takes the shape (one pass over the table instead of the product's write + pzn_sa_prep_f32's read-modify-write:
+  // 4 x 25 -> 4 x 6 us per step, the same bits), Q by the small pass that is left
+  int rc = pzn_ws_gemm_r3(feat, D, wf, D, P, C1, B * N, C1, D, xyz, wx, st);
+  const bool fused_xyz = rc == PZN_OK;
+  if (rc == PZN_EUNSUPPORTED) rc = pzn_linear_fwd_f32(feat, wf, nullptr, B * N, D, C1, 0, P, stream);
   if (rc != PZN_OK) return rc;
   if (!idx) {
     int64_t* mine = reinterpret_cast<int64_t*>(base + f.idx);
@@ -94,7 +108,7 @@ PZN_EXPORT int pzn_sa_level_chain_fwd_f32(const float* xyz, const float* feat, c
     if (rc != PZN_OK) return rc;
     idx = mine;
   }
-  rc = pzn_sa_prep_f32(xyz, new_xyz, W1, b1, B, N, S, D, C1, P, Q, stream);
+  rc = fused_xyz ? pzn_sa_prep_q(new_xyz, W1, b1, B, S, D, C1, Q, st) : pzn_sa_prep_f32(xyz, new_xyz, W1, b1, B, N, S, D, C1, P, Q, stream);
   if (rc != PZN_OK) return rc;
   void* planes = base + f.planes;
   if (pzn_sa_level_fwd_workspace_bytes(C1, C2) > 0) {

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "pzn_common.h"
+#include "pzn_internal.h"
 
 namespace {
 
@@ -189,6 +190,17 @@ PZN_EXPORT int pzn_sa_prep_f32(const float* xyz, const float* new_xyz, const flo
   if (blocks > 1024) blocks = 1024;             // a few rows per thread: the LDS prologue is paid per workgroup
   PZN_LAUNCH(sa_prep_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * C1 * sizeof(float), pzn_hip_stream(stream),
                      xyz, new_xyz, W1, 3 + D, b1, prow, groups, C1, P, Q);
+  PZN_RETURN_LAUNCH_STATUS();
+}
+
+int pzn_sa_prep_q(const float* new_xyz, const float* W1, const float* b1, int B, int S, int D, int C1, float* Q, hipStream_t st) {
+  if (!new_xyz || !W1 || !Q || B <= 0 || S <= 0 || C1 <= 0) return PZN_EINVAL;
+  if ((C1 & 3) || C1 > 4096 || (reinterpret_cast<uintptr_t>(Q) & 15)) return PZN_EUNSUPPORTED;
+  const long groups = (long)B * S;
+  long blocks = (groups * (C1 >> 2) + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  PZN_LAUNCH(sa_prep_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * C1 * sizeof(float), st, new_xyz, new_xyz, W1, 3 + D, b1,
+             0L, groups, C1, Q, Q);      // no point rows: every row of the walk is a row of Q
   PZN_RETURN_LAUNCH_STATUS();
 }
 

@@ -70,6 +70,11 @@ struct WsArgs {
   const float* sbias[3];
   float* sC[3];
   int sN[3];
+  // store epilogue: C(m, n) += x_m wx[n] + y_m wy[n] + z_m wz[n], the three coordinate columns of a layer whose input is
+  // [xyz | features] (first set-abstraction layer per point, csrc/sachain.hip): r3_xyz[M, 3], r3_w = {wx[N], wy[N], wz[N]};
+  // the arithmetic of sa_prep_kernel, which made a pass of its own over the table for it: fmaf(wz, z, fmaf(wy, y, wx x))
+  const float* r3_xyz;
+  const float* r3_w;
 };
 
 // two floats -> their three bf16 planes, packed (lo = first element)
@@ -341,6 +346,20 @@ __global__ __launch_bounds__(NW * 64) void ws_gemm_kernel(WsArgs p) {
                 else
                   v = w;
               }
+              if (p.r3_xyz) {
+                const float* q = p.r3_xyz + (size_t)row * 3;
+                float x = q[0], y = q[1], z = q[2];
+                // (registers of their own: loaded as a pair, y or z is broadcast into a packed multiply with op_sel on src1 -
+                // the form that is wrong beside AGPR-accumulator MFMAs, tests/test_isa_forms.py)
+                asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+                const float4 wx = *reinterpret_cast<const float4*>(p.r3_w + col);
+                const float4 wy = *reinterpret_cast<const float4*>(p.r3_w + p.N + col);
+                const float4 wz = *reinterpret_cast<const float4*>(p.r3_w + 2 * p.N + col);
+                v.x = __fadd_rn(v.x, __fmaf_rn(wz.x, z, __fmaf_rn(wy.x, y, __fmul_rn(wx.x, x))));
+                v.y = __fadd_rn(v.y, __fmaf_rn(wz.y, z, __fmaf_rn(wy.y, y, __fmul_rn(wx.y, x))));
+                v.z = __fadd_rn(v.z, __fmaf_rn(wz.z, z, __fmaf_rn(wy.z, y, __fmul_rn(wx.z, x))));
+                v.w = __fadd_rn(v.w, __fmaf_rn(wz.w, z, __fmaf_rn(wy.w, y, __fmul_rn(wx.w, x))));
+              }
               if (p.accumulate) {
                 const float4 c = *reinterpret_cast<const float4*>(p.C + o);
                 v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
@@ -482,6 +501,20 @@ int pzn_ws_gemm_ex(const float* A, int lda, const float* W, int ldw, int w_kmajo
       (reinterpret_cast<uintptr_t>(C2) & 15))
     return PZN_EUNSUPPORTED;
   return genY ? launch_mg<false, true>(p, nt, st) : launch_mg<false, false>(p, nt, st);
+}
+
+// C[M, N] = A[M, K] W[N, K]^T + xyz[M, 3] (wx | wy | wz)[N]: a linear layer over [xyz | features] with the coordinate columns in
+// the store epilogue (planes: wx[N], wy[N], wz[N] contiguous).  PZN_EUNSUPPORTED for shapes / alignments the kernel does not take.
+int pzn_ws_gemm_r3(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, const float* xyz,
+                   const float* planes, hipStream_t st) {
+  if (!pzn_ws_gemm_supported(M, N, K, A, lda, nullptr, false) || !xyz || !planes) return PZN_EUNSUPPORTED;
+  if ((ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15) || (reinterpret_cast<uintptr_t>(planes) & 15)) return PZN_EUNSUPPORTED;
+  WsArgs p{A, lda, W, ldw, 0, C, ldc, M, N, K, (K + 31) / 32, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0,
+           nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr},
+           {nullptr, nullptr, nullptr}, {0, 0, 0}, xyz, planes};
+  const int nt = pick_nt(N, p.nd, false);
+  if (!nt) return PZN_EUNSUPPORTED;
+  return launch_mg<false, false>(p, nt, st);
 }
 
 int pzn_ws_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor, float* C, int ldc, int M, int N, int K,

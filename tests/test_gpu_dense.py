@@ -228,6 +228,37 @@ def test_sa_mlp_max_fused_vs_composed(dev, precision, B, N, S, D, C1, C2):
             assert torch.equal(d2[2].grad, d[2].grad) and torch.equal(d2[3].grad, d[3].grad)
 
 
+@pytest.mark.parametrize("B,N,S,D,C", [(4, 2048, 512, 64, 128), (4, 512, 256, 128, 256), (2, 300, 40, 64, 128)])
+def test_sa_level_one_call_equals_the_stepwise_form(dev, B, N, S, D, C):
+    """The level behind one C entry point each way (csrc/sachain.hip: the coordinate columns of the first layer in the store
+    epilogue of the product on the features, pzn_ws_gemm_r3, where the skinny-layer kernel takes the shape) against the same
+    level enqueued entry point by entry point from Python (product, then pzn_sa_prep_f32's pass over the table): output,
+    arg-max and the order-fixed gradients bit-identical."""
+    from puzzlenet_amd import ops
+    g = torch.Generator().manual_seed(C + N)
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    feat0 = torch.randn(B, N, D, generator=g).to(dev)
+    new_xyz = xyz[:, :S].contiguous()
+    w = [(torch.randn(C, 3 + D, generator=g) / math.sqrt(3 + D)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev),
+         (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)]
+    go = torch.randn(B, S, C, generator=g).to(dev)
+
+    def run(stepwise):
+        feat = feat0.clone().requires_grad_(True)
+        ps = [t.clone().requires_grad_(True) for t in w]
+        ops.KernelTimer.enabled = stepwise
+        try:
+            y = ops.sa_mlp_max(xyz, feat, new_xyz, None, *ps)
+            (y * go).sum().backward()
+        finally:
+            ops.KernelTimer.enabled = False
+        return y.detach(), feat.grad, ps[2].grad, ps[3].grad
+
+    one, step = run(False), run(True)
+    for a, b in zip(one, step):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("sinks", [False, True])
 def test_attention_block_fused_vs_composed(dev, sinks):
     """pzn_attn_block_* (layerAttention behind one entry point each way, residual / offset lines and the dx sums
